@@ -1,0 +1,161 @@
+/*
+ * raftq.h -- C-ABI of the MI355X batched multi-raft quorum engine.
+ *
+ * This is the drop-in boundary for ONE hot path of chzchzchz/raftsql: the
+ * per-group quorum arithmetic that the reference reaches through
+ *     rc.node.Step     (raft.go:268-270, inbound MsgAppResp / MsgVoteResp)
+ *     rc.node.Propose  (raft.go:211-215, leader-local append)
+ *     rc.node.Tick     (raft.go:223-224)
+ * and whose result the reference consumes from rc.node.Ready() (raft.go:227,
+ * HardState.Commit / CommittedEntries).  The arithmetic itself lives in the
+ * un-vendored dependency github.com/coreos/etcd/raft (SURVEY.md section 0,
+ * F1/F2): raft.maybeCommit, raftLog.maybeCommit, raft.q and raft.poll.  The
+ * reference has no FFI for it, so the entry points below are what a cgo shim
+ * in a G-group raftsql would bind (see INTEGRATION.md for that shim).
+ *
+ * Conventions
+ *   - every function returns RAFTQ_OK (0) or a negative RAFTQ_E* code; none
+ *     throws, aborts or calls exit().  raftq_last_error() gives the text.
+ *   - a handle owns device-resident SoA state for G groups x N peers on one
+ *     GPU.  One handle is NOT thread-safe (the caller serialises, mirroring
+ *     the one-goroutine rule of raft.Node); different handles are independent.
+ *   - host buffers are caller-owned and are only read/written during the
+ *     call; no pointer is retained after return (cgo pointer rule).
+ *   - host-side matrices are peer-major and dense:  x[p * G + g].
+ *   - vote encoding (uint8): 0 = no response yet, 1 = granted, 2 = rejected.
+ *     Any other byte value counts as "no response".
+ *   - outcome encoding (uint8): 0 = pending, 1 = won, 2 = lost.
+ *   - log indices and terms are uint64, as raftpb's.  Index 0 is the dummy
+ *     entry: it carries term 0 and never commits.
+ */
+#ifndef RAFTQ_H
+#define RAFTQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFTQ_ABI_VERSION 1
+#define RAFTQ_MAX_PEERS 9 /* north_star: selection network for N <= 9 */
+
+/* return codes */
+#define RAFTQ_OK 0
+#define RAFTQ_EINVAL (-1)  /* bad argument (NULL, N out of range, G == 0 ...) */
+#define RAFTQ_ENOMEM (-2)  /* device or pinned-host allocation failed */
+#define RAFTQ_EHIP (-3)    /* a HIP runtime call failed; see raftq_last_error */
+#define RAFTQ_ESTATE (-4)  /* call sequence error (e.g. gated sweep, no terms) */
+#define RAFTQ_ENODEV (-5)  /* no usable GPU / device index out of range */
+
+/* sweep flags (raftq_step_async) */
+#define RAFTQ_SWEEP_COMMIT 0x01u /* commit-advance: etcd raft.maybeCommit */
+#define RAFTQ_SWEEP_GATED 0x02u  /* + raftLog.maybeCommit's current-term gate */
+#define RAFTQ_SWEEP_VOTES 0x04u  /* RequestVote tally: etcd raft.poll */
+#define RAFTQ_SWEEP_NO_ADOPT 0x08u /* evaluate into the shadow commit buffer
+                                      but do not make it current ("what-if") */
+#define RAFTQ_SWEEP_LDS 0x10u /* A/B variant: LDS-staged odd-even transposition
+                                 sort instead of the in-register network */
+#define RAFTQ_SWEEP_CHANGED 0x20u /* also emit the changed-groups bitmap that
+                                     raftq_collect_changed() compacts */
+
+typedef struct raftq raftq_t;
+
+/* per-sweep tallies (reduced from per-wave partials when waited for) */
+typedef struct raftq_counts {
+  uint64_t n_changed; /* groups whose commit index advanced   */
+  uint64_t n_won;     /* groups whose candidate reached quorum */
+  uint64_t n_lost;    /* groups whose candidate was rejected by a quorum */
+} raftq_counts_t;
+
+/* one MsgAppResp-shaped update: peer `peer` of group `group` now matches
+ * `match` (raft.go:268-270 -> Step -> Progress.maybeUpdate: only increases) */
+typedef struct raftq_delta {
+  uint64_t group;
+  uint64_t match;
+  uint32_t peer;
+  uint32_t _pad;
+} raftq_delta_t;
+
+/* one MsgVoteResp-shaped update (first response from a peer wins, as poll) */
+typedef struct raftq_vote_delta {
+  uint64_t group;
+  uint32_t peer;
+  uint8_t vote; /* 1 granted, 2 rejected */
+  uint8_t _pad[3];
+} raftq_vote_delta_t;
+
+/* one advanced group: what would surface in Ready.HardState.Commit */
+typedef struct raftq_advance {
+  uint64_t group;
+  uint64_t old_commit;
+  uint64_t new_commit;
+} raftq_advance_t;
+
+/* ---- library / device ------------------------------------------------- */
+int raftq_abi_version(void);
+int raftq_device_count(int* n);
+/* quorum size q = floor(N/2)+1  (etcd raft.q) -- host-side helper */
+uint32_t raftq_quorum(uint32_t n_peers);
+
+/* ---- handle lifetime --------------------------------------------------- */
+/* allocates the padded SoA state for G groups x N peers in HBM on `device`;
+ * everything starts zeroed (match 0, committed 0, no votes, no terms). */
+int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out);
+void raftq_destroy(raftq_t* h);
+uint64_t raftq_groups(const raftq_t* h);
+uint32_t raftq_peers(const raftq_t* h);
+const char* raftq_last_error(const raftq_t* h); /* h may be NULL: global */
+
+/* all handles default to their own non-blocking stream.  A caller that owns
+ * streams (torch, a Go batching goroutine with one stream per device) can
+ * install one; `stream` is a hipStream_t passed as void*. */
+int raftq_set_stream(raftq_t* h, void* stream);
+void* raftq_get_stream(const raftq_t* h);
+
+/* ---- bulk load of resident state (host -> HBM) ------------------------- */
+int raftq_load_match(raftq_t* h, const uint64_t* match /*[N][G]*/,
+                     const uint64_t* committed /*[G]*/);
+/* first_idx_cur_term[g] = first log index whose entry has term cur_term[g],
+ * or 0 when the leader's log holds no entry of its current term yet. */
+int raftq_load_terms(raftq_t* h, const uint64_t* cur_term /*[G]*/,
+                     const uint64_t* first_idx_cur_term /*[G]*/);
+int raftq_load_votes(raftq_t* h, const uint8_t* votes /*[N][G]*/);
+
+/* ---- sparse ingest ----------------------------------- */
+int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n);
+int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n);
+
+/* ---- the sweep ---------------------------------------------------------- */
+/* enqueue one pass over all G groups on the handle's stream. */
+int raftq_step_async(raftq_t* h, unsigned flags);
+/* block until everything enqueued on the handle has finished; if `counts` is
+ * not NULL, fill it with the tallies of the most recent sweep. */
+int raftq_wait(raftq_t* h, raftq_counts_t* counts);
+
+/* synchronous conveniences = step_async + wait + optional read-back */
+int raftq_commit_advance(raftq_t* h, int gated, uint64_t* committed_out /*[G]|NULL*/,
+                         uint64_t* n_changed /*|NULL*/);
+int raftq_vote_tally(raftq_t* h, uint8_t* outcome_out /*[G]|NULL*/,
+                     raftq_counts_t* counts /*|NULL*/);
+
+/* ---- read-back ---------------------------------------------------------- */
+int raftq_read_committed(raftq_t* h, uint64_t* committed_out /*[G]*/);
+int raftq_read_outcome(raftq_t* h, uint8_t* outcome_out /*[G]*/);
+int raftq_read_match(raftq_t* h, uint64_t* match_out /*[N][G]*/);
+int raftq_read_votes(raftq_t* h, uint8_t* votes_out /*[N][G]*/);
+/* compacted list of the groups the last RAFTQ_SWEEP_CHANGED sweep advanced,
+ * in ascending group order; returns the count in *n (<= cap entries stored). */
+int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n);
+
+/* ---- measurement hooks (bench harness) --------------------------------- */
+/* HIP events recorded on the handle's own stream, so the elapsed time covers
+ * exactly the kernels enqueued between begin and end. */
+int raftq_timer_begin(raftq_t* h);
+int raftq_timer_end(raftq_t* h, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTQ_H */

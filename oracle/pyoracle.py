@@ -1,0 +1,180 @@
+"""ctypes binding of oracle/libraftq_oracle.so.  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module; the product package raftsql_amd never does.  PARITY UNPINNED --
+see oracle/raftq_oracle.h for why and for what pins the restatement instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libraftq_oracle.so")
+
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "raftq_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libraftq_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.rq_oracle_quorum.restype = C.c_int
+        L.rq_oracle_quorum.argtypes = [C.c_int]
+        for f in (L.rq_oracle_mci_sort, L.rq_oracle_mci_count):
+            f.restype = C.c_uint64
+            f.argtypes = [_u64p, C.c_int]
+        L.rq_oracle_log_term.restype = C.c_uint64
+        L.rq_oracle_log_term.argtypes = [_u64p, _u64p, C.c_int, C.c_uint64, C.c_uint64]
+        L.rq_oracle_maybe_commit.restype = C.c_uint64
+        L.rq_oracle_maybe_commit.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
+        L.rq_oracle_poll.restype = C.c_uint8
+        L.rq_oracle_poll.argtypes = [_u8p, C.c_int]
+        L.rq_oracle_commit_advance.restype = C.c_uint64
+        L.rq_oracle_commit_advance.argtypes = [
+            _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, C.c_int, C.c_void_p, _u64p]
+        L.rq_oracle_commit_advance_log.restype = C.c_uint64
+        L.rq_oracle_commit_advance_log.argtypes = [
+            _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p]
+        L.rq_oracle_first_idx_cur_term.restype = None
+        L.rq_oracle_first_idx_cur_term.argtypes = [C.c_size_t, _u64p, _u64p, _u64p, _u64p, _u64p]
+        L.rq_oracle_vote_tally.restype = None
+        L.rq_oracle_vote_tally.argtypes = [
+            _u8p, C.c_size_t, C.c_int, C.c_size_t, _u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.rq_oracle_apply_deltas.restype = None
+        L.rq_oracle_apply_deltas.argtypes = [
+            _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, _u32p, _u64p, C.c_size_t]
+        L.rq_oracle_apply_vote_deltas.restype = None
+        L.rq_oracle_apply_vote_deltas.argtypes = [
+            _u8p, C.c_size_t, C.c_int, C.c_size_t, _u64p, _u32p, _u8p, C.c_size_t]
+        L.rq_oracle_timed_sweeps.restype = C.c_double
+        L.rq_oracle_timed_sweeps.argtypes = [
+            C.c_int, C.c_int, C.c_int, _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_size_t, _u64p, _u8p]
+        _lib = L
+    return _lib
+
+
+def quorum(n: int) -> int:
+    return int(lib().rq_oracle_quorum(n))
+
+
+def mci_sort(match_col) -> int:
+    a = np.ascontiguousarray(match_col, dtype=np.uint64)
+    return int(lib().rq_oracle_mci_sort(a, a.size))
+
+
+def mci_count(match_col) -> int:
+    a = np.ascontiguousarray(match_col, dtype=np.uint64)
+    return int(lib().rq_oracle_mci_count(a, a.size))
+
+
+def poll(votes_col) -> int:
+    a = np.ascontiguousarray(votes_col, dtype=np.uint8)
+    return int(lib().rq_oracle_poll(a, a.size))
+
+
+def log_term(run_start, run_term, last_index: int, i: int) -> int:
+    rs = np.ascontiguousarray(run_start, dtype=np.uint64)
+    rt = np.ascontiguousarray(run_term, dtype=np.uint64)
+    return int(lib().rq_oracle_log_term(rs, rt, rs.size, last_index, i))
+
+
+def commit_advance(match, committed, gated: bool = False, first_idx_cur_term=None):
+    """-> (committed_out [G] u64, n_changed)."""
+    match = np.ascontiguousarray(match, dtype=np.uint64)
+    committed = np.ascontiguousarray(committed, dtype=np.uint64)
+    N, G = match.shape
+    out = np.empty(G, dtype=np.uint64)
+    fi = None
+    if gated:
+        fi_arr = np.ascontiguousarray(first_idx_cur_term, dtype=np.uint64)
+        fi = fi_arr.ctypes.data
+    n = lib().rq_oracle_commit_advance(match, G, N, G, committed, int(gated), fi, out)
+    return out, int(n)
+
+
+def commit_advance_log(st):
+    """Full-log gated form on a synth.GroupState that carries its logs."""
+    out = np.empty(st.n_groups, dtype=np.uint64)
+    n = lib().rq_oracle_commit_advance_log(
+        np.ascontiguousarray(st.match), st.n_groups, st.n_peers, st.n_groups,
+        np.ascontiguousarray(st.committed), np.ascontiguousarray(st.cur_term),
+        np.ascontiguousarray(st.run_off), np.ascontiguousarray(st.run_start),
+        np.ascontiguousarray(st.run_term), np.ascontiguousarray(st.last_index), out)
+    return out, int(n)
+
+
+def first_idx_cur_term(st):
+    out = np.empty(st.n_groups, dtype=np.uint64)
+    lib().rq_oracle_first_idx_cur_term(
+        st.n_groups, np.ascontiguousarray(st.cur_term), np.ascontiguousarray(st.run_off),
+        np.ascontiguousarray(st.run_start), np.ascontiguousarray(st.run_term), out)
+    return out
+
+
+def vote_tally(votes):
+    """-> (outcome [G] u8, n_won, n_lost)."""
+    votes = np.ascontiguousarray(votes, dtype=np.uint8)
+    N, G = votes.shape
+    out = np.empty(G, dtype=np.uint8)
+    w, l = C.c_uint64(0), C.c_uint64(0)
+    lib().rq_oracle_vote_tally(votes, G, N, G, out, C.byref(w), C.byref(l))
+    return out, int(w.value), int(l.value)
+
+
+def apply_deltas(match, d_group, d_peer, d_match):
+    match = np.ascontiguousarray(match, dtype=np.uint64).copy()
+    N, G = match.shape
+    dg = np.ascontiguousarray(d_group, dtype=np.uint64)
+    dp = np.ascontiguousarray(d_peer, dtype=np.uint32)
+    dm = np.ascontiguousarray(d_match, dtype=np.uint64)
+    lib().rq_oracle_apply_deltas(match, G, N, G, dg, dp, dm, dg.size)
+    return match
+
+
+def apply_vote_deltas(votes, d_group, d_peer, d_vote):
+    votes = np.ascontiguousarray(votes, dtype=np.uint8).copy()
+    N, G = votes.shape
+    dg = np.ascontiguousarray(d_group, dtype=np.uint64)
+    dp = np.ascontiguousarray(d_peer, dtype=np.uint32)
+    dv = np.ascontiguousarray(d_vote, dtype=np.uint8)
+    lib().rq_oracle_apply_vote_deltas(votes, G, N, G, dg, dp, dv, dg.size)
+    return votes
+
+
+def timed_sweeps(kind: int, threads: int, sweeps: int, match, committed, votes=None,
+                 gated: bool = False, first_idx_cur_term=None):
+    """Timed CPU baseline; -> (seconds, committed_out, outcome_out)."""
+    match = np.ascontiguousarray(match, dtype=np.uint64)
+    committed = np.ascontiguousarray(committed, dtype=np.uint64)
+    N, G = match.shape
+    cout = np.empty(G, dtype=np.uint64)
+    oout = np.zeros(G, dtype=np.uint8)
+    fi = vp = None
+    if gated:
+        fi_arr = np.ascontiguousarray(first_idx_cur_term, dtype=np.uint64)
+        fi = fi_arr.ctypes.data
+    if votes is not None:
+        v_arr = np.ascontiguousarray(votes, dtype=np.uint8)
+        vp = v_arr.ctypes.data
+    sec = lib().rq_oracle_timed_sweeps(kind, threads, sweeps, match, G, N, G, committed,
+                                       int(gated), fi, vp, G, cout, oout)
+    return float(sec), cout, oout

@@ -1,0 +1,92 @@
+/*
+ * raftq_oracle.h -- CPU oracle for the quorum hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this library, and only as the checker / the timed CPU baseline.
+ * The product (libraftq.so) never links or loads it.
+ *
+ * PARITY UNPINNED.  The arithmetic restated here lives in the reference's
+ * un-vendored, un-pinned dependency github.com/coreos/etcd/raft (2015-era,
+ * v2.2-v2.3 line by API shape).  Its source
+ * is not in /root/reference, there is no Go toolchain, and the reference's
+ * own tests (raftsql_test.go:92-171) hold no numeric vector for this path.
+ * What pins this file instead: a second independent implementation
+ * (rq_oracle_mci_count, the brute-force definition), a numpy third in
+ * tests/, hand-written known-answer vectors and properties (tests/).
+ */
+#ifndef RAFTQ_ORACLE_H
+#define RAFTQ_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a5: etcd raft.q() -- quorum size over N voting peers */
+int rq_oracle_quorum(int n);
+
+/* a6: etcd raft.maybeCommit, first half -- gather the peers' Match into a
+ * fresh slice, sort descending, take element q-1.  Sort-shaped on purpose. */
+uint64_t rq_oracle_mci_sort(const uint64_t* match, int n);
+/* independent restatement: the largest index stored on >= q peers */
+uint64_t rq_oracle_mci_count(const uint64_t* match, int n);
+
+/* raftLog.term(i) over a run-length log: runs r = 0..nruns-1 cover
+ * [run_start[r], run_start[r+1]) with term run_term[r]; the last run ends at
+ * last_index.  Index 0, indices below run_start[0] (compacted) and indices
+ * above last_index yield 0 (etcd's zeroTermOnErrCompacted + out-of-range). */
+uint64_t rq_oracle_log_term(const uint64_t* run_start, const uint64_t* run_term,
+                            int nruns, uint64_t last_index, uint64_t i);
+
+/* a7: etcd raftLog.maybeCommit(maxIndex, term) -- returns the new committed */
+uint64_t rq_oracle_maybe_commit(uint64_t mci, uint64_t committed, int gated,
+                                uint64_t term_of_mci, uint64_t cur_term);
+
+/* a8: etcd raft.poll + the candidate's MsgVoteResp switch, on a snapshot:
+ * 1 = won (granted >= q), 2 = lost (rejected >= q), 0 = pending. */
+uint8_t rq_oracle_poll(const uint8_t* votes, int n);
+
+/* ---- batched forms over G groups, SoA x[p*ld + g] ----------------------- */
+/* ungated (gated=0) or compact-gated (gated=1, first_idx_cur_term[g]) */
+uint64_t rq_oracle_commit_advance(const uint64_t* match, size_t ld, int n, size_t G,
+                                  const uint64_t* committed, int gated,
+                                  const uint64_t* first_idx_cur_term,
+                                  uint64_t* committed_out);
+/* full-log gated form: term looked up in each group's run-length log.
+ * runs are CSR: group g owns runs [run_off[g], run_off[g+1]). */
+uint64_t rq_oracle_commit_advance_log(const uint64_t* match, size_t ld, int n, size_t G,
+                                      const uint64_t* committed, const uint64_t* cur_term,
+                                      const uint64_t* run_off, const uint64_t* run_start,
+                                      const uint64_t* run_term, const uint64_t* last_index,
+                                      uint64_t* committed_out);
+/* derive the compact encoding from the run-length log */
+void rq_oracle_first_idx_cur_term(size_t G, const uint64_t* cur_term,
+                                  const uint64_t* run_off, const uint64_t* run_start,
+                                  const uint64_t* run_term, uint64_t* first_idx_out);
+void rq_oracle_vote_tally(const uint8_t* votes, size_t ld, int n, size_t G,
+                          uint8_t* outcome_out, uint64_t* n_won, uint64_t* n_lost);
+
+/* sparse ingest restatements (Progress.maybeUpdate / poll's first-wins) */
+void rq_oracle_apply_deltas(uint64_t* match, size_t ld, int n, size_t G,
+                            const uint64_t* d_group, const uint32_t* d_peer,
+                            const uint64_t* d_match, size_t nd);
+void rq_oracle_apply_vote_deltas(uint8_t* votes, size_t ld, int n, size_t G,
+                                 const uint64_t* d_group, const uint32_t* d_peer,
+                                 const uint8_t* d_vote, size_t nd);
+
+/* ---- timed CPU baselines (bench.py cpu_baseline leg) -------------------- */
+/* kind 0: reference-shaped loop (malloc N-slice, sort desc, index q-1, scan
+ * votes); kind 1: tight selection network, no allocation.  Runs `sweeps`
+ * passes over the G groups on `threads` pthreads (contiguous group ranges),
+ * returns wall seconds; outputs land in committed_out / outcome_out. */
+double rq_oracle_timed_sweeps(int kind, int threads, int sweeps,
+                              const uint64_t* match, size_t ld, int n, size_t G,
+                              const uint64_t* committed, int gated,
+                              const uint64_t* first_idx_cur_term,
+                              const uint8_t* votes, size_t ldv,
+                              uint64_t* committed_out, uint8_t* outcome_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

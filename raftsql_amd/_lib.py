@@ -1,0 +1,105 @@
+"""ctypes binding of libraftq.so (the C-ABI in include/raftq.h).
+
+The library is the product: if it is missing or does not load, importing the
+engine fails loudly.  There is no CPU fallback path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraftq.so")
+
+RAFTQ_OK = 0
+RAFTQ_EINVAL, RAFTQ_ENOMEM, RAFTQ_EHIP, RAFTQ_ESTATE, RAFTQ_ENODEV = -1, -2, -3, -4, -5
+
+SWEEP_COMMIT = 0x01
+SWEEP_GATED = 0x02
+SWEEP_VOTES = 0x04
+SWEEP_NO_ADOPT = 0x08
+SWEEP_LDS = 0x10
+SWEEP_CHANGED = 0x20
+
+MAX_PEERS = 9
+
+
+class Counts(C.Structure):
+    _fields_ = [("n_changed", C.c_uint64), ("n_won", C.c_uint64), ("n_lost", C.c_uint64)]
+
+
+class Delta(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("match", C.c_uint64), ("peer", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class VoteDelta(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("peer", C.c_uint32), ("vote", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+class Advance(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("old_commit", C.c_uint64), ("new_commit", C.c_uint64)]
+
+
+# every symbol include/raftq.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+_SIGS = [
+    ("raftq_abi_version", C.c_int, []),
+    ("raftq_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("raftq_quorum", C.c_uint32, [C.c_uint32]),
+    ("raftq_create", C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_H)]),
+    ("raftq_destroy", None, [_H]),
+    ("raftq_groups", C.c_uint64, [_H]),
+    ("raftq_peers", C.c_uint32, [_H]),
+    ("raftq_last_error", C.c_char_p, [_H]),
+    ("raftq_set_stream", C.c_int, [_H, C.c_void_p]),
+    ("raftq_get_stream", C.c_void_p, [_H]),
+    ("raftq_load_match", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("raftq_load_terms", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("raftq_load_votes", C.c_int, [_H, C.c_void_p]),
+    ("raftq_apply_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    ("raftq_apply_vote_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    ("raftq_step_async", C.c_int, [_H, C.c_uint]),
+    ("raftq_wait", C.c_int, [_H, C.POINTER(Counts)]),
+    ("raftq_commit_advance", C.c_int, [_H, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("raftq_vote_tally", C.c_int, [_H, C.c_void_p, C.POINTER(Counts)]),
+    ("raftq_read_committed", C.c_int, [_H, C.c_void_p]),
+    ("raftq_read_outcome", C.c_int, [_H, C.c_void_p]),
+    ("raftq_read_match", C.c_int, [_H, C.c_void_p]),
+    ("raftq_read_votes", C.c_int, [_H, C.c_void_p]),
+    ("raftq_collect_changed", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_timer_begin", C.c_int, [_H]),
+    ("raftq_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
+]
+EXPORTS = [s[0] for s in _SIGS]
+
+_lib = None
+
+
+class RaftqError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"raftq error {code}: {msg}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """dlopen libraftq.so.  torch (when present) is imported first so that the
+    process ends up with ONE HIP runtime: torch bundles its own libamdhip64
+    under the same soname, and whichever is mapped first serves both."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -m raftsql_amd.build` (needs hipcc). "
+            "raftsql_amd has no CPU fallback for the quorum sweep.")
+    try:
+        import torch  # noqa: F401  (HIP runtime unification, see docstring)
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in _SIGS:
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,549 @@
+// raftq_capi.hip -- implementation of include/raftq.h over the gfx950 kernels.
+// Host side of the drop-in boundary: owns the padded SoA state in HBM, the
+// stream, the double-buffered commit index and the per-wave tallies.  There is
+// deliberately no CPU fallback: without a GPU every entry point that needs one
+// returns RAFTQ_ENODEV / RAFTQ_EHIP.
+#include "raftq.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "raftq_kernels.hpp"
+
+#ifndef RAFTQ_GPL
+#define RAFTQ_GPL 8
+#endif
+#ifndef RAFTQ_NT
+#define RAFTQ_NT 0
+#endif
+#ifndef RAFTQ_LDS_GPL
+#define RAFTQ_LDS_GPL 4
+#endif
+
+using namespace raftqk;
+
+namespace {
+
+constexpr int kGPL = RAFTQ_GPL;
+constexpr bool kNT = RAFTQ_NT != 0;
+constexpr int kLdsGPL = RAFTQ_LDS_GPL;
+constexpr uint64_t kTile = (uint64_t)kBlock * kGPL;
+static_assert(kTileMax % (kBlock * RAFTQ_GPL) == 0, "ld granule must be a multiple of the tile");
+static_assert(kTileMax % (kBlock * RAFTQ_LDS_GPL) == 0, "ld granule must be a multiple of the LDS tile");
+
+thread_local std::string g_err;
+
+}  // namespace
+
+struct raftq {
+  int device = 0;
+  uint64_t G = 0, ld = 0;
+  uint32_t N = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint64_t* match = nullptr;
+  uint64_t* committed[2] = {nullptr, nullptr};
+  int cur = 0;
+  uint64_t* first_idx = nullptr;
+  uint8_t* votes = nullptr;
+  uint8_t* outcome = nullptr;
+  uint64_t* changed_bits = nullptr;
+  uint4* partials = nullptr;
+  uint4* h_partials = nullptr;  // pinned
+  uint64_t n_partials = 0;      // of the most recent sweep
+  uint64_t max_partials = 0;
+  uint64_t* offsets = nullptr;  // [max_partials + 1]; last = total
+  uint64_t* h_total = nullptr;  // pinned
+  void* staging = nullptr;      // delta upload buffer
+  size_t staging_bytes = 0;
+  Advance* adv = nullptr;
+  uint64_t adv_cap = 0;
+  bool have_terms = false;
+  unsigned last_flags = 0;
+  int last_gpl = kGPL;
+  const uint64_t* last_old = nullptr;
+  const uint64_t* last_new = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace {
+
+int fail(raftq_t* h, int code, const std::string& msg) {
+  g_err = msg;
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      return fail((h), _e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP,                  \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+    }                                                                                          \
+  } while (0)
+
+template <int N, bool COMMIT, bool GATED, bool VOTES>
+hipError_t launch_reg(const SweepArgs& a, hipStream_t s) {
+  const dim3 grid((unsigned)(a.ld / kTile));
+  hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kNT, true>), grid, dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+template <int N, bool GATED, bool VOTES>
+hipError_t launch_lds(const SweepArgs& a, hipStream_t s) {
+  constexpr uint64_t tile = (uint64_t)kBlock * kLdsGPL;
+  constexpr int rows = N + 1 + (GATED ? 1 : 0);
+  constexpr size_t lds = (size_t)kWaves * (kLdsGPL / 2) * rows * 1024;
+  const dim3 grid((unsigned)(a.ld / tile));
+  hipLaunchKernelGGL((sweep_lds_kernel<N, kLdsGPL, GATED, VOTES, true>), grid, dim3(kBlock), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_n(const SweepArgs& a, unsigned flags, hipStream_t s) {
+  const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+  const bool gated = flags & RAFTQ_SWEEP_GATED;
+  const bool votes = flags & RAFTQ_SWEEP_VOTES;
+  if ((flags & RAFTQ_SWEEP_LDS) && commit) {
+    if (gated) return votes ? launch_lds<N, true, true>(a, s) : launch_lds<N, true, false>(a, s);
+    return votes ? launch_lds<N, false, true>(a, s) : launch_lds<N, false, false>(a, s);
+  }
+  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, s) : launch_reg<N, true, true, false>(a, s);
+  if (commit) return votes ? launch_reg<N, true, false, true>(a, s) : launch_reg<N, true, false, false>(a, s);
+  return launch_reg<N, false, false, true>(a, s);
+}
+
+hipError_t launch_sweep(uint32_t N, const SweepArgs& a, unsigned flags, hipStream_t s) {
+  switch (N) {
+    case 1: return launch_n<1>(a, flags, s);
+    case 2: return launch_n<2>(a, flags, s);
+    case 3: return launch_n<3>(a, flags, s);
+    case 4: return launch_n<4>(a, flags, s);
+    case 5: return launch_n<5>(a, flags, s);
+    case 6: return launch_n<6>(a, flags, s);
+    case 7: return launch_n<7>(a, flags, s);
+    case 8: return launch_n<8>(a, flags, s);
+    case 9: return launch_n<9>(a, flags, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+int ensure_staging(raftq_t* h, size_t bytes) {
+  if (bytes <= h->staging_bytes) return RAFTQ_OK;
+  size_t want = std::max(bytes, h->staging_bytes * 2);
+  want = std::max<size_t>(want, 1 << 16);
+  if (h->staging) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(h->staging));
+    h->staging = nullptr;
+    h->staging_bytes = 0;
+  }
+  HIPCHK(h, hipMalloc(&h->staging, want));
+  h->staging_bytes = want;
+  return RAFTQ_OK;
+}
+
+int use_device(raftq_t* h) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  return RAFTQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int raftq_abi_version(void) { return RAFTQ_ABI_VERSION; }
+
+uint32_t raftq_quorum(uint32_t n_peers) { return n_peers / 2 + 1; }
+
+int raftq_device_count(int* n) {
+  if (!n) return fail(nullptr, RAFTQ_EINVAL, "raftq_device_count: null out");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return fail(nullptr, RAFTQ_ENODEV, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *n = c;
+  return RAFTQ_OK;
+}
+
+const char* raftq_last_error(const raftq_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+uint64_t raftq_groups(const raftq_t* h) { return h ? h->G : 0; }
+uint32_t raftq_peers(const raftq_t* h) { return h ? h->N : 0; }
+
+int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out) {
+  if (!out) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: null out");
+  *out = nullptr;
+  if (n_groups == 0 || n_groups > (1ull << 40)) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: n_groups out of range");
+  if (n_peers < 1 || n_peers > RAFTQ_MAX_PEERS) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: n_peers must be 1..9");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, RAFTQ_ENODEV, "raftq_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, RAFTQ_ENODEV, "raftq_create: device index out of range");
+  raftq_t* h = new (std::nothrow) raftq();
+  if (!h) return fail(nullptr, RAFTQ_ENOMEM, "raftq_create: host allocation failed");
+  h->device = device;
+  h->G = n_groups;
+  h->N = n_peers;
+  h->ld = (n_groups + kTileMax - 1) / kTileMax * kTileMax;
+  const uint64_t ld = h->ld;
+  // the finest tile any variant uses bounds the number of per-wave partials
+  h->max_partials = ld / (kBlock * 2) * kWaves;
+  int rc = RAFTQ_OK;
+  auto alloc = [&](void** p, size_t bytes) -> int {
+    HIPCHK(h, hipMalloc(p, bytes));
+    HIPCHK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
+    return RAFTQ_OK;
+  };
+  do {
+    if ((rc = use_device(h))) break;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { rc = fail(h, RAFTQ_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); break; }
+    h->own_stream = true;
+    if ((rc = alloc((void**)&h->match, (size_t)n_peers * ld * 8))) break;
+    if ((rc = alloc((void**)&h->committed[0], ld * 8))) break;
+    if ((rc = alloc((void**)&h->committed[1], ld * 8))) break;
+    if ((rc = alloc((void**)&h->first_idx, ld * 8))) break;
+    if ((rc = alloc((void**)&h->votes, (size_t)n_peers * ld))) break;
+    if ((rc = alloc((void**)&h->outcome, ld))) break;
+    if ((rc = alloc((void**)&h->changed_bits, ld / 8))) break;
+    if ((rc = alloc((void**)&h->partials, h->max_partials * sizeof(uint4)))) break;
+    if ((rc = alloc((void**)&h->offsets, (h->max_partials + 1) * 8))) break;
+    e = hipHostMalloc((void**)&h->h_partials, h->max_partials * sizeof(uint4), hipHostMallocDefault);
+    if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
+    e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocDefault);
+    if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
+    e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { rc = fail(h, RAFTQ_EHIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); break; }
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { rc = fail(h, RAFTQ_EHIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (rc != RAFTQ_OK) {
+    std::string keep = h->err;
+    raftq_destroy(h);
+    g_err = keep;
+    return rc;
+  }
+  *out = h;
+  return RAFTQ_OK;
+}
+
+void raftq_destroy(raftq_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->match);
+  (void)hipFree(h->committed[0]);
+  (void)hipFree(h->committed[1]);
+  (void)hipFree(h->first_idx);
+  (void)hipFree(h->votes);
+  (void)hipFree(h->outcome);
+  (void)hipFree(h->changed_bits);
+  (void)hipFree(h->partials);
+  (void)hipFree(h->offsets);
+  (void)hipFree(h->staging);
+  (void)hipFree(h->adv);
+  if (h->h_partials) (void)hipHostFree(h->h_partials);
+  if (h->h_total) (void)hipHostFree(h->h_total);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int raftq_set_stream(raftq_t* h, void* stream) {
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->own_stream) HIPCHK(h, hipStreamDestroy(h->stream));
+  h->stream = (hipStream_t)stream;
+  h->own_stream = false;
+  return RAFTQ_OK;
+}
+
+void* raftq_get_stream(const raftq_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int raftq_load_match(raftq_t* h, const uint64_t* match, const uint64_t* committed) {
+  if (int rc = use_device(h)) return rc;
+  if (!match && !committed) return fail(h, RAFTQ_EINVAL, "raftq_load_match: nothing to load");
+  if (match)
+    HIPCHK(h, hipMemcpy2DAsync(h->match, h->ld * 8, match, h->G * 8, h->G * 8, h->N, hipMemcpyHostToDevice, h->stream));
+  if (committed)
+    HIPCHK(h, hipMemcpyAsync(h->committed[h->cur], committed, h->G * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_load_terms(raftq_t* h, const uint64_t* cur_term, const uint64_t* first_idx_cur_term) {
+  if (int rc = use_device(h)) return rc;
+  if (!cur_term || !first_idx_cur_term) return fail(h, RAFTQ_EINVAL, "raftq_load_terms: null argument");
+  // A group whose term is 0 has never seen an election: it is not a leader and
+  // commits nothing.  Fold that into the compact gate so the kernel reads one
+  // array (DESIGN.md "term gate").
+  std::vector<uint64_t> f;
+  try {
+    f.assign(first_idx_cur_term, first_idx_cur_term + h->G);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_load_terms: host allocation failed");
+  }
+  for (uint64_t g = 0; g < h->G; ++g)
+    if (cur_term[g] == 0) f[g] = 0;
+  HIPCHK(h, hipMemcpyAsync(h->first_idx, f.data(), h->G * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_terms = true;
+  return RAFTQ_OK;
+}
+
+int raftq_load_votes(raftq_t* h, const uint8_t* votes) {
+  if (int rc = use_device(h)) return rc;
+  if (!votes) return fail(h, RAFTQ_EINVAL, "raftq_load_votes: null argument");
+  HIPCHK(h, hipMemcpy2DAsync(h->votes, h->ld, votes, h->G, h->G, h->N, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
+  if (int rc = use_device(h)) return rc;
+  if (n == 0) return RAFTQ_OK;
+  if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (d[i].group >= h->G || d[i].peer >= h->N)
+      return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: delta " + std::to_string(i) + " out of range (nothing applied)");
+  // SoA staging: group | match | peer
+  const size_t bytes = (size_t)n * (8 + 8 + 4);
+  if (int rc = ensure_staging(h, bytes + 64)) return rc;
+  std::vector<uint64_t> grp(n), mat(n);
+  std::vector<uint32_t> peer(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    grp[i] = d[i].group;
+    mat[i] = d[i].match;
+    peer[i] = d[i].peer;
+  }
+  uint8_t* base = (uint8_t*)h->staging;
+  DeltaSoA s;
+  s.group = (const uint64_t*)base;
+  s.match = (const uint64_t*)(base + n * 8);
+  s.peer = (const uint32_t*)(base + n * 16);
+  HIPCHK(h, hipMemcpyAsync((void*)s.group, grp.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync((void*)s.match, mat.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync((void*)s.peer, peer.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld, s, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors die here
+  return RAFTQ_OK;
+}
+
+int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n) {
+  if (int rc = use_device(h)) return rc;
+  if (n == 0) return RAFTQ_OK;
+  if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (d[i].group >= h->G || d[i].peer >= h->N || (d[i].vote != 1 && d[i].vote != 2))
+      return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: delta " + std::to_string(i) + " invalid (nothing applied)");
+  // first response of a peer wins, also inside one batch: keep the earliest
+  std::vector<uint64_t> grp;
+  std::vector<uint32_t> peer;
+  std::vector<uint8_t> vote;
+  std::unordered_set<uint64_t> seen;
+  seen.reserve((size_t)n * 2);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t key = d[i].group * 16 + d[i].peer;
+    if (!seen.insert(key).second) continue;
+    grp.push_back(d[i].group);
+    peer.push_back(d[i].peer);
+    vote.push_back(d[i].vote);
+  }
+  const uint64_t m = grp.size();
+  if (int rc = ensure_staging(h, (size_t)m * 13 + 64)) return rc;
+  uint8_t* base = (uint8_t*)h->staging;
+  uint64_t* dg = (uint64_t*)base;
+  uint32_t* dp = (uint32_t*)(base + m * 8);
+  uint8_t* dv = base + m * 12;
+  HIPCHK(h, hipMemcpyAsync(dg, grp.data(), m * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dp, peer.data(), m * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dv, vote.data(), m, hipMemcpyHostToDevice, h->stream));
+  const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(apply_vote_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->ld, dg, dp, dv, m);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_step_async(raftq_t* h, unsigned flags) {
+  if (int rc = use_device(h)) return rc;
+  const unsigned known = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_VOTES | RAFTQ_SWEEP_NO_ADOPT |
+                         RAFTQ_SWEEP_LDS | RAFTQ_SWEEP_CHANGED;
+  if (flags & ~known) return fail(h, RAFTQ_EINVAL, "raftq_step_async: unknown flag");
+  const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+  const bool votes = flags & RAFTQ_SWEEP_VOTES;
+  if (!commit && !votes) return fail(h, RAFTQ_EINVAL, "raftq_step_async: nothing to sweep");
+  if ((flags & RAFTQ_SWEEP_GATED) && !h->have_terms)
+    return fail(h, RAFTQ_ESTATE, "raftq_step_async: gated sweep before raftq_load_terms");
+  if ((flags & RAFTQ_SWEEP_CHANGED) && !commit)
+    return fail(h, RAFTQ_EINVAL, "raftq_step_async: RAFTQ_SWEEP_CHANGED needs a commit sweep");
+  SweepArgs a;
+  a.match = h->match;
+  a.committed = h->committed[h->cur];
+  a.committed_out = h->committed[h->cur ^ 1];
+  a.first_idx = h->first_idx;
+  a.votes = h->votes;
+  a.outcome = h->outcome;
+  a.changed_bits = (flags & RAFTQ_SWEEP_CHANGED) ? h->changed_bits : nullptr;
+  a.partials = h->partials;
+  a.ld = h->ld;
+  const bool lds = (flags & RAFTQ_SWEEP_LDS) && commit;
+  const int gpl = lds ? kLdsGPL : kGPL;
+  HIPCHK(h, launch_sweep(h->N, a, flags, h->stream));
+  h->n_partials = h->ld / ((uint64_t)kBlock * gpl) * kWaves;
+  h->last_flags = flags;
+  h->last_gpl = gpl;
+  if (commit) {
+    h->last_old = a.committed;
+    h->last_new = a.committed_out;
+    if (!(flags & RAFTQ_SWEEP_NO_ADOPT)) h->cur ^= 1;
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_wait(raftq_t* h, raftq_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) {
+    if (h->n_partials == 0) return fail(h, RAFTQ_ESTATE, "raftq_wait: no sweep to report on");
+    HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (counts) {
+    uint64_t c = 0, w = 0, l = 0;
+    for (uint64_t i = 0; i < h->n_partials; ++i) {
+      c += h->h_partials[i].x;
+      w += h->h_partials[i].y;
+      l += h->h_partials[i].z;
+    }
+    const bool commit = h->last_flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+    const bool votes = h->last_flags & RAFTQ_SWEEP_VOTES;
+    counts->n_changed = commit ? c : 0;
+    counts->n_won = votes ? w : 0;
+    counts->n_lost = votes ? l : 0;
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_read_committed(raftq_t* h, uint64_t* out) {
+  if (int rc = use_device(h)) return rc;
+  if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_committed: null argument");
+  // after a NO_ADOPT sweep the caller wants the evaluated (shadow) values
+  const uint64_t* src = (h->last_flags & RAFTQ_SWEEP_NO_ADOPT) && h->last_new ? h->last_new : h->committed[h->cur];
+  HIPCHK(h, hipMemcpyAsync(out, src, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_read_outcome(raftq_t* h, uint8_t* out) {
+  if (int rc = use_device(h)) return rc;
+  if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_outcome: null argument");
+  HIPCHK(h, hipMemcpyAsync(out, h->outcome, h->G, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_read_match(raftq_t* h, uint64_t* out) {
+  if (int rc = use_device(h)) return rc;
+  if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_match: null argument");
+  HIPCHK(h, hipMemcpy2DAsync(out, h->G * 8, h->match, h->ld * 8, h->G * 8, h->N, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_read_votes(raftq_t* h, uint8_t* out) {
+  if (int rc = use_device(h)) return rc;
+  if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_votes: null argument");
+  HIPCHK(h, hipMemcpy2DAsync(out, h->G, h->votes, h->ld, h->G, h->N, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_commit_advance(raftq_t* h, int gated, uint64_t* committed_out, uint64_t* n_changed) {
+  if (int rc = raftq_step_async(h, gated ? (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED) : RAFTQ_SWEEP_COMMIT)) return rc;
+  raftq_counts_t c;
+  if (int rc = raftq_wait(h, &c)) return rc;
+  if (n_changed) *n_changed = c.n_changed;
+  if (committed_out) return raftq_read_committed(h, committed_out);
+  return RAFTQ_OK;
+}
+
+int raftq_vote_tally(raftq_t* h, uint8_t* outcome_out, raftq_counts_t* counts) {
+  if (int rc = raftq_step_async(h, RAFTQ_SWEEP_VOTES)) return rc;
+  raftq_counts_t c;
+  if (int rc = raftq_wait(h, &c)) return rc;
+  if (counts) *counts = c;
+  if (outcome_out) return raftq_read_outcome(h, outcome_out);
+  return RAFTQ_OK;
+}
+
+int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
+  if (int rc = use_device(h)) return rc;
+  if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_changed: null count");
+  if (!(h->last_flags & RAFTQ_SWEEP_CHANGED) || !h->last_old)
+    return fail(h, RAFTQ_ESTATE, "raftq_collect_changed: last sweep did not set RAFTQ_SWEEP_CHANGED");
+  if (cap && !out) return fail(h, RAFTQ_EINVAL, "raftq_collect_changed: null out with cap > 0");
+  static_assert(sizeof(Advance) == sizeof(raftq_advance_t), "ABI struct mismatch");
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->partials, h->n_partials,
+                     h->offsets, h->offsets + h->max_partials);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h->h_total, h->offsets + h->max_partials, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t total = *h->h_total;
+  *n = total;
+  const uint64_t take = std::min(total, cap);
+  if (take == 0) return RAFTQ_OK;
+  if (h->adv_cap < take) {
+    if (h->adv) HIPCHK(h, hipFree(h->adv));
+    h->adv = nullptr;
+    h->adv_cap = 0;
+    const uint64_t want = std::min<uint64_t>(h->G, std::max<uint64_t>(take, 4096));
+    HIPCHK(h, hipMalloc((void**)&h->adv, want * sizeof(Advance)));
+    h->adv_cap = want;
+  }
+  const int gpl = h->last_gpl;
+  const dim3 grid((unsigned)(h->ld / ((uint64_t)kBlock * gpl)));
+  if (gpl == kGPL)
+    hipLaunchKernelGGL((compact_changed_kernel<kGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
+                       h->last_old, h->last_new, h->adv, take);
+  else
+    hipLaunchKernelGGL((compact_changed_kernel<kLdsGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
+                       h->offsets, h->last_old, h->last_new, h->adv, take);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, h->adv, take * sizeof(Advance), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_timer_begin(raftq_t* h) {
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_timer_end(raftq_t* h, float* elapsed_ms) {
+  if (int rc = use_device(h)) return rc;
+  if (!elapsed_ms) return fail(h, RAFTQ_EINVAL, "raftq_timer_end: null argument");
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return RAFTQ_OK;
+}
+
+}  // extern "C"

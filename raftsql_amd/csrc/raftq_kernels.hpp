@@ -1,0 +1,485 @@
+// raftq_kernels.hpp -- CDNA4 (gfx950) device code of the batched multi-raft
+// quorum sweep.  Hand-written HIP, wave64, no MFMA: the path is integer
+// selection over uint64 log indices and byte compares over votes, bound by
+// HBM bandwidth (DESIGN.md "Kernels").
+//
+// What it computes, per raft group g (restating etcd/raft, the dependency the
+// reference drives from raft.go:214,224,269 -- SURVEY.md 8a rows a5-a8):
+//   mci          = q-th largest of match[0..N)[g],  q = N/2+1     (maybeCommit)
+//   committed'   = mci > committed && gate ? mci : committed      (raftLog.maybeCommit)
+//   outcome      = granted>=q ? won : rejected>=q ? lost : pending (poll)
+//
+// HBM layout (peer-major SoA, every row padded to `ld` groups, ld % 2048 == 0,
+// padding zero-filled so a full tile is always safe to process):
+//   match[p*ld + g] u64 | committed[g] u64 | first_idx[g] u64 | votes[p*ld + g] u8
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace raftqk {
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxPeers = 9;
+constexpr int kTileMax = 2048;       // groups per block at GPL=8; ld granule
+
+struct SweepArgs {
+  const uint64_t* match;       // [N][ld]
+  const uint64_t* committed;   // [ld]   current commit index
+  uint64_t* committed_out;     // [ld]   shadow buffer (may alias committed)
+  const uint64_t* first_idx;   // [ld]   first index of cur_term, 0 = none
+  const uint8_t* votes;        // [N][ld]
+  uint8_t* outcome;            // [ld]
+  uint64_t* changed_bits;      // [ld/64] lane-ordered bitmap, or nullptr
+  uint4* partials;             // [ld/kTile * kWaves] {changed, won, lost, 0}
+  uint64_t ld;
+};
+
+// ---------------------------------------------------------------------------
+// uint64 compare-exchange, descending: a <- max, b <- min.  gfx950 has no
+// v_max_u64; this is one v_cmp_gt_u64 + 4 v_cndmask_b32, and the dead half of
+// a CE whose other output is never read is removed by the compiler.
+__device__ __forceinline__ void ce_desc(uint64_t& a, uint64_t& b) {
+  const bool gt = a > b;
+  const uint64_t hi = gt ? a : b;
+  const uint64_t lo = gt ? b : a;
+  a = hi;
+  b = lo;
+}
+
+// Optimal-size sorting networks for N <= 9 (0-1-principle checked in
+// tests/test_networks.py against the same comparator lists).  Only element
+// q-1 = N/2 of the descending order is consumed, so the compiler prunes the
+// comparators (and halves of comparators) that cannot reach it.
+template <int N>
+__device__ __forceinline__ uint64_t select_quorum_network(uint64_t (&v)[N]) {
+#define CE(i, j) ce_desc(v[i], v[j])
+  if constexpr (N == 2) { CE(0, 1); }
+  if constexpr (N == 3) { CE(0, 2); CE(0, 1); CE(1, 2); }
+  if constexpr (N == 4) { CE(0, 2); CE(1, 3); CE(0, 1); CE(2, 3); CE(1, 2); }
+  if constexpr (N == 5) {
+    CE(0, 3); CE(1, 4); CE(0, 2); CE(1, 3); CE(0, 1); CE(2, 4); CE(1, 2); CE(3, 4); CE(2, 3);
+  }
+  if constexpr (N == 6) {
+    CE(0, 5); CE(1, 3); CE(2, 4); CE(1, 2); CE(3, 4); CE(0, 3);
+    CE(2, 5); CE(0, 1); CE(2, 3); CE(4, 5); CE(1, 2); CE(3, 4);
+  }
+  if constexpr (N == 7) {
+    CE(0, 6); CE(2, 3); CE(4, 5); CE(0, 2); CE(1, 4); CE(3, 6); CE(0, 1); CE(2, 5);
+    CE(3, 4); CE(1, 2); CE(4, 6); CE(2, 3); CE(4, 5); CE(1, 2); CE(3, 4); CE(5, 6);
+  }
+  if constexpr (N == 8) {
+    CE(0, 2); CE(1, 3); CE(4, 6); CE(5, 7); CE(0, 4); CE(1, 5); CE(2, 6); CE(3, 7); CE(0, 1); CE(2, 3);
+    CE(4, 5); CE(6, 7); CE(2, 4); CE(3, 5); CE(1, 4); CE(3, 6); CE(1, 2); CE(3, 4); CE(5, 6);
+  }
+  if constexpr (N == 9) {
+    CE(0, 3); CE(1, 7); CE(2, 5); CE(4, 8); CE(0, 7); CE(2, 4); CE(3, 8); CE(5, 6); CE(0, 2);
+    CE(1, 3); CE(4, 5); CE(7, 8); CE(1, 4); CE(3, 6); CE(5, 7); CE(0, 1); CE(2, 4); CE(3, 5);
+    CE(6, 8); CE(2, 3); CE(4, 5); CE(6, 7); CE(1, 2); CE(3, 4); CE(5, 6);
+  }
+#undef CE
+  return v[N / 2];
+}
+
+// Odd-even transposition sort (N rounds of neighbour exchanges): the network
+// north_star names for the LDS-staged variant.
+template <int N>
+__device__ __forceinline__ uint64_t select_quorum_oddeven(uint64_t (&v)[N]) {
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+#pragma unroll
+    for (int i = (r & 1); i + 1 < N; i += 2) ce_desc(v[i], v[i + 1]);
+  }
+  return v[N / 2];
+}
+
+// raftLog.maybeCommit's test; GATED uses the compact encoding:
+// term(mci) == cur_term  <=>  first_idx != 0 && mci >= first_idx.
+template <bool GATED>
+__device__ __forceinline__ uint64_t maybe_commit(uint64_t mci, uint64_t committed, uint64_t first_idx) {
+  bool adv = mci > committed;
+  if constexpr (GATED) adv = adv && (first_idx != 0) && (mci >= first_idx);
+  return adv ? mci : committed;
+}
+
+// ---------------------------------------------------------------------------
+// SWAR byte lanes for the vote tally: a lane owns 8 consecutive groups of one
+// peer row as one uint64.
+__device__ __forceinline__ uint64_t bytes_equal(uint64_t v, uint64_t pattern) {
+  // exact per-byte equality -> 0x01 in every equal byte (no cross-byte carry)
+  const uint64_t k7f = 0x7f7f7f7f7f7f7f7full;
+  const uint64_t x = v ^ pattern;
+  uint64_t y = (x & k7f) + k7f;
+  y = ~(y | x | k7f);  // 0x80 where the byte of x is zero
+  return y >> 7;
+}
+
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  return __builtin_nontemporal_load(p);
+}
+template <typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  __builtin_nontemporal_store(v, p);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// ---------------------------------------------------------------------------
+// The sweep.  One 256-thread workgroup owns a tile of 256*GPL consecutive
+// groups, each of its 4 waves a contiguous 64*GPL of them.  Commit part:
+// GPL/2 rounds; in round j a wave covers 128 consecutive groups, lane l
+// holding the 16-byte pair {g, g+1}, so every global access is a fully
+// coalesced 1 KiB per wave instruction.  All
+// (N+1[+1]) * GPL/2 loads of a lane are issued before the first compare.
+// Vote part: lane t owns the 8 groups [8t, 8t+8) of the tile as one 8-byte
+// load per peer row (votes are 1 byte per group).
+//
+// NT: stream the inputs/outputs with the non-temporal policy (they are read
+// once per sweep).  Chosen per launch by the host; see DESIGN.md for the A/B.
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, bool NT, bool BITS>
+__global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
+  constexpr int kTile = kBlock * GPL;
+  constexpr int kRounds = GPL / 2;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+  uint32_t n_changed = 0;  // wave-uniform
+  uint32_t won_lost = 0;   // per lane: won | lost << 16
+
+  // vote rows first: their loads fly while the commit part computes
+  constexpr int kVoteLanes = kTile / 8;  // lanes that own 8 groups each
+  const bool vote_lane = VOTES && tid < kVoteLanes;  // wave-uniform (kVoteLanes % 64 == 0)
+  uint64_t vv[N];
+  if constexpr (VOTES) {
+    if (vote_lane) {
+      const uint64_t g = tile0 + 8ull * tid;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g);
+        vv[p] = NT ? ld_stream(src) : *src;
+      }
+    }
+  }
+
+  if constexpr (COMMIT) {
+    u64x2 m[kRounds][N];
+    u64x2 c[kRounds];
+    u64x2 f[kRounds];
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const u64x2* src = reinterpret_cast<const u64x2*>(a.match + (uint64_t)p * a.ld + g);
+        m[j][p] = NT ? ld_stream(src) : *src;
+      }
+      {
+        const u64x2* src = reinterpret_cast<const u64x2*>(a.committed + g);
+        c[j] = NT ? ld_stream(src) : *src;
+      }
+      if constexpr (GATED) {
+        const u64x2* src = reinterpret_cast<const u64x2*>(a.first_idx + g);
+        f[j] = NT ? ld_stream(src) : *src;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
+      uint64_t v0[N], v1[N];
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        v0[p] = m[j][p].x;
+        v1[p] = m[j][p].y;
+      }
+      uint64_t mci0, mci1;
+      if constexpr (N == 1) {
+        mci0 = v0[0];
+        mci1 = v1[0];
+      } else {
+        mci0 = select_quorum_network<N>(v0);
+        mci1 = select_quorum_network<N>(v1);
+      }
+      u64x2 o;
+      o.x = maybe_commit<GATED>(mci0, c[j].x, GATED ? f[j].x : 0);
+      o.y = maybe_commit<GATED>(mci1, c[j].y, GATED ? f[j].y : 0);
+      const bool ch0 = o.x != c[j].x;
+      const bool ch1 = o.y != c[j].y;
+      const uint64_t b0 = __ballot(ch0);
+      const uint64_t b1 = __ballot(ch1);
+      n_changed += __popcll(b0) + __popcll(b1);
+      if constexpr (BITS) {
+        // lane-ordered bitmap: word 2k = even groups, 2k+1 = odd groups of the
+        // k-th 128-group run (decoded by compact_changed_kernel)
+        if (a.changed_bits != nullptr && (tid & 63) == 0) {
+          u64x2 w;
+          w.x = b0;
+          w.y = b1;
+          *reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)) = w;
+        }
+      }
+      u64x2* dst = reinterpret_cast<u64x2*>(a.committed_out + g);
+      if (NT) st_stream(dst, o); else *dst = o;
+    }
+  }
+
+  if constexpr (VOTES) {
+    if (vote_lane) {
+      const uint64_t g = tile0 + 8ull * tid;
+      uint64_t granted = 0, rejected = 0;  // per-byte counters, <= N <= 9
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        granted += bytes_equal(vv[p], 0x0101010101010101ull);
+        rejected += bytes_equal(vv[p], 0x0202020202020202ull);
+      }
+      constexpr uint64_t q = N / 2 + 1;
+      constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
+      const uint64_t k80 = 0x8080808080808080ull;
+      const uint64_t won = ((granted + bias) & k80) >> 7;    // 0x01 where granted >= q
+      const uint64_t lost = ((rejected + bias) & k80) >> 7;  // exclusive with won (g+r <= N < 2q)
+      const uint64_t out = won | ((lost & ~won) << 1);
+      uint64_t* dst = reinterpret_cast<uint64_t*>(a.outcome + g);
+      if (NT) st_stream(dst, out); else *dst = out;
+      won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
+    }
+  }
+
+  const uint32_t wl = VOTES ? wave_sum_u32(won_lost) : 0u;
+  if ((tid & 63) == 0) {
+    uint4 r;
+    r.x = n_changed;
+    r.y = wl & 0xffffu;
+    r.z = wl >> 16;
+    r.w = 0;
+    a.partials[(uint64_t)blockIdx.x * kWaves + (tid >> 6)] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A/B variant named by north_star: "one wavefront per tile of groups with an
+// LDS-staged odd-even sort".  Each wave DMA-stages its tile rows straight from
+// HBM into LDS (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR
+// round trip), waits on its own vmcnt, reads its two groups' columns back with
+// conflict-free ds_read_b128 and runs the odd-even transposition network.
+// Every lane reads only bytes its own DMA lane wrote, so no barrier is needed.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_cvoid_t;
+
+template <int N, int GPL, bool GATED, bool VOTES, bool BITS>
+__global__ __launch_bounds__(kBlock) void sweep_lds_kernel(SweepArgs a) {
+  constexpr int kTile = kBlock * GPL;
+  constexpr int kRounds = GPL / 2;
+  constexpr int kRows = N + 1 + (GATED ? 1 : 0);   // match rows, committed, first_idx
+  constexpr int kRowBytes = 64 * 16;               // one wave instruction
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = tid >> 6;
+  unsigned char* wbase = smem + (size_t)wave * (kRounds * kRows * kRowBytes);
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+  uint32_t n_changed = 0;
+  uint32_t won_lost = 0;
+
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
+    unsigned char* rbase = wbase + (size_t)j * kRows * kRowBytes;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a.match + (uint64_t)p * a.ld + g),
+                                       (lds_void_t*)(rbase + p * kRowBytes), 16, 0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a.committed + g),
+                                     (lds_void_t*)(rbase + N * kRowBytes), 16, 0, 0);
+    if constexpr (GATED) {
+      __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a.first_idx + g),
+                                       (lds_void_t*)(rbase + (N + 1) * kRowBytes), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
+    const unsigned char* rbase = wbase + (size_t)j * kRows * kRowBytes;
+    uint64_t v0[N], v1[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      const u64x2 t = *reinterpret_cast<const u64x2*>(rbase + p * kRowBytes + lane * 16);
+      v0[p] = t.x;
+      v1[p] = t.y;
+    }
+    const u64x2 c = *reinterpret_cast<const u64x2*>(rbase + N * kRowBytes + lane * 16);
+    u64x2 f;
+    f.x = f.y = 0;
+    if constexpr (GATED) f = *reinterpret_cast<const u64x2*>(rbase + (N + 1) * kRowBytes + lane * 16);
+    const uint64_t mci0 = select_quorum_oddeven<N>(v0);
+    const uint64_t mci1 = select_quorum_oddeven<N>(v1);
+    u64x2 o;
+    o.x = maybe_commit<GATED>(mci0, c.x, f.x);
+    o.y = maybe_commit<GATED>(mci1, c.y, f.y);
+    const uint64_t b0 = __ballot(o.x != c.x);
+    const uint64_t b1 = __ballot(o.y != c.y);
+    n_changed += __popcll(b0) + __popcll(b1);
+    if constexpr (BITS) {
+      if (a.changed_bits != nullptr && lane == 0) {
+        u64x2 w;
+        w.x = b0;
+        w.y = b1;
+        *reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)) = w;
+      }
+    }
+    *reinterpret_cast<u64x2*>(a.committed_out + g) = o;
+  }
+
+  if constexpr (VOTES) {
+    constexpr int kVoteLanes = kTile / 8;
+    if (tid < kVoteLanes) {
+      const uint64_t g = tile0 + 8ull * tid;
+      uint64_t granted = 0, rejected = 0;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g);
+        granted += bytes_equal(v, 0x0101010101010101ull);
+        rejected += bytes_equal(v, 0x0202020202020202ull);
+      }
+      constexpr uint64_t q = N / 2 + 1;
+      constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
+      const uint64_t k80 = 0x8080808080808080ull;
+      const uint64_t won = ((granted + bias) & k80) >> 7;
+      const uint64_t lost = ((rejected + bias) & k80) >> 7;
+      *reinterpret_cast<uint64_t*>(a.outcome + g) = won | ((lost & ~won) << 1);
+      won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
+    }
+  }
+  const uint32_t wl = VOTES ? wave_sum_u32(won_lost) : 0u;
+  if (lane == 0) {
+    uint4 r;
+    r.x = n_changed;
+    r.y = wl & 0xffffu;
+    r.z = wl >> 16;
+    r.w = 0;
+    a.partials[(uint64_t)blockIdx.x * kWaves + wave] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sparse ingest.  Progress.maybeUpdate only ever raises
+// Match, so a batch of MsgAppResp deltas is an order-independent atomic max.
+struct DeltaSoA {
+  const uint64_t* group;
+  const uint64_t* match;
+  const uint32_t* peer;
+};
+
+__global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld, DeltaSoA d,
+                                                              uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long* slot =
+      reinterpret_cast<unsigned long long*>(match + (uint64_t)d.peer[i] * ld + d.group[i]);
+  atomicMax(slot, (unsigned long long)d.match[i]);
+}
+
+// poll(): the first response of a peer wins.  The host has already removed
+// duplicate (group, peer) pairs from the batch (keeping the earliest), so
+// slots are disjoint bytes; neighbours share a 32-bit word, hence the CAS.
+__global__ __launch_bounds__(kBlock) void apply_vote_deltas_kernel(uint8_t* votes, uint64_t ld,
+                                                                   const uint64_t* group,
+                                                                   const uint32_t* peer,
+                                                                   const uint8_t* vote, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t byte = (uint64_t)peer[i] * ld + group[i];
+  unsigned int* word = reinterpret_cast<unsigned int*>(votes + (byte & ~3ull));
+  const unsigned sh = (unsigned)(byte & 3ull) * 8u;
+  const unsigned nv = (unsigned)vote[i] << sh;
+  unsigned old = *word;
+  while (true) {
+    const unsigned cur = (old >> sh) & 0xffu;
+    if (cur == 1u || cur == 2u) return;  // already answered
+    const unsigned want = (old & ~(0xffu << sh)) | nv;
+    const unsigned seen = atomicCAS(word, old, want);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Changed-group compaction (the Ready side): turn the
+// lane-ordered bitmap of a RAFTQ_SWEEP_CHANGED sweep into a dense, ascending
+// list of {group, old_commit, new_commit}.  Deterministic two-pass: the sweep
+// already left per-wave change counts in partials[].x; scan_partials_kernel
+// turns them into exclusive offsets (one workgroup, the array is small), then
+// every wave of compact_changed_kernel ranks its own bits with popcounts.
+struct Advance {
+  uint64_t group, old_commit, new_commit;
+};
+
+__global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* partials, uint64_t n_waves,
+                                                             uint64_t* offsets, uint64_t* total) {
+  __shared__ uint64_t warp_tot[16];
+  __shared__ uint64_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n_waves; base += 1024) {
+    const uint64_t i = base + tid;
+    uint64_t x = i < n_waves ? partials[i].x : 0;
+    uint64_t incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t y = __shfl_up(incl, o, 64);
+      if (lane >= (uint32_t)o) incl += y;
+    }
+    if (lane == 63) warp_tot[w] = incl;
+    __syncthreads();
+    uint64_t pre = carry;
+    for (uint32_t k = 0; k < w; ++k) pre += warp_tot[k];
+    if (i < n_waves) offsets[i] = pre + incl - x;
+    __syncthreads();
+    if (tid == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
+// Mirrors the sweep's geometry: wave `wv` of block `b` owns the 64*GPL
+// consecutive groups from b*kTile + wv*64*GPL and produced, for each round j,
+// one {even, odd} word pair for the 128 groups at + j*128 -- so (block, wave,
+// round, lane, parity) order IS ascending group order.
+template <int GPL>
+__global__ __launch_bounds__(kBlock) void compact_changed_kernel(const uint64_t* changed_bits,
+                                                                 const uint64_t* offsets,
+                                                                 const uint64_t* old_commit,
+                                                                 const uint64_t* new_commit,
+                                                                 Advance* out, uint64_t cap) {
+  constexpr int kTile = kBlock * GPL;
+  constexpr int kRounds = GPL / 2;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t pos = offsets[(uint64_t)blockIdx.x * kWaves + wave];
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint64_t g0 = (uint64_t)blockIdx.x * kTile + (uint64_t)wave * (64 * GPL) + (uint64_t)j * 128;
+    const uint64_t b0 = changed_bits[(g0 >> 6)];
+    const uint64_t b1 = changed_bits[(g0 >> 6) + 1];
+    const bool e = (b0 >> lane) & 1, o = (b1 >> lane) & 1;
+    const uint64_t rank = __popcll(b0 & below) + __popcll(b1 & below);
+    if (e) {
+      const uint64_t g = g0 + 2 * lane, s = pos + rank;
+      if (s < cap) out[s] = Advance{g, old_commit[g], new_commit[g]};
+    }
+    if (o) {
+      const uint64_t g = g0 + 2 * lane + 1, s = pos + rank + (e ? 1 : 0);
+      if (s < cap) out[s] = Advance{g, old_commit[g], new_commit[g]};
+    }
+    pos += __popcll(b0) + __popcll(b1);
+  }
+}
+
+}  // namespace raftqk

@@ -1,0 +1,207 @@
+"""Host-side handle on the resident quorum state of G raft groups on one GPU.
+
+Thin, typed wrapper over the C-ABI (include/raftq.h) for the Python harnesses
+(tests, bench).  The names follow the reference's domain: groups, peers,
+match index, commit index, votes, and the error behaviour is
+the C-ABI's: a failing call raises RaftqError with the library's message, it
+never falls back to a CPU computation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import (SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
+                   SWEEP_VOTES, Advance, Counts, Delta, RaftqError, VoteDelta)
+
+__all__ = ["QuorumEngine", "SweepCounts", "device_count", "RaftqError", "SWEEP_COMMIT", "SWEEP_GATED",
+           "SWEEP_VOTES", "SWEEP_NO_ADOPT", "SWEEP_LDS", "SWEEP_CHANGED"]
+
+
+@dataclass
+class SweepCounts:
+    n_changed: int
+    n_won: int
+    n_lost: int
+
+
+def device_count() -> int:
+    lib = _lib.load()
+    n = C.c_int(0)
+    rc = lib.raftq_device_count(C.byref(n))
+    if rc != 0:
+        return 0
+    return int(n.value)
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+class QuorumEngine:
+    """G groups x N peers of raft quorum state resident in one GPU's HBM."""
+
+    def __init__(self, n_groups: int, n_peers: int, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p(None)
+        self.n_groups = int(n_groups)
+        self.n_peers = int(n_peers)
+        self.device = int(device)
+        rc = self._lib.raftq_create(self.device, self.n_groups, self.n_peers, C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.raftq_last_error(None)
+            self._h = C.c_void_p(None)
+            raise RaftqError(rc, msg.decode() if msg else "raftq_create failed")
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.raftq_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            msg = self._lib.raftq_last_error(self._h)
+            raise RaftqError(rc, msg.decode() if msg else "?")
+
+    def set_stream(self, stream_ptr: int) -> None:
+        self._chk(self._lib.raftq_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def get_stream(self) -> int:
+        return int(self._lib.raftq_get_stream(self._h) or 0)
+
+    # -- bulk load --------------------------------------------------------
+    def load_match(self, match: Optional[np.ndarray], committed: Optional[np.ndarray]) -> None:
+        m = c = None
+        if match is not None:
+            m = np.ascontiguousarray(match, dtype=np.uint64)
+            if m.shape != (self.n_peers, self.n_groups):
+                raise ValueError(f"match must be [{self.n_peers}, {self.n_groups}]")
+        if committed is not None:
+            c = np.ascontiguousarray(committed, dtype=np.uint64)
+            if c.shape != (self.n_groups,):
+                raise ValueError("committed must be [G]")
+        self._chk(self._lib.raftq_load_match(self._h, _ptr(m) if m is not None else None,
+                                             _ptr(c) if c is not None else None))
+
+    def load_terms(self, cur_term: np.ndarray, first_idx_cur_term: np.ndarray) -> None:
+        t = np.ascontiguousarray(cur_term, dtype=np.uint64)
+        f = np.ascontiguousarray(first_idx_cur_term, dtype=np.uint64)
+        if t.shape != (self.n_groups,) or f.shape != (self.n_groups,):
+            raise ValueError("terms must be [G]")
+        self._chk(self._lib.raftq_load_terms(self._h, _ptr(t), _ptr(f)))
+
+    def load_votes(self, votes: np.ndarray) -> None:
+        v = np.ascontiguousarray(votes, dtype=np.uint8)
+        if v.shape != (self.n_peers, self.n_groups):
+            raise ValueError(f"votes must be [{self.n_peers}, {self.n_groups}]")
+        self._chk(self._lib.raftq_load_votes(self._h, _ptr(v)))
+
+    def load_state(self, st) -> None:
+        """Load a synth.GroupState (match, committed, votes and, if present, terms)."""
+        self.load_match(st.match, st.committed)
+        self.load_votes(st.votes)
+        if st.first_idx_cur_term is not None:
+            self.load_terms(st.cur_term, st.first_idx_cur_term)
+
+    # -- sparse ingest ----------------------------------------------------
+    def apply_deltas(self, group, peer, match) -> None:
+        n = len(group)
+        arr = (Delta * n)()
+        a = np.frombuffer(arr, dtype=np.dtype(
+            [("group", "<u8"), ("match", "<u8"), ("peer", "<u4"), ("_pad", "<u4")]))
+        a["group"], a["match"], a["peer"] = group, match, peer
+        self._chk(self._lib.raftq_apply_deltas(self._h, C.addressof(arr) if n else None, n))
+
+    def apply_vote_deltas(self, group, peer, vote) -> None:
+        n = len(group)
+        arr = (VoteDelta * n)()
+        a = np.frombuffer(arr, dtype=np.dtype(
+            [("group", "<u8"), ("peer", "<u4"), ("vote", "u1"), ("_pad", "u1", (3,))]))
+        a["group"], a["peer"], a["vote"] = group, peer, vote
+        self._chk(self._lib.raftq_apply_vote_deltas(self._h, C.addressof(arr) if n else None, n))
+
+    # -- the sweep --------------------------------------------------------
+    def step_async(self, flags: int) -> None:
+        self._chk(self._lib.raftq_step_async(self._h, flags))
+
+    def wait(self, want_counts: bool = False) -> Optional[SweepCounts]:
+        if not want_counts:
+            self._chk(self._lib.raftq_wait(self._h, None))
+            return None
+        c = Counts()
+        self._chk(self._lib.raftq_wait(self._h, C.byref(c)))
+        return SweepCounts(int(c.n_changed), int(c.n_won), int(c.n_lost))
+
+    def sweep(self, flags: int) -> SweepCounts:
+        self.step_async(flags)
+        return self.wait(want_counts=True)
+
+    def commit_advance(self, gated: bool = False):
+        """-> (committed [G] u64, n_changed): raft.maybeCommit over every group."""
+        out = np.empty(self.n_groups, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_commit_advance(self._h, int(gated), _ptr(out), C.byref(n)))
+        return out, int(n.value)
+
+    def vote_tally(self):
+        """-> (outcome [G] u8, SweepCounts): raft.poll over every group."""
+        out = np.empty(self.n_groups, dtype=np.uint8)
+        c = Counts()
+        self._chk(self._lib.raftq_vote_tally(self._h, _ptr(out), C.byref(c)))
+        return out, SweepCounts(int(c.n_changed), int(c.n_won), int(c.n_lost))
+
+    # -- read-back --------------------------------------------------------
+    def read_committed(self) -> np.ndarray:
+        out = np.empty(self.n_groups, dtype=np.uint64)
+        self._chk(self._lib.raftq_read_committed(self._h, _ptr(out)))
+        return out
+
+    def read_outcome(self) -> np.ndarray:
+        out = np.empty(self.n_groups, dtype=np.uint8)
+        self._chk(self._lib.raftq_read_outcome(self._h, _ptr(out)))
+        return out
+
+    def read_match(self) -> np.ndarray:
+        out = np.empty((self.n_peers, self.n_groups), dtype=np.uint64)
+        self._chk(self._lib.raftq_read_match(self._h, _ptr(out)))
+        return out
+
+    def read_votes(self) -> np.ndarray:
+        out = np.empty((self.n_peers, self.n_groups), dtype=np.uint8)
+        self._chk(self._lib.raftq_read_votes(self._h, _ptr(out)))
+        return out
+
+    def collect_changed(self, cap: Optional[int] = None):
+        """-> structured array (group, old_commit, new_commit), ascending group."""
+        cap = self.n_groups if cap is None else int(cap)
+        arr = (Advance * cap)()
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_collect_changed(self._h, C.addressof(arr) if cap else None, cap, C.byref(n)))
+        a = np.frombuffer(arr, dtype=np.dtype([("group", "<u8"), ("old_commit", "<u8"), ("new_commit", "<u8")]))
+        return a[: min(int(n.value), cap)].copy(), int(n.value)
+
+    # -- measurement ------------------------------------------------------
+    def timer_begin(self) -> None:
+        self._chk(self._lib.raftq_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0.0)
+        self._chk(self._lib.raftq_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)

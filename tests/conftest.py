@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; oracle/raftq_oracle.h)."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def gpu_engine_cls():
+    """QuorumEngine bound to the native library; refuses to run without it."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test started without a visible GPU")
+    from raftsql_amd.engine import QuorumEngine, device_count
+
+    assert device_count() >= 1, "libraftq.so sees no HIP device"
+    return QuorumEngine

@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads and exports every symbol that
+include/raftq.h declares; argument validation and the no-GPU error path work
+without touching a device.  No compute is called here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from raftsql_amd import _lib, build
+
+    build.build_lib()  # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "raftq.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(raftq_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_list_the_same_symbols():
+    from raftsql_amd import _lib
+
+    assert _declared() == sorted(_lib.EXPORTS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_quorum(lib):
+    assert lib.raftq_abi_version() == 1
+    assert [lib.raftq_quorum(n) for n in range(1, 10)] == [1, 2, 2, 3, 3, 4, 4, 5, 5]
+
+
+def test_argument_validation_without_device(lib):
+    from raftsql_amd import _lib
+
+    h = C.c_void_p(None)
+    assert lib.raftq_create(0, 0, 3, C.byref(h)) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_create(0, 1024, 0, C.byref(h)) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_create(0, 1024, 10, C.byref(h)) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_create(0, 1024, 3, None) == _lib.RAFTQ_EINVAL
+    assert b"n_peers" in lib.raftq_last_error(None) or b"null" in lib.raftq_last_error(None)
+    assert lib.raftq_step_async(None, 1) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wait(None, None) == _lib.RAFTQ_EINVAL
+    lib.raftq_destroy(None)  # must be a no-op
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU the product must refuse, not compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible; the refusal path is for GPU-less hosts")
+    from raftsql_amd.engine import QuorumEngine, RaftqError
+
+    with pytest.raises(RaftqError) as ei:
+        QuorumEngine(4096, 5)
+    assert ei.value.code in (-5, -3)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "raftsql_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "raftq_oracle" not in txt, f

@@ -1,0 +1,195 @@
+"""CPU: pins the oracle (parity is UNPINNED against the reference -- no Go,
+no etcd source, no vectors in raftsql_test.go:92-171 -- so the oracle is held
+by hand-derived known answers, two further independent implementations and
+properties)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as hst
+
+from raftsql_amd import synth
+from tests import ref_numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+U64 = hst.integers(min_value=0, max_value=2**64 - 1)
+
+
+def test_quorum(oracle):
+    # etcd raft.q(): len(prs)/2 + 1
+    assert [oracle.quorum(n) for n in range(1, 10)] == [1, 2, 2, 3, 3, 4, 4, 5, 5]
+    assert [synth.quorum(n) for n in range(1, 10)] == [1, 2, 2, 3, 3, 4, 4, 5, 5]
+
+
+@pytest.mark.parametrize("case", KAT["mci"], ids=lambda c: "m" + "_".join(map(str, c["match"]))[:40])
+def test_kat_mci(oracle, case):
+    m = np.array(case["match"], dtype=np.uint64)
+    assert oracle.mci_sort(m) == case["mci"]
+    assert oracle.mci_count(m) == case["mci"]
+    assert int(ref_numpy.mci(m[:, None])[0]) == case["mci"]
+    assert int(ref_numpy.mci_bruteforce(m[:, None])[0]) == case["mci"]
+
+
+@pytest.mark.parametrize("case", KAT["commit"])
+def test_kat_commit(oracle, case):
+    m = np.array(case["match"], dtype=np.uint64)[:, None]
+    c = np.array([case["committed"]], dtype=np.uint64)
+    out, n = oracle.commit_advance(m, c)
+    assert int(out[0]) == case["ungated"] and n == int(case["ungated"] != case["committed"])
+    if "gated" in case:
+        f = np.array([case["first_idx"]], dtype=np.uint64)
+        out, n = oracle.commit_advance(m, c, True, f)
+        assert int(out[0]) == case["gated"] and n == int(case["gated"] != case["committed"])
+        out2, _ = ref_numpy.commit_advance(m, c, True, f)
+        assert int(out2[0]) == case["gated"]
+
+
+@pytest.mark.parametrize("case", KAT["poll"], ids=lambda c: "v" + "".join(map(str, c["votes"])))
+def test_kat_poll(oracle, case):
+    v = np.array(case["votes"], dtype=np.uint8)
+    assert oracle.poll(v) == case["outcome"]
+    out, _, _ = oracle.vote_tally(v[:, None])
+    assert int(out[0]) == case["outcome"]
+    assert int(ref_numpy.vote_tally(v[:, None])[0][0]) == case["outcome"]
+
+
+@pytest.mark.parametrize("case", KAT["log_term"])
+def test_kat_log_term(oracle, case):
+    for i, t in case["queries"]:
+        assert oracle.log_term(case["run_start"], case["run_term"], case["last_index"], i) == t
+
+
+@settings(max_examples=300, deadline=None)
+@given(hst.lists(U64, min_size=1, max_size=9))
+def test_three_implementations_agree(oracle, col):
+    m = np.array(col, dtype=np.uint64)
+    a = oracle.mci_sort(m)
+    assert a == oracle.mci_count(m) == int(ref_numpy.mci(m[:, None])[0]) == int(ref_numpy.mci_bruteforce(m[:, None])[0])
+    # definition: at least q peers are >= mci, and fewer than q are > mci
+    q = synth.quorum(len(col))
+    assert sum(x >= a for x in col) >= q and sum(x > a for x in col) < q
+
+
+@settings(max_examples=200, deadline=None)
+@given(hst.lists(U64, min_size=1, max_size=9), hst.randoms(use_true_random=False), U64)
+def test_properties(oracle, col, rnd, bump):
+    m = np.array(col, dtype=np.uint64)
+    base = oracle.mci_sort(m)
+    # permutation invariance over peers
+    perm = list(col)
+    rnd.shuffle(perm)
+    assert oracle.mci_sort(np.array(perm, dtype=np.uint64)) == base
+    # monotone in each match[p]
+    p = rnd.randrange(len(col))
+    up = list(col)
+    up[p] = max(up[p], bump)
+    assert oracle.mci_sort(np.array(up, dtype=np.uint64)) >= base
+    # new >= committed, gated subset of ungated
+    c = np.array([bump], dtype=np.uint64)
+    ung, _ = oracle.commit_advance(m[:, None], c)
+    assert int(ung[0]) >= bump
+    for f in (0, 1, base, base + 1 if base < 2**64 - 1 else base, 2**64 - 1):
+        g, _ = oracle.commit_advance(m[:, None], c, True, np.array([f], dtype=np.uint64))
+        assert int(g[0]) in (bump, int(ung[0]))
+        if int(g[0]) != bump:
+            assert int(ung[0]) == int(g[0])
+
+
+@pytest.mark.parametrize("n", range(1, 10))
+def test_batched_matches_numpy_on_synth(oracle, n):
+    st = synth.concat(synth.make_groups(5000, n, seed=1234 + n, with_terms=True), synth.adversarial_block(n))
+    for gated in (False, True):
+        a, na = oracle.commit_advance(st.match, st.committed, gated, st.first_idx_cur_term)
+        b, nb = ref_numpy.commit_advance(st.match, st.committed, gated, st.first_idx_cur_term)
+        assert np.array_equal(a, b) and na == nb
+    a, w, l = oracle.vote_tally(st.votes)
+    b, w2, l2 = ref_numpy.vote_tally(st.votes)
+    assert np.array_equal(a, b) and (w, l) == (w2, l2)
+
+
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_compact_gate_equals_full_log_lookup(oracle, n):
+    """a7: term(mci) == cur_term via the run-length log == compact first-index encoding."""
+    st = synth.make_groups(20000, n, seed=77 + n, with_terms=True)
+    derived = oracle.first_idx_cur_term(st)
+    assert np.array_equal(derived, st.first_idx_cur_term)
+    full, nf = oracle.commit_advance_log(st)
+    compact, nc = oracle.commit_advance(st.match, st.committed, True, st.first_idx_cur_term)
+    assert np.array_equal(full, compact) and nf == nc
+    ung, nu = oracle.commit_advance(st.match, st.committed)
+    # the gate must actually bite on this workload, and only ever withhold
+    assert 0 < nc < nu
+    assert np.all((compact == ung) | (compact == st.committed))
+
+
+def test_synth_distribution():
+    st = synth.make_groups(40000, 5, seed=synth.SEED_BASE + 3)
+    m = ref_numpy.mci(st.match)
+    ahead = (m > st.committed).mean()
+    at = (m == st.committed).mean()
+    stale = (m < st.committed).mean()
+    assert 0.45 < ahead < 0.55 and 0.2 < at < 0.3 and 0.2 < stale < 0.3
+    assert np.array_equal(st.match[0], st.match.max(axis=0))  # leader slot holds the row max
+    assert np.all(st.votes[0] == 1)
+    frac = [(st.votes[1:] == v).mean() for v in (0, 1, 2)]
+    assert abs(frac[0] - 0.3) < 0.02 and abs(frac[1] - 0.5) < 0.02 and abs(frac[2] - 0.2) < 0.02
+
+
+def test_synth_shards_are_slices_of_the_whole_job():
+    whole = synth.make_groups(3000, 7, seed=99, with_terms=True)
+    for rank in range(3):
+        g0, g1 = synth.shard_range(3000, rank, 3)
+        part = synth.make_groups(g1 - g0, 7, seed=99, with_terms=True, group_offset=g0)
+        ref = whole.slice(g0, g1)
+        for name in ("match", "committed", "votes", "cur_term", "first_idx_cur_term"):
+            assert np.array_equal(getattr(part, name), getattr(ref, name)), name
+
+
+def test_deltas_semantics(oracle):
+    st = synth.make_groups(100, 3, seed=5)
+    # maybeUpdate only raises Match; duplicates resolve to the max; out-of-range ignored
+    g = np.array([0, 0, 1, 2, 500], dtype=np.uint64)
+    p = np.array([1, 1, 2, 0, 0], dtype=np.uint32)
+    v = np.array([int(st.match[1, 0]) + 5, int(st.match[1, 0]) + 3, 0, 2**64 - 1, 7], dtype=np.uint64)
+    out = oracle.apply_deltas(st.match, g, p, v)
+    assert int(out[1, 0]) == int(st.match[1, 0]) + 5
+    assert int(out[2, 1]) == int(st.match[2, 1])
+    assert int(out[0, 2]) == 2**64 - 1
+    # poll: first response wins
+    votes = np.zeros((3, 4), dtype=np.uint8)
+    out = oracle.apply_vote_deltas(votes, np.array([1, 1, 2], dtype=np.uint64), np.array([0, 0, 1], dtype=np.uint32),
+                                   np.array([2, 1, 1], dtype=np.uint8))
+    assert out[0, 1] == 2 and out[1, 2] == 1 and out.sum() == 3
+
+
+def test_golden_small(oracle):
+    z = np.load(os.path.join(HERE, "golden", "golden_small.npz"))
+    for n in range(1, 10):
+        p = f"n{n}_"
+        ung, ch = oracle.commit_advance(z[p + "match"], z[p + "committed"])
+        gat, chg = oracle.commit_advance(z[p + "match"], z[p + "committed"], True, z[p + "first_idx"])
+        oc, w, l = oracle.vote_tally(z[p + "votes"])
+        assert np.array_equal(ung, z[p + "ungated"]) and np.array_equal(gat, z[p + "gated"])
+        assert np.array_equal(oc, z[p + "outcome"])
+        assert [ch, chg, w, l] == [int(x) for x in z[p + "counts"]]
+
+
+def test_timed_baseline_outputs_are_the_oracle_answers(oracle):
+    st = synth.make_groups(10000, 5, seed=42, with_terms=True)
+    ung, _ = oracle.commit_advance(st.match, st.committed)
+    oc, _, _ = oracle.vote_tally(st.votes)
+    for kind in (0, 1):
+        for threads in (1, 3):
+            sec, c, o = oracle.timed_sweeps(kind, threads, 2, st.match, st.committed, st.votes)
+            assert sec > 0 and np.array_equal(c, ung) and np.array_equal(o, oc)
+    gat, _ = oracle.commit_advance(st.match, st.committed, True, st.first_idx_cur_term)
+    _, c, _ = oracle.timed_sweeps(1, 2, 1, st.match, st.committed, None, True, st.first_idx_cur_term)
+    assert np.array_equal(c, gat)
+    for n in range(1, 10):  # every CPU selection network
+        s2 = synth.make_groups(3000, n, seed=n)
+        ref, _ = oracle.commit_advance(s2.match, s2.committed)
+        _, c, _ = oracle.timed_sweeps(1, 1, 1, s2.match, s2.committed)
+        assert np.array_equal(c, ref)

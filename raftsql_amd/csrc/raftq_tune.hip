@@ -1,0 +1,235 @@
+// raftq_tune.hip -- within-process A/B of the sweep-kernel variants on MI355X.
+// Not part of libraftq.so: a measurement tool.  For each (N, variant, GPL, NT)
+// it times R launches with HIP events, once re-sweeping a single resident set
+// (1M groups fit the 256 MiB Infinity Cache -> an L3 number) and once rotating
+// through K independent sets totalling > 1 GiB (an HBM number); SURVEY.md F9.
+// A plain 16 B/lane copy of the same byte volume is timed beside them as the
+// chip's attainable streaming rate for this footprint.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "raftq_kernels.hpp"
+
+using namespace raftqk;
+
+#define CK(x)                                                                            \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                           \
+    }                                                                                    \
+  } while (0)
+
+__global__ void fill_kernel(uint64_t* p, uint64_t n, uint64_t seed, uint64_t mask, uint64_t add) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p[i] = (z & mask) + add;
+  }
+}
+
+__global__ void fill_votes_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 29;
+    const unsigned u = (unsigned)(z % 10);
+    p[i] = u < 3 ? 0 : (u < 8 ? 1 : 2);
+  }
+}
+
+// streaming copy reference: in_bytes read, out_bytes written, 16 B per lane
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_ref_kernel(const u64x2* __restrict__ in, uint64_t n_in,
+                                                        u64x2* __restrict__ out, uint64_t n_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u64x2 acc = {0, 0};
+  for (uint64_t k = i; k < n_in; k += stride) {
+    const u64x2 v = NT ? __builtin_nontemporal_load(in + k) : in[k];
+    acc ^= v;
+    if (k < n_out) {
+      if (NT) __builtin_nontemporal_store(v, out + k); else out[k] = v;
+    }
+  }
+  if (acc.x == 0x123456789abcdefull && acc.y == 1) out[0] = acc;  // keep the loads alive
+}
+
+struct Set {
+  uint64_t *match, *committed, *committed_out, *first_idx, *changed;
+  uint8_t *votes, *outcome;
+  uint4* partials;
+};
+
+static Set make_set(int N, uint64_t ld, uint64_t seed) {
+  Set s;
+  CK(hipMalloc(&s.match, (size_t)N * ld * 8));
+  CK(hipMalloc(&s.committed, ld * 8));
+  CK(hipMalloc(&s.committed_out, ld * 8));
+  CK(hipMalloc(&s.first_idx, ld * 8));
+  CK(hipMalloc(&s.changed, ld / 8));
+  CK(hipMalloc(&s.votes, (size_t)N * ld));
+  CK(hipMalloc(&s.outcome, ld));
+  CK(hipMalloc(&s.partials, ld / 512 * 4 * sizeof(uint4)));
+  const uint64_t base = 1ull << 30;
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, s.match, (uint64_t)N * ld, seed, 2047ull, base);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, s.committed, ld, seed + 1, 1023ull, base + 512);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, s.first_idx, ld, seed + 2, 2047ull, base);
+  hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, s.votes, (uint64_t)N * ld, seed + 3);
+  CK(hipGetLastError());
+  return s;
+}
+
+static void free_set(Set& s) {
+  hipFree(s.match); hipFree(s.committed); hipFree(s.committed_out); hipFree(s.first_idx);
+  hipFree(s.changed); hipFree(s.votes); hipFree(s.outcome); hipFree(s.partials);
+}
+
+static SweepArgs args_of(const Set& s, uint64_t ld) {
+  SweepArgs a;
+  a.match = s.match; a.committed = s.committed; a.committed_out = s.committed_out;
+  a.first_idx = s.first_idx; a.votes = s.votes; a.outcome = s.outcome;
+  a.changed_bits = nullptr; a.partials = s.partials; a.ld = ld;
+  return a;
+}
+
+typedef void (*launch_fn)(const SweepArgs&, hipStream_t);
+
+template <int N, int GPL, bool GATED, bool VOTES, bool NT>
+static void launch_reg(const SweepArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((sweep_kernel<N, GPL, true, GATED, VOTES, NT, true>), dim3((unsigned)(a.ld / (256 * GPL))),
+                     dim3(256), 0, st, a);
+}
+template <int N, int GPL, bool GATED, bool VOTES>
+static void launch_lds(const SweepArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)4 * (GPL / 2) * (N + 1 + (GATED ? 1 : 0)) * 1024;
+  hipLaunchKernelGGL((sweep_lds_kernel<N, GPL, GATED, VOTES, true>), dim3((unsigned)(a.ld / (256 * GPL))), dim3(256),
+                     lds, st, a);
+}
+
+struct Variant {
+  const char* name;
+  int N, GPL, NT, gated, votes;
+  launch_fn fn;
+};
+
+#define REG(N, GPL, G_, V_, NT) \
+  { "reg", N, GPL, NT, G_, V_, launch_reg<N, GPL, G_, V_, NT> }
+#define LDS(N, GPL, G_, V_) \
+  { "lds", N, GPL, 0, G_, V_, launch_lds<N, GPL, G_, V_> }
+
+static const Variant kVariants[] = {
+    // config 3: 1M x 5 commit + votes (the headline)
+    REG(5, 2, false, true, false), REG(5, 4, false, true, false), REG(5, 8, false, true, false),
+    REG(5, 2, false, true, true),  REG(5, 4, false, true, true),  REG(5, 8, false, true, true),
+    LDS(5, 2, false, true),        LDS(5, 4, false, true),        LDS(5, 8, false, true),
+    // config 2: 1M x 3 commit only
+    REG(3, 2, false, false, false), REG(3, 4, false, false, false), REG(3, 8, false, false, false),
+    REG(3, 4, false, false, true),  REG(3, 8, false, false, true),  LDS(3, 4, false, false),
+    // config 4 shard: 2M x 7 commit + votes
+    REG(7, 2, false, true, false), REG(7, 4, false, true, false), REG(7, 8, false, true, false),
+    REG(7, 4, false, true, true),  LDS(7, 2, false, true),        LDS(7, 4, false, true),
+    // config 5: 1M x 5 gated
+    REG(5, 4, true, false, false), REG(5, 8, true, false, false), REG(5, 8, true, false, true),
+    LDS(5, 4, true, false),
+    // N = 9 upper bound of the network
+    REG(9, 2, false, true, false), REG(9, 4, false, true, false), LDS(9, 2, false, true),
+};
+
+static double bytes_per_group(const Variant& v) {
+  double b = 8.0 * v.N + 8 + 8;            // match + committed in + committed out
+  if (v.gated) b += 8;                      // first_idx (cur_term is folded on the host)
+  if (v.votes) b += v.N + 1;                // vote bytes + outcome
+  return b;
+}
+
+int main(int argc, char** argv) {
+  uint64_t G1 = 1ull << 20;
+  int reps = 200;
+  if (argc > 1) reps = atoi(argv[1]);
+  int dev = 0;
+  CK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, dev));
+  printf("{\"device\":\"%s\",\"cus\":%d,\"clock_mhz\":%d}\n", prop.name, prop.multiProcessorCount,
+         prop.clockRate / 1000);
+  hipStream_t st;
+  CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+
+  int curN = -1;
+  uint64_t curG = 0;
+  std::vector<Set> sets;
+  for (const Variant& v : kVariants) {
+    const uint64_t G = v.N == 7 ? 2 * G1 : G1;
+    const uint64_t ld = (G + 2047) / 2048 * 2048;
+    if (v.N != curN || G != curG) {
+      for (auto& s : sets) free_set(s);
+      sets.clear();
+      const double set_bytes = ld * (8.0 * v.N + 24 + v.N + 1);
+      const int K = (int)(1.5 * 1024 * 1024 * 1024 / set_bytes) + 1;
+      for (int k = 0; k < K; ++k) sets.push_back(make_set(v.N, ld, 1000 * v.N + k));
+      CK(hipDeviceSynchronize());
+      curN = v.N;
+      curG = G;
+      // copy reference for this footprint
+      const double bpg = 8.0 * v.N + 16 + v.N + 1;
+      const uint64_t n_in = (uint64_t)(G * (bpg - 9) / 16), n_out = (uint64_t)(G * 9 / 16);
+      for (int nt = 0; nt < 2; ++nt) {
+        for (int rot = 0; rot < 2; ++rot) {
+          for (int w = 0; w < 5; ++w) {
+            const Set& s = sets[rot ? w % sets.size() : 0];
+            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+          }
+          CK(hipEventRecord(e0, st));
+          for (int r = 0; r < reps; ++r) {
+            const Set& s = sets[rot ? r % sets.size() : 0];
+            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+          }
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms = 0;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          const double us = 1e3 * ms / reps;
+          printf("{\"kernel\":\"copy_ref\",\"N\":%d,\"G\":%llu,\"NT\":%d,\"rotate\":%d,\"K\":%zu,\"us\":%.3f,\"GBps\":%.1f}\n",
+                 v.N, (unsigned long long)G, nt, rot, sets.size(), us, (n_in + n_out) * 16.0 / us / 1e3);
+        }
+      }
+    }
+    for (int rot = 0; rot < 2; ++rot) {
+      for (int w = 0; w < 10; ++w) v.fn(args_of(sets[rot ? w % sets.size() : 0], ld), st);
+      CK(hipGetLastError());
+      CK(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) v.fn(args_of(sets[rot ? r % sets.size() : 0], ld), st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = 1e3 * ms / reps;
+      const double bpg = bytes_per_group(v);
+      printf("{\"kernel\":\"%s\",\"N\":%d,\"GPL\":%d,\"NT\":%d,\"gated\":%d,\"votes\":%d,\"G\":%llu,\"rotate\":%d,\"K\":%zu,"
+             "\"us\":%.3f,\"GBps\":%.1f,\"Gdec_per_s\":%.2f}\n",
+             v.name, v.N, v.GPL, v.NT, v.gated, v.votes, (unsigned long long)G, rot, sets.size(), us,
+             G * bpg / us / 1e3, G / us / 1e3);
+      fflush(stdout);
+    }
+  }
+  for (auto& s : sets) free_set(s);
+  return 0;
+}

@@ -1,0 +1,290 @@
+"""GPU: the HIP path (through the C-ABI) against the CPU oracle, bit-exact.
+
+Integer/index work -> the bar is equality of every output word.  Sizes the
+oracle finishes in seconds, ragged group counts around every tile edge, the
+adversarial block, the committed golden fixtures, and -- at BASELINE's full
+sizes -- both the full oracle comparison (the C oracle is fast enough) and
+size-independent properties.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raftsql_amd import synth
+from raftsql_amd._lib import (SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT, SWEEP_VOTES)
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+RAGGED = [1, 2, 63, 64, 65, 127, 129, 511, 513, 1023, 2047, 2048, 2049, 4097, 100003]
+
+
+def _state(G, n, seed, terms=True, adversarial=True):
+    st = synth.make_groups(G, n, seed=seed, with_terms=terms)
+    if adversarial:
+        st = synth.concat(st, synth.adversarial_block(n))
+    return st
+
+
+def _check_all_modes(E, oracle, st, variant_flag=0):
+    n = st.n_peers
+    ung, n_ung = oracle.commit_advance(st.match, st.committed)
+    gat, n_gat = oracle.commit_advance(st.match, st.committed, True, st.first_idx_cur_term)
+    oc, w, l = oracle.vote_tally(st.votes)
+    with E(st.n_groups, n) as e:
+        e.load_state(st)
+        # commit only (what-if: state not adopted, so every mode sees the same input)
+        c = e.sweep(SWEEP_COMMIT | SWEEP_NO_ADOPT | variant_flag)
+        assert np.array_equal(e.read_committed(), ung)
+        assert c.n_changed == n_ung
+        # gated only
+        c = e.sweep(SWEEP_COMMIT | SWEEP_GATED | SWEEP_NO_ADOPT | variant_flag)
+        assert np.array_equal(e.read_committed(), gat)
+        assert c.n_changed == n_gat
+        # votes only
+        c = e.sweep(SWEEP_VOTES)
+        assert np.array_equal(e.read_outcome(), oc)
+        assert (c.n_won, c.n_lost) == (w, l)
+        # fused commit + votes
+        c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT | variant_flag)
+        assert np.array_equal(e.read_committed(), ung) and np.array_equal(e.read_outcome(), oc)
+        assert (c.n_changed, c.n_won, c.n_lost) == (n_ung, w, l)
+        # fused gated + votes, adopted this time
+        c = e.sweep(SWEEP_COMMIT | SWEEP_GATED | SWEEP_VOTES | variant_flag)
+        assert np.array_equal(e.read_committed(), gat) and np.array_equal(e.read_outcome(), oc)
+        assert (c.n_changed, c.n_won, c.n_lost) == (n_gat, w, l)
+        # idempotence: a second adopted sweep advances nothing
+        c = e.sweep(SWEEP_COMMIT | SWEEP_GATED | variant_flag)
+        assert c.n_changed == 0 and np.array_equal(e.read_committed(), gat)
+        # inputs untouched
+        assert np.array_equal(e.read_match(), st.match) and np.array_equal(e.read_votes(), st.votes)
+
+
+@pytest.mark.parametrize("n", range(1, 10))
+def test_parity_every_peer_count(gpu_engine_cls, oracle, n):
+    _check_all_modes(gpu_engine_cls, oracle, _state(5000, n, 1000 + n))
+
+
+@pytest.mark.parametrize("n", range(1, 10))
+def test_parity_lds_variant(gpu_engine_cls, oracle, n):
+    _check_all_modes(gpu_engine_cls, oracle, _state(5000, n, 2000 + n), SWEEP_LDS)
+
+
+@pytest.mark.parametrize("G", RAGGED)
+def test_parity_ragged_group_counts(gpu_engine_cls, oracle, G):
+    for n in (3, 5):
+        _check_all_modes(gpu_engine_cls, oracle, _state(G, n, 3000 + G, adversarial=False))
+
+
+def test_synth_adversarial_only(gpu_engine_cls, oracle):
+    for n in range(1, 10):
+        st = synth.adversarial_block(n)
+        _check_all_modes(gpu_engine_cls, oracle, st)
+        _check_all_modes(gpu_engine_cls, oracle, st, SWEEP_LDS)
+
+
+def test_hand_derived_known_answers(gpu_engine_cls):
+    """tests/golden/kat.json straight through the HIP path (no oracle involved)."""
+    kat = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+    for case in kat["mci"]:
+        m = np.array(case["match"], dtype=np.uint64)[:, None]
+        with gpu_engine_cls(1, m.shape[0]) as e:
+            e.load_match(m, np.zeros(1, dtype=np.uint64))
+            out, _ = e.commit_advance()
+            assert int(out[0]) == case["mci"], case
+    for case in kat["commit"]:
+        m = np.array(case["match"], dtype=np.uint64)[:, None]
+        c = np.array([case["committed"]], dtype=np.uint64)
+        with gpu_engine_cls(1, m.shape[0]) as e:
+            e.load_match(m, c)
+            e.step_async(SWEEP_COMMIT | SWEEP_NO_ADOPT)
+            e.wait()
+            assert int(e.read_committed()[0]) == case["ungated"], case
+            if "gated" in case:
+                e.load_terms(np.array([3], dtype=np.uint64), np.array([case["first_idx"]], dtype=np.uint64))
+                out, ch = e.commit_advance(gated=True)
+                assert int(out[0]) == case["gated"] and ch == int(case["gated"] != case["committed"]), case
+    for case in kat["poll"]:
+        v = np.array(case["votes"], dtype=np.uint8)[:, None]
+        with gpu_engine_cls(1, v.shape[0]) as e:
+            e.load_votes(v)
+            out, cnt = e.vote_tally()
+            assert int(out[0]) == case["outcome"], case
+            assert (cnt.n_won, cnt.n_lost) == (int(case["outcome"] == 1), int(case["outcome"] == 2))
+
+
+def test_golden_small_fixtures(gpu_engine_cls):
+    z = np.load(os.path.join(HERE, "golden", "golden_small.npz"))
+    for n in range(1, 10):
+        p = f"n{n}_"
+        G = z[p + "committed"].shape[0]
+        for variant in (0, SWEEP_LDS):
+            with gpu_engine_cls(G, n) as e:
+                e.load_match(z[p + "match"], z[p + "committed"])
+                e.load_votes(z[p + "votes"])
+                e.load_terms(z[p + "cur_term"], z[p + "first_idx"])
+                c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT | variant)
+                assert np.array_equal(e.read_committed(), z[p + "ungated"])
+                assert np.array_equal(e.read_outcome(), z[p + "outcome"])
+                c2 = e.sweep(SWEEP_COMMIT | SWEEP_GATED | variant)
+                assert np.array_equal(e.read_committed(), z[p + "gated"])
+                assert [c.n_changed, c2.n_changed, c.n_won, c.n_lost] == [int(x) for x in z[p + "counts"]]
+
+
+def test_cur_term_zero_never_commits(gpu_engine_cls, oracle):
+    st = _state(3000, 5, 77, adversarial=False)
+    st.cur_term[::3] = 0
+    with gpu_engine_cls(st.n_groups, 5) as e:
+        e.load_state(st)
+        out, _ = e.commit_advance(gated=True)
+    f = st.first_idx_cur_term.copy()
+    f[::3] = 0
+    ref, _ = oracle.commit_advance(st.match, st.committed, True, f)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(out[::3], st.committed[::3])
+
+
+FULL = [
+    ("config2_1Mx3", 1 << 20, 3, synth.SEED_BASE + 2),
+    ("config3_1Mx5", 1 << 20, 5, synth.SEED_BASE + 3),
+    ("config4_shard_2Mx7", 1 << 21, 7, synth.SEED_BASE + 4),
+    ("config5_1Mx5_gated", 1 << 20, 5, synth.SEED_BASE + 5),
+]
+
+
+@pytest.mark.parametrize("name,G,n,seed", FULL, ids=[f[0] for f in FULL])
+def test_full_size_configs(gpu_engine_cls, oracle, name, G, n, seed):
+    """BASELINE.json configs 2-5 at full size: whole-array equality with the C
+    oracle plus size-independent properties."""
+    st = synth.make_groups(G, n, seed=seed, with_terms=True)
+    ung, n_ung = oracle.commit_advance(st.match, st.committed)
+    gat, n_gat = oracle.commit_advance(st.match, st.committed, True, st.first_idx_cur_term)
+    oc, w, l = oracle.vote_tally(st.votes)
+    with gpu_engine_cls(G, n) as e:
+        e.load_state(st)
+        for variant in (0, SWEEP_LDS):
+            c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT | variant)
+            got = e.read_committed()
+            assert np.array_equal(got, ung) and np.array_equal(e.read_outcome(), oc)
+            assert (c.n_changed, c.n_won, c.n_lost) == (n_ung, w, l)
+            c = e.sweep(SWEEP_COMMIT | SWEEP_GATED | SWEEP_NO_ADOPT | variant)
+            gg = e.read_committed()
+            assert np.array_equal(gg, gat) and c.n_changed == n_gat
+            # properties: monotone, gated subset of ungated
+            assert np.all(got >= st.committed)
+            assert np.all((gg == got) | (gg == st.committed))
+        # permutation invariance over peers: rotate the peer rows
+        perm = np.roll(np.arange(n), 1)
+        e.load_match(st.match[perm], None)
+        e.load_votes(st.votes[perm])
+        c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT)
+        assert np.array_equal(e.read_committed(), ung) and np.array_equal(e.read_outcome(), oc)
+        # adopt, then a re-sweep is a fixed point
+        c = e.sweep(SWEEP_COMMIT)
+        assert c.n_changed == n_ung
+        c = e.sweep(SWEEP_COMMIT)
+        assert c.n_changed == 0 and np.array_equal(e.read_committed(), ung)
+        # raising one follower's match can only raise the commit index
+        bumped = st.match.copy()
+        bumped[1] += np.uint64(5000)
+        e.load_match(bumped[perm], st.committed)
+        c = e.sweep(SWEEP_COMMIT | SWEEP_NO_ADOPT)
+        assert np.all(e.read_committed() >= ung)
+
+
+def test_error_behaviour(gpu_engine_cls):
+    from raftsql_amd.engine import RaftqError
+
+    with gpu_engine_cls(1000, 3) as e:
+        with pytest.raises(RaftqError) as ei:
+            e.step_async(SWEEP_COMMIT | SWEEP_GATED)  # no terms loaded
+        assert ei.value.code == -4
+        with pytest.raises(RaftqError) as ei:
+            e.step_async(0)
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            e.step_async(0x4000)
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            e.apply_deltas([1000], [0], [5])  # group out of range
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            e.apply_deltas([1], [3], [5])  # peer out of range
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            e.collect_changed()
+        assert ei.value.code == -4
+    with pytest.raises(RaftqError):
+        gpu_engine_cls(1000, 3, device=99)
+
+
+def test_deltas_and_changed_list(gpu_engine_cls, oracle):
+    """sparse MsgAppResp ingest -> sweep -> compacted advance list."""
+    rng = np.random.default_rng(7)
+    for n, G in ((3, 5000), (5, 70001), (7, 2048)):
+        st = _state(G, n, 4000 + n, adversarial=False)
+        with gpu_engine_cls(G, n) as e:
+            e.load_state(st)
+            e.sweep(SWEEP_COMMIT)  # settle: committed == quorum index where ahead
+            settled = e.read_committed()
+            nd = max(1, G // 7)
+            dg = rng.integers(0, G, nd).astype(np.uint64)
+            dp = rng.integers(0, n, nd).astype(np.uint32)
+            dm = (settled[dg.astype(np.int64)] + rng.integers(0, 2000, nd).astype(np.uint64)
+                  - np.uint64(500)).astype(np.uint64)
+            # duplicates on purpose: maybeUpdate keeps the max
+            dg[: nd // 10] = dg[0]
+            dp[: nd // 10] = dp[0]
+            e.apply_deltas(dg, dp, dm)
+            ref_match = oracle.apply_deltas(st.match, dg, dp, dm)
+            assert np.array_equal(e.read_match(), ref_match)
+            c = e.sweep(SWEEP_COMMIT | SWEEP_CHANGED)
+            ref, n_ref = oracle.commit_advance(ref_match, settled)
+            assert np.array_equal(e.read_committed(), ref) and c.n_changed == n_ref
+            adv, total = e.collect_changed()
+            idx = np.nonzero(ref != settled)[0]
+            assert total == n_ref == len(idx)
+            assert np.array_equal(adv["group"], idx.astype(np.uint64))
+            assert np.array_equal(adv["old_commit"], settled[idx]) and np.array_equal(adv["new_commit"], ref[idx])
+            # capped collection still reports the full count
+            adv2, total2 = e.collect_changed(cap=3)
+            assert total2 == n_ref and np.array_equal(adv2["group"], idx[:3].astype(np.uint64))
+
+
+def test_vote_deltas_first_response_wins(gpu_engine_cls, oracle):
+    rng = np.random.default_rng(11)
+    n, G = 5, 30011
+    votes = np.zeros((n, G), dtype=np.uint8)
+    votes[0] = 1  # candidates voted for themselves
+    with gpu_engine_cls(G, n) as e:
+        e.load_votes(votes)
+        ref = votes
+        for _ in range(3):
+            nd = 20000
+            dg = rng.integers(0, G, nd).astype(np.uint64)
+            dp = rng.integers(0, n, nd).astype(np.uint32)
+            dv = rng.integers(1, 3, nd).astype(np.uint8)
+            e.apply_vote_deltas(dg, dp, dv)
+            ref = oracle.apply_vote_deltas(ref, dg, dp, dv)
+            assert np.array_equal(e.read_votes(), ref)
+            out, cnt = e.vote_tally()
+            oc, w, l = oracle.vote_tally(ref)
+            assert np.array_equal(out, oc) and (cnt.n_won, cnt.n_lost) == (w, l)
+
+
+def test_timer_and_stream(gpu_engine_cls):
+    import torch
+
+    s = torch.cuda.Stream()
+    with gpu_engine_cls(1 << 16, 3) as e:
+        own = e.get_stream()
+        assert own != 0
+        e.set_stream(s.cuda_stream)
+        assert e.get_stream() == s.cuda_stream
+        e.timer_begin()
+        for _ in range(10):
+            e.step_async(SWEEP_COMMIT | SWEEP_NO_ADOPT)
+        ms = e.timer_end()
+        assert 0.0 < ms < 1000.0

@@ -59,6 +59,32 @@ def sweep_flags(cfg) -> int:
     return f
 
 
+def side_measure(cfg_id, rotate_bytes, steps, stream_ptr, dist):
+    """Short single-GPU measurement of another BASELINE config (rank 0, N=1)."""
+    from raftsql_amd import _lib, synth
+
+    cfg = CONFIGS[cfg_id]
+    rd, wr = bytes_per_decision(cfg)
+    nb = max(2, int(np.ceil(rotate_bytes / (cfg["G"] * (rd + wr)))))
+    engines, _ = build_batches(cfg, nb, 0, synth.SEED_BASE + cfg_id, stream_ptr)
+    flags = sweep_flags(cfg) | _lib.SWEEP_STREAM
+    for i in range(steps // 4):
+        engines[i % nb].step_async(flags)
+    wall, ev = timed_loop(engines, flags, steps, dist.World(), dist)
+    for e in engines:
+        e.close()
+    us = ev * 1e3 / steps
+    return {
+        "workload": cfg["name"],
+        "decisions_per_s": cfg["G"] * steps / wall,
+        "launch_us": us,
+        "GBps": (rd + wr) * cfg["G"] / (us * 1e-6) / 1e9,
+        "frac": (rd + wr) * cfg["G"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+        "bytes_per_decision": {"read": rd, "write": wr},
+        "batches_rotated": nb,
+    }
+
+
 def build_batches(cfg, n_batches, rank, seed_base, stream_ptr):
     from raftsql_amd import synth
     from raftsql_amd.engine import QuorumEngine
@@ -132,6 +158,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--rotate-bytes", type=float, default=1.5 * 2**30)
     ap.add_argument("--variant", choices=["reg", "lds"], default="reg")
+    ap.add_argument("--policy", choices=["stream", "cached", "auto"], default="stream",
+                    help="cache policy of the rotating loop: no batch stays cached between its sweeps, so stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the l3_resident / other-config side measurements")
     args = ap.parse_args()
@@ -154,6 +182,8 @@ def main():
     set_bytes = cfg["G"] * (rd + wr)
     n_batches = max(2, int(np.ceil(args.rotate_bytes / set_bytes)))
     flags = sweep_flags(cfg) | (_lib.SWEEP_LDS if args.variant == "lds" else 0)
+    base_flags = flags
+    flags |= {"stream": _lib.SWEEP_STREAM, "cached": _lib.SWEEP_CACHED, "auto": 0}[args.policy]
     engines, st0 = build_batches(cfg, n_batches, world.rank, synth.SEED_BASE + args.config, stream.cuda_stream)
 
     # correctness gate before any timing: tallies of batch 0 against numpy
@@ -195,6 +225,7 @@ def main():
             "batches_rotated": n_batches,
             "rotating_bytes_per_gpu": n_batches * set_bytes,
             "variant": args.variant,
+            "cache_policy": args.policy,
             "parallelism": f"groups sharded x{world.size}, no collective",
         },
         "roofline": {
@@ -224,9 +255,10 @@ def main():
 
     if world.rank == 0 and not args.no_extras:
         # cache-resident regime: one batch re-swept (fits the 256 MiB Infinity Cache)
+        cflags = base_flags | _lib.SWEEP_CACHED
         for _ in range(50):
-            engines[0].step_async(flags)
-        w1, e1 = timed_loop(engines[:1], flags, min(args.steps, 2000), dist.World(), dist)
+            engines[0].step_async(cflags)
+        w1, e1 = timed_loop(engines[:1], cflags, min(args.steps, 2000), dist.World(), dist)
         k1 = min(args.steps, 2000)
         out["l3_resident"] = {
             "decisions_per_s": cfg["G"] * k1 / w1,
@@ -240,6 +272,11 @@ def main():
         out["cpu_baseline"] = None
     for e in engines:
         e.close()
+    if world.rank == 0 and world.size == 1 and not args.no_extras:
+        out["other_configs"] = {
+            f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist)
+            for c in sorted(CONFIGS) if c != args.config
+        }
     dist.barrier(world)
     if world.rank == 0:
         print(json.dumps(out))

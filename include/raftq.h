@@ -59,6 +59,13 @@ extern "C" {
                                  sort instead of the in-register network */
 #define RAFTQ_SWEEP_CHANGED 0x20u /* also emit the changed-groups bitmap that
                                      raftq_collect_changed() compacts */
+/* cache policy of the sweep's loads/stores.  Default (neither bit): chosen by
+ * the handle's footprint -- state that fits the 256 MiB Infinity Cache is
+ * swept with normal (cached) accesses so the next sweep hits on-die, larger
+ * state is streamed non-temporally.  A caller that knows better (e.g. many
+ * handles swept round-robin, so none stays cached) forces one. */
+#define RAFTQ_SWEEP_STREAM 0x40u /* force non-temporal streaming accesses */
+#define RAFTQ_SWEEP_CACHED 0x80u /* force normal cached accesses */
 
 typedef struct raftq raftq_t;
 

@@ -20,6 +20,8 @@ SWEEP_VOTES = 0x04
 SWEEP_NO_ADOPT = 0x08
 SWEEP_LDS = 0x10
 SWEEP_CHANGED = 0x20
+SWEEP_STREAM = 0x40
+SWEEP_CACHED = 0x80
 
 MAX_PEERS = 9
 

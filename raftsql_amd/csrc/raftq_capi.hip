@@ -18,10 +18,10 @@
 #include "raftq_kernels.hpp"
 
 #ifndef RAFTQ_GPL
-#define RAFTQ_GPL 8
+#define RAFTQ_GPL 4 /* groups per lane; 4 measured best on MI355X (profiles/tune_r01.txt) */
 #endif
-#ifndef RAFTQ_NT
-#define RAFTQ_NT 0
+#ifndef RAFTQ_AUTO_STREAM_BYTES
+#define RAFTQ_AUTO_STREAM_BYTES (128ull << 20) /* footprint above which sweeps stream non-temporally */
 #endif
 #ifndef RAFTQ_LDS_GPL
 #define RAFTQ_LDS_GPL 4
@@ -32,7 +32,6 @@ using namespace raftqk;
 namespace {
 
 constexpr int kGPL = RAFTQ_GPL;
-constexpr bool kNT = RAFTQ_NT != 0;
 constexpr int kLdsGPL = RAFTQ_LDS_GPL;
 constexpr uint64_t kTile = (uint64_t)kBlock * kGPL;
 static_assert(kTileMax % (kBlock * RAFTQ_GPL) == 0, "ld granule must be a multiple of the tile");
@@ -92,9 +91,12 @@ int fail(raftq_t* h, int code, const std::string& msg) {
   } while (0)
 
 template <int N, bool COMMIT, bool GATED, bool VOTES>
-hipError_t launch_reg(const SweepArgs& a, hipStream_t s) {
+hipError_t launch_reg(const SweepArgs& a, bool stream_nt, hipStream_t s) {
   const dim3 grid((unsigned)(a.ld / kTile));
-  hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kNT, true>), grid, dim3(kBlock), 0, s, a);
+  if (stream_nt)
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, true, true>), grid, dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, false, true>), grid, dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
@@ -109,7 +111,7 @@ hipError_t launch_lds(const SweepArgs& a, hipStream_t s) {
 }
 
 template <int N>
-hipError_t launch_n(const SweepArgs& a, unsigned flags, hipStream_t s) {
+hipError_t launch_n(const SweepArgs& a, unsigned flags, bool nt, hipStream_t s) {
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool gated = flags & RAFTQ_SWEEP_GATED;
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
@@ -117,22 +119,22 @@ hipError_t launch_n(const SweepArgs& a, unsigned flags, hipStream_t s) {
     if (gated) return votes ? launch_lds<N, true, true>(a, s) : launch_lds<N, true, false>(a, s);
     return votes ? launch_lds<N, false, true>(a, s) : launch_lds<N, false, false>(a, s);
   }
-  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, s) : launch_reg<N, true, true, false>(a, s);
-  if (commit) return votes ? launch_reg<N, true, false, true>(a, s) : launch_reg<N, true, false, false>(a, s);
-  return launch_reg<N, false, false, true>(a, s);
+  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, nt, s) : launch_reg<N, true, true, false>(a, nt, s);
+  if (commit) return votes ? launch_reg<N, true, false, true>(a, nt, s) : launch_reg<N, true, false, false>(a, nt, s);
+  return launch_reg<N, false, false, true>(a, nt, s);
 }
 
-hipError_t launch_sweep(uint32_t N, const SweepArgs& a, unsigned flags, hipStream_t s) {
+hipError_t launch_sweep(uint32_t N, const SweepArgs& a, unsigned flags, bool nt, hipStream_t s) {
   switch (N) {
-    case 1: return launch_n<1>(a, flags, s);
-    case 2: return launch_n<2>(a, flags, s);
-    case 3: return launch_n<3>(a, flags, s);
-    case 4: return launch_n<4>(a, flags, s);
-    case 5: return launch_n<5>(a, flags, s);
-    case 6: return launch_n<6>(a, flags, s);
-    case 7: return launch_n<7>(a, flags, s);
-    case 8: return launch_n<8>(a, flags, s);
-    case 9: return launch_n<9>(a, flags, s);
+    case 1: return launch_n<1>(a, flags, nt, s);
+    case 2: return launch_n<2>(a, flags, nt, s);
+    case 3: return launch_n<3>(a, flags, nt, s);
+    case 4: return launch_n<4>(a, flags, nt, s);
+    case 5: return launch_n<5>(a, flags, nt, s);
+    case 6: return launch_n<6>(a, flags, nt, s);
+    case 7: return launch_n<7>(a, flags, nt, s);
+    case 8: return launch_n<8>(a, flags, nt, s);
+    case 9: return launch_n<9>(a, flags, nt, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -385,13 +387,15 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
 int raftq_step_async(raftq_t* h, unsigned flags) {
   if (int rc = use_device(h)) return rc;
   const unsigned known = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_VOTES | RAFTQ_SWEEP_NO_ADOPT |
-                         RAFTQ_SWEEP_LDS | RAFTQ_SWEEP_CHANGED;
+                         RAFTQ_SWEEP_LDS | RAFTQ_SWEEP_CHANGED | RAFTQ_SWEEP_STREAM | RAFTQ_SWEEP_CACHED;
   if (flags & ~known) return fail(h, RAFTQ_EINVAL, "raftq_step_async: unknown flag");
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
   if (!commit && !votes) return fail(h, RAFTQ_EINVAL, "raftq_step_async: nothing to sweep");
   if ((flags & RAFTQ_SWEEP_GATED) && !h->have_terms)
     return fail(h, RAFTQ_ESTATE, "raftq_step_async: gated sweep before raftq_load_terms");
+  if ((flags & RAFTQ_SWEEP_STREAM) && (flags & RAFTQ_SWEEP_CACHED))
+    return fail(h, RAFTQ_EINVAL, "raftq_step_async: RAFTQ_SWEEP_STREAM and RAFTQ_SWEEP_CACHED are exclusive");
   if ((flags & RAFTQ_SWEEP_CHANGED) && !commit)
     return fail(h, RAFTQ_EINVAL, "raftq_step_async: RAFTQ_SWEEP_CHANGED needs a commit sweep");
   SweepArgs a;
@@ -406,7 +410,11 @@ int raftq_step_async(raftq_t* h, unsigned flags) {
   a.ld = h->ld;
   const bool lds = (flags & RAFTQ_SWEEP_LDS) && commit;
   const int gpl = lds ? kLdsGPL : kGPL;
-  HIPCHK(h, launch_sweep(h->N, a, flags, h->stream));
+  const uint64_t footprint = h->ld * (8ull * h->N + 24 + h->N + 1);
+  const bool nt = (flags & RAFTQ_SWEEP_STREAM) ? true
+                  : (flags & RAFTQ_SWEEP_CACHED) ? false
+                                                 : footprint >= RAFTQ_AUTO_STREAM_BYTES;
+  HIPCHK(h, launch_sweep(h->N, a, flags, nt, h->stream));
   h->n_partials = h->ld / ((uint64_t)kBlock * gpl) * kWaves;
   h->last_flags = flags;
   h->last_gpl = gpl;

@@ -67,21 +67,33 @@ __global__ __launch_bounds__(256) void copy_ref_kernel(const u64x2* __restrict__
 }
 
 struct Set {
+  uint8_t* arena;
+  size_t arena_bytes;
   uint64_t *match, *committed, *committed_out, *first_idx, *changed;
-  uint8_t *votes, *outcome;
+  uint8_t *votes, *outcome, *copy_out;
   uint4* partials;
 };
 
+// one arena per set: match | committed | committed_out | first_idx | votes |
+// outcome | changed | partials | copy_out (scratch for the copy reference)
 static Set make_set(int N, uint64_t ld, uint64_t seed) {
   Set s;
-  CK(hipMalloc(&s.match, (size_t)N * ld * 8));
-  CK(hipMalloc(&s.committed, ld * 8));
-  CK(hipMalloc(&s.committed_out, ld * 8));
-  CK(hipMalloc(&s.first_idx, ld * 8));
-  CK(hipMalloc(&s.changed, ld / 8));
-  CK(hipMalloc(&s.votes, (size_t)N * ld));
-  CK(hipMalloc(&s.outcome, ld));
-  CK(hipMalloc(&s.partials, ld / 512 * 4 * sizeof(uint4)));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_match = carve((size_t)N * ld * 8), o_c = carve(ld * 8), o_co = carve(ld * 8), o_f = carve(ld * 8);
+  const size_t o_v = carve((size_t)N * ld), o_o = carve(ld), o_ch = carve(ld / 8);
+  const size_t o_p = carve(ld / 512 * 4 * sizeof(uint4)), o_copy = carve(ld * 16);
+  s.arena_bytes = off;
+  CK(hipMalloc(&s.arena, off));
+  s.match = (uint64_t*)(s.arena + o_match);
+  s.committed = (uint64_t*)(s.arena + o_c);
+  s.committed_out = (uint64_t*)(s.arena + o_co);
+  s.first_idx = (uint64_t*)(s.arena + o_f);
+  s.votes = s.arena + o_v;
+  s.outcome = s.arena + o_o;
+  s.changed = (uint64_t*)(s.arena + o_ch);
+  s.partials = (uint4*)(s.arena + o_p);
+  s.copy_out = s.arena + o_copy;
   const uint64_t base = 1ull << 30;
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, s.match, (uint64_t)N * ld, seed, 2047ull, base);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, s.committed, ld, seed + 1, 1023ull, base + 512);
@@ -91,10 +103,7 @@ static Set make_set(int N, uint64_t ld, uint64_t seed) {
   return s;
 }
 
-static void free_set(Set& s) {
-  hipFree(s.match); hipFree(s.committed); hipFree(s.committed_out); hipFree(s.first_idx);
-  hipFree(s.changed); hipFree(s.votes); hipFree(s.outcome); hipFree(s.partials);
-}
+static void free_set(Set& s) { (void)hipFree(s.arena); }
 
 static SweepArgs args_of(const Set& s, uint64_t ld) {
   SweepArgs a;
@@ -192,14 +201,14 @@ int main(int argc, char** argv) {
         for (int rot = 0; rot < 2; ++rot) {
           for (int w = 0; w < 5; ++w) {
             const Set& s = sets[rot ? w % sets.size() : 0];
-            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
-            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.arena, n_in, (u64x2*)s.copy_out, n_out);
+            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.arena, n_in, (u64x2*)s.copy_out, n_out);
           }
           CK(hipEventRecord(e0, st));
           for (int r = 0; r < reps; ++r) {
             const Set& s = sets[rot ? r % sets.size() : 0];
-            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
-            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.match, n_in, (u64x2*)s.committed_out, n_out);
+            if (nt) hipLaunchKernelGGL(copy_ref_kernel<true>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.arena, n_in, (u64x2*)s.copy_out, n_out);
+            else hipLaunchKernelGGL(copy_ref_kernel<false>, dim3(2048), dim3(256), 0, st, (const u64x2*)s.arena, n_in, (u64x2*)s.copy_out, n_out);
           }
           CK(hipEventRecord(e1, st));
           CK(hipEventSynchronize(e1));

@@ -15,11 +15,11 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
-                   SWEEP_VOTES, Advance, Counts, Delta, RaftqError, VoteDelta)
+from ._lib import (SWEEP_CACHED, SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
+                   SWEEP_STREAM, SWEEP_VOTES, Advance, Counts, Delta, RaftqError, VoteDelta)
 
 __all__ = ["QuorumEngine", "SweepCounts", "device_count", "RaftqError", "SWEEP_COMMIT", "SWEEP_GATED",
-           "SWEEP_VOTES", "SWEEP_NO_ADOPT", "SWEEP_LDS", "SWEEP_CHANGED"]
+           "SWEEP_VOTES", "SWEEP_NO_ADOPT", "SWEEP_LDS", "SWEEP_CHANGED", "SWEEP_STREAM", "SWEEP_CACHED"]
 
 
 @dataclass

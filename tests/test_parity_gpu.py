@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 from raftsql_amd import synth
-from raftsql_amd._lib import (SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT, SWEEP_VOTES)
+from raftsql_amd._lib import (SWEEP_CACHED, SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
+                              SWEEP_STREAM, SWEEP_VOTES)
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +66,13 @@ def _check_all_modes(E, oracle, st, variant_flag=0):
 @pytest.mark.parametrize("n", range(1, 10))
 def test_parity_every_peer_count(gpu_engine_cls, oracle, n):
     _check_all_modes(gpu_engine_cls, oracle, _state(5000, n, 1000 + n))
+
+
+@pytest.mark.parametrize("n", range(1, 10))
+def test_parity_streaming_policy(gpu_engine_cls, oracle, n):
+    """the non-temporal instantiation of every kernel (auto picks it only for big state)"""
+    _check_all_modes(gpu_engine_cls, oracle, _state(5000, n, 1500 + n), SWEEP_STREAM)
+    _check_all_modes(gpu_engine_cls, oracle, _state(3000, n, 1600 + n), SWEEP_CACHED)
 
 
 @pytest.mark.parametrize("n", range(1, 10))
@@ -164,7 +172,7 @@ def test_full_size_configs(gpu_engine_cls, oracle, name, G, n, seed):
     oc, w, l = oracle.vote_tally(st.votes)
     with gpu_engine_cls(G, n) as e:
         e.load_state(st)
-        for variant in (0, SWEEP_LDS):
+        for variant in (0, SWEEP_STREAM, SWEEP_CACHED, SWEEP_LDS):
             c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT | variant)
             got = e.read_committed()
             assert np.array_equal(got, ung) and np.array_equal(e.read_outcome(), oc)
@@ -206,6 +214,9 @@ def test_error_behaviour(gpu_engine_cls):
         assert ei.value.code == -1
         with pytest.raises(RaftqError) as ei:
             e.step_async(0x4000)
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            e.step_async(SWEEP_COMMIT | SWEEP_STREAM | SWEEP_CACHED)
         assert ei.value.code == -1
         with pytest.raises(RaftqError) as ei:
             e.apply_deltas([1000], [0], [5])  # group out of range

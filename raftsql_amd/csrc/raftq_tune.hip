@@ -179,10 +179,13 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
 
+  const char* only = getenv("RAFTQ_TUNE_ONLY_N");
+  const int only_n = only ? atoi(only) : 0;
   int curN = -1;
   uint64_t curG = 0;
   std::vector<Set> sets;
   for (const Variant& v : kVariants) {
+    if (only_n && v.N != only_n) continue;
     const uint64_t G = v.N == 7 ? 2 * G1 : G1;
     const uint64_t ld = (G + 2047) / 2048 * 2048;
     if (v.N != curN || G != curG) {

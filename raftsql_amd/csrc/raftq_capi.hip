@@ -34,6 +34,7 @@ namespace {
 constexpr int kGPL = RAFTQ_GPL;
 constexpr int kLdsGPL = RAFTQ_LDS_GPL;
 constexpr uint64_t kTile = (uint64_t)kBlock * kGPL;
+constexpr uint64_t kRowStagger = 288;  // groups; must stay a multiple of 8 (vote rows are read 8 B at a time)
 static_assert(kTileMax % (kBlock * RAFTQ_GPL) == 0, "ld granule must be a multiple of the tile");
 static_assert(kTileMax % (kBlock * RAFTQ_LDS_GPL) == 0, "ld granule must be a multiple of the LDS tile");
 
@@ -43,7 +44,7 @@ thread_local std::string g_err;
 
 struct raftq {
   int device = 0;
-  uint64_t G = 0, ld = 0;
+  uint64_t G = 0, gpad = 0, ld = 0;  // groups, groups padded to the tile granule, row stride
   uint32_t N = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -91,50 +92,50 @@ int fail(raftq_t* h, int code, const std::string& msg) {
   } while (0)
 
 template <int N, bool COMMIT, bool GATED, bool VOTES>
-hipError_t launch_reg(const SweepArgs& a, bool stream_nt, hipStream_t s) {
-  const dim3 grid((unsigned)(a.ld / kTile));
+hipError_t launch_reg(const SweepArgs& a, uint64_t gpad, bool stream_nt, hipStream_t s) {
+  const dim3 grid((unsigned)(gpad / kTile));
   if (stream_nt)
-    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, true, true>), grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kLdNT | kStNT, true>), grid, dim3(kBlock), 0, s, a);
   else
-    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, false, true>), grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, 0, true>), grid, dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
 template <int N, bool GATED, bool VOTES>
-hipError_t launch_lds(const SweepArgs& a, hipStream_t s) {
+hipError_t launch_lds(const SweepArgs& a, uint64_t gpad, hipStream_t s) {
   constexpr uint64_t tile = (uint64_t)kBlock * kLdsGPL;
   constexpr int rows = N + 1 + (GATED ? 1 : 0);
   constexpr size_t lds = (size_t)kWaves * (kLdsGPL / 2) * rows * 1024;
-  const dim3 grid((unsigned)(a.ld / tile));
+  const dim3 grid((unsigned)(gpad / tile));
   hipLaunchKernelGGL((sweep_lds_kernel<N, kLdsGPL, GATED, VOTES, true>), grid, dim3(kBlock), lds, s, a);
   return hipGetLastError();
 }
 
 template <int N>
-hipError_t launch_n(const SweepArgs& a, unsigned flags, bool nt, hipStream_t s) {
+hipError_t launch_n(const SweepArgs& a, uint64_t gpad, unsigned flags, bool nt, hipStream_t s) {
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool gated = flags & RAFTQ_SWEEP_GATED;
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
   if ((flags & RAFTQ_SWEEP_LDS) && commit) {
-    if (gated) return votes ? launch_lds<N, true, true>(a, s) : launch_lds<N, true, false>(a, s);
-    return votes ? launch_lds<N, false, true>(a, s) : launch_lds<N, false, false>(a, s);
+    if (gated) return votes ? launch_lds<N, true, true>(a, gpad, s) : launch_lds<N, true, false>(a, gpad, s);
+    return votes ? launch_lds<N, false, true>(a, gpad, s) : launch_lds<N, false, false>(a, gpad, s);
   }
-  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, nt, s) : launch_reg<N, true, true, false>(a, nt, s);
-  if (commit) return votes ? launch_reg<N, true, false, true>(a, nt, s) : launch_reg<N, true, false, false>(a, nt, s);
-  return launch_reg<N, false, false, true>(a, nt, s);
+  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, gpad, nt, s) : launch_reg<N, true, true, false>(a, gpad, nt, s);
+  if (commit) return votes ? launch_reg<N, true, false, true>(a, gpad, nt, s) : launch_reg<N, true, false, false>(a, gpad, nt, s);
+  return launch_reg<N, false, false, true>(a, gpad, nt, s);
 }
 
-hipError_t launch_sweep(uint32_t N, const SweepArgs& a, unsigned flags, bool nt, hipStream_t s) {
+hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned flags, bool nt, hipStream_t s) {
   switch (N) {
-    case 1: return launch_n<1>(a, flags, nt, s);
-    case 2: return launch_n<2>(a, flags, nt, s);
-    case 3: return launch_n<3>(a, flags, nt, s);
-    case 4: return launch_n<4>(a, flags, nt, s);
-    case 5: return launch_n<5>(a, flags, nt, s);
-    case 6: return launch_n<6>(a, flags, nt, s);
-    case 7: return launch_n<7>(a, flags, nt, s);
-    case 8: return launch_n<8>(a, flags, nt, s);
-    case 9: return launch_n<9>(a, flags, nt, s);
+    case 1: return launch_n<1>(a, gpad, flags, nt, s);
+    case 2: return launch_n<2>(a, gpad, flags, nt, s);
+    case 3: return launch_n<3>(a, gpad, flags, nt, s);
+    case 4: return launch_n<4>(a, gpad, flags, nt, s);
+    case 5: return launch_n<5>(a, gpad, flags, nt, s);
+    case 6: return launch_n<6>(a, gpad, flags, nt, s);
+    case 7: return launch_n<7>(a, gpad, flags, nt, s);
+    case 8: return launch_n<8>(a, gpad, flags, nt, s);
+    case 9: return launch_n<9>(a, gpad, flags, nt, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -199,10 +200,14 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
   h->device = device;
   h->G = n_groups;
   h->N = n_peers;
-  h->ld = (n_groups + kTileMax - 1) / kTileMax * kTileMax;
+  h->gpad = (n_groups + kTileMax - 1) / kTileMax * kTileMax;
+  // Row stride = padded groups + a stagger.  Rows exactly 2^k bytes apart put the N+1 row loads of
+  // a wave on the same HBM channel at the same instant; 288 groups (2304 B of u64, 288 B of u8 --
+  // not a multiple of 16 KiB) measured -2.3 % sweep time on MI355X (profiles/r01/tune_stagger.txt).
+  h->ld = h->gpad + kRowStagger;
   const uint64_t ld = h->ld;
   // the finest tile any variant uses bounds the number of per-wave partials
-  h->max_partials = ld / (kBlock * 2) * kWaves;
+  h->max_partials = h->gpad / (kBlock * 2) * kWaves;
   int rc = RAFTQ_OK;
   auto alloc = [&](void** p, size_t bytes) -> int {
     HIPCHK(h, hipMalloc(p, bytes));
@@ -220,7 +225,7 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     if ((rc = alloc((void**)&h->first_idx, ld * 8))) break;
     if ((rc = alloc((void**)&h->votes, (size_t)n_peers * ld))) break;
     if ((rc = alloc((void**)&h->outcome, ld))) break;
-    if ((rc = alloc((void**)&h->changed_bits, ld / 8))) break;
+    if ((rc = alloc((void**)&h->changed_bits, h->gpad / 8))) break;
     if ((rc = alloc((void**)&h->partials, h->max_partials * sizeof(uint4)))) break;
     if ((rc = alloc((void**)&h->offsets, (h->max_partials + 1) * 8))) break;
     e = hipHostMalloc((void**)&h->h_partials, h->max_partials * sizeof(uint4), hipHostMallocDefault);
@@ -414,8 +419,8 @@ int raftq_step_async(raftq_t* h, unsigned flags) {
   const bool nt = (flags & RAFTQ_SWEEP_STREAM) ? true
                   : (flags & RAFTQ_SWEEP_CACHED) ? false
                                                  : footprint >= RAFTQ_AUTO_STREAM_BYTES;
-  HIPCHK(h, launch_sweep(h->N, a, flags, nt, h->stream));
-  h->n_partials = h->ld / ((uint64_t)kBlock * gpl) * kWaves;
+  HIPCHK(h, launch_sweep(h->N, a, h->gpad, flags, nt, h->stream));
+  h->n_partials = h->gpad / ((uint64_t)kBlock * gpl) * kWaves;
   h->last_flags = flags;
   h->last_gpl = gpl;
   if (commit) {
@@ -526,7 +531,7 @@ int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64
     h->adv_cap = want;
   }
   const int gpl = h->last_gpl;
-  const dim3 grid((unsigned)(h->ld / ((uint64_t)kBlock * gpl)));
+  const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
   if (gpl == kGPL)
     hipLaunchKernelGGL((compact_changed_kernel<kGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
                        h->last_old, h->last_new, h->adv, take);

@@ -143,9 +143,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 //
 // NT: stream the inputs/outputs with the non-temporal policy (they are read
 // once per sweep).  Chosen per launch by the host; see DESIGN.md for the A/B.
-template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, bool NT, bool BITS>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
-  constexpr int kTile = kBlock * GPL;
+//
+// POLICY bits: kLdNT (non-temporal loads), kStNT (non-temporal stores); kNoStore
+// is a measurement-only ablation (tuner) that drops the output stores.
+constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
+
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
+  constexpr bool NT = (POLICY & kLdNT) != 0;
+  constexpr bool STNT = (POLICY & kStNT) != 0;
+  constexpr bool NOSTORE = (POLICY & kNoStore) != 0;
+  constexpr int kTile = BLOCK * GPL;
+  constexpr int kWavesB = BLOCK / 64;
   constexpr int kRounds = GPL / 2;
   const uint32_t tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
@@ -224,7 +233,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
         }
       }
       u64x2* dst = reinterpret_cast<u64x2*>(a.committed_out + g);
-      if (NT) st_stream(dst, o); else *dst = o;
+      if constexpr (NOSTORE) {
+        asm volatile("" ::"v"(o.x), "v"(o.y));
+      } else {
+        if (STNT) st_stream(dst, o); else *dst = o;
+      }
     }
   }
 
@@ -244,7 +257,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
       const uint64_t lost = ((rejected + bias) & k80) >> 7;  // exclusive with won (g+r <= N < 2q)
       const uint64_t out = won | ((lost & ~won) << 1);
       uint64_t* dst = reinterpret_cast<uint64_t*>(a.outcome + g);
-      if (NT) st_stream(dst, out); else *dst = out;
+      if constexpr (NOSTORE) {
+        asm volatile("" ::"v"(out));
+      } else {
+        if (STNT) st_stream(dst, out); else *dst = out;
+      }
       won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
     }
   }
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     r.y = wl & 0xffffu;
     r.z = wl >> 16;
     r.w = 0;
-    a.partials[(uint64_t)blockIdx.x * kWaves + (tid >> 6)] = r;
+    a.partials[(uint64_t)blockIdx.x * kWavesB + (tid >> 6)] = r;
   }
 }
 

@@ -113,47 +113,50 @@ static SweepArgs args_of(const Set& s, uint64_t ld) {
   return a;
 }
 
-typedef void (*launch_fn)(const SweepArgs&, hipStream_t);
+typedef void (*launch_fn)(const SweepArgs&, uint64_t G, hipStream_t);
 
-template <int N, int GPL, bool GATED, bool VOTES, bool NT>
-static void launch_reg(const SweepArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((sweep_kernel<N, GPL, true, GATED, VOTES, NT, true>), dim3((unsigned)(a.ld / (256 * GPL))),
-                     dim3(256), 0, st, a);
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY, int BLOCK>
+static void launch_reg(const SweepArgs& a, uint64_t G, hipStream_t st) {
+  hipLaunchKernelGGL((sweep_kernel<N, GPL, true, GATED, VOTES, POLICY, true, BLOCK>),
+                     dim3((unsigned)(G / (BLOCK * GPL))), dim3(BLOCK), 0, st, a);
 }
 template <int N, int GPL, bool GATED, bool VOTES>
-static void launch_lds(const SweepArgs& a, hipStream_t st) {
+static void launch_lds(const SweepArgs& a, uint64_t G, hipStream_t st) {
   constexpr size_t lds = (size_t)4 * (GPL / 2) * (N + 1 + (GATED ? 1 : 0)) * 1024;
-  hipLaunchKernelGGL((sweep_lds_kernel<N, GPL, GATED, VOTES, true>), dim3((unsigned)(a.ld / (256 * GPL))), dim3(256),
+  hipLaunchKernelGGL((sweep_lds_kernel<N, GPL, GATED, VOTES, true>), dim3((unsigned)(G / (256 * GPL))), dim3(256),
                      lds, st, a);
 }
 
 struct Variant {
   const char* name;
-  int N, GPL, NT, gated, votes;
+  int N, GPL, policy, block, gated, votes;
   launch_fn fn;
 };
 
-#define REG(N, GPL, G_, V_, NT) \
-  { "reg", N, GPL, NT, G_, V_, launch_reg<N, GPL, G_, V_, NT> }
+#define REG(N, GPL, G_, V_, POL, BLK) \
+  { "reg", N, GPL, POL, BLK, G_, V_, launch_reg<N, GPL, G_, V_, POL, BLK> }
 #define LDS(N, GPL, G_, V_) \
-  { "lds", N, GPL, 0, G_, V_, launch_lds<N, GPL, G_, V_> }
+  { "lds", N, GPL, 0, 256, G_, V_, launch_lds<N, GPL, G_, V_> }
 
+// policy: 1 = NT loads, 2 = NT stores, 4 = ablation: no stores
 static const Variant kVariants[] = {
-    // config 3: 1M x 5 commit + votes (the headline)
-    REG(5, 2, false, true, false), REG(5, 4, false, true, false), REG(5, 8, false, true, false),
-    REG(5, 2, false, true, true),  REG(5, 4, false, true, true),  REG(5, 8, false, true, true),
-    LDS(5, 2, false, true),        LDS(5, 4, false, true),        LDS(5, 8, false, true),
+    // config 3: 1M x 5 commit + votes (the headline): policy x tile x block
+    REG(5, 4, false, true, 0, 256), REG(5, 4, false, true, 1, 256), REG(5, 4, false, true, 2, 256),
+    REG(5, 4, false, true, 3, 256), REG(5, 2, false, true, 3, 256), REG(5, 8, false, true, 3, 256),
+    REG(5, 4, false, true, 3, 128), REG(5, 4, false, true, 3, 512), REG(5, 4, false, true, 3, 1024),
+    REG(5, 2, false, true, 3, 512), REG(5, 2, false, true, 3, 1024),
+    REG(5, 4, false, true, 7, 256), REG(5, 4, false, true, 4, 256),  // no-store ablations
+    LDS(5, 4, false, true),
     // config 2: 1M x 3 commit only
-    REG(3, 2, false, false, false), REG(3, 4, false, false, false), REG(3, 8, false, false, false),
-    REG(3, 4, false, false, true),  REG(3, 8, false, false, true),  LDS(3, 4, false, false),
+    REG(3, 4, false, false, 0, 256), REG(3, 4, false, false, 3, 256), REG(3, 8, false, false, 3, 256),
+    REG(3, 4, false, false, 3, 512), LDS(3, 4, false, false),
     // config 4 shard: 2M x 7 commit + votes
-    REG(7, 2, false, true, false), REG(7, 4, false, true, false), REG(7, 8, false, true, false),
-    REG(7, 4, false, true, true),  LDS(7, 2, false, true),        LDS(7, 4, false, true),
+    REG(7, 4, false, true, 0, 256), REG(7, 4, false, true, 3, 256), REG(7, 2, false, true, 3, 256),
+    REG(7, 4, false, true, 3, 512), LDS(7, 4, false, true),
     // config 5: 1M x 5 gated
-    REG(5, 4, true, false, false), REG(5, 8, true, false, false), REG(5, 8, true, false, true),
-    LDS(5, 4, true, false),
+    REG(5, 4, true, false, 3, 256), LDS(5, 4, true, false),
     // N = 9 upper bound of the network
-    REG(9, 2, false, true, false), REG(9, 4, false, true, false), LDS(9, 2, false, true),
+    REG(9, 4, false, true, 3, 256), REG(9, 2, false, true, 3, 256), LDS(9, 2, false, true),
 };
 
 static double bytes_per_group(const Variant& v) {
@@ -224,10 +227,10 @@ int main(int argc, char** argv) {
       }
     }
     for (int rot = 0; rot < 2; ++rot) {
-      for (int w = 0; w < 10; ++w) v.fn(args_of(sets[rot ? w % sets.size() : 0], ld), st);
+      for (int w = 0; w < 10; ++w) v.fn(args_of(sets[rot ? w % sets.size() : 0], ld), G, st);
       CK(hipGetLastError());
       CK(hipEventRecord(e0, st));
-      for (int r = 0; r < reps; ++r) v.fn(args_of(sets[rot ? r % sets.size() : 0], ld), st);
+      for (int r = 0; r < reps; ++r) v.fn(args_of(sets[rot ? r % sets.size() : 0], ld), G, st);
       CK(hipEventRecord(e1, st));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());
@@ -235,13 +238,94 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = 1e3 * ms / reps;
       const double bpg = bytes_per_group(v);
-      printf("{\"kernel\":\"%s\",\"N\":%d,\"GPL\":%d,\"NT\":%d,\"gated\":%d,\"votes\":%d,\"G\":%llu,\"rotate\":%d,\"K\":%zu,"
+      printf("{\"kernel\":\"%s\",\"N\":%d,\"GPL\":%d,\"policy\":%d,\"block\":%d,\"gated\":%d,\"votes\":%d,\"G\":%llu,\"rotate\":%d,\"K\":%zu,"
              "\"us\":%.3f,\"GBps\":%.1f,\"Gdec_per_s\":%.2f}\n",
-             v.name, v.N, v.GPL, v.NT, v.gated, v.votes, (unsigned long long)G, rot, sets.size(), us,
+             v.name, v.N, v.GPL, v.policy, v.block, v.gated, v.votes, (unsigned long long)G, rot, sets.size(), us,
              G * bpg / us / 1e3, G / us / 1e3);
       fflush(stdout);
     }
   }
   for (auto& s : sets) free_set(s);
+  sets.clear();
+
+  // ---- row-stride stagger: rows exactly 2^k bytes apart put a wave's N+1 row loads on the same
+  // HBM channel at the same time; pad the row stride by `pad` groups (u64 rows: 8*pad B, vote rows: pad B)
+  if (!only_n || only_n == 5) {
+    const uint64_t G = 1ull << 20;
+    const uint64_t pads[] = {0, 32, 64, 160, 288, 544, 2048, 2080, 6144, 10240 + 32, 34816};
+    for (uint64_t pad : pads) {
+      const uint64_t ld = G + pad;
+      const int K = 26;
+      for (int k = 0; k < K; ++k) sets.push_back(make_set(5, ld, 555 + k));
+      CK(hipDeviceSynchronize());
+      for (int rep = 0; rep < 2; ++rep) {
+        for (int w = 0; w < 10; ++w) launch_reg<5, 4, false, true, 3, 256>(args_of(sets[w % sets.size()], ld), G, st);
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch_reg<5, 4, false, true, 3, 256>(args_of(sets[r % sets.size()], ld), G, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / reps;
+        printf("{\"kernel\":\"stagger\",\"pad_groups\":%llu,\"rep\":%d,\"us\":%.3f,\"GBps\":%.1f}\n",
+               (unsigned long long)pad, rep, us, G * 62.0 / us / 1e3);
+      }
+      fflush(stdout);
+      for (auto& s : sets) free_set(s);
+      sets.clear();
+    }
+  }
+
+  // ---- G-curve: fixed per-launch overhead vs per-byte slope (N=5, commit+votes, NT, GPL=4) ----
+  if (!only_n || only_n == 5) {
+    for (int lg = 18; lg <= 24; ++lg) {
+      const uint64_t G = 1ull << lg, ld = G;
+      const double set_bytes = ld * (8.0 * 5 + 24 + 5 + 1 + 16);
+      const int K = (int)(2.0 * 1024 * 1024 * 1024 / set_bytes) + 2;
+      for (int k = 0; k < K; ++k) sets.push_back(make_set(5, ld, 777 + k));
+      CK(hipDeviceSynchronize());
+      const int r2 = lg >= 22 ? reps / 4 + 1 : reps;
+      for (int w = 0; w < 10; ++w) launch_reg<5, 4, false, true, 3, 256>(args_of(sets[w % sets.size()], ld), G, st);
+      CK(hipEventRecord(e0, st));
+      for (int r = 0; r < r2; ++r) launch_reg<5, 4, false, true, 3, 256>(args_of(sets[r % sets.size()], ld), G, st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = 1e3 * ms / r2;
+      printf("{\"kernel\":\"gcurve\",\"N\":5,\"G\":%llu,\"K\":%zu,\"us\":%.3f,\"GBps\":%.1f,\"Gdec_per_s\":%.2f}\n",
+             (unsigned long long)G, sets.size(), us, G * 62.0 / us / 1e3, G / us / 1e3);
+      fflush(stdout);
+      if (lg == 20) {
+        // independent batches on 2 and 4 streams: lets one launch's drain overlap the next one's ramp
+        for (int ns = 2; ns <= 4; ns += 2) {
+          hipStream_t ss[4];
+          for (int i = 0; i < ns; ++i) CK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+          CK(hipDeviceSynchronize());
+          hipEvent_t a0, a1;
+          CK(hipEventCreate(&a0));
+          CK(hipEventCreate(&a1));
+          CK(hipEventRecord(a0, ss[0]));
+          for (int i = 1; i < ns; ++i) CK(hipStreamWaitEvent(ss[i], a0, 0));
+          for (int r = 0; r < reps; ++r)
+            launch_reg<5, 4, false, true, 3, 256>(args_of(sets[r % sets.size()], ld), G, ss[r % ns]);
+          for (int i = 1; i < ns; ++i) {
+            hipEvent_t j;
+            CK(hipEventCreate(&j));
+            CK(hipEventRecord(j, ss[i]));
+            CK(hipStreamWaitEvent(ss[0], j, 0));
+          }
+          CK(hipEventRecord(a1, ss[0]));
+          CK(hipEventSynchronize(a1));
+          CK(hipEventElapsedTime(&ms, a0, a1));
+          const double us2 = 1e3 * ms / reps;
+          printf("{\"kernel\":\"multistream\",\"streams\":%d,\"N\":5,\"G\":%llu,\"us_per_sweep\":%.3f,\"GBps\":%.1f}\n", ns,
+                 (unsigned long long)G, us2, G * 62.0 / us2 / 1e3);
+        }
+      }
+      for (auto& s : sets) free_set(s);
+      sets.clear();
+    }
+  }
   return 0;
 }

@@ -104,6 +104,65 @@ def build_batches(cfg, n_batches, rank, seed_base, stream_ptr):
     return engines, first_state
 
 
+def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
+    """SURVEY 8f-1 measured end to end through raftq_cycle (rank 0, N=1): per turn, D MsgAppResp
+    deltas cross PCIe, are scattered into resident state, all G groups are swept, and the
+    compacted list of advanced groups comes back.  Wall time of the call, one sync per turn."""
+    from raftsql_amd import _lib, synth
+    from raftsql_amd.engine import QuorumEngine
+
+    G, N = cfg["G"], cfg["N"]
+    q = synth.quorum(N)
+    st = synth.make_groups(G, N, seed=synth.SEED_BASE + 77)
+    e = QuorumEngine(G, N, device=device)
+    e.load_state(st)
+    e.sweep(_lib.SWEEP_COMMIT)
+    base = e.read_committed()
+    rng = np.random.default_rng(5)
+    n_groups = deltas_per_cycle // q
+    packs = []
+    for v in range(4):  # four different group subsets, q acks each (a quorum -> the group advances)
+        g = rng.choice(G, n_groups, replace=False).astype(np.uint64)
+        gg = np.repeat(g, q)
+        pp = np.tile(np.arange(q, dtype=np.uint32), n_groups)
+        packs.append((gg, e.pack_deltas(gg, pp, base[gg.astype(np.int64)])))
+    flags = _lib.SWEEP_COMMIT
+    nd = n_groups * q
+    staged, _ = e.stage(nd, 0)  # pinned, device-visible: the message handlers' batch buffer
+    t_total, adv_total, t_copy = 0.0, 0, 0.0
+    for c in range(cycles + 10):
+        gg, pk = packs[c % 4]
+        # producer side (not timed): the rafthttp handlers writing this turn's acks into the batch
+        staged[:] = pk
+        staged["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
+        t0 = time.perf_counter()
+        total = e.cycle_inplace(flags, staged, None, cap=n_groups)
+        adv = e.last_advances()
+        dt = time.perf_counter() - t0
+        if c >= 10:
+            t_total += dt
+            adv_total += total
+            assert len(adv) == total
+    # the copying form of the same call (caller-owned pageable buffers in and out), for comparison
+    out = np.empty(n_groups, dtype=e._ADV_DT)
+    for c in range(cycles + 10, 2 * cycles + 20):
+        gg, pk = packs[c % 4]
+        pk["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
+        t0 = time.perf_counter()
+        e.cycle(flags, pk, None, cap=n_groups, out=out, want_counts=False)
+        if c >= cycles + 20:
+            t_copy += time.perf_counter() - t0
+    e.close()
+    return {
+        "what": "raftq_cycle: PCIe-in deltas -> scatter -> full sweep of G groups -> compacted advance list out "
+                "(zero-copy staging; wall time of the call incl. its one sync)",
+        "groups": G, "peers": N, "deltas_per_cycle": nd, "advanced_per_cycle": adv_total / cycles,
+        "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
+        "decisions_per_s": G * cycles / t_total,
+        "us_per_cycle_copying_form": t_copy / cycles * 1e6,
+    }
+
+
 def timed_loop(engines, flags, steps, world, dist):
     """Barrier + sync, K steps, barrier + sync.  -> (wall_s, event_ms)."""
     import torch
@@ -273,6 +332,7 @@ def main():
     for e in engines:
         e.close()
     if world.rank == 0 and world.size == 1 and not args.no_extras:
+        out["pipeline"] = pipeline_measure(cfg, world.local_rank)
         out["other_configs"] = {
             f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist)
             for c in sorted(CONFIGS) if c != args.config

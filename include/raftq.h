@@ -156,6 +156,28 @@ int raftq_read_votes(raftq_t* h, uint8_t* votes_out /*[N][G]*/);
  * in ascending group order; returns the count in *n (<= cap entries stored). */
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n);
 
+/* ---- one batching iteration ----------------------------
+ * What the single batching goroutine does per turn, fused into one call with
+ * ONE host/device sync: scatter the MsgAppResp / MsgVoteResp deltas, sweep all
+ * groups with `flags`, and return the compacted list of advanced groups (the
+ * batched Ready.HardState.Commit).  Any of the arrays may be NULL with length 0;
+ * `n_advanced` receives the full count even when it exceeds `cap`. */
+int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas,
+                const raftq_vote_delta_t* vote_deltas, uint64_t n_vote_deltas, unsigned flags,
+                raftq_advance_t* advances_out, uint64_t cap, uint64_t* n_advanced,
+                raftq_counts_t* counts);
+
+/* zero-copy variants: raftq_stage returns pinned, device-visible host buffers
+ * with room for the given counts; fill them and pass the SAME pointers to
+ * raftq_cycle and no staging copy is made.  They stay valid until the next
+ * raftq_stage / raftq_apply_* / raftq_destroy on the handle.  With
+ * advances_out == NULL and cap > 0, raftq_cycle leaves the advance list in
+ * pinned memory; raftq_last_advances returns it (valid until the next
+ * raftq_cycle / raftq_collect_changed). */
+int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta_t** deltas,
+                raftq_vote_delta_t** vote_deltas);
+int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed);
+
 /* ---- measurement hooks (bench harness) --------------------------------- */
 /* HIP events recorded on the handle's own stream, so the elapsed time covers
  * exactly the kernels enqueued between begin and end. */

@@ -69,6 +69,10 @@ _SIGS = [
     ("raftq_read_match", C.c_int, [_H, C.c_void_p]),
     ("raftq_read_votes", C.c_int, [_H, C.c_void_p]),
     ("raftq_collect_changed", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_cycle", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
+                              C.POINTER(C.c_uint64), C.POINTER(Counts)]),
+    ("raftq_stage", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("raftq_last_advances", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_timer_begin", C.c_int, [_H]),
     ("raftq_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
 ]

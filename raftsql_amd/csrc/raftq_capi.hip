@@ -61,10 +61,17 @@ struct raftq {
   uint64_t max_partials = 0;
   uint64_t* offsets = nullptr;  // [max_partials + 1]; last = total
   uint64_t* h_total = nullptr;  // pinned
-  void* staging = nullptr;      // delta upload buffer
-  size_t staging_bytes = 0;
-  Advance* adv = nullptr;
+  // pinned, device-mapped host buffers: deltas go in, advances come out, both
+  // accessed by the kernels directly over PCIe (no staging memcpy launches)
+  void* stage_h = nullptr;      // delta staging (host pointer)
+  void* stage_d = nullptr;      // same memory, device pointer
+  size_t stage_bytes = 0;
+  Advance* adv_h = nullptr;     // compacted advance list (host pointer)
+  Advance* adv_d = nullptr;
   uint64_t adv_cap = 0;
+  uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
+  uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
+  uint64_t* d_total = nullptr;  // device alias of h_total
   bool have_terms = false;
   unsigned last_flags = 0;
   int last_gpl = kGPL;
@@ -141,17 +148,34 @@ hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned 
 }
 
 int ensure_staging(raftq_t* h, size_t bytes) {
-  if (bytes <= h->staging_bytes) return RAFTQ_OK;
-  size_t want = std::max(bytes, h->staging_bytes * 2);
-  want = std::max<size_t>(want, 1 << 16);
-  if (h->staging) {
+  if (bytes <= h->stage_bytes) return RAFTQ_OK;
+  size_t want = std::max(bytes, h->stage_bytes * 2);
+  want = std::max<size_t>(want, 1 << 20);
+  if (h->stage_h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(h->staging));
-    h->staging = nullptr;
-    h->staging_bytes = 0;
+    HIPCHK(h, hipHostFree(h->stage_h));
+    h->stage_h = h->stage_d = nullptr;
+    h->stage_bytes = 0;
   }
-  HIPCHK(h, hipMalloc(&h->staging, want));
-  h->staging_bytes = want;
+  HIPCHK(h, hipHostMalloc(&h->stage_h, want, hipHostMallocMapped));
+  HIPCHK(h, hipHostGetDevicePointer(&h->stage_d, h->stage_h, 0));
+  h->stage_bytes = want;
+  return RAFTQ_OK;
+}
+
+int ensure_adv(raftq_t* h, uint64_t entries) {
+  if (entries <= h->adv_cap) return RAFTQ_OK;
+  uint64_t want = std::max<uint64_t>(entries, h->adv_cap * 2);
+  want = std::min<uint64_t>(std::max<uint64_t>(want, 4096), h->gpad);
+  if (h->adv_h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipHostFree(h->adv_h));
+    h->adv_h = h->adv_d = nullptr;
+    h->adv_cap = 0;
+  }
+  HIPCHK(h, hipHostMalloc((void**)&h->adv_h, want * sizeof(Advance), hipHostMallocMapped));
+  HIPCHK(h, hipHostGetDevicePointer((void**)&h->adv_d, h->adv_h, 0));
+  h->adv_cap = want;
   return RAFTQ_OK;
 }
 
@@ -230,7 +254,8 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     if ((rc = alloc((void**)&h->offsets, (h->max_partials + 1) * 8))) break;
     e = hipHostMalloc((void**)&h->h_partials, h->max_partials * sizeof(uint4), hipHostMallocDefault);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
-    e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocDefault);
+    e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_total, h->h_total, 0);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
     e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -261,8 +286,9 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->changed_bits);
   (void)hipFree(h->partials);
   (void)hipFree(h->offsets);
-  (void)hipFree(h->staging);
-  (void)hipFree(h->adv);
+  (void)hipFree(h->claim);
+  if (h->stage_h) (void)hipHostFree(h->stage_h);
+  if (h->adv_h) (void)hipHostFree(h->adv_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
   if (h->h_total) (void)hipHostFree(h->h_total);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -321,35 +347,68 @@ int raftq_load_votes(raftq_t* h, const uint8_t* votes) {
   return RAFTQ_OK;
 }
 
+// enqueue only (no sync): validate, copy into the pinned staging area at byte
+// offset `off`, launch the scatter.  Shared by raftq_apply_* and raftq_cycle.
+static int enqueue_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n, size_t off) {
+  static_assert(sizeof(DeltaRec) == sizeof(raftq_delta_t), "ABI struct mismatch");
+  // one pass: range-check (branch-free OR-reduce) and, unless the caller filled
+  // the pinned staging area in place (raftq_stage), copy into it
+  raftq_delta_t* dst = (raftq_delta_t*)((uint8_t*)h->stage_h + off);
+  const bool in_place = (const void*)d == (const void*)dst;
+  const uint64_t G = h->G, N = h->N;
+  uint64_t bad = 0;
+  if (in_place) {
+    for (uint64_t i = 0; i < n; ++i) bad |= (uint64_t)(d[i].group >= G) | (uint64_t)(d[i].peer >= N);
+  } else {
+    for (uint64_t i = 0; i < n; ++i) {
+      const raftq_delta_t r = d[i];
+      bad |= (uint64_t)(r.group >= G) | (uint64_t)(r.peer >= N);
+      dst[i] = r;
+    }
+  }
+  if (bad) return fail(h, RAFTQ_EINVAL, "a match delta is out of range (group >= G or peer >= N); nothing applied");
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld,
+                     (const DeltaRec*)((uint8_t*)h->stage_d + off), n);
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
+
+static int enqueue_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n, size_t off) {
+  static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
+  if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
+  raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off);
+  const bool in_place = (const void*)d == (const void*)dst;
+  {
+    const uint64_t G = h->G, N = h->N;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const raftq_vote_delta_t r = d[i];
+      bad |= (uint64_t)(r.group >= G) | (uint64_t)(r.peer >= N) | (uint64_t)((unsigned)(r.vote - 1) > 1u);
+      if (!in_place) dst[i] = r;
+    }
+    if (bad) return fail(h, RAFTQ_EINVAL, "a vote delta is invalid (group/peer out of range or vote not 1/2); nothing applied");
+  }
+  if (!h->claim) {
+    const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
+    HIPCHK(h, hipMalloc((void**)&h->claim, bytes));
+    HIPCHK(h, hipMemsetAsync(h->claim, 0xff, bytes, h->stream));
+  }
+  const VoteDeltaRec* dd = (const VoteDeltaRec*)((uint8_t*)h->stage_d + off);
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(vote_claim_kernel, grid, dim3(kBlock), 0, h->stream, h->claim, h->ld, dd, n);
+  hipLaunchKernelGGL(vote_apply_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, dd, n);
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
+
 int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
   if (int rc = use_device(h)) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: null argument");
-  for (uint64_t i = 0; i < n; ++i)
-    if (d[i].group >= h->G || d[i].peer >= h->N)
-      return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: delta " + std::to_string(i) + " out of range (nothing applied)");
-  // SoA staging: group | match | peer
-  const size_t bytes = (size_t)n * (8 + 8 + 4);
-  if (int rc = ensure_staging(h, bytes + 64)) return rc;
-  std::vector<uint64_t> grp(n), mat(n);
-  std::vector<uint32_t> peer(n);
-  for (uint64_t i = 0; i < n; ++i) {
-    grp[i] = d[i].group;
-    mat[i] = d[i].match;
-    peer[i] = d[i].peer;
-  }
-  uint8_t* base = (uint8_t*)h->staging;
-  DeltaSoA s;
-  s.group = (const uint64_t*)base;
-  s.match = (const uint64_t*)(base + n * 8);
-  s.peer = (const uint32_t*)(base + n * 16);
-  HIPCHK(h, hipMemcpyAsync((void*)s.group, grp.data(), n * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync((void*)s.match, mat.data(), n * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync((void*)s.peer, peer.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld, s, n);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors die here
+  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
+  if (int rc = enqueue_deltas(h, d, n, 0)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging area is reused by the next call
   return RAFTQ_OK;
 }
 
@@ -357,34 +416,8 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
   if (int rc = use_device(h)) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: null argument");
-  for (uint64_t i = 0; i < n; ++i)
-    if (d[i].group >= h->G || d[i].peer >= h->N || (d[i].vote != 1 && d[i].vote != 2))
-      return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: delta " + std::to_string(i) + " invalid (nothing applied)");
-  // first response of a peer wins, also inside one batch: keep the earliest
-  std::vector<uint64_t> grp;
-  std::vector<uint32_t> peer;
-  std::vector<uint8_t> vote;
-  std::unordered_set<uint64_t> seen;
-  seen.reserve((size_t)n * 2);
-  for (uint64_t i = 0; i < n; ++i) {
-    const uint64_t key = d[i].group * 16 + d[i].peer;
-    if (!seen.insert(key).second) continue;
-    grp.push_back(d[i].group);
-    peer.push_back(d[i].peer);
-    vote.push_back(d[i].vote);
-  }
-  const uint64_t m = grp.size();
-  if (int rc = ensure_staging(h, (size_t)m * 13 + 64)) return rc;
-  uint8_t* base = (uint8_t*)h->staging;
-  uint64_t* dg = (uint64_t*)base;
-  uint32_t* dp = (uint32_t*)(base + m * 8);
-  uint8_t* dv = base + m * 12;
-  HIPCHK(h, hipMemcpyAsync(dg, grp.data(), m * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(dp, peer.data(), m * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(dv, vote.data(), m, hipMemcpyHostToDevice, h->stream));
-  const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(apply_vote_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->ld, dg, dp, dv, m);
-  HIPCHK(h, hipGetLastError());
+  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
+  if (int rc = enqueue_vote_deltas(h, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
 }
@@ -506,41 +539,112 @@ int raftq_vote_tally(raftq_t* h, uint8_t* outcome_out, raftq_counts_t* counts) {
   return RAFTQ_OK;
 }
 
+// enqueue scan + compaction of the last RAFTQ_SWEEP_CHANGED sweep; the kernels
+// write the total and up to `take_cap` entries straight into pinned host memory.
+static int enqueue_collect(raftq_t* h, uint64_t take_cap) {
+  static_assert(sizeof(Advance) == sizeof(raftq_advance_t), "ABI struct mismatch");
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->partials, h->n_partials,
+                     h->offsets, h->d_total);
+  if (take_cap) {
+    const int gpl = h->last_gpl;
+    const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
+    if (gpl == kGPL)
+      hipLaunchKernelGGL((compact_changed_kernel<kGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
+                         h->offsets, h->last_old, h->last_new, h->adv_d, take_cap);
+    else
+      hipLaunchKernelGGL((compact_changed_kernel<kLdsGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
+                         h->offsets, h->last_old, h->last_new, h->adv_d, take_cap);
+  }
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
+
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
   if (int rc = use_device(h)) return rc;
   if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_changed: null count");
   if (!(h->last_flags & RAFTQ_SWEEP_CHANGED) || !h->last_old)
     return fail(h, RAFTQ_ESTATE, "raftq_collect_changed: last sweep did not set RAFTQ_SWEEP_CHANGED");
   if (cap && !out) return fail(h, RAFTQ_EINVAL, "raftq_collect_changed: null out with cap > 0");
-  static_assert(sizeof(Advance) == sizeof(raftq_advance_t), "ABI struct mismatch");
-  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->partials, h->n_partials,
-                     h->offsets, h->offsets + h->max_partials);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(h->h_total, h->offsets + h->max_partials, 8, hipMemcpyDeviceToHost, h->stream));
+  const uint64_t take_cap = std::min<uint64_t>(cap, h->G);
+  if (take_cap)
+    if (int rc = ensure_adv(h, take_cap)) return rc;
+  if (int rc = enqueue_collect(h, take_cap)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint64_t total = *h->h_total;
   *n = total;
-  const uint64_t take = std::min(total, cap);
-  if (take == 0) return RAFTQ_OK;
-  if (h->adv_cap < take) {
-    if (h->adv) HIPCHK(h, hipFree(h->adv));
-    h->adv = nullptr;
-    h->adv_cap = 0;
-    const uint64_t want = std::min<uint64_t>(h->G, std::max<uint64_t>(take, 4096));
-    HIPCHK(h, hipMalloc((void**)&h->adv, want * sizeof(Advance)));
-    h->adv_cap = want;
-  }
-  const int gpl = h->last_gpl;
-  const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
-  if (gpl == kGPL)
-    hipLaunchKernelGGL((compact_changed_kernel<kGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
-                       h->last_old, h->last_new, h->adv, take);
-  else
-    hipLaunchKernelGGL((compact_changed_kernel<kLdsGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
-                       h->offsets, h->last_old, h->last_new, h->adv, take);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(out, h->adv, take * sizeof(Advance), hipMemcpyDeviceToHost, h->stream));
+  const uint64_t take = std::min(total, take_cap);
+  h->adv_listed = take;
+  if (take) std::memcpy(out, h->adv_h, take * sizeof(Advance));
+  return RAFTQ_OK;
+}
+
+static size_t vote_stage_offset(uint64_t n_deltas) {
+  return ((size_t)n_deltas * sizeof(raftq_delta_t) + 255) / 256 * 256;
+}
+
+int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta_t** deltas,
+                raftq_vote_delta_t** vote_deltas) {
+  if (int rc = use_device(h)) return rc;
+  const size_t off_votes = vote_stage_offset(n_deltas);
+  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  if (deltas) *deltas = (raftq_delta_t*)h->stage_h;
+  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+  return RAFTQ_OK;
+}
+
+int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!list || !n_listed) return fail(h, RAFTQ_EINVAL, "raftq_last_advances: null argument");
+  *list = (const raftq_advance_t*)h->adv_h;
+  *n_listed = h->adv_listed;
+  return RAFTQ_OK;
+}
+
+int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
+                uint64_t n_vote_deltas, unsigned flags, raftq_advance_t* advances_out, uint64_t cap,
+                uint64_t* n_advanced, raftq_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if ((n_deltas && !deltas) || (n_vote_deltas && !vote_deltas))
+    return fail(h, RAFTQ_EINVAL, "raftq_cycle: null array with non-zero length");
+  const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+  const bool want_list = commit && (advances_out || n_advanced || cap);
+  if (want_list) flags |= RAFTQ_SWEEP_CHANGED;
+  const size_t off_votes = vote_stage_offset(n_deltas);
+  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  const uint64_t take_cap = want_list ? std::min<uint64_t>(cap, h->G) : 0;
+  if (take_cap)
+    if (int rc = ensure_adv(h, take_cap)) return rc;
+  // everything below is enqueued back to back on the handle's stream; one sync at the end
+  if (n_deltas)
+    if (int rc = enqueue_deltas(h, deltas, n_deltas, 0)) return rc;
+  if (n_vote_deltas)
+    if (int rc = enqueue_vote_deltas(h, vote_deltas, n_vote_deltas, off_votes)) return rc;
+  if (int rc = raftq_step_async(h, flags)) return rc;
+  if (want_list)
+    if (int rc = enqueue_collect(h, take_cap)) return rc;
+  if (counts)
+    HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost,
+                             h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (counts) {
+    uint64_t c = 0, w = 0, l = 0;
+    for (uint64_t i = 0; i < h->n_partials; ++i) {
+      c += h->h_partials[i].x;
+      w += h->h_partials[i].y;
+      l += h->h_partials[i].z;
+    }
+    counts->n_changed = commit ? c : 0;
+    counts->n_won = (flags & RAFTQ_SWEEP_VOTES) ? w : 0;
+    counts->n_lost = (flags & RAFTQ_SWEEP_VOTES) ? l : 0;
+  }
+  if (want_list) {
+    const uint64_t total = *h->h_total;
+    if (n_advanced) *n_advanced = total;
+    const uint64_t take = std::min(total, take_cap);
+    h->adv_listed = take;
+    // advances_out == NULL: the caller reads the pinned list in place (raftq_last_advances)
+    if (take && advances_out) std::memcpy(advances_out, h->adv_h, take * sizeof(Advance));
+  }
   return RAFTQ_OK;
 }
 

@@ -385,45 +385,64 @@ __global__ __launch_bounds__(kBlock) void sweep_lds_kernel(SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Sparse ingest.  Progress.maybeUpdate only ever raises
-// Match, so a batch of MsgAppResp deltas is an order-independent atomic max.
-struct DeltaSoA {
-  const uint64_t* group;
-  const uint64_t* match;
-  const uint32_t* peer;
+// Sparse ingest.  Deltas arrive as the C-ABI's AoS structs in
+// pinned, device-mapped host memory; the kernels read them straight over PCIe
+// (coalesced: consecutive lanes, consecutive 24 / 16 byte structs).
+struct DeltaRec {      // == raftq_delta_t
+  uint64_t group, match;
+  uint32_t peer, pad;
+};
+struct VoteDeltaRec {  // == raftq_vote_delta_t
+  uint64_t group;
+  uint32_t peer;
+  uint8_t vote, pad[3];
 };
 
-__global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld, DeltaSoA d,
-                                                              uint64_t n) {
+// Progress.maybeUpdate only ever raises Match, so a batch of MsgAppResp
+// deltas is an order-independent atomic max.
+__global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld,
+                                                              const DeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  unsigned long long* slot =
-      reinterpret_cast<unsigned long long*>(match + (uint64_t)d.peer[i] * ld + d.group[i]);
-  atomicMax(slot, (unsigned long long)d.match[i]);
+  const DeltaRec r = d[i];
+  atomicMax(reinterpret_cast<unsigned long long*>(match + (uint64_t)r.peer * ld + r.group),
+            (unsigned long long)r.match);
 }
 
-// poll(): the first response of a peer wins.  The host has already removed
-// duplicate (group, peer) pairs from the batch (keeping the earliest), so
-// slots are disjoint bytes; neighbours share a 32-bit word, hence the CAS.
-__global__ __launch_bounds__(kBlock) void apply_vote_deltas_kernel(uint8_t* votes, uint64_t ld,
-                                                                   const uint64_t* group,
-                                                                   const uint32_t* peer,
-                                                                   const uint8_t* vote, uint64_t n) {
+// poll(): the first response of a peer wins -- also inside one batch, where
+// "first" means lowest batch position.  Two launches make that deterministic
+// without any host-side hashing: (1) every record claims its slot with
+// atomicMin(batch position); (2) only the claim holder writes the vote (if the
+// slot is still unanswered) and then releases the claim for the next batch.
+// claim[] is u32 [N][ld], UINT32_MAX when free.
+__global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uint64_t ld,
+                                                            const VoteDeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const uint64_t byte = (uint64_t)peer[i] * ld + group[i];
-  unsigned int* word = reinterpret_cast<unsigned int*>(votes + (byte & ~3ull));
-  const unsigned sh = (unsigned)(byte & 3ull) * 8u;
-  const unsigned nv = (unsigned)vote[i] << sh;
+  const VoteDeltaRec r = d[i];
+  atomicMin(claim + (uint64_t)r.peer * ld + r.group, (uint32_t)i);
+}
+
+__global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
+                                                            const VoteDeltaRec* __restrict__ d, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const VoteDeltaRec r = d[i];
+  const uint64_t slot = (uint64_t)r.peer * ld + r.group;
+  if (claim[slot] != (uint32_t)i) return;  // an earlier record of this batch owns the slot
+  // neighbouring slots share a 32-bit word and may be written by other lanes: CAS the byte in
+  unsigned int* word = reinterpret_cast<unsigned int*>(votes + (slot & ~3ull));
+  const unsigned sh = (unsigned)(slot & 3ull) * 8u;
+  const unsigned nv = (unsigned)r.vote << sh;
   unsigned old = *word;
   while (true) {
     const unsigned cur = (old >> sh) & 0xffu;
-    if (cur == 1u || cur == 2u) return;  // already answered
-    const unsigned want = (old & ~(0xffu << sh)) | nv;
-    const unsigned seen = atomicCAS(word, old, want);
-    if (seen == old) return;
+    if (cur == 1u || cur == 2u) break;  // answered in an earlier batch
+    const unsigned seen = atomicCAS(word, old, (old & ~(0xffu << sh)) | nv);
+    if (seen == old) break;
     old = seen;
   }
+  claim[slot] = 0xffffffffu;  // only the holder releases; later readers see "not mine" either way
 }
 
 // ---------------------------------------------------------------------------

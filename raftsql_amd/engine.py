@@ -137,6 +137,82 @@ class QuorumEngine:
         a["group"], a["peer"], a["vote"] = group, peer, vote
         self._chk(self._lib.raftq_apply_vote_deltas(self._h, C.addressof(arr) if n else None, n))
 
+    _DELTA_DT = np.dtype([("group", "<u8"), ("match", "<u8"), ("peer", "<u4"), ("_pad", "<u4")])
+    _VDELTA_DT = np.dtype([("group", "<u8"), ("peer", "<u4"), ("vote", "u1"), ("_pad", "u1", (3,))])
+    _ADV_DT = np.dtype([("group", "<u8"), ("old_commit", "<u8"), ("new_commit", "<u8")])
+
+    @classmethod
+    def pack_deltas(cls, group, peer, match) -> np.ndarray:
+        """AoS array layout-identical to raftq_delta_t[] (build once, reuse)."""
+        a = np.zeros(len(group), dtype=cls._DELTA_DT)
+        a["group"], a["match"], a["peer"] = group, match, peer
+        return a
+
+    @classmethod
+    def pack_vote_deltas(cls, group, peer, vote) -> np.ndarray:
+        a = np.zeros(len(group), dtype=cls._VDELTA_DT)
+        a["group"], a["peer"], a["vote"] = group, peer, vote
+        return a
+
+    def stage(self, n_deltas: int, n_vote_deltas: int = 0):
+        """Pinned, device-visible staging arrays (raftq_stage): fill them in place and hand
+        them to cycle() -- no copy is made.  -> (deltas view, vote_deltas view)"""
+        pd, pv = C.c_void_p(None), C.c_void_p(None)
+        self._chk(self._lib.raftq_stage(self._h, n_deltas, n_vote_deltas, C.byref(pd), C.byref(pv)))
+
+        def view(ptr, n, dt):
+            if n == 0:
+                return np.empty(0, dtype=dt)
+            buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dt, count=n)
+
+        return view(pd, n_deltas, self._DELTA_DT), view(pv, n_vote_deltas, self._VDELTA_DT)
+
+    def last_advances(self) -> np.ndarray:
+        """The advance list of the last cycle(), read in place from pinned memory (no copy)."""
+        p, n = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_last_advances(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.empty(0, dtype=self._ADV_DT)
+        buf = (C.c_char * (n.value * self._ADV_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=self._ADV_DT, count=n.value)
+
+    def cycle_inplace(self, flags: int, deltas: Optional[np.ndarray], vote_deltas: Optional[np.ndarray],
+                      cap: int):
+        """cycle() for staged inputs, leaving the advance list in pinned memory.
+        -> n_advanced_total; read the list with last_advances()."""
+        nd = 0 if deltas is None else len(deltas)
+        nv = 0 if vote_deltas is None else len(vote_deltas)
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_cycle(
+            self._h, _ptr(deltas) if nd else None, nd, _ptr(vote_deltas) if nv else None, nv, flags,
+            None, int(cap), C.byref(n), None))
+        return int(n.value)
+
+    def cycle(self, flags: int, deltas: Optional[np.ndarray] = None, vote_deltas: Optional[np.ndarray] = None,
+              cap: Optional[int] = None, out: Optional[np.ndarray] = None, want_counts: bool = True):
+        """One batching iteration (raftq_cycle): scatter deltas -> sweep -> advance list.
+
+        -> (advances structured array, n_advanced_total, SweepCounts | None)
+        """
+        nd = 0 if deltas is None else len(deltas)
+        nv = 0 if vote_deltas is None else len(vote_deltas)
+        if nd:
+            assert deltas.dtype == self._DELTA_DT and deltas.flags.c_contiguous
+        if nv:
+            assert vote_deltas.dtype == self._VDELTA_DT and vote_deltas.flags.c_contiguous
+        cap = (self.n_groups if cap is None else int(cap))
+        if out is None:
+            out = np.empty(cap, dtype=self._ADV_DT)
+        n = C.c_uint64(0)
+        c = Counts()
+        self._chk(self._lib.raftq_cycle(
+            self._h, _ptr(deltas) if nd else None, nd, _ptr(vote_deltas) if nv else None, nv, flags,
+            _ptr(out) if cap else None, cap, C.byref(n), C.byref(c) if want_counts else None))
+        total = int(n.value)
+        cnt = SweepCounts(int(c.n_changed), int(c.n_won), int(c.n_lost)) if want_counts else None
+        return out[: min(total, cap)], total, cnt
+
     # -- the sweep --------------------------------------------------------
     def step_async(self, flags: int) -> None:
         self._chk(self._lib.raftq_step_async(self._h, flags))

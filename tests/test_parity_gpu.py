@@ -285,6 +285,101 @@ def test_vote_deltas_first_response_wins(gpu_engine_cls, oracle):
             assert np.array_equal(out, oc) and (cnt.n_won, cnt.n_lost) == (w, l)
 
 
+def test_cycle_pipeline_matches_oracle(gpu_engine_cls, oracle):
+    """raftq_cycle = one turn of the batching goroutine: MsgAppResp + MsgVoteResp deltas in,
+    one fused sweep, compacted Ready-style advance list out; several turns in a row."""
+    rng = np.random.default_rng(23)
+    n, G = 5, 150001
+    st = _state(G, n, 5150, adversarial=False)
+    votes = np.zeros((n, G), dtype=np.uint8)
+    votes[0] = 1
+    with gpu_engine_cls(G, n) as e:
+        e.load_match(st.match, st.committed)
+        e.load_terms(st.cur_term, st.first_idx_cur_term)
+        e.load_votes(votes)
+        ref_match, ref_commit, ref_votes = st.match.copy(), st.committed.copy(), votes.copy()
+        for turn in range(4):
+            nd, nv = 40000, 30000
+            dg = rng.integers(0, G, nd).astype(np.uint64)
+            dp = rng.integers(0, n, nd).astype(np.uint32)
+            dm = (ref_commit[dg.astype(np.int64)] + rng.integers(0, 3000, nd).astype(np.uint64)).astype(np.uint64)
+            vg = rng.integers(0, G, nv).astype(np.uint64)
+            vp = rng.integers(1, n, nv).astype(np.uint32)
+            vv = rng.integers(1, 3, nv).astype(np.uint8)
+            vg[:2000] = vg[0]  # heavy conflicting duplicates: first in batch order must win
+            vp[:2000] = vp[0]
+            gated = bool(turn & 1)
+            flags = SWEEP_COMMIT | SWEEP_VOTES | (SWEEP_GATED if gated else 0)
+            adv, total, cnt = e.cycle(flags, e.pack_deltas(dg, dp, dm), e.pack_vote_deltas(vg, vp, vv))
+            ref_match = oracle.apply_deltas(ref_match, dg, dp, dm)
+            ref_votes = oracle.apply_vote_deltas(ref_votes, vg, vp, vv)
+            new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit, gated, st.first_idx_cur_term)
+            oc, w, l = oracle.vote_tally(ref_votes)
+            idx = np.nonzero(new_commit != ref_commit)[0]
+            assert total == n_ch == len(idx) and (cnt.n_changed, cnt.n_won, cnt.n_lost) == (n_ch, w, l)
+            assert np.array_equal(adv["group"], idx.astype(np.uint64))
+            assert np.array_equal(adv["old_commit"], ref_commit[idx])
+            assert np.array_equal(adv["new_commit"], new_commit[idx])
+            assert np.array_equal(e.read_committed(), new_commit)
+            assert np.array_equal(e.read_outcome(), oc)
+            assert np.array_equal(e.read_votes(), ref_votes) and np.array_equal(e.read_match(), ref_match)
+            ref_commit = new_commit
+        # empty turn under the same gate as the last turn: nothing in, nothing out
+        adv, total, cnt = e.cycle(SWEEP_COMMIT | SWEEP_GATED)
+        assert total == 0 and len(adv) == 0 and cnt.n_changed == 0
+        # capped output still reports the full count
+        dg = np.arange(0, 5000, dtype=np.uint64)
+        dm = (ref_commit[:5000] + np.uint64(10)).astype(np.uint64)
+        for p in range(n):
+            pp = np.full(5000, p, dtype=np.uint32)
+            e.apply_deltas(dg, pp, dm)
+            ref_match = oracle.apply_deltas(ref_match, dg, pp, dm)
+        new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+        idx = np.nonzero(new_commit != ref_commit)[0]
+        assert n_ch >= 5000
+        adv, total, cnt = e.cycle(SWEEP_COMMIT, cap=7)
+        assert total == n_ch and len(adv) == 7 and np.array_equal(adv["group"], idx[:7].astype(np.uint64))
+
+
+def test_cycle_zero_copy_staging(gpu_engine_cls, oracle):
+    """raftq_stage + in-place advance list give the same answers as the copying form."""
+    rng = np.random.default_rng(31)
+    n, G = 3, 40000
+    st = _state(G, n, 6100, adversarial=False)
+    with gpu_engine_cls(G, n) as e:
+        e.load_state(st)
+        ref_match, ref_commit = st.match.copy(), st.committed.copy()
+        for turn in range(3):
+            nd, nv = 9000 + turn, 1000
+            d, v = e.stage(nd, nv)
+            assert len(d) == nd and len(v) == nv
+            d["group"] = rng.integers(0, G, nd)
+            d["peer"] = rng.integers(0, n, nd)
+            d["match"] = ref_commit[d["group"].astype(np.int64)] + rng.integers(0, 4000, nd).astype(np.uint64)
+            v["group"] = rng.integers(0, G, nv)
+            v["peer"] = rng.integers(0, n, nv)
+            v["vote"] = rng.integers(1, 3, nv)
+            total = e.cycle_inplace(SWEEP_COMMIT | SWEEP_VOTES, d, v, cap=G)
+            adv = e.last_advances().copy()
+            ref_match = oracle.apply_deltas(ref_match, d["group"].copy(), d["peer"].copy(), d["match"].copy())
+            new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+            idx = np.nonzero(new_commit != ref_commit)[0]
+            assert total == n_ch == len(adv)
+            assert np.array_equal(adv["group"], idx.astype(np.uint64))
+            assert np.array_equal(adv["new_commit"], new_commit[idx])
+            ref_commit = new_commit
+        # an out-of-range staged delta is refused and nothing is applied
+        from raftsql_amd.engine import RaftqError
+        d, _ = e.stage(4, 0)
+        d["group"] = [1, 2, G, 3]
+        d["peer"] = 0
+        d["match"] = 2**63
+        with pytest.raises(RaftqError) as ei:
+            e.cycle_inplace(SWEEP_COMMIT, d, None, cap=G)
+        assert ei.value.code == -1
+        assert np.array_equal(e.read_match(), ref_match)
+
+
 def test_timer_and_stream(gpu_engine_cls):
     import torch
 

@@ -93,6 +93,14 @@ typedef struct raftq_vote_delta {
   uint8_t _pad[3];
 } raftq_vote_delta_t;
 
+/* one group whose leader entered a new term (or appended the first entry of
+ * its term): updates the gate of raftLog.maybeCommit for that group */
+typedef struct raftq_term_delta {
+  uint64_t group;
+  uint64_t cur_term;
+  uint64_t first_idx_cur_term; /* 0 = no entry of cur_term in the log yet */
+} raftq_term_delta_t;
+
 /* one advanced group: what would surface in Ready.HardState.Commit */
 typedef struct raftq_advance {
   uint64_t group;
@@ -133,6 +141,8 @@ int raftq_load_votes(raftq_t* h, const uint8_t* votes /*[N][G]*/);
 /* ---- sparse ingest ----------------------------------- */
 int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n);
 int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n);
+/* later records of the same group win (applied in order on the host side) */
+int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n);
 
 /* ---- the sweep ---------------------------------------------------------- */
 /* enqueue one pass over all G groups on the handle's stream. */

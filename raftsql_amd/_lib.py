@@ -60,6 +60,7 @@ _SIGS = [
     ("raftq_load_votes", C.c_int, [_H, C.c_void_p]),
     ("raftq_apply_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_apply_vote_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    ("raftq_apply_term_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_step_async", C.c_int, [_H, C.c_uint]),
     ("raftq_wait", C.c_int, [_H, C.POINTER(Counts)]),
     ("raftq_commit_advance", C.c_int, [_H, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),

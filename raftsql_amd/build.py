@@ -33,10 +33,13 @@ def _stale(target: str, sources: list[str]) -> bool:
 
 
 def lib_sources() -> list[str]:
+    """[translation units..., headers...] -- the first two are compiled."""
     return [
         os.path.join(CSRC, "raftq_capi.hip"),
+        os.path.join(CSRC, "raftq_pipe.cpp"),
         os.path.join(CSRC, "raftq_kernels.hpp"),
         os.path.join(ROOT, "include", "raftq.h"),
+        os.path.join(ROOT, "include", "raftq_pipe.h"),
     ]
 
 
@@ -48,7 +51,7 @@ def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = 
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     for k, v in (defines or {}).items():
         cmd.append(f"-D{k}={v}")
-    cmd += ["-o", LIB, srcs[0]]
+    cmd += ["-o", LIB, srcs[0], srcs[1]]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

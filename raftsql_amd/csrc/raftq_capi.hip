@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -79,6 +81,9 @@ struct raftq {
   const uint64_t* last_new = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
+  // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
+  double prof[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t prof_n = 0;
 };
 
 namespace {
@@ -275,6 +280,12 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
 
 void raftq_destroy(raftq_t* h) {
   if (!h) return;
+  if (h->prof_n && std::getenv("RAFTQ_PROFILE"))
+    std::fprintf(stderr,
+                 "[raftq] cycle phases, avg us over %llu calls: stage/validate %.1f | enqueue scatter %.1f | enqueue sweep "
+                 "%.1f | enqueue collect %.1f | sync %.1f | copy-out %.1f\n",
+                 (unsigned long long)h->prof_n, h->prof[0] / h->prof_n, h->prof[1] / h->prof_n, h->prof[2] / h->prof_n,
+                 h->prof[3] / h->prof_n, h->prof[4] / h->prof_n, h->prof[5] / h->prof_n);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->match);
@@ -409,6 +420,35 @@ int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
   if (int rc = enqueue_deltas(h, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging area is reused by the next call
+  return RAFTQ_OK;
+}
+
+int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n) {
+  static_assert(sizeof(TermDeltaRec) == sizeof(raftq_term_delta_t), "ABI struct mismatch");
+  if (int rc = use_device(h)) return rc;
+  if (n == 0) return RAFTQ_OK;
+  if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_term_deltas: null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (d[i].group >= h->G) return fail(h, RAFTQ_EINVAL, "a term delta is out of range; nothing applied");
+  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_term_delta_t))) return rc;
+  // keep only the last record per group so the scatter has no write-write race
+  raftq_term_delta_t* dst = (raftq_term_delta_t*)h->stage_h;
+  uint64_t m = 0;
+  {
+    std::unordered_set<uint64_t> seen;
+    seen.reserve((size_t)n * 2);
+    std::vector<uint64_t> keep;
+    keep.reserve(n);
+    for (uint64_t i = n; i-- > 0;)
+      if (seen.insert(d[i].group).second) keep.push_back(i);
+    for (auto it = keep.rbegin(); it != keep.rend(); ++it) dst[m++] = d[*it];
+  }
+  const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(apply_term_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->first_idx,
+                     (const TermDeltaRec*)h->stage_d, m);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_terms = true;
   return RAFTQ_OK;
 }
 
@@ -615,17 +655,29 @@ int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, cons
   if (take_cap)
     if (int rc = ensure_adv(h, take_cap)) return rc;
   // everything below is enqueued back to back on the handle's stream; one sync at the end
+  using clk = std::chrono::steady_clock;
+  auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  const auto t0 = clk::now();
   if (n_deltas)
     if (int rc = enqueue_deltas(h, deltas, n_deltas, 0)) return rc;
   if (n_vote_deltas)
     if (int rc = enqueue_vote_deltas(h, vote_deltas, n_vote_deltas, off_votes)) return rc;
+  const auto t1 = clk::now();
   if (int rc = raftq_step_async(h, flags)) return rc;
+  const auto t2 = clk::now();
   if (want_list)
     if (int rc = enqueue_collect(h, take_cap)) return rc;
   if (counts)
     HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost,
                              h->stream));
+  const auto t3 = clk::now();
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  const auto t4 = clk::now();
+  h->prof[1] += us(t0, t1);
+  h->prof[2] += us(t1, t2);
+  h->prof[3] += us(t2, t3);
+  h->prof[4] += us(t3, t4);
+  h->prof_n++;
   if (counts) {
     uint64_t c = 0, w = 0, l = 0;
     for (uint64_t i = 0; i < h->n_partials; ++i) {

@@ -409,6 +409,20 @@ __global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, u
             (unsigned long long)r.match);
 }
 
+// Sparse term update: a group's leader changed term (became leader / appended
+// the first entry of its term).  first_idx already has the cur_term == 0 rule
+// folded in by the host.  Records are unique per group within a batch.
+struct TermDeltaRec {  // == raftq_term_delta_t
+  uint64_t group, cur_term, first_idx_cur_term;
+};
+__global__ __launch_bounds__(kBlock) void apply_term_deltas_kernel(uint64_t* first_idx,
+                                                                   const TermDeltaRec* __restrict__ d, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const TermDeltaRec r = d[i];
+  first_idx[r.group] = r.cur_term == 0 ? 0ull : r.first_idx_cur_term;
+}
+
 // poll(): the first response of a peer wins -- also inside one batch, where
 // "first" means lowest batch position.  Two launches make that deterministic
 // without any host-side hashing: (1) every record claims its slot with

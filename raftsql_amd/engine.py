@@ -137,6 +137,11 @@ class QuorumEngine:
         a["group"], a["peer"], a["vote"] = group, peer, vote
         self._chk(self._lib.raftq_apply_vote_deltas(self._h, C.addressof(arr) if n else None, n))
 
+    def apply_term_deltas(self, group, cur_term, first_idx_cur_term) -> None:
+        a = np.zeros(len(group), dtype=np.dtype([("group", "<u8"), ("cur_term", "<u8"), ("first_idx", "<u8")]))
+        a["group"], a["cur_term"], a["first_idx"] = group, cur_term, first_idx_cur_term
+        self._chk(self._lib.raftq_apply_term_deltas(self._h, _ptr(a) if len(a) else None, len(a)))
+
     _DELTA_DT = np.dtype([("group", "<u8"), ("match", "<u8"), ("peer", "<u4"), ("_pad", "<u4")])
     _VDELTA_DT = np.dtype([("group", "<u8"), ("peer", "<u4"), ("vote", "u1"), ("_pad", "u1", (3,))])
     _ADV_DT = np.dtype([("group", "<u8"), ("old_commit", "<u8"), ("new_commit", "<u8")])

@@ -18,21 +18,35 @@ def lib():
     return _lib.load()
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "raftq.h")).read()
+def _declared(header="raftq.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(raftq_[a-z_]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_list_the_same_symbols():
-    from raftsql_amd import _lib
+    from raftsql_amd import _lib, pipe
 
     assert _declared() == sorted(_lib.EXPORTS)
+    assert _declared("raftq_pipe.h") == sorted(pipe.EXPORTS)
 
 
 def test_every_declared_symbol_is_exported(lib):
-    for name in _declared():
+    for name in _declared() + _declared("raftq_pipe.h"):
         assert hasattr(lib, name), name
+
+
+def test_pipe_refuses_without_device(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from raftsql_amd.engine import RaftqError
+    from raftsql_amd.pipe import MultiRaftPipe
+
+    with pytest.raises(RaftqError) as ei:
+        MultiRaftPipe(8, 3)
+    assert ei.value.code in (-5, -3)
 
 
 def test_abi_version_and_quorum(lib):

@@ -59,14 +59,14 @@ def sweep_flags(cfg) -> int:
     return f
 
 
-def side_measure(cfg_id, rotate_bytes, steps, stream_ptr, dist):
+def side_measure(cfg_id, rotate_bytes, steps, stream_ptr, dist, device=0):
     """Short single-GPU measurement of another BASELINE config (rank 0, N=1)."""
     from raftsql_amd import _lib, synth
 
     cfg = CONFIGS[cfg_id]
     rd, wr = bytes_per_decision(cfg)
     nb = max(2, int(np.ceil(rotate_bytes / (cfg["G"] * (rd + wr)))))
-    engines, _ = build_batches(cfg, nb, 0, synth.SEED_BASE + cfg_id, stream_ptr)
+    engines, _ = build_batches(cfg, nb, 0, synth.SEED_BASE + cfg_id, stream_ptr, device)
     flags = sweep_flags(cfg) | _lib.SWEEP_STREAM
     for i in range(steps // 4):
         engines[i % nb].step_async(flags)
@@ -85,7 +85,7 @@ def side_measure(cfg_id, rotate_bytes, steps, stream_ptr, dist):
     }
 
 
-def build_batches(cfg, n_batches, rank, seed_base, stream_ptr):
+def build_batches(cfg, n_batches, rank, seed_base, stream_ptr, device=0):
     from raftsql_amd import synth
     from raftsql_amd.engine import QuorumEngine
 
@@ -95,7 +95,7 @@ def build_batches(cfg, n_batches, rank, seed_base, stream_ptr):
         # distinct data per batch and per rank (counter-based: offset the group ids)
         off = (rank * n_batches + b) * cfg["G"]
         st = synth.make_groups(cfg["G"], cfg["N"], seed=seed_base, with_terms=cfg["gated"], group_offset=off)
-        e = QuorumEngine(cfg["G"], cfg["N"], device=int(os.environ.get("LOCAL_RANK", "0")))
+        e = QuorumEngine(cfg["G"], cfg["N"], device=device)
         e.set_stream(stream_ptr)
         e.load_state(st)
         engines.append(e)
@@ -219,6 +219,10 @@ def main():
     ap.add_argument("--variant", choices=["reg", "lds"], default="reg")
     ap.add_argument("--policy", choices=["stream", "cached", "auto"], default="stream",
                     help="cache policy of the rotating loop: no batch stays cached between its sweeps, so stream")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="torch.distributed backend for N>1 (default nccl = RCCL); gloo is for testing the "
+                         "multi-process path on a box with fewer GPUs than ranks")
+    ap.add_argument("--device", type=int, default=None, help="force this GPU index on every rank (testing only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the l3_resident / other-config side measurements")
     args = ap.parse_args()
@@ -227,12 +231,15 @@ def main():
 
     from raftsql_amd import _lib, dist, synth
 
-    world = dist.init_from_env()
-    if world.size != max(1, args.gpus) and world.size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world.size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the quorum sweep has no CPU path (only the oracle baseline does)")
-    torch.cuda.set_device(world.local_rank)
+    world = dist.init_from_env(args.backend)
+    if world.size != max(1, args.gpus) and world.size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world.size}")
+    device = world.local_rank if args.device is None else args.device
+    if device >= torch.cuda.device_count():
+        raise SystemExit(f"rank {world.rank}: GPU {device} not visible ({torch.cuda.device_count()} present)")
+    torch.cuda.set_device(device)
     _lib.load()
     stream = torch.cuda.Stream()
 
@@ -243,7 +250,7 @@ def main():
     flags = sweep_flags(cfg) | (_lib.SWEEP_LDS if args.variant == "lds" else 0)
     base_flags = flags
     flags |= {"stream": _lib.SWEEP_STREAM, "cached": _lib.SWEEP_CACHED, "auto": 0}[args.policy]
-    engines, st0 = build_batches(cfg, n_batches, world.rank, synth.SEED_BASE + args.config, stream.cuda_stream)
+    engines, st0 = build_batches(cfg, n_batches, world.rank, synth.SEED_BASE + args.config, stream.cuda_stream, device)
 
     # correctness gate before any timing: tallies of batch 0 against numpy
     c = engines[0].sweep(flags)
@@ -332,9 +339,9 @@ def main():
     for e in engines:
         e.close()
     if world.rank == 0 and world.size == 1 and not args.no_extras:
-        out["pipeline"] = pipeline_measure(cfg, world.local_rank)
+        out["pipeline"] = pipeline_measure(cfg, device)
         out["other_configs"] = {
-            f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist)
+            f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
             for c in sorted(CONFIGS) if c != args.config
         }
     dist.barrier(world)

@@ -40,6 +40,10 @@ def init_from_env(backend: str | None = None) -> World:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=size,
                                 device_id=torch.device("cuda", local_rank))
+        # first collective creates the communicator: do it here, outside any timed region
+        warm = torch.zeros(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     else:
         dist.init_process_group(backend, rank=rank, world_size=size)
     return World(rank, local_rank, size, backend)

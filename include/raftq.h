@@ -166,6 +166,34 @@ int raftq_read_votes(raftq_t* h, uint8_t* votes_out /*[N][G]*/);
  * in ascending group order; returns the count in *n (<= cap entries stored). */
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n);
 
+/* ---- batched Tick --------------------------------------
+ * rc.node.Tick() (raft.go:223-224) for every group at once: etcd's
+ * tickHeartbeat for leaders, tickElection + isElectionTimeout for the rest.
+ * role: 0 follower, 1 candidate, 2 leader; action: 0 none, 1 MsgHup, 2 MsgBeat.
+ * Timers default to the reference's ElectionTick 10 / HeartbeatTick 1
+ * (raft.go:154-155).  The randomised election timeout draws from a
+ * counter-based splitmix64 stream (seed, tick number, group), not Go's
+ * math/rand -- see oracle/raftq_oracle.h. */
+#define RAFTQ_ROLE_FOLLOWER 0
+#define RAFTQ_ROLE_CANDIDATE 1
+#define RAFTQ_ROLE_LEADER 2
+typedef struct raftq_tick_counts {
+  uint64_t n_hup;  /* groups whose election timer fired: they campaign */
+  uint64_t n_beat; /* leader groups due a heartbeat */
+} raftq_tick_counts_t;
+int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed);
+int raftq_load_roles(raftq_t* h, const uint8_t* role /*[G]*/, const uint32_t* elapsed /*[G]|NULL = 0*/);
+/* one Tick for every group; synchronous when counts != NULL, else enqueued */
+int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts);
+/* any of the outputs may be NULL */
+int raftq_read_tick(raftq_t* h, uint8_t* action /*[G]*/, uint32_t* elapsed /*[G]*/, uint8_t* role /*[G]*/);
+/* ascending list of the groups the last raftq_tick sent MsgHup to */
+int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
+/* becomeCandidate for `n` distinct groups: role = candidate, elapsed = 0, votes
+ * cleared, the candidate's own slot (`self_peer`) granted.  Term bookkeeping is
+ * the caller's (raftq_apply_term_deltas). */
+int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self_peer);
+
 /* ---- one batching iteration ----------------------------
  * What the single batching goroutine does per turn, fused into one call with
  * ONE host/device sync: scatter the MsgAppResp / MsgVoteResp deltas, sweep all

@@ -64,6 +64,14 @@ def lib() -> C.CDLL:
         L.rq_oracle_apply_vote_deltas.restype = None
         L.rq_oracle_apply_vote_deltas.argtypes = [
             _u8p, C.c_size_t, C.c_int, C.c_size_t, _u64p, _u32p, _u8p, C.c_size_t]
+        L.rq_oracle_tick_rand.restype = C.c_uint32
+        L.rq_oracle_tick_rand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.rq_oracle_tick.restype = None
+        L.rq_oracle_tick.argtypes = [_u8p, _u32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _u8p,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.rq_oracle_campaign.restype = None
+        L.rq_oracle_campaign.argtypes = [_u8p, _u32p, _u8p, C.c_size_t, C.c_int, C.c_size_t, _u64p, C.c_size_t,
+                                         C.c_uint32]
         L.rq_oracle_timed_sweeps.restype = C.c_double
         L.rq_oracle_timed_sweeps.argtypes = [
             C.c_int, C.c_int, C.c_int, _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, C.c_int,
@@ -158,6 +166,30 @@ def apply_vote_deltas(votes, d_group, d_peer, d_vote):
     dv = np.ascontiguousarray(d_vote, dtype=np.uint8)
     lib().rq_oracle_apply_vote_deltas(votes, G, N, G, dg, dp, dv, dg.size)
     return votes
+
+
+def tick_rand(seed: int, tick_no: int, group: int) -> int:
+    return int(lib().rq_oracle_tick_rand(seed, tick_no, group))
+
+
+def tick(role, elapsed, election_tick: int, heartbeat_tick: int, seed: int, tick_no: int):
+    """-> (elapsed' [G] u32, action [G] u8, n_hup, n_beat)"""
+    role = np.ascontiguousarray(role, dtype=np.uint8)
+    el = np.ascontiguousarray(elapsed, dtype=np.uint32).copy()
+    act = np.empty(role.size, dtype=np.uint8)
+    h, b = C.c_uint64(0), C.c_uint64(0)
+    lib().rq_oracle_tick(role, el, role.size, election_tick, heartbeat_tick, seed, tick_no, act, C.byref(h), C.byref(b))
+    return el, act, int(h.value), int(b.value)
+
+
+def campaign(role, elapsed, votes, groups, self_peer: int = 0):
+    role = np.ascontiguousarray(role, dtype=np.uint8).copy()
+    el = np.ascontiguousarray(elapsed, dtype=np.uint32).copy()
+    votes = np.ascontiguousarray(votes, dtype=np.uint8).copy()
+    N, G = votes.shape
+    gs = np.ascontiguousarray(groups, dtype=np.uint64)
+    lib().rq_oracle_campaign(role, el, votes, G, N, G, gs, gs.size, self_peer)
+    return role, el, votes
 
 
 def timed_sweeps(kind: int, threads: int, sweeps: int, match, committed, votes=None,

@@ -210,6 +210,65 @@ void rq_oracle_apply_vote_deltas(uint8_t* votes, size_t ld, int n, size_t G,
 }
 
 /* ------------------------------------------------------------------------ */
+/* batched Tick: rc.node.Tick() every 100 ms (raft.go:207, 223-224)          */
+
+uint32_t rq_oracle_tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
+  uint64_t z = (seed ^ (tick_no * 0xD1B54A32D192ED03ull)) + (group + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+/* etcd raft.tickHeartbeat (leaders):
+ *     r.elapsed++; if r.elapsed >= r.heartbeatTimeout { r.elapsed = 0; Step(MsgBeat) }
+ * etcd raft.tickElection (followers, candidates):
+ *     r.elapsed++; if r.isElectionTimeout() { r.elapsed = 0; Step(MsgHup) }
+ * etcd raft.isElectionTimeout:
+ *     d := r.elapsed - r.electionTimeout; if d < 0 { return false }
+ *     return d > r.rand.Int() % r.electionTimeout                              */
+void rq_oracle_tick(const uint8_t* role, uint32_t* elapsed, size_t G, uint32_t election_tick,
+                    uint32_t heartbeat_tick, uint64_t seed, uint64_t tick_no, uint8_t* action_out,
+                    uint64_t* n_hup, uint64_t* n_beat) {
+  uint64_t hup = 0, beat = 0;
+  for (size_t g = 0; g < G; ++g) {
+    uint8_t act = 0;
+    uint32_t e = elapsed[g] + 1;
+    if (role[g] == 2) {
+      if (e >= heartbeat_tick) {
+        e = 0;
+        act = 2;
+      }
+    } else {
+      const int64_t d = (int64_t)e - (int64_t)election_tick;
+      if (d >= 0 && d > (int64_t)(rq_oracle_tick_rand(seed, tick_no, g) % election_tick)) {
+        e = 0;
+        act = 1;
+      }
+    }
+    elapsed[g] = e;
+    action_out[g] = act;
+    hup += (act == 1);
+    beat += (act == 2);
+  }
+  if (n_hup) *n_hup = hup;
+  if (n_beat) *n_beat = beat;
+}
+
+/* etcd raft.campaign -> becomeCandidate: r.reset(term+1) clears r.votes and
+ * r.elapsed, r.Vote = r.id, state = candidate; then poll(r.id, true). */
+void rq_oracle_campaign(uint8_t* role, uint32_t* elapsed, uint8_t* votes, size_t ld, int n, size_t G,
+                        const uint64_t* groups, size_t ng, uint32_t self_peer) {
+  for (size_t i = 0; i < ng; ++i) {
+    const uint64_t g = groups[i];
+    if (g >= G) continue;
+    role[g] = 1;
+    elapsed[g] = 0;
+    for (int p = 0; p < n; ++p) votes[(size_t)p * ld + g] = ((uint32_t)p == self_peer) ? 1 : 0;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
 /* timed CPU baselines                                                      */
 
 #define CE_DESC(a, b)            \

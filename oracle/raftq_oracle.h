@@ -74,6 +74,20 @@ void rq_oracle_apply_vote_deltas(uint8_t* votes, size_t ld, int n, size_t G,
                                  const uint64_t* d_group, const uint32_t* d_peer,
                                  const uint8_t* d_vote, size_t nd);
 
+/* ---- batched Tick: etcd raft.tickElection / tickHeartbeat ----
+ * role: 0 follower, 1 candidate, 2 leader.  action_out: 0 none, 1 MsgHup
+ * (campaign), 2 MsgBeat (heartbeat).  The randomised election timeout uses a
+ * counter-based splitmix64 stream instead of Go's math/rand (which cannot be
+ * reproduced without the Go runtime): rnd = splitmix64(seed, tick_no, group) >> 32. */
+uint32_t rq_oracle_tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group);
+void rq_oracle_tick(const uint8_t* role, uint32_t* elapsed /*in/out*/, size_t G, uint32_t election_tick,
+                    uint32_t heartbeat_tick, uint64_t seed, uint64_t tick_no, uint8_t* action_out,
+                    uint64_t* n_hup, uint64_t* n_beat);
+/* becomeCandidate for the listed groups: role = candidate, every vote slot
+ * cleared, the candidate's own slot granted, elapsed = 0. */
+void rq_oracle_campaign(uint8_t* role, uint32_t* elapsed, uint8_t* votes, size_t ld, int n, size_t G,
+                        const uint64_t* groups, size_t ng, uint32_t self_peer);
+
 /* ---- timed CPU baselines (bench.py cpu_baseline leg) -------------------- */
 /* kind 0: reference-shaped loop (malloc N-slice, sort desc, index q-1, scan
  * votes); kind 1: tight selection network, no allocation.  Runs `sweeps`

@@ -30,6 +30,10 @@ class Counts(C.Structure):
     _fields_ = [("n_changed", C.c_uint64), ("n_won", C.c_uint64), ("n_lost", C.c_uint64)]
 
 
+class TickCounts(C.Structure):
+    _fields_ = [("n_hup", C.c_uint64), ("n_beat", C.c_uint64)]
+
+
 class Delta(C.Structure):
     _fields_ = [("group", C.c_uint64), ("match", C.c_uint64), ("peer", C.c_uint32), ("_pad", C.c_uint32)]
 
@@ -70,6 +74,12 @@ _SIGS = [
     ("raftq_read_match", C.c_int, [_H, C.c_void_p]),
     ("raftq_read_votes", C.c_int, [_H, C.c_void_p]),
     ("raftq_collect_changed", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_set_timers", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint64]),
+    ("raftq_load_roles", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("raftq_tick", C.c_int, [_H, C.POINTER(TickCounts)]),
+    ("raftq_read_tick", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("raftq_collect_hups", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_campaign", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint32]),
     ("raftq_cycle", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_uint64), C.POINTER(Counts)]),
     ("raftq_stage", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -73,6 +73,15 @@ struct raftq {
   uint64_t adv_cap = 0;
   uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
   uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
+  // batched Tick state, lazily allocated
+  uint8_t* role = nullptr;      // [ld]
+  uint32_t* elapsed = nullptr;  // [ld]
+  uint8_t* action = nullptr;    // [ld]
+  uint64_t* hup_bits = nullptr; // [gpad/64]
+  uint4* tick_partials = nullptr;  // [gpad/256]
+  uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
+  uint64_t tick_seed = 0x1000, tick_no = 0;
+  bool ticked = false;
   uint64_t* d_total = nullptr;  // device alias of h_total
   bool have_terms = false;
   unsigned last_flags = 0;
@@ -298,6 +307,11 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->partials);
   (void)hipFree(h->offsets);
   (void)hipFree(h->claim);
+  (void)hipFree(h->role);
+  (void)hipFree(h->elapsed);
+  (void)hipFree(h->action);
+  (void)hipFree(h->hup_bits);
+  (void)hipFree(h->tick_partials);
   if (h->stage_h) (void)hipHostFree(h->stage_h);
   if (h->adv_h) (void)hipHostFree(h->adv_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -576,6 +590,129 @@ int raftq_vote_tally(raftq_t* h, uint8_t* outcome_out, raftq_counts_t* counts) {
   if (int rc = raftq_wait(h, &c)) return rc;
   if (counts) *counts = c;
   if (outcome_out) return raftq_read_outcome(h, outcome_out);
+  return RAFTQ_OK;
+}
+
+static int ensure_tick_state(raftq_t* h) {
+  if (h->role) return RAFTQ_OK;
+  auto alloc = [&](void** p, size_t bytes) -> int {
+    HIPCHK(h, hipMalloc(p, bytes));
+    HIPCHK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
+    return RAFTQ_OK;
+  };
+  if (int rc = alloc((void**)&h->role, h->ld)) return rc;
+  if (int rc = alloc((void**)&h->elapsed, h->ld * 4)) return rc;
+  if (int rc = alloc((void**)&h->action, h->ld)) return rc;
+  if (int rc = alloc((void**)&h->hup_bits, h->gpad / 8)) return rc;
+  if (int rc = alloc((void**)&h->tick_partials, h->gpad / 256 * sizeof(uint4))) return rc;
+  return RAFTQ_OK;
+}
+
+int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (election_tick == 0 || heartbeat_tick == 0)
+    return fail(h, RAFTQ_EINVAL, "raftq_set_timers: ticks must be >= 1");
+  h->election_tick = election_tick;
+  h->heartbeat_tick = heartbeat_tick;
+  h->tick_seed = seed;
+  return RAFTQ_OK;
+}
+
+int raftq_load_roles(raftq_t* h, const uint8_t* role, const uint32_t* elapsed) {
+  if (int rc = use_device(h)) return rc;
+  if (!role) return fail(h, RAFTQ_EINVAL, "raftq_load_roles: null role array");
+  for (uint64_t g = 0; g < h->G; ++g)
+    if (role[g] > RAFTQ_ROLE_LEADER) return fail(h, RAFTQ_EINVAL, "raftq_load_roles: role must be 0, 1 or 2");
+  if (int rc = ensure_tick_state(h)) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->role, role, h->G, hipMemcpyHostToDevice, h->stream));
+  if (elapsed) HIPCHK(h, hipMemcpyAsync(h->elapsed, elapsed, h->G * 4, hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(h, hipMemsetAsync(h->elapsed, 0, h->ld * 4, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (int rc = ensure_tick_state(h)) return rc;
+  TickArgs a;
+  a.role = h->role;
+  a.elapsed = h->elapsed;
+  a.action = h->action;
+  a.hup_bits = h->hup_bits;
+  a.partials = h->tick_partials;
+  a.n_groups = h->G;
+  a.seed = h->tick_seed;
+  a.tick_no = h->tick_no++;
+  a.election_tick = h->election_tick;
+  a.heartbeat_tick = h->heartbeat_tick;
+  hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  h->ticked = true;
+  if (counts) {
+    const uint64_t nw = h->gpad / 256;
+    HIPCHK(h, hipMemcpyAsync(h->h_partials, h->tick_partials, nw * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint64_t hup = 0, beat = 0;
+    for (uint64_t i = 0; i < nw; ++i) {
+      hup += h->h_partials[i].x;
+      beat += h->h_partials[i].y;
+    }
+    counts->n_hup = hup;
+    counts->n_beat = beat;
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_read_tick(raftq_t* h, uint8_t* action, uint32_t* elapsed, uint8_t* role) {
+  if (int rc = use_device(h)) return rc;
+  if (!h->role) return fail(h, RAFTQ_ESTATE, "raftq_read_tick: no tick state (raftq_load_roles / raftq_tick first)");
+  if (action) HIPCHK(h, hipMemcpyAsync(action, h->action, h->G, hipMemcpyDeviceToHost, h->stream));
+  if (elapsed) HIPCHK(h, hipMemcpyAsync(elapsed, h->elapsed, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+  if (role) HIPCHK(h, hipMemcpyAsync(role, h->role, h->G, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) {
+  if (int rc = use_device(h)) return rc;
+  if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null count");
+  if (!h->ticked) return fail(h, RAFTQ_ESTATE, "raftq_collect_hups: no raftq_tick yet");
+  if (cap && !groups) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null out with cap > 0");
+  const uint64_t take_cap = std::min<uint64_t>(cap, h->G);
+  // the advance buffer doubles as the (smaller) group-id list: 8 B of every 24
+  if (take_cap)
+    if (int rc = ensure_adv(h, (take_cap + 2) / 3 + 1)) return rc;
+  const uint64_t nw = h->gpad / 256;
+  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets,
+                     h->d_total);
+  if (take_cap)
+    hipLaunchKernelGGL(compact_hups_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream,
+                       h->hup_bits, h->offsets, (uint64_t*)h->adv_d, take_cap);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t total = *h->h_total;
+  *n = total;
+  const uint64_t take = std::min(total, take_cap);
+  if (take) std::memcpy(groups, h->adv_h, take * 8);
+  h->adv_listed = 0;
+  return RAFTQ_OK;
+}
+
+int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self_peer) {
+  if (int rc = use_device(h)) return rc;
+  if (n == 0) return RAFTQ_OK;
+  if (!groups) return fail(h, RAFTQ_EINVAL, "raftq_campaign: null argument");
+  if (self_peer >= h->N) return fail(h, RAFTQ_EINVAL, "raftq_campaign: self_peer out of range");
+  uint64_t bad = 0;
+  for (uint64_t i = 0; i < n; ++i) bad |= (uint64_t)(groups[i] >= h->G);
+  if (bad) return fail(h, RAFTQ_EINVAL, "raftq_campaign: a group is out of range; nothing applied");
+  if (int rc = ensure_tick_state(h)) return rc;
+  if (int rc = ensure_staging(h, (size_t)n * 8)) return rc;
+  std::memcpy(h->stage_h, groups, n * 8);
+  hipLaunchKernelGGL(campaign_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                     h->role, h->elapsed, h->votes, h->ld, h->N, self_peer, (const uint64_t*)h->stage_d, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
 }
 

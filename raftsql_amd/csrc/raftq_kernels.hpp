@@ -532,4 +532,102 @@ __global__ __launch_bounds__(kBlock) void compact_changed_kernel(const uint64_t*
   }
 }
 
+// ---------------------------------------------------------------------------
+// Batched Tick: rc.node.Tick() (raft.go:223-224) for every
+// group at once -- etcd raft.tickElection / tickHeartbeat / isElectionTimeout.
+// A lane owns 4 consecutive groups: one 16-byte load/store of `elapsed`, one
+// 4-byte load of `role`, one 4-byte store of `action`.  10 B per group: HBM /
+// launch bound.  MsgHup groups are flagged in a lane-ordered bitmap (word k of
+// a wave's 4 = its groups 4*lane + k) that compact_hups_kernel turns into an
+// ascending list, with the same scan as the commit compaction.
+struct TickArgs {
+  const uint8_t* role;   // 0 follower, 1 candidate, 2 leader
+  uint32_t* elapsed;     // in/out
+  uint8_t* action;       // 0 none, 1 MsgHup, 2 MsgBeat
+  uint64_t* hup_bits;    // [gpad/64]
+  uint4* partials;       // [gpad/256] {hup, beat, 0, 0} per wave
+  uint64_t n_groups;     // padding groups never act
+  uint64_t seed, tick_no;
+  uint32_t election_tick, heartbeat_tick;
+};
+
+__device__ __forceinline__ uint32_t tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
+  uint64_t z = (seed ^ (tick_no * 0xD1B54A32D192ED03ull)) + (group + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+__global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t g = ((uint64_t)blockIdx.x * kBlock + tid) * 4;
+  const uint32_t roles = *reinterpret_cast<const uint32_t*>(a.role + g);
+  uint4 el = *reinterpret_cast<const uint4*>(a.elapsed + g);
+  uint32_t e[4] = {el.x, el.y, el.z, el.w};
+  uint32_t acts = 0;
+  uint32_t n_hup = 0, n_beat = 0;  // wave-uniform
+  uint64_t hb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t role = (roles >> (8 * k)) & 0xffu;
+    const bool valid = g + k < a.n_groups;
+    uint32_t v = e[k] + 1;
+    const bool beat = role == 2u && v >= a.heartbeat_tick;
+    const int64_t d = (int64_t)v - (int64_t)a.election_tick;
+    const bool hup = role != 2u && d >= 0 && d > (int64_t)(tick_rand(a.seed, a.tick_no, g + k) % a.election_tick);
+    const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
+    e[k] = !valid ? e[k] : (act ? 0u : v);
+    acts |= act << (8 * k);
+    hb[k] = __ballot(act == 1u);
+    n_hup += __popcll(hb[k]);
+    n_beat += __popcll(__ballot(act == 2u));
+  }
+  el.x = e[0]; el.y = e[1]; el.z = e[2]; el.w = e[3];
+  *reinterpret_cast<uint4*>(a.elapsed + g) = el;
+  *reinterpret_cast<uint32_t*>(a.action + g) = acts;
+  if (lane == 0) {
+    const uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * 4;  // 4 words per wave (256 groups)
+    u64x2 lo, hi;
+    lo.x = hb[0]; lo.y = hb[1]; hi.x = hb[2]; hi.y = hb[3];
+    *reinterpret_cast<u64x2*>(a.hup_bits + w0) = lo;
+    *reinterpret_cast<u64x2*>(a.hup_bits + w0 + 2) = hi;
+    uint4 r;
+    r.x = n_hup; r.y = n_beat; r.z = 0; r.w = 0;
+    a.partials[(uint64_t)blockIdx.x * kWaves + wave] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hup_bits, const uint64_t* offsets,
+                                                              uint64_t* out, uint64_t cap) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t wv = (uint64_t)blockIdx.x * kWaves + wave;
+  const uint64_t pos = offsets[wv];
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint64_t b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = hup_bits[wv * 4 + k];
+  uint64_t rank = pos + __popcll(b[0] & below) + __popcll(b[1] & below) + __popcll(b[2] & below) + __popcll(b[3] & below);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((b[k] >> lane) & 1) {
+      if (rank < cap) out[rank] = wv * 256 + 4ull * lane + k;
+      ++rank;
+    }
+  }
+}
+
+// becomeCandidate for a list of (distinct) groups: role = candidate, elapsed = 0,
+// every vote slot cleared, the candidate's own slot granted.  Byte stores.
+__global__ __launch_bounds__(kBlock) void campaign_kernel(uint8_t* role, uint32_t* elapsed, uint8_t* votes,
+                                                          uint64_t ld, uint32_t n_peers, uint32_t self_peer,
+                                                          const uint64_t* __restrict__ groups, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t g = groups[i];
+  role[g] = 1;
+  elapsed[g] = 0;
+  for (uint32_t p = 0; p < n_peers; ++p) votes[(uint64_t)p * ld + g] = p == self_peer ? 1 : 0;
+}
+
 }  // namespace raftqk

@@ -278,6 +278,45 @@ class QuorumEngine:
         a = np.frombuffer(arr, dtype=np.dtype([("group", "<u8"), ("old_commit", "<u8"), ("new_commit", "<u8")]))
         return a[: min(int(n.value), cap)].copy(), int(n.value)
 
+    # -- batched Tick --------------------------------------
+    def set_timers(self, election_tick: int = 10, heartbeat_tick: int = 1, seed: int = 0x1000) -> None:
+        self._chk(self._lib.raftq_set_timers(self._h, election_tick, heartbeat_tick, seed))
+
+    def load_roles(self, role: np.ndarray, elapsed: Optional[np.ndarray] = None) -> None:
+        r = np.ascontiguousarray(role, dtype=np.uint8)
+        if r.shape != (self.n_groups,):
+            raise ValueError("role must be [G]")
+        e = None if elapsed is None else np.ascontiguousarray(elapsed, dtype=np.uint32)
+        self._chk(self._lib.raftq_load_roles(self._h, _ptr(r), _ptr(e) if e is not None else None))
+
+    def tick(self, want_counts: bool = True):
+        """rc.node.Tick() for every group -> (n_hup, n_beat) | None"""
+        if not want_counts:
+            self._chk(self._lib.raftq_tick(self._h, None))
+            return None
+        c = _lib.TickCounts()
+        self._chk(self._lib.raftq_tick(self._h, C.byref(c)))
+        return int(c.n_hup), int(c.n_beat)
+
+    def read_tick(self):
+        """-> (action [G] u8, elapsed [G] u32, role [G] u8)"""
+        a = np.empty(self.n_groups, dtype=np.uint8)
+        e = np.empty(self.n_groups, dtype=np.uint32)
+        r = np.empty(self.n_groups, dtype=np.uint8)
+        self._chk(self._lib.raftq_read_tick(self._h, _ptr(a), _ptr(e), _ptr(r)))
+        return a, e, r
+
+    def collect_hups(self, cap: Optional[int] = None):
+        cap = self.n_groups if cap is None else int(cap)
+        out = np.empty(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_collect_hups(self._h, _ptr(out) if cap else None, cap, C.byref(n)))
+        return out[: min(cap, int(n.value))], int(n.value)
+
+    def campaign(self, groups, self_peer: int = 0) -> None:
+        g = np.ascontiguousarray(groups, dtype=np.uint64)
+        self._chk(self._lib.raftq_campaign(self._h, _ptr(g) if len(g) else None, len(g), self_peer))
+
     # -- measurement ------------------------------------------------------
     def timer_begin(self) -> None:
         self._chk(self._lib.raftq_timer_begin(self._h))

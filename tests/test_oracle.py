@@ -193,3 +193,68 @@ def test_timed_baseline_outputs_are_the_oracle_answers(oracle):
         ref, _ = oracle.commit_advance(s2.match, s2.committed)
         _, c, _ = oracle.timed_sweeps(1, 1, 1, s2.match, s2.committed)
         assert np.array_equal(c, ref)
+
+
+# ---- batched Tick --------------------------------------------------------------
+def test_tick_leader_heartbeats(oracle):
+    role = np.full(4, 2, dtype=np.uint8)
+    el = np.zeros(4, dtype=np.uint32)
+    # HeartbeatTick 1 (raft.go:155): a leader beats on every tick and its counter stays 0
+    for t in range(5):
+        el, act, hup, beat = oracle.tick(role, el, 10, 1, 7, t)
+        assert list(act) == [2, 2, 2, 2] and (hup, beat) == (0, 4) and not el.any()
+    # heartbeat every 3rd tick
+    seq = []
+    for t in range(7):
+        el, act, _, _ = oracle.tick(role, el, 10, 3, 7, t)
+        seq.append(int(act[0]))
+    assert seq == [0, 0, 2, 0, 0, 2, 0]
+
+
+def test_tick_election_timeout_window(oracle):
+    """isElectionTimeout: never before elapsed > ElectionTick, always by 2*ElectionTick."""
+    G, et = 5000, 10
+    role = (np.arange(G) % 2).astype(np.uint8)  # followers and candidates time out alike
+    el = np.zeros(G, dtype=np.uint32)
+    fired_at = np.zeros(G, dtype=np.int64)
+    for t in range(1, 3 * et):
+        el, act, hup, beat = oracle.tick(role, el, et, 1, 99, t)
+        assert beat == 0 and hup == int((act == 1).sum())
+        newly = (act == 1) & (fired_at == 0)
+        fired_at[newly] = t
+        assert np.all(el[act == 1] == 0)
+    assert fired_at.min() == et + 1 and fired_at.max() <= 2 * et
+    # spread over the window, not all at once (that is the point of the randomisation)
+    assert len(np.unique(fired_at)) == et
+    # deterministic: same seed, same schedule
+    el2 = np.zeros(G, dtype=np.uint32)
+    for t in range(1, et + 3):
+        el2, act2, _, _ = oracle.tick(role, el2, et, 1, 99, t)
+    el3 = np.zeros(G, dtype=np.uint32)
+    for t in range(1, et + 3):
+        el3, act3, _, _ = oracle.tick(role, el3, et, 1, 99, t)
+    assert np.array_equal(act2, act3) and np.array_equal(el2, el3)
+
+
+def test_tick_hand_checked_draw(oracle):
+    # one group, walk the rule by hand with the documented stream
+    et, seed = 10, 0x1000
+    el = np.zeros(1, dtype=np.uint32)
+    role = np.zeros(1, dtype=np.uint8)
+    for t in range(40):
+        before = int(el[0])
+        el, act, _, _ = oracle.tick(role, el, et, 1, seed, t)
+        d = before + 1 - et
+        expect = d >= 0 and d > oracle.tick_rand(seed, t, 0) % et
+        assert int(act[0]) == (1 if expect else 0)
+        assert int(el[0]) == (0 if expect else before + 1)
+
+
+def test_campaign_semantics(oracle):
+    role = np.array([0, 2, 0, 1], dtype=np.uint8)
+    el = np.array([5, 6, 7, 8], dtype=np.uint32)
+    votes = np.full((3, 4), 2, dtype=np.uint8)
+    r, e, v = oracle.campaign(role, el, votes, [0, 3, 99], self_peer=0)
+    assert list(r) == [1, 2, 0, 1] and list(e) == [0, 6, 7, 0]
+    assert v[:, 0].tolist() == [1, 0, 0] and v[:, 3].tolist() == [1, 0, 0]
+    assert v[:, 1].tolist() == [2, 2, 2] and v[:, 2].tolist() == [2, 2, 2]

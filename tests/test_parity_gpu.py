@@ -394,3 +394,67 @@ def test_timer_and_stream(gpu_engine_cls):
             e.step_async(SWEEP_COMMIT | SWEEP_NO_ADOPT)
         ms = e.timer_end()
         assert 0.0 < ms < 1000.0
+
+
+@pytest.mark.parametrize("G", [1, 255, 256, 257, 1023, 1025, 4096, 70001])
+def test_tick_parity(gpu_engine_cls, oracle, G):
+    """Batched Tick (raft.go:223-224) vs the oracle over many ticks, ragged G, mixed roles."""
+    rng = np.random.default_rng(G)
+    role = rng.integers(0, 3, G).astype(np.uint8)
+    el = rng.integers(0, 25, G).astype(np.uint32)
+    for et, hb, seed in ((10, 1, 0x1000), (7, 3, 12345)):
+        with gpu_engine_cls(G, 3) as e:
+            e.set_timers(et, hb, seed)
+            e.load_roles(role, el)
+            ref_el = el.copy()
+            for t in range(25):
+                hup, beat = e.tick()
+                ref_el, ref_act, rh, rb = oracle.tick(role, ref_el, et, hb, seed, t)
+                act, got_el, got_role = e.read_tick()
+                assert (hup, beat) == (rh, rb)
+                assert np.array_equal(act, ref_act) and np.array_equal(got_el, ref_el)
+                assert np.array_equal(got_role, role)
+                hups, n = e.collect_hups()
+                assert n == rh and np.array_equal(hups, np.nonzero(ref_act == 1)[0].astype(np.uint64))
+            hups2, n2 = e.collect_hups(cap=2)
+            assert n2 == rh and len(hups2) == min(2, rh)
+
+
+def test_election_round_trip(gpu_engine_cls, oracle):
+    """Tick -> MsgHup list -> campaign -> MsgVoteResp deltas -> tally: the election half of the
+    path end to end on the device, checked step by step against the oracle."""
+    rng = np.random.default_rng(17)
+    G, n = 20000, 5
+    role = np.zeros(G, dtype=np.uint8)
+    role[::7] = 2  # some groups already have a leader here
+    with gpu_engine_cls(G, n) as e:
+        e.set_timers(10, 1, 42)
+        e.load_roles(role)
+        ref_role, ref_el = role.copy(), np.zeros(G, dtype=np.uint32)
+        ref_votes = np.zeros((n, G), dtype=np.uint8)
+        campaigned = np.zeros(G, dtype=bool)
+        for t in range(22):
+            hup, beat = e.tick()
+            ref_el, ref_act, rh, rb = oracle.tick(ref_role, ref_el, 10, 1, 42, t)
+            assert (hup, beat) == (rh, rb)
+            hups, _ = e.collect_hups()
+            if len(hups):
+                e.campaign(hups, self_peer=0)
+                ref_role, ref_el, ref_votes = oracle.campaign(ref_role, ref_el, ref_votes, hups, 0)
+                campaigned[hups.astype(np.int64)] = True
+        act, got_el, got_role = e.read_tick()
+        assert np.array_equal(got_role, ref_role) and np.array_equal(got_el, ref_el)
+        assert np.array_equal(e.read_votes(), ref_votes)
+        assert campaigned[role == 0].all() and not campaigned[role == 2].any()
+        # peers answer: random grants / rejections for the candidates
+        cands = np.nonzero(ref_role == 1)[0]
+        vg = np.repeat(cands, n - 1).astype(np.uint64)
+        vp = np.tile(np.arange(1, n, dtype=np.uint32), len(cands))
+        vv = rng.integers(1, 3, len(vg)).astype(np.uint8)
+        keep = rng.random(len(vg)) < 0.8  # some answers never arrive
+        e.apply_vote_deltas(vg[keep], vp[keep], vv[keep])
+        ref_votes = oracle.apply_vote_deltas(ref_votes, vg[keep], vp[keep], vv[keep])
+        out, cnt = e.vote_tally()
+        oc, w, l = oracle.vote_tally(ref_votes)
+        assert np.array_equal(out, oc) and (cnt.n_won, cnt.n_lost) == (w, l)
+        assert w > 0 and l > 0 and (oc[cands] == 0).any()

@@ -163,6 +163,30 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
     }
 
 
+def tick_measure(cfg, device, ticks=2000):
+    """rc.node.Tick() for every group as one launch (10 B per group: role 1 +
+    elapsed 4+4 + action 1).  1M groups is 10 MB -> cache-resident and launch-bound; reported as is."""
+    from raftsql_amd.engine import QuorumEngine
+
+    G = cfg["G"]
+    e = QuorumEngine(G, cfg["N"], device=device)
+    role = (np.arange(G) % 3).astype(np.uint8)
+    e.load_roles(role)
+    for _ in range(50):
+        e.tick(want_counts=False)
+    e.wait()
+    e.timer_begin()
+    for _ in range(ticks):
+        e.tick(want_counts=False)
+    ms = e.timer_end()
+    hup, beat = e.tick()
+    e.close()
+    us = ms * 1e3 / ticks
+    return {"what": "batched Tick (tickElection/tickHeartbeat) over all groups", "groups": G, "launch_us": us,
+            "group_ticks_per_s": G / (us * 1e-6), "GBps": 10.0 * G / (us * 1e-6) / 1e9,
+            "last_tick": {"n_hup": hup, "n_beat": beat}}
+
+
 def timed_loop(engines, flags, steps, world, dist):
     """Barrier + sync, K steps, barrier + sync.  -> (wall_s, event_ms)."""
     import torch
@@ -340,6 +364,7 @@ def main():
         e.close()
     if world.rank == 0 and world.size == 1 and not args.no_extras:
         out["pipeline"] = pipeline_measure(cfg, device)
+        out["tick"] = tick_measure(cfg, device)
         out["other_configs"] = {
             f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
             for c in sorted(CONFIGS) if c != args.config

@@ -197,6 +197,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
         f[j] = NT ? ld_stream(src) : *src;
       }
     }
+    // (A/B, profiles/r01/tune_sched_barrier.txt: forcing every load ahead of the first compare with
+    // a sched_barrier is SLOWER -- 12.5 vs 12.3 us at N=5, 50 vs 30 us at N=7 from register
+    // pressure; hipcc's own split of 8 loads up front + 4 interleaved is kept.)
 #pragma unroll
     for (int j = 0; j < kRounds; ++j) {
       const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);

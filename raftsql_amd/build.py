@@ -70,9 +70,24 @@ def build_tuner(force: bool = False) -> str | None:
     return TUNER
 
 
+def build_tuner2(force: bool = False) -> str | None:
+    """Second tuner: layout / instruction-count A/B (profiles/r01/tune2_*.jsonl)."""
+    src = os.path.join(CSRC, "raftq_tune2.hip")
+    out = TUNER + "2"
+    if not os.path.exists(src):
+        return None
+    if not force and not _stale(out, [src, os.path.join(CSRC, "raftq_kernels.hpp")]):
+        return out
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "-o", out, src]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_lib(force=force)
     build_tuner(force=force)
+    build_tuner2(force=force)
 
 
 if __name__ == "__main__":

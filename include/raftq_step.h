@@ -1,0 +1,135 @@
+/*
+ * raftq_step.h -- C-ABI of the batched raft `Step`.
+ *
+ * The reference hands every inbound peer message to the consensus core one at
+ * a time:  raftNode.Process -> rc.node.Step(ctx, m)   (raft.go:268-270), and
+ * drives the local timers through rc.node.Tick() (raft.go:223-224).  With G
+ * groups per process that is G goroutine sets and one channel hand-off per
+ * message.  raftq_step_batch() is the vectorised replacement: one call takes
+ * a batch of messages addressed to any of the handle's G groups, applies
+ * etcd's raft.Step / stepLeader / stepCandidate / stepFollower to the
+ * device-resident group state, and returns one result record per message.
+ *
+ * What lives on the device (per group): Term, Vote, lead, role, the election
+ * clock (shared with raftq_tick), raftLog.committed / lastIndex / lastTerm,
+ * every peer's Progress.Match, the candidate's vote map and the compact
+ * current-term gate.  What stays with the caller: the log entries themselves
+ * (so MsgProp / MsgSnap are not accepted and MsgApp is processed as a header:
+ * the term / leader / clock handling happens here, raftLog.maybeAppend runs on
+ * the caller's log and is reported back with raftq_apply_log_deltas), and the
+ * replication flow control (Progress.Next / probe / replicate / inflights),
+ * which decides what to send, not what is committed.
+ *
+ * Ordering: messages of one group are applied in batch order, exactly as if
+ * Step had been called for them one after another; messages of different
+ * groups are independent (raft groups share nothing).
+ *
+ * The arithmetic restated here lives in the un-vendored dependency
+ * github.com/coreos/etcd/raft (2015-era API): PARITY
+ * UNPINNED; the checker is oracle/raftq_step_oracle.c.
+ */
+#ifndef RAFTQ_STEP_H
+#define RAFTQ_STEP_H
+
+#include "raftq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* raftpb.MessageType values of the message kinds Step accepts */
+#define RAFTQ_MSG_HUP 0            /* local: election timer fired (raftq_tick's MsgHup) */
+#define RAFTQ_MSG_BEAT 1           /* local: heartbeat timer fired (raftq_tick's MsgBeat) */
+#define RAFTQ_MSG_APP 3            /* header only (see above) */
+#define RAFTQ_MSG_APP_RESP 4
+#define RAFTQ_MSG_VOTE 5
+#define RAFTQ_MSG_VOTE_RESP 6
+#define RAFTQ_MSG_HEARTBEAT 8
+#define RAFTQ_MSG_HEARTBEAT_RESP 9
+
+/* one inbound message: the fields of raftpb.Message that Step reads */
+typedef struct raftq_msg {
+  uint64_t group;
+  uint64_t term;        /* m.Term; 0 marks a local message (MsgHup / MsgBeat) */
+  uint64_t log_term;    /* m.LogTerm: MsgVote = candidate's last term */
+  uint64_t index;       /* m.Index: MsgVote = candidate's last index; MsgAppResp = acked / rejected index */
+  uint64_t commit;      /* m.Commit: MsgHeartbeat */
+  uint64_t reject_hint; /* m.RejectHint (MsgAppResp with reject; passes through to the caller) */
+  uint32_t from;        /* sender's peer slot 0..N-1 (raft ID - 1); ignored for local messages */
+  uint8_t type;         /* RAFTQ_MSG_* */
+  uint8_t reject;       /* m.Reject */
+  uint8_t _pad[2];
+  uint64_t _resv;       /* library use */
+} raftq_msg_t;          /* 64 bytes */
+
+/* what Step did with message i: out[i] answers msgs[i] */
+#define RAFTQ_OUT_NONE 0            /* ignored: stale term, or this role does not handle the type */
+#define RAFTQ_OUT_VOTE_RESP 1       /* send MsgVoteResp{To: to, Term: term, Reject: reject} */
+#define RAFTQ_OUT_HEARTBEAT_RESP 2  /* send MsgHeartbeatResp{To: to, Term: term} */
+#define RAFTQ_OUT_CAMPAIGN 3        /* became candidate: send MsgVote{Term: term, Index: index, LogTerm: log_term} to every other peer */
+#define RAFTQ_OUT_BECAME_LEADER 4   /* won the election: append the empty entry {Term: term, Index: index}, then bcastAppend */
+#define RAFTQ_OUT_PROGRESS 5        /* leader took MsgAppResp / MsgHeartbeatResp from `to`: index = Progress.Match now */
+#define RAFTQ_OUT_BCAST_HEARTBEAT 6 /* leader's MsgBeat: send MsgHeartbeat to every other peer */
+#define RAFTQ_OUT_APPEND 7          /* MsgApp header accepted: run raftLog.maybeAppend on the log, then raftq_apply_log_deltas */
+
+#define RAFTQ_OUTF_HARDSTATE 0x01u    /* Term, Vote or Commit changed: HardState must be persisted (wal.Save, raft.go:228) */
+#define RAFTQ_OUTF_COMMITTED 0x02u    /* raftLog.committed advanced (leader: bcastAppend carries it) */
+#define RAFTQ_OUTF_UPDATED 0x04u      /* Progress.maybeUpdate returned true */
+#define RAFTQ_OUTF_STEPPED_DOWN 0x08u /* was leader or candidate, is follower now */
+
+typedef struct raftq_step_out {
+  uint64_t group;
+  uint64_t term;       /* r.Term after the message */
+  uint64_t index;      /* by type, see RAFTQ_OUT_* */
+  uint64_t log_term;   /* by type */
+  uint64_t commit;     /* raftLog.committed after the message */
+  uint64_t last_index; /* raftLog.lastIndex() after the message */
+  uint32_t to;         /* addressee of the response = sender of the message */
+  uint32_t vote;       /* r.Vote after: 0 = None, else peer slot + 1 */
+  uint32_t lead;       /* r.lead after: 0 = None, else peer slot + 1 */
+  uint8_t type;        /* RAFTQ_OUT_* */
+  uint8_t reject;
+  uint8_t flags;       /* RAFTQ_OUTF_* */
+  uint8_t role;        /* RAFTQ_ROLE_* after the message */
+} raftq_step_out_t;    /* 64 bytes */
+
+/* the caller's log changed: it now ends at (last_index, last_term).  Leader
+ * (appendEntry): Progress[self].maybeUpdate(last_index) and maybeCommit.
+ * Follower (handleAppendEntries after maybeAppend): commitTo(min(commit_to,
+ * last_index)); commit_to = 0 leaves the commit index alone. */
+typedef struct raftq_log_delta {
+  uint64_t group;
+  uint64_t last_index;
+  uint64_t last_term;
+  uint64_t commit_to;
+} raftq_log_delta_t;
+
+typedef struct raftq_step_counts {
+  uint64_t n_msgs;
+  uint64_t n_groups_touched;
+} raftq_step_counts_t;
+
+/* which peer slot this process is in every group of the handle (raft ID - 1) */
+int raftq_set_self(raftq_t* h, uint32_t self_peer);
+
+/* bulk load / read-back of the node state ([G] each; any pointer may be NULL).
+ * vote / lead: 0 = None, else peer slot + 1. */
+int raftq_load_node(raftq_t* h, const uint64_t* term, const uint32_t* vote, const uint32_t* lead,
+                    const uint64_t* last_index, const uint64_t* last_term);
+int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, uint64_t* last_index,
+                    uint64_t* last_term, uint64_t* first_idx_cur_term);
+
+/* Step for a batch.  `out` receives n records (out[i] answers msgs[i]); may be
+ * NULL when the caller only wants the state change.  Returns RAFTQ_EINVAL and
+ * applies nothing if any message is malformed (group / from out of range,
+ * unknown type). */
+int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
+                     raftq_step_counts_t* counts);
+
+/* records of one group are applied in order */
+int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTQ_STEP_H */

@@ -21,10 +21,64 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "raftq_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("raftq_oracle.c", "raftq_step_oracle.c", "raftq_oracle.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "raftq_step.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libraftq_oracle.so"])
     return _SO
+
+
+class _NodeStateC(C.Structure):  # == rq_node_state_t
+    _fields_ = [("G", C.c_size_t), ("ld", C.c_size_t), ("n", C.c_int), ("self", C.c_uint32)] + [
+        (k, C.c_void_p) for k in ("role", "elapsed", "term", "vote", "lead", "last_index", "last_term", "committed",
+                                  "first_idx", "match", "votes")]
+
+
+# record layouts of include/raftq_step.h, written out independently of raftsql_amd/step.py
+STEP_MSG_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("log_term", "<u8"), ("index", "<u8"), ("commit", "<u8"),
+                        ("reject_hint", "<u8"), ("from", "<u4"), ("type", "u1"), ("reject", "u1"), ("_pad", "u1", (2,)),
+                        ("_resv", "<u8")])
+STEP_OUT_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("log_term", "<u8"), ("commit", "<u8"),
+                        ("last_index", "<u8"), ("to", "<u4"), ("vote", "<u4"), ("lead", "<u4"), ("type", "u1"),
+                        ("reject", "u1"), ("flags", "u1"), ("role", "u1")])
+STEP_LOG_DELTA_DT = np.dtype([("group", "<u8"), ("last_index", "<u8"), ("last_term", "<u8"), ("commit_to", "<u8")])
+
+
+class NodeState:
+    """One raft node's state for G groups (rq_node_state_t): the oracle side of the batched Step."""
+
+    FIELDS = (("role", np.uint8), ("elapsed", np.uint32), ("term", np.uint64), ("vote", np.uint32),
+              ("lead", np.uint32), ("last_index", np.uint64), ("last_term", np.uint64), ("committed", np.uint64),
+              ("first_idx", np.uint64))
+
+    def __init__(self, n_groups: int, n_peers: int, self_peer: int = 0):
+        self.G, self.N, self.self_peer = int(n_groups), int(n_peers), int(self_peer)
+        for k, dt in self.FIELDS:
+            setattr(self, k, np.zeros(self.G, dtype=dt))
+        self.match = np.zeros((self.N, self.G), dtype=np.uint64)
+        self.votes = np.zeros((self.N, self.G), dtype=np.uint8)
+
+    def _c(self) -> _NodeStateC:
+        c = _NodeStateC(self.G, self.G, self.N, self.self_peer)
+        for k, _ in self.FIELDS:
+            setattr(c, k, getattr(self, k).ctypes.data)
+        c.match, c.votes = self.match.ctypes.data, self.votes.ctypes.data
+        return c
+
+    def step_batch(self, msgs: np.ndarray) -> np.ndarray:
+        """etcd raft.Step for every message, in order -> raftq_step_out_t[]"""
+        m = np.ascontiguousarray(msgs)
+        assert m.dtype.itemsize == 64
+        out = np.zeros(len(m), dtype=STEP_OUT_DT)
+        c = self._c()
+        lib().rq_oracle_step_batch(C.byref(c), m.ctypes.data, len(m), out.ctypes.data)
+        return out
+
+    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> None:
+        a = np.zeros(len(np.atleast_1d(group)), dtype=STEP_LOG_DELTA_DT)
+        a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to
+        c = self._c()
+        lib().rq_oracle_apply_log_deltas(C.byref(c), a.ctypes.data, len(a))
 
 
 _lib = None
@@ -76,6 +130,10 @@ def lib() -> C.CDLL:
         L.rq_oracle_timed_sweeps.argtypes = [
             C.c_int, C.c_int, C.c_int, _u64p, C.c_size_t, C.c_int, C.c_size_t, _u64p, C.c_int,
             C.c_void_p, C.c_void_p, C.c_size_t, _u64p, _u8p]
+        L.rq_oracle_step_batch.restype = None
+        L.rq_oracle_step_batch.argtypes = [C.POINTER(_NodeStateC), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rq_oracle_apply_log_deltas.restype = None
+        L.rq_oracle_apply_log_deltas.argtypes = [C.POINTER(_NodeStateC), C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 

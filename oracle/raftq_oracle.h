@@ -18,9 +18,13 @@
 #define RAFTQ_ORACLE_H
 #include <stddef.h>
 #include <stdint.h>
+
+#include "raftq_step.h" /* record layouts of the batched Step (types only: the oracle links nothing of the product) */
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define RQ_MAX_PEERS 9
 
 /* a5: etcd raft.q() -- quorum size over N voting peers */
 int rq_oracle_quorum(int n);
@@ -87,6 +91,30 @@ void rq_oracle_tick(const uint8_t* role, uint32_t* elapsed /*in/out*/, size_t G,
  * cleared, the candidate's own slot granted, elapsed = 0. */
 void rq_oracle_campaign(uint8_t* role, uint32_t* elapsed, uint8_t* votes, size_t ld, int n, size_t G,
                         const uint64_t* groups, size_t ng, uint32_t self_peer);
+
+/* ---- batched Step (raftq_step_oracle.c) -------------------
+ * One raft node's state for G groups, SoA, caller-owned arrays.  role/elapsed are
+ * the arrays rq_oracle_tick works on; committed/first_idx/match/votes those of the
+ * sweep oracles above.  vote / lead: 0 = None, else peer slot + 1. */
+typedef struct rq_node_state {
+  size_t G, ld; /* groups; row stride of match / votes */
+  int n;        /* voting peers */
+  uint32_t self; /* this node's peer slot */
+  uint8_t* role;
+  uint32_t* elapsed;
+  uint64_t* term;
+  uint32_t* vote;
+  uint32_t* lead;
+  uint64_t* last_index;
+  uint64_t* last_term;
+  uint64_t* committed;
+  uint64_t* first_idx; /* compact current-term gate: first index of Term, 0 = none */
+  uint64_t* match;     /* [n][ld] */
+  uint8_t* votes;      /* [n][ld] */
+} rq_node_state_t;
+/* etcd raft.Step for every message, in order; out[i] answers msgs[i] */
+void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n, raftq_step_out_t* out);
+void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n);
 
 /* ---- timed CPU baselines (bench.py cpu_baseline leg) -------------------- */
 /* kind 0: reference-shaped loop (malloc N-slice, sort desc, index q-1, scan

@@ -89,6 +89,21 @@ _SIGS = [
 ]
 EXPORTS = [s[0] for s in _SIGS]
 
+
+class StepCounts(C.Structure):
+    _fields_ = [("n_msgs", C.c_uint64), ("n_groups_touched", C.c_uint64)]
+
+
+# every symbol include/raftq_step.h declares
+_STEP_SIGS = [
+    ("raftq_set_self", C.c_int, [_H, C.c_uint32]),
+    ("raftq_load_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("raftq_read_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("raftq_step_batch", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(StepCounts)]),
+    ("raftq_apply_log_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+]
+STEP_EXPORTS = [s[0] for s in _STEP_SIGS]
+
 _lib = None
 
 
@@ -114,7 +129,7 @@ def load() -> C.CDLL:
     except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
         pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, res, args in _SIGS:
+    for name, res, args in _SIGS + _STEP_SIGS:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -32,13 +32,20 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+N_UNITS = 3
+
+
 def lib_sources() -> list[str]:
-    """[translation units..., headers...] -- the first two are compiled."""
+    """[translation units..., headers...] -- the first N_UNITS are compiled."""
     return [
         os.path.join(CSRC, "raftq_capi.hip"),
+        os.path.join(CSRC, "raftq_step.hip"),
         os.path.join(CSRC, "raftq_pipe.cpp"),
         os.path.join(CSRC, "raftq_kernels.hpp"),
+        os.path.join(CSRC, "raftq_step_kernels.hpp"),
+        os.path.join(CSRC, "raftq_internal.hpp"),
         os.path.join(ROOT, "include", "raftq.h"),
+        os.path.join(ROOT, "include", "raftq_step.h"),
         os.path.join(ROOT, "include", "raftq_pipe.h"),
     ]
 
@@ -51,7 +58,7 @@ def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = 
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     for k, v in (defines or {}).items():
         cmd.append(f"-D{k}={v}")
-    cmd += ["-o", LIB, srcs[0], srcs[1]]
+    cmd += ["-o", LIB] + srcs[:N_UNITS]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

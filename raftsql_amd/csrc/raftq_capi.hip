@@ -17,7 +17,7 @@
 #include <unordered_set>
 #include <vector>
 
-#include "raftq_kernels.hpp"
+#include "raftq_internal.hpp"
 
 #ifndef RAFTQ_GPL
 #define RAFTQ_GPL 4 /* groups per lane; 4 measured best on MI355X (profiles/tune_r01.txt) */
@@ -44,58 +44,7 @@ thread_local std::string g_err;
 
 }  // namespace
 
-struct raftq {
-  int device = 0;
-  uint64_t G = 0, gpad = 0, ld = 0;  // groups, groups padded to the tile granule, row stride
-  uint32_t N = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  uint64_t* match = nullptr;
-  uint64_t* committed[2] = {nullptr, nullptr};
-  int cur = 0;
-  uint64_t* first_idx = nullptr;
-  uint8_t* votes = nullptr;
-  uint8_t* outcome = nullptr;
-  uint64_t* changed_bits = nullptr;
-  uint4* partials = nullptr;
-  uint4* h_partials = nullptr;  // pinned
-  uint64_t n_partials = 0;      // of the most recent sweep
-  uint64_t max_partials = 0;
-  uint64_t* offsets = nullptr;  // [max_partials + 1]; last = total
-  uint64_t* h_total = nullptr;  // pinned
-  // pinned, device-mapped host buffers: deltas go in, advances come out, both
-  // accessed by the kernels directly over PCIe (no staging memcpy launches)
-  void* stage_h = nullptr;      // delta staging (host pointer)
-  void* stage_d = nullptr;      // same memory, device pointer
-  size_t stage_bytes = 0;
-  Advance* adv_h = nullptr;     // compacted advance list (host pointer)
-  Advance* adv_d = nullptr;
-  uint64_t adv_cap = 0;
-  uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
-  uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
-  // batched Tick state, lazily allocated
-  uint8_t* role = nullptr;      // [ld]
-  uint32_t* elapsed = nullptr;  // [ld]
-  uint8_t* action = nullptr;    // [ld]
-  uint64_t* hup_bits = nullptr; // [gpad/64]
-  uint4* tick_partials = nullptr;  // [gpad/256]
-  uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
-  uint64_t tick_seed = 0x1000, tick_no = 0;
-  bool ticked = false;
-  uint64_t* d_total = nullptr;  // device alias of h_total
-  bool have_terms = false;
-  unsigned last_flags = 0;
-  int last_gpl = kGPL;
-  const uint64_t* last_old = nullptr;
-  const uint64_t* last_new = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::string err;
-  // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
-  double prof[6] = {0, 0, 0, 0, 0, 0};
-  uint64_t prof_n = 0;
-};
-
-namespace {
+namespace raftq_detail {
 
 int fail(raftq_t* h, int code, const std::string& msg) {
   g_err = msg;
@@ -103,14 +52,10 @@ int fail(raftq_t* h, int code, const std::string& msg) {
   return code;
 }
 
-#define HIPCHK(h, expr)                                                                        \
-  do {                                                                                         \
-    hipError_t _e = (expr);                                                                    \
-    if (_e != hipSuccess) {                                                                    \
-      return fail((h), _e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP,                  \
-                  std::string(#expr) + ": " + hipGetErrorString(_e));                          \
-    }                                                                                          \
-  } while (0)
+}  // namespace raftq_detail
+using raftq_detail::fail;
+
+namespace {
 
 template <int N, bool COMMIT, bool GATED, bool VOTES>
 hipError_t launch_reg(const SweepArgs& a, uint64_t gpad, bool stream_nt, hipStream_t s) {
@@ -161,7 +106,8 @@ hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned 
   }
 }
 
-int ensure_staging(raftq_t* h, size_t bytes) {
+}  // namespace
+int raftq_detail::ensure_staging(raftq_t* h, size_t bytes) {
   if (bytes <= h->stage_bytes) return RAFTQ_OK;
   size_t want = std::max(bytes, h->stage_bytes * 2);
   want = std::max<size_t>(want, 1 << 20);
@@ -177,6 +123,7 @@ int ensure_staging(raftq_t* h, size_t bytes) {
   return RAFTQ_OK;
 }
 
+namespace {
 int ensure_adv(raftq_t* h, uint64_t entries) {
   if (entries <= h->adv_cap) return RAFTQ_OK;
   uint64_t want = std::max<uint64_t>(entries, h->adv_cap * 2);
@@ -193,13 +140,15 @@ int ensure_adv(raftq_t* h, uint64_t entries) {
   return RAFTQ_OK;
 }
 
-int use_device(raftq_t* h) {
+}  // namespace
+int raftq_detail::use_device(raftq_t* h) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   HIPCHK(h, hipSetDevice(h->device));
   return RAFTQ_OK;
 }
-
-}  // namespace
+using raftq_detail::ensure_staging;
+using raftq_detail::use_device;
+using raftq_detail::ensure_tick_state;
 
 extern "C" {
 
@@ -238,6 +187,7 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
   h->device = device;
   h->G = n_groups;
   h->N = n_peers;
+  h->last_gpl = kGPL;
   h->gpad = (n_groups + kTileMax - 1) / kTileMax * kTileMax;
   // Row stride = padded groups + a stagger.  Rows exactly 2^k bytes apart put the N+1 row loads of
   // a wave on the same HBM channel at the same instant; 288 groups (2304 B of u64, 288 B of u8 --
@@ -312,6 +262,7 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->action);
   (void)hipFree(h->hup_bits);
   (void)hipFree(h->tick_partials);
+  raftq_detail::free_node_state(h);
   if (h->stage_h) (void)hipHostFree(h->stage_h);
   if (h->adv_h) (void)hipHostFree(h->adv_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
@@ -593,7 +544,9 @@ int raftq_vote_tally(raftq_t* h, uint8_t* outcome_out, raftq_counts_t* counts) {
   return RAFTQ_OK;
 }
 
-static int ensure_tick_state(raftq_t* h) {
+}  // extern "C"
+
+int raftq_detail::ensure_tick_state(raftq_t* h) {
   if (h->role) return RAFTQ_OK;
   auto alloc = [&](void** p, size_t bytes) -> int {
     HIPCHK(h, hipMalloc(p, bytes));
@@ -607,6 +560,8 @@ static int ensure_tick_state(raftq_t* h) {
   if (int rc = alloc((void**)&h->tick_partials, h->gpad / 256 * sizeof(uint4))) return rc;
   return RAFTQ_OK;
 }
+
+extern "C" {
 
 int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");

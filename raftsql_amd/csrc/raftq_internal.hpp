@@ -1,0 +1,87 @@
+// raftq_internal.hpp -- the handle behind raftq_t, shared by the translation units
+// that implement include/raftq.h (raftq_capi.hip) and include/raftq_step.h (raftq_step.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "raftq.h"
+#include "raftq_kernels.hpp"
+
+struct raftq {
+  int device = 0;
+  uint64_t G = 0, gpad = 0, ld = 0;  // groups, groups padded to the tile granule, row stride
+  uint32_t N = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint64_t* match = nullptr;
+  uint64_t* committed[2] = {nullptr, nullptr};
+  int cur = 0;
+  uint64_t* first_idx = nullptr;
+  uint8_t* votes = nullptr;
+  uint8_t* outcome = nullptr;
+  uint64_t* changed_bits = nullptr;
+  uint4* partials = nullptr;
+  uint4* h_partials = nullptr;  // pinned
+  uint64_t n_partials = 0;      // of the most recent sweep
+  uint64_t max_partials = 0;
+  uint64_t* offsets = nullptr;  // [max_partials + 1]; last = total
+  uint64_t* h_total = nullptr;  // pinned
+  // pinned, device-mapped host buffers: deltas go in, advances come out, both
+  // accessed by the kernels directly over PCIe (no staging memcpy launches)
+  void* stage_h = nullptr;      // delta staging (host pointer)
+  void* stage_d = nullptr;      // same memory, device pointer
+  size_t stage_bytes = 0;
+  raftqk::Advance* adv_h = nullptr;     // compacted advance list (host pointer)
+  raftqk::Advance* adv_d = nullptr;
+  uint64_t adv_cap = 0;
+  uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
+  uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
+  // batched Tick state, lazily allocated
+  uint8_t* role = nullptr;      // [ld]
+  uint32_t* elapsed = nullptr;  // [ld]
+  uint8_t* action = nullptr;    // [ld]
+  uint64_t* hup_bits = nullptr; // [gpad/64]
+  uint4* tick_partials = nullptr;  // [gpad/256]
+  uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
+  uint64_t tick_seed = 0x1000, tick_no = 0;
+  bool ticked = false;
+  uint64_t* d_total = nullptr;  // device alias of h_total
+  bool have_terms = false;
+  unsigned last_flags = 0;
+  int last_gpl = 0;
+  const uint64_t* last_old = nullptr;
+  const uint64_t* last_new = nullptr;
+  // batched Step node state (raftq_step.hip), lazily allocated
+  uint32_t self_peer = 0;
+  uint64_t* term = nullptr;        // [ld]
+  uint32_t* vote = nullptr;        // [ld] 0 = None, else slot + 1
+  uint32_t* lead = nullptr;        // [ld]
+  uint64_t* last_index = nullptr;  // [ld]
+  uint64_t* last_term = nullptr;   // [ld]
+  void* step_dev = nullptr;        // device scratch of raftq_step_batch (msgs, keys, order, outs, sort temp)
+  size_t step_dev_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
+  double prof[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t prof_n = 0;
+};
+
+
+namespace raftq_detail {
+int fail(raftq_t* h, int code, const std::string& msg);
+int use_device(raftq_t* h);
+int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped delta staging
+int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
+void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)
+}  // namespace raftq_detail
+
+#define HIPCHK(h, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      return raftq_detail::fail((h), _e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP,    \
+                                std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    }                                                                                          \
+  } while (0)

@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
 
 template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
+static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
   constexpr bool NT = (POLICY & kLdNT) != 0;
   constexpr bool STNT = (POLICY & kStNT) != 0;
   constexpr bool NOSTORE = (POLICY & kNoStore) != 0;
@@ -291,7 +291,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_cvoid_t;
 
 template <int N, int GPL, bool GATED, bool VOTES, bool BITS>
-__global__ __launch_bounds__(kBlock) void sweep_lds_kernel(SweepArgs a) {
+static __global__ __launch_bounds__(kBlock) void sweep_lds_kernel(SweepArgs a) {
   constexpr int kTile = kBlock * GPL;
   constexpr int kRounds = GPL / 2;
   constexpr int kRows = N + 1 + (GATED ? 1 : 0);   // match rows, committed, first_idx
@@ -403,7 +403,7 @@ struct VoteDeltaRec {  // == raftq_vote_delta_t
 
 // Progress.maybeUpdate only ever raises Match, so a batch of MsgAppResp
 // deltas is an order-independent atomic max.
-__global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld,
+static __global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld,
                                                               const DeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, u
 struct TermDeltaRec {  // == raftq_term_delta_t
   uint64_t group, cur_term, first_idx_cur_term;
 };
-__global__ __launch_bounds__(kBlock) void apply_term_deltas_kernel(uint64_t* first_idx,
+static __global__ __launch_bounds__(kBlock) void apply_term_deltas_kernel(uint64_t* first_idx,
                                                                    const TermDeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void apply_term_deltas_kernel(uint64_t* fir
 // atomicMin(batch position); (2) only the claim holder writes the vote (if the
 // slot is still unanswered) and then releases the claim for the next batch.
 // claim[] is u32 [N][ld], UINT32_MAX when free.
-__global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uint64_t ld,
+static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uint64_t ld,
                                                             const VoteDeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uin
   atomicMin(claim + (uint64_t)r.peer * ld + r.group, (uint32_t)i);
 }
 
-__global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
+static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
                                                             const VoteDeltaRec* __restrict__ d, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -473,7 +473,7 @@ struct Advance {
   uint64_t group, old_commit, new_commit;
 };
 
-__global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* partials, uint64_t n_waves,
+static __global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* partials, uint64_t n_waves,
                                                              uint64_t* offsets, uint64_t* total) {
   __shared__ uint64_t warp_tot[16];
   __shared__ uint64_t carry;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* partia
 // one {even, odd} word pair for the 128 groups at + j*128 -- so (block, wave,
 // round, lane, parity) order IS ascending group order.
 template <int GPL>
-__global__ __launch_bounds__(kBlock) void compact_changed_kernel(const uint64_t* changed_bits,
+static __global__ __launch_bounds__(kBlock) void compact_changed_kernel(const uint64_t* changed_bits,
                                                                  const uint64_t* offsets,
                                                                  const uint64_t* old_commit,
                                                                  const uint64_t* new_commit,
@@ -562,7 +562,7 @@ __device__ __forceinline__ uint32_t tick_rand(uint64_t seed, uint64_t tick_no, u
   return (uint32_t)(z >> 32);
 }
 
-__global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
+static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t g = ((uint64_t)blockIdx.x * kBlock + tid) * 4;
   const uint32_t roles = *reinterpret_cast<const uint32_t*>(a.role + g);
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hup_bits, const uint64_t* offsets,
+static __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hup_bits, const uint64_t* offsets,
                                                               uint64_t* out, uint64_t cap) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t wv = (uint64_t)blockIdx.x * kWaves + wave;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hu
 
 // becomeCandidate for a list of (distinct) groups: role = candidate, elapsed = 0,
 // every vote slot cleared, the candidate's own slot granted.  Byte stores.
-__global__ __launch_bounds__(kBlock) void campaign_kernel(uint8_t* role, uint32_t* elapsed, uint8_t* votes,
+static __global__ __launch_bounds__(kBlock) void campaign_kernel(uint8_t* role, uint32_t* elapsed, uint8_t* votes,
                                                           uint64_t ld, uint32_t n_peers, uint32_t self_peer,
                                                           const uint64_t* __restrict__ groups, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -1,0 +1,263 @@
+// raftq_step.hip -- implementation of include/raftq_step.h: the batched raft Step over
+// the device-resident group state.  Host side: validate + stage the batch in pinned
+// memory, key/sort/walk it on the handle's stream (raftq_step_kernels.hpp), copy the
+// result records back.  No CPU path: the state machine itself runs only on the GPU.
+#include "raftq_step.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "raftq_internal.hpp"
+#include "raftq_step_kernels.hpp"
+
+using namespace raftqk;
+using raftq_detail::ensure_staging;
+using raftq_detail::ensure_tick_state;
+using raftq_detail::fail;
+using raftq_detail::use_device;
+
+static_assert(sizeof(raftq_msg_t) == sizeof(MsgRec) && sizeof(raftq_step_out_t) == sizeof(StepOutRec) &&
+                  sizeof(raftq_log_delta_t) == sizeof(LogDeltaRec),
+              "ABI struct mismatch");
+
+namespace {
+
+int ensure_node_state(raftq_t* h) {
+  if (h->term) return RAFTQ_OK;
+  if (int rc = ensure_tick_state(h)) return rc;  // role, elapsed
+  auto alloc = [&](void** p, size_t bytes) -> int {
+    HIPCHK(h, hipMalloc(p, bytes));
+    HIPCHK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
+    return RAFTQ_OK;
+  };
+  if (int rc = alloc((void**)&h->vote, h->ld * 4)) return rc;
+  if (int rc = alloc((void**)&h->lead, h->ld * 4)) return rc;
+  if (int rc = alloc((void**)&h->last_index, h->ld * 8)) return rc;
+  if (int rc = alloc((void**)&h->last_term, h->ld * 8)) return rc;
+  if (int rc = alloc((void**)&h->term, h->ld * 8)) return rc;  // last: marks the state complete
+  h->have_terms = true;  // Step maintains the current-term gate itself (closed = 0 until a group leads)
+  return RAFTQ_OK;
+}
+
+NodeArrays node_arrays(raftq_t* h) {
+  NodeArrays a;
+  a.role = h->role;
+  a.elapsed = h->elapsed;
+  a.term = h->term;
+  a.vote = h->vote;
+  a.lead = h->lead;
+  a.last_index = h->last_index;
+  a.last_term = h->last_term;
+  a.committed = h->committed[h->cur];
+  a.first_idx = h->first_idx;
+  a.match = h->match;
+  a.votes = h->votes;
+  a.ld = h->ld;
+  a.n_peers = h->N;
+  a.self = h->self_peer;
+  return a;
+}
+
+// device scratch of one batch, carved from a single allocation
+struct Scratch {
+  MsgRec* msgs;
+  StepOutRec* outs;
+  uint64_t *keys_in, *keys_out;
+  uint32_t *order_in, *order_out;
+  unsigned long long* n_heads;
+  void* cub_temp;
+  size_t cub_bytes;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+int ensure_scratch(raftq_t* h, uint64_t n, int end_bit, Scratch* s) {
+  size_t cub_bytes = 0;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, end_bit,
+                                               h->stream));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+  const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec)), o_ki = carve(n * 8),
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_nh = carve(8), o_cub = carve(cub_bytes);
+  if (off > h->step_dev_bytes) {
+    if (h->step_dev) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipFree(h->step_dev));
+      h->step_dev = nullptr;
+      h->step_dev_bytes = 0;
+    }
+    const size_t want = std::max(off, (size_t)1 << 20) * 2;
+    HIPCHK(h, hipMalloc(&h->step_dev, want));
+    h->step_dev_bytes = want;
+  }
+  uint8_t* base = (uint8_t*)h->step_dev;
+  s->msgs = (MsgRec*)(base + o_msgs);
+  s->outs = (StepOutRec*)(base + o_outs);
+  s->keys_in = (uint64_t*)(base + o_ki);
+  s->keys_out = (uint64_t*)(base + o_ko);
+  s->order_in = (uint32_t*)(base + o_oi);
+  s->order_out = (uint32_t*)(base + o_oo);
+  s->n_heads = (unsigned long long*)(base + o_nh);
+  s->cub_temp = base + o_cub;
+  s->cub_bytes = cub_bytes;
+  return RAFTQ_OK;
+}
+
+bool known_type(uint8_t t) {
+  return t == RAFTQ_MSG_HUP || t == RAFTQ_MSG_BEAT || t == RAFTQ_MSG_APP || t == RAFTQ_MSG_APP_RESP ||
+         t == RAFTQ_MSG_VOTE || t == RAFTQ_MSG_VOTE_RESP || t == RAFTQ_MSG_HEARTBEAT || t == RAFTQ_MSG_HEARTBEAT_RESP;
+}
+
+}  // namespace
+
+void raftq_detail::free_node_state(raftq_t* h) {
+  (void)hipFree(h->term);
+  (void)hipFree(h->vote);
+  (void)hipFree(h->lead);
+  (void)hipFree(h->last_index);
+  (void)hipFree(h->last_term);
+  (void)hipFree(h->step_dev);
+}
+
+extern "C" {
+
+int raftq_set_self(raftq_t* h, uint32_t self_peer) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (self_peer >= h->N) return fail(h, RAFTQ_EINVAL, "raftq_set_self: self_peer out of range");
+  h->self_peer = self_peer;
+  return RAFTQ_OK;
+}
+
+int raftq_load_node(raftq_t* h, const uint64_t* term, const uint32_t* vote, const uint32_t* lead,
+                    const uint64_t* last_index, const uint64_t* last_term) {
+  if (int rc = use_device(h)) return rc;
+  if (int rc = ensure_node_state(h)) return rc;
+  for (uint64_t g = 0; g < h->G; ++g)
+    if ((vote && vote[g] > h->N) || (lead && lead[g] > h->N))
+      return fail(h, RAFTQ_EINVAL, "raftq_load_node: vote / lead must be 0 (None) or a peer slot + 1");
+  if (term) HIPCHK(h, hipMemcpyAsync(h->term, term, h->G * 8, hipMemcpyHostToDevice, h->stream));
+  if (vote) HIPCHK(h, hipMemcpyAsync(h->vote, vote, h->G * 4, hipMemcpyHostToDevice, h->stream));
+  if (lead) HIPCHK(h, hipMemcpyAsync(h->lead, lead, h->G * 4, hipMemcpyHostToDevice, h->stream));
+  if (last_index) HIPCHK(h, hipMemcpyAsync(h->last_index, last_index, h->G * 8, hipMemcpyHostToDevice, h->stream));
+  if (last_term) HIPCHK(h, hipMemcpyAsync(h->last_term, last_term, h->G * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, uint64_t* last_index,
+                    uint64_t* last_term, uint64_t* first_idx_cur_term) {
+  if (int rc = use_device(h)) return rc;
+  if (int rc = ensure_node_state(h)) return rc;
+  if (term) HIPCHK(h, hipMemcpyAsync(term, h->term, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  if (vote) HIPCHK(h, hipMemcpyAsync(vote, h->vote, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+  if (lead) HIPCHK(h, hipMemcpyAsync(lead, h->lead, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+  if (last_index) HIPCHK(h, hipMemcpyAsync(last_index, h->last_index, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  if (last_term) HIPCHK(h, hipMemcpyAsync(last_term, h->last_term, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  if (first_idx_cur_term)
+    HIPCHK(h, hipMemcpyAsync(first_idx_cur_term, h->first_idx, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
+                     raftq_step_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) counts->n_msgs = counts->n_groups_touched = 0;
+  if (n == 0) return RAFTQ_OK;
+  if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: null messages");
+  if (n > 0x7fffffffull) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: batch too large (2^31 - 1 messages at most)");
+  if (int rc = ensure_node_state(h)) return rc;
+  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_msg_t))) return rc;
+  // one pass: validate and copy into the pinned staging area
+  {
+    raftq_msg_t* dst = (raftq_msg_t*)h->stage_h;
+    const uint64_t G = h->G, N = h->N;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const raftq_msg_t m = msgs[i];
+      const bool local = m.type == RAFTQ_MSG_HUP || m.type == RAFTQ_MSG_BEAT;
+      bad |= (uint64_t)(m.group >= G) | (uint64_t)(!known_type(m.type)) | (uint64_t)(!local && m.from >= N);
+      dst[i] = m;
+    }
+    if (bad)
+      return fail(h, RAFTQ_EINVAL,
+                  "raftq_step_batch: a message is malformed (group or from out of range, or a type Step does not take); "
+                  "nothing applied");
+  }
+  int end_bit = 1;
+  while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
+  Scratch s;
+  if (int rc = ensure_scratch(h, n, end_bit, &s)) return rc;
+  HIPCHK(h, hipMemsetAsync(s.n_heads, 0, 8, h->stream));
+  const uint64_t n_quads = n * 4;
+  hipLaunchKernelGGL(step_keys_kernel, dim3((unsigned)((n_quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                     (const uint4*)h->stage_d, (uint4*)s.msgs, s.keys_in, s.order_in, n_quads);
+  HIPCHK(h, hipGetLastError());
+  size_t cub_bytes = s.cub_bytes;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
+                                               (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
+  hipLaunchKernelGGL(step_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                     node_arrays(h), (const MsgRec*)s.msgs, (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out,
+                     s.outs, n, s.n_heads);
+  HIPCHK(h, hipGetLastError());
+  if (out) HIPCHK(h, hipMemcpyAsync(out, s.outs, n * sizeof(StepOutRec), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long heads = 0;
+  if (counts) HIPCHK(h, hipMemcpyAsync(&heads, s.n_heads, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (counts) {
+    counts->n_msgs = n;
+    counts->n_groups_touched = heads;
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n) {
+  if (int rc = use_device(h)) return rc;
+  if (n == 0) return RAFTQ_OK;
+  if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (d[i].group >= h->G) return fail(h, RAFTQ_EINVAL, "a log delta is out of range; nothing applied");
+  if (int rc = ensure_node_state(h)) return rc;
+  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_log_delta_t))) return rc;
+  // records of one group apply in order: the k-th record of a group goes into launch k
+  std::vector<uint32_t> round(n);
+  uint32_t n_rounds = 1;
+  try {
+    std::unordered_map<uint64_t, uint32_t> seen;
+    seen.reserve((size_t)n * 2);
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t r = seen[d[i].group]++;
+      round[i] = r;
+      n_rounds = std::max(n_rounds, r + 1);
+    }
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
+  }
+  raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
+  uint64_t pos = 0;
+  for (uint32_t r = 0; r < n_rounds; ++r) {
+    const uint64_t start = pos;
+    if (n_rounds == 1) {
+      std::memcpy(dst, d, n * sizeof(raftq_log_delta_t));
+      pos = n;
+    } else {
+      for (uint64_t i = 0; i < n; ++i)
+        if (round[i] == r) dst[pos++] = d[i];
+    }
+    const uint64_t m = pos - start;
+    if (m == 0) continue;
+    hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+}  // extern "C"

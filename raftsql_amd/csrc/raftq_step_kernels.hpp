@@ -1,0 +1,299 @@
+// raftq_step_kernels.hpp -- device code of the batched raft Step (include/raftq_step.h).
+//
+// etcd's raft.Step is a per-group sequential state machine; what is parallel is the G
+// groups.  A batch is therefore (1) keyed by group, (2) stably radix-sorted by that key
+// (hipCUB; arrival order inside a group survives), and (3) walked by step_kernel with one
+// lane per *run* of equal keys: the lane at the head of a run gathers its group's scalar
+// state into registers, applies the run's messages in order and scatters the state back.
+// Different runs touch different groups, so there are no atomics and the result is
+// identical to calling Step message by message (tests/test_step_gpu.py).
+//
+// Restates (2015-era etcd raft, reached from raft.go:268-270 / :223-224): Step, stepLeader,
+// stepCandidate, stepFollower, reset, becomeFollower / becomeCandidate / becomeLeader,
+// campaign, poll, maybeCommit, handleHeartbeat, raftLog.isUpToDate / commitTo,
+// Progress.maybeUpdate.  Sparse, scattered access: bound by HBM latency / PCIe, not bandwidth.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raftq_kernels.hpp"
+
+namespace raftqk {
+
+struct MsgRec {  // == raftq_msg_t
+  uint64_t group, term, log_term, index, commit, reject_hint;
+  uint32_t from;
+  uint8_t type, reject, pad[2];
+  uint64_t resv;
+};
+struct StepOutRec {  // == raftq_step_out_t
+  uint64_t group, term, index, log_term, commit, last_index;
+  uint32_t to, vote, lead;
+  uint8_t type, reject, flags, role;
+};
+struct LogDeltaRec {  // == raftq_log_delta_t
+  uint64_t group, last_index, last_term, commit_to;
+};
+static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32, "record layout");
+
+struct NodeArrays {
+  uint8_t* role;
+  uint32_t* elapsed;
+  uint64_t* term;
+  uint32_t* vote;
+  uint32_t* lead;
+  uint64_t* last_index;
+  uint64_t* last_term;
+  uint64_t* committed;
+  uint64_t* first_idx;
+  uint64_t* match;  // [N][ld]
+  uint8_t* votes;   // [N][ld]
+  uint64_t ld;
+  uint32_t n_peers, self;
+};
+
+constexpr uint8_t kMsgHup = 0, kMsgBeat = 1, kMsgApp = 3, kMsgAppResp = 4, kMsgVote = 5, kMsgVoteResp = 6,
+                  kMsgHeartbeat = 8, kMsgHeartbeatResp = 9;
+constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCampaign = 3, kOutBecameLeader = 4,
+                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7;
+constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
+constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
+
+// ---- (1) stage -> device copy + sort keys.  The staged records sit in pinned, device-mapped
+// host memory; they are read once, 16 B per lane, fully coalesced over PCIe.
+static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const uint4* __restrict__ staged, uint4* __restrict__ msgs,
+                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ order,
+                                                           uint64_t n_quads) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_quads) return;
+  const uint4 v = staged[i];
+  msgs[i] = v;
+  if ((i & 3) == 0) {  // first quarter of a record: {group lo, group hi, term lo, term hi}
+    keys[i >> 2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    order[i >> 2] = (uint32_t)(i >> 2);
+  }
+}
+
+// ---- (3) one group's state in registers ------------------------------------------------------
+struct Node {
+  const NodeArrays& a;
+  uint64_t g;
+  uint64_t term, last_index, last_term, committed, first_idx;
+  uint32_t vote, lead, elapsed;
+  uint8_t role;
+
+  __device__ Node(const NodeArrays& arr, uint64_t group) : a(arr), g(group) {
+    term = a.term[g]; last_index = a.last_index[g]; last_term = a.last_term[g];
+    committed = a.committed[g]; first_idx = a.first_idx[g];
+    vote = a.vote[g]; lead = a.lead[g]; elapsed = a.elapsed[g]; role = a.role[g];
+  }
+  __device__ void store() const {
+    a.term[g] = term; a.last_index[g] = last_index; a.last_term[g] = last_term;
+    a.committed[g] = committed; a.first_idx[g] = first_idx;
+    a.vote[g] = vote; a.lead[g] = lead; a.elapsed[g] = elapsed; a.role[g] = role;
+  }
+  __device__ uint64_t& match(uint32_t p) const { return a.match[(uint64_t)p * a.ld + g]; }
+  __device__ uint8_t& votes(uint32_t p) const { return a.votes[(uint64_t)p * a.ld + g]; }
+  __device__ uint32_t quorum() const { return a.n_peers / 2 + 1; }
+
+  // raft.reset(term)
+  __device__ void reset(uint64_t t) {
+    if (term != t) { term = t; vote = 0; }
+    lead = 0;
+    elapsed = 0;
+    for (uint32_t p = 0; p < a.n_peers; ++p) {
+      votes(p) = 0;
+      match(p) = p == a.self ? last_index : 0;
+    }
+  }
+  __device__ void become_follower(uint64_t t, uint32_t new_lead) {
+    reset(t);
+    lead = new_lead;
+    role = kFollower;
+    first_idx = 0;
+  }
+  __device__ void become_candidate() {
+    reset(term + 1);
+    vote = a.self + 1;
+    role = kCandidate;
+    first_idx = 0;
+  }
+  // raft.maybeCommit + raftLog.maybeCommit: the largest index held by >= q peers (counting form),
+  // then the compact current-term gate
+  __device__ bool maybe_commit() {
+    uint64_t m[kMaxPeers];
+    const uint32_t n = a.n_peers, q = quorum();
+#pragma unroll
+    for (uint32_t p = 0; p < kMaxPeers; ++p) m[p] = p < n ? match(p) : 0;
+    uint64_t mci = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kMaxPeers; ++c) {
+      uint32_t ge = 0;
+#pragma unroll
+      for (uint32_t p = 0; p < kMaxPeers; ++p) ge += (p < n && m[p] >= m[c]) ? 1u : 0u;
+      if (c < n && ge >= q && m[c] > mci) mci = m[c];
+    }
+    if (mci > committed && first_idx != 0 && mci >= first_idx) {
+      committed = mci;
+      return true;
+    }
+    return false;
+  }
+  // raft.becomeLeader incl. appendEntry(empty entry of the new term)
+  __device__ void become_leader() {
+    reset(term);
+    lead = a.self + 1;
+    role = kLeader;
+    last_index += 1;
+    last_term = term;
+    first_idx = last_index;
+    match(a.self) = last_index;
+    (void)maybe_commit();
+  }
+  // raft.poll: the first response of a peer wins; returns {granted, recorded}
+  __device__ void poll(uint32_t from, bool granted, uint32_t& n_granted, uint32_t& n_recorded) {
+    const uint8_t cur = votes(from);
+    if (cur != 1 && cur != 2) votes(from) = granted ? 1 : 2;
+    n_granted = n_recorded = 0;
+    for (uint32_t p = 0; p < a.n_peers; ++p) {
+      const uint8_t v = votes(p);
+      n_granted += v == 1;
+      n_recorded += (v == 1 || v == 2);
+    }
+  }
+  __device__ void commit_to(uint64_t tocommit) {
+    if (tocommit > last_index) tocommit = last_index;
+    if (committed < tocommit) committed = tocommit;
+  }
+
+  __device__ void step(const MsgRec& m, StepOutRec& o) {
+    const uint64_t term0 = term, commit0 = committed;
+    const uint32_t vote0 = vote;
+    const uint8_t role0 = role;
+    o.index = 0; o.log_term = 0; o.type = kOutNone; o.reject = 0; o.flags = 0;
+    const uint32_t q = quorum();
+    bool handled = false;
+    if (m.type == kMsgHup) {
+      handled = true;
+      if (role != kLeader) {  // campaign()
+        become_candidate();
+        uint32_t gr, rec;
+        poll(a.self, true, gr, rec);
+        if (gr == q) { become_leader(); o.type = kOutBecameLeader; }
+        else o.type = kOutCampaign;
+        o.index = last_index;
+        o.log_term = last_term;
+      }
+    } else if (m.term != 0) {
+      if (m.term > term) become_follower(m.term, m.type == kMsgVote ? 0u : m.from + 1);
+      else if (m.term < term) handled = true;  // stale: ignored
+    }
+    if (!handled) {
+      if (role == kLeader) {
+        if (m.type == kMsgBeat) {
+          o.type = kOutBcastHeartbeat;
+        } else if (m.type == kMsgVote) {
+          o.type = kOutVoteResp; o.reject = 1;
+        } else if (m.type == kMsgAppResp) {
+          o.type = kOutProgress; o.reject = m.reject;
+          if (!m.reject) {
+            const uint64_t idx = m.index > last_index ? last_index : m.index;
+            if (match(m.from) < idx) {
+              match(m.from) = idx;
+              o.flags |= kFlagUpdated;
+              (void)maybe_commit();
+            }
+          }
+          o.index = match(m.from);
+        } else if (m.type == kMsgHeartbeatResp) {
+          o.type = kOutProgress;
+          o.index = match(m.from);
+        }
+      } else if (role == kCandidate) {
+        if (m.type == kMsgApp) {
+          become_follower(term, m.from + 1);
+          o.type = kOutAppend;
+        } else if (m.type == kMsgHeartbeat) {
+          become_follower(term, m.from + 1);
+          commit_to(m.commit);
+          o.type = kOutHeartbeatResp;
+        } else if (m.type == kMsgVote) {
+          o.type = kOutVoteResp; o.reject = 1;
+        } else if (m.type == kMsgVoteResp) {
+          uint32_t gr, rec;
+          poll(m.from, !m.reject, gr, rec);
+          if (gr == q) {
+            become_leader();
+            o.type = kOutBecameLeader; o.index = last_index; o.log_term = last_term;
+          } else if (rec - gr == q) {
+            become_follower(term, 0);
+          }
+        }
+      } else {
+        if (m.type == kMsgApp) {
+          elapsed = 0; lead = m.from + 1;
+          o.type = kOutAppend;
+        } else if (m.type == kMsgHeartbeat) {
+          elapsed = 0; lead = m.from + 1;
+          commit_to(m.commit);
+          o.type = kOutHeartbeatResp;
+        } else if (m.type == kMsgVote) {
+          o.type = kOutVoteResp;
+          const bool up_to_date = m.log_term > last_term || (m.log_term == last_term && m.index >= last_index);
+          if ((vote == 0 || vote == m.from + 1) && up_to_date) { elapsed = 0; vote = m.from + 1; }
+          else o.reject = 1;
+        }
+      }
+    }
+    o.group = g; o.term = term; o.commit = committed; o.last_index = last_index;
+    o.to = m.from; o.vote = vote; o.lead = lead; o.role = role;
+    if (term != term0 || vote != vote0 || committed != commit0) o.flags |= kFlagHardState;
+    if (committed != commit0) o.flags |= kFlagCommitted;
+    if (role0 != kFollower && role == kFollower) o.flags |= kFlagSteppedDown;
+  }
+};
+
+static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
+                                                      const uint64_t* __restrict__ keys_sorted,
+                                                      const uint32_t* __restrict__ order, StepOutRec* __restrict__ out,
+                                                      uint64_t n, unsigned long long* n_heads) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool head = false;
+  uint64_t g = 0;
+  if (k < n) {
+    g = keys_sorted[k];
+    head = k == 0 || keys_sorted[k - 1] != g;
+  }
+  const uint64_t hb = __ballot(head);
+  if ((threadIdx.x & 63) == 0 && hb) atomicAdd(n_heads, (unsigned long long)__popcll(hb));
+  if (!head) return;
+  Node node(a, g);
+  for (uint64_t j = k; j < n && keys_sorted[j] == g; ++j) {
+    const uint32_t i = order[j];
+    const MsgRec m = msgs[i];
+    StepOutRec o;
+    node.step(m, o);
+    out[i] = o;
+  }
+  node.store();
+}
+
+// the log owner's tail reports; records are unique per group within a launch (the host splits
+// repeated groups into successive launches)
+static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a, const LogDeltaRec* __restrict__ d, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const LogDeltaRec r = d[i];
+  Node node(a, r.group);
+  node.last_index = r.last_index;
+  node.last_term = r.last_term;
+  if (node.role == kLeader) {
+    if (node.match(a.self) < node.last_index) node.match(a.self) = node.last_index;
+    (void)node.maybe_commit();
+  } else if (r.commit_to != 0) {
+    node.commit_to(r.commit_to);
+  }
+  node.store();
+}
+
+}  // namespace raftqk

@@ -1,0 +1,95 @@
+"""Host-side mirror of the batched raft Step (include/raftq_step.h).
+
+`NodeEngine` is a QuorumEngine that also holds the node state of every group
+(Term, Vote, lead, role, raftLog tail) on the GPU and applies whole batches of
+raftpb-shaped messages to it: the vectorised form of the reference's
+`raftNode.Process -> rc.node.Step` (raft.go:268-270).  Records are numpy
+structured arrays layout-identical to the C structs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .engine import QuorumEngine, _ptr
+
+# raftpb.MessageType values Step accepts
+MSG_HUP, MSG_BEAT, MSG_APP, MSG_APP_RESP, MSG_VOTE, MSG_VOTE_RESP, MSG_HEARTBEAT, MSG_HEARTBEAT_RESP = 0, 1, 3, 4, 5, 6, 8, 9
+MSG_TYPES = (MSG_HUP, MSG_BEAT, MSG_APP, MSG_APP_RESP, MSG_VOTE, MSG_VOTE_RESP, MSG_HEARTBEAT, MSG_HEARTBEAT_RESP)
+
+OUT_NONE, OUT_VOTE_RESP, OUT_HEARTBEAT_RESP, OUT_CAMPAIGN, OUT_BECAME_LEADER, OUT_PROGRESS, OUT_BCAST_HEARTBEAT, OUT_APPEND = range(8)
+OUTF_HARDSTATE, OUTF_COMMITTED, OUTF_UPDATED, OUTF_STEPPED_DOWN = 1, 2, 4, 8
+
+ROLE_FOLLOWER, ROLE_CANDIDATE, ROLE_LEADER = 0, 1, 2
+
+MSG_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("log_term", "<u8"), ("index", "<u8"), ("commit", "<u8"),
+                   ("reject_hint", "<u8"), ("from", "<u4"), ("type", "u1"), ("reject", "u1"), ("_pad", "u1", (2,)),
+                   ("_resv", "<u8")])
+OUT_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("log_term", "<u8"), ("commit", "<u8"),
+                   ("last_index", "<u8"), ("to", "<u4"), ("vote", "<u4"), ("lead", "<u4"), ("type", "u1"),
+                   ("reject", "u1"), ("flags", "u1"), ("role", "u1")])
+LOG_DELTA_DT = np.dtype([("group", "<u8"), ("last_index", "<u8"), ("last_term", "<u8"), ("commit_to", "<u8")])
+assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32
+
+
+def pack_msgs(group, type, term=0, frm=0, index=0, log_term=0, commit=0, reject=0, reject_hint=0) -> np.ndarray:
+    """raftq_msg_t[] from per-field arrays / scalars (broadcast)."""
+    n = len(np.atleast_1d(group))
+    a = np.zeros(n, dtype=MSG_DT)
+    a["group"], a["type"], a["term"], a["from"] = group, type, term, frm
+    a["index"], a["log_term"], a["commit"], a["reject"], a["reject_hint"] = index, log_term, commit, reject, reject_hint
+    return a
+
+
+class NodeEngine(QuorumEngine):
+    """G raft groups' node state on one GPU + batched Step."""
+
+    def __init__(self, n_groups: int, n_peers: int, self_peer: int = 0, device: int = 0):
+        super().__init__(n_groups, n_peers, device=device)
+        self.self_peer = int(self_peer)
+        self._chk(self._lib.raftq_set_self(self._h, self.self_peer))
+
+    def load_node(self, term=None, vote=None, lead=None, last_index=None, last_term=None) -> None:
+        def arr(x, dt):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(x, dtype=dt)
+            if a.shape != (self.n_groups,):
+                raise ValueError("node arrays must be [G]")
+            return a
+
+        t, v, l = arr(term, np.uint64), arr(vote, np.uint32), arr(lead, np.uint32)
+        li, lt = arr(last_index, np.uint64), arr(last_term, np.uint64)
+        p = lambda a: _ptr(a) if a is not None else None  # noqa: E731
+        self._chk(self._lib.raftq_load_node(self._h, p(t), p(v), p(l), p(li), p(lt)))
+
+    def read_node(self) -> dict:
+        """-> dict of [G] arrays: term, vote, lead, last_index, last_term, first_idx, role, elapsed, committed"""
+        G = self.n_groups
+        out = {"term": np.empty(G, np.uint64), "vote": np.empty(G, np.uint32), "lead": np.empty(G, np.uint32),
+               "last_index": np.empty(G, np.uint64), "last_term": np.empty(G, np.uint64),
+               "first_idx": np.empty(G, np.uint64)}
+        self._chk(self._lib.raftq_read_node(self._h, _ptr(out["term"]), _ptr(out["vote"]), _ptr(out["lead"]),
+                                            _ptr(out["last_index"]), _ptr(out["last_term"]), _ptr(out["first_idx"])))
+        _, out["elapsed"], out["role"] = self.read_tick()
+        out["committed"] = self.read_committed()
+        return out
+
+    def step_batch(self, msgs: np.ndarray, want_out: bool = True):
+        """raft.Step for every message of the batch (per group in batch order).
+        -> (raftq_step_out_t[] | None, n_groups_touched)"""
+        assert msgs.dtype == MSG_DT and msgs.flags.c_contiguous
+        n = len(msgs)
+        out = np.zeros(n, dtype=OUT_DT) if want_out else None
+        c = _lib.StepCounts()
+        self._chk(self._lib.raftq_step_batch(self._h, _ptr(msgs) if n else None, n,
+                                             _ptr(out) if (want_out and n) else None, C.byref(c)))
+        return out, int(c.n_groups_touched)
+
+    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> None:
+        a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)
+        a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to
+        self._chk(self._lib.raftq_apply_log_deltas(self._h, _ptr(a) if len(a) else None, len(a)))

@@ -1,0 +1,86 @@
+"""Shared generator of random raft message batches for the Step tests.
+
+Messages are drawn relative to the CURRENT oracle state (terms around the
+group's term, indices around its log tail) so that every branch of
+Step / stepLeader / stepCandidate / stepFollower is exercised: stale terms,
+term bumps, grants and rejections, duplicate responses, acks that do and do
+not reach a quorum, heartbeats that do and do not move the commit index.
+"""
+import numpy as np
+
+from oracle import pyoracle
+
+TYPES = np.array([0, 1, 3, 4, 5, 6, 8, 9], dtype=np.uint8)  # Hup Beat App AppResp Vote VoteResp Heartbeat HeartbeatResp
+#                 Hup   Beat  App   AppResp Vote  VoteResp Hb    HbResp
+TYPE_P = np.array([0.08, 0.05, 0.07, 0.30, 0.12, 0.22, 0.10, 0.06])
+
+
+def random_state(rng, G, N, self_peer=0):
+    """A plausible mid-flight node state (same arrays for the oracle and the engine)."""
+    s = pyoracle.NodeState(G, N, self_peer)
+    s.term[:] = rng.integers(1, 6, G)
+    s.last_index[:] = rng.integers(0, 50, G)
+    s.last_term[:] = np.minimum(s.term, rng.integers(0, 6, G))
+    s.last_term[s.last_index == 0] = 0
+    s.committed[:] = (s.last_index * rng.random(G)).astype(np.uint64)
+    s.role[:] = rng.choice([0, 0, 1, 2], G)
+    s.elapsed[:] = rng.integers(0, 10, G)
+    lead = s.role == 2
+    cand = s.role == 1
+    s.vote[:] = rng.integers(0, N + 1, G)
+    s.vote[lead | cand] = self_peer + 1
+    s.lead[:] = np.where(lead, self_peer + 1, np.where(cand, 0, rng.integers(0, N + 1, G)))
+    # leaders: an entry of their own term exists somewhere at or below the tail
+    s.last_term[lead] = s.term[lead]
+    s.last_index[lead] = np.maximum(s.last_index[lead], 1)
+    s.committed[:] = np.minimum(s.committed, s.last_index)
+    s.first_idx[lead] = np.maximum(1, (s.last_index[lead] * rng.random(int(lead.sum()))).astype(np.uint64))
+    for p in range(N):
+        m = (s.last_index * rng.random(G)).astype(np.uint64)
+        s.match[p] = np.where(lead, m, 0)
+    s.match[self_peer] = s.last_index
+    v = rng.choice([0, 0, 1, 2], (N, G)).astype(np.uint8)
+    s.votes[:] = np.where(cand[None, :], v, 0)
+    s.votes[self_peer, cand] = 1
+    return s
+
+
+def random_batch(rng, s, n, hot_groups=None):
+    """n messages over s's groups; `hot_groups` concentrates them (many per group per batch)."""
+    G, N = s.G, s.N
+    if hot_groups is None:
+        g = rng.integers(0, G, n)
+    else:
+        g = rng.choice(hot_groups, n)
+    t = rng.choice(TYPES, n, p=TYPE_P)
+    m = np.zeros(n, dtype=pyoracle.STEP_MSG_DT)
+    m["group"], m["type"] = g, t
+    local = (t == 0) | (t == 1)
+    dterm = rng.choice([-1, 0, 0, 0, 0, 1, 2], n)
+    term = np.maximum(1, s.term[g].astype(np.int64) + dterm).astype(np.uint64)
+    m["term"] = np.where(local, 0, term)
+    m["from"] = rng.integers(0, N, n)
+    li = s.last_index[g].astype(np.int64)
+    m["index"] = np.maximum(0, li + rng.integers(-3, 4, n)).astype(np.uint64)
+    m["log_term"] = np.maximum(0, s.last_term[g].astype(np.int64) + rng.integers(-1, 2, n)).astype(np.uint64)
+    m["commit"] = np.maximum(0, li + rng.integers(-4, 3, n)).astype(np.uint64)
+    m["reject"] = rng.random(n) < 0.3
+    m["reject_hint"] = m["index"]
+    return m
+
+
+def load_engine(e, s):
+    """Put the oracle state `s` onto a raftsql_amd.step.NodeEngine `e`."""
+    e.load_match(s.match, s.committed)
+    e.load_votes(s.votes)
+    e.load_terms(np.where(s.first_idx != 0, np.maximum(s.term, 1), 0), s.first_idx)
+    e.load_roles(s.role, s.elapsed)
+    e.load_node(s.term, s.vote, s.lead, s.last_index, s.last_term)
+
+
+def assert_same_state(e, s):
+    got = e.read_node()
+    for k in ("term", "vote", "lead", "last_index", "last_term", "first_idx", "role", "elapsed", "committed"):
+        assert np.array_equal(got[k], getattr(s, k)), k
+    assert np.array_equal(e.read_match(), s.match), "match"
+    assert np.array_equal(e.read_votes(), s.votes), "votes"

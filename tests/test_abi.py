@@ -29,10 +29,11 @@ def test_header_and_binding_list_the_same_symbols():
 
     assert _declared() == sorted(_lib.EXPORTS)
     assert _declared("raftq_pipe.h") == sorted(pipe.EXPORTS)
+    assert _declared("raftq_step.h") == sorted(_lib.STEP_EXPORTS)
 
 
 def test_every_declared_symbol_is_exported(lib):
-    for name in _declared() + _declared("raftq_pipe.h"):
+    for name in _declared() + _declared("raftq_pipe.h") + _declared("raftq_step.h"):
         assert hasattr(lib, name), name
 
 
@@ -66,6 +67,9 @@ def test_argument_validation_without_device(lib):
     assert lib.raftq_step_async(None, 1) == _lib.RAFTQ_EINVAL
     assert lib.raftq_wait(None, None) == _lib.RAFTQ_EINVAL
     lib.raftq_destroy(None)  # must be a no-op
+    assert lib.raftq_step_batch(None, None, 0, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_set_self(None, 0) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_apply_log_deltas(None, None, 0) == _lib.RAFTQ_EINVAL
 
 
 def test_no_silent_cpu_fallback(lib):

@@ -1,0 +1,165 @@
+"""GPU: the batched raft Step (raftq_step_batch, through the C-ABI) against the
+sequential CPU oracle, bit-exact: every result record and every word of the node state.
+
+Batches are drawn around the live state so every branch of Step is hit, with many
+messages per group per batch (the in-batch ordering is the hard part), for odd and even
+N, any self slot, interleaved with log-tail reports, dense sweeps and ticks."""
+import numpy as np
+import pytest
+
+from raftsql_amd import _lib
+from tests import _stepgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def NodeEngine(gpu_engine_cls):
+    from raftsql_amd.step import NodeEngine as NE
+
+    return NE
+
+
+@pytest.mark.parametrize("N,self_peer", [(1, 0), (2, 1), (3, 0), (3, 2), (4, 1), (5, 4), (7, 3), (9, 8)])
+def test_step_parity_hot_groups(NodeEngine, oracle, N, self_peer):
+    rng = np.random.default_rng(1000 + 10 * N + self_peer)
+    G = 777
+    s = _stepgen.random_state(rng, G, N, self_peer)
+    with NodeEngine(G, N, self_peer) as e:
+        _stepgen.load_engine(e, s)
+        _stepgen.assert_same_state(e, s)
+        hot = rng.choice(G, 40, replace=False)
+        for rnd in range(8):
+            # alternate: everything on 40 groups (runs of ~100 messages) / spread over all groups
+            m = _stepgen.random_batch(rng, s, 4000, hot_groups=hot if rnd % 2 == 0 else None)
+            want = s.step_batch(m)
+            got, touched = e.step_batch(m)
+            assert touched == len(np.unique(m["group"]))
+            bad = np.nonzero(got.view(np.uint8).reshape(len(m), 64) != want.view(np.uint8).reshape(len(m), 64))[0]
+            assert len(bad) == 0, (rnd, m[bad[0]], got[bad[0]], want[bad[0]])
+            _stepgen.assert_same_state(e, s)
+            # the log's owner reports new tails; a group may repeat inside one call (applied in order)
+            g = np.sort(rng.integers(0, G, 300)).astype(np.uint64)
+            first = np.concatenate([[True], g[1:] != g[:-1]])
+            k = np.arange(300) - np.maximum.accumulate(np.where(first, np.arange(300), 0))  # 0,1,2.. within a group
+            li = s.last_index[g] + k.astype(np.uint64) + rng.integers(0, 2, 300).astype(np.uint64) * first
+            lt = np.maximum(s.last_term[g], s.term[g] * (s.role[g] == 2))
+            ct = np.where(rng.random(300) < 0.5, 0, s.committed[g] + rng.integers(0, 4, 300).astype(np.uint64))
+            p = rng.permutation(300)
+            p = p[np.argsort(g[p], kind="stable")] if rnd % 2 else np.arange(300)  # grouped or as generated
+            s.apply_log_deltas(g[p], li[p], lt[p], ct[p])
+            e.apply_log_deltas(g[p], li[p], lt[p], ct[p])
+            _stepgen.assert_same_state(e, s)
+
+
+def test_step_then_dense_sweep_agree(NodeEngine, oracle):
+    """After Step has moved match / first_idx, the dense gated sweep and the in-lane
+    maybeCommit are the same function: a sweep right after a batch advances nothing."""
+    rng = np.random.default_rng(7)
+    G, N = 5000, 5
+    s = _stepgen.random_state(rng, G, N, 0)
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        # bring every leader's commit index up to date first (random_state leaves slack)
+        e.sweep(_lib.SWEEP_COMMIT | _lib.SWEEP_GATED)
+        s.committed[:] = oracle.commit_advance(s.match, s.committed, True, s.first_idx)[0]
+        for _ in range(4):
+            m = _stepgen.random_batch(rng, s, 20000)
+            want = s.step_batch(m)
+            got, _ = e.step_batch(m)
+            assert np.array_equal(got, want)
+            c = e.sweep(_lib.SWEEP_COMMIT | _lib.SWEEP_GATED | _lib.SWEEP_VOTES)
+            assert c.n_changed == 0
+            _stepgen.assert_same_state(e, s)
+            # and the vote tally of the sweep sees what poll recorded
+            oc, w, l = oracle.vote_tally(s.votes)
+            assert np.array_equal(e.read_outcome(), oc)
+
+
+def test_election_round_trip_tick_to_leader(NodeEngine, oracle):
+    """Tick -> MsgHup list -> Step(MsgHup) -> CAMPAIGN -> peers' MsgVoteResp -> BECAME_LEADER
+    -> MsgAppResp -> commit: the whole election path on the device, checked against the oracle."""
+    from raftsql_amd import step as S
+
+    G, N = 3000, 5
+    s = oracle.NodeState(G, N, 0)
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        e.set_timers(10, 1, seed=99)
+        hups = np.empty(0, dtype=np.uint64)
+        for t in range(25):
+            e.tick()
+            h, n = e.collect_hups()
+            act = np.zeros(G, np.uint8)
+            oracle.lib().rq_oracle_tick(s.role, s.elapsed, G, 10, 1, 99, t, act, None, None)
+            assert np.array_equal(h, np.nonzero(act == 1)[0])
+            if len(h) == 0:
+                continue
+            m = S.pack_msgs(h, S.MSG_HUP)
+            want = s.step_batch(m)
+            got, _ = e.step_batch(m)
+            assert np.array_equal(got, want) and np.all(got["type"] == S.OUT_CAMPAIGN)
+            hups = np.concatenate([hups, h])
+        assert len(hups) > G // 2
+        cand = np.nonzero(s.role == 1)[0].astype(np.uint64)
+        # two peers grant, one rejects, in random arrival order across groups
+        rng = np.random.default_rng(5)
+        g = np.concatenate([cand, cand, cand])
+        frm = np.concatenate([np.full(len(cand), 1), np.full(len(cand), 2), np.full(len(cand), 3)])
+        rej = np.concatenate([np.zeros(len(cand)), np.ones(len(cand)), np.zeros(len(cand))])
+        p = rng.permutation(len(g))
+        m = S.pack_msgs(g[p], S.MSG_VOTE_RESP, term=s.term[g[p]], frm=frm[p], reject=rej[p])
+        want = s.step_batch(m)
+        got, _ = e.step_batch(m)
+        assert np.array_equal(got, want)
+        assert np.all(s.role[cand] == 2) and (got["type"] == S.OUT_BECAME_LEADER).sum() == len(cand)
+        # followers ack the empty entry: every new leader commits it
+        m = S.pack_msgs(np.concatenate([cand, cand]), S.MSG_APP_RESP, term=np.concatenate([s.term[cand]] * 2),
+                        frm=np.concatenate([np.full(len(cand), 1), np.full(len(cand), 4)]),
+                        index=np.concatenate([s.last_index[cand]] * 2))
+        want = s.step_batch(m)
+        got, _ = e.step_batch(m)
+        assert np.array_equal(got, want)
+        assert np.all(s.committed[cand] == s.last_index[cand]) and np.all(s.committed[cand] == 1)
+        _stepgen.assert_same_state(e, s)
+
+
+def test_step_large_sparse_batch(NodeEngine, oracle):
+    """1M groups, 200k messages: mostly one message per group (the production shape)."""
+    rng = np.random.default_rng(11)
+    G, N = 1 << 20, 5
+    s = _stepgen.random_state(rng, G, N, 2)
+    with NodeEngine(G, N, 2) as e:
+        _stepgen.load_engine(e, s)
+        for _ in range(2):
+            m = _stepgen.random_batch(rng, s, 200_000)
+            want = s.step_batch(m)
+            got, touched = e.step_batch(m)
+            assert touched == len(np.unique(m["group"]))
+            assert np.array_equal(got, want)
+        _stepgen.assert_same_state(e, s)
+
+
+def test_step_rejects_malformed_batches_and_applies_nothing(NodeEngine, oracle):
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+
+    G, N = 100, 3
+    s = _stepgen.random_state(np.random.default_rng(3), G, N, 0)
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        good = S.pack_msgs([1, 2, 3], S.MSG_HUP)
+        for field, val in (("group", G), ("type", 2), ("type", 7), ("type", 10)):
+            bad = good.copy()
+            bad[field][1] = val
+            with pytest.raises(RaftqError) as ei:
+                e.step_batch(bad)
+            assert ei.value.code == _lib.RAFTQ_EINVAL
+        bad = S.pack_msgs([1, 2, 3], S.MSG_VOTE, term=9, frm=[0, N, 1])
+        with pytest.raises(RaftqError):
+            e.step_batch(bad)
+        _stepgen.assert_same_state(e, s)  # nothing was applied
+        out, touched = e.step_batch(good[:0])
+        assert len(out) == 0 and touched == 0
+        with pytest.raises(RaftqError):
+            e.apply_log_deltas([G], [1], [1])

@@ -1,0 +1,207 @@
+"""CPU: the Step oracle (oracle/raftq_step_oracle.c) against hand-derived scenarios from
+the Raft rules (Raft paper 5.1-5.4; etcd raft's Step / stepX of the 2015 era) and
+against invariants under random traffic.  PARITY UNPINNED: the reference's tests hold no
+vector for this path, so these scenarios ARE the pin."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import pyoracle
+from tests import _stepgen
+
+HUP, BEAT, APP, APP_RESP, VOTE, VOTE_RESP, HB, HB_RESP = 0, 1, 3, 4, 5, 6, 8, 9
+NONE, O_VOTE_RESP, O_HB_RESP, O_CAMPAIGN, O_LEADER, O_PROGRESS, O_BCAST_HB, O_APPEND = range(8)
+F_HARD, F_COMMIT, F_UPD, F_DOWN = 1, 2, 4, 8
+
+
+def msg(group=0, type=HUP, term=0, frm=0, index=0, log_term=0, commit=0, reject=0):
+    m = np.zeros(1, dtype=pyoracle.STEP_MSG_DT)
+    m["group"], m["type"], m["term"], m["from"] = group, type, term, frm
+    m["index"], m["log_term"], m["commit"], m["reject"] = index, log_term, commit, reject
+    return m
+
+
+def one(s, **kw):
+    return s.step_batch(msg(**kw))[0]
+
+
+def test_election_then_commit_three_peers():
+    s = pyoracle.NodeState(1, 3, self_peer=0)
+    s.last_index[0], s.last_term[0] = 4, 0
+    o = one(s, type=HUP)
+    assert (o["type"], o["term"], o["index"], o["log_term"], o["vote"], o["role"]) == (O_CAMPAIGN, 1, 4, 0, 1, 1)
+    assert o["flags"] & F_HARD and list(s.votes[:, 0]) == [1, 0, 0]
+    o = one(s, type=VOTE_RESP, term=1, frm=1)  # second grant = quorum of 3
+    assert (o["type"], o["index"], o["log_term"], o["role"], o["lead"]) == (O_LEADER, 5, 1, 2, 1)
+    assert s.last_index[0] == 5 and s.first_idx[0] == 5 and list(s.match[:, 0]) == [5, 0, 0]
+    assert list(s.votes[:, 0]) == [0, 0, 0]  # reset() clears the vote map
+    o = one(s, type=APP_RESP, term=1, frm=2, index=5)
+    assert o["type"] == O_PROGRESS and o["index"] == 5 and o["commit"] == 5
+    assert o["flags"] == F_HARD | F_COMMIT | F_UPD
+    o = one(s, type=APP_RESP, term=1, frm=2, index=5)  # duplicate ack: nothing changes
+    assert o["flags"] == 0 and o["commit"] == 5
+
+
+def test_old_term_entries_commit_only_with_the_leaders_own_entry():
+    """Raft 5.4.2: counting replicas commits only entries of the current term."""
+    s = pyoracle.NodeState(1, 3)
+    s.term[0], s.last_index[0], s.last_term[0], s.role[0] = 2, 5, 2, 1  # candidate at term 2... campaigns again
+    one(s, type=HUP)                                # term 3
+    one(s, type=VOTE_RESP, term=3, frm=1)           # leader, empty entry at 6
+    assert s.first_idx[0] == 6 and s.last_index[0] == 6
+    o = one(s, type=APP_RESP, term=3, frm=1, index=5)  # a quorum holds 5, an entry of term 2
+    assert o["commit"] == 0 and not (o["flags"] & F_COMMIT) and o["flags"] & F_UPD
+    o = one(s, type=APP_RESP, term=3, frm=1, index=6)
+    assert o["commit"] == 6 and o["flags"] & F_COMMIT
+
+
+def test_vote_granting_rules():
+    s = pyoracle.NodeState(1, 3, self_peer=0)
+    s.term[0], s.last_index[0], s.last_term[0] = 2, 5, 2
+    o = one(s, type=VOTE, term=3, frm=1, index=4, log_term=2)  # higher term, but log behind
+    assert (o["type"], o["reject"], o["term"], o["vote"], o["lead"]) == (O_VOTE_RESP, 1, 3, 0, 0)
+    assert o["flags"] & F_HARD
+    o = one(s, type=VOTE, term=3, frm=2, index=5, log_term=2)  # as up to date as ours
+    assert (o["reject"], o["vote"]) == (0, 3) and s.elapsed[0] == 0
+    o = one(s, type=VOTE, term=3, frm=1, index=9, log_term=3)  # better log, but already voted for 2
+    assert (o["reject"], o["vote"]) == (1, 3) and o["flags"] == 0
+    o = one(s, type=VOTE, term=3, frm=2, index=5, log_term=2)  # the same candidate again
+    assert (o["reject"], o["vote"]) == (0, 3)
+    o = one(s, type=VOTE, term=4, frm=1, index=0, log_term=3)  # higher last term beats a longer log
+    assert (o["reject"], o["vote"], o["term"]) == (0, 2, 4)
+
+
+def test_stale_term_is_ignored():
+    s = pyoracle.NodeState(1, 3)
+    s.term[0], s.role[0], s.lead[0] = 5, 0, 2
+    before = {k: getattr(s, k).copy() for k, _ in s.FIELDS}
+    for t in (APP, APP_RESP, VOTE, VOTE_RESP, HB, HB_RESP):
+        o = one(s, type=t, term=4, frm=1, index=3, commit=3)
+        assert o["type"] == NONE and o["flags"] == 0 and o["term"] == 5
+    for k, _ in s.FIELDS:
+        assert np.array_equal(before[k], getattr(s, k)), k
+
+
+def test_candidate_rejected_by_quorum_steps_down_and_even_n_rule():
+    s = pyoracle.NodeState(2, 5)
+    one(s, group=0, type=HUP)
+    for p in (1, 2):
+        assert one(s, group=0, type=VOTE_RESP, term=1, frm=p, reject=1)["role"] == 1
+    o = one(s, group=0, type=VOTE_RESP, term=1, frm=3, reject=1)  # third rejection = q
+    assert o["role"] == 0 and o["flags"] & F_DOWN and o["lead"] == 0 and o["term"] == 1 and o["vote"] == 1
+    # N = 4, q = 3: two rejections make winning impossible, but the 2015 rule waits for q of them
+    s4 = pyoracle.NodeState(1, 4)
+    one(s4, type=HUP)
+    one(s4, type=VOTE_RESP, term=1, frm=1, reject=1)
+    assert one(s4, type=VOTE_RESP, term=1, frm=2, reject=1)["role"] == 1
+    assert one(s4, type=VOTE_RESP, term=1, frm=3, reject=1)["role"] == 0
+
+
+def test_first_vote_response_of_a_peer_wins():
+    s = pyoracle.NodeState(1, 5)
+    one(s, type=HUP)
+    one(s, type=VOTE_RESP, term=1, frm=1, reject=1)
+    one(s, type=VOTE_RESP, term=1, frm=1, reject=0)  # a later "grant" from the same peer is ignored
+    assert s.votes[1, 0] == 2
+    one(s, type=VOTE_RESP, term=1, frm=2)
+    assert s.role[0] == 1  # 2 granted of 5 (self + peer 2): not yet
+    assert one(s, type=VOTE_RESP, term=1, frm=3)["type"] == O_LEADER
+
+
+def test_heartbeat_follower_and_candidate():
+    s = pyoracle.NodeState(2, 3, self_peer=2)
+    s.term[:], s.last_index[:], s.elapsed[:] = 3, 10, 7
+    o = one(s, group=0, type=HB, term=3, frm=0, commit=8)
+    assert (o["type"], o["to"], o["commit"], o["lead"]) == (O_HB_RESP, 0, 8, 1) and s.elapsed[0] == 0
+    assert o["flags"] == F_HARD | F_COMMIT
+    o = one(s, group=0, type=HB, term=3, frm=0, commit=25)  # clamped to the log tail (upstream would panic)
+    assert o["commit"] == 10
+    o = one(s, group=0, type=HB, term=3, frm=0, commit=4)   # never decreases
+    assert o["commit"] == 10 and o["flags"] == 0
+    one(s, group=1, type=HUP)                               # candidate at term 4
+    o = one(s, group=1, type=HB, term=4, frm=1, commit=2)   # a leader exists at our term
+    assert (o["role"], o["lead"], o["commit"]) == (0, 2, 2) and o["flags"] & F_DOWN
+
+
+def test_leader_steps_down_on_higher_term():
+    s = pyoracle.NodeState(1, 3)
+    one(s, type=HUP)
+    one(s, type=VOTE_RESP, term=1, frm=1)
+    one(s, type=APP_RESP, term=1, frm=1, index=1)
+    assert s.committed[0] == 1 and s.role[0] == 2
+    o = one(s, type=HB_RESP, term=2, frm=2)  # any message of a higher term
+    assert (o["role"], o["term"], o["lead"], o["vote"], o["type"]) == (0, 2, 3, 0, NONE)
+    assert o["flags"] == F_HARD | F_DOWN
+    assert s.first_idx[0] == 0 and list(s.match[:, 0]) == [1, 0, 0] and s.committed[0] == 1
+    o = one(s, type=VOTE, term=3, frm=1, index=1, log_term=1)  # MsgVote of a higher term: lead = None
+    assert (o["lead"], o["reject"], o["vote"]) == (0, 0, 2)
+
+
+def test_single_voter_group_leads_and_commits_at_once():
+    s = pyoracle.NodeState(1, 1)
+    s.last_index[0], s.last_term[0] = 3, 0
+    o = one(s, type=HUP)
+    assert (o["type"], o["role"], o["term"], o["index"], o["commit"]) == (O_LEADER, 2, 1, 4, 4)
+    assert one(s, type=HUP)["type"] == NONE  # a leader ignores MsgHup
+    s.apply_log_deltas([0], [6], [1])         # two proposals appended
+    assert s.committed[0] == 6
+
+
+def test_local_beat_and_roles():
+    s = pyoracle.NodeState(2, 3)
+    one(s, group=0, type=HUP)
+    one(s, group=0, type=VOTE_RESP, term=1, frm=1)
+    assert one(s, group=0, type=BEAT)["type"] == O_BCAST_HB
+    assert one(s, group=1, type=BEAT)["type"] == NONE
+    assert one(s, group=0, type=VOTE, term=1, frm=2)["reject"] == 1      # leader rejects same-term votes
+    assert one(s, group=0, type=HB, term=1, frm=2)["type"] == NONE       # no case upstream
+    assert one(s, group=0, type=HB_RESP, term=1, frm=2)["type"] == O_PROGRESS
+
+
+def test_app_header_and_log_deltas_on_a_follower():
+    s = pyoracle.NodeState(1, 3, self_peer=1)
+    s.term[0] = 2
+    one(s, type=HUP)  # candidate at 3
+    o = one(s, type=APP, term=3, frm=0)
+    assert (o["type"], o["role"], o["lead"]) == (O_APPEND, 0, 1)
+    s.apply_log_deltas([0], [7], [3], commit_to=9)  # maybeAppend put the tail at 7; leader's commit is 9
+    assert (s.last_index[0], s.last_term[0], s.committed[0]) == (7, 3, 7)
+    s.apply_log_deltas([0, 0], [8, 9], [3, 3], commit_to=[0, 8])  # two reports of one group, in order
+    assert (s.last_index[0], s.committed[0]) == (9, 8)
+
+
+def test_ack_beyond_the_leaders_log_is_clamped():
+    s = pyoracle.NodeState(1, 3)
+    one(s, type=HUP)
+    one(s, type=VOTE_RESP, term=1, frm=1)
+    o = one(s, type=APP_RESP, term=1, frm=1, index=1000)
+    assert o["index"] == 1 and o["commit"] == 1
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**31), st.sampled_from([1, 2, 3, 4, 5, 7, 9]), st.integers(0, 8))
+def test_invariants_under_random_traffic(seed, N, self_peer):
+    rng = np.random.default_rng(seed)
+    G = 48
+    s = _stepgen.random_state(rng, G, N, self_peer % N)
+    for _ in range(6):
+        t0, c0 = s.term.copy(), s.committed.copy()
+        m = _stepgen.random_batch(rng, s, 400)
+        out = s.step_batch(m)
+        assert np.all(s.term >= t0) and np.all(s.committed >= c0)
+        assert np.all(s.committed <= s.last_index)
+        lead = s.role == 2
+        assert np.all(s.lead[lead] == s.self_peer + 1) and np.all(s.first_idx[lead] != 0)
+        assert np.all(s.first_idx[~lead] == 0)
+        assert np.all(s.votes[:, s.role != 1] == 0)
+        assert np.all(out["term"] >= m["term"] * (out["type"] != NONE))
+        assert np.all(s.match[s.self_peer][lead] == s.last_index[lead])
+        # batch split invariance: the oracle is sequential, so any split gives the same result
+    a = _stepgen.random_state(np.random.default_rng(seed), G, N, self_peer % N)
+    b = _stepgen.random_state(np.random.default_rng(seed), G, N, self_peer % N)
+    m = _stepgen.random_batch(rng, a, 300)
+    oa = a.step_batch(m)
+    ob = np.concatenate([b.step_batch(m[:77]), b.step_batch(m[77:])])
+    assert np.array_equal(oa, ob)
+    for k, _ in a.FIELDS:
+        assert np.array_equal(getattr(a, k), getattr(b, k))

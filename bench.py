@@ -187,6 +187,76 @@ def tick_measure(cfg, device, ticks=2000):
             "last_tick": {"n_hup": hup, "n_beat": beat}}
 
 
+def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
+    """raftNode.Process -> rc.node.Step (raft.go:268-270) for a whole batch of
+    inbound messages (raftq_step_batch).  Every group is led by this node; the traffic is what a
+    leader of many groups sees: MsgAppResp acks (75 %), MsgHeartbeatResp (20 %), a few MsgVote of a
+    higher term (the leader steps down) and stale-term stragglers.  Wall time of the call, PCIe
+    both ways included (64 B in + 64 B out per message)."""
+    from raftsql_amd import step as S
+
+    G, N = cfg["G"], cfg["N"]
+    rng = np.random.default_rng(77)
+    e = S.NodeEngine(G, N, self_peer=0, device=device)
+    term = np.full(G, 3, np.uint64)
+    last = rng.integers(50, 100, G).astype(np.uint64)
+    match = (last[None, :] * rng.random((N, G))).astype(np.uint64)
+    match[0] = last
+    committed = np.sort(match, axis=0)[N - (N // 2 + 1)] // 2
+    e.load_match(match, committed)
+    e.load_terms(term, np.ones(G, np.uint64))
+    e.load_roles(np.full(G, 2, np.uint8))
+    e.load_node(term, np.ones(G, np.uint32), np.ones(G, np.uint32), last, term)
+
+    def batch():
+        g = rng.integers(0, G, msgs_per_batch).astype(np.uint64)
+        u = rng.random(msgs_per_batch)
+        t = np.where(u < 0.75, S.MSG_APP_RESP, np.where(u < 0.95, S.MSG_HEARTBEAT_RESP, S.MSG_VOTE)).astype(np.uint8)
+        mt = np.where(t == S.MSG_VOTE, 4, np.where(rng.random(msgs_per_batch) < 0.02, 2, 3)).astype(np.uint64)
+        return S.pack_msgs(g, t, term=mt, frm=rng.integers(1, N, msgs_per_batch),
+                           index=(last[g] * rng.random(msgs_per_batch)).astype(np.uint64), log_term=3)
+
+    bs = [batch() for _ in range(batches)]
+    e.step_batch(bs[0])
+    half = (batches - 1) // 2
+    # (a) copying form: caller-owned (pageable) arrays in and out
+    t0 = time.perf_counter()
+    for b in bs[1:1 + half]:
+        e.step_batch(b)
+    dt_copy = time.perf_counter() - t0
+    # (b) zero-copy form: the batch is produced straight into the pinned staging area (as a
+    # network receive loop would) and the result records are read in place
+    staged = e.step_stage(msgs_per_batch)
+    touched, dt = 0, 0.0
+    for b in bs[1 + half:]:
+        staged[:] = b  # producing the batch is the caller's cost, not the call's
+        t0 = time.perf_counter()
+        _, k = e.step_inplace(staged)
+        dt += time.perf_counter() - t0
+        touched += k
+    nb = batches - 1 - half
+    out = {"what": "raftq_step_batch: batched raft.Step (MsgAppResp / MsgHeartbeatResp / MsgVote mix) over "
+                   "device-resident node state; wall time of the call incl. PCIe both ways (64 B in + 64 B out per "
+                   "message) and its one sync; zero-copy staging form",
+           "groups": G, "peers": N, "msgs_per_batch": msgs_per_batch, "us_per_batch": dt / nb * 1e6,
+           "msgs_per_s": msgs_per_batch * nb / dt, "groups_touched_per_batch": touched / nb,
+           "us_per_batch_copying_form": dt_copy / half * 1e6}
+    e.close()
+    if with_cpu:
+        from oracle import pyoracle  # cpu_baseline leg: the sequential restatement, one thread
+
+        s = pyoracle.NodeState(G, N, 0)
+        s.term[:], s.last_index[:], s.last_term[:], s.role[:] = term, last, term, 2
+        s.vote[:], s.lead[:], s.first_idx[:], s.committed[:] = 1, 1, 1, committed
+        s.match[:] = match
+        t0 = time.perf_counter()
+        for b in bs[1:9]:
+            s.step_batch(b)
+        dtc = time.perf_counter() - t0
+        out["cpu_port_msgs_per_s_1thread"] = msgs_per_batch * 8 / dtc
+    return out
+
+
 def timed_loop(engines, flags, steps, world, dist):
     """Barrier + sync, K steps, barrier + sync.  -> (wall_s, event_ms)."""
     import torch
@@ -365,6 +435,7 @@ def main():
     if world.rank == 0 and world.size == 1 and not args.no_extras:
         out["pipeline"] = pipeline_measure(cfg, device)
         out["tick"] = tick_measure(cfg, device)
+        out["step"] = step_measure(cfg, device, with_cpu=not args.no_cpu_baseline)
         out["other_configs"] = {
             f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
             for c in sorted(CONFIGS) if c != args.config

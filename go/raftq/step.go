@@ -1,0 +1,97 @@
+// step.go -- cgo binding of include/raftq_step.h: the batched raft Step.
+//
+// SOURCE ONLY: never compiled or run (no Go toolchain in the build image; see README.md).
+// It is the binding INTEGRATION.md section 1b describes.
+package raftq
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../raftsql_amd -lraftq -Wl,-rpath,${SRCDIR}/../../raftsql_amd
+#include "raftq_step.h"
+*/
+import "C"
+
+import "unsafe"
+
+// raftpb.MessageType values Step accepts.
+const (
+	MsgHup           = C.RAFTQ_MSG_HUP
+	MsgBeat          = C.RAFTQ_MSG_BEAT
+	MsgApp           = C.RAFTQ_MSG_APP // header only: entries stay with the log's owner
+	MsgAppResp       = C.RAFTQ_MSG_APP_RESP
+	MsgVote          = C.RAFTQ_MSG_VOTE
+	MsgVoteResp      = C.RAFTQ_MSG_VOTE_RESP
+	MsgHeartbeat     = C.RAFTQ_MSG_HEARTBEAT
+	MsgHeartbeatResp = C.RAFTQ_MSG_HEARTBEAT_RESP
+)
+
+// Msg is layout-identical to raftq_msg_t (64 bytes).
+type Msg struct {
+	Group, Term, LogTerm, Index, Commit, RejectHint uint64
+	From                                            uint32 // peer slot = raft ID - 1
+	Type, Reject                                    uint8
+	_                                               [2]uint8
+	_                                               uint64
+}
+
+// StepOut is layout-identical to raftq_step_out_t (64 bytes).
+type StepOut struct {
+	Group, Term, Index, LogTerm, Commit, LastIndex uint64
+	To, Vote, Lead                                 uint32
+	Type, Reject, Flags, Role                      uint8
+}
+
+const (
+	OutNone           = C.RAFTQ_OUT_NONE
+	OutVoteResp       = C.RAFTQ_OUT_VOTE_RESP
+	OutHeartbeatResp  = C.RAFTQ_OUT_HEARTBEAT_RESP
+	OutCampaign       = C.RAFTQ_OUT_CAMPAIGN
+	OutBecameLeader   = C.RAFTQ_OUT_BECAME_LEADER
+	OutProgress       = C.RAFTQ_OUT_PROGRESS
+	OutBcastHeartbeat = C.RAFTQ_OUT_BCAST_HEARTBEAT
+	OutAppend         = C.RAFTQ_OUT_APPEND
+
+	FlagHardState   = C.RAFTQ_OUTF_HARDSTATE // persist {Term, Vote, Commit} before sending (raft.go:228-230)
+	FlagCommitted   = C.RAFTQ_OUTF_COMMITTED
+	FlagUpdated     = C.RAFTQ_OUTF_UPDATED
+	FlagSteppedDown = C.RAFTQ_OUTF_STEPPED_DOWN
+)
+
+// LogDelta is layout-identical to raftq_log_delta_t.
+type LogDelta struct{ Group, LastIndex, LastTerm, CommitTo uint64 }
+
+// SetSelf: which peer slot this process is in every group (raft.Config.ID - 1, raft.go:153).
+func (e *Engine) SetSelf(slot uint32) error { return e.err(C.raftq_set_self(e.h, C.uint32_t(slot))) }
+
+// StepBatch is rc.node.Step (raft.go:268-270) for every message; out[i] answers msgs[i].
+// Messages of one group are applied in slice order.
+func (e *Engine) StepBatch(msgs []Msg, out []StepOut) (groupsTouched uint64, err error) {
+	if len(msgs) == 0 {
+		return 0, nil
+	}
+	var c C.raftq_step_counts_t
+	var po *C.raftq_step_out_t
+	if len(out) >= len(msgs) {
+		po = (*C.raftq_step_out_t)(unsafe.Pointer(&out[0]))
+	}
+	rc := C.raftq_step_batch(e.h, (*C.raftq_msg_t)(unsafe.Pointer(&msgs[0])), C.uint64_t(len(msgs)), po, &c)
+	return uint64(c.n_groups_touched), e.err(rc)
+}
+
+// StepStage returns the pinned staging slice for n messages: fill it in place (e.g. straight
+// from the rafthttp receive path) and hand the same slice to StepBatch -- no host copy is made.
+func (e *Engine) StepStage(n int) ([]Msg, error) {
+	var p *C.raftq_msg_t
+	if rc := C.raftq_step_stage(e.h, C.uint64_t(n), &p); rc != C.RAFTQ_OK {
+		return nil, e.err(rc)
+	}
+	return unsafe.Slice((*Msg)(unsafe.Pointer(p)), n), nil
+}
+
+// ApplyLogDeltas reports new log tails (appendEntry on a leader, maybeAppend on a follower).
+func (e *Engine) ApplyLogDeltas(d []LogDelta) error {
+	if len(d) == 0 {
+		return nil
+	}
+	return e.err(C.raftq_apply_log_deltas(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d))))
+}

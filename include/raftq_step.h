@@ -126,6 +126,14 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
                      raftq_step_counts_t* counts);
 
+/* zero-copy variants.  raftq_step_stage returns a pinned staging array with room for n messages:
+ * fill it in place and pass the SAME pointer to raftq_step_batch and no host copy is made (valid
+ * until the next raftq_step_stage / raftq_stage / raftq_apply_* / raftq_destroy on the handle).
+ * With out == NULL the result records stay in pinned memory; raftq_step_results returns them
+ * (valid until the next raftq_step_batch). */
+int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);
+int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n);
+
 /* records of one group are applied in order */
 int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n);
 

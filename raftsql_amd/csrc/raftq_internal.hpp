@@ -61,6 +61,9 @@ struct raftq {
   uint64_t* last_term = nullptr;   // [ld]
   void* step_dev = nullptr;        // device scratch of raftq_step_batch (msgs, keys, order, outs, sort temp)
   size_t step_dev_bytes = 0;
+  void* step_out_h = nullptr;      // pinned result records of the last raftq_step_batch (+ flag, count)
+  size_t step_out_bytes = 0;
+  uint64_t step_out_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy

@@ -84,7 +84,7 @@ int ensure_scratch(raftq_t* h, uint64_t n, int end_bit, Scratch* s) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec)), o_ki = carve(n * 8),
-               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_nh = carve(8), o_cub = carve(cub_bytes);
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_nh = carve(16), o_cub = carve(cub_bytes);
   if (off > h->step_dev_bytes) {
     if (h->step_dev) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -109,11 +109,6 @@ int ensure_scratch(raftq_t* h, uint64_t n, int end_bit, Scratch* s) {
   return RAFTQ_OK;
 }
 
-bool known_type(uint8_t t) {
-  return t == RAFTQ_MSG_HUP || t == RAFTQ_MSG_BEAT || t == RAFTQ_MSG_APP || t == RAFTQ_MSG_APP_RESP ||
-         t == RAFTQ_MSG_VOTE || t == RAFTQ_MSG_VOTE_RESP || t == RAFTQ_MSG_HEARTBEAT || t == RAFTQ_MSG_HEARTBEAT_RESP;
-}
-
 }  // namespace
 
 void raftq_detail::free_node_state(raftq_t* h) {
@@ -123,6 +118,7 @@ void raftq_detail::free_node_state(raftq_t* h) {
   (void)hipFree(h->last_index);
   (void)hipFree(h->last_term);
   (void)hipFree(h->step_dev);
+  if (h->step_out_h) (void)hipHostFree(h->step_out_h);
 }
 
 extern "C" {
@@ -165,51 +161,80 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
   return RAFTQ_OK;
 }
 
+int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
+  if (int rc = use_device(h)) return rc;
+  if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");
+  if (int rc = ensure_staging(h, (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t))) return rc;
+  *msgs = (raftq_msg_t*)h->stage_h;
+  return RAFTQ_OK;
+}
+
+int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results: null argument");
+  *out = (const raftq_step_out_t*)h->step_out_h;
+  *n = h->step_out_n;
+  return RAFTQ_OK;
+}
+
 int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
                      raftq_step_counts_t* counts) {
   if (int rc = use_device(h)) return rc;
   if (counts) counts->n_msgs = counts->n_groups_touched = 0;
+  h->step_out_n = 0;
   if (n == 0) return RAFTQ_OK;
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: null messages");
   if (n > 0x7fffffffull) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: batch too large (2^31 - 1 messages at most)");
   if (int rc = ensure_node_state(h)) return rc;
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_msg_t))) return rc;
-  // one pass: validate and copy into the pinned staging area
-  {
-    raftq_msg_t* dst = (raftq_msg_t*)h->stage_h;
-    const uint64_t G = h->G, N = h->N;
-    uint64_t bad = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-      const raftq_msg_t m = msgs[i];
-      const bool local = m.type == RAFTQ_MSG_HUP || m.type == RAFTQ_MSG_BEAT;
-      bad |= (uint64_t)(m.group >= G) | (uint64_t)(!known_type(m.type)) | (uint64_t)(!local && m.from >= N);
-      dst[i] = m;
+  // pinned result area: n records + {bad flag, touched-group count}
+  const size_t out_bytes = (size_t)n * sizeof(StepOutRec) + 16;
+  if (out_bytes > h->step_out_bytes) {
+    if (h->step_out_h) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipHostFree(h->step_out_h));
+      h->step_out_h = nullptr;
+      h->step_out_bytes = 0;
     }
-    if (bad)
-      return fail(h, RAFTQ_EINVAL,
-                  "raftq_step_batch: a message is malformed (group or from out of range, or a type Step does not take); "
-                  "nothing applied");
+    const size_t want = std::max(out_bytes * 2, (size_t)1 << 20);
+    HIPCHK(h, hipHostMalloc(&h->step_out_h, want, hipHostMallocDefault));
+    h->step_out_bytes = want;
   }
+  // unless the caller filled the staging area in place (raftq_step_stage), copy into it
+  if ((const void*)msgs != h->stage_h) std::memcpy(h->stage_h, msgs, (size_t)n * sizeof(raftq_msg_t));
   int end_bit = 1;
   while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
   Scratch s;
   if (int rc = ensure_scratch(h, n, end_bit, &s)) return rc;
-  HIPCHK(h, hipMemsetAsync(s.n_heads, 0, 8, h->stream));
-  const uint64_t n_quads = n * 4;
-  hipLaunchKernelGGL(step_keys_kernel, dim3((unsigned)((n_quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                     (const uint4*)h->stage_d, (uint4*)s.msgs, s.keys_in, s.order_in, n_quads);
+  // everything below is enqueued back to back on the handle's stream; one sync at the end
+  HIPCHK(h, hipMemsetAsync(s.n_heads, 0, 16, h->stream));  // touched-group count + bad flag
+  unsigned int* bad = (unsigned int*)(s.n_heads + 1);
+  HIPCHK(h, hipMemcpyAsync(s.msgs, h->stage_h, (size_t)n * sizeof(MsgRec), hipMemcpyHostToDevice, h->stream));
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
+                     h->G, h->N, bad);
   HIPCHK(h, hipGetLastError());
   size_t cub_bytes = s.cub_bytes;
   HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
                                                (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
-  hipLaunchKernelGGL(step_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                     node_arrays(h), (const MsgRec*)s.msgs, (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out,
-                     s.outs, n, s.n_heads);
+  hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
+                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, s.outs, n, s.n_heads,
+                     (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
-  if (out) HIPCHK(h, hipMemcpyAsync(out, s.outs, n * sizeof(StepOutRec), hipMemcpyDeviceToHost, h->stream));
-  unsigned long long heads = 0;
-  if (counts) HIPCHK(h, hipMemcpyAsync(&heads, s.n_heads, 8, hipMemcpyDeviceToHost, h->stream));
+  uint8_t* tail = (uint8_t*)h->step_out_h + (size_t)n * sizeof(StepOutRec);
+  HIPCHK(h, hipMemcpyAsync(h->step_out_h, s.outs, (size_t)n * sizeof(StepOutRec), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(tail, s.n_heads, 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned long long heads;
+  unsigned int bad_h;
+  std::memcpy(&heads, tail, 8);
+  std::memcpy(&bad_h, tail + 8, 4);
+  if (bad_h)
+    return fail(h, RAFTQ_EINVAL,
+                "raftq_step_batch: a message is malformed (group or from out of range, or a type Step does not take); "
+                "nothing applied");
+  h->step_out_n = n;
+  if (out) std::memcpy(out, h->step_out_h, (size_t)n * sizeof(StepOutRec));
   if (counts) {
     counts->n_msgs = n;
     counts->n_groups_touched = heads;

@@ -59,19 +59,28 @@ constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCam
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
-// ---- (1) stage -> device copy + sort keys.  The staged records sit in pinned, device-mapped
-// host memory; they are read once, 16 B per lane, fully coalesced over PCIe.
-static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const uint4* __restrict__ staged, uint4* __restrict__ msgs,
-                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ order,
-                                                           uint64_t n_quads) {
+// ---- (1) validate + sort keys.  The batch was DMA-copied from the pinned staging area into
+// HBM; one lane per record reads its first 16 B (group, term) and the 16 B holding from/type.
+// A malformed record raises *bad; step_kernel then applies nothing (the ABI's all-or-nothing rule).
+static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* __restrict__ msgs,
+                                                                  uint64_t* __restrict__ keys,
+                                                                  uint32_t* __restrict__ order, uint64_t n,
+                                                                  uint64_t n_groups, uint32_t n_peers,
+                                                                  unsigned int* bad) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_quads) return;
-  const uint4 v = staged[i];
-  msgs[i] = v;
-  if ((i & 3) == 0) {  // first quarter of a record: {group lo, group hi, term lo, term hi}
-    keys[i >> 2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    order[i >> 2] = (uint32_t)(i >> 2);
+  bool is_bad = false;
+  if (i < n) {
+    const uint64_t g = msgs[i].group;
+    const uint32_t from = msgs[i].from;
+    const uint8_t t = msgs[i].type;
+    const bool local = t == kMsgHup || t == kMsgBeat;
+    const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
+                       t == kMsgHeartbeat || t == kMsgHeartbeatResp;
+    is_bad = g >= n_groups || !known || (!local && from >= n_peers);
+    keys[i] = is_bad ? 0 : g;  // keep the sort's key range valid
+    order[i] = (uint32_t)i;
   }
+  if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 
 // ---- (3) one group's state in registers ------------------------------------------------------
@@ -256,7 +265,9 @@ struct Node {
 static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
                                                       const uint64_t* __restrict__ keys_sorted,
                                                       const uint32_t* __restrict__ order, StepOutRec* __restrict__ out,
-                                                      uint64_t n, unsigned long long* n_heads) {
+                                                      uint64_t n, unsigned long long* n_heads,
+                                                      const unsigned int* bad) {
+  if (*bad) return;  // a malformed record somewhere in the batch: nothing is applied
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool head = false;
   uint64_t g = 0;

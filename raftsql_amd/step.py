@@ -89,6 +89,28 @@ class NodeEngine(QuorumEngine):
                                              _ptr(out) if (want_out and n) else None, C.byref(c)))
         return out, int(c.n_groups_touched)
 
+    def step_stage(self, n: int) -> np.ndarray:
+        """Pinned staging array for n messages (raftq_step_stage): fill in place, pass to step_inplace()."""
+        p = C.c_void_p(None)
+        self._chk(self._lib.raftq_step_stage(self._h, int(n), C.byref(p)))
+        if n == 0:
+            return np.empty(0, dtype=MSG_DT)
+        buf = (C.c_char * (n * MSG_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MSG_DT, count=n)
+
+    def step_inplace(self, staged: np.ndarray):
+        """Step for a staged batch; the result records are read in place from pinned memory.
+        -> (raftq_step_out_t[] view valid until the next step, n_groups_touched)"""
+        n = len(staged)
+        c = _lib.StepCounts()
+        self._chk(self._lib.raftq_step_batch(self._h, _ptr(staged) if n else None, n, None, C.byref(c)))
+        p, k = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_step_results(self._h, C.byref(p), C.byref(k)))
+        if k.value == 0:
+            return np.empty(0, dtype=OUT_DT), int(c.n_groups_touched)
+        buf = (C.c_char * (k.value * OUT_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=OUT_DT, count=k.value), int(c.n_groups_touched)
+
     def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> None:
         a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)
         a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to

@@ -140,6 +140,22 @@ def test_step_large_sparse_batch(NodeEngine, oracle):
         _stepgen.assert_same_state(e, s)
 
 
+def test_step_staged_zero_copy_form(NodeEngine, oracle):
+    rng = np.random.default_rng(21)
+    G, N = 4096, 3
+    s = _stepgen.random_state(rng, G, N, 1)
+    with NodeEngine(G, N, 1) as e:
+        _stepgen.load_engine(e, s)
+        for n in (1, 63, 5000, 129):
+            m = _stepgen.random_batch(rng, s, n)
+            staged = e.step_stage(n)
+            staged[:] = m
+            want = s.step_batch(m)
+            got, touched = e.step_inplace(staged)
+            assert np.array_equal(got, want) and touched == len(np.unique(m["group"]))
+        _stepgen.assert_same_state(e, s)
+
+
 def test_step_rejects_malformed_batches_and_applies_nothing(NodeEngine, oracle):
     from raftsql_amd import step as S
     from raftsql_amd.engine import RaftqError

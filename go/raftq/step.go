@@ -89,9 +89,14 @@ func (e *Engine) StepStage(n int) ([]Msg, error) {
 }
 
 // ApplyLogDeltas reports new log tails (appendEntry on a leader, maybeAppend on a follower).
-func (e *Engine) ApplyLogDeltas(d []LogDelta) error {
+// committed (len(d) or nil) receives raftLog.committed after each record.
+func (e *Engine) ApplyLogDeltas(d []LogDelta, committed []uint64) error {
 	if len(d) == 0 {
 		return nil
 	}
-	return e.err(C.raftq_apply_log_deltas(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d))))
+	var pc *C.uint64_t
+	if len(committed) >= len(d) {
+		pc = (*C.uint64_t)(unsafe.Pointer(&committed[0]))
+	}
+	return e.err(C.raftq_apply_log_deltas(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d)), pc))
 }

@@ -134,8 +134,10 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n);
 
-/* records of one group are applied in order */
-int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n);
+/* records of one group are applied in order; committed_out (may be NULL) receives
+ * raftLog.committed after record i -- how a commit moved by a tail report (a leader that
+ * is its own quorum, a follower's commitTo) surfaces, the way Ready.HardState.Commit does */
+int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out /*[n]|NULL*/);
 
 #ifdef __cplusplus
 }

@@ -74,11 +74,13 @@ class NodeState:
         lib().rq_oracle_step_batch(C.byref(c), m.ctypes.data, len(m), out.ctypes.data)
         return out
 
-    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> None:
+    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> np.ndarray:
         a = np.zeros(len(np.atleast_1d(group)), dtype=STEP_LOG_DELTA_DT)
         a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to
         c = self._c()
-        lib().rq_oracle_apply_log_deltas(C.byref(c), a.ctypes.data, len(a))
+        out = np.zeros(len(a), dtype=np.uint64)
+        lib().rq_oracle_apply_log_deltas(C.byref(c), a.ctypes.data, len(a), out.ctypes.data)
+        return out
 
 
 _lib = None
@@ -133,7 +135,7 @@ def lib() -> C.CDLL:
         L.rq_oracle_step_batch.restype = None
         L.rq_oracle_step_batch.argtypes = [C.POINTER(_NodeStateC), C.c_void_p, C.c_size_t, C.c_void_p]
         L.rq_oracle_apply_log_deltas.restype = None
-        L.rq_oracle_apply_log_deltas.argtypes = [C.POINTER(_NodeStateC), C.c_void_p, C.c_size_t]
+        L.rq_oracle_apply_log_deltas.argtypes = [C.POINTER(_NodeStateC), C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 

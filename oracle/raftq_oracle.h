@@ -114,7 +114,8 @@ typedef struct rq_node_state {
 } rq_node_state_t;
 /* etcd raft.Step for every message, in order; out[i] answers msgs[i] */
 void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n, raftq_step_out_t* out);
-void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n);
+void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n,
+                                uint64_t* committed_out /*[n]|NULL*/);
 
 /* ---- timed CPU baselines (bench.py cpu_baseline leg) -------------------- */
 /* kind 0: reference-shaped loop (malloc N-slice, sort desc, index q-1, scan

@@ -291,7 +291,7 @@ void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n,
 /* the log's owner reports its new tail: leader = appendEntry's bookkeeping
  * (prs[id].maybeUpdate(lastIndex); maybeCommit()), follower = the tail of
  * handleAppendEntries (`commitTo(min(m.Commit, lastnewi))`). */
-void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n) {
+void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n, uint64_t* committed_out) {
   for (size_t i = 0; i < n; ++i) {
     node_t rr = {s, (size_t)d[i].group};
     node_t* r = &rr;
@@ -303,5 +303,6 @@ void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, 
     } else if (d[i].commit_to != 0) {
       commit_to(r, d[i].commit_to);
     }
+    if (committed_out) committed_out[i] = F(committed);
   }
 }

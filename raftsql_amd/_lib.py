@@ -100,7 +100,7 @@ _STEP_SIGS = [
     ("raftq_load_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_read_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_step_batch", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(StepCounts)]),
-    ("raftq_apply_log_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    ("raftq_apply_log_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("raftq_step_stage", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("raftq_step_results", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
 ]

@@ -242,18 +242,21 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
   return RAFTQ_OK;
 }
 
-int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n) {
+int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {
   if (int rc = use_device(h)) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: null argument");
   for (uint64_t i = 0; i < n; ++i)
     if (d[i].group >= h->G) return fail(h, RAFTQ_EINVAL, "a log delta is out of range; nothing applied");
   if (int rc = ensure_node_state(h)) return rc;
-  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_log_delta_t))) return rc;
+  const size_t off_out = align256((size_t)n * sizeof(raftq_log_delta_t));
+  if (int rc = ensure_staging(h, off_out + (size_t)n * 8)) return rc;
   // records of one group apply in order: the k-th record of a group goes into launch k
-  std::vector<uint32_t> round(n);
+  std::vector<uint32_t> round, pos_of;  // pos_of[staged position] = caller's index
   uint32_t n_rounds = 1;
   try {
+    round.resize(n);
+    pos_of.resize(n);
     std::unordered_map<uint64_t, uint32_t> seen;
     seen.reserve((size_t)n * 2);
     for (uint64_t i = 0; i < n; ++i) {
@@ -265,23 +268,26 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n) {
     return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
   }
   raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
+  uint64_t* out_h = (uint64_t*)((uint8_t*)h->stage_h + off_out);
+  uint64_t* out_d = (uint64_t*)((uint8_t*)h->stage_d + off_out);
   uint64_t pos = 0;
   for (uint32_t r = 0; r < n_rounds; ++r) {
     const uint64_t start = pos;
-    if (n_rounds == 1) {
-      std::memcpy(dst, d, n * sizeof(raftq_log_delta_t));
-      pos = n;
-    } else {
-      for (uint64_t i = 0; i < n; ++i)
-        if (round[i] == r) dst[pos++] = d[i];
-    }
+    for (uint64_t i = 0; i < n; ++i)
+      if (round[i] == r) {
+        pos_of[pos] = (uint32_t)i;
+        dst[pos++] = d[i];
+      }
     const uint64_t m = pos - start;
     if (m == 0) continue;
     hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m);
+                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m,
+                       committed_out ? out_d + start : (uint64_t*)nullptr);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (committed_out)
+    for (uint64_t k = 0; k < n; ++k) committed_out[pos_of[k]] = out_h[k];
   return RAFTQ_OK;
 }
 

@@ -291,7 +291,8 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
 
 // the log owner's tail reports; records are unique per group within a launch (the host splits
 // repeated groups into successive launches)
-static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a, const LogDeltaRec* __restrict__ d, uint64_t n) {
+static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a, const LogDeltaRec* __restrict__ d,
+                                                                   uint64_t n, uint64_t* __restrict__ committed_out) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const LogDeltaRec r = d[i];
@@ -305,6 +306,7 @@ static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a,
     node.commit_to(r.commit_to);
   }
   node.store();
+  if (committed_out) committed_out[i] = node.committed;
 }
 
 }  // namespace raftqk

@@ -1,0 +1,283 @@
+"""Python mirror of include/raftq_node.h: one raft NODE for G groups -- the reference's
+raftNode + serveChannels (raft.go:36-78, 204-246) multiplied by G -- and `Cluster`, the
+in-process multi-node fixture the tests use the way raftsql_test.go uses its `cluster`
+(raftsql_test.go:11-90: N real nodes in one process; there over loopback TCP, here over an
+in-memory transport that can drop, delay and partition)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import RaftqError
+
+ENTRY, SENTINEL, CLOSED, TIMEOUT = 0, 1, 2, 3
+ROLE_FOLLOWER, ROLE_CANDIDATE, ROLE_LEADER = 0, 1, 2
+_P = C.c_void_p
+
+
+class Status(C.Structure):
+    _fields_ = [("term", C.c_uint64), ("commit", C.c_uint64), ("last_index", C.c_uint64), ("applied", C.c_uint64),
+                ("lead", C.c_uint32), ("vote", C.c_uint32), ("role", C.c_uint8), ("_pad", C.c_uint8 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("turns", "msgs_stepped", "msgs_sent", "entries_published", "hard_states",
+                                          "proposals_dropped")]
+
+
+_SIGS = [
+    ("raftq_node_create", C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("raftq_node_replay", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("raftq_node_set_hard_state", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
+    ("raftq_node_start", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64]),
+    ("raftq_node_propose", C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32]),
+    ("raftq_node_tick", C.c_int, [_P]),
+    ("raftq_node_deliver", C.c_int, [_P, C.c_void_p, C.c_uint64]),
+    ("raftq_node_advance", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("raftq_node_poll", C.c_int, [_P, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_int)]),
+    ("raftq_node_status", C.c_int, [_P, C.c_uint64, C.POINTER(Status)]),
+    ("raftq_node_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("raftq_node_entry", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint64)]),
+    ("raftq_node_engine", C.c_void_p, [_P]),
+    ("raftq_node_close", C.c_int, [_P]),
+    ("raftq_node_error", C.c_int, [_P]),
+    ("raftq_node_last_error", C.c_char_p, [_P]),
+    ("raftq_node_destroy", None, [_P]),
+]
+EXPORTS = [s[0] for s in _SIGS]
+_bound = None
+
+
+def _load():
+    global _bound
+    if _bound is None:
+        lib = _lib.load()
+        for name, res, args in _SIGS:
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _bound = lib
+    return _bound
+
+
+class RaftNode:
+    """newRaftNode for G groups: this process is peer slot `self_peer` of every group."""
+
+    def __init__(self, n_groups: int, n_peers: int, self_peer: int, device: int = 0):
+        self._lib = _load()
+        self._p = _P(None)
+        self.n_groups, self.n_peers, self.self_peer = int(n_groups), int(n_peers), int(self_peer)
+        rc = self._lib.raftq_node_create(device, n_groups, n_peers, self_peer, C.byref(self._p))
+        if rc != 0:
+            self._p = _P(None)
+            msg = self._lib.raftq_last_error(None)
+            raise RaftqError(rc, msg.decode() if msg else "raftq_node_create failed")
+        self._buf = C.create_string_buffer(1 << 16)
+        self._wire = C.create_string_buffer(1 << 22)
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            msg = self._lib.raftq_node_last_error(self._p)
+            raise RaftqError(rc, msg.decode() if msg else "?")
+
+    # -- before start -------------------------------------------------------
+    def replay(self, group: int, entries: Iterable[tuple[int, bytes]]) -> None:
+        ents = list(entries)
+        n = len(ents)
+        terms = (C.c_uint64 * n)(*[t for t, _ in ents])
+        bufs = [C.create_string_buffer(d, len(d)) for _, d in ents]
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        lens = (C.c_uint32 * n)(*[len(d) for _, d in ents])
+        self._chk(self._lib.raftq_node_replay(self._p, group, terms, ptrs, lens, n))
+
+    def set_hard_state(self, group: int, term: int, vote: int, commit: int) -> None:
+        self._chk(self._lib.raftq_node_set_hard_state(self._p, group, term, vote, commit))
+
+    def start(self, election_tick: int = 10, heartbeat_tick: int = 1, seed: int = 0x1000) -> None:
+        self._chk(self._lib.raftq_node_start(self._p, election_tick, heartbeat_tick, seed))
+
+    # -- the crank ----------------------------------------------------------
+    def propose(self, group: int, data: bytes) -> None:
+        self._chk(self._lib.raftq_node_propose(self._p, group, data, len(data)))
+
+    def tick(self) -> None:
+        self._chk(self._lib.raftq_node_tick(self._p))
+
+    def deliver(self, frames: bytes) -> None:
+        if frames:
+            self._chk(self._lib.raftq_node_deliver(self._p, frames, len(frames)))
+
+    def advance(self) -> int:
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_node_advance(self._p, C.byref(n)))
+        return int(n.value)
+
+    def poll(self, to_peer: int) -> bytes:
+        out = []
+        while True:
+            n = C.c_uint64(0)
+            self._chk(self._lib.raftq_node_poll(self._p, to_peer, self._wire, len(self._wire), C.byref(n)))
+            if n.value == 0:
+                return b"".join(out)
+            out.append(self._wire.raw[: n.value])
+
+    # -- commit channel -----------------------------------------------------
+    def recv(self, group: int, timeout_ms: int = 0):
+        """-> (kind, payload | None)"""
+        ln, kind = C.c_uint32(0), C.c_int(0)
+        self._chk(self._lib.raftq_node_recv(self._p, group, timeout_ms, self._buf, len(self._buf), C.byref(ln),
+                                            C.byref(kind)))
+        if kind.value == ENTRY:
+            return ENTRY, self._buf.raw[: ln.value]
+        return kind.value, None
+
+    def drain(self, group: int) -> list:
+        """everything on the group's commit channel right now; the nil sentinel shows as None"""
+        out = []
+        while True:
+            kind, data = self.recv(group, 0)
+            if kind == ENTRY:
+                out.append(data)
+            elif kind == SENTINEL:
+                out.append(None)
+            else:
+                return out
+
+    def status(self, group: int) -> Status:
+        st = Status()
+        self._chk(self._lib.raftq_node_status(self._p, group, C.byref(st)))
+        return st
+
+    def stats(self) -> dict:
+        st = Stats()
+        self._chk(self._lib.raftq_node_stats(self._p, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in Stats._fields_}
+
+    def entry(self, group: int, index: int) -> tuple[int, bytes]:
+        ln, term = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self._lib.raftq_node_entry(self._p, group, index, self._buf, len(self._buf), C.byref(ln),
+                                             C.byref(term)))
+        return int(term.value), self._buf.raw[: ln.value]
+
+    def log(self, group: int) -> list[tuple[int, bytes]]:
+        return [self.entry(group, i) for i in range(1, int(self.status(group).last_index) + 1)]
+
+    def roles(self) -> np.ndarray:
+        return np.array([self.status(g).role for g in range(self.n_groups)], dtype=np.uint8)
+
+    def close(self) -> int:
+        if self._p.value:
+            return int(self._lib.raftq_node_close(self._p))
+        return 0
+
+    def destroy(self) -> None:
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self._lib.raftq_node_destroy(self._p)
+            self._p = _P(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Cluster:
+    """N RaftNodes (one per peer slot) for the same G groups, wired by an in-memory transport.
+
+    `step()` is one iteration of every node's serveChannels loop: optional Tick, advance, then
+    the transport moves every polled frame batch to its addressee.  `down` nodes neither run
+    nor receive (the reference's tests stop a node by closing it, raftsql_test.go:47-52);
+    `cut` holds (a, b) pairs whose traffic is dropped in both directions."""
+
+    def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7):
+        self.G, self.N, self.device, self.election_tick, self.seed = n_groups, n_peers, device, election_tick, seed
+        self.nodes: list[Optional[RaftNode]] = [RaftNode(n_groups, n_peers, p, device) for p in range(n_peers)]
+        self.down: set[int] = set()
+        self.cut: set[tuple[int, int]] = set()
+        self.ticks = 0
+
+    def start(self) -> None:
+        for p, nd in enumerate(self.nodes):
+            nd.start(self.election_tick, 1, seed=self.seed + 1000 * p)
+
+    def step(self, tick: bool = True) -> int:
+        published = 0
+        for p, nd in enumerate(self.nodes):
+            if p in self.down:
+                continue
+            if tick:
+                nd.tick()
+            published += nd.advance()
+        for p, nd in enumerate(self.nodes):
+            if p in self.down:
+                continue
+            for q in range(self.N):
+                if q == p:
+                    continue
+                frames = nd.poll(q)
+                if q in self.down or (p, q) in self.cut or (q, p) in self.cut:
+                    continue  # lost on the wire
+                self.nodes[q].deliver(frames)
+        self.ticks += int(tick)
+        return published
+
+    def run(self, steps: int, tick: bool = True) -> int:
+        return sum(self.step(tick) for _ in range(steps))
+
+    def settle(self, max_steps: int = 50) -> None:
+        """keep cranking without ticks until no node has anything left to say"""
+        for _ in range(max_steps):
+            before = [nd.stats()["msgs_sent"] for p, nd in enumerate(self.nodes) if p not in self.down]
+            self.step(tick=False)
+            after = [nd.stats()["msgs_sent"] for p, nd in enumerate(self.nodes) if p not in self.down]
+            if before == after:
+                return
+
+    def leaders(self) -> np.ndarray:
+        """[G] leader slot per group among the live nodes at the highest term, -1 if none"""
+        out = np.full(self.G, -1, dtype=np.int64)
+        best = np.zeros(self.G, dtype=np.uint64)
+        for p, nd in enumerate(self.nodes):
+            if p in self.down:
+                continue
+            for g in range(self.G):
+                st = nd.status(g)
+                if st.role == ROLE_LEADER and st.term >= best[g]:
+                    out[g], best[g] = p, st.term
+        return out
+
+    def stop(self, p: int) -> list[list[tuple[int, bytes]]]:
+        """close node p and return its logs (its WAL, for a later restart)"""
+        nd = self.nodes[p]
+        logs = [nd.log(g) for g in range(self.G)]
+        assert nd.close() == 0
+        nd.destroy()
+        self.down.add(p)
+        return logs
+
+    def restart(self, p: int, logs) -> RaftNode:
+        nd = RaftNode(self.G, self.N, p, self.device)
+        for g, ents in enumerate(logs):
+            if ents:
+                nd.replay(g, ents)
+        nd.start(self.election_tick, 1, seed=self.seed + 1000 * p + 17)
+        self.nodes[p] = nd
+        self.down.discard(p)
+        return nd
+
+    def close(self) -> None:
+        for p, nd in enumerate(self.nodes):
+            if nd is not None and p not in self.down:
+                nd.destroy()

@@ -111,7 +111,11 @@ class NodeEngine(QuorumEngine):
         buf = (C.c_char * (k.value * OUT_DT.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=OUT_DT, count=k.value), int(c.n_groups_touched)
 
-    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> None:
+    def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> np.ndarray:
+        """-> committed [n] after each record"""
         a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)
         a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to
-        self._chk(self._lib.raftq_apply_log_deltas(self._h, _ptr(a) if len(a) else None, len(a)))
+        out = np.zeros(len(a), dtype=np.uint64)
+        self._chk(self._lib.raftq_apply_log_deltas(self._h, _ptr(a) if len(a) else None, len(a),
+                                                   _ptr(out) if len(a) else None))
+        return out

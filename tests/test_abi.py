@@ -25,15 +25,16 @@ def _declared(header="raftq.h"):
 
 
 def test_header_and_binding_list_the_same_symbols():
-    from raftsql_amd import _lib, pipe
+    from raftsql_amd import _lib, node, pipe
 
+    assert _declared("raftq_node.h") == sorted(node.EXPORTS)
     assert _declared() == sorted(_lib.EXPORTS)
     assert _declared("raftq_pipe.h") == sorted(pipe.EXPORTS)
     assert _declared("raftq_step.h") == sorted(_lib.STEP_EXPORTS)
 
 
 def test_every_declared_symbol_is_exported(lib):
-    for name in _declared() + _declared("raftq_pipe.h") + _declared("raftq_step.h"):
+    for name in _declared() + _declared("raftq_pipe.h") + _declared("raftq_step.h") + _declared("raftq_node.h"):
         assert hasattr(lib, name), name
 
 
@@ -69,7 +70,7 @@ def test_argument_validation_without_device(lib):
     lib.raftq_destroy(None)  # must be a no-op
     assert lib.raftq_step_batch(None, None, 0, None, None) == _lib.RAFTQ_EINVAL
     assert lib.raftq_set_self(None, 0) == _lib.RAFTQ_EINVAL
-    assert lib.raftq_apply_log_deltas(None, None, 0) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_apply_log_deltas(None, None, 0, None) == _lib.RAFTQ_EINVAL
 
 
 def test_no_silent_cpu_fallback(lib):

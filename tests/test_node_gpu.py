@@ -1,0 +1,213 @@
+"""GPU: multi-node raft clusters of G groups, after the reference's own integration tests
+(raftsql_test.go:11-171).  There: 3 real nodes in one process over loopback TCP, one group.
+Here: 3 (or 5) real nodes in one process over an in-memory transport, G groups each; every
+election, vote, heartbeat and commit decision is the batched GPU Step / Tick.  What is
+asserted is what the reference asserts -- statements become visible on every node, in order;
+a stopped node does not block a quorum; a restarted node replays exactly its log and then
+the nil sentinel -- plus the raft safety properties the reference takes on faith."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def Cluster(gpu_engine_cls):
+    from raftsql_amd.node import Cluster as C
+
+    return C
+
+
+def elect(c, max_ticks=60):
+    for _ in range(max_ticks):
+        c.step(tick=True)
+        if np.all(c.leaders() >= 0):
+            c.settle()
+            return
+    raise AssertionError(f"no leader for groups {np.nonzero(c.leaders() < 0)[0][:10]} after {max_ticks} ticks")
+
+
+def check_safety(c):
+    """Election safety + log matching + leader completeness over the live nodes."""
+    live = [nd for p, nd in enumerate(c.nodes) if p not in c.down]
+    for g in range(c.G):
+        sts = [nd.status(g) for nd in live]
+        by_term = {}
+        for st in sts:
+            if st.role == 2:
+                assert by_term.setdefault(st.term, 0) == 0, f"two leaders in term {st.term} of group {g}"
+                by_term[st.term] += 1
+        logs = [nd.log(g) for nd in live]
+        commit = min(st.commit for st in sts)
+        for lg in logs[1:]:
+            assert lg[:commit] == logs[0][:commit], f"committed prefixes differ in group {g}"
+        for a in logs:
+            assert all(a[i][0] <= a[i + 1][0] for i in range(len(a) - 1)), "log terms must not decrease"
+
+
+def test_new_db_analog_three_nodes(Cluster):
+    """TestNewDB (raftsql_test.go:92-115): CREATE on node 0, one INSERT per node; every node
+    sees all four statements, in the same order."""
+    c = Cluster(6, 3)
+    try:
+        c.start()
+        for nd in c.nodes:
+            for g in range(c.G):
+                assert nd.drain(g) == [None]  # fresh WAL: only the nil sentinel (raft.go:131-132)
+        elect(c)
+        lead = c.leaders()
+        assert np.all(lead >= 0)
+        g = 2
+        c.nodes[0].propose(g, b"CREATE TABLE t (id int primary key, v int)")
+        c.settle()
+        for i, nd in enumerate(c.nodes):  # followers forward to the leader (MsgProp)
+            nd.propose(g, b"INSERT INTO t (v) VALUES (%d)" % i)
+            c.settle()
+        want = [b"CREATE TABLE t (id int primary key, v int)"] + [b"INSERT INTO t (v) VALUES (%d)" % i for i in range(3)]
+        for nd in c.nodes:
+            assert nd.drain(g) == want
+            for other in range(c.G):
+                if other != g:
+                    assert nd.drain(other) == []  # "main.x does not exist" on every node
+        check_safety(c)
+    finally:
+        c.close()
+
+
+def test_restart_db_analog(Cluster):
+    """TestRestartDB (raftsql_test.go:117-171): stop a node; 2 of 3 still commit; the restarted
+    node replays exactly its 4 logged statements before the nil sentinel, does not have `foo`
+    right after replay, and gets it once the leader has caught it up."""
+    c = Cluster(3, 3)
+    try:
+        c.start()
+        elect(c)
+        g = 1
+        stmts = [b"CREATE TABLE t (id int primary key, v int)"] + [b"INSERT INTO t (v) VALUES (%d)" % i for i in range(3)]
+        for s in stmts:
+            c.nodes[int(c.leaders()[g])].propose(g, s)
+            c.settle()
+        for nd in c.nodes:
+            assert [d for d in nd.drain(g) if d is not None] == stmts
+        victim = (int(c.leaders()[g]) + 1) % 3  # a follower of group g
+        logs = c.stop(victim)
+        assert [d for _, d in logs[g] if d] == stmts
+        elect(c)  # groups the victim led need a new leader; 2 of 3 is a quorum
+        c.nodes[int(c.leaders()[g])].propose(g, b"INSERT INTO t (v) VALUES ('foo')")
+        c.settle()
+        for p, nd in enumerate(c.nodes):
+            if p != victim:
+                assert nd.drain(g) == [b"INSERT INTO t (v) VALUES ('foo')"]
+        nd = c.restart(victim, logs)
+        replayed = nd.drain(g)
+        assert replayed[-1] is None and replayed[:-1] == stmts and len(replayed) == 5  # exactly 4, then nil
+        assert nd.status(g).term == 0  # HardState is not restored by replay (raft.go:124)
+        c.run(5)
+        c.settle()
+        assert nd.drain(g) == [b"INSERT INTO t (v) VALUES ('foo')"]
+        check_safety(c)
+    finally:
+        c.close()
+
+
+def test_many_groups_elect_and_commit(Cluster):
+    """2000 groups x 3 nodes: every group elects exactly one leader, leadership spreads over the
+    nodes (randomised timeouts), and a proposal per group commits on every node."""
+    G = 2000
+    c = Cluster(G, 3, seed=11)
+    try:
+        c.start()
+        elect(c, max_ticks=80)
+        lead = c.leaders()
+        counts = np.bincount(lead, minlength=3)
+        assert counts.sum() == G and counts.min() > G // 10, counts
+        for g in range(G):
+            c.nodes[int(lead[g])].propose(g, b"v%d" % g)
+        c.settle()
+        c.run(2)  # a heartbeat round carries the commit index to the followers
+        c.settle()
+        for p, nd in enumerate(c.nodes):
+            got = [nd.drain(g) for g in range(G)]
+            assert all(got[g] == [None, b"v%d" % g] for g in range(G)), p
+        st = c.nodes[0].stats()
+        assert st["msgs_stepped"] > 3 * G and st["proposals_dropped"] == 0
+        check_safety(c)
+    finally:
+        c.close()
+
+
+def test_partitioned_leader_cannot_commit_and_rejoins(Cluster):
+    """5 nodes: cut the leader of a group off.  It keeps accepting proposals but commits nothing;
+    the majority side elects a new leader and commits; after healing, the old leader's
+    uncommitted entry is overwritten and every node delivers the same sequence."""
+    c = Cluster(4, 5, seed=3)
+    try:
+        c.start()
+        elect(c)
+        g = 0
+        old = int(c.leaders()[g])
+        c.nodes[old].propose(g, b"a")
+        c.settle()
+        for q in range(5):
+            if q != old:
+                c.cut.add((old, q))
+        c.nodes[old].propose(g, b"lost")  # reaches nobody
+        c.run(3)
+        assert c.nodes[old].status(g).commit == c.nodes[old].status(g).last_index - 1
+        for _ in range(80):
+            c.step()
+            l2 = [p for p in range(5) if p != old and c.nodes[p].status(g).role == 2]
+            if l2:
+                break
+        assert l2, "majority side elected no leader"
+        new = l2[0]
+        assert c.nodes[new].status(g).term > c.nodes[old].status(g).term
+        c.nodes[new].propose(g, b"b")
+        c.settle()
+        c.run(2)
+        c.settle()
+        c.cut.clear()
+        c.run(6)
+        c.settle()
+        assert c.nodes[old].status(g).role == 0
+        seqs = [[d for d in nd.drain(g) if d is not None] for nd in c.nodes]
+        assert all(s == [b"a", b"b"] for s in seqs), seqs
+        assert b"lost" not in [d for _, d in c.nodes[old].log(g)]
+        check_safety(c)
+    finally:
+        c.close()
+
+
+def test_single_node_cluster_commits_immediately(Cluster):
+    c = Cluster(5, 1)
+    try:
+        c.start()
+        elect(c, max_ticks=30)
+        for g in range(5):
+            c.nodes[0].propose(g, b"x%d" % g)
+        c.step(tick=False)
+        for g in range(5):
+            assert c.nodes[0].drain(g) == [None, b"x%d" % g]
+    finally:
+        c.close()
+
+
+def test_node_rejects_garbage_frames_and_bad_calls(Cluster):
+    from raftsql_amd.engine import RaftqError
+
+    c = Cluster(2, 3)
+    try:
+        nd = c.nodes[0]
+        with pytest.raises(RaftqError):
+            nd.propose(0, b"too early")  # not started
+        c.start()
+        for bad in (b"\x00" * 10, b"\xff" * 64, b"\x00" * 56 + b"\x05\x00\x00\x00\x00\x00\x00\x00"):
+            with pytest.raises(RaftqError):
+                nd.deliver(bad)
+        with pytest.raises(RaftqError):
+            nd.propose(2, b"no such group")
+        assert nd.advance() == 0
+        assert nd.close() == 0
+        assert nd.recv(0)[0] in (1, 2)  # the sentinel is still queued, then CLOSED
+    finally:
+        c.close()

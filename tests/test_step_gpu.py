@@ -47,8 +47,8 @@ def test_step_parity_hot_groups(NodeEngine, oracle, N, self_peer):
             ct = np.where(rng.random(300) < 0.5, 0, s.committed[g] + rng.integers(0, 4, 300).astype(np.uint64))
             p = rng.permutation(300)
             p = p[np.argsort(g[p], kind="stable")] if rnd % 2 else np.arange(300)  # grouped or as generated
-            s.apply_log_deltas(g[p], li[p], lt[p], ct[p])
-            e.apply_log_deltas(g[p], li[p], lt[p], ct[p])
+            assert np.array_equal(e.apply_log_deltas(g[p], li[p], lt[p], ct[p]),
+                                  s.apply_log_deltas(g[p], li[p], lt[p], ct[p]))
             _stepgen.assert_same_state(e, s)
 
 

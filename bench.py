@@ -257,6 +257,54 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     return out
 
 
+def node_measure(device, G=32768, N=3, rounds=6):
+    """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
+    same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
+    waves of one proposal per group on its leader, cranked until every node has delivered every
+    entry on its commit channels.  Wall time, Python transport included."""
+    from raftsql_amd.node import Cluster
+
+    c = Cluster(G, N, device=device, seed=5)
+    c.start()
+    t0 = time.perf_counter()
+    ticks = 0
+    while True:
+        c.step(tick=True)
+        ticks += 1
+        lead = c.leaders() if ticks % 4 == 0 else None
+        if lead is not None and np.all(lead >= 0):
+            break
+        if ticks > 200:
+            raise SystemExit("node_measure: elections did not finish")
+    c.settle()
+    t_elect = time.perf_counter() - t0
+    lead = c.leaders()
+    base = [nd.stats() for nd in c.nodes]
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        for g in range(G):
+            c.nodes[int(lead[g])].propose(g, b"INSERT INTO t (v) VALUES (%d)" % r)
+        want = (r + 1) * G
+        for _ in range(40):
+            c.step(tick=False)
+            if all(nd.stats()["entries_published"] - b["entries_published"] >= want for nd, b in zip(c.nodes, base)):
+                break
+            if _ % 3 == 2:
+                c.step(tick=True)  # a heartbeat carries the commit index to the followers
+        else:
+            raise SystemExit("node_measure: a proposal wave did not commit everywhere")
+    dt = time.perf_counter() - t0
+    st = [nd.stats() for nd in c.nodes]
+    stepped = sum(s["msgs_stepped"] - b["msgs_stepped"] for s, b in zip(st, base))
+    c.close()
+    return {"what": "raftq_node x%d on one GPU, %d groups: propose on the leader -> MsgApp -> MsgAppResp -> batched "
+                    "Step -> commit -> delivered on every node's commit channel" % (N, G),
+            "groups": G, "nodes": N, "election_s": t_elect, "election_ticks": ticks,
+            "leaders_per_node": np.bincount(lead, minlength=N).tolist(),
+            "proposals_committed_everywhere_per_s": rounds * G / dt, "msgs_stepped_per_s": stepped / dt,
+            "s_per_wave": dt / rounds}
+
+
 def timed_loop(engines, flags, steps, world, dist):
     """Barrier + sync, K steps, barrier + sync.  -> (wall_s, event_ms)."""
     import torch
@@ -436,6 +484,7 @@ def main():
         out["pipeline"] = pipeline_measure(cfg, device)
         out["tick"] = tick_measure(cfg, device)
         out["step"] = step_measure(cfg, device, with_cpu=not args.no_cpu_baseline)
+        out["node"] = node_measure(device)
         out["other_configs"] = {
             f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
             for c in sorted(CONFIGS) if c != args.config

@@ -206,6 +206,8 @@ class Cluster:
         self.nodes: list[Optional[RaftNode]] = [RaftNode(n_groups, n_peers, p, device) for p in range(n_peers)]
         self.down: set[int] = set()
         self.cut: set[tuple[int, int]] = set()
+        self.loss = 0.0  # probability that one node-to-node transfer (a batch of frames) is lost
+        self._rng = np.random.default_rng(seed)
         self.ticks = 0
 
     def start(self) -> None:
@@ -229,6 +231,8 @@ class Cluster:
                 frames = nd.poll(q)
                 if q in self.down or (p, q) in self.cut or (q, p) in self.cut:
                     continue  # lost on the wire
+                if self.loss and frames and self._rng.random() < self.loss:
+                    continue
                 self.nodes[q].deliver(frames)
         self.ticks += int(tick)
         return published
@@ -259,19 +263,28 @@ class Cluster:
         return out
 
     def stop(self, p: int) -> list[list[tuple[int, bytes]]]:
-        """close node p and return its logs (its WAL, for a later restart)"""
+        """close node p and return its logs (its WAL, for a later restart); the HardStates a WAL
+        would also hold are kept in self.hard_states[p] as (term, vote, commit) per group"""
         nd = self.nodes[p]
         logs = [nd.log(g) for g in range(self.G)]
+        sts = [nd.status(g) for g in range(self.G)]
+        if not hasattr(self, "hard_states"):
+            self.hard_states = {}
+        self.hard_states[p] = [(int(st.term), int(st.vote), int(st.commit)) for st in sts]
         assert nd.close() == 0
         nd.destroy()
         self.down.add(p)
         return logs
 
-    def restart(self, p: int, logs) -> RaftNode:
+    def restart(self, p: int, logs, restore_hard_state: bool = False) -> RaftNode:
+        """restart from the WAL.  restore_hard_state=False is the reference's behaviour (replayWAL
+        discards HardState, raft.go:124); True is what a correct raft needs to stay safe."""
         nd = RaftNode(self.G, self.N, p, self.device)
         for g, ents in enumerate(logs):
             if ents:
                 nd.replay(g, ents)
+            if restore_hard_state:
+                nd.set_hard_state(g, *self.hard_states[p][g])
         nd.start(self.election_tick, 1, seed=self.seed + 1000 * p + 17)
         self.nodes[p] = nd
         self.down.discard(p)

@@ -178,6 +178,92 @@ def test_partitioned_leader_cannot_commit_and_rejoins(Cluster):
         c.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_chaos_safety_and_convergence(Cluster, seed):
+    """Random message loss, partitions, stops and restarts (WAL + HardState restored) while clients
+    keep proposing on whatever node they reach.  Throughout: at most one leader per term, committed
+    prefixes agree, and what the never-restarted nodes delivered are prefixes of one sequence per
+    group.  After healing: all nodes hold the same committed sequence, no payload twice, nothing
+    invented, and every live stream is exactly that sequence."""
+    rng = np.random.default_rng(seed)
+    G, N = 24, 5
+    c = Cluster(G, N, seed=seed)
+    # delivered[p][g]: the live commit stream of node p; None once p was restarted (a replay
+    # re-publishes the whole WAL, uncommitted tail included -- the reference's contract, raft.go:129-132)
+    delivered = [[[] for _ in range(G)] for _ in range(N)]
+    proposed = set()
+
+    def collect():
+        for p, nd in enumerate(c.nodes):
+            if p in c.down or delivered[p] is None:
+                continue
+            for g in range(G):
+                delivered[p][g] += [d for d in nd.drain(g) if d is not None]
+        for g in range(G):
+            streams = [delivered[p][g] for p in range(N) if delivered[p] is not None]
+            longest = max(streams, key=len)
+            for st in streams:
+                assert st == longest[: len(st)], f"group {g}: delivered streams diverged"
+
+    try:
+        c.start()
+        elect(c)
+        stopped = {}
+        k = 0
+        for it in range(160):
+            c.loss = 0.25 if (it // 20) % 2 == 0 else 0.0
+            r = rng.random()
+            if r < 0.04 and len(c.down) < N // 2:
+                p = int(rng.choice([q for q in range(N) if q not in c.down]))
+                collect()
+                stopped[p] = c.stop(p)
+                delivered[p] = None
+            elif r < 0.10 and c.down:
+                p = int(rng.choice(sorted(c.down)))
+                c.restart(p, stopped.pop(p), restore_hard_state=True)
+            elif r < 0.14:
+                a, b = rng.choice(N, 2, replace=False)
+                c.cut.add((int(a), int(b)))
+            elif r < 0.20:
+                c.cut.clear()
+            live = [q for q in range(N) if q not in c.down]
+            for _ in range(int(rng.integers(0, 6))):
+                payload = b"op%d" % k
+                k += 1
+                proposed.add(payload)
+                c.nodes[int(rng.choice(live))].propose(int(rng.integers(0, G)), payload)
+            c.step(tick=True)
+            if it % 10 == 0:
+                check_safety(c)
+                collect()
+        # heal everything and let the cluster converge
+        c.loss = 0.0
+        c.cut.clear()
+        for p in sorted(c.down):
+            c.restart(p, stopped.pop(p), restore_hard_state=True)
+        elect(c, max_ticks=150)
+        c.run(8)
+        c.settle()
+        check_safety(c)
+        collect()
+        n_committed = 0
+        for g in range(G):
+            commits = {int(nd.status(g).commit) for nd in c.nodes}
+            assert len(commits) == 1, (g, commits)
+            commit = commits.pop()
+            seqs = [[d for _, d in nd.log(g)[:commit] if d] for nd in c.nodes]
+            assert all(sq == seqs[0] for sq in seqs), g
+            assert len(set(seqs[0])) == len(seqs[0]) and set(seqs[0]) <= proposed, g
+            n_committed += len(seqs[0])
+            for p in range(N):
+                if delivered[p] is not None:
+                    assert delivered[p][g] == seqs[0], (g, p)
+        assert any(d is not None for d in delivered)
+        assert n_committed > k // 4, (n_committed, k)  # the cluster made real progress under chaos
+    finally:
+        c.close()
+
+
 def test_single_node_cluster_commits_immediately(Cluster):
     c = Cluster(5, 1)
     try:

@@ -481,12 +481,19 @@ def main():
     for e in engines:
         e.close()
     if world.rank == 0 and world.size == 1 and not args.no_extras:
-        out["pipeline"] = pipeline_measure(cfg, device)
-        out["tick"] = tick_measure(cfg, device)
-        out["step"] = step_measure(cfg, device, with_cpu=not args.no_cpu_baseline)
-        out["node"] = node_measure(device)
+        # side measurements never take the headline line down with them
+        def guarded(fn, *a, **k):
+            try:
+                return fn(*a, **k)
+            except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
+                return {"error": f"{type(e).__name__}: {e}"}
+
+        out["pipeline"] = guarded(pipeline_measure, cfg, device)
+        out["tick"] = guarded(tick_measure, cfg, device)
+        out["step"] = guarded(step_measure, cfg, device, with_cpu=not args.no_cpu_baseline)
+        out["node"] = guarded(node_measure, device)
         out["other_configs"] = {
-            f"config{c}": side_measure(c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
+            f"config{c}": guarded(side_measure, c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
             for c in sorted(CONFIGS) if c != args.config
         }
     dist.barrier(world)

@@ -205,3 +205,36 @@ def test_invariants_under_random_traffic(seed, N, self_peer):
     assert np.array_equal(oa, ob)
     for k, _ in a.FIELDS:
         assert np.array_equal(getattr(a, k), getattr(b, k))
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.integers(0, 2**31), st.sampled_from([1, 2, 3, 4, 5, 6, 7, 9]), st.integers(0, 8))
+def test_c_oracle_agrees_with_the_object_shaped_python_statement(seed, N, self_peer):
+    """Third implementation (tests/ref_raft_py.py: one Python object per group, votes / progress as
+    maps, shaped like the Go original) against the C oracle: every result record and every word of
+    state, message by message."""
+    from tests import ref_raft_py as R
+
+    rng = np.random.default_rng(seed)
+    G = 16
+    s = _stepgen.random_state(rng, G, N, self_peer % N)
+    rafts = [R.from_node_state(s, g) for g in range(G)]
+    for g in range(G):
+        assert R.matches_node_state(rafts[g], s, g)
+    for _ in range(4):
+        m = _stepgen.random_batch(rng, s, 250)
+        out = s.step_batch(m)
+        for i in range(len(m)):
+            g = int(m["group"][i])
+            local = int(m["type"][i]) in (R.MsgHup, R.MsgBeat)
+            res = rafts[g].step(R.Message(type=int(m["type"][i]), frm=0 if local else int(m["from"][i]) + 1,
+                                          term=int(m["term"][i]), log_term=int(m["log_term"][i]),
+                                          index=int(m["index"][i]), commit=int(m["commit"][i]),
+                                          reject=bool(m["reject"][i])))
+            o, r = out[i], rafts[g]
+            assert (res.type, res.index, res.log_term, res.reject, res.flags) == \
+                (o["type"], o["index"], o["log_term"], o["reject"], o["flags"]), (i, m[i], o, res)
+            assert (r.term, r.committed, r.last_index, r.vote, r.lead, r.state) == \
+                (o["term"], o["commit"], o["last_index"], o["vote"], o["lead"], o["role"]), (i, m[i], o)
+        for g in range(G):
+            assert R.matches_node_state(rafts[g], s, g), g

@@ -126,11 +126,20 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
                      raftq_step_counts_t* counts);
 
-/* zero-copy variants.  raftq_step_stage returns a pinned staging array with room for n messages:
- * fill it in place and pass the SAME pointer to raftq_step_batch and no host copy is made (valid
- * until the next raftq_step_stage / raftq_stage / raftq_apply_* / raftq_destroy on the handle).
- * With out == NULL the result records stay in pinned memory; raftq_step_results returns them
- * (valid until the next raftq_step_batch). */
+/* pipelined form: up to TWO batches in flight.  raftq_step_submit enqueues a batch and returns
+ * at once; raftq_step_collect blocks for the oldest batch in flight and hands out its results.
+ * Batches are applied in submission order; the H2D copy of batch k+1 and the D2H copy of batch
+ * k-1 overlap the kernels of batch k (three streams).  raftq_step_batch == submit + collect.
+ * A malformed batch is reported by ITS collect and applies nothing; a batch submitted behind it
+ * is still applied. */
+int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n);
+int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_step_counts_t* counts /*|NULL*/);
+
+/* zero-copy variants.  raftq_step_stage returns the pinned staging array the NEXT submit will use,
+ * with room for n messages: fill it in place and pass the SAME pointer to raftq_step_submit /
+ * raftq_step_batch and no host copy is made (valid until that submit).  With out == NULL the result
+ * records stay in pinned memory; raftq_step_results returns those of the batch collected last
+ * (valid until the next raftq_step_submit / raftq_step_batch). */
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n);
 

@@ -101,6 +101,8 @@ _STEP_SIGS = [
     ("raftq_read_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_step_batch", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(StepCounts)]),
     ("raftq_apply_log_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("raftq_step_submit", C.c_int, [_H, C.c_void_p, C.c_uint64]),
+    ("raftq_step_collect", C.c_int, [_H, C.c_void_p, C.POINTER(StepCounts)]),
     ("raftq_step_stage", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("raftq_step_results", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
 ]

@@ -59,11 +59,26 @@ struct raftq {
   uint32_t* lead = nullptr;        // [ld]
   uint64_t* last_index = nullptr;  // [ld]
   uint64_t* last_term = nullptr;   // [ld]
-  void* step_dev = nullptr;        // device scratch of raftq_step_batch (msgs, keys, order, outs, sort temp)
-  size_t step_dev_bytes = 0;
-  void* step_out_h = nullptr;      // pinned result records of the last raftq_step_batch (+ flag, count)
-  size_t step_out_bytes = 0;
-  uint64_t step_out_n = 0;
+  // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
+  // (pinned staging in, device scratch, pinned results out), pipelined over three streams so the
+  // H2D of batch k+1 and the D2H of batch k-1 overlap the kernels of batch k
+  struct StepSlot {
+    void* in_h = nullptr;          // pinned staging (what raftq_step_stage hands out)
+    size_t in_bytes = 0;
+    void* dev = nullptr;           // device scratch: msgs, keys, order, outs, sort temp, flags
+    size_t dev_bytes = 0;
+    void* out_h = nullptr;         // pinned, device-mapped result records + {touched-group count, bad flag}
+    void* out_d = nullptr;         // device alias of out_h
+    size_t out_bytes = 0;
+    uint64_t n = 0;
+    hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+    bool busy = false;
+  } step_slot[2];
+  uint64_t step_submitted = 0, step_collected = 0;  // slot of batch k = k & 1
+  hipStream_t step_s_in = nullptr, step_s_out = nullptr;
+  int step_stream_mode = 2;
+  const void* step_last_out = nullptr;  // results of the last collected batch
+  uint64_t step_last_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy

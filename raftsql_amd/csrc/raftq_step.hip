@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -76,27 +77,58 @@ struct Scratch {
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-int ensure_scratch(raftq_t* h, uint64_t n, int end_bit, Scratch* s) {
+int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratch* s) {
+  if (!h->step_s_in) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->step_s_in, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->step_s_out, hipStreamNonBlocking));
+    // Stream topology.  Default 2: the H2D DMA on its own stream (overlaps the previous batch's kernels),
+    // the result copy on the handle's stream.  Measured on MI355X (profiles/r01/step_pipeline_trace.txt):
+    // a kernel that writes to host memory over PCIe keeps every other queue's NEXT kernel from starting
+    // until it retires (a kernel that merely spins does not), so a third stream for the D2H buys nothing
+    // (3: 186 us per 64K batch, 2: 176 us, 1 = everything on one stream: 426 us, 4 = copies share a stream: 459 us).
+    // RAFTQ_STEP_STREAMS overrides it for A/B runs.
+    if (const char* m = std::getenv("RAFTQ_STEP_STREAMS")) h->step_stream_mode = std::atoi(m);
+  }
+  if (!sl.ev_in) {
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+  }
   size_t cub_bytes = 0;
   HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                                (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, end_bit,
                                                h->stream));
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-  const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec)), o_ki = carve(n * 8),
-               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_nh = carve(16), o_cub = carve(cub_bytes);
-  if (off > h->step_dev_bytes) {
-    if (h->step_dev) {
+  // the 16-byte {touched count, bad flag} tail sits right behind the result records: one copy moves both
+  const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes);
+  const size_t o_nh = o_outs + n * sizeof(StepOutRec);
+  if (off > sl.dev_bytes) {  // the slot is idle (its previous batch was collected): safe to regrow
+    if (sl.dev) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
-      HIPCHK(h, hipFree(h->step_dev));
-      h->step_dev = nullptr;
-      h->step_dev_bytes = 0;
+      HIPCHK(h, hipFree(sl.dev));
+      sl.dev = nullptr;
+      sl.dev_bytes = 0;
     }
     const size_t want = std::max(off, (size_t)1 << 20) * 2;
-    HIPCHK(h, hipMalloc(&h->step_dev, want));
-    h->step_dev_bytes = want;
+    HIPCHK(h, hipMalloc(&sl.dev, want));
+    sl.dev_bytes = want;
   }
-  uint8_t* base = (uint8_t*)h->step_dev;
+  const size_t out_bytes = (size_t)n * sizeof(StepOutRec) + 16;
+  if (out_bytes > sl.out_bytes) {
+    if (sl.out_h) {
+      if (h->step_last_out == sl.out_h) h->step_last_out = nullptr, h->step_last_n = 0;
+      HIPCHK(h, hipHostFree(sl.out_h));
+      sl.out_h = sl.out_d = nullptr;
+      sl.out_bytes = 0;
+    }
+    const size_t want = std::max(out_bytes * 2, (size_t)1 << 20);
+    HIPCHK(h, hipHostMalloc(&sl.out_h, want, hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer(&sl.out_d, sl.out_h, 0));
+    sl.out_bytes = want;
+  }
+  uint8_t* base = (uint8_t*)sl.dev;
   s->msgs = (MsgRec*)(base + o_msgs);
   s->outs = (StepOutRec*)(base + o_outs);
   s->keys_in = (uint64_t*)(base + o_ki);
@@ -109,6 +141,20 @@ int ensure_scratch(raftq_t* h, uint64_t n, int end_bit, Scratch* s) {
   return RAFTQ_OK;
 }
 
+int ensure_slot_staging(raftq_t* h, raftq::StepSlot& sl, uint64_t n) {
+  const size_t bytes = (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
+  if (bytes <= sl.in_bytes) return RAFTQ_OK;
+  if (sl.in_h) {
+    HIPCHK(h, hipHostFree(sl.in_h));
+    sl.in_h = nullptr;
+    sl.in_bytes = 0;
+  }
+  const size_t want = std::max(bytes * 2, (size_t)1 << 20);
+  HIPCHK(h, hipHostMalloc(&sl.in_h, want, hipHostMallocDefault));
+  sl.in_bytes = want;
+  return RAFTQ_OK;
+}
+
 }  // namespace
 
 void raftq_detail::free_node_state(raftq_t* h) {
@@ -117,8 +163,17 @@ void raftq_detail::free_node_state(raftq_t* h) {
   (void)hipFree(h->lead);
   (void)hipFree(h->last_index);
   (void)hipFree(h->last_term);
-  (void)hipFree(h->step_dev);
-  if (h->step_out_h) (void)hipHostFree(h->step_out_h);
+  for (auto& sl : h->step_slot) {
+    if (sl.ev_out && sl.busy) (void)hipEventSynchronize(sl.ev_out);
+    (void)hipFree(sl.dev);
+    if (sl.in_h) (void)hipHostFree(sl.in_h);
+    if (sl.out_h) (void)hipHostFree(sl.out_h);
+    if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+    if (sl.ev_comp) (void)hipEventDestroy(sl.ev_comp);
+    if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+  }
+  if (h->step_s_in) (void)hipStreamDestroy(h->step_s_in);
+  if (h->step_s_out) (void)hipStreamDestroy(h->step_s_out);
 }
 
 extern "C" {
@@ -164,52 +219,51 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
   if (int rc = use_device(h)) return rc;
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");
-  if (int rc = ensure_staging(h, (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t))) return rc;
-  *msgs = (raftq_msg_t*)h->stage_h;
+  raftq::StepSlot& sl = h->step_slot[h->step_submitted & 1];  // the slot the next submit will use
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage: two batches already in flight; collect one first");
+  if (int rc = ensure_slot_staging(h, sl, n)) return rc;
+  *msgs = (raftq_msg_t*)sl.in_h;
   return RAFTQ_OK;
 }
 
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   if (!out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results: null argument");
-  *out = (const raftq_step_out_t*)h->step_out_h;
-  *n = h->step_out_n;
+  *out = (const raftq_step_out_t*)h->step_last_out;
+  *n = h->step_last_n;
   return RAFTQ_OK;
 }
 
-int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
-                     raftq_step_counts_t* counts) {
+int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   if (int rc = use_device(h)) return rc;
-  if (counts) counts->n_msgs = counts->n_groups_touched = 0;
-  h->step_out_n = 0;
-  if (n == 0) return RAFTQ_OK;
-  if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: null messages");
-  if (n > 0x7fffffffull) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: batch too large (2^31 - 1 messages at most)");
+  if (n == 0 || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_submit: empty batch");
+  if (n > 0x7fffffffull) return fail(h, RAFTQ_EINVAL, "raftq_step_submit: batch too large (2^31 - 1 messages at most)");
+  raftq::StepSlot& sl = h->step_slot[h->step_submitted & 1];
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_submit: two batches already in flight; collect one first");
   if (int rc = ensure_node_state(h)) return rc;
-  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_msg_t))) return rc;
-  // pinned result area: n records + {bad flag, touched-group count}
-  const size_t out_bytes = (size_t)n * sizeof(StepOutRec) + 16;
-  if (out_bytes > h->step_out_bytes) {
-    if (h->step_out_h) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      HIPCHK(h, hipHostFree(h->step_out_h));
-      h->step_out_h = nullptr;
-      h->step_out_bytes = 0;
-    }
-    const size_t want = std::max(out_bytes * 2, (size_t)1 << 20);
-    HIPCHK(h, hipHostMalloc(&h->step_out_h, want, hipHostMallocDefault));
-    h->step_out_bytes = want;
-  }
-  // unless the caller filled the staging area in place (raftq_step_stage), copy into it
-  if ((const void*)msgs != h->stage_h) std::memcpy(h->stage_h, msgs, (size_t)n * sizeof(raftq_msg_t));
   int end_bit = 1;
   while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
+  // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into it
+  if ((const void*)msgs != sl.in_h) {
+    if (int rc = ensure_slot_staging(h, sl, n)) return rc;
+    std::memcpy(sl.in_h, msgs, (size_t)n * sizeof(raftq_msg_t));
+  } else if ((size_t)n * sizeof(raftq_msg_t) > sl.in_bytes) {
+    return fail(h, RAFTQ_EINVAL, "raftq_step_submit: more messages than were staged");
+  }
   Scratch s;
-  if (int rc = ensure_scratch(h, n, end_bit, &s)) return rc;
-  // everything below is enqueued back to back on the handle's stream; one sync at the end
-  HIPCHK(h, hipMemsetAsync(s.n_heads, 0, 16, h->stream));  // touched-group count + bad flag
+  if (int rc = ensure_slot(h, sl, n, end_bit, &s)) return rc;
+  // copy-in stream -> compute stream (the handle's: state changes stay ordered with every other
+  // call on the handle) -> copy-out stream, chained by events
+  const int mode = h->step_stream_mode;
+  hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
+  hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
+  HIPCHK(h, hipMemcpyAsync(s.msgs, sl.in_h, (size_t)n * sizeof(MsgRec), hipMemcpyHostToDevice, s_in));
+  if (s_in != h->stream) {
+    HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+  }
+  hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);  // touched count + bad flag
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
-  HIPCHK(h, hipMemcpyAsync(s.msgs, h->stage_h, (size_t)n * sizeof(MsgRec), hipMemcpyHostToDevice, h->stream));
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
                      h->G, h->N, bad);
@@ -221,25 +275,64 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
                      (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, s.outs, n, s.n_heads,
                      (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
-  uint8_t* tail = (uint8_t*)h->step_out_h + (size_t)n * sizeof(StepOutRec);
-  HIPCHK(h, hipMemcpyAsync(h->step_out_h, s.outs, (size_t)n * sizeof(StepOutRec), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(tail, s.n_heads, 16, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (s_out != h->stream) {
+    HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
+  }
+  const uint64_t out_quads = n * 4 + 1;  // records + the 16-byte tail
+  hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
+  sl.n = n;
+  sl.busy = true;
+  h->step_submitted++;
+  return RAFTQ_OK;
+}
+
+int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) counts->n_msgs = counts->n_groups_touched = 0;
+  if (h->step_collected == h->step_submitted) return fail(h, RAFTQ_ESTATE, "raftq_step_collect: nothing in flight");
+  raftq::StepSlot& sl = h->step_slot[h->step_collected & 1];
+  HIPCHK(h, hipEventSynchronize(sl.ev_out));
+  sl.busy = false;
+  h->step_collected++;
+  const uint64_t n = sl.n;
+  const uint8_t* tail = (const uint8_t*)sl.out_h + (size_t)n * sizeof(StepOutRec);
   unsigned long long heads;
   unsigned int bad_h;
   std::memcpy(&heads, tail, 8);
   std::memcpy(&bad_h, tail + 8, 4);
-  if (bad_h)
+  if (bad_h) {
+    h->step_last_out = nullptr;
+    h->step_last_n = 0;
     return fail(h, RAFTQ_EINVAL,
-                "raftq_step_batch: a message is malformed (group or from out of range, or a type Step does not take); "
-                "nothing applied");
-  h->step_out_n = n;
-  if (out) std::memcpy(out, h->step_out_h, (size_t)n * sizeof(StepOutRec));
+                "raftq_step: a message is malformed (group or from out of range, or a type Step does not take); "
+                "nothing of that batch was applied");
+  }
+  h->step_last_out = sl.out_h;
+  h->step_last_n = n;
+  if (out) std::memcpy(out, sl.out_h, (size_t)n * sizeof(StepOutRec));
   if (counts) {
     counts->n_msgs = n;
     counts->n_groups_touched = heads;
   }
   return RAFTQ_OK;
+}
+
+int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
+                     raftq_step_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) counts->n_msgs = counts->n_groups_touched = 0;
+  if (h->step_collected != h->step_submitted)
+    return fail(h, RAFTQ_ESTATE, "raftq_step_batch: submitted batches are still in flight; collect them first");
+  h->step_last_out = nullptr;
+  h->step_last_n = 0;
+  if (n == 0) return RAFTQ_OK;
+  if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: null messages");
+  if (int rc = raftq_step_submit(h, msgs, n)) return rc;
+  return raftq_step_collect(h, out, counts);
 }
 
 int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {

@@ -59,6 +59,11 @@ constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCam
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
+// zero the batch's {touched-group count, bad flag} (a plain kernel: no runtime blit in the chain)
+static __global__ void step_reset_kernel(unsigned long long* flags) {
+  if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+}
+
 // ---- (1) validate + sort keys.  The batch was DMA-copied from the pinned staging area into
 // HBM; one lane per record reads its first 16 B (group, term) and the 16 B holding from/type.
 // A malformed record raises *bad; step_kernel then applies nothing (the ABI's all-or-nothing rule).
@@ -287,6 +292,16 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
     out[i] = o;
   }
   node.store();
+}
+
+// ---- (4) results -> pinned, device-mapped host memory.  A small grid (grid-stride, 16 B per lane): the
+// transfer is PCIe-bound and 64 workgroups keep the link full (77 us for 4 MB, the same as the
+// runtime's own blit copy).
+static __global__ __launch_bounds__(kBlock) void step_d2h_kernel(const u64x2* __restrict__ src, u64x2* __restrict__ dst,
+                                                                 uint64_t n_quads) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_quads; i += stride)
+    __builtin_nontemporal_store(src[i], dst + i);
 }
 
 // the log owner's tail reports; records are unique per group within a launch (the host splits

@@ -111,6 +111,22 @@ class NodeEngine(QuorumEngine):
         buf = (C.c_char * (k.value * OUT_DT.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=OUT_DT, count=k.value), int(c.n_groups_touched)
 
+    def step_submit(self, msgs: np.ndarray) -> None:
+        """enqueue a batch (raftq_step_submit); at most two may be in flight"""
+        assert msgs.dtype == MSG_DT and msgs.flags.c_contiguous and len(msgs) > 0
+        self._chk(self._lib.raftq_step_submit(self._h, _ptr(msgs), len(msgs)))
+
+    def step_collect(self, copy: bool = True):
+        """results of the oldest batch in flight -> (raftq_step_out_t[], n_groups_touched); with
+        copy=False the array is a view of pinned memory, valid until the next submit"""
+        c = _lib.StepCounts()
+        self._chk(self._lib.raftq_step_collect(self._h, None, C.byref(c)))
+        p, k = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_step_results(self._h, C.byref(p), C.byref(k)))
+        buf = (C.c_char * (k.value * OUT_DT.itemsize)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=OUT_DT, count=k.value)
+        return (a.copy() if copy else a), int(c.n_groups_touched)
+
     def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> np.ndarray:
         """-> committed [n] after each record"""
         a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)

@@ -156,6 +156,53 @@ def test_step_staged_zero_copy_form(NodeEngine, oracle):
         _stepgen.assert_same_state(e, s)
 
 
+def test_step_pipelined_submit_collect(NodeEngine, oracle):
+    """Two batches in flight: applied in submission order, each collect returns its own batch's
+    records; a third submit is refused; a malformed batch fails alone."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(33)
+    G, N = 3000, 5
+    s = _stepgen.random_state(rng, G, N, 3)
+    with NodeEngine(G, N, 3) as e:
+        _stepgen.load_engine(e, s)
+        prev = None
+        for it in range(12):
+            m = _stepgen.random_batch(rng, s, int(rng.integers(1, 6000)), hot_groups=rng.choice(G, 50) if it % 3 == 0 else None)
+            want = s.step_batch(m)  # the oracle state runs one batch ahead of what has been collected
+            e.step_submit(m)
+            if prev is not None:
+                got, touched = e.step_collect()
+                assert np.array_equal(got, prev[0]) and touched == prev[1]
+            prev = (want, len(np.unique(m["group"])))
+        got, touched = e.step_collect()
+        assert np.array_equal(got, prev[0]) and touched == prev[1]
+        _stepgen.assert_same_state(e, s)
+        with pytest.raises(RaftqError):
+            e.step_collect()  # nothing in flight
+        a, b, c3 = (_stepgen.random_batch(rng, s, 100) for _ in range(3))
+        e.step_submit(a)
+        e.step_submit(b)
+        with pytest.raises(RaftqError) as ei:
+            e.step_submit(c3)
+        assert ei.value.code == _lib.RAFTQ_ESTATE
+        with pytest.raises(RaftqError):
+            e.step_batch(c3)  # the synchronous form refuses to jump the queue
+        wa, wb = s.step_batch(a), s.step_batch(b)
+        assert np.array_equal(e.step_collect()[0], wa) and np.array_equal(e.step_collect()[0], wb)
+        # a malformed batch fails alone; the batch behind it still applies
+        bad = _stepgen.random_batch(rng, s, 50)
+        bad["group"][7] = G
+        good = _stepgen.random_batch(rng, s, 50)
+        e.step_submit(bad)
+        e.step_submit(good)
+        with pytest.raises(RaftqError):
+            e.step_collect()
+        assert np.array_equal(e.step_collect()[0], s.step_batch(good))
+        _stepgen.assert_same_state(e, s)
+
+
 def test_step_rejects_malformed_batches_and_applies_nothing(NodeEngine, oracle):
     from raftsql_amd import step as S
     from raftsql_amd.engine import RaftqError

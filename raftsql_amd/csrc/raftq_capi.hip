@@ -57,11 +57,14 @@ using raftq_detail::fail;
 
 namespace {
 
+// nt: 0 = cached loads and stores, 1 = non-temporal loads, normal stores, 3 = both non-temporal
 template <int N, bool COMMIT, bool GATED, bool VOTES>
-hipError_t launch_reg(const SweepArgs& a, uint64_t gpad, bool stream_nt, hipStream_t s) {
+hipError_t launch_reg(const SweepArgs& a, uint64_t gpad, int nt, hipStream_t s) {
   const dim3 grid((unsigned)(gpad / kTile));
-  if (stream_nt)
+  if (nt == 3)
     hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kLdNT | kStNT, true>), grid, dim3(kBlock), 0, s, a);
+  else if (nt == 1)
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kLdNT, true>), grid, dim3(kBlock), 0, s, a);
   else
     hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, 0, true>), grid, dim3(kBlock), 0, s, a);
   return hipGetLastError();
@@ -78,7 +81,7 @@ hipError_t launch_lds(const SweepArgs& a, uint64_t gpad, hipStream_t s) {
 }
 
 template <int N>
-hipError_t launch_n(const SweepArgs& a, uint64_t gpad, unsigned flags, bool nt, hipStream_t s) {
+hipError_t launch_n(const SweepArgs& a, uint64_t gpad, unsigned flags, int nt, hipStream_t s) {
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool gated = flags & RAFTQ_SWEEP_GATED;
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
@@ -91,7 +94,7 @@ hipError_t launch_n(const SweepArgs& a, uint64_t gpad, unsigned flags, bool nt, 
   return launch_reg<N, false, false, true>(a, gpad, nt, s);
 }
 
-hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned flags, bool nt, hipStream_t s) {
+hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned flags, int nt, hipStream_t s) {
   switch (N) {
     case 1: return launch_n<1>(a, gpad, flags, nt, s);
     case 2: return launch_n<2>(a, gpad, flags, nt, s);
@@ -454,9 +457,13 @@ int raftq_step_async(raftq_t* h, unsigned flags) {
   const bool lds = (flags & RAFTQ_SWEEP_LDS) && commit;
   const int gpl = lds ? kLdsGPL : kGPL;
   const uint64_t footprint = h->ld * (8ull * h->N + 24 + h->N + 1);
-  const bool nt = (flags & RAFTQ_SWEEP_STREAM) ? true
-                  : (flags & RAFTQ_SWEEP_CACHED) ? false
-                                                 : footprint >= RAFTQ_AUTO_STREAM_BYTES;
+  // Streaming policy (profiles/r01/tune_policy_ld_vs_ldst.txt): loads always non-temporal; stores too only
+  // once the state outgrows ~128 MiB (2M x 7: -1.7 % with NT stores; 1M x 3/5/9: +1-2 % without them,
+  // and +9 % when the state is cache-resident, because the written commit indices are re-read next sweep)
+  const bool stream = (flags & RAFTQ_SWEEP_STREAM) ? true
+                      : (flags & RAFTQ_SWEEP_CACHED) ? false
+                                                     : footprint >= RAFTQ_AUTO_STREAM_BYTES;
+  const int nt = !stream ? 0 : footprint >= RAFTQ_AUTO_STREAM_BYTES ? 3 : 1;
   HIPCHK(h, launch_sweep(h->N, a, h->gpad, flags, nt, h->stream));
   h->n_partials = h->gpad / ((uint64_t)kBlock * gpl) * kWaves;
   h->last_flags = flags;

@@ -252,6 +252,9 @@ int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   }
   Scratch s;
   if (int rc = ensure_slot(h, sl, n, end_bit, &s)) return rc;
+  // Step moves the live commit index: a what-if (NO_ADOPT) sweep's shadow values are no longer what
+  // raftq_read_committed should hand out
+  h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;
   // copy-in stream -> compute stream (the handle's: state changes stay ordered with every other
   // call on the handle) -> copy-out stream, chained by events
   const int mode = h->step_stream_mode;
@@ -360,6 +363,7 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   } catch (...) {
     return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
   }
+  h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;  // as in raftq_step_submit: the live commit index moves
   raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
   uint64_t* out_h = (uint64_t*)((uint8_t*)h->stage_h + off_out);
   uint64_t* out_d = (uint64_t*)((uint8_t*)h->stage_d + off_out);

@@ -148,15 +148,18 @@ static const Variant kVariants[] = {
     REG(5, 4, false, true, 7, 256), REG(5, 4, false, true, 4, 256),  // no-store ablations
     LDS(5, 4, false, true),
     // config 2: 1M x 3 commit only
-    REG(3, 4, false, false, 0, 256), REG(3, 4, false, false, 3, 256), REG(3, 8, false, false, 3, 256),
+    REG(3, 4, false, false, 0, 256), REG(3, 4, false, false, 3, 256), REG(3, 4, false, false, 1, 256),
+    REG(3, 8, false, false, 3, 256),
     REG(3, 4, false, false, 3, 512), LDS(3, 4, false, false),
     // config 4 shard: 2M x 7 commit + votes
-    REG(7, 4, false, true, 0, 256), REG(7, 4, false, true, 3, 256), REG(7, 2, false, true, 3, 256),
+    REG(7, 4, false, true, 0, 256), REG(7, 4, false, true, 3, 256), REG(7, 4, false, true, 1, 256),
+    REG(7, 2, false, true, 3, 256),
     REG(7, 4, false, true, 3, 512), LDS(7, 4, false, true),
     // config 5: 1M x 5 gated
-    REG(5, 4, true, false, 3, 256), LDS(5, 4, true, false),
+    REG(5, 4, true, false, 3, 256), REG(5, 4, true, false, 1, 256), LDS(5, 4, true, false),
     // N = 9 upper bound of the network
-    REG(9, 4, false, true, 3, 256), REG(9, 2, false, true, 3, 256), LDS(9, 2, false, true),
+    REG(9, 4, false, true, 3, 256), REG(9, 4, false, true, 1, 256), REG(9, 2, false, true, 3, 256),
+    LDS(9, 2, false, true),
 };
 
 static double bytes_per_group(const Variant& v) {

@@ -200,6 +200,88 @@ __global__ __launch_bounds__(256) void sweep2(Args2 a) {
   }
 }
 
+// ---- cache-policy sweep: the shipped kernel's access pattern through raw buffer loads / stores so
+// that every gfx950 cache-policy bit combination can be set per instruction
+// (aux: 1 = sc0, 2 = nt, 16 = sc1).  Peer-major layout, N = 5 or 7, commit + votes.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int N, int GPL, int LDAUX, int STAUX>
+__global__ __launch_bounds__(256) void sweep3(Args2 a) {
+  constexpr int T = 256 * GPL;
+  constexpr int kRounds = GPL / 2;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * T;
+  const uint32_t row_bytes = (uint32_t)(T * 8);
+  uint32_t n_changed = 0, won_lost = 0;
+  constexpr int kVoteLanes = T / 8;
+  const bool vote_lane = tid < kVoteLanes;
+  uint64_t vv[N];
+  if (vote_lane) {
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.votes + (uint64_t)p * a.ld + tile0), 0, T, 0x00020000);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, 8u * tid, 0, LDAUX);
+      vv[p] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    }
+  }
+  u32x4 m[kRounds][N], c[kRounds];
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint32_t off = (wave * (64 * GPL) + j * 128) * 8 + 16u * lane;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.match + (uint64_t)p * a.ld + tile0), 0, row_bytes, 0x00020000);
+      m[j][p] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LDAUX);
+    }
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.committed + tile0), 0, row_bytes, 0x00020000);
+    c[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LDAUX);
+  }
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.committed_out + tile0), 0, row_bytes, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint32_t off = (wave * (64 * GPL) + j * 128) * 8 + 16u * lane;
+    uint64_t v0[N], v1[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      v0[p] = (uint64_t)m[j][p].x | ((uint64_t)m[j][p].y << 32);
+      v1[p] = (uint64_t)m[j][p].z | ((uint64_t)m[j][p].w << 32);
+    }
+    const uint64_t c0 = (uint64_t)c[j].x | ((uint64_t)c[j].y << 32), c1 = (uint64_t)c[j].z | ((uint64_t)c[j].w << 32);
+    const uint64_t o0 = maybe_commit<false>(select_quorum_network<N>(v0), c0, 0);
+    const uint64_t o1 = maybe_commit<false>(select_quorum_network<N>(v1), c1, 0);
+    n_changed += __popcll(__ballot(o0 != c0)) + __popcll(__ballot(o1 != c1));
+    u32x4 o;
+    o.x = (uint32_t)o0; o.y = (uint32_t)(o0 >> 32); o.z = (uint32_t)o1; o.w = (uint32_t)(o1 >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(o, wr, off, 0, STAUX);
+  }
+  if (vote_lane) {
+    uint64_t granted = 0, rejected = 0;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      granted += bytes_equal(vv[p], 0x0101010101010101ull);
+      rejected += bytes_equal(vv[p], 0x0202020202020202ull);
+    }
+    constexpr uint64_t q = N / 2 + 1;
+    constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
+    const uint64_t k80 = 0x8080808080808080ull;
+    const uint64_t won = ((granted + bias) & k80) >> 7;
+    const uint64_t lost = (((rejected + bias) & k80) >> 7) & ~won;
+    const uint64_t out = won | (lost << 1);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.outcome + tile0), 0, T, 0x00020000);
+    u32x2 ov;
+    ov.x = (uint32_t)out; ov.y = (uint32_t)(out >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(ov, r, 8u * tid, 0, STAUX);
+    won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost) << 16);
+  }
+  const uint32_t wl = wave_sum_u32(won_lost);
+  if (lane == 0) {
+    uint4 r;
+    r.x = n_changed; r.y = wl & 0xffffu; r.z = wl >> 16; r.w = 0;
+    a.partials[(uint64_t)blockIdx.x * 4 + wave] = r;
+  }
+}
+
 // ---- data ------------------------------------------------------------------------------------
 __global__ void fill_kernel(uint64_t* p, uint64_t n, uint64_t seed, uint64_t mask, uint64_t add) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +359,17 @@ static void launch2(const Set& s, uint64_t ld, uint64_t pad, hipStream_t st) {
   hipLaunchKernelGGL((sweep2<N, GPL, GATED, VOTES, LAYOUT, LEAN, XCD, VOTE4, NT>), dim3(a.n_tiles), dim3(256), 0, st, a);
 }
 
+template <int N, int GPL, int LDAUX, int STAUX>
+static void launch3(const Set& s, uint64_t ld, uint64_t pad, hipStream_t st) {
+  Args2 a;
+  a.match = s.match; a.votes = s.votes;
+  a.committed = s.committed; a.committed_out = s.committed_out; a.first_idx = s.first_idx;
+  a.outcome = s.outcome; a.partials = s.partials;
+  a.ld = ld + pad;
+  a.n_tiles = (uint32_t)(ld / (256 * GPL));
+  hipLaunchKernelGGL((sweep3<N, GPL, LDAUX, STAUX>), dim3(a.n_tiles), dim3(256), 0, st, a);
+}
+
 struct Variant {
   const char* name;
   int N, GPL, gated, votes, layout, lean, xcd, vote4, nt;
@@ -284,6 +377,9 @@ struct Variant {
 };
 #define V2(N, GPL, GA, VO, LA, LE, XC, V4, NT) \
   { "sweep2", N, GPL, GA, VO, LA, LE, XC, V4, NT, launch2<N, GPL, GA, VO, LA, LE, XC, V4, NT> }
+
+#define V3(N, GPL, LD, ST) \
+  { "sweep3", N, GPL, 0, 1, LD, ST, 0, 0, 1, launch3<N, GPL, LD, ST> }
 
 static const Variant kVariants[] = {
     // config 3 (headline): N=5 commit+votes, streaming policy
@@ -300,6 +396,11 @@ static const Variant kVariants[] = {
     V2(5, 2, false, true, 1, true, false, false, true),   // tiled lean GPL=2
     V2(5, 8, false, true, 1, true, false, false, true),   // tiled lean GPL=8
     V2(5, 4, false, true, 1, true, false, false, false),  // tiled lean cached policy
+    // cache-policy bits through buffer loads/stores (layout column = load aux, lean column = store aux;
+    // aux: 1 sc0, 2 nt, 16 sc1): reference nt/nt = (2, 2)
+    V3(5, 4, 2, 2), V3(5, 4, 0, 0), V3(5, 4, 2, 0), V3(5, 4, 0, 2), V3(5, 4, 18, 2), V3(5, 4, 16, 2), V3(5, 4, 17, 2),
+    V3(5, 4, 19, 2), V3(5, 4, 2, 18), V3(5, 4, 2, 3), V3(5, 4, 2, 19), V3(5, 4, 2, 17), V3(5, 4, 18, 18), V3(5, 4, 3, 3),
+    V3(5, 4, 1, 2), V3(5, 4, 2, 16),
     // config 5: gated
     V2(5, 4, true, false, 0, false, false, false, true), V2(5, 4, true, false, 1, true, false, false, true),
     // config 2: N=3 commit only
@@ -361,7 +462,7 @@ int main(int argc, char** argv) {
       std::vector<uint8_t> o(ld);
       CK(hipMemcpy(c.data(), sets[0].committed_out, ld * 8, hipMemcpyDeviceToHost));
       CK(hipMemcpy(o.data(), sets[0].outcome, ld, hipMemcpyDeviceToHost));
-      const bool is_ref = v.layout == 0 && !v.lean && !v.xcd && !v.vote4;
+      const bool is_ref = v.name[5] == '2' && v.layout == 0 && !v.lean && !v.xcd && !v.vote4;
       if (is_ref) {
         ref_c = c;
         ref_o = o;
@@ -385,9 +486,9 @@ int main(int argc, char** argv) {
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = 1e3 * ms / reps;
-      printf("{\"kernel\":\"sweep2\",\"N\":%d,\"GPL\":%d,\"gated\":%d,\"votes\":%d,\"layout\":%d,\"lean\":%d,\"xcd\":%d,\"vote4\":%d,"
+      printf("{\"kernel\":\"%s\",\"N\":%d,\"GPL\":%d,\"gated\":%d,\"votes\":%d,\"layout\":%d,\"lean\":%d,\"xcd\":%d,\"vote4\":%d,"
              "\"nt\":%d,\"G\":%llu,\"rotate\":%d,\"K\":%zu,\"us\":%.3f,\"GBps\":%.1f,\"Gdec_per_s\":%.2f}\n",
-             v.N, v.GPL, v.gated, v.votes, v.layout, v.lean, v.xcd, v.vote4, v.nt, (unsigned long long)G, rot, sets.size(), us,
+             v.name, v.N, v.GPL, v.gated, v.votes, v.layout, v.lean, v.xcd, v.vote4, v.nt, (unsigned long long)G, rot, sets.size(), us,
              G * bytes_per_group(v) / us / 1e3, G / us / 1e3);
       fflush(stdout);
     }

@@ -76,6 +76,26 @@ def test_step_then_dense_sweep_agree(NodeEngine, oracle):
             assert np.array_equal(e.read_outcome(), oc)
 
 
+def test_what_if_sweep_does_not_shadow_later_steps(NodeEngine, oracle):
+    """A NO_ADOPT sweep leaves its evaluation in the shadow buffer for read_committed; once Step (or a
+    log-tail report) moves the live commit index, read-back must show the live one again."""
+    rng = np.random.default_rng(4)
+    G, N = 600, 3
+    s = _stepgen.random_state(rng, G, N, 0)
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        e.sweep(_lib.SWEEP_COMMIT | _lib.SWEEP_NO_ADOPT)
+        assert np.array_equal(e.read_committed(), oracle.commit_advance(s.match, s.committed)[0])
+        m = _stepgen.random_batch(rng, s, 2000)
+        assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))
+        _stepgen.assert_same_state(e, s)
+        e.sweep(_lib.SWEEP_COMMIT | _lib.SWEEP_GATED | _lib.SWEEP_NO_ADOPT)
+        g = np.arange(G, dtype=np.uint64)
+        e.apply_log_deltas(g, s.last_index, s.last_term, s.last_index)
+        s.apply_log_deltas(g, s.last_index, s.last_term, s.last_index)
+        _stepgen.assert_same_state(e, s)
+
+
 def test_election_round_trip_tick_to_leader(NodeEngine, oracle):
     """Tick -> MsgHup list -> Step(MsgHup) -> CAMPAIGN -> peers' MsgVoteResp -> BECAME_LEADER
     -> MsgAppResp -> commit: the whole election path on the device, checked against the oracle."""

@@ -93,3 +93,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "raftq_oracle" not in txt, f
+
+
+def test_headers_are_plain_c99_and_link_from_c(lib, tmp_path):
+    """cgo compiles its preamble as C: all public headers must pass a pedantic C99 compiler and the
+    library must link and answer from a C program (no C++ runtime needed by the caller)."""
+    import subprocess
+
+    from raftsql_amd import _lib
+
+    exe = str(tmp_path / "abi_c99")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_c99.c"), "-o", exe, _lib.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "C99-ABI-OK" in out.stdout, (out.returncode, out.stdout, out.stderr)

@@ -1,0 +1,189 @@
+/*
+ * raftq_wire.h -- C-ABI of the batched wire / WAL codecs: the
+ * data formats either side of the quorum path.
+ *
+ * The reference moves two byte formats around its one raft group, both owned by
+ * the un-vendored etcd dependency:
+ *     rc.transport.Send(rd.Messages)        raft.go:230   raftpb.Message over rafthttp
+ *     rc.wal.Save(rd.HardState, rd.Entries) raft.go:228   walpb.Record frames, CRC-32C chained
+ *     w.ReadAll() in replayWAL              raft.go:122-134
+ * With G groups per process those are per-message / per-record marshal calls in
+ * G goroutines.  The entry points below do a whole batch on the GPU: protobuf
+ * field encoding / parsing one lane per message, CRC-32C one lane per record
+ * with the chain resolved by a parallel scan over (crc, x^(8 len)) pairs.
+ *
+ * FORMATS (restated from the published 2015-era etcd sources, v2.2-v2.3 line;
+ * PARITY UNPINNED for the schema -- the .proto files are not on this machine --
+ * but every byte produced is checked against the protobuf runtime on that schema
+ * and against RFC 3720's CRC-32C vectors, see oracle/raftq_wire_oracle.c):
+ *
+ *   raftpb.Message   1 type  2 to  3 from  4 term  5 logTerm  6 index  7 entries*
+ *                    8 commit  9 snapshot  10 reject  11 rejectHint  [12 group]
+ *   raftpb.Entry     1 Type  2 Term  3 Index  4 Data  [5 group, WAL only]
+ *   raftpb.HardState 1 term  2 vote  3 commit  [4 group]
+ *   walpb.Record     1 type  2 crc  3 data       walpb.Snapshot  1 index  2 term
+ *
+ *   [n group] is this library's one extension: etcd runs a single group per
+ *   process, so its messages carry none.  It is an ordinary varint field with an
+ *   unused number, inside the CRC-covered bytes; a stock decoder skips it.
+ *
+ *   Encoding is canonical gogoproto (`nullable=false`): every scalar field is
+ *   written, zero or not, in field order; Message.snapshot is always written
+ *   (empty: 4a 08 12 06 0a 00 10 00 18 00); Entry.Data is omitted when empty.
+ *   Decoding is ordinary protobuf: any field order, last scalar wins, unknown
+ *   fields skipped, wrong wire type on a known field = malformed.
+ *
+ *   stream frame (rafthttp messageEncoder):  u64 BIG-endian length | Message
+ *   WAL frame (wal/encoder.go, pre-3.0: no padding):  i64 LITTLE-endian length | Record
+ *   Record.crc = crc32.Update(previous record's crc, castagnoli, Record.data)
+ *   -- the running CRC of all Data bytes since the segment's crcType record.
+ *
+ * raft IDs on the wire are 1-based (raft.go:148-151); the structs carry peer
+ * SLOTS (ID - 1) like the rest of this ABI.  An absent / zero ID decodes to
+ * slot 0xFF (to) / 0xFFFFFFFF (from), which raftq_step_* rejects.
+ *
+ * No CPU path: all entry points need the handle's GPU.
+ */
+#ifndef RAFTQ_WIRE_H
+#define RAFTQ_WIRE_H
+
+#include "raftq_step.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFTQ_MSG_SNAP 7 /* decoded, never accepted by Step */
+
+/* raftq_wire_msg_t.flags */
+#define RAFTQ_WIRE_F_MALFORMED 0x01u /* frame did not parse: every other field of the record is 0 */
+#define RAFTQ_WIRE_F_SNAPSHOT 0x02u  /* a non-empty Message.snapshot was present (skipped) */
+#define RAFTQ_WIRE_F_GROUP 0x04u     /* field 12 was present (absent = group 0, a stock etcd peer) */
+
+/* One message header.  Same layout as raftq_msg_t (raftq_step.h) in the fields Step reads,
+ * so a decoded array can be handed to raftq_step_submit unchanged. */
+typedef struct raftq_wire_msg {
+  uint64_t group;
+  uint64_t term;
+  uint64_t log_term;
+  uint64_t index;
+  uint64_t commit;
+  uint64_t reject_hint;
+  uint32_t from;      /* sender's peer slot */
+  uint8_t type;       /* raftpb.MessageType; > 255 decodes to 255 */
+  uint8_t reject;
+  uint8_t to;         /* addressee's peer slot */
+  uint8_t flags;      /* RAFTQ_WIRE_F_* (decode) */
+  uint32_t ent_first; /* this message's entries are ents[ent_first .. ent_first + n_ents) */
+  uint32_t n_ents;
+} raftq_wire_msg_t; /* 64 bytes */
+
+/* One log entry.  data_off points into the payload pool (encode) or into the
+ * decoded stream itself (decode: no payload byte is copied). */
+typedef struct raftq_wire_ent {
+  uint64_t term;
+  uint64_t index;
+  uint64_t data_off;
+  uint32_t data_len;
+  uint32_t type; /* raftpb.EntryType: 0 EntryNormal, 1 EntryConfChange */
+} raftq_wire_ent_t; /* 32 bytes */
+
+typedef struct raftq_wire_counts {
+  uint64_t n_msgs;
+  uint64_t n_ents;
+  uint64_t n_malformed;
+  uint64_t bytes; /* encoded / consumed */
+} raftq_wire_counts_t;
+
+/* Marshal n messages into rafthttp stream frames, in order.  frame_off (may be NULL) receives
+ * n + 1 byte offsets into out; cap is out's size.  RAFTQ_EINVAL if cap is too small (counts->bytes
+ * then says what is needed), if an entry range or payload range is out of bounds, or to/from >= 255. */
+int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, const raftq_wire_ent_t* ents,
+                      uint64_t n_ents, const void* pool, uint64_t pool_bytes, void* out, uint64_t cap,
+                      uint64_t* frame_off /*[n+1]|NULL*/, raftq_wire_counts_t* counts /*|NULL*/);
+
+/* Unmarshal n frames.  frame_off[i] .. frame_off[i+1] is frame i (its 8-byte length included) --
+ * the receive loop knows the boundaries, it read the lengths to read the bodies.  A frame whose
+ * length word disagrees with its extent, or whose body does not parse, is flagged MALFORMED and
+ * counted; the call still succeeds.  ents receives the entry headers of all messages (message
+ * order); RAFTQ_EINVAL if there are more than ents_cap (counts->n_ents says how many). */
+int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off /*[n+1]*/, uint64_t n,
+                      raftq_wire_msg_t* msgs /*[n]*/, raftq_wire_ent_t* ents /*[ents_cap]|NULL*/, uint64_t ents_cap,
+                      raftq_wire_counts_t* counts /*|NULL*/);
+
+/* Walk the length words of a byte buffer (host side; pointer chasing, inherently serial):
+ * off[0..n] for the n whole frames found.  big_endian = 1 for rafthttp streams, 0 for WAL files.
+ * *n_frames = whole frames; *consumed = bytes they cover (a torn tail is left to the caller). */
+int raftq_wire_scan_frames(const void* buf, uint64_t nbytes, int big_endian, uint64_t* off /*[cap+1]*/, uint64_t cap,
+                           uint64_t* n_frames, uint64_t* consumed);
+
+/* Step straight from the wire: decode on the device into the batch's message records (the 64-byte
+ * records never cross PCIe), then exactly raftq_step_submit.  Frames that are malformed, or whose
+ * type Step does not take, fail the batch at its collect like any malformed message.  Entry
+ * headers of the batch (MsgApp) are available after the collect through raftq_step_wire_entries,
+ * msgs[i].ent_first / n_ents through raftq_step_wire_msgs -- both in pinned memory, valid until
+ * the next submit into that slot. */
+int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n);
+int raftq_step_wire_msgs(raftq_t* h, const raftq_wire_msg_t** msgs, uint64_t* n);
+int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t* n_ents);
+
+/* ---- WAL ------------------------------------------------------------------------------------ */
+
+/* walpb record types (wal/wal.go) */
+#define RAFTQ_WAL_METADATA 1
+#define RAFTQ_WAL_ENTRY 2
+#define RAFTQ_WAL_STATE 3
+#define RAFTQ_WAL_CRC 4
+#define RAFTQ_WAL_SNAPSHOT 5
+
+#define RAFTQ_WAL_F_MALFORMED 0x01u /* record or its Data did not parse */
+#define RAFTQ_WAL_F_BADCRC 0x02u    /* Record.crc is not the running CRC (wal.ErrCRCMismatch) */
+#define RAFTQ_WAL_F_GROUP 0x04u     /* the group extension field was present */
+
+/* One WAL record:
+ *   ENTRY     Data = Entry{Type: entry_type, Term: term, Index: index, Data: pool[data_off, +data_len), group}
+ *   STATE     Data = HardState{term, vote (raft ID, 0 = None), commit = index, group}
+ *   SNAPSHOT  Data = walpb.Snapshot{index, term}
+ *   METADATA  Data = pool[data_off, +data_len) verbatim
+ *   CRC       no Data; Record.crc = the running CRC (wal.saveCrc at the head of a segment) */
+typedef struct raftq_wal_rec {
+  uint64_t group;
+  uint64_t term;
+  uint64_t index;
+  uint64_t data_off;
+  uint32_t data_len;
+  uint32_t vote;
+  uint32_t crc;       /* decode: Record.crc as stored */
+  uint8_t kind;       /* RAFTQ_WAL_* */
+  uint8_t entry_type;
+  uint8_t flags;      /* RAFTQ_WAL_F_* (decode) */
+  uint8_t _pad;
+} raftq_wal_rec_t; /* 48 bytes */
+
+typedef struct raftq_wal_counts {
+  uint64_t n_recs;
+  uint64_t n_valid;  /* decode: records before the first malformed / CRC-mismatching one */
+  uint64_t bytes;
+  uint32_t last_crc; /* running CRC after the last (valid) record: prev_crc of the next batch */
+  uint32_t _pad;
+} raftq_wal_counts_t;
+
+/* wal.Save for a batch: n records -> WAL frames appended to a segment whose running CRC is
+ * prev_crc (0 for a new file, whose first record must then be a CRC record).  Records are
+ * written in order; every record's crc continues the chain. */
+int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes,
+                     uint32_t prev_crc, void* out, uint64_t cap, uint64_t* frame_off /*[n+1]|NULL*/,
+                     raftq_wal_counts_t* counts /*|NULL*/);
+
+/* w.ReadAll for a batch of frames (boundaries from raftq_wire_scan_frames, big_endian = 0):
+ * parse every record, recompute the CRC chain from prev_crc and compare.  As ReadAll, a CRC
+ * record re-seeds the chain (and must equal the running value unless that is 0).
+ * counts->n_valid = index of the first bad record (n if none); records from there on still
+ * carry their parsed fields and flags, the caller decides (the reference log.Fatalf's, raft.go:126). */
+int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint64_t* frame_off /*[n+1]*/, uint64_t n,
+                     uint32_t prev_crc, raftq_wal_rec_t* recs /*[n]*/, raftq_wal_counts_t* counts /*|NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTQ_WIRE_H */

@@ -21,8 +21,9 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("raftq_oracle.c", "raftq_step_oracle.c", "raftq_oracle.h")]
-    srcs.append(os.path.join(_HERE, "..", "include", "raftq_step.h"))
+    srcs = [os.path.join(_HERE, f) for f in ("raftq_oracle.c", "raftq_step_oracle.c", "raftq_wire_oracle.c",
+                                                "raftq_oracle.h")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("raftq_step.h", "raftq_wire.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libraftq_oracle.so"])
     return _SO

@@ -117,6 +117,30 @@ void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n,
 void rq_oracle_apply_log_deltas(rq_node_state_t* s, const raftq_log_delta_t* d, size_t n,
                                 uint64_t* committed_out /*[n]|NULL*/);
 
+/* ---- wire / WAL codecs (raftq_wire_oracle.c, structs in include/raftq_wire.h) ----
+ * raftpb.Message marshal / unmarshal in rafthttp frames, walpb.Record frames with the chained
+ * CRC-32C.  Pinned against the protobuf runtime and RFC 3720 (see raftq_wire_oracle.c). */
+struct raftq_wire_msg;
+struct raftq_wire_ent;
+struct raftq_wal_rec;
+uint32_t rq_crc32c_update(uint32_t crc, const uint8_t* p, size_t n);       /* hash/crc32 Update, bitwise */
+uint32_t rq_crc32c_update_table(uint32_t crc, const uint8_t* p, size_t n); /* same, table-driven */
+uint32_t rq_crc32c_mulmod(uint32_t a, uint32_t b);
+uint32_t rq_crc32c_xpow8(uint64_t n);
+uint32_t rq_crc32c_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+/* returns the bytes the encoding takes (also when that exceeds cap: nothing past cap is written) */
+uint64_t rq_wire_encode(const struct raftq_wire_msg* msgs, uint64_t n, const struct raftq_wire_ent* ents,
+                        const uint8_t* pool, uint8_t* out, uint64_t cap, uint64_t* frame_off /*[n+1]|NULL*/);
+int rq_wire_decode(const uint8_t* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n,
+                   struct raftq_wire_msg* msgs, struct raftq_wire_ent* ents /*|NULL*/, uint64_t ents_cap,
+                   uint64_t* n_ents, uint64_t* n_bad);
+int rq_wire_scan_frames(const uint8_t* buf, uint64_t nbytes, int big_endian, uint64_t* off, uint64_t cap,
+                        uint64_t* n_frames, uint64_t* consumed);
+uint64_t rq_wal_encode(const struct raftq_wal_rec* recs, uint64_t n, const uint8_t* pool, uint32_t prev_crc,
+                       uint8_t* out, uint64_t cap, uint64_t* frame_off /*[n+1]|NULL*/, uint32_t* last_crc);
+int rq_wal_decode(const uint8_t* bytes, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, uint32_t prev_crc,
+                  struct raftq_wal_rec* recs, uint64_t* n_valid, uint32_t* last_crc);
+
 /* ---- timed CPU baselines (bench.py cpu_baseline leg) -------------------- */
 /* kind 0: reference-shaped loop (malloc N-slice, sort desc, index q-1, scan
  * votes); kind 1: tight selection network, no allocation.  Runs `sweeps`

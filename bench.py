@@ -284,6 +284,113 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     return out
 
 
+def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
+    """the byte formats either side of Step, a batch per call.  (a) raftpb.Message stream
+    frames: the traffic of step_measure (acks / heartbeat responses / votes, no entries) plus a MsgApp
+    share carrying 1-3 entries of ~80 B; (b) Step fed straight from received frames, two batches in
+    flight; (c) walpb.Record WAL frames (wal.Save / ReadAll) with the CRC-32C chain.  Wall time of the
+    calls incl. PCIe both ways (caller-owned pageable buffers); the oracle's per-message loop on one host
+    core beside each."""
+    from oracle import pywire as W  # inputs built with the shared record dtypes; cpu leg below
+    from raftsql_amd.wire import WireEngine
+
+    G, N = cfg["G"], cfg["N"]
+    rng = np.random.default_rng(99)
+    e = WireEngine(G, N, self_peer=0, device=device)
+    term = np.full(G, 3, np.uint64)
+    last = rng.integers(50, 100, G).astype(np.uint64)
+    e.load_match(np.tile(last // 2, (N, 1)), last // 4)
+    e.load_terms(term, np.ones(G, np.uint64))
+    e.load_roles(np.full(G, 2, np.uint8))
+    e.load_node(term, np.ones(G, np.uint32), np.ones(G, np.uint32), last, term)
+
+    def traffic(app_frac):
+        m = np.zeros(n, W.WIRE_MSG_DT)
+        g = rng.integers(0, G, n)
+        u = rng.random(n)
+        m["group"] = g
+        m["type"] = np.where(u < app_frac, 3, np.where(u < 0.8, 4, np.where(u < 0.97, 9, 5)))
+        m["term"] = np.where(m["type"] == 5, 4, 3)
+        m["from"] = rng.integers(1, N, n)
+        m["index"] = (last[g] * rng.random(n)).astype(np.uint64)
+        m["log_term"], m["commit"] = 3, last[g] // 4
+        cnt = np.where(m["type"] == 3, rng.integers(1, 4, n), 0).astype(np.uint32)
+        m["n_ents"] = cnt
+        m["ent_first"] = np.where(cnt > 0, np.cumsum(cnt) - cnt, 0)
+        ne = int(cnt.sum())
+        ents = np.zeros(ne, W.WIRE_ENT_DT)
+        ents["term"], ents["index"] = 3, rng.integers(50, 100, ne)
+        ents["data_len"] = rng.integers(40, 120, ne)
+        ents["data_off"] = np.cumsum(ents["data_len"]) - ents["data_len"]
+        pool = rng.integers(0, 256, max(1, int(ents["data_len"].sum())), dtype=np.uint8)
+        return m, ents, pool
+
+    def timeit(fn, k=reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        return (time.perf_counter() - t0) / k
+
+    out = {"what": "batched raftpb.Message / walpb.Record codecs on the GPU; wall time per call incl. PCIe both ways "
+                   "(pageable caller buffers)", "msgs_per_batch": n}
+    m, ents, pool = traffic(0.15)
+    stream, off = e.wire_encode(m, ents, pool)
+    t_enc = timeit(lambda: e.wire_encode(m, ents, pool)) / 2  # the mirror calls twice (size, then bytes)
+    t_dec = timeit(lambda: e.wire_decode(stream, off))
+    out["message_frames"] = {"entries": len(ents), "stream_bytes": int(len(stream)),
+                             "encode_us": t_enc * 1e6, "encode_msgs_per_s": n / t_enc,
+                             "decode_us": t_dec * 1e6, "decode_msgs_per_s": n / t_dec,
+                             "decode_GBps": len(stream) / t_dec / 1e9}
+    # Step from frames (no entries in this traffic: what a leader of many groups receives)
+    m2, _, _ = traffic(0.0)
+    s2, off2 = e.wire_encode(m2)
+    e.step_submit_wire(s2, off2)
+    e.step_collect(copy=False)
+    k = 3 * reps
+    t0 = time.perf_counter()
+    e.step_submit_wire(s2, off2)
+    for _ in range(k - 1):
+        e.step_submit_wire(s2, off2)
+        e.step_collect(copy=False)
+    e.step_collect(copy=False)
+    dt = (time.perf_counter() - t0) / k
+    out["step_from_frames"] = {"what": "raftq_step_submit_wire / _collect, two batches in flight: frames in "
+                                       "(%.1f B per message), 64-byte result records out" % (len(s2) / n),
+                               "us_per_batch": dt * 1e6, "msgs_per_s": n / dt, "frame_bytes": int(len(s2))}
+    # WAL: one Save's worth per group -- an entry (~80 B payload) and a HardState, interleaved
+    r = np.zeros(n, W.WAL_REC_DT)
+    r["kind"] = np.where(np.arange(n) % 2 == 0, W.WAL_ENTRY, W.WAL_STATE)
+    r["group"] = rng.integers(0, G, n)
+    r["term"], r["index"] = 3, rng.integers(50, 100, n)
+    r["vote"] = np.where(r["kind"] == W.WAL_STATE, 1, 0)
+    r["data_len"] = np.where(r["kind"] == W.WAL_ENTRY, rng.integers(40, 120, n), 0)
+    r["data_off"] = np.where(r["data_len"] > 0, np.cumsum(r["data_len"]) - r["data_len"], 0)
+    wpool = rng.integers(0, 256, max(1, int(r["data_len"].sum())), dtype=np.uint8)
+    wal, woff, wlast = e.wal_encode(r, wpool, 0)
+    t_wenc = timeit(lambda: e.wal_encode(r, wpool, 0)) / 2
+    t_wdec = timeit(lambda: e.wal_decode(wal, woff, 0))
+    _, nv, lc = e.wal_decode(wal, woff, 0)
+    assert nv == n and lc == wlast
+    out["wal_frames"] = {"records": n, "wal_bytes": int(len(wal)), "encode_us": t_wenc * 1e6,
+                         "encode_recs_per_s": n / t_wenc, "decode_us": t_wdec * 1e6, "decode_recs_per_s": n / t_wdec,
+                         "decode_GBps": len(wal) / t_wdec / 1e9}
+    e.close()
+    if with_cpu:
+        W.set_fast_crc(True)  # table-driven CRC: the fair single-core comparison
+        try:
+            c_enc = timeit(lambda: W.wire_encode(m, ents, pool), 3) / 2
+            c_dec = timeit(lambda: W.wire_decode(stream, off), 3) / 2  # the binding decodes twice (count, then fill)
+            c_wenc = timeit(lambda: W.wal_encode(r, wpool, 0), 3) / 2
+            c_wdec = timeit(lambda: W.wal_decode(wal, woff, 0), 3)
+        finally:
+            W.set_fast_crc(False)
+        out["cpu_port_1thread"] = {"encode_msgs_per_s": n / c_enc, "decode_msgs_per_s": n / c_dec,
+                                   "wal_encode_recs_per_s": n / c_wenc, "wal_decode_recs_per_s": n / c_wdec,
+                                   "note": "oracle/raftq_wire_oracle.c, one core, table-driven CRC-32C"}
+    return out
+
+
 def node_measure(device, G=32768, N=3, rounds=6):
     """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
     same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
@@ -518,6 +625,7 @@ def main():
         out["pipeline"] = guarded(pipeline_measure, cfg, device)
         out["tick"] = guarded(tick_measure, cfg, device)
         out["step"] = guarded(step_measure, cfg, device, with_cpu=not args.no_cpu_baseline)
+        out["wire"] = guarded(wire_measure, cfg, device, with_cpu=not args.no_cpu_baseline)
         out["node"] = guarded(node_measure, device)
         out["other_configs"] = {
             f"config{c}": guarded(side_measure, c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)

@@ -43,8 +43,14 @@ def _lib() -> C.CDLL:
         L.rq_wire_scan_frames.restype, L.rq_wire_scan_frames.argtypes = C.c_int, [vp, u64, C.c_int, vp, u64, vp, vp]
         L.rq_wal_encode.restype, L.rq_wal_encode.argtypes = u64, [vp, u64, vp, u32, vp, u64, vp, vp]
         L.rq_wal_decode.restype, L.rq_wal_decode.argtypes = C.c_int, [vp, u64, vp, u64, u32, vp, vp, vp]
+        L.rq_wire_set_fast_crc.restype, L.rq_wire_set_fast_crc.argtypes = None, [C.c_int]
         _ready = True
     return L
+
+
+def set_fast_crc(on: bool) -> None:
+    """table-driven instead of bitwise CRC inside wal_encode / wal_decode (bench cpu baseline only)"""
+    _lib().rq_wire_set_fast_crc(int(on))
 
 
 def _bytes_arr(b) -> np.ndarray:

@@ -125,6 +125,7 @@ struct raftq_wire_ent;
 struct raftq_wal_rec;
 uint32_t rq_crc32c_update(uint32_t crc, const uint8_t* p, size_t n);       /* hash/crc32 Update, bitwise */
 uint32_t rq_crc32c_update_table(uint32_t crc, const uint8_t* p, size_t n); /* same, table-driven */
+void rq_wire_set_fast_crc(int on); /* WAL functions: 1 = table CRC (cpu_baseline timing), 0 = bitwise (default) */
 uint32_t rq_crc32c_mulmod(uint32_t a, uint32_t b);
 uint32_t rq_crc32c_xpow8(uint64_t n);
 uint32_t rq_crc32c_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);

@@ -63,6 +63,15 @@ uint32_t rq_crc32c_update_table(uint32_t crc, const uint8_t* p, size_t n) {
   return ~crc;
 }
 
+/* which of the two the WAL functions below use: 0 = bitwise (the definition; what the parity tests
+ * run), 1 = table-driven (bench.py's cpu_baseline leg: Go's hash/crc32 is table / SSE4.2 driven, a
+ * bit-at-a-time loop would be a strawman) */
+static int g_crc_fast;
+void rq_wire_set_fast_crc(int on) { g_crc_fast = on; }
+static uint32_t crc_update(uint32_t crc, const uint8_t* p, size_t n) {
+  return g_crc_fast ? rq_crc32c_update_table(crc, p, n) : rq_crc32c_update(crc, p, n);
+}
+
 /* a(x) * b(x) mod P in the reflected representation (bit 31 = x^0); zlib's multmodp */
 uint32_t rq_crc32c_mulmod(uint32_t a, uint32_t b) {
   uint32_t p = 0;
@@ -479,7 +488,7 @@ uint64_t rq_wal_encode(const raftq_wal_rec_t* recs, uint64_t n, const uint8_t* p
     buf_t d = {scratch, 0, scratch_cap, 0};
     wal_data_marshal(&d, r, pool);
     if (d.n != dsz) abort();
-    crc = rq_crc32c_update(crc, scratch, dsz);
+    crc = crc_update(crc, scratch, dsz);
     /* Record.MarshalTo: 08 type, 10 crc, `if m.Data != nil` 1a len data */
     const int has_data = r->kind != RAFTQ_WAL_CRC && !(r->kind == RAFTQ_WAL_METADATA && dsz == 0);
     const uint64_t rsz = 1 + sov(r->kind) + 1 + sov(crc) + (has_data ? 1 + sov(dsz) + dsz : 0);
@@ -614,7 +623,7 @@ int rq_wal_decode(const uint8_t* bytes, uint64_t nbytes, const uint64_t* frame_o
       if (crc != 0 && recs[i].crc != crc) recs[i].flags |= RAFTQ_WAL_F_BADCRC;
       crc = recs[i].crc;
     } else {
-      crc = rq_crc32c_update(crc, bytes + a + 8 + d_off, (size_t)d_len);
+      crc = crc_update(crc, bytes + a + 8 + d_off, (size_t)d_len);
       if (recs[i].crc != crc) recs[i].flags |= RAFTQ_WAL_F_BADCRC;
     }
     if ((recs[i].flags & RAFTQ_WAL_F_BADCRC) && first_bad == n) first_bad = i;

@@ -108,6 +108,35 @@ _STEP_SIGS = [
 ]
 STEP_EXPORTS = [s[0] for s in _STEP_SIGS]
 
+
+
+class WireCounts(C.Structure):
+    _fields_ = [("n_msgs", C.c_uint64), ("n_ents", C.c_uint64), ("n_malformed", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+class WalCounts(C.Structure):
+    _fields_ = [("n_recs", C.c_uint64), ("n_valid", C.c_uint64), ("bytes", C.c_uint64), ("last_crc", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+# every symbol include/raftq_wire.h declares
+_WIRE_SIGS = [
+    ("raftq_wire_encode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                    C.c_uint64, C.c_void_p, C.POINTER(WireCounts)]),
+    ("raftq_wire_decode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                    C.POINTER(WireCounts)]),
+    ("raftq_wire_scan_frames", C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]),
+    ("raftq_step_submit_wire", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    ("raftq_step_wire_msgs", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_step_wire_entries", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_wal_encode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                   C.c_void_p, C.POINTER(WalCounts)]),
+    ("raftq_wal_decode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                   C.POINTER(WalCounts)]),
+]
+WIRE_EXPORTS = [s[0] for s in _WIRE_SIGS]
+
 _lib = None
 
 
@@ -133,7 +162,7 @@ def load() -> C.CDLL:
     except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
         pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, res, args in _SIGS + _STEP_SIGS:
+    for name, res, args in _SIGS + _STEP_SIGS + _WIRE_SIGS:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -32,7 +32,7 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-N_UNITS = 4
+N_UNITS = 5
 
 
 def lib_sources() -> list[str]:
@@ -40,15 +40,18 @@ def lib_sources() -> list[str]:
     return [
         os.path.join(CSRC, "raftq_capi.hip"),
         os.path.join(CSRC, "raftq_step.hip"),
+        os.path.join(CSRC, "raftq_wire.hip"),
         os.path.join(CSRC, "raftq_pipe.cpp"),
         os.path.join(CSRC, "raftq_node.cpp"),
         os.path.join(CSRC, "raftq_kernels.hpp"),
         os.path.join(CSRC, "raftq_step_kernels.hpp"),
         os.path.join(CSRC, "raftq_internal.hpp"),
+        os.path.join(CSRC, "raftq_wire_kernels.hpp"),
         os.path.join(ROOT, "include", "raftq.h"),
         os.path.join(ROOT, "include", "raftq_step.h"),
         os.path.join(ROOT, "include", "raftq_pipe.h"),
         os.path.join(ROOT, "include", "raftq_node.h"),
+        os.path.join(ROOT, "include", "raftq_wire.h"),
     ]
 
 

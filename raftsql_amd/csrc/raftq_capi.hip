@@ -266,6 +266,7 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->hup_bits);
   (void)hipFree(h->tick_partials);
   raftq_detail::free_node_state(h);
+  raftq_detail::free_wire_state(h);
   if (h->stage_h) (void)hipHostFree(h->stage_h);
   if (h->adv_h) (void)hipHostFree(h->adv_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);

@@ -73,13 +73,32 @@ struct raftq {
     uint64_t n = 0;
     hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
     bool busy = false;
+    // raftq_step_submit_wire: where this batch's decoded records sit in `dev`, and the pinned
+    // copies raftq_step_wire_msgs / _entries hand out (fetched on demand)
+    bool wire = false;
+    void* w_msgs_d = nullptr;      // raftq_wire_msg_t [n]
+    void* w_ents_d = nullptr;      // raftq_wire_ent_t [w_ents_cap]
+    const uint64_t* w_ent_total_d = nullptr;
+    uint64_t w_ents_cap = 0;
+    void* w_pin = nullptr;         // pinned: msgs, then entries
+    size_t w_pin_bytes = 0;
+    bool w_msgs_fetched = false, w_ents_fetched = false;
+    uint64_t w_n_ents = 0;
   } step_slot[2];
+  int step_last_slot = -1;         // slot of the last collected batch
   uint64_t step_submitted = 0, step_collected = 0;  // slot of batch k = k & 1
   hipStream_t step_s_in = nullptr, step_s_out = nullptr;
   int step_stream_mode = 2;
   const void* step_last_out = nullptr;  // results of the last collected batch
   uint64_t step_last_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // wire / WAL codecs (raftq_wire.hip): growable device scratch (inputs + temporaries), device
+  // output buffer, a small pinned block for totals / flags
+  void* wire_dev = nullptr;
+  size_t wire_dev_bytes = 0;
+  void* wire_out = nullptr;
+  size_t wire_out_bytes = 0;
+  uint64_t* wire_pin = nullptr;    // pinned, 256 bytes
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};
@@ -93,6 +112,7 @@ int use_device(raftq_t* h);
 int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped delta staging
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)
+void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations (called by raftq_destroy)
 }  // namespace raftq_detail
 
 #define HIPCHK(h, expr)                                                                        \

@@ -15,6 +15,8 @@
 
 #include "raftq_internal.hpp"
 #include "raftq_step_kernels.hpp"
+#include "raftq_wire.h"
+#include "raftq_wire_kernels.hpp"
 
 using namespace raftqk;
 using raftq_detail::ensure_staging;
@@ -73,11 +75,21 @@ struct Scratch {
   unsigned long long* n_heads;
   void* cub_temp;
   size_t cub_bytes;
+  // raftq_step_submit_wire only: the staged frames and what the decoder needs
+  uint64_t* w_off;       // [n + 1] frame offsets, the stream bytes right behind them
+  uint8_t* w_stream;
+  uint64_t *w_cnt, *w_base;  // [n + 1] entries per message, their exclusive scan
+  unsigned long long* w_bad;
+  WireEnt* w_ents;
+  uint64_t w_ents_cap;
+  void* w_cub;
+  size_t w_cub_bytes;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratch* s) {
+int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratch* s, bool wire = false,
+                uint64_t wire_nbytes = 0) {
   if (!h->step_s_in) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->step_s_in, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->step_s_out, hipStreamNonBlocking));
@@ -104,6 +116,19 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
                o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes);
   const size_t o_nh = o_outs + n * sizeof(StepOutRec);
+  // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
+  const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
+  size_t w_cub_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wcub = 0;
+  if (wire) {
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, w_cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                               (int)(n + 1), h->stream));
+    o_wfr = carve((n + 1) * 8 + wire_nbytes + 16);
+    o_wcnt = carve((n + 1) * 8);
+    o_wbase = carve((n + 1) * 8);
+    o_wbad = carve(8);
+    o_wents = carve(w_ents_cap * sizeof(WireEnt));
+    o_wcub = carve(w_cub_bytes);
+  }
   if (off > sl.dev_bytes) {  // the slot is idle (its previous batch was collected): safe to regrow
     if (sl.dev) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -138,11 +163,20 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   s->n_heads = (unsigned long long*)(base + o_nh);
   s->cub_temp = base + o_cub;
   s->cub_bytes = cub_bytes;
+  s->w_off = (uint64_t*)(base + o_wfr);
+  s->w_stream = base + o_wfr + (n + 1) * 8;
+  s->w_cnt = (uint64_t*)(base + o_wcnt);
+  s->w_base = (uint64_t*)(base + o_wbase);
+  s->w_bad = (unsigned long long*)(base + o_wbad);
+  s->w_ents = (WireEnt*)(base + o_wents);
+  s->w_ents_cap = w_ents_cap;
+  s->w_cub = base + o_wcub;
+  s->w_cub_bytes = w_cub_bytes;
   return RAFTQ_OK;
 }
 
-int ensure_slot_staging(raftq_t* h, raftq::StepSlot& sl, uint64_t n) {
-  const size_t bytes = (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
+int ensure_slot_staging(raftq_t* h, raftq::StepSlot& sl, uint64_t n, size_t raw_bytes = 0) {
+  const size_t bytes = raw_bytes ? raw_bytes : (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
   if (bytes <= sl.in_bytes) return RAFTQ_OK;
   if (sl.in_h) {
     HIPCHK(h, hipHostFree(sl.in_h));
@@ -168,6 +202,7 @@ void raftq_detail::free_node_state(raftq_t* h) {
     (void)hipFree(sl.dev);
     if (sl.in_h) (void)hipHostFree(sl.in_h);
     if (sl.out_h) (void)hipHostFree(sl.out_h);
+    if (sl.w_pin) (void)hipHostFree(sl.w_pin);
     if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
     if (sl.ev_comp) (void)hipEventDestroy(sl.ev_comp);
     if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
@@ -234,24 +269,47 @@ int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n) {
   return RAFTQ_OK;
 }
 
-int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
+// One batch into the pipeline.  wire == nullptr: n raftq_msg_t records at msgs.  Otherwise the
+// records are decoded on the device from n rafthttp stream frames (raftq_wire.h).
+struct WireSrc {
+  const void* stream;
+  uint64_t nbytes;
+  const uint64_t* frame_off;
+};
+
+static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const WireSrc* wire, const char* who) {
   if (int rc = use_device(h)) return rc;
-  if (n == 0 || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_submit: empty batch");
-  if (n > 0x7fffffffull) return fail(h, RAFTQ_EINVAL, "raftq_step_submit: batch too large (2^31 - 1 messages at most)");
-  raftq::StepSlot& sl = h->step_slot[h->step_submitted & 1];
-  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_submit: two batches already in flight; collect one first");
+  if (n == 0 || (!wire && !msgs)) return fail(h, RAFTQ_EINVAL, std::string(who) + ": empty batch");
+  if (n > 0x7ffffffeull) return fail(h, RAFTQ_EINVAL, std::string(who) + ": batch too large (2^31 - 2 messages at most)");
+  if (wire && ((!wire->stream && wire->nbytes) || !wire->frame_off))
+    return fail(h, RAFTQ_EINVAL, std::string(who) + ": null argument");
+  const int slot_no = (int)(h->step_submitted & 1);
+  raftq::StepSlot& sl = h->step_slot[slot_no];
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, std::string(who) + ": two batches already in flight; collect one first");
   if (int rc = ensure_node_state(h)) return rc;
   int end_bit = 1;
   while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
-  // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into it
-  if ((const void*)msgs != sl.in_h) {
-    if (int rc = ensure_slot_staging(h, sl, n)) return rc;
-    std::memcpy(sl.in_h, msgs, (size_t)n * sizeof(raftq_msg_t));
-  } else if ((size_t)n * sizeof(raftq_msg_t) > sl.in_bytes) {
-    return fail(h, RAFTQ_EINVAL, "raftq_step_submit: more messages than were staged");
+  size_t in_bytes;
+  if (wire) {
+    // staging = [frame offsets][stream bytes]: one DMA moves both
+    in_bytes = (size_t)(n + 1) * 8 + (size_t)wire->nbytes;
+    if (int rc = ensure_slot_staging(h, sl, n, in_bytes)) return rc;
+    std::memcpy(sl.in_h, wire->frame_off, (size_t)(n + 1) * 8);
+    if (wire->nbytes) std::memcpy((uint8_t*)sl.in_h + (size_t)(n + 1) * 8, wire->stream, (size_t)wire->nbytes);
+  } else {
+    in_bytes = (size_t)n * sizeof(raftq_msg_t);
+    // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into it
+    if ((const void*)msgs != sl.in_h) {
+      if (int rc = ensure_slot_staging(h, sl, n)) return rc;
+      std::memcpy(sl.in_h, msgs, in_bytes);
+    } else if (in_bytes > sl.in_bytes) {
+      return fail(h, RAFTQ_EINVAL, std::string(who) + ": more messages than were staged");
+    }
   }
+  if (h->step_last_slot == slot_no) h->step_last_slot = -1;  // that batch's decoded records are about to be overwritten
+  sl.wire = false;
   Scratch s;
-  if (int rc = ensure_slot(h, sl, n, end_bit, &s)) return rc;
+  if (int rc = ensure_slot(h, sl, n, end_bit, &s, wire != nullptr, wire ? wire->nbytes : 0)) return rc;
   // Step moves the live commit index: a what-if (NO_ADOPT) sweep's shadow values are no longer what
   // raftq_read_committed should hand out
   h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;
@@ -260,7 +318,7 @@ int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   const int mode = h->step_stream_mode;
   hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
   hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
-  HIPCHK(h, hipMemcpyAsync(s.msgs, sl.in_h, (size_t)n * sizeof(MsgRec), hipMemcpyHostToDevice, s_in));
+  HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
   if (s_in != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
@@ -268,8 +326,21 @@ int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);  // touched count + bad flag
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  if (wire) {
+    // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe
+    const dim3 grid1((unsigned)((n + 1 + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.w_bad);  // zeroes 16 bytes from w_bad
+    hipLaunchKernelGGL(wire_dec_kernel, grid1, dim3(kBlock), 0, h->stream, (const uint8_t*)s.w_stream, wire->nbytes,
+                       (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, s.w_cnt, s.w_bad);
+    HIPCHK(h, hipGetLastError());
+    size_t wb = s.w_cub_bytes;
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(s.w_cub, wb, (const uint64_t*)s.w_cnt, s.w_base, (int)(n + 1), h->stream));
+    hipLaunchKernelGGL(wire_dec_ents_kernel, grid, dim3(kBlock), 0, h->stream, (const uint8_t*)s.w_stream,
+                       (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base, s.w_ents, s.w_ents_cap);
+    HIPCHK(h, hipGetLastError());
+  }
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
-                     h->G, h->N, bad);
+                     h->G, h->N, bad, wire != nullptr);
   HIPCHK(h, hipGetLastError());
   size_t cub_bytes = s.cub_bytes;
   HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
@@ -289,7 +360,85 @@ int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
   sl.n = n;
   sl.busy = true;
+  sl.wire = wire != nullptr;
+  sl.w_msgs_d = s.msgs;
+  sl.w_ents_d = s.w_ents;
+  sl.w_ent_total_d = s.w_base + n;
+  sl.w_ents_cap = s.w_ents_cap;
+  sl.w_msgs_fetched = sl.w_ents_fetched = false;
+  sl.w_n_ents = 0;
   h->step_submitted++;
+  return RAFTQ_OK;
+}
+
+int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
+  return submit_impl(h, msgs, n, nullptr, "raftq_step_submit");
+}
+
+int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n) {
+  const WireSrc w = {stream, nbytes, frame_off};
+  return submit_impl(h, nullptr, n, &w, "raftq_step_submit_wire");
+}
+
+// the decoded records of the last collected batch, fetched from its slot on demand
+static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSlot** out) {
+  if (int rc = use_device(h)) return rc;
+  if (h->step_last_slot < 0 || !h->step_slot[h->step_last_slot].wire)
+    return fail(h, RAFTQ_ESTATE, std::string(who) + ": the last collected batch was not submitted from the wire "
+                                                      "(or its slot has been reused)");
+  raftq::StepSlot& sl = h->step_slot[h->step_last_slot];
+  const size_t msg_bytes = (size_t)sl.n * sizeof(WireMsg);
+  hipStream_t st = h->step_s_out;  // not behind whatever batch is in flight on the handle's stream
+  if (!sl.w_msgs_fetched) {
+    // first request for this batch: learn the entry count, size the pinned block for both arrays
+    // (so a pointer handed out for the messages stays valid when the entries are asked for later)
+    uint64_t total = 0;
+    HIPCHK(h, hipMemcpyAsync(&total, sl.w_ent_total_d, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (total > sl.w_ents_cap) total = sl.w_ents_cap;  // cannot happen: the cap is the worst case
+    const size_t need = align256(msg_bytes) + (size_t)total * sizeof(WireEnt);
+    if (need > sl.w_pin_bytes) {
+      if (sl.w_pin) HIPCHK(h, hipHostFree(sl.w_pin));
+      sl.w_pin = nullptr;
+      sl.w_pin_bytes = 0;
+      const size_t want = std::max(need * 2, (size_t)1 << 20);
+      HIPCHK(h, hipHostMalloc(&sl.w_pin, want, hipHostMallocDefault));
+      sl.w_pin_bytes = want;
+    }
+    HIPCHK(h, hipMemcpyAsync(sl.w_pin, sl.w_msgs_d, msg_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    sl.w_n_ents = total;
+    sl.w_msgs_fetched = true;
+  }
+  if (want_ents && !sl.w_ents_fetched) {
+    if (sl.w_n_ents) {
+      HIPCHK(h, hipMemcpyAsync((uint8_t*)sl.w_pin + align256(msg_bytes), sl.w_ents_d,
+                               (size_t)sl.w_n_ents * sizeof(WireEnt), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+    }
+    sl.w_ents_fetched = true;
+  }
+  *out = &sl;
+  return RAFTQ_OK;
+}
+
+int raftq_step_wire_msgs(raftq_t* h, const raftq_wire_msg_t** msgs, uint64_t* n) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!msgs || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_wire_msgs: null argument");
+  raftq::StepSlot* sl = nullptr;
+  if (int rc = fetch_wire(h, false, "raftq_step_wire_msgs", &sl)) return rc;
+  *msgs = (const raftq_wire_msg_t*)sl->w_pin;
+  *n = sl->n;
+  return RAFTQ_OK;
+}
+
+int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t* n_ents) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!ents || !n_ents) return fail(h, RAFTQ_EINVAL, "raftq_step_wire_entries: null argument");
+  raftq::StepSlot* sl = nullptr;
+  if (int rc = fetch_wire(h, true, "raftq_step_wire_entries", &sl)) return rc;
+  *ents = (const raftq_wire_ent_t*)((const uint8_t*)sl->w_pin + align256((size_t)sl->n * sizeof(WireMsg)));
+  *n_ents = sl->w_n_ents;
   return RAFTQ_OK;
 }
 
@@ -300,6 +449,7 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   raftq::StepSlot& sl = h->step_slot[h->step_collected & 1];
   HIPCHK(h, hipEventSynchronize(sl.ev_out));
   sl.busy = false;
+  h->step_last_slot = (int)(h->step_collected & 1);
   h->step_collected++;
   const uint64_t n = sl.n;
   const uint8_t* tail = (const uint8_t*)sl.out_h + (size_t)n * sizeof(StepOutRec);

@@ -71,7 +71,7 @@ static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* 
                                                                   uint64_t* __restrict__ keys,
                                                                   uint32_t* __restrict__ order, uint64_t n,
                                                                   uint64_t n_groups, uint32_t n_peers,
-                                                                  unsigned int* bad) {
+                                                                  unsigned int* bad, bool from_wire) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool is_bad = false;
   if (i < n) {
@@ -82,6 +82,10 @@ static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* 
     const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
                        t == kMsgHeartbeat || t == kMsgHeartbeatResp;
     is_bad = g >= n_groups || !known || (!local && from >= n_peers);
+    // records decoded on the device from stream frames (raftq_step_submit_wire) also carry the
+    // addressee's slot and the decoder's flags in the two pad bytes: a frame that did not parse, or
+    // one addressed to no peer of this cluster, fails the batch like any malformed message
+    if (from_wire) is_bad = is_bad || (msgs[i].pad[1] & 1u) != 0 || msgs[i].pad[0] >= n_peers;
     keys[i] = is_bad ? 0 : g;  // keep the sort's key range valid
     order[i] = (uint32_t)i;
   }

@@ -1,0 +1,361 @@
+// raftq_wire.hip -- implementation of include/raftq_wire.h: batched raftpb.Message stream frames
+// and walpb.Record WAL frames on the GPU (raftq_wire_kernels.hpp).  Host side: move the caller's
+// buffers to the device, run the launch chain on the handle's stream, move the results back.
+// No CPU path: without the handle's GPU nothing here encodes or decodes a byte
+// (raftq_wire_scan_frames, the serial length-word walk, is the one host-only entry point).
+#include "raftq_wire.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+#include "raftq_internal.hpp"
+#include "raftq_wire_kernels.hpp"
+
+using namespace raftqk;
+using raftq_detail::fail;
+using raftq_detail::use_device;
+
+static_assert(sizeof(raftq_wire_msg_t) == sizeof(WireMsg) && sizeof(raftq_wire_ent_t) == sizeof(WireEnt) &&
+                  sizeof(raftq_wal_rec_t) == sizeof(WalRec),
+              "ABI struct mismatch");
+
+namespace {
+
+constexpr uint64_t kMaxItems = 0x7ffffffeull;  // hipCUB item counts are int
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += align256(bytes + 16);  // 16 bytes of slack behind every byte buffer
+    return o;
+  }
+};
+
+int grow(raftq_t* h, void** buf, size_t* have, size_t want) {
+  if (want <= *have) return RAFTQ_OK;
+  if (*buf) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  const size_t bytes = std::max(want + want / 2, (size_t)1 << 20);
+  HIPCHK(h, hipMalloc(buf, bytes));
+  *have = bytes;
+  return RAFTQ_OK;
+}
+
+int ensure_pin(raftq_t* h) {
+  if (h->wire_pin) return RAFTQ_OK;
+  HIPCHK(h, hipHostMalloc((void**)&h->wire_pin, 256, hipHostMallocDefault));
+  return RAFTQ_OK;
+}
+
+unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / kBlock); }
+
+int h2d(raftq_t* h, void* dst, const void* src, size_t bytes) {
+  if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return RAFTQ_OK;
+}
+int d2h(raftq_t* h, void* dst, const void* src, size_t bytes) {
+  if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  return RAFTQ_OK;
+}
+
+}  // namespace
+
+void raftq_detail::free_wire_state(raftq_t* h) {
+  (void)hipFree(h->wire_dev);
+  (void)hipFree(h->wire_out);
+  if (h->wire_pin) (void)hipHostFree(h->wire_pin);
+  h->wire_dev = h->wire_out = nullptr;
+  h->wire_pin = nullptr;
+}
+
+extern "C" {
+
+int raftq_wire_scan_frames(const void* buf, uint64_t nbytes, int big_endian, uint64_t* off, uint64_t cap,
+                           uint64_t* n_frames, uint64_t* consumed) {
+  if ((!buf && nbytes) || !off || !n_frames || !consumed) return fail(nullptr, RAFTQ_EINVAL, "raftq_wire_scan_frames: null argument");
+  const uint8_t* p = (const uint8_t*)buf;
+  uint64_t at = 0, k = 0;
+  for (; k < cap && nbytes - at >= 8; ++k) {
+    uint64_t len;
+    std::memcpy(&len, p + at, 8);  // this library only runs on little-endian hosts
+    if (big_endian) len = __builtin_bswap64(len);
+    if (len > nbytes - at - 8) break;  // the tail is torn: leave it to the caller
+    off[k] = at;
+    at += 8 + len;
+  }
+  off[k] = at;
+  *n_frames = k;
+  *consumed = at;
+  return RAFTQ_OK;
+}
+
+int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, const raftq_wire_ent_t* ents,
+                      uint64_t n_ents, const void* pool, uint64_t pool_bytes, void* out, uint64_t cap,
+                      uint64_t* frame_off, raftq_wire_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  if (n == 0) {
+    if (frame_off) frame_off[0] = 0;
+    return RAFTQ_OK;
+  }
+  if (!msgs || (n_ents && !ents) || (pool_bytes && !pool) || (cap && !out))
+    return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: null argument");
+  if (n > kMaxItems || n_ents > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  size_t cub_bytes = 0;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (int)(n + 1), h->stream));
+  Carver c;
+  const size_t o_msgs = c.take(n * sizeof(WireMsg)), o_ents = c.take(n_ents * sizeof(WireEnt)),
+               o_pool = c.take(pool_bytes), o_sizes = c.take((n + 1) * 8), o_off = c.take((n + 1) * 8),
+               o_bad = c.take(8), o_cub = c.take(cub_bytes);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
+  WireEnt* d_ents = (WireEnt*)(base + o_ents);
+  uint8_t* d_pool = base + o_pool;
+  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
+  unsigned int* d_bad = (unsigned int*)(base + o_bad);
+  if (int rc = h2d(h, d_msgs, msgs, n * sizeof(WireMsg))) return rc;
+  if (int rc = h2d(h, d_ents, ents, n_ents * sizeof(WireEnt))) return rc;
+  if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
+  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
+                     (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_sizes, d_off, (int)(n + 1),
+                                             h->stream));
+  if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
+  if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t total = h->wire_pin[0];
+  if ((uint32_t)h->wire_pin[1])
+    return fail(h, RAFTQ_EINVAL,
+                "raftq_wire_encode: a message has to / from >= 255, an entry range outside ents[], or a payload outside "
+                "the pool; nothing was written");
+  if (counts) {
+    counts->n_msgs = n;
+    counts->n_ents = n_ents;
+    counts->bytes = total;
+  }
+  if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: out is too small (counts->bytes is the size needed)");
+  if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
+  uint8_t* d_out = (uint8_t*)h->wire_out;
+  hipLaunchKernelGGL(wire_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
+                     (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out);
+  if (n_ents)
+    hipLaunchKernelGGL(wire_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
+                       (const WireMsg*)d_msgs, n, (const WireEnt*)d_ents, (const uint64_t*)d_off,
+                       (const uint8_t*)d_pool, d_out);
+  HIPCHK(h, hipGetLastError());
+  if (int rc = d2h(h, out, d_out, total)) return rc;
+  if (frame_off)
+    if (int rc = d2h(h, frame_off, d_off, (n + 1) * 8)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n,
+                      raftq_wire_msg_t* msgs, raftq_wire_ent_t* ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  if (n == 0) return RAFTQ_OK;
+  if ((!stream && nbytes) || !frame_off || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: null argument");
+  if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: batch too large");
+  if (!ents) ents_cap = 0;
+  if (int rc = ensure_pin(h)) return rc;
+  // an entry costs its message at least two bytes (tag, length), so this many can never be exceeded
+  const uint64_t dev_cap = std::min<uint64_t>(ents_cap, nbytes / 2 + 1);
+  size_t cub_bytes = 0;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (int)(n + 1), h->stream));
+  Carver c;
+  const size_t o_stream = c.take(nbytes), o_off = c.take((n + 1) * 8), o_msgs = c.take(n * sizeof(WireMsg)),
+               o_cnt = c.take((n + 1) * 8), o_base = c.take((n + 1) * 8), o_bad = c.take(8), o_cub = c.take(cub_bytes);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, dev_cap * sizeof(WireEnt) + 16)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  uint8_t* d_stream = base + o_stream;
+  uint64_t *d_off = (uint64_t*)(base + o_off), *d_cnt = (uint64_t*)(base + o_cnt), *d_base = (uint64_t*)(base + o_base);
+  WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
+  WireEnt* d_ents = (WireEnt*)h->wire_out;
+  unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
+  if (int rc = h2d(h, d_stream, stream, nbytes)) return rc;
+  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  hipLaunchKernelGGL(wire_dec_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
+                     nbytes, (const uint64_t*)d_off, n, d_msgs, d_cnt, d_bad);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_cnt, d_base, (int)(n + 1),
+                                             h->stream));
+  hipLaunchKernelGGL(wire_dec_ents_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
+                     (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
+                     dev_cap);
+  HIPCHK(h, hipGetLastError());
+  if (int rc = d2h(h, msgs, d_msgs, n * sizeof(WireMsg))) return rc;
+  if (int rc = d2h(h, &h->wire_pin[0], d_base + n, 8)) return rc;
+  if (int rc = d2h(h, &h->wire_pin[1], d_bad, 8)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t total = h->wire_pin[0];
+  if (counts) {
+    counts->n_msgs = n;
+    counts->n_ents = total;
+    counts->n_malformed = h->wire_pin[1];
+    counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+  }
+  if (!ents) return RAFTQ_OK;  // headers only
+  if (total > ents_cap)
+    return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
+  if (total) {
+    if (int rc = d2h(h, ents, d_ents, total * sizeof(WireEnt))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes,
+                     uint32_t prev_crc, void* out, uint64_t cap, uint64_t* frame_off, raftq_wal_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) {
+    *counts = raftq_wal_counts_t{0, 0, 0, 0, 0};
+    counts->last_crc = prev_crc;
+  }
+  if (n == 0) {
+    if (frame_off) frame_off[0] = 0;
+    return RAFTQ_OK;
+  }
+  if (!recs || (pool_bytes && !pool) || (cap && !out)) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: null argument");
+  if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  size_t cub_sum = 0, cub_crc = 0;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_sum, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (int)(n + 1), h->stream));
+  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(nullptr, cub_crc, (const CrcPair*)nullptr, (CrcPair*)nullptr, CrcCompose(),
+                                              (int)n, h->stream));
+  size_t cub_bytes = std::max(cub_sum, cub_crc);
+  Carver c;
+  const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
+               o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
+               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_cub = c.take(cub_bytes);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  WalRec* d_recs = (WalRec*)(base + o_recs);
+  uint8_t* d_pool = base + o_pool;
+  uint32_t* d_pcrc = (uint32_t*)(base + o_pcrc);
+  CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
+  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
+  unsigned int* d_bad = (unsigned int*)(base + o_flags);
+  uint32_t* d_last = (uint32_t*)(base + o_flags) + 1;
+  if (int rc = h2d(h, d_recs, recs, n * sizeof(WalRec))) return rc;
+  if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
+  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  hipLaunchKernelGGL(wal_enc_payload_crc_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
+                     (const WalRec*)d_recs, n, (const uint8_t*)d_pool, pool_bytes, d_pcrc);
+  hipLaunchKernelGGL(wal_enc_crc_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
+                     (const uint8_t*)d_pool, pool_bytes, (const uint32_t*)d_pcrc, prev_crc, d_pair, d_bad);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(base + o_cub, cub_bytes, (const CrcPair*)d_pair, d_chain, CrcCompose(),
+                                              (int)n, h->stream));
+  hipLaunchKernelGGL(wal_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
+                     (const CrcPair*)d_chain, d_sizes);
+  HIPCHK(h, hipGetLastError());
+  cub_bytes = std::max(cub_sum, cub_crc);
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_sizes, d_off, (int)(n + 1),
+                                             h->stream));
+  if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
+  if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t total = h->wire_pin[0];
+  if ((uint32_t)h->wire_pin[1])
+    return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: a record has an unknown kind or a payload outside the pool; nothing was written");
+  if (counts) {
+    counts->n_recs = n;
+    counts->bytes = total;
+  }
+  if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
+  if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
+  uint8_t* d_out = (uint8_t*)h->wire_out;
+  hipLaunchKernelGGL(wal_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
+                     (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last);
+  if (pool_bytes)
+    hipLaunchKernelGGL(wal_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
+                       (const WalRec*)d_recs, n, (const CrcPair*)d_chain, (const uint64_t*)d_off,
+                       (const uint8_t*)d_pool, d_out);
+  HIPCHK(h, hipGetLastError());
+  if (int rc = d2h(h, out, d_out, total)) return rc;
+  if (frame_off)
+    if (int rc = d2h(h, frame_off, d_off, (n + 1) * 8)) return rc;
+  if (int rc = d2h(h, &h->wire_pin[2], d_last, 4)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (counts) {
+    counts->n_valid = n;
+    counts->last_crc = (uint32_t)h->wire_pin[2];
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint64_t* frame_off, uint64_t n,
+                     uint32_t prev_crc, raftq_wal_rec_t* recs, raftq_wal_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) {
+    *counts = raftq_wal_counts_t{0, 0, 0, 0, 0};
+    counts->last_crc = prev_crc;
+  }
+  if (n == 0) return RAFTQ_OK;
+  if ((!bytes && nbytes) || !frame_off || !recs) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: null argument");
+  if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  size_t cub_bytes = 0;
+  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(nullptr, cub_bytes, (const CrcPair*)nullptr, (CrcPair*)nullptr, CrcCompose(),
+                                              (int)n, h->stream));
+  Carver c;
+  const size_t o_bytes = c.take(nbytes), o_off = c.take((n + 1) * 8), o_recs = c.take(n * sizeof(WalRec)),
+               o_span = c.take(n * sizeof(WalSpan)), o_pair = c.take(n * 8), o_chain = c.take(n * 8),
+               o_tail = c.take(32), o_cub = c.take(cub_bytes);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  uint8_t* d_bytes = base + o_bytes;
+  uint64_t* d_off = (uint64_t*)(base + o_off);
+  WalRec* d_recs = (WalRec*)(base + o_recs);
+  WalSpan* d_span = (WalSpan*)(base + o_span);
+  CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
+  unsigned long long* d_first_bad = (unsigned long long*)(base + o_tail);
+  uint64_t* d_tail = (uint64_t*)(base + o_tail) + 1;
+  if (int rc = h2d(h, d_bytes, bytes, nbytes)) return rc;
+  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  HIPCHK(h, hipMemsetAsync(d_first_bad, 0xff, 8, h->stream));
+  hipLaunchKernelGGL(wal_dec_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_bytes, nbytes,
+                     (const uint64_t*)d_off, n, prev_crc, d_recs, d_span, d_pair);
+  hipLaunchKernelGGL(wal_dec_long_crc_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
+                     (const uint8_t*)d_bytes, n, (const WalSpan*)d_span, prev_crc, d_pair);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(base + o_cub, cub_bytes, (const CrcPair*)d_pair, d_chain, CrcCompose(),
+                                              (int)n, h->stream));
+  hipLaunchKernelGGL(wal_dec_check_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, d_recs, n,
+                     (const CrcPair*)d_chain, prev_crc, d_first_bad);
+  hipLaunchKernelGGL(wal_dec_tail_kernel, dim3(1), dim3(64), 0, h->stream, (const CrcPair*)d_chain, n, prev_crc,
+                     (const unsigned long long*)d_first_bad, d_tail);
+  HIPCHK(h, hipGetLastError());
+  if (int rc = d2h(h, recs, d_recs, n * sizeof(WalRec))) return rc;
+  if (int rc = d2h(h, &h->wire_pin[0], d_tail, 16)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (counts) {
+    counts->n_recs = n;
+    counts->n_valid = h->wire_pin[0];
+    counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+    counts->last_crc = (uint32_t)h->wire_pin[1];
+  }
+  return RAFTQ_OK;
+}
+
+}  // extern "C"

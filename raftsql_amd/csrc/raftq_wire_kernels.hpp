@@ -1,0 +1,942 @@
+// raftq_wire_kernels.hpp -- device code of the batched wire / WAL codecs (include/raftq_wire.h).
+//
+// The reference marshals one raftpb.Message per rafthttp send (raft.go:230) and one walpb.Record
+// per wal.Save / ReadAll step (raft.go:228, :124), each inside its group's goroutine.  Here a whole
+// batch is one launch chain on the GPU:
+//   * protobuf fields: one lane per message / record.  Sizes first, an exclusive scan turns them
+//     into frame offsets, then every lane writes its own frame.  Output bytes go through an 8-byte
+//     register accumulator (one unaligned 8-byte store per 8 bytes produced); input varints are
+//     cut out of one unaligned 8-byte load with a SWAR compress, not a byte loop.
+//   * entry payloads never pass through a lane's byte loop: a wave per message / record copies them
+//     (16 B per lane per step) and CRCs the long ones cooperatively.
+//   * CRC-32C: per-record CRCs are independent (LDS table, one lane per record; 64 lanes per long
+//     record).  The running CRC that chains the records of a WAL segment is a scan over affine maps
+//     x -> x * X^(8 len) + crc in GF(2)[X]/P: an associative, non-commutative operator (hipCUB
+//     DeviceScan).  A crcType record that re-seeds the chain is the constant map (multiplier 0).
+// Bound: PCIe (the ABI takes and returns host buffers) -- these kernels are a few us per 64K
+// records; DESIGN.md 4.10 has the measured split.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raftq_kernels.hpp"
+
+namespace raftqk {
+
+struct WireMsg {  // == raftq_wire_msg_t; the first 46 bytes are MsgRec's
+  uint64_t group, term, log_term, index, commit, reject_hint;
+  uint32_t from;
+  uint8_t type, reject, to, flags;
+  uint32_t ent_first, n_ents;
+};
+struct WireEnt {  // == raftq_wire_ent_t
+  uint64_t term, index, data_off;
+  uint32_t data_len, type;
+};
+struct WalRec {  // == raftq_wal_rec_t
+  uint64_t group, term, index, data_off;
+  uint32_t data_len, vote, crc;
+  uint8_t kind, entry_type, flags, pad;
+};
+static_assert(sizeof(WireMsg) == 64 && sizeof(WireEnt) == 32 && sizeof(WalRec) == 48, "record layout");
+
+constexpr uint8_t kWireMalformed = 1, kWireSnapshot = 2, kWireGroup = 4;
+constexpr uint8_t kWalMetadata = 1, kWalEntry = 2, kWalState = 3, kWalCrc = 4, kWalSnapshot = 5;
+constexpr uint8_t kWalMalformed = 1, kWalBadCrc = 2, kWalGroup = 4;
+constexpr uint32_t kCoopBytes = 512;  // payloads longer than this are CRC'd by a whole wave
+
+// ---- CRC-32C (Castagnoli, reflected 0x82f63b78; bit 31 of a word is x^0) -------------------------
+
+constexpr uint32_t kCastagnoli = 0x82f63b78u;
+
+// a(x) * b(x) mod P
+__host__ __device__ constexpr uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; ++i) {
+    p ^= b & (0u - (a >> 31));
+    a <<= 1;
+    b = (b >> 1) ^ (kCastagnoli & (0u - (b & 1u)));
+  }
+  return p;
+}
+
+struct XpowTable {
+  uint32_t v[40];  // v[k] = x^(8 * 2^k) mod P
+  constexpr XpowTable() : v{} {
+    uint32_t s = 0x00800000u;  // x^8
+    for (int k = 0; k < 40; ++k) {
+      v[k] = s;
+      s = crc_mulmod(s, s);
+    }
+  }
+};
+__device__ const XpowTable kXpow8{};
+
+// x^(8 n) mod P
+__device__ __forceinline__ uint32_t crc_xpow8(uint64_t n) {
+  uint32_t r = 0x80000000u;
+  for (int k = 0; n != 0 && k < 40; ++k, n >>= 1)
+    if (n & 1u) r = crc_mulmod(r, kXpow8.v[k]);
+  return r;
+}
+
+// the affine map  x -> x * p + c  one record applies to the running CRC
+struct CrcPair {
+  uint32_t c, p;
+};
+struct CrcCompose {  // (l then r)
+  __host__ __device__ __forceinline__ CrcPair operator()(const CrcPair& l, const CrcPair& r) const {
+    CrcPair o;
+    o.c = crc_mulmod(r.p, l.c) ^ r.c;
+    o.p = crc_mulmod(l.p, r.p);
+    return o;
+  }
+};
+
+// 256-entry byte table in LDS, built by the block (256 threads)
+__device__ __forceinline__ void crc_table_init(uint32_t* tab) {
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (kCastagnoli & (0u - (c & 1u)));
+    tab[i] = c;
+  }
+  __syncthreads();
+}
+
+// raw (un-inverted) register update
+__device__ __forceinline__ uint32_t crc_byte(const uint32_t* tab, uint32_t raw, uint8_t b) {
+  return tab[(raw ^ b) & 0xffu] ^ (raw >> 8);
+}
+__device__ __forceinline__ uint32_t crc_varint(const uint32_t* tab, uint32_t raw, uint64_t v) {
+  while (v >= 0x80) {
+    raw = crc_byte(tab, raw, (uint8_t)(v | 0x80));
+    v >>= 7;
+  }
+  return crc_byte(tab, raw, (uint8_t)v);
+}
+__device__ __forceinline__ uint32_t crc_field(const uint32_t* tab, uint32_t raw, uint8_t tag, uint64_t v) {
+  return crc_varint(tab, crc_byte(tab, raw, tag), v);
+}
+__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
+  uint64_t w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+}
+__device__ inline uint32_t crc_span(const uint32_t* tab, uint32_t raw, const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w = load_u64(p + i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k, w >>= 8) raw = crc_byte(tab, raw, (uint8_t)w);
+  }
+  for (; i < n; ++i) raw = crc_byte(tab, raw, p[i]);
+  return raw;
+}
+
+// CRC-32C (init 0, standard inversions) of p[0, n) by the 64 lanes of a wave: each lane a contiguous
+// chunk, then an ordered tree of compositions.  Valid in lane 0.
+__device__ inline uint32_t wave_crc(const uint32_t* tab, const uint8_t* p, uint64_t n) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t chunk = (n + 63) / 64;
+  const uint64_t lo = lane * chunk < n ? lane * chunk : n;
+  const uint64_t hi = lo + chunk < n ? lo + chunk : n;
+  CrcPair me;
+  me.c = ~crc_span(tab, 0xffffffffu, p + lo, hi - lo);
+  me.p = crc_xpow8(hi - lo);
+  if (hi == lo) me.c = 0;  // crc of nothing
+  CrcCompose op;
+  for (int s = 1; s < 64; s <<= 1) {
+    CrcPair right;
+    right.c = __shfl_down(me.c, s);
+    right.p = __shfl_down(me.p, s);
+    if ((lane & (2 * s - 1)) == 0) me = op(me, right);
+  }
+  return me.c;
+}
+
+// dst[0, n) = src[0, n) by a wave, 16 B per lane per step (both sides may be unaligned)
+__device__ inline void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t chunks = n >> 4;
+  for (uint64_t c = lane; c < chunks; c += 64) {
+    uint4 v;
+    __builtin_memcpy(&v, src + (c << 4), 16);
+    __builtin_memcpy(dst + (c << 4), &v, 16);
+  }
+  for (uint64_t b = (chunks << 4) + lane; b < n; b += 64) dst[b] = src[b];
+}
+
+// ---- protobuf primitives ----------------------------------------------------------------------------
+
+// sovRaft: encoded size of a varint
+__device__ __forceinline__ uint32_t sov(uint64_t v) { return v ? (uint32_t)(70 - __clzll((long long)v)) / 7u : 1u; }
+
+// byte sink over global memory: bytes collect in a register, 8 at a time go out in one store
+struct Sink {
+  uint8_t* p;
+  uint64_t acc = 0;
+  uint32_t k = 0;  // bytes in acc
+  __device__ explicit Sink(uint8_t* dst) : p(dst) {}
+  __device__ __forceinline__ void byte(uint8_t b) {
+    acc |= (uint64_t)b << (8 * k);
+    if (++k == 8) {
+      __builtin_memcpy(p, &acc, 8);
+      p += 8;
+      acc = 0;
+      k = 0;
+    }
+  }
+  __device__ __forceinline__ void varint(uint64_t v) {
+    while (v >= 0x80) {
+      byte((uint8_t)(v | 0x80));
+      v >>= 7;
+    }
+    byte((uint8_t)v);
+  }
+  __device__ __forceinline__ void field(uint8_t tag, uint64_t v) {
+    byte(tag);
+    varint(v);
+  }
+  __device__ __forceinline__ void flush() {
+    for (uint32_t i = 0; i < k; ++i) p[i] = (uint8_t)(acc >> (8 * i));
+    p += k;
+    acc = 0;
+    k = 0;
+  }
+  __device__ __forceinline__ void skip(uint64_t n) {  // someone else writes these bytes
+    flush();
+    p += n;
+  }
+  __device__ __forceinline__ void u64_be(uint64_t v) {
+    for (int i = 56; i >= 0; i -= 8) byte((uint8_t)(v >> i));
+  }
+  __device__ __forceinline__ void u64_le(uint64_t v) {
+    for (int i = 0; i < 64; i += 8) byte((uint8_t)(v >> i));
+  }
+};
+
+// the Unmarshal varint loop.  Returns bytes consumed, 0 = malformed (truncated or > 10 bytes).
+__device__ inline uint32_t get_varint(const uint8_t* p, uint64_t n, uint64_t* v) {
+  if (n >= 8) {
+    uint64_t w = load_u64(p);
+    const uint64_t stop = ~w & 0x8080808080808080ull;  // bit 7 of every byte that ends a varint
+    if (stop) {
+      const uint32_t len = ((uint32_t)__ffsll((long long)stop)) >> 3;  // 1..8
+      if (len < 8) w &= (1ull << (8 * len)) - 1;
+      w &= 0x7f7f7f7f7f7f7f7full;
+      w = ((w & 0x7f007f007f007f00ull) >> 1) | (w & 0x007f007f007f007full);
+      w = ((w & 0x3fff00003fff0000ull) >> 2) | (w & 0x00003fff00003fffull);
+      w = ((w & 0x0fffffff00000000ull) >> 4) | (w & 0x000000000fffffffull);
+      *v = w;
+      return len;
+    }
+  }
+  uint64_t r = 0;
+  for (uint32_t i = 0; i < n && i < 10; ++i) {
+    const uint8_t b = p[i];
+    r |= (uint64_t)(b & 0x7f) << (7 * i);  // the 10th byte's high bits fall off, as in Go
+    if (b < 0x80) {
+      *v = r;
+      return i + 1;
+    }
+  }
+  return 0;
+}
+
+// skipRaft: bytes of one unknown field's value, 0 = malformed
+__device__ inline uint64_t skip_value(const uint8_t* p, uint64_t n, uint32_t wt) {
+  uint64_t v;
+  if (wt == 0) return get_varint(p, n, &v);
+  if (wt == 1) return n >= 8 ? 8 : 0;
+  if (wt == 5) return n >= 4 ? 4 : 0;
+  if (wt == 2) {
+    const uint32_t k = get_varint(p, n, &v);
+    if (!k || v > n - k) return 0;
+    return k + v;
+  }
+  return 0;  // groups and the two unassigned wire types
+}
+
+// one field key; false = malformed
+struct Key {
+  uint64_t fn;
+  uint32_t wt;
+};
+__device__ __forceinline__ bool get_key(const uint8_t* p, uint64_t n, uint64_t& i, Key& k) {
+  uint64_t key;
+  const uint32_t used = get_varint(p + i, n - i, &key);
+  if (!used) return false;
+  i += used;
+  k.wt = (uint32_t)(key & 7);
+  k.fn = key >> 3;
+  return k.fn != 0;  // "illegal tag 0"
+}
+
+// ---- raftpb.Entry -----------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t entry_size(uint32_t type, uint64_t term, uint64_t index, uint32_t data_len) {
+  uint64_t n = 3 + sov(type) + sov(term) + sov(index);
+  if (data_len) n += 1 + sov(data_len) + data_len;
+  return n;
+}
+
+// Entry.Unmarshal.  base = offset of p[0] in the enclosing buffer.  group == nullptr: field 5 is unknown.
+__device__ inline bool parse_entry(const uint8_t* p, uint64_t n, uint64_t base, WireEnt& e, uint64_t* group,
+                                   bool* has_group) {
+  e.term = e.index = e.data_off = 0;
+  e.data_len = e.type = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return false;
+    if (k.fn <= 3 || (k.fn == 5 && group)) {
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used) return false;
+      i += used;
+      if (k.fn == 1) e.type = (uint32_t)v;
+      else if (k.fn == 2) e.term = v;
+      else if (k.fn == 3) e.index = v;
+      else {
+        *group = v;
+        *has_group = true;
+      }
+    } else if (k.fn == 4) {
+      if (k.wt != 2) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used || v > n - i - used || v > 0xffffffffull) return false;
+      i += used;
+      e.data_off = base + i;
+      e.data_len = (uint32_t)v;
+      i += v;
+    } else {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return false;
+      i += used;
+    }
+  }
+  if (e.data_len == 0) e.data_off = 0;
+  return true;
+}
+
+// ---- raftpb.Message ---------------------------------------------------------------------------------
+
+// bytes of the six fields in front of the entries
+__device__ __forceinline__ uint64_t msg_head_size(const WireMsg& m) {
+  return 6 + sov(m.type) + sov((uint64_t)m.to + 1) + sov((uint64_t)m.from + 1) + sov(m.term) + sov(m.log_term) +
+         sov(m.index);
+}
+// commit, the empty snapshot (10 bytes), reject (2), rejectHint, group
+__device__ __forceinline__ uint64_t msg_tail_size(const WireMsg& m) {
+  return 1 + sov(m.commit) + 10 + 2 + 1 + sov(m.reject_hint) + 1 + sov(m.group);
+}
+
+// SnapshotMetadata{1 conf_state (message), 2 index, 3 term}: 1 = something set, 0 = all empty, -1 = malformed
+__device__ inline int snapshot_meta_nonempty(const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  int nonempty = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return -1;
+    if (k.fn > 3) {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return -1;
+      i += used;
+      continue;
+    }
+    const bool is_len = k.fn == 1;
+    if (k.wt != (is_len ? 2u : 0u)) return -1;
+    const uint32_t used = get_varint(p + i, n - i, &v);
+    if (!used) return -1;
+    i += used;
+    if (is_len) {
+      if (v > n - i) return -1;
+      i += v;
+    }
+    if (v) nonempty = 1;
+  }
+  return nonempty;
+}
+// Snapshot{1 data (bytes), 2 metadata (message)}
+__device__ inline int snapshot_nonempty(const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  int nonempty = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return -1;
+    if (k.fn > 2) {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return -1;
+      i += used;
+      continue;
+    }
+    if (k.wt != 2) return -1;
+    const uint32_t used = get_varint(p + i, n - i, &v);
+    if (!used) return -1;
+    i += used;
+    if (v > n - i) return -1;
+    if (k.fn == 2) {
+      const int r = snapshot_meta_nonempty(p + i, v);
+      if (r < 0) return -1;
+      nonempty |= r;
+    } else if (v) {
+      nonempty = 1;
+    }
+    i += v;
+  }
+  return nonempty;
+}
+
+__device__ __forceinline__ uint32_t id_to_slot(uint64_t id, uint32_t none) {
+  return id == 0 || id - 1 >= none ? none : (uint32_t)(id - 1);
+}
+
+// Message.Unmarshal over p[0, n).  ents != nullptr: entry k of this message goes to ents[ent_base + k]
+// when that is below ents_cap.  false = malformed.
+__device__ inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t base, WireMsg& m, WireEnt* ents,
+                                 uint64_t ent_base, uint64_t ents_cap) {
+  m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
+  m.from = 0xffffffffu;
+  m.type = m.reject = m.flags = 0;
+  m.to = 0xff;
+  m.ent_first = m.n_ents = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return false;
+    if (k.fn > 12) {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return false;
+      i += used;
+      continue;
+    }
+    const bool is_len = k.fn == 7 || k.fn == 9;
+    if (k.wt != (is_len ? 2u : 0u)) return false;  // "wrong wireType"
+    const uint32_t used = get_varint(p + i, n - i, &v);
+    if (!used) return false;
+    i += used;
+    if (is_len && v > n - i) return false;  // io.ErrUnexpectedEOF
+    switch (k.fn) {
+      case 1: m.type = (uint32_t)v > 255 ? 255 : (uint8_t)v; break;
+      case 2: m.to = (uint8_t)id_to_slot(v, 0xff); break;
+      case 3: m.from = id_to_slot(v, 0xffffffffu); break;
+      case 4: m.term = v; break;
+      case 5: m.log_term = v; break;
+      case 6: m.index = v; break;
+      case 7: {
+        WireEnt e;
+        if (!parse_entry(p + i, v, base + i, e, nullptr, nullptr)) return false;
+        const uint64_t slot = ent_base + m.n_ents;
+        if (ents && slot < ents_cap) ents[slot] = e;
+        ++m.n_ents;
+        i += v;
+        break;
+      }
+      case 8: m.commit = v; break;
+      case 9: {
+        const int r = snapshot_nonempty(p + i, v);
+        if (r < 0) return false;
+        if (r) m.flags |= kWireSnapshot;
+        i += v;
+        break;
+      }
+      case 10: m.reject = v != 0; break;
+      case 11: m.reject_hint = v; break;
+      default:  // 12
+        m.group = v;
+        m.flags |= kWireGroup;
+        break;
+    }
+  }
+  return true;
+}
+
+// ---- kernels: raftpb.Message -> rafthttp stream frames -----------------------------------------
+
+// sizes[i] = 8 + Message.Size(); sizes[n] = 0 (so the exclusive scan yields n + 1 offsets)
+static __global__ __launch_bounds__(kBlock) void wire_enc_size_kernel(const WireMsg* __restrict__ msgs, uint64_t n,
+                                                                      const WireEnt* __restrict__ ents,
+                                                                      uint64_t n_ents, uint64_t pool_bytes,
+                                                                      uint64_t* __restrict__ sizes,
+                                                                      unsigned int* bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool is_bad = false;
+  if (i < n) {
+    const WireMsg m = msgs[i];
+    is_bad = m.to >= 255 || m.from >= 255 || (m.n_ents != 0 && (uint64_t)m.ent_first + m.n_ents > n_ents);
+    uint64_t sz = 8 + msg_head_size(m) + msg_tail_size(m);
+    if (!is_bad) {
+      for (uint32_t k = 0; k < m.n_ents; ++k) {
+        const WireEnt e = ents[m.ent_first + k];
+        if (e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off)) is_bad = true;
+        const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);
+        sz += 1 + sov(es) + es;
+      }
+    }
+    sizes[i] = is_bad ? 0 : sz;
+  } else if (i == n) {
+    sizes[i] = 0;
+  }
+  if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// every byte of frame i except the entry payloads
+static __global__ __launch_bounds__(kBlock) void wire_enc_write_kernel(const WireMsg* __restrict__ msgs, uint64_t n,
+                                                                       const WireEnt* __restrict__ ents,
+                                                                       const uint64_t* __restrict__ off,
+                                                                       uint8_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const WireMsg m = msgs[i];
+  const uint64_t a = off[i];
+  Sink s(out + a);
+  s.u64_be(off[i + 1] - a - 8);
+  s.field(0x08, m.type);
+  s.field(0x10, (uint64_t)m.to + 1);
+  s.field(0x18, (uint64_t)m.from + 1);
+  s.field(0x20, m.term);
+  s.field(0x28, m.log_term);
+  s.field(0x30, m.index);
+  for (uint32_t k = 0; k < m.n_ents; ++k) {
+    const WireEnt e = ents[m.ent_first + k];
+    s.field(0x3a, entry_size(e.type, e.term, e.index, e.data_len));
+    s.field(0x08, e.type);
+    s.field(0x10, e.term);
+    s.field(0x18, e.index);
+    if (e.data_len) {
+      s.field(0x22, e.data_len);
+      s.skip(e.data_len);
+    }
+  }
+  s.field(0x40, m.commit);
+  s.u64_le(0x0010000a0612084aull);  // 4a 08 12 06 0a 00 10 00 | 18 00: the empty Snapshot
+  s.byte(0x18);
+  s.byte(0x00);
+  s.field(0x50, m.reject ? 1 : 0);
+  s.field(0x58, m.reject_hint);
+  s.field(0x60, m.group);
+  s.flush();
+}
+
+// one wave per message: its entries' payloads, pool -> frame
+static __global__ __launch_bounds__(kBlock) void wire_enc_payload_kernel(const WireMsg* __restrict__ msgs, uint64_t n,
+                                                                         const WireEnt* __restrict__ ents,
+                                                                         const uint64_t* __restrict__ off,
+                                                                         const uint8_t* __restrict__ pool,
+                                                                         uint8_t* __restrict__ out) {
+  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const uint32_t n_ents = msgs[i].n_ents;
+  if (n_ents == 0) return;
+  const WireMsg m = msgs[i];
+  uint64_t pos = off[i] + 8 + msg_head_size(m);
+  for (uint32_t k = 0; k < n_ents; ++k) {
+    const WireEnt e = ents[m.ent_first + k];
+    const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);
+    pos += 1 + sov(es) + 3 + sov(e.type) + sov(e.term) + sov(e.index);
+    if (e.data_len) {
+      pos += 1 + sov(e.data_len);
+      wave_copy(out + pos, pool + e.data_off, e.data_len);
+      pos += e.data_len;
+    }
+  }
+}
+
+// ---- kernels: stream frames -> raftpb.Message headers ----------------------------------------------
+
+// frame extent + length word; body = [a + 8, b)
+__device__ __forceinline__ bool frame_body(const uint8_t* buf, uint64_t nbytes, uint64_t a, uint64_t b, bool big_endian) {
+  if (!(a <= b && b <= nbytes && b - a >= 8)) return false;
+  uint64_t w = load_u64(buf + a);
+  if (big_endian) w = __builtin_bswap64(w);
+  return w == b - a - 8;
+}
+
+// pass 1: parse every frame, count its entries.  ent_cnt[n] = 0.
+static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
+                                                                 const uint64_t* __restrict__ off, uint64_t n,
+                                                                 WireMsg* __restrict__ msgs,
+                                                                 uint64_t* __restrict__ ent_cnt,
+                                                                 unsigned long long* n_bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool malformed = false;
+  if (i < n) {
+    const uint64_t a = off[i], b = off[i + 1];
+    WireMsg m;
+    bool ok = frame_body(stream, nbytes, a, b, true);
+    if (ok) ok = parse_msg(stream + a + 8, b - a - 8, a + 8, m, nullptr, 0, 0);
+    if (!ok) {
+      m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
+      m.from = 0;
+      m.type = m.reject = m.to = 0;
+      m.ent_first = m.n_ents = 0;
+      m.flags = kWireMalformed;
+      malformed = true;
+    }
+    msgs[i] = m;
+    ent_cnt[i] = m.n_ents;
+  } else if (i == n) {
+    ent_cnt[i] = 0;
+  }
+  const uint64_t mb = __ballot(malformed);
+  if (mb != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, (unsigned long long)__popcll(mb));
+}
+
+// pass 2: the entry headers, in message order (ent_base = exclusive scan of ent_cnt)
+static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint8_t* __restrict__ stream,
+                                                                      const uint64_t* __restrict__ off, uint64_t n,
+                                                                      WireMsg* __restrict__ msgs,
+                                                                      const uint64_t* __restrict__ ent_base,
+                                                                      WireEnt* __restrict__ ents, uint64_t ents_cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || msgs[i].n_ents == 0) return;
+  const uint64_t a = off[i], b = off[i + 1], first = ent_base[i];
+  WireMsg m;
+  (void)parse_msg(stream + a + 8, b - a - 8, a + 8, m, ents, first, ents_cap);
+  msgs[i].ent_first = (uint32_t)first;
+}
+
+// ---- kernels: walpb.Record ---------------------------------------------------------------------------
+
+__device__ __forceinline__ bool wal_has_payload(uint8_t kind) { return kind == kWalEntry || kind == kWalMetadata; }
+
+// bytes of Record.data
+__device__ __forceinline__ uint64_t wal_data_size(const WalRec& r) {
+  switch (r.kind) {
+    case kWalEntry: return entry_size(r.entry_type, r.term, r.index, r.data_len) + 1 + sov(r.group);
+    case kWalState: return 4 + sov(r.term) + sov(r.vote) + sov(r.index) + sov(r.group);
+    case kWalSnapshot: return 2 + sov(r.index) + sov(r.term);
+    case kWalMetadata: return r.data_len;
+    default: return 0;
+  }
+}
+
+// encode, step 0: one wave per record with a long payload -> pcrc[i] = crc32c(payload)
+static __global__ __launch_bounds__(kBlock) void wal_enc_payload_crc_kernel(const WalRec* __restrict__ recs, uint64_t n,
+                                                                            const uint8_t* __restrict__ pool,
+                                                                            uint64_t pool_bytes,
+                                                                            uint32_t* __restrict__ pcrc) {
+  __shared__ uint32_t tab[256];
+  crc_table_init(tab);
+  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const uint32_t len = recs[i].data_len;
+  const uint64_t o = recs[i].data_off;
+  if (len <= kCoopBytes || !wal_has_payload(recs[i].kind)) return;
+  if (o > pool_bytes || len > pool_bytes - o) return;  // flagged by wal_enc_crc_kernel
+  const uint32_t c = wave_crc(tab, pool + o, len);
+  if ((threadIdx.x & 63) == 0) pcrc[i] = c;
+}
+
+// encode, step 1: pair[i] = the map record i applies to the running CRC (record 0 has prev_crc folded in)
+static __global__ __launch_bounds__(kBlock) void wal_enc_crc_kernel(const WalRec* __restrict__ recs, uint64_t n,
+                                                                    const uint8_t* __restrict__ pool,
+                                                                    uint64_t pool_bytes,
+                                                                    const uint32_t* __restrict__ pcrc,
+                                                                    uint32_t prev_crc, CrcPair* __restrict__ pair,
+                                                                    unsigned int* bad) {
+  __shared__ uint32_t tab[256];
+  crc_table_init(tab);
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool is_bad = false;
+  if (i < n) {
+    const WalRec r = recs[i];
+    is_bad = r.kind < 1 || r.kind > 5;
+    const bool payload = !is_bad && wal_has_payload(r.kind) && r.data_len != 0;
+    if (payload && (r.data_off > pool_bytes || r.data_len > pool_bytes - r.data_off)) is_bad = true;
+    CrcPair me = {0u, 0x80000000u};
+    if (!is_bad) {
+      uint32_t raw = 0xffffffffu;
+      // bytes in front of the payload
+      if (r.kind == kWalEntry) {
+        raw = crc_field(tab, raw, 0x08, r.entry_type);
+        raw = crc_field(tab, raw, 0x10, r.term);
+        raw = crc_field(tab, raw, 0x18, r.index);
+        if (r.data_len) raw = crc_field(tab, raw, 0x22, r.data_len);
+      } else if (r.kind == kWalState) {
+        raw = crc_field(tab, raw, 0x08, r.term);
+        raw = crc_field(tab, raw, 0x10, r.vote);
+        raw = crc_field(tab, raw, 0x18, r.index);
+        raw = crc_field(tab, raw, 0x20, r.group);
+      } else if (r.kind == kWalSnapshot) {
+        raw = crc_field(tab, raw, 0x08, r.index);
+        raw = crc_field(tab, raw, 0x10, r.term);
+      }
+      if (payload) {
+        if (r.data_len > kCoopBytes) {
+          const uint32_t joined = crc_mulmod(crc_xpow8(r.data_len), ~raw) ^ pcrc[i];  // crc(front || payload)
+          raw = ~joined;
+        } else {
+          raw = crc_span(tab, raw, pool + r.data_off, r.data_len);
+        }
+      }
+      if (r.kind == kWalEntry) raw = crc_field(tab, raw, 0x28, r.group);
+      const uint64_t dsz = wal_data_size(r);
+      me.c = dsz ? ~raw : 0u;
+      me.p = crc_xpow8(dsz);
+      if (i == 0) me.c ^= crc_mulmod(me.p, prev_crc);
+    }
+    pair[i] = me;
+  }
+  if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// Record.Size() given the chained crc
+__device__ __forceinline__ uint64_t wal_rec_size(const WalRec& r, uint32_t crc, uint64_t dsz) {
+  const bool has_data = r.kind != kWalCrc && !(r.kind == kWalMetadata && dsz == 0);
+  return 2 + sov(r.kind) + sov(crc) + (has_data ? 1 + sov(dsz) + dsz : 0);
+}
+
+// encode, step 2: frame sizes (they depend on the chained CRC's varint length); sizes[n] = 0
+static __global__ __launch_bounds__(kBlock) void wal_enc_size_kernel(const WalRec* __restrict__ recs, uint64_t n,
+                                                                     const CrcPair* __restrict__ chain,
+                                                                     uint64_t* __restrict__ sizes) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    const WalRec r = recs[i];
+    sizes[i] = 8 + wal_rec_size(r, chain[i].c, wal_data_size(r));
+  } else if (i == n) {
+    sizes[i] = 0;
+  }
+}
+
+// encode, step 3: every byte except the payloads; *last_crc = the chain after the last record
+static __global__ __launch_bounds__(kBlock) void wal_enc_write_kernel(const WalRec* __restrict__ recs, uint64_t n,
+                                                                      const CrcPair* __restrict__ chain,
+                                                                      const uint64_t* __restrict__ off,
+                                                                      uint8_t* __restrict__ out,
+                                                                      uint32_t* __restrict__ last_crc) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const WalRec r = recs[i];
+  const uint32_t crc = chain[i].c;
+  if (i == n - 1) *last_crc = crc;
+  const uint64_t dsz = wal_data_size(r);
+  Sink s(out + off[i]);
+  s.u64_le(wal_rec_size(r, crc, dsz));
+  s.field(0x08, r.kind);
+  s.field(0x10, crc);
+  const bool has_data = r.kind != kWalCrc && !(r.kind == kWalMetadata && dsz == 0);
+  if (has_data) {
+    s.field(0x1a, dsz);
+    if (r.kind == kWalEntry) {
+      s.field(0x08, r.entry_type);
+      s.field(0x10, r.term);
+      s.field(0x18, r.index);
+      if (r.data_len) {
+        s.field(0x22, r.data_len);
+        s.skip(r.data_len);
+      }
+      s.field(0x28, r.group);
+    } else if (r.kind == kWalState) {
+      s.field(0x08, r.term);
+      s.field(0x10, r.vote);
+      s.field(0x18, r.index);
+      s.field(0x20, r.group);
+    } else if (r.kind == kWalSnapshot) {
+      s.field(0x08, r.index);
+      s.field(0x10, r.term);
+    }  // metadata: payload only
+  }
+  s.flush();
+}
+
+// encode, step 4: one wave per record, payload pool -> frame
+static __global__ __launch_bounds__(kBlock) void wal_enc_payload_kernel(const WalRec* __restrict__ recs, uint64_t n,
+                                                                        const CrcPair* __restrict__ chain,
+                                                                        const uint64_t* __restrict__ off,
+                                                                        const uint8_t* __restrict__ pool,
+                                                                        uint8_t* __restrict__ out) {
+  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (i >= n) return;
+  if (recs[i].data_len == 0 || !wal_has_payload(recs[i].kind)) return;
+  const WalRec r = recs[i];
+  const uint64_t dsz = wal_data_size(r);
+  uint64_t pos = off[i] + 8 + 2 + sov(r.kind) + sov(chain[i].c) + 1 + sov(dsz);
+  if (r.kind == kWalEntry) pos += 3 + sov(r.entry_type) + sov(r.term) + sov(r.index) + 1 + sov(r.data_len);
+  wave_copy(out + pos, pool + r.data_off, r.data_len);
+}
+
+// Record.Unmarshal + the Data unmarshal ReadAll does per type.  d_off / d_len: Record.data inside p.
+__device__ inline bool parse_wal_rec(const uint8_t* p, uint64_t n, uint64_t base, WalRec& r, uint64_t& d_off,
+                                     uint64_t& d_len) {
+  r.group = r.term = r.index = r.data_off = 0;
+  r.data_len = r.vote = r.crc = 0;
+  r.kind = r.entry_type = r.flags = r.pad = 0;
+  d_off = d_len = 0;
+  uint64_t i = 0, type = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return false;
+    if (k.fn <= 2) {
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used) return false;
+      i += used;
+      if (k.fn == 1) type = v;
+      else r.crc = (uint32_t)v;
+    } else if (k.fn == 3) {
+      if (k.wt != 2) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used || v > n - i - used) return false;
+      i += used;
+      d_off = i;
+      d_len = v;
+      i += v;
+    } else {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return false;
+      i += used;
+    }
+  }
+  if (type < 1 || type > 5) return false;  // ReadAll: "unexpected block type"
+  r.kind = (uint8_t)type;
+  const uint8_t* d = p + d_off;
+  if (r.kind == kWalEntry) {
+    WireEnt e;
+    bool hg = false;
+    if (!parse_entry(d, d_len, base + d_off, e, &r.group, &hg)) return false;
+    r.term = e.term;
+    r.index = e.index;
+    r.data_off = e.data_off;
+    r.data_len = e.data_len;
+    r.entry_type = (uint8_t)e.type;
+    if (hg) r.flags |= kWalGroup;
+  } else if (r.kind == kWalState || r.kind == kWalSnapshot) {
+    const uint64_t known = r.kind == kWalState ? 4 : 2;
+    uint64_t j = 0;
+    while (j < d_len) {
+      Key k;
+      uint64_t v;
+      if (!get_key(d, d_len, j, k)) return false;
+      if (k.fn > known) {
+        const uint64_t used = skip_value(d + j, d_len - j, k.wt);
+        if (!used) return false;
+        j += used;
+        continue;
+      }
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(d + j, d_len - j, &v);
+      if (!used) return false;
+      j += used;
+      if (r.kind == kWalState) {
+        if (k.fn == 1) r.term = v;
+        else if (k.fn == 2) r.vote = (uint32_t)v;
+        else if (k.fn == 3) r.index = v;
+        else {
+          r.group = v;
+          r.flags |= kWalGroup;
+        }
+      } else {
+        if (k.fn == 1) r.index = v;
+        else r.term = v;
+      }
+    }
+  } else if (r.kind == kWalMetadata) {
+    if (d_len > 0xffffffffull) return false;
+    r.data_off = d_len ? base + d_off : 0;
+    r.data_len = (uint32_t)d_len;
+  }
+  return true;
+}
+
+struct WalSpan {  // Record.data of record i inside the input buffer
+  uint64_t off, len;
+};
+
+// decode, step 1: parse; CRC the short Data spans in the lane; pair[i] = the record's map
+static __global__ __launch_bounds__(kBlock) void wal_dec_kernel(const uint8_t* __restrict__ bytes, uint64_t nbytes,
+                                                                const uint64_t* __restrict__ off, uint64_t n,
+                                                                uint32_t prev_crc, WalRec* __restrict__ recs,
+                                                                WalSpan* __restrict__ span,
+                                                                CrcPair* __restrict__ pair) {
+  __shared__ uint32_t tab[256];
+  crc_table_init(tab);
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t a = off[i], b = off[i + 1];
+  WalRec r;
+  uint64_t d_off = 0, d_len = 0;
+  bool ok = frame_body(bytes, nbytes, a, b, false);
+  if (ok) ok = parse_wal_rec(bytes + a + 8, b - a - 8, a + 8, r, d_off, d_len);
+  CrcPair me = {0u, 0x80000000u};  // a record that does not parse leaves the chain alone
+  WalSpan sp = {0, 0};
+  if (!ok) {
+    r.group = r.term = r.index = r.data_off = 0;
+    r.data_len = r.vote = r.crc = 0;
+    r.kind = r.entry_type = r.pad = 0;
+    r.flags = kWalMalformed;
+  } else if (r.kind == kWalCrc) {
+    me.c = r.crc;  // re-seed: the constant map
+    me.p = 0;
+  } else {
+    sp.off = a + 8 + d_off;
+    sp.len = d_len;
+    me.p = crc_xpow8(d_len);
+    if (d_len != 0 && d_len <= kCoopBytes) me.c = ~crc_span(tab, 0xffffffffu, bytes + sp.off, d_len);
+  }
+  if (i == 0) me.c ^= crc_mulmod(me.p, prev_crc);
+  recs[i] = r;
+  span[i] = sp;
+  pair[i] = me;
+}
+
+// decode, step 2: one wave per record whose Data is long
+static __global__ __launch_bounds__(kBlock) void wal_dec_long_crc_kernel(const uint8_t* __restrict__ bytes, uint64_t n,
+                                                                         const WalSpan* __restrict__ span,
+                                                                         uint32_t prev_crc,
+                                                                         CrcPair* __restrict__ pair) {
+  __shared__ uint32_t tab[256];
+  crc_table_init(tab);
+  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const WalSpan sp = span[i];
+  if (sp.len <= kCoopBytes) return;
+  uint32_t c = wave_crc(tab, bytes + sp.off, sp.len);
+  if ((threadIdx.x & 63) == 0) {
+    if (i == 0) c ^= crc_mulmod(pair[0].p, prev_crc);
+    pair[i].c = c;
+  }
+}
+
+// decode, step 3: compare every stored crc with the chain; first_bad = min index of a bad record
+static __global__ __launch_bounds__(kBlock) void wal_dec_check_kernel(WalRec* __restrict__ recs, uint64_t n,
+                                                                      const CrcPair* __restrict__ chain,
+                                                                      uint32_t prev_crc,
+                                                                      unsigned long long* first_bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const uint8_t flags = recs[i].flags;
+    bad = (flags & kWalMalformed) != 0;
+    if (!bad) {
+      const uint32_t stored = recs[i].crc;
+      if (recs[i].kind == kWalCrc) {
+        const uint32_t before = i == 0 ? prev_crc : chain[i - 1].c;  // decoder.crc.Sum32() when the record arrives
+        bad = before != 0 && stored != before;
+      } else {
+        bad = stored != chain[i].c;
+      }
+      if (bad) recs[i].flags = flags | kWalBadCrc;
+    }
+  }
+  const uint64_t bb = __ballot(bad);
+  if (bad && (uint64_t)__ffsll((long long)bb) - 1 == (threadIdx.x & 63)) atomicMin(first_bad, (unsigned long long)i);
+}
+
+// decode, step 4: {n_valid, last_crc} behind the records
+static __global__ void wal_dec_tail_kernel(const CrcPair* __restrict__ chain, uint64_t n, uint32_t prev_crc,
+                                           const unsigned long long* __restrict__ first_bad,
+                                           uint64_t* __restrict__ tail) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint64_t fb = *first_bad < n ? *first_bad : n;
+  tail[0] = fb;
+  tail[1] = fb == 0 ? prev_crc : chain[fb - 1].c;
+}
+
+}  // namespace raftqk

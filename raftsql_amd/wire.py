@@ -1,0 +1,148 @@
+"""Host-side mirror of the batched wire / WAL codecs (include/raftq_wire.h).
+
+`WireEngine` is a NodeEngine that also marshals / unmarshals whole batches of
+raftpb.Message stream frames (what the reference sends with
+`rc.transport.Send(rd.Messages)`, raft.go:230) and walpb.Record WAL frames
+(`rc.wal.Save`, raft.go:228; `w.ReadAll`, raft.go:124) on the GPU, and can feed
+Step straight from received frames.  Records are numpy structured arrays
+layout-identical to the C structs.  No CPU path: every codec call goes to the
+library, which needs the handle's GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .engine import _ptr
+from .step import NodeEngine
+
+MSG_SNAP = 7
+F_MALFORMED, F_SNAPSHOT, F_GROUP = 1, 2, 4
+WAL_METADATA, WAL_ENTRY, WAL_STATE, WAL_CRC, WAL_SNAPSHOT = 1, 2, 3, 4, 5
+WAL_F_MALFORMED, WAL_F_BADCRC, WAL_F_GROUP = 1, 2, 4
+
+WIRE_MSG_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("log_term", "<u8"), ("index", "<u8"), ("commit", "<u8"),
+                        ("reject_hint", "<u8"), ("from", "<u4"), ("type", "u1"), ("reject", "u1"), ("to", "u1"),
+                        ("flags", "u1"), ("ent_first", "<u4"), ("n_ents", "<u4")])
+WIRE_ENT_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("data_off", "<u8"), ("data_len", "<u4"), ("type", "<u4")])
+WAL_REC_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("data_off", "<u8"), ("data_len", "<u4"),
+                       ("vote", "<u4"), ("crc", "<u4"), ("kind", "u1"), ("entry_type", "u1"), ("flags", "u1"),
+                       ("_pad", "u1")])
+assert WIRE_MSG_DT.itemsize == 64 and WIRE_ENT_DT.itemsize == 32 and WAL_REC_DT.itemsize == 48
+
+
+def _u8(b) -> np.ndarray:
+    if isinstance(b, np.ndarray):
+        return np.ascontiguousarray(b, dtype=np.uint8)
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def _p(a: np.ndarray):
+    return _ptr(a) if a.size else None
+
+
+def scan_frames(buf, big_endian: bool, cap: int | None = None):
+    """The length-word walk (raftq_wire_scan_frames; host only) -> (off uint64[n+1], consumed)."""
+    lib = _lib.load()
+    b = _u8(buf)
+    cap = len(b) // 8 + 1 if cap is None else int(cap)
+    off = np.zeros(cap + 1, np.uint64)
+    n, used = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.raftq_wire_scan_frames(_p(b), len(b), int(big_endian), _ptr(off), cap, C.byref(n), C.byref(used))
+    if rc != 0:
+        raise _lib.RaftqError(rc, (lib.raftq_last_error(None) or b"?").decode())
+    return off[: n.value + 1].copy(), int(used.value)
+
+
+class WireEngine(NodeEngine):
+    """NodeEngine + the codecs of the byte formats either side of Step."""
+
+    # -- raftpb.Message <-> rafthttp stream frames -----------------------------------------
+    def wire_encode(self, msgs: np.ndarray, ents: np.ndarray | None = None, pool=b""):
+        """-> (stream uint8[], frame_off uint64[n+1]).  Two calls: the first learns the size."""
+        m = np.ascontiguousarray(msgs, dtype=WIRE_MSG_DT)
+        e = np.ascontiguousarray(ents if ents is not None else np.zeros(0, WIRE_ENT_DT), dtype=WIRE_ENT_DT)
+        p = _u8(pool)
+        off = np.zeros(len(m) + 1, np.uint64)
+        c = _lib.WireCounts()
+        args = (self._h, _p(m), len(m), _p(e), len(e), _p(p), len(p))
+        rc = self._lib.raftq_wire_encode(*args, None, 0, _ptr(off), C.byref(c))
+        if rc == 0:  # nothing to write
+            return np.zeros(0, np.uint8), off
+        if c.bytes == 0:
+            self._chk(rc)
+        out = np.zeros(int(c.bytes), np.uint8)
+        self._chk(self._lib.raftq_wire_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
+        assert c.bytes == len(out)
+        return out, off
+
+    def wire_decode(self, stream, frame_off, want_ents: bool = True):
+        """-> (msgs, ents, n_malformed)"""
+        s = _u8(stream)
+        off = np.ascontiguousarray(frame_off, np.uint64)
+        n = len(off) - 1
+        msgs = np.zeros(n, WIRE_MSG_DT)
+        c = _lib.WireCounts()
+        if not want_ents:
+            self._chk(self._lib.raftq_wire_decode(self._h, _p(s), len(s), _ptr(off), n, _p(msgs), None, 0, C.byref(c)))
+            return msgs, np.zeros(0, WIRE_ENT_DT), int(c.n_malformed)
+        cap = max(n, 16)
+        while True:
+            ents = np.zeros(cap, WIRE_ENT_DT)
+            rc = self._lib.raftq_wire_decode(self._h, _p(s), len(s), _ptr(off), n, _p(msgs), _ptr(ents), cap, C.byref(c))
+            if rc != 0 and c.n_ents > cap:
+                cap = int(c.n_ents)
+                continue
+            self._chk(rc)
+            return msgs, ents[: int(c.n_ents)].copy(), int(c.n_malformed)
+
+    # -- Step from the wire -------------------------------------------------------------------
+    def step_submit_wire(self, stream, frame_off) -> None:
+        s = _u8(stream)
+        off = np.ascontiguousarray(frame_off, np.uint64)
+        self._chk(self._lib.raftq_step_submit_wire(self._h, _p(s), len(s), _ptr(off), len(off) - 1))
+
+    def step_wire_msgs(self) -> np.ndarray:
+        p, k = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_step_wire_msgs(self._h, C.byref(p), C.byref(k)))
+        if k.value == 0:
+            return np.zeros(0, WIRE_MSG_DT)
+        buf = (C.c_char * (k.value * 64)).from_address(p.value)
+        return np.frombuffer(buf, dtype=WIRE_MSG_DT, count=k.value).copy()
+
+    def step_wire_entries(self) -> np.ndarray:
+        p, k = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_step_wire_entries(self._h, C.byref(p), C.byref(k)))
+        if k.value == 0:
+            return np.zeros(0, WIRE_ENT_DT)
+        buf = (C.c_char * (k.value * 32)).from_address(p.value)
+        return np.frombuffer(buf, dtype=WIRE_ENT_DT, count=k.value).copy()
+
+    # -- walpb.Record <-> WAL frames ------------------------------------------------------------
+    def wal_encode(self, recs: np.ndarray, pool=b"", prev_crc: int = 0):
+        """wal.Save for a batch -> (bytes uint8[], frame_off, last_crc)"""
+        r = np.ascontiguousarray(recs, dtype=WAL_REC_DT)
+        p = _u8(pool)
+        off = np.zeros(len(r) + 1, np.uint64)
+        c = _lib.WalCounts()
+        args = (self._h, _p(r), len(r), _p(p), len(p), int(prev_crc))
+        rc = self._lib.raftq_wal_encode(*args, None, 0, _ptr(off), C.byref(c))
+        if rc == 0:
+            return np.zeros(0, np.uint8), off, int(c.last_crc)
+        if c.bytes == 0:
+            self._chk(rc)
+        out = np.zeros(int(c.bytes), np.uint8)
+        self._chk(self._lib.raftq_wal_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
+        return out, off, int(c.last_crc)
+
+    def wal_decode(self, data, frame_off, prev_crc: int = 0):
+        """w.ReadAll for a batch -> (recs, n_valid, last_crc)"""
+        b = _u8(data)
+        off = np.ascontiguousarray(frame_off, np.uint64)
+        n = len(off) - 1
+        recs = np.zeros(n, WAL_REC_DT)
+        c = _lib.WalCounts()
+        self._chk(self._lib.raftq_wal_decode(self._h, _p(b), len(b), _ptr(off), n, int(prev_crc), _p(recs), C.byref(c)))
+        return recs, int(c.n_valid), int(c.last_crc)

@@ -31,10 +31,12 @@ def test_header_and_binding_list_the_same_symbols():
     assert _declared() == sorted(_lib.EXPORTS)
     assert _declared("raftq_pipe.h") == sorted(pipe.EXPORTS)
     assert _declared("raftq_step.h") == sorted(_lib.STEP_EXPORTS)
+    assert _declared("raftq_wire.h") == sorted(_lib.WIRE_EXPORTS)
 
 
 def test_every_declared_symbol_is_exported(lib):
-    for name in _declared() + _declared("raftq_pipe.h") + _declared("raftq_step.h") + _declared("raftq_node.h"):
+    for name in _declared() + _declared("raftq_pipe.h") + _declared("raftq_step.h") + _declared("raftq_node.h") + \
+            _declared("raftq_wire.h"):
         assert hasattr(lib, name), name
 
 
@@ -71,6 +73,12 @@ def test_argument_validation_without_device(lib):
     assert lib.raftq_step_batch(None, None, 0, None, None) == _lib.RAFTQ_EINVAL
     assert lib.raftq_set_self(None, 0) == _lib.RAFTQ_EINVAL
     assert lib.raftq_apply_log_deltas(None, None, 0, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wire_encode(None, None, 0, None, 0, None, 0, None, 0, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wire_decode(None, None, 0, None, 0, None, None, 0, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wal_encode(None, None, 0, None, 0, 0, None, 0, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wal_decode(None, None, 0, None, 0, 0, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_step_submit_wire(None, None, 0, None, 0) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_wire_scan_frames(None, 8, 1, None, 0, None, None) == _lib.RAFTQ_EINVAL
 
 
 def test_no_silent_cpu_fallback(lib):

@@ -1,0 +1,542 @@
+"""GPU parity: the batched wire / WAL codecs (include/raftq_wire.h, raftq_wire_kernels.hpp) through the
+C-ABI against the CPU oracle (oracle/raftq_wire_oracle.c, itself pinned to the protobuf runtime and
+RFC 3720 in tests/test_wire_oracle.py), byte for byte and record for record: canonical and
+non-canonical streams, malformed / corrupted / random-garbage frames, long payloads (the
+wave-cooperative CRC and copy paths), CRC chains with re-seeding records, the committed fixtures,
+and -- at sizes the oracle would not finish quickly -- round-trip and chain-splitting properties.
+Step fed from frames must equal Step fed the decoded records."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pywire as W
+from tests import _wiregen
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "wire_golden.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test started without a visible GPU")
+    from raftsql_amd.wire import WireEngine
+
+    with WireEngine(4096, 5, self_peer=0) as e:
+        yield e
+
+
+def _same(a: np.ndarray, b: np.ndarray, what=""):
+    assert a.dtype.itemsize == b.dtype.itemsize and len(a) == len(b), what
+    if a.tobytes() != b.tobytes():
+        for i in range(len(a)):
+            assert a[i].tobytes() == b[i].tobytes(), (what, i, a[i], b[i])
+
+
+def _be(body: bytes) -> bytes:
+    return len(body).to_bytes(8, "big") + body
+
+
+# ---- raftpb.Message ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed,n,big", [(101, 1, 0), (102, 63, 0), (103, 1000, 7), (104, 5000, 3), (105, 257, 1)])
+def test_encode_parity(eng, seed, n, big):
+    rng = np.random.default_rng(seed)
+    m, e, pool = _wiregen.random_msgs(rng, n, big_every=big, ent_frac=0.3)
+    want, want_off = W.wire_encode(m, e, pool)
+    got, off = eng.wire_encode(m, e, pool)
+    assert np.array_equal(off, want_off)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_encode_hand_vector(eng):
+    m = np.zeros(1, W.WIRE_MSG_DT)
+    m["type"], m["to"], m["from"], m["term"] = 6, 1, 0, 5  # MsgVoteResp{To: 2, From: 1, Term: 5}
+    s, off = eng.wire_encode(m)
+    body = bytes.fromhex("0806" "1002" "1801" "2005" "2800" "3000" "4000" "4a0812060a0010001800" "5000" "5800" "6000")
+    assert s.tobytes() == _be(body) and list(off) == [0, 38]
+
+
+def test_encode_shared_and_unordered_entry_ranges(eng):
+    """ent_first is arbitrary: messages may share entries (a leader sends the same suffix to every
+    follower) and reference them out of order."""
+    rng = np.random.default_rng(7)
+    m, e, pool = _wiregen.random_msgs(rng, 40, ent_frac=1.0, big_every=4)
+    m["type"] = 3
+    m["n_ents"] = np.minimum(3, len(e))
+    m["ent_first"] = rng.integers(0, len(e) - 3, len(m))
+    want, want_off = W.wire_encode(m, e, pool)
+    got, off = eng.wire_encode(m, e, pool)
+    assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
+
+
+def test_encode_rejects_bad_input(eng):
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(8)
+    m, e, pool = _wiregen.random_msgs(rng, 100, ent_frac=0.5)
+    for field, val in (("to", 255), ("from", 255), ("from", 0xFFFFFFFF)):
+        bad = m.copy()
+        bad[field][50] = val
+        with pytest.raises(RaftqError):
+            eng.wire_encode(bad, e, pool)
+    i = int(np.nonzero(m["n_ents"])[0][0])
+    bad = m.copy()
+    bad["ent_first"][i] = len(e)  # entry range past ents[]
+    with pytest.raises(RaftqError):
+        eng.wire_encode(bad, e, pool)
+    j = int(np.nonzero(e["data_len"])[0][0])
+    bade = e.copy()
+    bade["data_off"][j] = len(pool)  # payload past the pool
+    mm = m.copy()
+    mm["ent_first"][i], mm["n_ents"][i] = j, 1
+    with pytest.raises(RaftqError):
+        eng.wire_encode(mm, bade, pool)
+    # a too-small buffer is refused and the size needed is reported
+    import ctypes as C
+
+    from raftsql_amd import _lib
+
+    c = _lib.WireCounts()
+    out = np.zeros(10, np.uint8)
+    rc = eng._lib.raftq_wire_encode(eng._h, m.ctypes.data, len(m), e.ctypes.data, len(e), pool.ctypes.data, len(pool),
+                                    out.ctypes.data, len(out), None, C.byref(c))
+    assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(W.wire_encode(m, e, pool)[0]) and not out.any()
+    # and the engine still works afterwards
+    got, _ = eng.wire_encode(m, e, pool)
+    assert got.tobytes() == W.wire_encode(m, e, pool)[0].tobytes()
+
+
+def test_empty_batches(eng):
+    s, off = eng.wire_encode(np.zeros(0, W.WIRE_MSG_DT))
+    assert len(s) == 0 and list(off) == [0]
+    mm, ee, bad = eng.wire_decode(b"", np.zeros(1, np.uint64))
+    assert len(mm) == 0 and len(ee) == 0 and bad == 0
+    out, off, last = eng.wal_encode(np.zeros(0, W.WAL_REC_DT), b"", 77)
+    assert len(out) == 0 and last == 77
+    rr, nv, last = eng.wal_decode(b"", np.zeros(1, np.uint64), 78)
+    assert len(rr) == 0 and nv == 0 and last == 78
+
+
+@pytest.mark.parametrize("seed,n,big", [(111, 700, 5), (112, 4000, 0)])
+def test_decode_parity_canonical(eng, seed, n, big):
+    rng = np.random.default_rng(seed)
+    m, e, pool = _wiregen.random_msgs(rng, n, big_every=big, ent_frac=0.4)
+    s, off = W.wire_encode(m, e, pool)
+    wm, we, wbad = W.wire_decode(s, off)
+    gm, ge, gbad = eng.wire_decode(s, off)
+    assert gbad == wbad == 0
+    _same(gm, wm, "msgs")
+    _same(ge, we, "ents")
+    hm, he, _ = eng.wire_decode(s, off, want_ents=False)  # headers only
+    _same(hm, wm, "msgs (no entries requested)")
+    assert len(he) == 0
+
+
+@pytest.mark.parametrize("seed", [121, 122])
+def test_decode_parity_noncanonical(eng, seed):
+    rng = np.random.default_rng(seed)
+    m, e, pool = _wiregen.random_msgs(rng, 300, ent_frac=0.4)
+    bodies = [_wiregen.noncanonical_message(rng, m[i], e, pool) for i in range(len(m))]
+    stream = b"".join(_be(b) for b in bodies)
+    off = np.concatenate([[0], np.cumsum([len(b) + 8 for b in bodies])]).astype(np.uint64)
+    wm, we, wbad = W.wire_decode(stream, off)
+    gm, ge, gbad = eng.wire_decode(stream, off)
+    assert wbad == gbad == 0
+    _same(gm, wm, "msgs")
+    _same(ge, we, "ents")
+
+
+def test_decode_malformed_frames(eng):
+    good = _be(bytes.fromhex("0806100218012005"))
+    cases = [
+        (9).to_bytes(8, "big") + bytes.fromhex("0806100218012005"),  # length word disagrees
+        _be(bytes.fromhex("080610021801208080")),  # truncated varint
+        _be(bytes.fromhex("20" + "80" * 10 + "01")),  # 11-byte varint
+        _be(bytes.fromhex("08033a0508001005")),  # entry length overruns
+        _be(bytes.fromhex("2201aa")),  # wrong wire type on term
+        _be(bytes.fromhex("0001")),  # tag 0
+        _be(bytes.fromhex("6b")),  # group wire type
+        _be(bytes.fromhex("3a021280")),  # bad entry inside
+        _be(bytes.fromhex("4a021201")),  # bad snapshot inside
+        b"\x00\x00\x00",  # shorter than a length word
+        _be(bytes.fromhex("08" + "ff" * 9 + "01" + "20" + "ff" * 9 + "7f")),  # 10-byte varints: fine
+        _be(bytes.fromhex("4a00")),  # empty snapshot, nothing else
+        _be(bytes.fromhex("4a061204" "0a020801" "3a00" "3a021001")),  # snapshot with a conf_state member; two entries
+    ]
+    stream, off = good, [0, len(good)]
+    for b in cases:
+        stream += b + good
+        off += [off[-1] + len(b), off[-1] + len(b) + len(good)]
+    off = np.array(off, np.uint64)
+    wm, we, wbad = W.wire_decode(stream, off)
+    gm, ge, gbad = eng.wire_decode(stream, off)
+    assert gbad == wbad == 10
+    assert list(wm["flags"][1::2]) == [W.F_MALFORMED] * 10 + [0, 0, W.F_SNAPSHOT] and wm["n_ents"][-2] == 2
+    _same(gm, wm, "msgs")
+    _same(ge, we, "ents")
+    # frame extents that are themselves nonsense: decreasing, past the end
+    off2 = np.array([0, len(good), 5, len(stream) + 100, len(stream)], np.uint64)
+    wm, we, wbad = W.wire_decode(stream, off2)
+    gm, ge, gbad = eng.wire_decode(stream, off2)
+    assert gbad == wbad
+    _same(gm, wm, "msgs")
+
+
+@pytest.mark.parametrize("seed", [131, 132, 133])
+def test_decode_fuzz(eng, seed):
+    """Mutated valid frames and pure noise: whatever the bytes, GPU and oracle agree on every record
+    (and nothing faults: every read stays inside the frame)."""
+    rng = np.random.default_rng(seed)
+    m, e, pool = _wiregen.random_msgs(rng, 1500, ent_frac=0.5, max_payload=60)
+    s, off = W.wire_encode(m, e, pool)
+    s = s.copy()
+    n_mut = len(s) // 40
+    pos = rng.integers(0, len(s), n_mut)
+    s[pos] = rng.integers(0, 256, n_mut, dtype=np.uint8)
+    # keep most length words intact so that the bodies get parsed
+    for i in rng.choice(len(m), len(m) * 9 // 10, replace=False):
+        a, b = int(off[i]), int(off[i + 1])
+        s[a:a + 8] = np.frombuffer((b - a - 8).to_bytes(8, "big"), np.uint8)
+    wm, we, wbad = W.wire_decode(s, off)
+    gm, ge, gbad = eng.wire_decode(s, off)
+    assert gbad == wbad and wbad > 0
+    _same(gm, wm, "msgs")
+    _same(ge, we, "ents")
+    noise = rng.integers(0, 256, 20000, dtype=np.uint8)
+    cuts = np.sort(rng.choice(np.arange(1, len(noise)), 600, replace=False))
+    off = np.concatenate([[0], cuts, [len(noise)]]).astype(np.uint64)
+    for i in range(len(off) - 1):  # valid length words, random bodies
+        a, b = int(off[i]), int(off[i + 1])
+        if b - a >= 8:
+            noise[a:a + 8] = np.frombuffer((b - a - 8).to_bytes(8, "big"), np.uint8)
+    wm, we, wbad = W.wire_decode(noise, off)
+    gm, ge, gbad = eng.wire_decode(noise, off)
+    assert gbad == wbad
+    _same(gm, wm, "noise msgs")
+    _same(ge, we, "noise ents")
+
+
+def test_decode_entry_capacity(eng):
+    import ctypes as C
+
+    from raftsql_amd import _lib
+
+    rng = np.random.default_rng(9)
+    m, e, pool = _wiregen.random_msgs(rng, 200, ent_frac=1.0)
+    s, off = W.wire_encode(m, e, pool)
+    assert len(e) > 10
+    msgs = np.zeros(len(m), W.WIRE_MSG_DT)
+    ents = np.zeros(10, W.WIRE_ENT_DT)
+    c = _lib.WireCounts()
+    rc = eng._lib.raftq_wire_decode(eng._h, s.ctypes.data, len(s), off.ctypes.data, len(m), msgs.ctypes.data,
+                                    ents.ctypes.data, 10, C.byref(c))
+    assert rc == _lib.RAFTQ_EINVAL and c.n_ents == len(e)
+
+
+def test_scan_frames_host(eng):
+    from raftsql_amd import wire
+
+    rng = np.random.default_rng(5)
+    m, e, pool = _wiregen.random_msgs(rng, 50)
+    s, off = W.wire_encode(m, e, pool)
+    for cut in (len(s), len(s) - 1, int(off[20]) + 3, int(off[20]) + 8, 0, 7):
+        want, wused = W.scan_frames(s[:cut], big_endian=True)
+        got, used = wire.scan_frames(s[:cut], big_endian=True)
+        assert used == wused and np.array_equal(got, want)
+    got, used = wire.scan_frames(s, big_endian=True, cap=10)
+    assert len(got) == 11 and used == off[10]
+
+
+def test_roundtrip_at_size(eng):
+    """200k messages: decode(encode(x)) == x field for field, payload bytes included."""
+    rng = np.random.default_rng(77)
+    m, e, pool = _wiregen.random_msgs(rng, 200_000, ent_frac=0.25, max_payload=120)
+    s, off = eng.wire_encode(m, e, pool)
+    assert off[-1] == len(s)
+    mm, ee, bad = eng.wire_decode(s, off)
+    assert bad == 0 and np.all(mm["flags"] == W.F_GROUP)
+    for k in ("group", "term", "log_term", "index", "commit", "reject_hint", "from", "type", "reject", "to", "n_ents", "ent_first"):
+        assert np.array_equal(mm[k], m[k]), k
+    for k in ("term", "index", "data_len", "type"):
+        assert np.array_equal(ee[k], e[k]), k
+    # payload bytes: a vectorised gather of every payload byte from both sides
+    ln = e["data_len"].astype(np.int64)
+    tot = int(ln.sum())
+    rel = np.arange(tot) - np.repeat(np.cumsum(ln) - ln, ln)
+    src = np.repeat(e["data_off"].astype(np.int64), ln) + rel
+    dst = np.repeat(ee["data_off"].astype(np.int64), ln) + rel
+    assert np.array_equal(s[dst], pool[src])
+    # the frames found from the length words alone are the ones encode reported
+    from raftsql_amd import wire
+
+    off2, used = wire.scan_frames(s, big_endian=True)
+    assert used == len(s) and np.array_equal(off2, off)
+
+
+# ---- Step from the wire ---------------------------------------------------------------------------
+
+def _step_traffic(rng, n, n_groups, n_peers):
+    m = np.zeros(n, W.WIRE_MSG_DT)
+    m["group"] = rng.integers(0, n_groups, n)
+    m["type"] = rng.choice([3, 4, 5, 6, 8, 9], n)
+    m["term"] = rng.integers(1, 4, n)
+    m["from"] = rng.integers(1, n_peers, n)
+    m["to"] = 0
+    m["index"] = rng.integers(0, 50, n)
+    m["log_term"] = rng.integers(0, 4, n)
+    m["commit"] = rng.integers(0, 30, n)
+    m["reject"] = rng.integers(0, 2, n)
+    m["reject_hint"] = rng.integers(0, 50, n)
+    return m
+
+
+def test_step_from_wire_equals_step_from_records():
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+    from raftsql_amd.wire import WireEngine
+
+    G, N = 2048, 5
+    rng = np.random.default_rng(31)
+    with WireEngine(G, N, 0) as a, S.NodeEngine(G, N, 0) as b:
+        for rnd in range(6):
+            m = _step_traffic(rng, 5000, G, N)
+            e = np.zeros(0, W.WIRE_ENT_DT)
+            pool = np.zeros(1, np.uint8)
+            if rnd % 2:  # MsgApp frames carry entries; Step reads only the header
+                app = np.nonzero(m["type"] == 3)[0]
+                m["n_ents"][app] = 2
+                m["ent_first"][app] = np.arange(len(app)) * 2
+                e = np.zeros(2 * len(app), W.WIRE_ENT_DT)
+                e["term"], e["index"], e["data_len"] = 3, np.arange(len(e)), 5
+                e["data_off"] = np.arange(len(e)) * 5
+                pool = rng.integers(0, 256, 5 * len(e) + 1, dtype=np.uint8)
+            s, off = W.wire_encode(m, e, pool)
+            a.step_submit_wire(s, off)
+            got, touched = a.step_collect()
+            rec = np.zeros(len(m), S.MSG_DT)
+            for k in ("group", "term", "log_term", "index", "commit", "reject_hint", "from", "type", "reject"):
+                rec[k] = m[k]
+            want, wtouched = b.step_batch(rec)
+            assert touched == wtouched
+            _same(got, want, "step results")
+            wm, we, _ = W.wire_decode(s, off)
+            _same(a.step_wire_msgs(), wm, "decoded records of the batch")
+            _same(a.step_wire_entries(), we, "decoded entries of the batch")
+        na, nb = a.read_node(), b.read_node()
+        for k in na:
+            assert np.array_equal(na[k], nb[k]), k
+        # a frame that does not parse fails the whole batch, nothing is applied
+        m = _step_traffic(rng, 100, G, N)
+        s, off = W.wire_encode(m)
+        s = s.copy()
+        s[int(off[40]) + 8] = 0x0B
+        a.step_submit_wire(s, off)
+        with pytest.raises(RaftqError):
+            a.step_collect()
+        assert a.step_wire_msgs()[40]["flags"] == W.F_MALFORMED  # which one: the decoded records say
+        # so does one addressed to no peer of the cluster, or a snapshot message
+        for field, val in (("to", 9), ("type", 7)):
+            mm = m.copy()
+            mm[field][3] = val
+            s, off = W.wire_encode(mm)
+            a.step_submit_wire(s, off)
+            with pytest.raises(RaftqError):
+                a.step_collect()
+        n2 = a.read_node()
+        for k in na:
+            assert np.array_equal(na[k], n2[k]), k
+        # two wire batches in flight, collected in order
+        m1, m2 = _step_traffic(rng, 3000, G, N), _step_traffic(rng, 3000, G, N)
+        for mm in (m1, m2):
+            s, off = W.wire_encode(mm)
+            a.step_submit_wire(s, off)
+        for mm in (m1, m2):
+            got, _ = a.step_collect()
+            rec = np.zeros(len(mm), S.MSG_DT)
+            for k in ("group", "term", "log_term", "index", "commit", "reject_hint", "from", "type", "reject"):
+                rec[k] = mm[k]
+            want, _ = b.step_batch(rec)
+            _same(got, want, "pipelined step results")
+
+
+# ---- WAL ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed,n,big,prev", [(141, 1, 0, 0), (142, 300, 9, 0), (143, 300, 2, 0xDEADBEEF), (144, 5000, 50, 0),
+                                             (145, 65, 1, 1)])
+def test_wal_encode_parity(eng, seed, n, big, prev):
+    rng = np.random.default_rng(seed)
+    r, pool = _wiregen.random_wal(rng, n, big_every=big, head=(prev == 0 and n >= 3))
+    want, want_off, want_last = W.wal_encode(r, pool, prev)
+    got, off, last = eng.wal_encode(r, pool, prev)
+    assert np.array_equal(off, want_off) and last == want_last
+    assert got.tobytes() == want.tobytes()
+
+
+def test_wal_encode_rejects_bad_input(eng):
+    from raftsql_amd.engine import RaftqError
+
+    r, pool = _wiregen.random_wal(np.random.default_rng(10), 50)
+    for kind in (0, 6, 255):
+        bad = r.copy()
+        bad["kind"][20] = kind
+        with pytest.raises(RaftqError):
+            eng.wal_encode(bad, pool, 0)
+    j = int(np.nonzero(r["data_len"])[0][0])
+    bad = r.copy()
+    bad["data_off"][j] = len(pool) - 1
+    bad["data_len"][j] = 2
+    with pytest.raises(RaftqError):
+        eng.wal_encode(bad, pool, 0)
+
+
+@pytest.mark.parametrize("seed,big", [(151, 11), (152, 2)])
+def test_wal_decode_parity(eng, seed, big):
+    rng = np.random.default_rng(seed)
+    r, pool = _wiregen.random_wal(rng, 400, big_every=big)
+    r["kind"][200] = W.WAL_CRC  # a segment cut in mid-stream
+    for k in ("group", "term", "index", "vote", "data_len", "data_off", "entry_type"):
+        r[k][200] = 0
+    out, off, last = W.wal_encode(r, pool, 0)
+
+    def both(data, offs, prev):
+        wr, wnv, wl = W.wal_decode(data, offs, prev)
+        gr, gnv, gl = eng.wal_decode(data, offs, prev)
+        assert (gnv, gl) == (wnv, wl)
+        _same(gr, wr, "recs")
+        return gr, gnv, gl
+
+    rr, nv, lc = both(out, off, 0)
+    assert nv == len(r) and lc == last
+    both(out, off, 12345)  # wrong seed
+    for j in rng.choice(np.nonzero(r["data_len"] > 0)[0], 12, replace=False):  # a flipped payload bit
+        bad = out.copy()
+        bad[int(rr[j]["data_off"]) + int(rng.integers(0, r[j]["data_len"]))] ^= 1 << int(rng.integers(0, 8))
+        _, nv, _ = both(bad, off, 0)
+        assert nv == j
+    for _ in range(12):  # a flipped bit anywhere: header fields, crc field, length words
+        bad = out.copy()
+        bad[int(rng.integers(0, len(out)))] ^= 1 << int(rng.integers(0, 8))
+        both(bad, off, 0)
+    bad = out.copy()
+    bad[int(off[10]) + 8] = 0x0B  # does not parse
+    _, nv, _ = both(bad, off, 0)
+    assert nv == 10
+    bad = out.copy()
+    bad[int(off[200]) + 11] ^= 0x40  # the re-seeding record's own crc is wrong: it and what follows mismatch
+    both(bad, off, 0)
+    cut = int(off[300]) + 5  # a torn tail
+    o3, used = W.scan_frames(out[:cut], big_endian=False)
+    _, nv, lc = both(out[:cut], o3, 0)
+    assert nv == 300
+    rest, _, last3 = eng.wal_encode(r[300:], pool, lc)  # appending continues the chain
+    assert rest.tobytes() == out[int(off[300]):].tobytes() and last3 == last
+
+
+def test_wal_decode_fuzz(eng):
+    rng = np.random.default_rng(161)
+    r, pool = _wiregen.random_wal(rng, 2000, max_payload=80)
+    out, off, _ = W.wal_encode(r, pool, 0)
+    s = out.copy()
+    n_mut = len(s) // 60
+    s[rng.integers(0, len(s), n_mut)] = rng.integers(0, 256, n_mut, dtype=np.uint8)
+    for i in rng.choice(len(r), len(r) * 9 // 10, replace=False):
+        a, b = int(off[i]), int(off[i + 1])
+        s[a:a + 8] = np.frombuffer((b - a - 8).to_bytes(8, "little"), np.uint8)
+    wr, wnv, wl = W.wal_decode(s, off, 0)
+    gr, gnv, gl = eng.wal_decode(s, off, 0)
+    assert (gnv, gl) == (wnv, wl)
+    _same(gr, wr, "recs")
+
+
+def test_wal_chain_properties_at_size(eng):
+    """300k records (with 4-20 KB payloads sprinkled in): decode(encode(x)) validates completely and
+    returns x; the chain splits anywhere -- encoding [0, k) then [k, n) seeded with the first half's
+    last_crc gives the same bytes as one call; a corrupted byte is found at its record."""
+    rng = np.random.default_rng(171)
+    n = 300_000
+    r, pool = _wiregen.random_wal(rng, n, max_payload=100, big_every=997)
+    out, off, last = eng.wal_encode(r, pool, 0)
+    assert off[-1] == len(out)
+    rr, nv, lc = eng.wal_decode(out, off, 0)
+    assert nv == n and lc == last
+    for k in ("group", "term", "index", "vote", "data_len", "kind", "entry_type"):
+        assert np.array_equal(rr[k], r[k]), k
+    ln = r["data_len"].astype(np.int64)
+    tot = int(ln.sum())
+    rel = np.arange(tot) - np.repeat(np.cumsum(ln) - ln, ln)
+    assert np.array_equal(out[np.repeat(rr["data_off"].astype(np.int64), ln) + rel],
+                          pool[np.repeat(r["data_off"].astype(np.int64), ln) + rel])
+    k = 123_457
+    a, _, la = eng.wal_encode(r[:k], pool, 0)
+    b, _, lb = eng.wal_encode(r[k:], pool, la)
+    assert lb == last and a.tobytes() == out[:int(off[k])].tobytes() and b.tobytes() == out[int(off[k]):].tobytes()
+    # the oracle agrees on a prefix it can do quickly
+    want, woff, wlast = W.wal_encode(r[:20000], pool, 0)
+    assert want.tobytes() == out[:int(off[20000])].tobytes()
+    j = int(np.nonzero(r["data_len"] > 4000)[0][3])
+    bad = out.copy()
+    bad[int(rr[j]["data_off"]) + 2000] ^= 0x10
+    _, nv, _ = eng.wal_decode(bad, off, 0)
+    assert nv == j
+
+
+def test_wal_hand_vector(eng):
+    r = np.zeros(5, W.WAL_REC_DT)
+    r["kind"] = [W.WAL_CRC, W.WAL_METADATA, W.WAL_SNAPSHOT, W.WAL_ENTRY, W.WAL_STATE]
+    r[3]["term"], r[3]["index"], r[3]["data_len"] = 1, 1, 1
+    r[4]["term"], r[4]["vote"], r[4]["index"] = 1, 2, 1
+    out, off, last = eng.wal_encode(r, b"a", 0)
+    snap = bytes.fromhex("08001000")
+    ent = bytes.fromhex("080010011801" "220161" "2800")
+    st = bytes.fromhex("0801100218012000")
+    c1 = W.crc32c(snap)
+    c2 = W.crc32c(ent, c1)
+    c3 = W.crc32c(st, c2)
+    vi = _wiregen._varint
+
+    def le(b):
+        return len(b).to_bytes(8, "little") + b
+
+    want = b"".join(le(x) for x in (
+        bytes.fromhex("08041000"),
+        bytes.fromhex("08011000"),
+        bytes.fromhex("0805") + b"\x10" + vi(c1) + b"\x1a\x04" + snap,
+        bytes.fromhex("0802") + b"\x10" + vi(c2) + b"\x1a\x0b" + ent,
+        bytes.fromhex("0803") + b"\x10" + vi(c3) + b"\x1a\x08" + st))
+    assert out.tobytes() == want and last == c3 and off[-1] == len(want)
+
+
+# ---- committed fixtures ---------------------------------------------------------------------------
+
+def test_golden_fixtures(eng):
+    g = json.load(open(GOLD))
+    w = g["wire"]
+    m = np.frombuffer(bytes.fromhex(w["msgs"]), W.WIRE_MSG_DT)
+    e = np.frombuffer(bytes.fromhex(w["ents"]), W.WIRE_ENT_DT)
+    pool = bytes.fromhex(w["pool"])
+    s, off = eng.wire_encode(m, e, pool)
+    assert s.tobytes().hex() == w["stream"] and list(map(int, off)) == w["frame_off"]
+    mm, ee, bad = eng.wire_decode(s, off)
+    assert bad == 0 and mm.tobytes().hex() == w["decoded_msgs"] and ee.tobytes().hex() == w["decoded_ents"]
+    nc = g["wire_noncanonical"]
+    mm, ee, bad = eng.wire_decode(bytes.fromhex(nc["stream"]), np.array(nc["frame_off"], np.uint64))
+    assert bad == nc["n_malformed"] and mm.tobytes().hex() == nc["decoded_msgs"] and ee.tobytes().hex() == nc["decoded_ents"]
+    a = g["wal"]
+    r = np.frombuffer(bytes.fromhex(a["recs"]), W.WAL_REC_DT)
+    out, off, last = eng.wal_encode(r, bytes.fromhex(a["pool"]), a["prev_crc"])
+    assert out.tobytes().hex() == a["bytes"] and last == a["last_crc"] and list(map(int, off)) == a["frame_off"]
+    rr, nv, lc = eng.wal_decode(out, off, a["prev_crc"])
+    assert nv == len(r) and lc == last and rr.tobytes().hex() == a["decoded_recs"]
+    # the CRC fixtures, through the WAL path: one metadata record whose Data is the vector, seeded
+    for c in g["crc32c"]:
+        data = bytes.fromhex(c["data"])
+        rec = np.zeros(1, W.WAL_REC_DT)
+        rec["kind"], rec["data_len"] = W.WAL_METADATA, len(data)
+        _, _, last = eng.wal_encode(rec, data, c["seed"])
+        assert last == c["crc"], c

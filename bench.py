@@ -338,10 +338,24 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     stream, off = e.wire_encode(m, ents, pool)
     t_enc = timeit(lambda: e.wire_encode(m, ents, pool)) / 2  # the mirror calls twice (size, then bytes)
     t_dec = timeit(lambda: e.wire_decode(stream, off))
+    # the same calls on page-locked buffers (raftq_host_alloc): direct DMA instead of staged pageable copies
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+
+    pm, pe, pp = pinned_copy(m), pinned_copy(ents), pinned_copy(pool)
+    pout, poff = pinned_empty(len(stream) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+    pstream, pmsgs, pents = pinned_copy(stream), pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(ents) + 1, W.WIRE_ENT_DT)
+    got, goff = e.wire_encode(pm, pe, pp, out=pout, off=poff)
+    assert got.tobytes() == stream.tobytes()
+    t_enc_p = timeit(lambda: e.wire_encode(pm, pe, pp, out=pout, off=poff))
+    t_dec_p = timeit(lambda: e.wire_decode(pstream, poff, msgs=pmsgs, ents=pents))
     out["message_frames"] = {"entries": len(ents), "stream_bytes": int(len(stream)),
                              "encode_us": t_enc * 1e6, "encode_msgs_per_s": n / t_enc,
                              "decode_us": t_dec * 1e6, "decode_msgs_per_s": n / t_dec,
-                             "decode_GBps": len(stream) / t_dec / 1e9}
+                             "decode_GBps": len(stream) / t_dec / 1e9,
+                             "pinned": {"encode_us": t_enc_p * 1e6, "encode_msgs_per_s": n / t_enc_p,
+                                        "decode_us": t_dec_p * 1e6, "decode_msgs_per_s": n / t_dec_p,
+                                        "bytes_over_pcie_encode": int(pm.nbytes + pe.nbytes + pp.nbytes + len(stream) + poff.nbytes),
+                                        "bytes_over_pcie_decode": int(len(stream) + poff.nbytes + pmsgs.nbytes + len(ents) * 32)}}
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)
@@ -372,9 +386,17 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     t_wdec = timeit(lambda: e.wal_decode(wal, woff, 0))
     _, nv, lc = e.wal_decode(wal, woff, 0)
     assert nv == n and lc == wlast
+    pr, pwp, pwal, precs = pinned_copy(r), pinned_copy(wpool), pinned_copy(wal), pinned_empty(n, W.WAL_REC_DT)
+    pwout = pinned_empty(len(wal) + 64, np.uint8)
+    t_wenc_p = timeit(lambda: e.wal_encode(pr, pwp, 0, out=pwout, off=poff))
+    t_wdec_p = timeit(lambda: e.wal_decode(pwal, poff, 0, recs=precs))
+    assert pwout[: len(wal)].tobytes() == wal.tobytes()
     out["wal_frames"] = {"records": n, "wal_bytes": int(len(wal)), "encode_us": t_wenc * 1e6,
                          "encode_recs_per_s": n / t_wenc, "decode_us": t_wdec * 1e6, "decode_recs_per_s": n / t_wdec,
-                         "decode_GBps": len(wal) / t_wdec / 1e9}
+                         "decode_GBps": len(wal) / t_wdec / 1e9,
+                         "pinned": {"encode_us": t_wenc_p * 1e6, "encode_recs_per_s": n / t_wenc_p,
+                                    "decode_us": t_wdec_p * 1e6, "decode_recs_per_s": n / t_wdec_p,
+                                    "decode_GBps": len(wal) / t_wdec_p / 1e9}}
     e.close()
     if with_cpu:
         W.set_fast_crc(True)  # table-driven CRC: the fair single-core comparison
@@ -608,6 +630,26 @@ def main():
             "GBps": (rd + wr) * cfg["G"] / (e1 * 1e-3 / k1) / 1e9,
             "note": "one 65 MB batch re-swept: served from Infinity Cache, NOT an HBM figure",
         }
+    if world.rank == 0 and not args.no_extras:
+        # the same rotating loop with the batches alternating between two streams: batches are
+        # independent handles, so the ramp of one sweep overlaps the drain of the previous one.  Wall
+        # clock only (per-kernel durations overlap, so this is not a roofline.achieved figure).
+        s2 = torch.cuda.Stream()
+        for i, e in enumerate(engines):
+            e.set_stream((stream if i % 2 == 0 else s2).cuda_stream)
+        for i in range(200):
+            engines[i % n_batches].step_async(flags)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            engines[i % n_batches].step_async(flags)
+        torch.cuda.synchronize()
+        w2 = time.perf_counter() - t0
+        for e in engines:
+            e.set_stream(stream.cuda_stream)
+        out["two_streams"] = {"decisions_per_s": cfg["G"] * args.steps / w2, "us_per_step": w2 * 1e6 / args.steps,
+                              "GBps": (rd + wr) * cfg["G"] * args.steps / w2 / 1e9,
+                              "note": "same workload, batches alternate between two HIP streams (wall clock)"}
     if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, st0)
     elif world.rank == 0:

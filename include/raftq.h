@@ -222,6 +222,16 @@ int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_li
 int raftq_timer_begin(raftq_t* h);
 int raftq_timer_end(raftq_t* h, float* elapsed_ms);
 
+/* ---- page-locked host memory for the caller's bulk buffers ------------- */
+/* Every entry point that takes or fills a caller-owned host buffer accepts any
+ * memory; given a buffer from raftq_host_alloc the transfer is a direct DMA at
+ * PCIe speed instead of a staged pageable copy (bulk loads, read-backs, the
+ * wire / WAL codecs of raftq_wire.h).  Needs a GPU runtime: RAFTQ_ENODEV /
+ * RAFTQ_ENOMEM otherwise.  A cgo caller wraps the pointer with unsafe.Slice;
+ * the memory is not Go-managed, so the cgo pointer rules do not apply to it. */
+int raftq_host_alloc(void** p, uint64_t bytes);
+void raftq_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,8 @@ _SIGS = [
     ("raftq_last_advances", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_timer_begin", C.c_int, [_H]),
     ("raftq_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
+    ("raftq_host_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_uint64]),
+    ("raftq_host_free", None, [C.c_void_p]),
 ]
 EXPORTS = [s[0] for s in _SIGS]
 

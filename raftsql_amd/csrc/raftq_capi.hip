@@ -815,4 +815,22 @@ int raftq_timer_end(raftq_t* h, float* elapsed_ms) {
   return RAFTQ_OK;
 }
 
+int raftq_host_alloc(void** p, uint64_t bytes) {
+  if (!p || bytes == 0) return fail(nullptr, RAFTQ_EINVAL, "raftq_host_alloc: null pointer or zero size");
+  *p = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(nullptr, RAFTQ_ENODEV, "raftq_host_alloc: no HIP device");
+  const hipError_t e = hipHostMalloc(p, (size_t)bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return fail(nullptr, e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP,
+                std::string("raftq_host_alloc: ") + hipGetErrorString(e));
+  }
+  return RAFTQ_OK;
+}
+
+void raftq_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 }  // extern "C"

@@ -317,7 +317,8 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   // call on the handle) -> copy-out stream, chained by events
   const int mode = h->step_stream_mode;
   hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
-  hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
+  // 5, 6: as 3 / 2, but the result copy is a runtime memcpy (DMA engine when the runtime picks one) instead of our kernel
+  hipStream_t s_out = (mode == 1 || mode == 2 || mode == 6 || mode == 8) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
   HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
   if (s_in != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
@@ -345,18 +346,38 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   size_t cub_bytes = s.cub_bytes;
   HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
                                                (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
+  // 8: the walk writes its result records straight into the pinned, device-mapped result area (no copy kernel)
   hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
-                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, s.outs, n, s.n_heads,
-                     (const unsigned int*)bad);
+                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out,
+                     mode == 8 ? (StepOutRec*)sl.out_d : s.outs, n, s.n_heads, (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
   if (s_out != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
     HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
   }
   const uint64_t out_quads = n * 4 + 1;  // records + the 16-byte tail
-  hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
-  HIPCHK(h, hipGetLastError());
+  if (mode == 5 || mode == 6) {
+    HIPCHK(h, hipMemcpyAsync(sl.out_h, s.outs, (size_t)out_quads * 16, hipMemcpyDeviceToHost, s_out));
+  } else if (mode == 8) {
+    hipLaunchKernelGGL(step_d2h_kernel, dim3(1), dim3(kBlock), 0, s_out, (const u64x2*)s.n_heads,
+                       (u64x2*)((uint8_t*)sl.out_d + (size_t)n * sizeof(StepOutRec)), (uint64_t)1);
+    HIPCHK(h, hipGetLastError());
+  } else if (mode == 7) {
+    // the result copy as several short kernels on its own stream: a kernel with PCIe writes in flight holds back
+    // kernel starts on the other queues only until it retires, so short ones let the next batch's chain interleave
+    static const int chunks = [] { const char* c = std::getenv("RAFTQ_STEP_D2H_CHUNKS"); return c ? std::max(1, std::atoi(c)) : 8; }();
+    const uint64_t per = (out_quads + chunks - 1) / chunks;
+    for (uint64_t q0 = 0; q0 < out_quads; q0 += per) {
+      const uint64_t nq = std::min(per, out_quads - q0);
+      hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         s_out, (const u64x2*)s.outs + q0, (u64x2*)sl.out_d + q0, nq);
+    }
+    HIPCHK(h, hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
+    HIPCHK(h, hipGetLastError());
+  }
   HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
   sl.n = n;
   sl.busy = true;

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import (SWEEP_CACHED, SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
                    SWEEP_STREAM, SWEEP_VOTES, Advance, Counts, Delta, RaftqError, VoteDelta)
 
-__all__ = ["QuorumEngine", "SweepCounts", "device_count", "RaftqError", "SWEEP_COMMIT", "SWEEP_GATED",
+__all__ = ["QuorumEngine", "SweepCounts", "device_count", "RaftqError", "pinned_empty", "pinned_copy", "SWEEP_COMMIT", "SWEEP_GATED",
            "SWEEP_VOTES", "SWEEP_NO_ADOPT", "SWEEP_LDS", "SWEEP_CHANGED", "SWEEP_STREAM", "SWEEP_CACHED"]
 
 
@@ -40,6 +40,38 @@ def device_count() -> int:
 
 def _ptr(a: np.ndarray) -> int:
     return a.ctypes.data
+
+
+class _Pinned:
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.lib.raftq_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(count: int, dtype) -> np.ndarray:
+    """numpy array over page-locked host memory (raftq_host_alloc): the library's transfers to and
+    from it are direct DMA.  Freed when the array (and every view of it) is gone."""
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(count) * dt.itemsize)
+    p = C.c_void_p(None)
+    rc = lib.raftq_host_alloc(C.byref(p), nbytes)
+    if rc != 0:
+        raise RaftqError(rc, (lib.raftq_last_error(None) or b"raftq_host_alloc failed").decode())
+    buf = (C.c_char * nbytes).from_address(p.value)
+    buf._raftq_owner = _Pinned(lib, p.value)  # the ctypes object is the array's base: it keeps this alive
+    return np.frombuffer(buf, dtype=dt, count=int(count))
+
+
+def pinned_copy(a: np.ndarray) -> np.ndarray:
+    out = pinned_empty(a.size, a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
 
 
 class QuorumEngine:

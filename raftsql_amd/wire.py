@@ -60,14 +60,20 @@ class WireEngine(NodeEngine):
     """NodeEngine + the codecs of the byte formats either side of Step."""
 
     # -- raftpb.Message <-> rafthttp stream frames -----------------------------------------
-    def wire_encode(self, msgs: np.ndarray, ents: np.ndarray | None = None, pool=b""):
-        """-> (stream uint8[], frame_off uint64[n+1]).  Two calls: the first learns the size."""
+    def wire_encode(self, msgs: np.ndarray, ents: np.ndarray | None = None, pool=b"", out: np.ndarray | None = None,
+                    off: np.ndarray | None = None):
+        """-> (stream uint8[], frame_off uint64[n+1]).  Without `out` two calls are made: the first learns
+        the size.  With `out` (uint8, e.g. from engine.pinned_empty) one call writes into it."""
         m = np.ascontiguousarray(msgs, dtype=WIRE_MSG_DT)
         e = np.ascontiguousarray(ents if ents is not None else np.zeros(0, WIRE_ENT_DT), dtype=WIRE_ENT_DT)
         p = _u8(pool)
-        off = np.zeros(len(m) + 1, np.uint64)
+        if off is None:
+            off = np.zeros(len(m) + 1, np.uint64)
         c = _lib.WireCounts()
         args = (self._h, _p(m), len(m), _p(e), len(e), _p(p), len(p))
+        if out is not None:
+            self._chk(self._lib.raftq_wire_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
+            return out[: int(c.bytes)], off
         rc = self._lib.raftq_wire_encode(*args, None, 0, _ptr(off), C.byref(c))
         if rc == 0:  # nothing to write
             return np.zeros(0, np.uint8), off
@@ -78,16 +84,22 @@ class WireEngine(NodeEngine):
         assert c.bytes == len(out)
         return out, off
 
-    def wire_decode(self, stream, frame_off, want_ents: bool = True):
-        """-> (msgs, ents, n_malformed)"""
+    def wire_decode(self, stream, frame_off, want_ents: bool = True, msgs: np.ndarray | None = None,
+                    ents: np.ndarray | None = None):
+        """-> (msgs, ents, n_malformed).  `msgs` / `ents`: caller-provided result arrays (e.g. pinned)."""
         s = _u8(stream)
         off = np.ascontiguousarray(frame_off, np.uint64)
         n = len(off) - 1
-        msgs = np.zeros(n, WIRE_MSG_DT)
+        if msgs is None:
+            msgs = np.zeros(n, WIRE_MSG_DT)
         c = _lib.WireCounts()
         if not want_ents:
             self._chk(self._lib.raftq_wire_decode(self._h, _p(s), len(s), _ptr(off), n, _p(msgs), None, 0, C.byref(c)))
-            return msgs, np.zeros(0, WIRE_ENT_DT), int(c.n_malformed)
+            return msgs[:n], np.zeros(0, WIRE_ENT_DT), int(c.n_malformed)
+        if ents is not None:
+            self._chk(self._lib.raftq_wire_decode(self._h, _p(s), len(s), _ptr(off), n, _p(msgs), _ptr(ents), len(ents),
+                                                  C.byref(c)))
+            return msgs[:n], ents[: int(c.n_ents)], int(c.n_malformed)
         cap = max(n, 16)
         while True:
             ents = np.zeros(cap, WIRE_ENT_DT)
@@ -121,13 +133,18 @@ class WireEngine(NodeEngine):
         return np.frombuffer(buf, dtype=WIRE_ENT_DT, count=k.value).copy()
 
     # -- walpb.Record <-> WAL frames ------------------------------------------------------------
-    def wal_encode(self, recs: np.ndarray, pool=b"", prev_crc: int = 0):
-        """wal.Save for a batch -> (bytes uint8[], frame_off, last_crc)"""
+    def wal_encode(self, recs: np.ndarray, pool=b"", prev_crc: int = 0, out: np.ndarray | None = None,
+                   off: np.ndarray | None = None):
+        """wal.Save for a batch -> (bytes uint8[], frame_off, last_crc); `out` as in wire_encode"""
         r = np.ascontiguousarray(recs, dtype=WAL_REC_DT)
         p = _u8(pool)
-        off = np.zeros(len(r) + 1, np.uint64)
+        if off is None:
+            off = np.zeros(len(r) + 1, np.uint64)
         c = _lib.WalCounts()
         args = (self._h, _p(r), len(r), _p(p), len(p), int(prev_crc))
+        if out is not None:
+            self._chk(self._lib.raftq_wal_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
+            return out[: int(c.bytes)], off, int(c.last_crc)
         rc = self._lib.raftq_wal_encode(*args, None, 0, _ptr(off), C.byref(c))
         if rc == 0:
             return np.zeros(0, np.uint8), off, int(c.last_crc)
@@ -137,12 +154,13 @@ class WireEngine(NodeEngine):
         self._chk(self._lib.raftq_wal_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
         return out, off, int(c.last_crc)
 
-    def wal_decode(self, data, frame_off, prev_crc: int = 0):
+    def wal_decode(self, data, frame_off, prev_crc: int = 0, recs: np.ndarray | None = None):
         """w.ReadAll for a batch -> (recs, n_valid, last_crc)"""
         b = _u8(data)
         off = np.ascontiguousarray(frame_off, np.uint64)
         n = len(off) - 1
-        recs = np.zeros(n, WAL_REC_DT)
+        if recs is None:
+            recs = np.zeros(n, WAL_REC_DT)
         c = _lib.WalCounts()
         self._chk(self._lib.raftq_wal_decode(self._h, _p(b), len(b), _ptr(off), n, int(prev_crc), _p(recs), C.byref(c)))
-        return recs, int(c.n_valid), int(c.last_crc)
+        return recs[:n], int(c.n_valid), int(c.last_crc)

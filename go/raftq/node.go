@@ -51,6 +51,45 @@ type MultiRaftPipe struct {
 	peers  uint32
 	stopc  chan struct{}
 	donec  chan error
+	Wal    WalFile // nil: no WAL is written (what the node would have saved is only counted)
+}
+
+// WalFile is where the node's WAL bytes go: the open segment file (*os.File satisfies it).
+type WalFile interface {
+	Write(p []byte) (int, error)
+	Sync() error
+}
+
+// NewMultiRaftPipeFromWAL is NewMultiRaftPipe for a restart: walBytes is the content of the WAL
+// segment (replayWAL, raft.go:122-134 -- w.ReadAll with every CRC checked on the GPU); the node keeps
+// appending to `segment` on the same CRC chain.  restoreHardState=false is the reference's behaviour.
+func NewMultiRaftPipeFromWAL(device, id, nPeers int, nGroups uint64, walBytes []byte, restoreHardState bool, segment WalFile, tr Transport) (*MultiRaftPipe, error) {
+	var n *C.raftq_node_t
+	if rc := C.raftq_node_create(C.int(device), C.uint64_t(nGroups), C.uint32_t(nPeers), C.uint32_t(id-1), &n); rc != C.RAFTQ_OK {
+		return nil, fmt.Errorf("raftq_node_create: %d: %s", int(rc), C.GoString(C.raftq_last_error(nil)))
+	}
+	m := &MultiRaftPipe{n: n, peers: uint32(nPeers), stopc: make(chan struct{}), donec: make(chan error, 1), Wal: segment}
+	restore := C.int(0)
+	if restoreHardState {
+		restore = 1
+	}
+	if len(walBytes) > 0 {
+		if rc := C.raftq_node_replay_wal(n, unsafe.Pointer(&walBytes[0]), C.uint64_t(len(walBytes)), restore, nil); rc != C.RAFTQ_OK {
+			return nil, nodeErr(n, rc) // the reference: log.Fatalf("raftsql: failed to read WAL (%v)", err) (raft.go:126)
+		}
+	}
+	if segment != nil {
+		C.raftq_node_wal_enable(n)
+	}
+	if rc := C.raftq_node_start(n, 10, 1, C.uint64_t(0x1000+id)); rc != C.RAFTQ_OK {
+		return nil, nodeErr(n, rc)
+	}
+	m.Groups = make([]*RaftPipe, nGroups)
+	for g := range m.Groups {
+		m.Groups[g] = m.pipeFor(uint64(g))
+	}
+	go m.run(tr)
+	return m, nil
 }
 
 func nodeErr(n *C.raftq_node_t, rc C.int) error {
@@ -175,6 +214,26 @@ func (m *MultiRaftPipe) run(tr Transport) {
 			m.donec <- nodeErr(m.n, rc) // writeError (raft.go:136-142): channels are closed by the node
 			return
 		}
+		// rc.wal.Save(rd.HardState, rd.Entries) (raft.go:228) for every group at once: the node hands out
+		// walpb.Record frames (raftq_node_wal_enable); they are on disk before anything is sent
+		if m.Wal != nil {
+			for {
+				var ln C.uint64_t
+				if rc := C.raftq_node_wal_poll(m.n, unsafe.Pointer(&wire[0]), C.uint64_t(len(wire)), &ln); rc != C.RAFTQ_OK || ln == 0 {
+					break
+				}
+				if _, err := m.Wal.Write(wire[:ln]); err != nil {
+					m.donec <- err
+					return
+				}
+			}
+			if err := m.Wal.Sync(); err != nil {
+				m.donec <- err
+				return
+			}
+		}
+		// rafthttp message-stream frames (u64 big-endian length | raftpb.Message): tr.Send writes them to
+		// the peer's stream as they are
 		for p := uint32(0); p < m.peers; p++ { // rc.transport.Send(rd.Messages) (raft.go:230)
 			for {
 				var ln C.uint64_t

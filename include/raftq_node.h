@@ -32,8 +32,20 @@
  *
  * Transport is the caller's (the reference uses rafthttp, raft.go:170-186):
  * raftq_node_poll(n, to, ...) hands out the bytes addressed to peer `to`,
- * raftq_node_deliver() takes bytes a peer polled for this node.  The byte
- * format is this library's own framing of raftq_msg_t (below), NOT raftpb.
+ * raftq_node_deliver() takes bytes a peer polled for this node.  The bytes
+ * are rafthttp message-stream frames -- u64 big-endian length | raftpb.Message,
+ * what rc.transport.Send(rd.Messages) puts on a stream (raft.go:230; format
+ * and the one `group` extension field in raftq_wire.h) -- marshalled and
+ * unmarshalled for all groups at once by the GPU codecs, one
+ * raftq_wire_encode / raftq_wire_decode per raftq_node_advance().
+ *
+ * WAL (opt-in, raftq_node_wal_enable): every advance() also produces what
+ * rc.wal.Save(rd.HardState, rd.Entries) (raft.go:228) would have appended --
+ * walpb.Record frames with the segment's CRC-32C chain, every touched group's
+ * entries and HardState in one raftq_wal_encode -- for the caller to write and
+ * fsync BEFORE it transmits that turn's raftq_node_poll bytes (the reference's
+ * save-then-send order, raft.go:228-230).  raftq_node_replay_wal() is
+ * replayWAL (raft.go:122-134) from such bytes.
  *
  * Not built (same as raftq_step.h): snapshots / log compaction, conf changes,
  * the inflight window.  The log lives in host memory, like the reference's
@@ -61,11 +73,11 @@ typedef struct raftq_node raftq_node_t;
 #define RAFTQ_NODE_CLOSED 2   /* commit channel closed */
 #define RAFTQ_NODE_TIMEOUT 3  /* nothing within timeout_ms */
 
-/* Wire frame (little endian), what raftq_node_poll emits and raftq_node_deliver parses:
- *   raftq_msg_t header (64 B): type = raftpb.MessageType (RAFTQ_MSG_* plus MsgProp = 2),
- *       from = sender's peer slot, _resv = number of entries that follow
- *   per entry: u64 term | u32 len | u32 0 | payload | zero padding to a multiple of 8
- * MsgApp: index / log_term = the entry preceding the first one carried, commit = leader's commit. */
+/* On the wire: raftpb.Message frames (raftq_wire.h).  type = raftpb.MessageType (RAFTQ_MSG_* plus
+ * MsgProp = 2, a follower forwarding a proposal to its leader); to / from = raft IDs (peer slot + 1).
+ * MsgApp: index / logTerm = the entry preceding the first one carried, commit = leader's commit;
+ * entries carry their own Index and Term.  Frames that do not parse, are not addressed to this node,
+ * or are of a kind a peer never sends (MsgHup, MsgBeat, MsgSnap, unknown) are dropped and counted. */
 #define RAFTQ_MSG_PROP 2
 
 typedef struct raftq_node_status {
@@ -83,6 +95,8 @@ typedef struct raftq_node_stats {
   uint64_t entries_published;
   uint64_t hard_states;      /* HardState changes that a WAL would have had to persist (raft.go:228) */
   uint64_t proposals_dropped; /* proposals that met a group with no leader (etcd drops them) */
+  uint64_t frames_dropped;    /* inbound frames that did not parse / were not for this node */
+  uint64_t wal_records;       /* walpb.Records produced (raftq_node_wal_enable) */
 } raftq_node_stats_t;
 
 int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t self_peer, raftq_node_t** out);
@@ -91,6 +105,14 @@ int raftq_node_replay(raftq_node_t* n, uint64_t group, const uint64_t* terms, co
                       const uint32_t* lens, uint64_t count);
 /* before start, optional: restore HardState (the reference does not) */
 int raftq_node_set_hard_state(raftq_node_t* n, uint64_t group, uint64_t term, uint32_t vote, uint64_t commit);
+/* before start: replayWAL (raft.go:122-134) from WAL bytes as raftq_node_wal_poll produced them (whole
+ * frames; a torn tail is ignored).  Every record's CRC is checked against the chain: a mismatch or a
+ * record that does not parse is RAFTQ_EINVAL (the reference log.Fatalf's, raft.go:126).  Entries go to
+ * their groups' logs; HardState records are restored only if restore_hard_state != 0 (the reference
+ * discards them).  A node replayed this way keeps appending to the same CRC chain. */
+int raftq_node_replay_wal(raftq_node_t* n, const void* wal, uint64_t len, int restore_hard_state, uint64_t* n_records);
+/* before start: produce WAL bytes from now on (see above) */
+int raftq_node_wal_enable(raftq_node_t* n);
 /* raft.Config{ElectionTick, HeartbeatTick} (raft.go:154-155: 10, 1) + seed of the randomised timeout */
 int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed);
 
@@ -101,6 +123,9 @@ int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len);
 int raftq_node_advance(raftq_node_t* n, uint64_t* n_published);
 /* whole frames addressed to `to_peer`, at most cap bytes; *len = bytes written (0 = nothing queued) */
 int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, uint64_t* len);
+
+/* whole WAL frames produced so far, at most cap bytes; *len = bytes written (0 = nothing pending) */
+int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len);
 
 int raftq_node_recv(raftq_node_t* n, uint64_t group, int timeout_ms, void* buf, uint32_t cap, uint32_t* len,
                     int* kind);

@@ -8,6 +8,8 @@
 // It computes no quorum, no vote tally and no commit index.
 #include "raftq_node.h"
 
+#include "raftq_wire.h"
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -45,6 +47,17 @@ struct Group {
   size_t qhead = 0;
   uint64_t hs_term = 0, hs_commit = 0;  // raftq_node_set_hard_state
   uint32_t hs_vote = 0;
+  // WAL bookkeeping (raftq_node_wal_enable): what wal.Save has been handed so far
+  uint64_t wal_upto = 0;                 // entries [1, wal_upto] are in the WAL as they stand in `log`
+  uint64_t wal_term = 0, wal_commit = 0;  // the last HardState record written
+  uint32_t wal_vote = 0;
+  bool wal_dirty = false;
+};
+
+// frames queued for one peer: rafthttp stream frames (u64 big-endian length | raftpb.Message), back to back
+struct PeerQueue {
+  std::string bytes;
+  size_t head = 0;  // bytes before `head` were polled
 };
 
 constexpr uint64_t kMaxEntriesPerMsg = 1024;     // with kMaxBytesPerMsg: raft.Config.MaxSizePerMsg (raft.go:157)
@@ -57,12 +70,23 @@ struct raftq_node {
   uint64_t G = 0;
   uint32_t N = 0, self = 0;
   std::vector<Group> groups;
-  std::mutex mu;  // guards inbound / proposals / pending_ticks / outbound / commit channels / status
+  std::mutex mu;  // guards in_bytes / proposals / pending_ticks / outbound / commit channels / status
   std::condition_variable cv_commit;
-  std::vector<InMsg> inbound;
   std::vector<std::pair<uint64_t, std::string>> proposals;
   uint32_t pending_ticks = 0;
-  std::vector<std::vector<std::string>> outbound;  // [peer] -> frames
+  std::vector<PeerQueue> outbound;  // [peer]
+  // inbound stream frames as delivered (decoded on the GPU at the next advance)
+  std::string in_bytes;
+  std::vector<uint64_t> in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size()]
+  // this turn's outbound messages, marshalled in one raftq_wire_encode at the end of advance()
+  std::vector<raftq_wire_msg_t> out_msgs;
+  std::vector<raftq_wire_ent_t> out_ents;
+  std::string out_pool;
+  // WAL (off unless raftq_node_wal_enable): encoded records waiting for raftq_node_wal_poll
+  bool wal_on = false, wal_head_written = false;
+  uint32_t wal_crc = 0;
+  PeerQueue wal_out;
+  std::vector<uint64_t> wal_dirty;  // groups touched this turn
   bool started = false, closed = false;
   int error = 0;
   std::string errtext;
@@ -101,25 +125,43 @@ uint64_t term_at(const Group& g, uint64_t index) {
   return (index == 0 || index > g.log.size()) ? 0 : g.log[index - 1].term;
 }
 
+// r.send(m): queue one raftpb.Message for peer `to`.  Nothing is marshalled here -- the headers, entry
+// ranges and payload bytes of the whole turn go through one raftq_wire_encode at the end of advance().
+// Entries carry explicit indices on the wire: hdr.index + 1 + k for MsgApp, 0 for a forwarded MsgProp.
 void put_frame(raftq_node_t* n, uint32_t to, const raftq_msg_t& hdr, const Entry* ents, size_t n_ents) {
-  std::string f;
-  size_t bytes = sizeof(raftq_msg_t);
-  for (size_t i = 0; i < n_ents; ++i) bytes += 16 + (ents[i].data.size() + 7) / 8 * 8;
-  f.reserve(bytes);
-  raftq_msg_t h = hdr;
-  h._resv = n_ents;
-  f.append((const char*)&h, sizeof(h));
+  raftq_wire_msg_t m;
+  std::memset(&m, 0, sizeof(m));
+  m.group = hdr.group;
+  m.term = hdr.term;
+  m.log_term = hdr.log_term;
+  m.index = hdr.index;
+  m.commit = hdr.commit;
+  m.reject_hint = hdr.reject_hint;
+  m.from = hdr.from;
+  m.type = hdr.type;
+  m.reject = hdr.reject;
+  m.to = (uint8_t)to;
+  m.ent_first = n_ents ? (uint32_t)n->out_ents.size() : 0;
+  m.n_ents = (uint32_t)n_ents;
   for (size_t i = 0; i < n_ents; ++i) {
-    const uint64_t term = ents[i].term;
-    const uint32_t len = (uint32_t)ents[i].data.size(), zero = 0;
-    f.append((const char*)&term, 8);
-    f.append((const char*)&len, 4);
-    f.append((const char*)&zero, 4);
-    f.append(ents[i].data);
-    f.append((8 - len % 8) % 8, '\0');
+    raftq_wire_ent_t e;
+    std::memset(&e, 0, sizeof(e));
+    e.term = ents[i].term;
+    e.index = hdr.type == RAFTQ_MSG_APP ? hdr.index + 1 + i : 0;
+    e.data_len = (uint32_t)ents[i].data.size();
+    e.data_off = e.data_len ? n->out_pool.size() : 0;
+    n->out_pool.append(ents[i].data);
+    n->out_ents.push_back(e);
   }
-  n->outbound[to].push_back(std::move(f));
+  n->out_msgs.push_back(m);
   n->stats.msgs_sent++;
+}
+
+void wal_touch(raftq_node_t* n, uint64_t gi, Group& g) {
+  if (n->wal_on && !g.wal_dirty) {
+    g.wal_dirty = true;
+    n->wal_dirty.push_back(gi);
+  }
 }
 
 raftq_msg_t header(const raftq_node_t* n, uint64_t group, uint8_t type, uint64_t term) {
@@ -149,6 +191,7 @@ void note_commit(raftq_node_t* n, Group& g, uint64_t commit) {
   if (commit > g.committed) {
     g.committed = commit;
     publish(n, g, commit);
+    if (n->wal_on) wal_touch(n, (uint64_t)(&g - n->groups.data()), g);  // HardState.Commit moved
   }
 }
 
@@ -191,6 +234,7 @@ void bcast_heartbeat(raftq_node_t* n, uint64_t gi, Group& g) {
 bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, std::vector<Entry>& ents) {
   if (g.role == RAFTQ_ROLE_LEADER) {
     for (Entry& e : ents) g.log.push_back(Entry{g.term, std::move(e.data)});
+    if (!ents.empty()) wal_touch(n, gi, g);
     return !ents.empty();
   }
   if (g.lead != 0 && g.lead - 1 != n->self) {  // stepFollower MsgProp: `m.To = r.lead; r.send(m)`
@@ -218,10 +262,12 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vec
       if (idx > g.log.size()) break;
       if (g.log[idx - 1].term != im.ents[k].term) {
         g.log.resize(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
+        g.wal_upto = std::min<uint64_t>(g.wal_upto, idx - 1);  // the WAL gets the replacement entries again
         break;
       }
     }
     for (; k < im.ents.size(); ++k) g.log.push_back(std::move(im.ents[k]));
+    wal_touch(n, gi, g);
     const uint64_t lastnewi = m.index + im.ents.size();
     r.index = lastnewi;
     put_frame(n, m.from, r, nullptr, 0);
@@ -262,7 +308,10 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
   g.lead = o.lead;
   g.vote = o.vote;
   g.role = o.role;
-  if (o.flags & RAFTQ_OUTF_HARDSTATE) n->stats.hard_states++;  // wal.Save(rd.HardState, ...) (raft.go:228)
+  if (o.flags & RAFTQ_OUTF_HARDSTATE) {
+    n->stats.hard_states++;  // wal.Save(rd.HardState, ...) (raft.go:228)
+    wal_touch(n, gi, g);
+  }
   if (o.flags & RAFTQ_OUTF_STEPPED_DOWN) {
     g.next.clear();
     g.match.clear();
@@ -292,7 +341,9 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
     case RAFTQ_OUT_BECAME_LEADER:
       // becomeLeader's appendEntry(pb.Entry{Data: nil}): the engine already counted it
       g.log.resize(std::min<uint64_t>(g.log.size(), o.index - 1));
+      g.wal_upto = std::min<uint64_t>(g.wal_upto, g.log.size());
       g.log.push_back(Entry{o.term, std::string()});
+      wal_touch(n, gi, g);
       g.next.assign(n->N, o.index);  // reset(): Next = lastIndex + 1 (before the empty entry)
       g.match.assign(n->N, 0);
       g.match[n->self] = o.index;
@@ -326,6 +377,141 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
     default:
       break;
   }
+}
+
+uint64_t load_len(const uint8_t* p, bool big_endian) {
+  uint64_t v;
+  std::memcpy(&v, p, 8);
+  return big_endian ? __builtin_bswap64(v) : v;
+}
+
+// hand out whole frames of q, at most cap bytes
+int poll_queue(raftq_node_t* n, PeerQueue& q, bool big_endian, void* buf, uint64_t cap, uint64_t* len) {
+  const uint64_t avail = q.bytes.size() - q.head;
+  const uint8_t* p = (const uint8_t*)q.bytes.data() + q.head;
+  uint64_t pos = 0;
+  while (avail - pos >= 8) {
+    const uint64_t body = load_len(p + pos, big_endian);
+    if (body > avail - pos - 8 || 8 + body > cap - pos) break;
+    pos += 8 + body;
+  }
+  if (pos) std::memcpy(buf, p, pos);
+  q.head += pos;
+  if (q.head == q.bytes.size()) {
+    q.bytes.clear();
+    q.head = 0;
+  }
+  *len = pos;
+  if (pos == 0 && avail != 0) {
+    n->errtext = "poll: buffer smaller than the next frame";
+    return RAFTQ_EINVAL;
+  }
+  return RAFTQ_OK;
+}
+
+// rc.transport.Send(rd.Messages) (raft.go:230) for the whole turn: one batched marshal on the GPU, then
+// every peer's slice of the stream goes onto its queue.  Lock convention as flush_deltas.
+int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+  const size_t nm = n->out_msgs.size();
+  if (nm == 0) return RAFTQ_OK;
+  // stable counting sort by addressee: per-peer order is the order of the sends
+  std::vector<uint64_t> first(n->N + 1, 0);
+  for (const raftq_wire_msg_t& m : n->out_msgs) first[m.to + 1]++;
+  for (uint32_t p = 0; p < n->N; ++p) first[p + 1] += first[p];
+  std::vector<raftq_wire_msg_t> sorted(nm);
+  {
+    std::vector<uint64_t> at(first.begin(), first.end() - 1);
+    for (const raftq_wire_msg_t& m : n->out_msgs) sorted[at[m.to]++] = m;
+  }
+  std::vector<raftq_wire_ent_t> ents;
+  std::string pool;
+  ents.swap(n->out_ents);
+  pool.swap(n->out_pool);
+  n->out_msgs.clear();
+  const uint64_t cap = (uint64_t)nm * 160 + (uint64_t)ents.size() * 48 + pool.size();
+  std::string out((size_t)cap, '\0');
+  std::vector<uint64_t> off(nm + 1);
+  raftq_wire_counts_t cnt;
+  lk.unlock();
+  const int rc = raftq_wire_encode(n->h, sorted.data(), nm, ents.data(), ents.size(), pool.data(), pool.size(), &out[0], cap,
+                                   off.data(), &cnt);
+  if (rc != RAFTQ_OK) return rc;
+  lk.lock();
+  for (uint32_t p = 0; p < n->N; ++p)
+    if (first[p + 1] > first[p])
+      n->outbound[p].bytes.append(out, (size_t)off[first[p]], (size_t)(off[first[p + 1]] - off[first[p]]));
+  return RAFTQ_OK;
+}
+
+// rc.wal.Save(rd.HardState, rd.Entries) (raft.go:228) for every group this turn touched: per group its new
+// entries, then its HardState if it changed (wal.Save's order), groups ascending; one batched encode with
+// the segment's running CRC carried across turns.  The first call also writes what wal.Create writes at
+// the head of a file: the crc record, the (empty) metadata, the empty snapshot.
+int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+  if (!n->wal_on || (n->wal_dirty.empty() && n->wal_head_written)) return RAFTQ_OK;
+  std::sort(n->wal_dirty.begin(), n->wal_dirty.end());
+  std::vector<raftq_wal_rec_t> recs;
+  std::string pool;
+  auto blank = [](uint8_t kind) {
+    raftq_wal_rec_t r;
+    std::memset(&r, 0, sizeof(r));
+    r.kind = kind;
+    return r;
+  };
+  if (!n->wal_head_written) {
+    recs.push_back(blank(RAFTQ_WAL_CRC));
+    recs.push_back(blank(RAFTQ_WAL_METADATA));
+    recs.push_back(blank(RAFTQ_WAL_SNAPSHOT));
+  }
+  for (uint64_t gi : n->wal_dirty) {
+    Group& g = n->groups[gi];
+    g.wal_dirty = false;
+    for (uint64_t idx = g.wal_upto + 1; idx <= g.log.size(); ++idx) {
+      const Entry& e = g.log[idx - 1];
+      raftq_wal_rec_t r = blank(RAFTQ_WAL_ENTRY);
+      r.group = gi;
+      r.term = e.term;
+      r.index = idx;
+      r.data_len = (uint32_t)e.data.size();
+      r.data_off = r.data_len ? pool.size() : 0;
+      pool.append(e.data);
+      recs.push_back(r);
+    }
+    g.wal_upto = g.log.size();
+    const bool empty_hs = g.term == 0 && g.vote == 0 && g.committed == 0;  // `if !raft.IsEmptyHardState(st)`
+    if (!empty_hs && (g.term != g.wal_term || g.vote != g.wal_vote || g.committed != g.wal_commit)) {
+      raftq_wal_rec_t r = blank(RAFTQ_WAL_STATE);
+      r.group = gi;
+      r.term = g.wal_term = g.term;
+      r.vote = g.wal_vote = g.vote;  // raft IDs are 1-based peer positions (raft.go:148-151); 0 = None
+      r.index = g.wal_commit = g.committed;
+      recs.push_back(r);
+    }
+  }
+  n->wal_dirty.clear();
+  if (recs.empty()) return RAFTQ_OK;
+  const uint64_t cap = (uint64_t)recs.size() * 80 + pool.size();
+  std::string out((size_t)cap, '\0');
+  raftq_wal_counts_t cnt;
+  const uint32_t prev = n->wal_crc;
+  lk.unlock();
+  const int rc = raftq_wal_encode(n->h, recs.data(), recs.size(), pool.data(), pool.size(), prev, &out[0], cap, nullptr, &cnt);
+  if (rc != RAFTQ_OK) return rc;
+  lk.lock();
+  n->wal_out.bytes.append(out, 0, (size_t)cnt.bytes);
+  n->wal_crc = cnt.last_crc;
+  n->wal_head_written = true;
+  n->stats.wal_records += recs.size();
+  return RAFTQ_OK;
+}
+
+// one entry into a group's log under the WAL's rule (wal.ReadAll: a later entry with an index already
+// seen replaces it and everything after it)
+bool log_put(Group& g, uint64_t index, uint64_t term, const char* data, uint32_t len) {
+  if (index == 0 || index > g.log.size() + 1) return false;
+  if (index <= g.log.size()) g.log.resize(index - 1);
+  g.log.push_back(Entry{term, std::string(data, len)});
+  return true;
 }
 
 }  // namespace
@@ -473,38 +659,27 @@ int raftq_node_tick(raftq_node_t* n) {
 int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len) {
   if (!n) return RAFTQ_EINVAL;
   if (len && !frames) return nfail(n, RAFTQ_EINVAL, "deliver: null buffer");
-  std::vector<InMsg> parsed;
-  const uint8_t* p = (const uint8_t*)frames;
-  uint64_t off = 0;
-  while (off < len) {
-    if (len - off < sizeof(raftq_msg_t)) return nfail(n, RAFTQ_EINVAL, "deliver: truncated frame header");
-    InMsg im;
-    std::memcpy(&im.h, p + off, sizeof(raftq_msg_t));
-    off += sizeof(raftq_msg_t);
-    const uint64_t n_ents = im.h._resv;
-    if (im.h.group >= n->G || im.h.from >= n->N || n_ents > (len - off) / 16)
-      return nfail(n, RAFTQ_EINVAL, "deliver: malformed frame (group / from / entry count)");
-    for (uint64_t i = 0; i < n_ents; ++i) {
-      if (len - off < 16) return nfail(n, RAFTQ_EINVAL, "deliver: truncated entry header");
-      uint64_t term;
-      uint32_t l;
-      std::memcpy(&term, p + off, 8);
-      std::memcpy(&l, p + off + 8, 4);
-      off += 16;
-      const uint64_t padded = ((uint64_t)l + 7) / 8 * 8;
-      if (len - off < padded) return nfail(n, RAFTQ_EINVAL, "deliver: truncated entry payload");
-      im.ents.push_back(Entry{term, std::string((const char*)p + off, l)});
-      off += padded;
-    }
-    im.h._resv = 0;
-    parsed.push_back(std::move(im));
+  if (len == 0) return RAFTQ_OK;
+  // the stream reader's part of messageDecoder.decode: the length words must tile the buffer.  The
+  // messages themselves are unmarshalled on the GPU, all of this turn's at once, by the next advance().
+  std::vector<uint64_t> off;
+  try {
+    off.resize((size_t)(len / 8) + 2);
+  } catch (...) {
+    return nfail(n, RAFTQ_ENOMEM, "deliver: host allocation failed");
   }
+  uint64_t nf = 0, used = 0;
+  raftq_wire_scan_frames(frames, len, 1, off.data(), off.size() - 1, &nf, &used);
+  if (used != len) return nfail(n, RAFTQ_EINVAL, "deliver: not a whole number of stream frames (truncated or garbage)");
   std::lock_guard<std::mutex> lk(n->mu);
   if (!n->started || n->closed) {
     n->errtext = "deliver: node not running";
     return RAFTQ_ESTATE;
   }
-  for (InMsg& im : parsed) n->inbound.push_back(std::move(im));
+  const uint64_t base = n->in_bytes.size();
+  n->in_bytes.append((const char*)frames, (size_t)len);
+  if (n->in_off.empty()) n->in_off.push_back(0);
+  for (uint64_t i = 1; i <= nf; ++i) n->in_off.push_back(base + off[i]);
   return RAFTQ_OK;
 }
 
@@ -513,21 +688,69 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   std::lock_guard<std::mutex> turn(n->turn_mu);
   std::vector<InMsg> work;
   std::vector<std::pair<uint64_t, std::string>> props;
+  std::string in_bytes;
+  std::vector<uint64_t> in_off;
   uint32_t ticks = 0;
   {
     std::lock_guard<std::mutex> lk(n->mu);
     if (!n->started) return RAFTQ_ESTATE;
     if (n->error) return n->error;
-    work.swap(n->inbound);
+    in_bytes.swap(n->in_bytes);
+    in_off.swap(n->in_off);
     props.swap(n->proposals);
     ticks = n->pending_ticks;
     n->pending_ticks = 0;
+  }
+  // -- rafthttp's messageDecoder + Message.Unmarshal for everything received since the last turn, on
+  // the GPU (raftq_wire_decode).  Frames that do not parse, are not addressed to this node's slot, come
+  // from no peer of the cluster or are of a kind a peer never sends are dropped and counted -- rafthttp
+  // would log and drop the stream; a raft node must survive any bytes a peer throws at it.
+  uint64_t dropped = 0;
+  if (in_off.size() > 1) {
+    const uint64_t nf = in_off.size() - 1;
+    std::vector<raftq_wire_msg_t> wm(nf);
+    std::vector<raftq_wire_ent_t> we(nf + 16);
+    raftq_wire_counts_t cnt;
+    int rc = raftq_wire_decode(n->h, in_bytes.data(), in_bytes.size(), in_off.data(), nf, wm.data(), we.data(), we.size(), &cnt);
+    if (rc == RAFTQ_EINVAL && cnt.n_ents > we.size()) {
+      we.resize(cnt.n_ents);
+      rc = raftq_wire_decode(n->h, in_bytes.data(), in_bytes.size(), in_off.data(), nf, wm.data(), we.data(), we.size(), &cnt);
+    }
+    if (rc != RAFTQ_OK) return poison(n, rc, "wire_decode");
+    for (uint64_t i = 0; i < nf; ++i) {
+      const raftq_wire_msg_t& m = wm[i];
+      const bool kind_ok = m.type == RAFTQ_MSG_PROP || m.type == RAFTQ_MSG_APP || m.type == RAFTQ_MSG_APP_RESP ||
+                           m.type == RAFTQ_MSG_VOTE || m.type == RAFTQ_MSG_VOTE_RESP || m.type == RAFTQ_MSG_HEARTBEAT ||
+                           m.type == RAFTQ_MSG_HEARTBEAT_RESP;
+      if ((m.flags & RAFTQ_WIRE_F_MALFORMED) || !kind_ok || m.group >= n->G || m.from >= n->N || m.to != n->self) {
+        ++dropped;
+        continue;
+      }
+      InMsg im;
+      std::memset(&im.h, 0, sizeof(im.h));
+      im.h.group = m.group;
+      im.h.term = m.term;
+      im.h.log_term = m.log_term;
+      im.h.index = m.index;
+      im.h.commit = m.commit;
+      im.h.reject_hint = m.reject_hint;
+      im.h.from = m.from;
+      im.h.type = m.type;
+      im.h.reject = m.reject;
+      im.ents.reserve(m.n_ents);
+      for (uint32_t k = 0; k < m.n_ents; ++k) {
+        const raftq_wire_ent_t& e = we[m.ent_first + k];
+        im.ents.push_back(Entry{e.term, std::string(in_bytes.data() + e.data_off, e.data_len)});
+      }
+      work.push_back(std::move(im));
+    }
   }
   // The commit channels, the status mirror and the outbound queues are only written below, under
   // mu, one short critical section per phase.
   std::unique_lock<std::mutex> lk(n->mu);
   const uint64_t published0 = n->stats.entries_published;
-  bool did = !work.empty() || !props.empty() || ticks != 0;
+  n->stats.frames_dropped += dropped;
+  bool did = !work.empty() || !props.empty() || ticks != 0 || dropped != 0;
 
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
@@ -631,6 +854,10 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     if (int rc = flush_deltas(n, lk)) return poison(n, rc, "apply_log_deltas");
     for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
   }
+  // -- wal.Save before transport.Send (raft.go:228-230): the caller persists what raftq_node_wal_poll
+  // hands out before it transmits what raftq_node_poll hands out
+  if (int rc = flush_wal(n, lk)) return poison(n, rc, "wal_encode");
+  if (int rc = flush_outbound(n, lk)) return poison(n, rc, "wire_encode");
   if (did) n->stats.turns++;
   const uint64_t pub = n->stats.entries_published - published0;
   lk.unlock();
@@ -645,20 +872,91 @@ int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, 
   if (to_peer >= n->N) return nfail(n, RAFTQ_EINVAL, "poll: peer out of range");
   if (cap && !buf) return nfail(n, RAFTQ_EINVAL, "poll: null buffer");
   std::lock_guard<std::mutex> lk(n->mu);
-  auto& q = n->outbound[to_peer];
-  size_t taken = 0;
-  uint64_t off = 0;
-  while (taken < q.size() && off + q[taken].size() <= cap) {
-    std::memcpy((uint8_t*)buf + off, q[taken].data(), q[taken].size());
-    off += q[taken].size();
-    ++taken;
+  return poll_queue(n, n->outbound[to_peer], true, buf, cap, len);
+}
+
+int raftq_node_wal_enable(raftq_node_t* n) {
+  if (!n) return RAFTQ_EINVAL;
+  std::lock_guard<std::mutex> lk(n->mu);
+  if (n->started) {
+    n->errtext = "wal_enable: node already started";
+    return RAFTQ_ESTATE;
   }
-  q.erase(q.begin(), q.begin() + taken);
-  *len = off;
-  if (taken == 0 && !q.empty()) {
-    n->errtext = "poll: buffer smaller than the next frame";
-    return RAFTQ_EINVAL;
+  n->wal_on = true;
+  return RAFTQ_OK;
+}
+
+int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len) {
+  if (!n || !len) return RAFTQ_EINVAL;
+  *len = 0;
+  if (cap && !buf) return nfail(n, RAFTQ_EINVAL, "wal_poll: null buffer");
+  std::lock_guard<std::mutex> lk(n->mu);
+  return poll_queue(n, n->wal_out, false, buf, cap, len);
+}
+
+int raftq_node_replay_wal(raftq_node_t* n, const void* wal, uint64_t len, int restore_hard_state, uint64_t* n_records) {
+  if (!n) return RAFTQ_EINVAL;
+  if (n_records) *n_records = 0;
+  if (len && !wal) return nfail(n, RAFTQ_EINVAL, "replay_wal: null buffer");
+  {
+    std::lock_guard<std::mutex> lk(n->mu);
+    if (n->started) {
+      n->errtext = "replay_wal: node already started";
+      return RAFTQ_ESTATE;
+    }
   }
+  if (len == 0) return RAFTQ_OK;
+  // w.ReadAll() (raft.go:124): the frames that are whole (a torn tail is a crash in mid-append: ignored,
+  // as wal.ReadAll tolerates io.ErrUnexpectedEOF on the last file), every record parsed and its CRC checked
+  // against the chain on the GPU
+  std::vector<uint64_t> off;
+  std::vector<raftq_wal_rec_t> recs;
+  uint64_t nf = 0, used = 0;
+  try {
+    off.resize((size_t)(len / 8) + 2);
+    raftq_wire_scan_frames(wal, len, 0, off.data(), off.size() - 1, &nf, &used);
+    recs.resize((size_t)nf);
+  } catch (...) {
+    return nfail(n, RAFTQ_ENOMEM, "replay_wal: host allocation failed");
+  }
+  if (nf == 0) return RAFTQ_OK;
+  raftq_wal_counts_t cnt;
+  const int rc = raftq_wal_decode(n->h, wal, used, off.data(), nf, 0, recs.data(), &cnt);
+  if (rc != RAFTQ_OK) return nfail(n, rc, std::string("replay_wal: ") + raftq_last_error(n->h));
+  if (cnt.n_valid != nf)  // the reference: log.Fatalf("raftsql: failed to read WAL (%v)", err) (raft.go:126)
+    return nfail(n, RAFTQ_EINVAL,
+                 "replay_wal: record " + std::to_string(cnt.n_valid) +
+                     ((recs[cnt.n_valid].flags & RAFTQ_WAL_F_MALFORMED) ? " does not parse" : " fails its CRC (wal.ErrCRCMismatch)"));
+  std::lock_guard<std::mutex> lk(n->mu);
+  const char* base = (const char*)wal;
+  for (uint64_t i = 0; i < nf; ++i) {
+    const raftq_wal_rec_t& r = recs[i];
+    if (r.kind == RAFTQ_WAL_ENTRY) {
+      if (r.group >= n->G || !log_put(n->groups[r.group], r.index, r.term, base + r.data_off, r.data_len)) {
+        n->errtext = "replay_wal: entry record " + std::to_string(i) + " has no place in its group's log";
+        return RAFTQ_EINVAL;
+      }
+    } else if (r.kind == RAFTQ_WAL_STATE) {
+      if (r.group >= n->G || r.vote > n->N) {
+        n->errtext = "replay_wal: state record " + std::to_string(i) + " out of range";
+        return RAFTQ_EINVAL;
+      }
+      Group& g = n->groups[r.group];
+      g.wal_term = r.term;
+      g.wal_vote = r.vote;
+      g.wal_commit = r.index;
+      if (restore_hard_state) {  // the reference does not: `_, _, ents, err := w.ReadAll()` (raft.go:124)
+        g.hs_term = r.term;
+        g.hs_vote = r.vote;
+        g.hs_commit = r.index;
+      }
+    }
+  }
+  for (Group& g : n->groups) g.wal_upto = g.log.size();
+  // appending continues this segment's chain
+  n->wal_crc = cnt.last_crc;
+  n->wal_head_written = true;
+  if (n_records) *n_records = nf;
   return RAFTQ_OK;
 }
 

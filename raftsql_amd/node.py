@@ -25,13 +25,16 @@ class Status(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("turns", "msgs_stepped", "msgs_sent", "entries_published", "hard_states",
-                                          "proposals_dropped")]
+                                          "proposals_dropped", "frames_dropped", "wal_records")]
 
 
 _SIGS = [
     ("raftq_node_create", C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("raftq_node_replay", C.c_int, [_P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("raftq_node_set_hard_state", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]),
+    ("raftq_node_replay_wal", C.c_int, [_P, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("raftq_node_wal_enable", C.c_int, [_P]),
+    ("raftq_node_wal_poll", C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_node_start", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("raftq_node_propose", C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32]),
     ("raftq_node_tick", C.c_int, [_P]),
@@ -94,6 +97,25 @@ class RaftNode:
         ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
         lens = (C.c_uint32 * n)(*[len(d) for _, d in ents])
         self._chk(self._lib.raftq_node_replay(self._p, group, terms, ptrs, lens, n))
+
+    def replay_wal(self, wal: bytes, restore_hard_state: bool = False) -> int:
+        """replayWAL (raft.go:122-134) from WAL bytes (raftq_node_wal_poll's); -> records read"""
+        k = C.c_uint64(0)
+        self._chk(self._lib.raftq_node_replay_wal(self._p, bytes(wal), len(wal), int(restore_hard_state), C.byref(k)))
+        return int(k.value)
+
+    def wal_enable(self) -> None:
+        self._chk(self._lib.raftq_node_wal_enable(self._p))
+
+    def wal_poll(self) -> bytes:
+        """the walpb.Record frames produced since the last call (persist before sending poll()'s bytes)"""
+        out = []
+        while True:
+            n = C.c_uint64(0)
+            self._chk(self._lib.raftq_node_wal_poll(self._p, self._wire, len(self._wire), C.byref(n)))
+            if n.value == 0:
+                return b"".join(out)
+            out.append(self._wire.raw[: n.value])
 
     def set_hard_state(self, group: int, term: int, vote: int, commit: int) -> None:
         self._chk(self._lib.raftq_node_set_hard_state(self._p, group, term, vote, commit))
@@ -201,9 +223,16 @@ class Cluster:
     nor receive (the reference's tests stop a node by closing it, raftsql_test.go:47-52);
     `cut` holds (a, b) pairs whose traffic is dropped in both directions."""
 
-    def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7):
+    def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7,
+                 wal: bool = False):
         self.G, self.N, self.device, self.election_tick, self.seed = n_groups, n_peers, device, election_tick, seed
         self.nodes: list[Optional[RaftNode]] = [RaftNode(n_groups, n_peers, p, device) for p in range(n_peers)]
+        # wal=True: every node produces its WAL (raftq_node_wal_enable); self.wal[p] is node p's "disk"
+        self.wal_on = wal
+        self.wal: list[bytearray] = [bytearray() for _ in range(n_peers)]
+        if wal:
+            for nd in self.nodes:
+                nd.wal_enable()
         self.down: set[int] = set()
         self.cut: set[tuple[int, int]] = set()
         self.loss = 0.0  # probability that one node-to-node transfer (a batch of frames) is lost
@@ -222,6 +251,8 @@ class Cluster:
             if tick:
                 nd.tick()
             published += nd.advance()
+            if self.wal_on:
+                self.wal[p] += nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
         for p, nd in enumerate(self.nodes):
             if p in self.down:
                 continue
@@ -285,6 +316,16 @@ class Cluster:
                 nd.replay(g, ents)
             if restore_hard_state:
                 nd.set_hard_state(g, *self.hard_states[p][g])
+        nd.start(self.election_tick, 1, seed=self.seed + 1000 * p + 17)
+        self.nodes[p] = nd
+        self.down.discard(p)
+        return nd
+
+    def restart_from_wal(self, p: int, restore_hard_state: bool = False, wal: Optional[bytes] = None) -> RaftNode:
+        """restart node p from its WAL bytes alone (replayWAL, raft.go:122-134); it keeps appending to them"""
+        nd = RaftNode(self.G, self.N, p, self.device)
+        nd.replay_wal(bytes(self.wal[p]) if wal is None else wal, restore_hard_state)
+        nd.wal_enable()
         nd.start(self.election_tick, 1, seed=self.seed + 1000 * p + 17)
         self.nodes[p] = nd
         self.down.discard(p)

@@ -297,3 +297,225 @@ def test_node_rejects_garbage_frames_and_bad_calls(Cluster):
         assert nd.recv(0)[0] in (1, 2)  # the sentinel is still queued, then CLOSED
     finally:
         c.close()
+
+
+# ---- the byte formats on the node's two outward faces (SURVEY 8f-4 wired into 8f-2) ----------------
+
+def _tap(c):
+    """wrap every node's poll() so that the frames crossing the transport are recorded"""
+    seen = []
+    for p, nd in enumerate(c.nodes):
+        orig = nd.poll
+
+        def poll(q, _orig=orig, _p=p):
+            b = _orig(q)
+            if b:
+                seen.append((_p, q, b))
+            return b
+
+        nd.poll = poll
+    return seen
+
+
+def test_node_speaks_raftpb_frames(Cluster):
+    """What leaves a node is what rc.transport.Send puts on a rafthttp stream (raft.go:230): u64
+    big-endian length | raftpb.Message.  The google.protobuf runtime parses every frame; sender,
+    addressee and group are right; a proposal travels as MsgApp entries with Index and Term set."""
+    from oracle import pywire as W
+    from tests import pbschema as P
+
+    c = Cluster(4, 3)
+    try:
+        seen = _tap(c)
+        c.start()
+        elect(c)
+        g = 3
+        lead = int(c.leaders()[g])
+        c.nodes[(lead + 1) % 3].propose(g, b"INSERT INTO t (v) VALUES (42)")  # forwarded: MsgProp on the wire
+        c.settle()
+        c.run(2)
+        c.settle()
+        for nd in c.nodes:
+            assert [d for d in nd.drain(g) if d is not None] == [b"INSERT INTO t (v) VALUES (42)"]
+        Msg = P.classes()["Message"]
+        kinds, app_entries, props = set(), [], []
+        for src, dst, blob in seen:
+            off, used = W.scan_frames(blob, big_endian=True)
+            assert used == len(blob) and len(off) > 1
+            mm, ee, bad = W.wire_decode(blob, off)
+            assert bad == 0
+            for i in range(len(off) - 1):
+                pm = Msg()
+                pm.ParseFromString(blob[int(off[i]) + 8:int(off[i + 1])])
+                assert getattr(pm, "from") == src + 1 and pm.to == dst + 1 and pm.group < c.G
+                assert (mm[i]["from"], mm[i]["to"], mm[i]["group"], mm[i]["type"]) == (src, dst, pm.group, pm.type)
+                assert pm.HasField("snapshot") and not pm.snapshot.data  # nullable=false: always there, empty
+                kinds.add(pm.type)
+                if pm.type == 3 and pm.group == g:
+                    for k, e in enumerate(pm.entries):
+                        assert e.Index == pm.index + 1 + k and e.Term >= 1
+                        app_entries.append(bytes(e.Data))
+                if pm.type == 2:
+                    props += [bytes(e.Data) for e in pm.entries]
+        assert {2, 3, 4, 5, 6, 8, 9} <= kinds, kinds  # MsgProp, MsgApp(+Resp), MsgVote(+Resp), MsgHeartbeat(+Resp)
+        assert props == [b"INSERT INTO t (v) VALUES (42)"]
+        assert b"INSERT INTO t (v) VALUES (42)" in app_entries and b"" in app_entries  # and the new leader's no-op
+        check_safety(c)
+    finally:
+        c.close()
+
+
+def test_node_drops_frames_that_are_not_for_it(Cluster):
+    """Well-framed bytes whose message does not parse, is addressed elsewhere, comes from no peer,
+    names no group or is of a kind a peer never sends are counted and dropped; the node lives on."""
+    from oracle import pywire as W
+
+    c = Cluster(2, 3)
+    try:
+        c.start()
+        elect(c)
+        nd = c.nodes[0]
+        m = np.zeros(6, W.WIRE_MSG_DT)
+        m["type"], m["term"], m["from"], m["to"] = 4, 1, 1, 0
+        m["to"][0] = 1  # for node 1
+        m["from"][1] = 7  # no such peer
+        m["group"][2] = 99  # no such group
+        m["type"][3] = 7  # MsgSnap
+        m["type"][4] = 0  # MsgHup from the wire
+        good, _ = W.wire_encode(m[5:6])  # a stale MsgAppResp: harmless, but it is stepped
+        bad, off = W.wire_encode(m[:5])
+        junk = (5).to_bytes(8, "big") + b"\x0b\x0b\x0b\x0b\x0b"  # framed, does not parse
+        before = nd.stats()
+        nd.deliver(bytes(bad) + junk + bytes(good))
+        nd.advance()
+        after = nd.stats()
+        assert after["frames_dropped"] - before["frames_dropped"] == 6
+        assert after["msgs_stepped"] - before["msgs_stepped"] == 1
+        c.nodes[int(c.leaders()[1])].propose(1, b"still alive")
+        c.settle()
+        c.run(2)
+        c.settle()
+        assert [d for d in nd.drain(1) if d is not None] == [b"still alive"]
+    finally:
+        c.close()
+
+
+def _wal_view(wal: bytes, G: int):
+    """what a WAL holds, by the oracle: per-group log (the later record of an index wins) and last HardState"""
+    from oracle import pywire as W
+
+    off, used = W.scan_frames(wal, big_endian=False)
+    assert used == len(wal)
+    recs, n_valid, last = W.wal_decode(wal, off, 0)
+    assert n_valid == len(recs), "the WAL's CRC chain must hold from its first byte"
+    logs = [[] for _ in range(G)]
+    hs = [None] * G
+    for r in recs:
+        g = int(r["group"])
+        if r["kind"] == W.WAL_ENTRY:
+            i = int(r["index"])
+            assert 1 <= i <= len(logs[g]) + 1
+            del logs[g][i - 1:]
+            a = int(r["data_off"])
+            logs[g].append((int(r["term"]), bytes(wal[a:a + int(r["data_len"])])))
+        elif r["kind"] == W.WAL_STATE:
+            hs[g] = (int(r["term"]), int(r["vote"]), int(r["index"]))
+    return recs, logs, hs
+
+
+def test_node_wal_is_a_valid_segment_and_restarts_the_node(Cluster):
+    """TestRestartDB with a real WAL: every node's WAL bytes are one valid segment (wal.Create's head,
+    then per turn every touched group's entries and HardState, one CRC-32C chain); they hold exactly the
+    node's logs and HardStates; a node restarted from those bytes alone replays exactly its statements,
+    then the nil sentinel, and keeps appending to the same chain."""
+    from oracle import pywire as W
+
+    G = 5
+    c = Cluster(G, 3, wal=True)
+    try:
+        c.start()
+        elect(c)
+        stmts = [b"CREATE TABLE t (id int primary key, v int)"] + [b"INSERT INTO t (v) VALUES (%d)" % i for i in range(3)]
+        for s in stmts:
+            for g in range(G):
+                c.nodes[int(c.leaders()[g])].propose(g, s + b" -- g%d" % g)
+            c.settle()
+        c.run(2)
+        c.settle()
+        for p, nd in enumerate(c.nodes):
+            recs, logs, hs = _wal_view(bytes(c.wal[p]), G)
+            assert list(recs["kind"][:3]) == [W.WAL_CRC, W.WAL_METADATA, W.WAL_SNAPSHOT]
+            assert nd.stats()["wal_records"] == len(recs)
+            for g in range(G):
+                st = nd.status(g)
+                assert logs[g] == nd.log(g), (p, g)
+                assert hs[g] == (st.term, st.vote, st.commit), (p, g, hs[g])
+        g = 1
+        victim = (int(c.leaders()[g]) + 1) % 3
+        for gg in range(G):
+            c.nodes[victim].drain(gg)
+        want_log = [c.nodes[victim].log(gg) for gg in range(G)]
+        c.stop(victim)
+        elect(c)
+        c.nodes[int(c.leaders()[g])].propose(g, b"INSERT INTO t (v) VALUES ('foo')")
+        c.settle()
+        before = len(c.wal[victim])
+        nd = c.restart_from_wal(victim)
+        for gg in range(G):
+            replayed = nd.drain(gg)
+            assert replayed[-1] is None and replayed[:-1] == [d for _, d in want_log[gg] if d]  # exactly its log, then nil
+            assert nd.log(gg) == want_log[gg] and nd.status(gg).term == 0  # HardState dropped, as the reference (F6)
+        c.run(5)
+        c.settle()
+        assert nd.drain(g) == [b"INSERT INTO t (v) VALUES ('foo')"]
+        assert len(c.wal[victim]) > before
+        _, logs, hs = _wal_view(bytes(c.wal[victim]), G)  # old bytes + what the restarted node appended: still one chain
+        for gg in range(G):
+            assert logs[gg] == nd.log(gg)
+        check_safety(c)
+        # restoring HardState instead (what a correct raft needs): term, vote and commit come back
+        c.stop(victim)
+        nd = c.restart_from_wal(victim, restore_hard_state=True)
+        for gg in range(G):
+            st = nd.status(gg)
+            assert (st.term, st.vote, st.commit) == hs[gg] and st.term > 0
+    finally:
+        c.close()
+
+
+def test_replay_wal_refuses_a_corrupt_segment(Cluster):
+    from raftsql_amd.engine import RaftqError
+    from raftsql_amd.node import RaftNode
+
+    c = Cluster(3, 3, wal=True)
+    try:
+        c.start()
+        elect(c)
+        for g in range(3):
+            c.nodes[int(c.leaders()[g])].propose(g, b"payload %d " % g * 40)
+        c.settle()
+        wal = bytes(c.wal[0])
+    finally:
+        c.close()
+    nd = RaftNode(3, 3, 0)
+    try:
+        assert nd.replay_wal(wal[: len(wal) - 3]) > 3  # a torn tail: the whole frames still replay
+    finally:
+        nd.destroy()
+    from oracle import pywire as W
+
+    off, _ = W.scan_frames(wal, big_endian=False)
+    recs, _, _ = W.wal_decode(wal, off, 0)
+    ent = [i for i in range(len(recs)) if recs[i]["kind"] == W.WAL_ENTRY and recs[i]["data_len"] > 10]
+    # a payload byte, a record's first tag (-> does not parse), a stored crc.  (A flipped bit in a length
+    # word moves the frame boundaries instead: the reader sees a torn tail there, as wal.ReadAll does.)
+    for pos in (int(recs[ent[0]]["data_off"]) + 5, int(off[ent[-1]]) + 8, int(off[ent[1]]) + 11):
+        bad = bytearray(wal)
+        bad[pos] ^= 0x04
+        nd = RaftNode(3, 3, 0)
+        try:
+            with pytest.raises(RaftqError) as ei:
+                nd.replay_wal(bytes(bad))
+            assert "CRC" in str(ei.value) or "parse" in str(ei.value) or "place" in str(ei.value)
+        finally:
+            nd.destroy()

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -35,6 +37,43 @@ struct Item {
 struct InMsg {
   raftq_msg_t h;
   std::vector<Entry> ents;
+};
+
+// Growable page-locked byte buffer (raftq_host_alloc) for everything the codecs read or fill: the GPU
+// moves such memory by direct DMA.  Measured on MI355X (tools/wire_fresh_buffers.py): a 64K-frame decode
+// into freshly allocated pageable arrays takes 2.8 ms, into the same pinned arrays every turn 0.21 ms.
+struct PinBuf {
+  uint8_t* p = nullptr;
+  size_t size = 0, cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { raftq_host_free(p); }
+  bool reserve(size_t want) {
+    if (want <= cap) return true;
+    const size_t nc = std::max<size_t>(std::max(want, cap * 2), (size_t)1 << 16);
+    void* q = nullptr;
+    if (raftq_host_alloc(&q, nc) != RAFTQ_OK) return false;
+    if (size) std::memcpy(q, p, size);
+    raftq_host_free(p);
+    p = (uint8_t*)q;
+    cap = nc;
+    return true;
+  }
+  bool append(const void* src, size_t n) {
+    if (!reserve(size + n)) return false;
+    if (n) std::memcpy(p + size, src, n);
+    size += n;
+    return true;
+  }
+  void clear() { size = 0; }
+  void swap(PinBuf& o) {
+    std::swap(p, o.p);
+    std::swap(size, o.size);
+    std::swap(cap, o.cap);
+  }
+  template <typename T> T* as() { return (T*)p; }
+  template <typename T> size_t count() const { return size / sizeof(T); }
 };
 
 struct Group {
@@ -76,17 +115,30 @@ struct raftq_node {
   uint32_t pending_ticks = 0;
   std::vector<PeerQueue> outbound;  // [peer]
   // inbound stream frames as delivered (decoded on the GPU at the next advance)
-  std::string in_bytes;
-  std::vector<uint64_t> in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size()]
+  PinBuf in_bytes;
+  std::vector<uint64_t> in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size]
   // this turn's outbound messages, marshalled in one raftq_wire_encode at the end of advance()
   std::vector<raftq_wire_msg_t> out_msgs;
-  std::vector<raftq_wire_ent_t> out_ents;
-  std::string out_pool;
+  PinBuf out_ents;  // raftq_wire_ent_t[]
+  PinBuf out_pool;  // entry payload bytes
+  bool out_oom = false;
+  // advance()'s own scratch (only touched under turn_mu): the other half of the inbound double buffer,
+  // decoded records, the sorted outbound batch and its stream
+  PinBuf turn_bytes, turn_msgs, turn_ents, enc_msgs, enc_out, wal_recs, wal_pool, wal_enc;
+  std::vector<uint64_t> turn_off, enc_off;
   // WAL (off unless raftq_node_wal_enable): encoded records waiting for raftq_node_wal_poll
   bool wal_on = false, wal_head_written = false;
   uint32_t wal_crc = 0;
   PeerQueue wal_out;
   std::vector<uint64_t> wal_dirty;  // groups touched this turn
+  // entries of the last send_append, so that a broadcast marshals one copy of a shared suffix
+  uint64_t shared_group = ~0ull, shared_first_idx = 0, shared_cnt = 0;
+  uint32_t shared_ent_first = 0;
+  // RAFTQ_PROFILE=1: host time of advance()'s phases, printed at destroy
+  enum { kPhDecode, kPhInbound, kPhTick, kPhStage, kPhStep, kPhApply, kPhDeltas, kPhProps, kPhWal, kPhEncode, kPhN };
+  double prof[kPhN] = {0};
+  uint64_t prof_turns = 0;
+  bool profiling = false;
   bool started = false, closed = false;
   int error = 0;
   std::string errtext;
@@ -141,17 +193,31 @@ void put_frame(raftq_node_t* n, uint32_t to, const raftq_msg_t& hdr, const Entry
   m.type = hdr.type;
   m.reject = hdr.reject;
   m.to = (uint8_t)to;
-  m.ent_first = n_ents ? (uint32_t)n->out_ents.size() : 0;
+  m.ent_first = n_ents ? (uint32_t)n->out_ents.count<raftq_wire_ent_t>() : 0;
   m.n_ents = (uint32_t)n_ents;
+  // bcastAppend sends most followers the same suffix: the encoder takes arbitrary entry ranges, so the
+  // second and later messages point at the first one's entries instead of queueing copies
+  const bool app = hdr.type == RAFTQ_MSG_APP && n_ents != 0;
+  if (app && n->shared_group == hdr.group && n->shared_first_idx == hdr.index + 1 && n->shared_cnt == n_ents) {
+    m.ent_first = n->shared_ent_first;
+    n->out_msgs.push_back(m);
+    n->stats.msgs_sent++;
+    return;
+  }
+  if (app) {
+    n->shared_group = hdr.group;
+    n->shared_first_idx = hdr.index + 1;
+    n->shared_cnt = n_ents;
+    n->shared_ent_first = m.ent_first;
+  }
   for (size_t i = 0; i < n_ents; ++i) {
     raftq_wire_ent_t e;
     std::memset(&e, 0, sizeof(e));
     e.term = ents[i].term;
     e.index = hdr.type == RAFTQ_MSG_APP ? hdr.index + 1 + i : 0;
     e.data_len = (uint32_t)ents[i].data.size();
-    e.data_off = e.data_len ? n->out_pool.size() : 0;
-    n->out_pool.append(ents[i].data);
-    n->out_ents.push_back(e);
+    e.data_off = e.data_len ? n->out_pool.size : 0;
+    if (!n->out_pool.append(ents[i].data.data(), ents[i].data.size()) || !n->out_ents.append(&e, sizeof(e))) n->out_oom = true;
   }
   n->out_msgs.push_back(m);
   n->stats.msgs_sent++;
@@ -263,6 +329,7 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vec
       if (g.log[idx - 1].term != im.ents[k].term) {
         g.log.resize(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
         g.wal_upto = std::min<uint64_t>(g.wal_upto, idx - 1);  // the WAL gets the replacement entries again
+        n->shared_group = ~0ull;
         break;
       }
     }
@@ -342,6 +409,7 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
       // becomeLeader's appendEntry(pb.Entry{Data: nil}): the engine already counted it
       g.log.resize(std::min<uint64_t>(g.log.size(), o.index - 1));
       g.wal_upto = std::min<uint64_t>(g.wal_upto, g.log.size());
+      n->shared_group = ~0ull;
       g.log.push_back(Entry{o.term, std::string()});
       wal_touch(n, gi, g);
       g.next.assign(n->N, o.index);  // reset(): Next = lastIndex + 1 (before the empty entry)
@@ -414,32 +482,51 @@ int poll_queue(raftq_node_t* n, PeerQueue& q, bool big_endian, void* buf, uint64
 int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   const size_t nm = n->out_msgs.size();
   if (nm == 0) return RAFTQ_OK;
+  if (n->out_oom) {
+    lk.unlock();
+    return RAFTQ_ENOMEM;
+  }
   // stable counting sort by addressee: per-peer order is the order of the sends
   std::vector<uint64_t> first(n->N + 1, 0);
   for (const raftq_wire_msg_t& m : n->out_msgs) first[m.to + 1]++;
   for (uint32_t p = 0; p < n->N; ++p) first[p + 1] += first[p];
-  std::vector<raftq_wire_msg_t> sorted(nm);
+  const raftq_wire_ent_t* ents = n->out_ents.as<raftq_wire_ent_t>();
+  const size_t n_ents = n->out_ents.count<raftq_wire_ent_t>();
+  uint64_t cap = 0;  // an upper bound of the stream: 12 varint fields + tags + the empty snapshot per message
+  n->enc_msgs.clear();
+  if (!n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t))) {
+    lk.unlock();
+    return RAFTQ_ENOMEM;
+  }
+  n->enc_msgs.size = nm * sizeof(raftq_wire_msg_t);
+  raftq_wire_msg_t* sorted = n->enc_msgs.as<raftq_wire_msg_t>();
   {
     std::vector<uint64_t> at(first.begin(), first.end() - 1);
-    for (const raftq_wire_msg_t& m : n->out_msgs) sorted[at[m.to]++] = m;
+    for (const raftq_wire_msg_t& m : n->out_msgs) {
+      sorted[at[m.to]++] = m;
+      cap += 160;
+      for (uint32_t k = 0; k < m.n_ents; ++k) cap += 48 + ents[m.ent_first + k].data_len;  // shared ranges count per use
+    }
   }
-  std::vector<raftq_wire_ent_t> ents;
-  std::string pool;
-  ents.swap(n->out_ents);
-  pool.swap(n->out_pool);
   n->out_msgs.clear();
-  const uint64_t cap = (uint64_t)nm * 160 + (uint64_t)ents.size() * 48 + pool.size();
-  std::string out((size_t)cap, '\0');
-  std::vector<uint64_t> off(nm + 1);
+  n->shared_group = ~0ull;
+  n->enc_off.resize(nm + 1);
+  if (!n->enc_out.reserve(cap)) {
+    lk.unlock();
+    return RAFTQ_ENOMEM;
+  }
   raftq_wire_counts_t cnt;
-  lk.unlock();
-  const int rc = raftq_wire_encode(n->h, sorted.data(), nm, ents.data(), ents.size(), pool.data(), pool.size(), &out[0], cap,
-                                   off.data(), &cnt);
+  lk.unlock();  // put_frame only runs inside advance(), which this thread holds (turn_mu): out_* are safe to read unlocked
+  const int rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap,
+                                   n->enc_off.data(), &cnt);
   if (rc != RAFTQ_OK) return rc;
   lk.lock();
+  n->out_ents.clear();
+  n->out_pool.clear();
+  const uint64_t* off = n->enc_off.data();
   for (uint32_t p = 0; p < n->N; ++p)
     if (first[p + 1] > first[p])
-      n->outbound[p].bytes.append(out, (size_t)off[first[p]], (size_t)(off[first[p + 1]] - off[first[p]]));
+      n->outbound[p].bytes.append((const char*)n->enc_out.p + off[first[p]], (size_t)(off[first[p + 1]] - off[first[p]]));
   return RAFTQ_OK;
 }
 
@@ -450,58 +537,63 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   if (!n->wal_on || (n->wal_dirty.empty() && n->wal_head_written)) return RAFTQ_OK;
   std::sort(n->wal_dirty.begin(), n->wal_dirty.end());
-  std::vector<raftq_wal_rec_t> recs;
-  std::string pool;
-  auto blank = [](uint8_t kind) {
+  PinBuf& recs = n->wal_recs;
+  PinBuf& pool = n->wal_pool;
+  recs.clear();
+  pool.clear();
+  bool oom = false;
+  auto put = [&](uint8_t kind, uint64_t group, uint64_t term, uint64_t index, uint32_t vote, const std::string* data) {
     raftq_wal_rec_t r;
     std::memset(&r, 0, sizeof(r));
     r.kind = kind;
-    return r;
+    r.group = group;
+    r.term = term;
+    r.index = index;
+    r.vote = vote;
+    if (data && !data->empty()) {
+      r.data_len = (uint32_t)data->size();
+      r.data_off = pool.size;
+      oom |= !pool.append(data->data(), data->size());
+    }
+    oom |= !recs.append(&r, sizeof(r));
   };
   if (!n->wal_head_written) {
-    recs.push_back(blank(RAFTQ_WAL_CRC));
-    recs.push_back(blank(RAFTQ_WAL_METADATA));
-    recs.push_back(blank(RAFTQ_WAL_SNAPSHOT));
+    put(RAFTQ_WAL_CRC, 0, 0, 0, 0, nullptr);
+    put(RAFTQ_WAL_METADATA, 0, 0, 0, 0, nullptr);
+    put(RAFTQ_WAL_SNAPSHOT, 0, 0, 0, 0, nullptr);
   }
   for (uint64_t gi : n->wal_dirty) {
     Group& g = n->groups[gi];
     g.wal_dirty = false;
     for (uint64_t idx = g.wal_upto + 1; idx <= g.log.size(); ++idx) {
       const Entry& e = g.log[idx - 1];
-      raftq_wal_rec_t r = blank(RAFTQ_WAL_ENTRY);
-      r.group = gi;
-      r.term = e.term;
-      r.index = idx;
-      r.data_len = (uint32_t)e.data.size();
-      r.data_off = r.data_len ? pool.size() : 0;
-      pool.append(e.data);
-      recs.push_back(r);
+      put(RAFTQ_WAL_ENTRY, gi, e.term, idx, 0, &e.data);
     }
     g.wal_upto = g.log.size();
     const bool empty_hs = g.term == 0 && g.vote == 0 && g.committed == 0;  // `if !raft.IsEmptyHardState(st)`
     if (!empty_hs && (g.term != g.wal_term || g.vote != g.wal_vote || g.committed != g.wal_commit)) {
-      raftq_wal_rec_t r = blank(RAFTQ_WAL_STATE);
-      r.group = gi;
-      r.term = g.wal_term = g.term;
-      r.vote = g.wal_vote = g.vote;  // raft IDs are 1-based peer positions (raft.go:148-151); 0 = None
-      r.index = g.wal_commit = g.committed;
-      recs.push_back(r);
+      // raft IDs are 1-based peer positions (raft.go:148-151), 0 = None: Vote goes out as it is
+      put(RAFTQ_WAL_STATE, gi, g.wal_term = g.term, g.wal_commit = g.committed, g.wal_vote = g.vote, nullptr);
     }
   }
   n->wal_dirty.clear();
-  if (recs.empty()) return RAFTQ_OK;
-  const uint64_t cap = (uint64_t)recs.size() * 80 + pool.size();
-  std::string out((size_t)cap, '\0');
+  const size_t n_recs = recs.count<raftq_wal_rec_t>();
+  if (n_recs == 0) return RAFTQ_OK;
+  const uint64_t cap = (uint64_t)n_recs * 80 + pool.size;
+  if (oom || !n->wal_enc.reserve(cap)) {
+    lk.unlock();
+    return RAFTQ_ENOMEM;
+  }
   raftq_wal_counts_t cnt;
   const uint32_t prev = n->wal_crc;
   lk.unlock();
-  const int rc = raftq_wal_encode(n->h, recs.data(), recs.size(), pool.data(), pool.size(), prev, &out[0], cap, nullptr, &cnt);
+  const int rc = raftq_wal_encode(n->h, recs.as<raftq_wal_rec_t>(), n_recs, pool.p, pool.size, prev, n->wal_enc.p, cap, nullptr, &cnt);
   if (rc != RAFTQ_OK) return rc;
   lk.lock();
-  n->wal_out.bytes.append(out, 0, (size_t)cnt.bytes);
+  n->wal_out.bytes.append((const char*)n->wal_enc.p, (size_t)cnt.bytes);
   n->wal_crc = cnt.last_crc;
   n->wal_head_written = true;
-  n->stats.wal_records += recs.size();
+  n->stats.wal_records += n_recs;
   return RAFTQ_OK;
 }
 
@@ -534,6 +626,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   n->G = n_groups;
   n->N = n_peers;
   n->self = self_peer;
+  n->profiling = std::getenv("RAFTQ_PROFILE") != nullptr;
   try {
     n->groups.resize(n_groups);
     n->outbound.resize(n_peers);
@@ -676,20 +769,46 @@ int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len) {
     n->errtext = "deliver: node not running";
     return RAFTQ_ESTATE;
   }
-  const uint64_t base = n->in_bytes.size();
-  n->in_bytes.append((const char*)frames, (size_t)len);
+  const uint64_t base = n->in_bytes.size;
+  if (!n->in_bytes.append(frames, (size_t)len)) {
+    n->errtext = "deliver: page-locked allocation failed";
+    return RAFTQ_ENOMEM;
+  }
   if (n->in_off.empty()) n->in_off.push_back(0);
   for (uint64_t i = 1; i <= nf; ++i) n->in_off.push_back(base + off[i]);
   return RAFTQ_OK;
 }
 
+namespace {
+struct Phase {  // accumulates wall time into n->prof[which] when RAFTQ_PROFILE is set
+  raftq_node_t* n;
+  int which;
+  std::chrono::steady_clock::time_point t0;
+  Phase(raftq_node_t* node, int w) : n(node), which(w) {
+    if (n->profiling) t0 = std::chrono::steady_clock::now();
+  }
+  void next(int w) {
+    if (!n->profiling) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    n->prof[which] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    which = w;
+    t0 = t1;
+  }
+  ~Phase() { next(which); }
+};
+}  // namespace
+
 int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> turn(n->turn_mu);
+  Phase ph(n, raftq_node::kPhDecode);
+  if (n->profiling) n->prof_turns++;
   std::vector<InMsg> work;
   std::vector<std::pair<uint64_t, std::string>> props;
-  std::string in_bytes;
-  std::vector<uint64_t> in_off;
+  PinBuf& in_bytes = n->turn_bytes;  // the half of the inbound double buffer this turn decodes
+  std::vector<uint64_t>& in_off = n->turn_off;
+  in_bytes.clear();
+  in_off.clear();
   uint32_t ticks = 0;
   {
     std::lock_guard<std::mutex> lk(n->mu);
@@ -708,15 +827,21 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   uint64_t dropped = 0;
   if (in_off.size() > 1) {
     const uint64_t nf = in_off.size() - 1;
-    std::vector<raftq_wire_msg_t> wm(nf);
-    std::vector<raftq_wire_ent_t> we(nf + 16);
+    uint64_t ents_cap = std::max<uint64_t>(nf + 1024, n->turn_ents.cap / sizeof(raftq_wire_ent_t));
+    if (!n->turn_msgs.reserve(nf * sizeof(raftq_wire_msg_t)) || !n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t)))
+      return poison(n, RAFTQ_ENOMEM, "wire_decode (page-locked result buffers)");
+    raftq_wire_msg_t* wm = n->turn_msgs.as<raftq_wire_msg_t>();
+    raftq_wire_ent_t* we = n->turn_ents.as<raftq_wire_ent_t>();
     raftq_wire_counts_t cnt;
-    int rc = raftq_wire_decode(n->h, in_bytes.data(), in_bytes.size(), in_off.data(), nf, wm.data(), we.data(), we.size(), &cnt);
-    if (rc == RAFTQ_EINVAL && cnt.n_ents > we.size()) {
-      we.resize(cnt.n_ents);
-      rc = raftq_wire_decode(n->h, in_bytes.data(), in_bytes.size(), in_off.data(), nf, wm.data(), we.data(), we.size(), &cnt);
+    int rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, wm, we, ents_cap, &cnt);
+    if (rc == RAFTQ_EINVAL && cnt.n_ents > ents_cap) {  // more entries than messages + 1024: grow once, decode again
+      ents_cap = cnt.n_ents;
+      if (!n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t))) return poison(n, RAFTQ_ENOMEM, "wire_decode (entries)");
+      we = n->turn_ents.as<raftq_wire_ent_t>();
+      rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, wm, we, ents_cap, &cnt);
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "wire_decode");
+    ph.next(raftq_node::kPhInbound);
     for (uint64_t i = 0; i < nf; ++i) {
       const raftq_wire_msg_t& m = wm[i];
       const bool kind_ok = m.type == RAFTQ_MSG_PROP || m.type == RAFTQ_MSG_APP || m.type == RAFTQ_MSG_APP_RESP ||
@@ -740,7 +865,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
       im.ents.reserve(m.n_ents);
       for (uint32_t k = 0; k < m.n_ents; ++k) {
         const raftq_wire_ent_t& e = we[m.ent_first + k];
-        im.ents.push_back(Entry{e.term, std::string(in_bytes.data() + e.data_off, e.data_len)});
+        im.ents.push_back(Entry{e.term, std::string((const char*)in_bytes.p + e.data_off, e.data_len)});
       }
       work.push_back(std::move(im));
     }
@@ -755,6 +880,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
   std::vector<InMsg> hups;
+  ph.next(raftq_node::kPhTick);
   for (uint32_t t = 0; t < ticks; ++t) {
     lk.unlock();
     int rc = raftq_tick(n->h, nullptr);
@@ -781,6 +907,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   std::vector<InMsg> batch, deferred;
   std::unordered_set<uint64_t> blocked, dirty;
   while (!work.empty()) {
+    ph.next(raftq_node::kPhStage);
     batch.clear();
     deferred.clear();
     blocked.clear();
@@ -809,12 +936,14 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
           staged[idx.size()] = batch[i].h;
           idx.push_back(i);
         }
+      ph.next(raftq_node::kPhStep);
       rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
       uint64_t n_out = 0;
       if (rc == RAFTQ_OK) rc = raftq_step_results(n->h, &outs, &n_out);
       if (rc != RAFTQ_OK) return poison(n, rc, "step_batch");
     }
     lk.lock();
+    ph.next(raftq_node::kPhApply);
     n->stats.msgs_stepped += n_step;
     // consequences, in arrival order (stepped results and proposals interleaved as they came)
     size_t k = 0;
@@ -827,6 +956,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
         apply_result(n, outs[k++], im);
       }
     }
+    ph.next(raftq_node::kPhDeltas);
     for (uint64_t gi : dirty) {
       Group& g = n->groups[gi];
       raftq_log_delta_t d{gi, g.log.size(), g.term, 0};
@@ -836,6 +966,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
     work.swap(deferred);
   }
+  ph.next(raftq_node::kPhProps);
 
   // -- proposeC (raft.go:211-215)
   if (!props.empty()) {
@@ -856,7 +987,9 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   }
   // -- wal.Save before transport.Send (raft.go:228-230): the caller persists what raftq_node_wal_poll
   // hands out before it transmits what raftq_node_poll hands out
+  ph.next(raftq_node::kPhWal);
   if (int rc = flush_wal(n, lk)) return poison(n, rc, "wal_encode");
+  ph.next(raftq_node::kPhEncode);
   if (int rc = flush_outbound(n, lk)) return poison(n, rc, "wire_encode");
   if (did) n->stats.turns++;
   const uint64_t pub = n->stats.entries_published - published0;
@@ -1046,6 +1179,12 @@ const char* raftq_node_last_error(const raftq_node_t* n) { return n ? n->errtext
 void raftq_node_destroy(raftq_node_t* n) {
   if (!n) return;
   raftq_node_close(n);
+  if (n->profiling && n->prof_turns) {
+    static const char* names[raftq_node::kPhN] = {"decode", "inbound", "tick", "stage", "step", "apply", "deltas", "props", "wal", "encode"};
+    std::fprintf(stderr, "[raftq_node %u] advance phases, total ms over %llu turns:", n->self, (unsigned long long)n->prof_turns);
+    for (int i = 0; i < raftq_node::kPhN; ++i) std::fprintf(stderr, " %s %.1f", names[i], n->prof[i] / 1e3);
+    std::fprintf(stderr, "\n");
+  }
   raftq_destroy(n->h);
   delete n;
 }

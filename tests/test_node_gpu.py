@@ -178,16 +178,25 @@ def test_partitioned_leader_cannot_commit_and_rejoins(Cluster):
         c.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_chaos_safety_and_convergence(Cluster, seed):
-    """Random message loss, partitions, stops and restarts (WAL + HardState restored) while clients
+@pytest.mark.parametrize("seed,from_wal", [(1, False), (2, False), (3, False), (4, True), (5, True)])
+def test_chaos_safety_and_convergence(Cluster, seed, from_wal):
+    """Random message loss, partitions, stops and restarts (WAL + HardState restored; from_wal: from the
+    node's own WAL bytes -- raftq_node_replay_wal -- and nothing else) while clients
     keep proposing on whatever node they reach.  Throughout: at most one leader per term, committed
     prefixes agree, and what the never-restarted nodes delivered are prefixes of one sequence per
     group.  After healing: all nodes hold the same committed sequence, no payload twice, nothing
     invented, and every live stream is exactly that sequence."""
     rng = np.random.default_rng(seed)
     G, N = 24, 5
-    c = Cluster(G, N, seed=seed)
+    c = Cluster(G, N, seed=seed, wal=from_wal)
+
+    def restart(p):
+        logs = stopped.pop(p)
+        if from_wal:
+            c.restart_from_wal(p, restore_hard_state=True)
+        else:
+            c.restart(p, logs, restore_hard_state=True)
+
     # delivered[p][g]: the live commit stream of node p; None once p was restarted (a replay
     # re-publishes the whole WAL, uncommitted tail included -- the reference's contract, raft.go:129-132)
     delivered = [[[] for _ in range(G)] for _ in range(N)]
@@ -220,7 +229,7 @@ def test_chaos_safety_and_convergence(Cluster, seed):
                 delivered[p] = None
             elif r < 0.10 and c.down:
                 p = int(rng.choice(sorted(c.down)))
-                c.restart(p, stopped.pop(p), restore_hard_state=True)
+                restart(p)
             elif r < 0.14:
                 a, b = rng.choice(N, 2, replace=False)
                 c.cut.add((int(a), int(b)))
@@ -240,7 +249,7 @@ def test_chaos_safety_and_convergence(Cluster, seed):
         c.loss = 0.0
         c.cut.clear()
         for p in sorted(c.down):
-            c.restart(p, stopped.pop(p), restore_hard_state=True)
+            restart(p)
         elect(c, max_ticks=150)
         c.run(8)
         c.settle()
@@ -260,6 +269,11 @@ def test_chaos_safety_and_convergence(Cluster, seed):
                     assert delivered[p][g] == seqs[0], (g, p)
         assert any(d is not None for d in delivered)
         assert n_committed > k // 4, (n_committed, k)  # the cluster made real progress under chaos
+        if from_wal:  # every node's disk is still one valid segment holding exactly its logs
+            for p, nd in enumerate(c.nodes):
+                _, logs, _ = _wal_view(bytes(c.wal[p]), G)
+                for g in range(G):
+                    assert logs[g] == nd.log(g), (p, g)
     finally:
         c.close()
 

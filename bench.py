@@ -291,7 +291,7 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     flight; (c) walpb.Record WAL frames (wal.Save / ReadAll) with the CRC-32C chain.  Wall time of the
     calls incl. PCIe both ways (caller-owned pageable buffers); the oracle's per-message loop on one host
     core beside each."""
-    from oracle import pywire as W  # inputs built with the shared record dtypes; cpu leg below
+    from raftsql_amd import wire as W  # record dtypes and constants of the product's host mirror
     from raftsql_amd.wire import WireEngine
 
     G, N = cfg["G"], cfg["N"]
@@ -399,14 +399,16 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                     "decode_GBps": len(wal) / t_wdec_p / 1e9}}
     e.close()
     if with_cpu:
-        W.set_fast_crc(True)  # table-driven CRC: the fair single-core comparison
+        from oracle import pywire as O  # cpu_baseline leg: the per-message loop of the codec oracle, one thread
+
+        O.set_fast_crc(True)  # table-driven CRC: the fair single-core comparison
         try:
-            c_enc = timeit(lambda: W.wire_encode(m, ents, pool), 3) / 2
-            c_dec = timeit(lambda: W.wire_decode(stream, off), 3) / 2  # the binding decodes twice (count, then fill)
-            c_wenc = timeit(lambda: W.wal_encode(r, wpool, 0), 3) / 2
-            c_wdec = timeit(lambda: W.wal_decode(wal, woff, 0), 3)
+            c_enc = timeit(lambda: O.wire_encode(m, ents, pool), 3) / 2
+            c_dec = timeit(lambda: O.wire_decode(stream, off), 3) / 2  # the binding decodes twice (count, then fill)
+            c_wenc = timeit(lambda: O.wal_encode(r, wpool, 0), 3) / 2
+            c_wdec = timeit(lambda: O.wal_decode(wal, woff, 0), 3)
         finally:
-            W.set_fast_crc(False)
+            O.set_fast_crc(False)
         out["cpu_port_1thread"] = {"encode_msgs_per_s": n / c_enc, "decode_msgs_per_s": n / c_dec,
                                    "wal_encode_recs_per_s": n / c_wenc, "wal_decode_recs_per_s": n / c_wdec,
                                    "note": "oracle/raftq_wire_oracle.c, one core, table-driven CRC-32C"}

@@ -131,7 +131,10 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
  * Batches are applied in submission order; the H2D copy of batch k+1 and the D2H copy of batch
  * k-1 overlap the kernels of batch k (three streams).  raftq_step_batch == submit + collect.
  * A malformed batch is reported by ITS collect and applies nothing; a batch submitted behind it
- * is still applied. */
+ * is still applied.  While batches are in flight every other call that reads or changes group
+ * state (sweeps, Tick, deltas, raftq_apply_log_deltas, raftq_load_* / raftq_read_*) returns RAFTQ_ESTATE:
+ * a batch is only guaranteed applied once collected (one holding more than 32 messages of a single
+ * group is replayed through the sorted walk at its collect, in order with whatever follows it). */
 int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n);
 int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_step_counts_t* counts /*|NULL*/);
 

@@ -149,8 +149,18 @@ int raftq_detail::use_device(raftq_t* h) {
   HIPCHK(h, hipSetDevice(h->device));
   return RAFTQ_OK;
 }
+// Every call that reads or changes group state outside raftq_step_submit / _collect: a submitted Step batch
+// is not necessarily applied until its collect (a batch with a long per-group run is replayed there), so
+// state calls are refused while batches are in flight instead of silently running ahead of them.
+int raftq_detail::use_device_idle(raftq_t* h, const char* who) {
+  if (int rc = use_device(h)) return rc;
+  if (h->step_collected != h->step_submitted)
+    return fail(h, RAFTQ_ESTATE, std::string(who) + ": Step batches are in flight; collect them first");
+  return RAFTQ_OK;
+}
 using raftq_detail::ensure_staging;
 using raftq_detail::use_device;
+using raftq_detail::use_device_idle;
 using raftq_detail::ensure_tick_state;
 
 extern "C" {
@@ -278,7 +288,7 @@ void raftq_destroy(raftq_t* h) {
 }
 
 int raftq_set_stream(raftq_t* h, void* stream) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_set_stream")) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->own_stream) HIPCHK(h, hipStreamDestroy(h->stream));
   h->stream = (hipStream_t)stream;
@@ -289,7 +299,7 @@ int raftq_set_stream(raftq_t* h, void* stream) {
 void* raftq_get_stream(const raftq_t* h) { return h ? (void*)h->stream : nullptr; }
 
 int raftq_load_match(raftq_t* h, const uint64_t* match, const uint64_t* committed) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_load_match")) return rc;
   if (!match && !committed) return fail(h, RAFTQ_EINVAL, "raftq_load_match: nothing to load");
   if (match)
     HIPCHK(h, hipMemcpy2DAsync(h->match, h->ld * 8, match, h->G * 8, h->G * 8, h->N, hipMemcpyHostToDevice, h->stream));
@@ -300,7 +310,7 @@ int raftq_load_match(raftq_t* h, const uint64_t* match, const uint64_t* committe
 }
 
 int raftq_load_terms(raftq_t* h, const uint64_t* cur_term, const uint64_t* first_idx_cur_term) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_load_terms")) return rc;
   if (!cur_term || !first_idx_cur_term) return fail(h, RAFTQ_EINVAL, "raftq_load_terms: null argument");
   // A group whose term is 0 has never seen an election: it is not a leader and
   // commits nothing.  Fold that into the compact gate so the kernel reads one
@@ -320,7 +330,7 @@ int raftq_load_terms(raftq_t* h, const uint64_t* cur_term, const uint64_t* first
 }
 
 int raftq_load_votes(raftq_t* h, const uint8_t* votes) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_load_votes")) return rc;
   if (!votes) return fail(h, RAFTQ_EINVAL, "raftq_load_votes: null argument");
   HIPCHK(h, hipMemcpy2DAsync(h->votes, h->ld, votes, h->G, h->G, h->N, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -383,7 +393,7 @@ static int enqueue_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t
 }
 
 int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_apply_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: null argument");
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
@@ -394,7 +404,7 @@ int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
 
 int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n) {
   static_assert(sizeof(TermDeltaRec) == sizeof(raftq_term_delta_t), "ABI struct mismatch");
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_apply_term_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_term_deltas: null argument");
   for (uint64_t i = 0; i < n; ++i)
@@ -422,7 +432,7 @@ int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n)
 }
 
 int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_apply_vote_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: null argument");
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
@@ -432,7 +442,7 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
 }
 
 int raftq_step_async(raftq_t* h, unsigned flags) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_step_async")) return rc;
   const unsigned known = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_VOTES | RAFTQ_SWEEP_NO_ADOPT |
                          RAFTQ_SWEEP_LDS | RAFTQ_SWEEP_CHANGED | RAFTQ_SWEEP_STREAM | RAFTQ_SWEEP_CACHED;
   if (flags & ~known) return fail(h, RAFTQ_EINVAL, "raftq_step_async: unknown flag");
@@ -478,7 +488,7 @@ int raftq_step_async(raftq_t* h, unsigned flags) {
 }
 
 int raftq_wait(raftq_t* h, raftq_counts_t* counts) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_wait")) return rc;
   if (counts) {
     if (h->n_partials == 0) return fail(h, RAFTQ_ESTATE, "raftq_wait: no sweep to report on");
     HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
@@ -501,7 +511,7 @@ int raftq_wait(raftq_t* h, raftq_counts_t* counts) {
 }
 
 int raftq_read_committed(raftq_t* h, uint64_t* out) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_read_committed")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_committed: null argument");
   // after a NO_ADOPT sweep the caller wants the evaluated (shadow) values
   const uint64_t* src = (h->last_flags & RAFTQ_SWEEP_NO_ADOPT) && h->last_new ? h->last_new : h->committed[h->cur];
@@ -511,7 +521,7 @@ int raftq_read_committed(raftq_t* h, uint64_t* out) {
 }
 
 int raftq_read_outcome(raftq_t* h, uint8_t* out) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_read_outcome")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_outcome: null argument");
   HIPCHK(h, hipMemcpyAsync(out, h->outcome, h->G, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -519,7 +529,7 @@ int raftq_read_outcome(raftq_t* h, uint8_t* out) {
 }
 
 int raftq_read_match(raftq_t* h, uint64_t* out) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_read_match")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_match: null argument");
   HIPCHK(h, hipMemcpy2DAsync(out, h->G * 8, h->match, h->ld * 8, h->G * 8, h->N, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -527,7 +537,7 @@ int raftq_read_match(raftq_t* h, uint64_t* out) {
 }
 
 int raftq_read_votes(raftq_t* h, uint8_t* out) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_read_votes")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_votes: null argument");
   HIPCHK(h, hipMemcpy2DAsync(out, h->G, h->votes, h->ld, h->G, h->N, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -582,7 +592,7 @@ int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick
 }
 
 int raftq_load_roles(raftq_t* h, const uint8_t* role, const uint32_t* elapsed) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_load_roles")) return rc;
   if (!role) return fail(h, RAFTQ_EINVAL, "raftq_load_roles: null role array");
   for (uint64_t g = 0; g < h->G; ++g)
     if (role[g] > RAFTQ_ROLE_LEADER) return fail(h, RAFTQ_EINVAL, "raftq_load_roles: role must be 0, 1 or 2");
@@ -595,7 +605,7 @@ int raftq_load_roles(raftq_t* h, const uint8_t* role, const uint32_t* elapsed) {
 }
 
 int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_tick")) return rc;
   if (int rc = ensure_tick_state(h)) return rc;
   TickArgs a;
   a.role = h->role;
@@ -627,7 +637,7 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
 }
 
 int raftq_read_tick(raftq_t* h, uint8_t* action, uint32_t* elapsed, uint8_t* role) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_read_tick")) return rc;
   if (!h->role) return fail(h, RAFTQ_ESTATE, "raftq_read_tick: no tick state (raftq_load_roles / raftq_tick first)");
   if (action) HIPCHK(h, hipMemcpyAsync(action, h->action, h->G, hipMemcpyDeviceToHost, h->stream));
   if (elapsed) HIPCHK(h, hipMemcpyAsync(elapsed, h->elapsed, h->G * 4, hipMemcpyDeviceToHost, h->stream));
@@ -637,7 +647,7 @@ int raftq_read_tick(raftq_t* h, uint8_t* action, uint32_t* elapsed, uint8_t* rol
 }
 
 int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_collect_hups")) return rc;
   if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null count");
   if (!h->ticked) return fail(h, RAFTQ_ESTATE, "raftq_collect_hups: no raftq_tick yet");
   if (cap && !groups) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null out with cap > 0");
@@ -662,7 +672,7 @@ int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) 
 }
 
 int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self_peer) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_campaign")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!groups) return fail(h, RAFTQ_EINVAL, "raftq_campaign: null argument");
   if (self_peer >= h->N) return fail(h, RAFTQ_EINVAL, "raftq_campaign: self_peer out of range");
@@ -700,7 +710,7 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap) {
 }
 
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_collect_changed")) return rc;
   if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_changed: null count");
   if (!(h->last_flags & RAFTQ_SWEEP_CHANGED) || !h->last_old)
     return fail(h, RAFTQ_ESTATE, "raftq_collect_changed: last sweep did not set RAFTQ_SWEEP_CHANGED");
@@ -724,7 +734,7 @@ static size_t vote_stage_offset(uint64_t n_deltas) {
 
 int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta_t** deltas,
                 raftq_vote_delta_t** vote_deltas) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_stage")) return rc;
   const size_t off_votes = vote_stage_offset(n_deltas);
   if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
   if (deltas) *deltas = (raftq_delta_t*)h->stage_h;
@@ -743,7 +753,7 @@ int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_li
 int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
                 uint64_t n_vote_deltas, unsigned flags, raftq_advance_t* advances_out, uint64_t cap,
                 uint64_t* n_advanced, raftq_counts_t* counts) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = use_device_idle(h, "raftq_cycle")) return rc;
   if ((n_deltas && !deltas) || (n_vote_deltas && !vote_deltas))
     return fail(h, RAFTQ_EINVAL, "raftq_cycle: null array with non-zero length");
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);

@@ -59,6 +59,13 @@ struct raftq {
   uint32_t* lead = nullptr;        // [ld]
   uint64_t* last_index = nullptr;  // [ld]
   uint64_t* last_term = nullptr;   // [ld]
+  // sort-free Step walk (raftq_step_kernels.hpp 2b/3b): per-group message lists of the batch in flight
+  uint32_t* lst_head = nullptr;    // [ld]
+  uint32_t* lst_cnt = nullptr;     // [ld]
+  uint32_t* lst_min = nullptr;     // [ld]
+  unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
+  int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)
+  uint64_t step_replays = 0;       // batches that went through the sorted path after a stall
   // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
   // (pinned staging in, device scratch, pinned results out), pipelined over three streams so the
   // H2D of batch k+1 and the D2H of batch k-1 overlap the kernels of batch k
@@ -73,6 +80,13 @@ struct raftq {
     uint64_t n = 0;
     hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
     bool busy = false;
+    bool lists = false;            // submitted through the sort-free walk
+    bool replayed = false;         // already re-run through the sorted path (after a stall)
+    int end_bit = 0;
+    bool tail_zeroed = false;      // the device copy of the 16-byte result tail is known to be zero (for tail_n, tail_dev)
+    uint64_t tail_n = 0;
+    const void* tail_dev = nullptr;
+    uint64_t w_nbytes = 0;
     // raftq_step_submit_wire: where this batch's decoded records sit in `dev`, and the pinned
     // copies raftq_step_wire_msgs / _entries hand out (fetched on demand)
     bool wire = false;
@@ -109,6 +123,7 @@ struct raftq {
 namespace raftq_detail {
 int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
+int use_device_idle(raftq_t* h, const char* who);  // + no Step batch in flight (RAFTQ_ESTATE otherwise)
 int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped delta staging
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)

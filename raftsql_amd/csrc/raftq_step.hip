@@ -42,6 +42,13 @@ int ensure_node_state(raftq_t* h) {
   if (int rc = alloc((void**)&h->lead, h->ld * 4)) return rc;
   if (int rc = alloc((void**)&h->last_index, h->ld * 8)) return rc;
   if (int rc = alloc((void**)&h->last_term, h->ld * 8)) return rc;
+  if (int rc = alloc((void**)&h->lst_cnt, h->ld * 4)) return rc;
+  HIPCHK(h, hipMalloc((void**)&h->lst_head, h->ld * 4));
+  HIPCHK(h, hipMalloc((void**)&h->lst_min, h->ld * 4));
+  HIPCHK(h, hipMemsetAsync(h->lst_head, 0xff, h->ld * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->lst_min, 0xff, h->ld * 4, h->stream));
+  if (int rc = alloc((void**)&h->step_stall, 256)) return rc;
+  if (const char* w = std::getenv("RAFTQ_STEP_WALK")) h->step_walk_mode = std::strcmp(w, "sort") == 0 ? 0 : 1;
   if (int rc = alloc((void**)&h->term, h->ld * 8)) return rc;  // last: marks the state complete
   h->have_terms = true;  // Step maintains the current-term gate itself (closed = 0 until a group leads)
   return RAFTQ_OK;
@@ -72,6 +79,7 @@ struct Scratch {
   StepOutRec* outs;
   uint64_t *keys_in, *keys_out;
   uint32_t *order_in, *order_out;
+  uint32_t* next;  // sort-free walk: list links
   unsigned long long* n_heads;
   void* cub_temp;
   size_t cub_bytes;
@@ -114,7 +122,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
   // the 16-byte {touched count, bad flag} tail sits right behind the result records: one copy moves both
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
-               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes);
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes), o_next = carve(n * 4);
   const size_t o_nh = o_outs + n * sizeof(StepOutRec);
   // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
@@ -160,6 +168,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   s->keys_out = (uint64_t*)(base + o_ko);
   s->order_in = (uint32_t*)(base + o_oi);
   s->order_out = (uint32_t*)(base + o_oo);
+  s->next = (uint32_t*)(base + o_next);
   s->n_heads = (unsigned long long*)(base + o_nh);
   s->cub_temp = base + o_cub;
   s->cub_bytes = cub_bytes;
@@ -197,6 +206,10 @@ void raftq_detail::free_node_state(raftq_t* h) {
   (void)hipFree(h->lead);
   (void)hipFree(h->last_index);
   (void)hipFree(h->last_term);
+  (void)hipFree(h->lst_head);
+  (void)hipFree(h->lst_cnt);
+  (void)hipFree(h->lst_min);
+  (void)hipFree(h->step_stall);
   for (auto& sl : h->step_slot) {
     if (sl.ev_out && sl.busy) (void)hipEventSynchronize(sl.ev_out);
     (void)hipFree(sl.dev);
@@ -222,7 +235,7 @@ int raftq_set_self(raftq_t* h, uint32_t self_peer) {
 
 int raftq_load_node(raftq_t* h, const uint64_t* term, const uint32_t* vote, const uint32_t* lead,
                     const uint64_t* last_index, const uint64_t* last_term) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_load_node")) return rc;
   if (int rc = ensure_node_state(h)) return rc;
   for (uint64_t g = 0; g < h->G; ++g)
     if ((vote && vote[g] > h->N) || (lead && lead[g] > h->N))
@@ -238,7 +251,7 @@ int raftq_load_node(raftq_t* h, const uint64_t* term, const uint32_t* vote, cons
 
 int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, uint64_t* last_index,
                     uint64_t* last_term, uint64_t* first_idx_cur_term) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_read_node")) return rc;
   if (int rc = ensure_node_state(h)) return rc;
   if (term) HIPCHK(h, hipMemcpyAsync(term, h->term, h->G * 8, hipMemcpyDeviceToHost, h->stream));
   if (vote) HIPCHK(h, hipMemcpyAsync(vote, h->vote, h->G * 4, hipMemcpyDeviceToHost, h->stream));
@@ -276,6 +289,45 @@ struct WireSrc {
   uint64_t nbytes;
   const uint64_t* frame_off;
 };
+
+static ListArrays list_arrays(raftq_t* h) {
+  ListArrays l;
+  l.head = h->lst_head;
+  l.cnt = h->lst_cnt;
+  l.minp = h->lst_min;
+  return l;
+}
+
+// key -> stable radix sort -> walk, on the handle's stream (the path that takes runs of any length)
+static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, bool from_wire, StepOutRec* outs) {
+  unsigned int* bad = (unsigned int*)(s.n_heads + 1);
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
+                     h->G, h->N, bad, from_wire);
+  HIPCHK(h, hipGetLastError());
+  size_t cub_bytes = s.cub_bytes;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
+                                               (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
+  hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
+                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, outs, n, s.n_heads,
+                     (const unsigned int*)bad);
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
+
+// link -> walk (and empty) the per-group lists: two launches, no sort (raftq_step_kernels.hpp 2b / 3b)
+static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from_wire) {
+  unsigned int* bad = (unsigned int*)(s.n_heads + 1);
+  unsigned int* skipped = bad + 1;  // the last word of the 16-byte tail behind the result records
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(step_link_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G, h->N, from_wire,
+                     list_arrays(h), s.next, bad, h->step_stall);
+  hipLaunchKernelGGL(step_lists_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs, s.outs, n,
+                     h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped, (const unsigned int*)bad,
+                     (const unsigned int*)h->step_stall);
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
 
 static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const WireSrc* wire, const char* who) {
   if (int rc = use_device(h)) return rc;
@@ -324,7 +376,10 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
   }
-  hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);  // touched count + bad flag
+  // touched count + bad + skipped: the default result copy leaves them zeroed behind it (step_d2h_kernel zero_tail)
+  const bool fused_tail = mode == 2 || mode == 3;
+  if (!sl.tail_zeroed || sl.tail_n != n || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
+  sl.tail_zeroed = false;
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   if (wire) {
@@ -340,17 +395,13 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
                        (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base, s.w_ents, s.w_ents_cap);
     HIPCHK(h, hipGetLastError());
   }
-  hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
-                     h->G, h->N, bad, wire != nullptr);
-  HIPCHK(h, hipGetLastError());
-  size_t cub_bytes = s.cub_bytes;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
-                                               (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
-  // 8: the walk writes its result records straight into the pinned, device-mapped result area (no copy kernel)
-  hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
-                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out,
-                     mode == 8 ? (StepOutRec*)sl.out_d : s.outs, n, s.n_heads, (const unsigned int*)bad);
-  HIPCHK(h, hipGetLastError());
+  const bool lists = h->step_walk_mode == 1;
+  if (lists) {
+    if (int rc = enqueue_list_walk(h, s, n, wire != nullptr)) return rc;
+  } else {
+    // 8: the walk writes its result records straight into the pinned, device-mapped result area (no copy kernel)
+    if (int rc = enqueue_sorted_walk(h, s, n, end_bit, wire != nullptr, mode == 8 ? (StepOutRec*)sl.out_d : s.outs)) return rc;
+  }
   if (s_out != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
     HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
@@ -358,7 +409,7 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   const uint64_t out_quads = n * 4 + 1;  // records + the 16-byte tail
   if (mode == 5 || mode == 6) {
     HIPCHK(h, hipMemcpyAsync(sl.out_h, s.outs, (size_t)out_quads * 16, hipMemcpyDeviceToHost, s_out));
-  } else if (mode == 8) {
+  } else if (mode == 8 && !lists) {
     hipLaunchKernelGGL(step_d2h_kernel, dim3(1), dim3(kBlock), 0, s_out, (const u64x2*)s.n_heads,
                        (u64x2*)((uint8_t*)sl.out_d + (size_t)n * sizeof(StepOutRec)), (uint64_t)1);
     HIPCHK(h, hipGetLastError());
@@ -375,12 +426,19 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     HIPCHK(h, hipGetLastError());
   } else {
     hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
+                       dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads, fused_tail);
     HIPCHK(h, hipGetLastError());
+    sl.tail_zeroed = fused_tail;  // holds for the next batch of the same size in the same scratch
+    sl.tail_n = n;
+    sl.tail_dev = sl.dev;
   }
   HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
   sl.n = n;
   sl.busy = true;
+  sl.lists = lists;
+  sl.replayed = false;
+  sl.end_bit = end_bit;
+  sl.w_nbytes = wire ? wire->nbytes : 0;
   sl.wire = wire != nullptr;
   sl.w_msgs_d = s.msgs;
   sl.w_ents_d = s.w_ents;
@@ -463,6 +521,32 @@ int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t*
   return RAFTQ_OK;
 }
 
+// first_slot's batch reported `skipped`; the other slot may hold a later batch that is still in flight
+static int replay_stalled(raftq_t* h, int first_slot) {
+  for (int k = 0; k < 2; ++k) {
+    raftq::StepSlot& sl = h->step_slot[(first_slot + k) & 1];
+    if (k == 1) {
+      if (!sl.busy) break;
+      HIPCHK(h, hipEventSynchronize(sl.ev_out));  // it ran behind the stalled batch: skipped as well
+    }
+    Scratch s;
+    if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, sl.wire, sl.w_nbytes)) return rc;
+    hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
+    if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.wire, s.outs)) return rc;
+    const uint64_t out_quads = sl.n * 4 + 1;
+    hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, h->stream, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(sl.ev_out, h->stream));
+    sl.tail_zeroed = false;
+    sl.replayed = true;
+    h->step_replays++;
+  }
+  HIPCHK(h, hipMemsetAsync(h->step_stall, 0, 4, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RAFTQ_OK;
+}
+
 int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* counts) {
   if (int rc = use_device(h)) return rc;
   if (counts) counts->n_msgs = counts->n_groups_touched = 0;
@@ -475,7 +559,13 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   const uint64_t n = sl.n;
   const uint8_t* tail = (const uint8_t*)sl.out_h + (size_t)n * sizeof(StepOutRec);
   unsigned long long heads;
-  unsigned int bad_h;
+  unsigned int bad_h, skipped_h;
+  std::memcpy(&skipped_h, tail + 12, 4);
+  if (skipped_h) {
+    // this batch has a run longer than the list walk takes: nothing of it, nor of the batch submitted behind it,
+    // was applied.  Replay them in submission order through the sorted walk, then let the list walk resume.
+    if (int rc = replay_stalled(h, (int)((h->step_collected - 1) & 1))) return rc;
+  }
   std::memcpy(&heads, tail, 8);
   std::memcpy(&bad_h, tail + 8, 4);
   if (bad_h) {
@@ -510,7 +600,7 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 }
 
 int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {
-  if (int rc = use_device(h)) return rc;
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_apply_log_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: null argument");
   for (uint64_t i = 0; i < n; ++i)

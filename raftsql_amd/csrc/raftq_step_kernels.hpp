@@ -298,14 +298,123 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
   node.store();
 }
 
+// ---- (2b, 3b) the same walk WITHOUT the sort.  Inbound traffic rarely brings more than a few messages
+// of one group in one batch, so grouping by a full stable sort (7 hipCUB launches, 55 us of a 95 us kernel
+// chain at 64K messages) is the wrong tool.  step_link_kernel threads every message onto its group's list
+// with three atomics on group-indexed arrays (exchange the list head, count, minimum batch position);
+// the lane of a group's FIRST message then owns the group: it gathers the list (arbitrary order), sorts
+// the <= kMaxRun positions in a private array, applies the messages in arrival order and empties the list -- the same
+// sequence the sorted walk applies, so the result records are identical byte for byte
+// (tests/test_step_gpu.py runs both paths).  A batch with a longer run sets the handle's `stall` word:
+// nothing of it -- nor of any later batch already in flight -- is applied, and the host replays those
+// batches, in order, through the sorted path (raftq_step.hip: replay_stalled).
+constexpr uint32_t kMaxRun = 32;
+constexpr uint32_t kNil = 0xffffffffu;
+
+struct ListArrays {
+  uint32_t* head;  // [ld] batch position of the last-linked message of the group, kNil = none
+  uint32_t* cnt;   // [ld] messages of the group in this batch
+  uint32_t* minp;  // [ld] smallest batch position of the group
+};
+
+static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* __restrict__ msgs, uint64_t n,
+                                                                  uint64_t n_groups, uint32_t n_peers, bool from_wire,
+                                                                  ListArrays l, uint32_t* __restrict__ next,
+                                                                  unsigned int* bad, unsigned int* stall) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool is_bad = false, too_long = false;
+  if (i < n) {
+    const uint64_t g = msgs[i].group;
+    const uint32_t from = msgs[i].from;
+    const uint8_t t = msgs[i].type;
+    const bool local = t == kMsgHup || t == kMsgBeat;
+    const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
+                       t == kMsgHeartbeat || t == kMsgHeartbeatResp;
+    is_bad = g >= n_groups || !known || (!local && from >= n_peers);
+    if (from_wire) is_bad = is_bad || (msgs[i].pad[1] & 1u) != 0 || msgs[i].pad[0] >= n_peers;
+    if (!is_bad) {
+      next[i] = atomicExch(&l.head[g], (uint32_t)i);
+      too_long = atomicAdd(&l.cnt[g], 1u) + 1 > kMaxRun;
+      atomicMin(&l.minp[g], (uint32_t)i);
+    }
+  }
+  if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+  if (__ballot(too_long) != 0 && (threadIdx.x & 63) == 0) atomicOr(stall, 1u);
+}
+
+static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
+                                                                   StepOutRec* __restrict__ out, uint64_t n,
+                                                                   uint64_t n_groups, ListArrays l,
+                                                                   const uint32_t* __restrict__ next,
+                                                                   unsigned long long* n_heads, unsigned int* tail_skipped,
+                                                                   const unsigned int* bad, const unsigned int* stall) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool stalled = *stall != 0;  // this batch, or one before it that has not been replayed yet, needs the sorted path
+  if (stalled || *bad) {             // (*bad: a malformed record somewhere in the batch) -- nothing is applied;
+    if (stalled && i == 0) *tail_skipped = 1u;
+    if (i < n && msgs[i].group < n_groups) {  // every message empties its group's list words (idempotent)
+      const uint64_t gg = msgs[i].group;
+      l.head[gg] = kNil;
+      l.cnt[gg] = 0;
+      l.minp[gg] = kNil;
+    }
+    return;
+  }
+  uint64_t g = 0;
+  bool owner = false;
+  if (i < n) {
+    g = msgs[i].group;
+    owner = l.minp[g] == (uint32_t)i;
+  }
+  const uint64_t ob = __ballot(owner);
+  if ((threadIdx.x & 63) == 0 && ob) atomicAdd(n_heads, (unsigned long long)__popcll(ob));
+  if (!owner) return;
+  const uint32_t c = l.cnt[g];
+  Node node(a, g);
+  if (c == 1) {
+    StepOutRec o;
+    node.step(msgs[i], o);
+    out[i] = o;
+  } else {
+    uint32_t pos[kMaxRun];
+    uint32_t p = l.head[g];
+    for (uint32_t k = 0; k < c; ++k) {  // gather, inserting in ascending order of batch position
+      uint32_t j = k;
+      while (j > 0 && pos[j - 1] > p) {
+        pos[j] = pos[j - 1];
+        --j;
+      }
+      pos[j] = p;
+      p = next[p];
+    }
+    for (uint32_t k = 0; k < c; ++k) {
+      const MsgRec m = msgs[pos[k]];
+      StepOutRec o;
+      node.step(m, o);
+      out[pos[k]] = o;
+    }
+  }
+  node.store();
+  // the group's list goes back to empty for the next batch.  Other lanes of this group only compare minp with
+  // their own position to learn that they are not the owner: kNil tells them the same.
+  l.head[g] = kNil;
+  l.cnt[g] = 0;
+  l.minp[g] = kNil;
+}
+
 // ---- (4) results -> pinned, device-mapped host memory.  A small grid (grid-stride, 16 B per lane): the
 // transfer is PCIe-bound and 64 workgroups keep the link full (77 us for 4 MB, the same as the
 // runtime's own blit copy).
+// zero_tail: the last quad is the batch's {touched count, bad, skipped} tail; once it is on its way to the host the
+// device copy is cleared for the slot's next batch (saves that batch a reset launch).
 static __global__ __launch_bounds__(kBlock) void step_d2h_kernel(const u64x2* __restrict__ src, u64x2* __restrict__ dst,
-                                                                 uint64_t n_quads) {
+                                                                 uint64_t n_quads, bool zero_tail = false) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_quads; i += stride)
-    __builtin_nontemporal_store(src[i], dst + i);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_quads; i += stride) {
+    const u64x2 v = src[i];
+    __builtin_nontemporal_store(v, dst + i);
+    if (zero_tail && i == n_quads - 1) const_cast<u64x2*>(src)[i] = u64x2{0, 0};
+  }
 }
 
 // the log owner's tail reports; records are unique per group within a launch (the host splits

@@ -246,3 +246,56 @@ def test_step_rejects_malformed_batches_and_applies_nothing(NodeEngine, oracle):
         assert len(out) == 0 and touched == 0
         with pytest.raises(RaftqError):
             e.apply_log_deltas([G], [1], [1])
+
+
+def test_list_walk_equals_sorted_walk_and_orders_stalled_batches(NodeEngine, oracle, monkeypatch):
+    """The default walk threads a batch's messages onto per-group lists (no sort) and takes runs of up to
+    32 messages; a batch with a longer run stalls the pipeline and is replayed, in order with the batch
+    behind it, through the sorted walk.  Every mix must give the sorted walk's -- the oracle's -- bytes:
+    short runs only, runs of exactly 32 and 33, a stalled batch first / second of two in flight."""
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(91)
+    G, N = 4096, 5
+    s = _stepgen.random_state(rng, G, N, 0)
+    s2 = _stepgen.random_state(np.random.default_rng(91), G, N, 0)  # an identical twin for the sorted-walk engine
+    monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    srt = NodeEngine(G, N, 0)
+    _stepgen.load_engine(srt, s2)
+    srt.step_batch(_stepgen.random_batch(np.random.default_rng(5), s2, 10))  # allocates its node state under the env
+    monkeypatch.delenv("RAFTQ_STEP_WALK")
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        w0 = _stepgen.random_batch(np.random.default_rng(5), s, 10)
+        assert np.array_equal(e.step_batch(w0)[0], s.step_batch(w0))
+
+        def run_of(k, g):  # k messages of one group + sparse traffic elsewhere
+            m = _stepgen.random_batch(rng, s, 600)
+            m["group"][:k] = g
+            return m
+
+        plan = [run_of(3, 7), run_of(32, 9), run_of(33, 11), run_of(1, 13), run_of(200, 9), run_of(31, 9)]
+        for m in plan:  # synchronous: each batch alone
+            want = s.step_batch(m)
+            got, touched = e.step_batch(m)
+            assert np.array_equal(got, want) and touched == len(np.unique(m["group"]))
+            assert np.array_equal(srt.step_batch(m)[0], want)
+        _stepgen.assert_same_state(e, s)
+        # two in flight: (long, short) and (short, long) on overlapping groups
+        for a, b in ((run_of(40, 21), run_of(5, 21)), (run_of(5, 22), run_of(40, 22)), (run_of(50, 23), run_of(60, 23))):
+            wa, wb = s.step_batch(a), s.step_batch(b)
+            e.step_submit(a)
+            e.step_submit(b)
+            with pytest.raises(RaftqError) as ei:  # state calls wait for the collects
+                e.read_node()
+            assert ei.value.code == _lib.RAFTQ_ESTATE
+            assert np.array_equal(e.step_collect()[0], wa) and np.array_equal(e.step_collect()[0], wb)
+            srt.step_batch(a)
+            srt.step_batch(b)
+        _stepgen.assert_same_state(e, s)
+        _stepgen.assert_same_state(srt, s)
+        # and the list walk resumes after a replay: a sparse batch behind it all
+        m = _stepgen.random_batch(rng, s, 3000)
+        assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))
+        _stepgen.assert_same_state(e, s)
+    srt.close()

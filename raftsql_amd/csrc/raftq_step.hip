@@ -389,11 +389,8 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     hipLaunchKernelGGL(wire_dec_kernel, grid1, dim3(kBlock), 0, h->stream, (const uint8_t*)s.w_stream, wire->nbytes,
                        (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, s.w_cnt, s.w_bad);
     HIPCHK(h, hipGetLastError());
-    size_t wb = s.w_cub_bytes;
-    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(s.w_cub, wb, (const uint64_t*)s.w_cnt, s.w_base, (int)(n + 1), h->stream));
-    hipLaunchKernelGGL(wire_dec_ents_kernel, grid, dim3(kBlock), 0, h->stream, (const uint8_t*)s.w_stream,
-                       (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base, s.w_ents, s.w_ents_cap);
-    HIPCHK(h, hipGetLastError());
+    // Step reads only the headers.  The entry headers (count -> scan -> second parse) are produced when
+    // raftq_step_wire_msgs / _entries first asks for them: fetch_wire below.
   }
   const bool lists = h->step_walk_mode == 1;
   if (lists) {
@@ -469,8 +466,18 @@ static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSl
   const size_t msg_bytes = (size_t)sl.n * sizeof(WireMsg);
   hipStream_t st = h->step_s_out;  // not behind whatever batch is in flight on the handle's stream
   if (!sl.w_msgs_fetched) {
-    // first request for this batch: learn the entry count, size the pinned block for both arrays
-    // (so a pointer handed out for the messages stays valid when the entries are asked for later)
+    // first request for this batch: the decoder's second pass (entry counts -> exclusive scan -> entry headers in
+    // message order, ent_first of every message), kept out of the Step chain because Step does not need it
+    Scratch s;
+    if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, true, sl.w_nbytes)) return rc;
+    size_t wb = s.w_cub_bytes;
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(s.w_cub, wb, (const uint64_t*)s.w_cnt, s.w_base, (int)(sl.n + 1), st));
+    hipLaunchKernelGGL(wire_dec_ents_kernel, dim3((unsigned)((sl.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       (const uint8_t*)s.w_stream, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base,
+                       s.w_ents, s.w_ents_cap);
+    HIPCHK(h, hipGetLastError());
+    // learn the entry count, size the pinned block for both arrays (so a pointer handed out for the messages
+    // stays valid when the entries are asked for later)
     uint64_t total = 0;
     HIPCHK(h, hipMemcpyAsync(&total, sl.w_ent_total_d, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));

@@ -562,6 +562,9 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* 
                                                                  WireMsg* __restrict__ msgs,
                                                                  uint64_t* __restrict__ ent_cnt,
                                                                  unsigned long long* n_bad) {
+  // (Staging each frame in an LDS row first -- one memory latency instead of ~20 dependent reads -- was tried and
+  // changed nothing: 17.5 us for 64K 40-byte frames either way.  At one wave per SIMD the kernel is bound by the
+  // dependent ALU chain of the field loop, not by memory; profiles/r01/wire_decode_lds_ab.txt.)
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool malformed = false;
   if (i < n) {

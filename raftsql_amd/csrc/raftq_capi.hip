@@ -270,6 +270,8 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->partials);
   (void)hipFree(h->offsets);
   (void)hipFree(h->claim);
+  (void)hipFree(h->delta_dev);
+  (void)hipFree(h->delta_bad);
   (void)hipFree(h->role);
   (void)hipFree(h->elapsed);
   (void)hipFree(h->action);
@@ -339,27 +341,52 @@ int raftq_load_votes(raftq_t* h, const uint8_t* votes) {
 
 // enqueue only (no sync): validate, copy into the pinned staging area at byte
 // offset `off`, launch the scatter.  Shared by raftq_apply_* and raftq_cycle.
+static int ensure_delta_dev(raftq_t* h, size_t bytes) {
+  if (!h->delta_bad) {
+    HIPCHK(h, hipMalloc((void**)&h->delta_bad, 64));
+    HIPCHK(h, hipMemsetAsync(h->delta_bad, 0, 64, h->stream));
+  }
+  if (bytes <= h->delta_dev_bytes) return RAFTQ_OK;
+  if (h->delta_dev) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(h->delta_dev));
+    h->delta_dev = nullptr;
+    h->delta_dev_bytes = 0;
+  }
+  const size_t want = std::max(bytes * 2, (size_t)1 << 20);
+  HIPCHK(h, hipMalloc(&h->delta_dev, want));
+  h->delta_dev_bytes = want;
+  return RAFTQ_OK;
+}
+
+// after the caller's sync: did the device find a bad record in the batch(es) enqueued since the last check?
+static int check_deltas(raftq_t* h) {
+  int rc = RAFTQ_OK;
+  if (h->delta_check[0] && h->h_total[1] == h->delta_check[0])
+    rc = fail(h, RAFTQ_EINVAL, "a match delta is out of range (group >= G or peer >= N); nothing applied");
+  if (h->delta_check[1] && h->h_total[2] == h->delta_check[1])
+    rc = fail(h, RAFTQ_EINVAL, "a vote delta is invalid (group/peer out of range or vote not 1/2); nothing applied");
+  h->delta_check[0] = h->delta_check[1] = 0;
+  return rc;
+}
+
+// enqueue only (no sync): copy into the pinned staging area at byte offset `off` unless the caller filled it in
+// place (raftq_stage), then device-side: bring the records into HBM validating them, scatter.  The verdict of the
+// validation is read by check_deltas() after the caller's sync.  Shared by raftq_apply_* and raftq_cycle.
 static int enqueue_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n, size_t off) {
   static_assert(sizeof(DeltaRec) == sizeof(raftq_delta_t), "ABI struct mismatch");
-  // one pass: range-check (branch-free OR-reduce) and, unless the caller filled
-  // the pinned staging area in place (raftq_stage), copy into it
   raftq_delta_t* dst = (raftq_delta_t*)((uint8_t*)h->stage_h + off);
-  const bool in_place = (const void*)d == (const void*)dst;
-  const uint64_t G = h->G, N = h->N;
-  uint64_t bad = 0;
-  if (in_place) {
-    for (uint64_t i = 0; i < n; ++i) bad |= (uint64_t)(d[i].group >= G) | (uint64_t)(d[i].peer >= N);
-  } else {
-    for (uint64_t i = 0; i < n; ++i) {
-      const raftq_delta_t r = d[i];
-      bad |= (uint64_t)(r.group >= G) | (uint64_t)(r.peer >= N);
-      dst[i] = r;
-    }
-  }
-  if (bad) return fail(h, RAFTQ_EINVAL, "a match delta is out of range (group >= G or peer >= N); nothing applied");
+  if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(raftq_delta_t));
+  // match and vote records share the device buffer: votes go behind the matches (same offsets as in staging)
+  if (int rc = ensure_delta_dev(h, h->stage_bytes)) return rc;
+  const unsigned long long epoch = ++h->delta_epoch;
+  h->delta_check[0] = epoch;
+  DeltaRec* dev = (DeltaRec*)((uint8_t*)h->delta_dev + off);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld,
-                     (const DeltaRec*)((uint8_t*)h->stage_d + off), n);
+  hipLaunchKernelGGL(deltas_in_kernel, grid, dim3(kBlock), 0, h->stream, (const DeltaRec*)((uint8_t*)h->stage_d + off), dev, n,
+                     h->G, h->N, h->delta_bad, h->d_total + 1, epoch);
+  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld, (const DeltaRec*)dev, n,
+                     (const unsigned long long*)h->delta_bad, epoch);
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
@@ -368,26 +395,23 @@ static int enqueue_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t
   static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
   if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
   raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off);
-  const bool in_place = (const void*)d == (const void*)dst;
-  {
-    const uint64_t G = h->G, N = h->N;
-    uint64_t bad = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-      const raftq_vote_delta_t r = d[i];
-      bad |= (uint64_t)(r.group >= G) | (uint64_t)(r.peer >= N) | (uint64_t)((unsigned)(r.vote - 1) > 1u);
-      if (!in_place) dst[i] = r;
-    }
-    if (bad) return fail(h, RAFTQ_EINVAL, "a vote delta is invalid (group/peer out of range or vote not 1/2); nothing applied");
-  }
+  if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(raftq_vote_delta_t));
   if (!h->claim) {
     const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
     HIPCHK(h, hipMalloc((void**)&h->claim, bytes));
     HIPCHK(h, hipMemsetAsync(h->claim, 0xff, bytes, h->stream));
   }
-  const VoteDeltaRec* dd = (const VoteDeltaRec*)((uint8_t*)h->stage_d + off);
+  if (int rc = ensure_delta_dev(h, h->stage_bytes)) return rc;
+  const unsigned long long epoch = ++h->delta_epoch;
+  h->delta_check[1] = epoch;
+  VoteDeltaRec* dev = (VoteDeltaRec*)((uint8_t*)h->delta_dev + off);
+  const unsigned long long* bad = h->delta_bad + 1;
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(vote_claim_kernel, grid, dim3(kBlock), 0, h->stream, h->claim, h->ld, dd, n);
-  hipLaunchKernelGGL(vote_apply_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, dd, n);
+  hipLaunchKernelGGL(vote_deltas_in_kernel, grid, dim3(kBlock), 0, h->stream, (const VoteDeltaRec*)((uint8_t*)h->stage_d + off),
+                     dev, n, h->G, h->N, h->delta_bad + 1, h->d_total + 2, epoch);
+  hipLaunchKernelGGL(vote_claim_kernel, grid, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev, n, bad, epoch);
+  hipLaunchKernelGGL(vote_apply_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, (const VoteDeltaRec*)dev, n,
+                     bad, epoch);
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
@@ -399,7 +423,7 @@ int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
   if (int rc = enqueue_deltas(h, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging area is reused by the next call
-  return RAFTQ_OK;
+  return check_deltas(h);
 }
 
 int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n) {
@@ -438,7 +462,7 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
   if (int rc = enqueue_vote_deltas(h, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return RAFTQ_OK;
+  return check_deltas(h);
 }
 
 int raftq_step_async(raftq_t* h, unsigned flags) {
@@ -788,6 +812,12 @@ int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, cons
   h->prof[3] += us(t2, t3);
   h->prof[4] += us(t3, t4);
   h->prof_n++;
+  if (int rc = check_deltas(h)) {  // the device found a record out of range: none of the batch was scattered
+    if (n_advanced) *n_advanced = 0;
+    if (counts) *counts = raftq_counts_t{0, 0, 0};
+    h->adv_listed = 0;
+    return rc;
+  }
   if (counts) {
     uint64_t c = 0, w = 0, l = 0;
     for (uint64_t i = 0; i < h->n_partials; ++i) {

@@ -37,6 +37,12 @@ struct raftq {
   uint64_t adv_cap = 0;
   uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
   uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
+  // sparse ingest: device copy of the batch (validated on the way in) and the "bad batch" epoch words
+  void* delta_dev = nullptr;
+  size_t delta_dev_bytes = 0;
+  unsigned long long* delta_bad = nullptr;  // device: [0] match deltas, [1] vote deltas -- epoch of the last bad batch
+  unsigned long long delta_epoch = 0;       // batches enqueued so far
+  unsigned long long delta_check[2] = {0, 0};  // epochs whose host-visible flag (h_total[1], [2]) is still to be checked
   // batched Tick state, lazily allocated
   uint8_t* role = nullptr;      // [ld]
   uint32_t* elapsed = nullptr;  // [ld]

@@ -403,8 +403,32 @@ struct VoteDeltaRec {  // == raftq_vote_delta_t
 
 // Progress.maybeUpdate only ever raises Match, so a batch of MsgAppResp
 // deltas is an order-independent atomic max.
+// Ingest, pass 1: the records sit in pinned, device-mapped host memory (the caller's batch buffer); one coalesced
+// read over PCIe brings them into HBM and range-checks them on the way.  A bad record stamps this batch's epoch
+// into *bad_epoch (device) and *bad_host (mapped host word): pass 2 then applies nothing, and the host reports
+// RAFTQ_EINVAL after its sync -- the all-or-nothing rule of the ABI without a 65K-iteration host loop (36 us).
+static __global__ __launch_bounds__(kBlock) void deltas_in_kernel(const DeltaRec* __restrict__ src, DeltaRec* __restrict__ dst,
+                                                                  uint64_t n, uint64_t n_groups, uint32_t n_peers,
+                                                                  unsigned long long* bad_epoch, uint64_t* bad_host,
+                                                                  unsigned long long epoch) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const DeltaRec r = src[i];
+    dst[i] = r;
+    bad = r.group >= n_groups || r.peer >= n_peers;
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) {
+    atomicMax(bad_epoch, epoch);
+    *bad_host = epoch;
+  }
+}
+
 static __global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld,
-                                                              const DeltaRec* __restrict__ d, uint64_t n) {
+                                                              const DeltaRec* __restrict__ d, uint64_t n,
+                                                              const unsigned long long* bad_epoch,
+                                                              unsigned long long epoch) {
+  if (*bad_epoch == epoch) return;  // a record of this batch is out of range: nothing is applied
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const DeltaRec r = d[i];
@@ -432,8 +456,29 @@ static __global__ __launch_bounds__(kBlock) void apply_term_deltas_kernel(uint64
 // atomicMin(batch position); (2) only the claim holder writes the vote (if the
 // slot is still unanswered) and then releases the claim for the next batch.
 // claim[] is u32 [N][ld], UINT32_MAX when free.
+static __global__ __launch_bounds__(kBlock) void vote_deltas_in_kernel(const VoteDeltaRec* __restrict__ src,
+                                                                       VoteDeltaRec* __restrict__ dst, uint64_t n,
+                                                                       uint64_t n_groups, uint32_t n_peers,
+                                                                       unsigned long long* bad_epoch, uint64_t* bad_host,
+                                                                       unsigned long long epoch) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const VoteDeltaRec r = src[i];
+    dst[i] = r;
+    bad = r.group >= n_groups || r.peer >= n_peers || (unsigned)(r.vote - 1) > 1u;
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) {
+    atomicMax(bad_epoch, epoch);
+    *bad_host = epoch;
+  }
+}
+
 static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uint64_t ld,
-                                                            const VoteDeltaRec* __restrict__ d, uint64_t n) {
+                                                            const VoteDeltaRec* __restrict__ d, uint64_t n,
+                                                            const unsigned long long* bad_epoch,
+                                                            unsigned long long epoch) {
+  if (*bad_epoch == epoch) return;
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const VoteDeltaRec r = d[i];
@@ -441,7 +486,10 @@ static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* cla
 }
 
 static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
-                                                            const VoteDeltaRec* __restrict__ d, uint64_t n) {
+                                                            const VoteDeltaRec* __restrict__ d, uint64_t n,
+                                                            const unsigned long long* bad_epoch,
+                                                            unsigned long long epoch) {
+  if (*bad_epoch == epoch) return;
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const VoteDeltaRec r = d[i];

@@ -380,12 +380,10 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   const bool fused_tail = mode == 2 || mode == 3;
   if (!sl.tail_zeroed || sl.tail_n != n || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
   sl.tail_zeroed = false;
-  unsigned int* bad = (unsigned int*)(s.n_heads + 1);
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   if (wire) {
-    // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe
+    // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe.  (s.w_bad only counts
+    // malformed frames for raftq_wire_decode's callers; here a malformed frame fails the batch through its flag byte.)
     const dim3 grid1((unsigned)((n + 1 + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.w_bad);  // zeroes 16 bytes from w_bad
     hipLaunchKernelGGL(wire_dec_kernel, grid1, dim3(kBlock), 0, h->stream, (const uint8_t*)s.w_stream, wire->nbytes,
                        (const uint64_t*)s.w_off, n, (WireMsg*)s.msgs, s.w_cnt, s.w_bad);
     HIPCHK(h, hipGetLastError());

@@ -258,6 +258,20 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
         e.step_collect(copy=False)
     dt_pipe_staged = time.perf_counter() - t0
     e.step_collect(copy=False)
+    # (d) the same with 40-byte result records (raftq_step_set_compact): the result copy is what a batch waits for
+    e.set_compact(True)
+    for b in bs[1:3]:
+        st = e.step_stage(msgs_per_batch)
+        st[:] = b
+        e.step_submit(st)
+    e.step_collect(copy=False)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e.step_submit(e.step_stage(msgs_per_batch))
+        e.step_collect(copy=False)
+    dt_pipe_compact = time.perf_counter() - t0
+    e.step_collect(copy=False)
+    e.set_compact(False)
     out = {"what": "raftq_step_batch: batched raft.Step (MsgAppResp / MsgHeartbeatResp / MsgVote mix) over "
                    "device-resident node state; wall time of the call incl. PCIe both ways (64 B in + 64 B out per "
                    "message) and its one sync; zero-copy staging form",
@@ -267,7 +281,10 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
            "pipelined": {"what": "two batches in flight (submit/collect), zero-copy staging",
                          "us_per_batch": dt_pipe_staged / reps * 1e6,
                          "msgs_per_s": msgs_per_batch * reps / dt_pipe_staged,
-                         "us_per_batch_caller_owned_arrays": dt_pipe / (batches - 1) * 1e6}}
+                         "us_per_batch_caller_owned_arrays": dt_pipe / (batches - 1) * 1e6,
+                         "compact_results": {"what": "40-byte result records (raftq_step_set_compact)",
+                                             "us_per_batch": dt_pipe_compact / reps * 1e6,
+                                             "msgs_per_s": msgs_per_batch * reps / dt_pipe_compact}}}
     e.close()
     if with_cpu:
         from oracle import pyoracle  # cpu_baseline leg: the sequential restatement, one thread

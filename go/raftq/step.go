@@ -57,6 +57,33 @@ const (
 	FlagSteppedDown = C.RAFTQ_OUTF_STEPPED_DOWN
 )
 
+// StepOutC is layout-identical to raftq_step_out_c_t (40 bytes): the result record without what the caller's
+// own batch already says (group, addressee); Aux = LogTerm for OutCampaign / OutBecameLeader, LastIndex otherwise.
+type StepOutC struct {
+	Term, Index, Commit, Aux            uint64
+	Vote, Lead, Type, Reject, Flags, Role uint8
+	_                                   [2]uint8
+}
+
+// SetCompact switches the result format (no batch in flight); StepResultsC reads the records of the batch
+// collected last in place (valid until the next submit).
+func (e *Engine) SetCompact(on bool) error {
+	v := C.int(0)
+	if on {
+		v = 1
+	}
+	return e.err(C.raftq_step_set_compact(e.h, v))
+}
+
+func (e *Engine) StepResultsC() ([]StepOutC, error) {
+	var p *C.raftq_step_out_c_t
+	var n C.uint64_t
+	if rc := C.raftq_step_results_c(e.h, &p, &n); rc != C.RAFTQ_OK {
+		return nil, e.err(rc)
+	}
+	return unsafe.Slice((*StepOutC)(unsafe.Pointer(p)), int(n)), nil
+}
+
 // LogDelta is layout-identical to raftq_log_delta_t.
 type LogDelta struct{ Group, LastIndex, LastTerm, CommitTo uint64 }
 

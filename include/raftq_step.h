@@ -146,6 +146,28 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_ste
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n);
 
+/* Compact result records: 40 instead of 64 bytes per message cross PCIe (the result copy is what a pipelined
+ * batch waits for).  Record i answers msgs[i], so its group and addressee (= msgs[i].group, msgs[i].from) are not
+ * repeated; `aux` is log_term for RAFTQ_OUT_CAMPAIGN / RAFTQ_OUT_BECAME_LEADER -- whose `index` is the last index --
+ * and raftLog.lastIndex() for every other type (whose log_term is 0): the full record is recovered exactly.
+ * While the format is on, raftq_step_collect / _batch take out == NULL and the records are read in place through
+ * raftq_step_results_c (valid until the next submit).  Switch only with no batch in flight. */
+typedef struct raftq_step_out_c {
+  uint64_t term;   /* r.Term after the message */
+  uint64_t index;  /* by type, as raftq_step_out_t */
+  uint64_t commit; /* raftLog.committed after */
+  uint64_t aux;    /* see above */
+  uint8_t vote;    /* 0 = None, else peer slot + 1 */
+  uint8_t lead;
+  uint8_t type;    /* RAFTQ_OUT_* */
+  uint8_t reject;
+  uint8_t flags;   /* RAFTQ_OUTF_* */
+  uint8_t role;
+  uint8_t _pad[2];
+} raftq_step_out_c_t; /* 40 bytes */
+int raftq_step_set_compact(raftq_t* h, int on);
+int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n);
+
 /* records of one group are applied in order; committed_out (may be NULL) receives
  * raftLog.committed after record i -- how a commit moved by a tail report (a leader that
  * is its own quorum, a follower's commitTo) surfaces, the way Ready.HardState.Commit does */

@@ -70,6 +70,7 @@ struct raftq {
   uint32_t* lst_cnt = nullptr;     // [ld]
   uint32_t* lst_min = nullptr;     // [ld]
   unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
+  bool step_compact = false;       // result records in the 40-byte format (raftq_step_set_compact)
   int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)
   uint64_t step_replays = 0;       // batches that went through the sorted path after a stall
   // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
@@ -89,8 +90,10 @@ struct raftq {
     bool lists = false;            // submitted through the sort-free walk
     bool replayed = false;         // already re-run through the sorted path (after a stall)
     int end_bit = 0;
+    uint32_t rec = 64;             // bytes per result record of this batch (64, or 40 compact)
     bool tail_zeroed = false;      // the device copy of the 16-byte result tail is known to be zero (for tail_n, tail_dev)
     uint64_t tail_n = 0;
+    uint32_t tail_rec = 0;
     const void* tail_dev = nullptr;
     uint64_t w_nbytes = 0;
     // raftq_step_submit_wire: where this batch's decoded records sit in `dev`, and the pinned
@@ -111,6 +114,7 @@ struct raftq {
   int step_stream_mode = 2;
   const void* step_last_out = nullptr;  // results of the last collected batch
   uint64_t step_last_n = 0;
+  uint32_t step_last_rec = 64;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // wire / WAL codecs (raftq_wire.hip): growable device scratch (inputs + temporaries), device
   // output buffer, a small pinned block for totals / flags

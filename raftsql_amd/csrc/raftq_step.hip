@@ -25,7 +25,7 @@ using raftq_detail::fail;
 using raftq_detail::use_device;
 
 static_assert(sizeof(raftq_msg_t) == sizeof(MsgRec) && sizeof(raftq_step_out_t) == sizeof(StepOutRec) &&
-                  sizeof(raftq_log_delta_t) == sizeof(LogDeltaRec),
+                  sizeof(raftq_log_delta_t) == sizeof(LogDeltaRec) && sizeof(raftq_step_out_c_t) == sizeof(StepOutC),
               "ABI struct mismatch");
 
 namespace {
@@ -76,7 +76,7 @@ NodeArrays node_arrays(raftq_t* h) {
 // device scratch of one batch, carved from a single allocation
 struct Scratch {
   MsgRec* msgs;
-  StepOutRec* outs;
+  void* outs;  // StepOutRec[n] or StepOutC[n], then the 16-byte tail at tail_off(n, rec)
   uint64_t *keys_in, *keys_out;
   uint32_t *order_in, *order_out;
   uint32_t* next;  // sort-free walk: list links
@@ -95,6 +95,8 @@ struct Scratch {
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+// result area: n records of `rec` bytes, then (16-byte aligned) the {touched count, bad, skipped} tail
+size_t tail_off(uint64_t n, uint32_t rec) { return ((size_t)n * rec + 15) / 16 * 16; }
 
 int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratch* s, bool wire = false,
                 uint64_t wire_nbytes = 0) {
@@ -106,7 +108,9 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
     // a kernel that writes to host memory over PCIe keeps every other queue's NEXT kernel from starting
     // until it retires (a kernel that merely spins does not), so a third stream for the D2H buys nothing
     // (3: 186 us per 64K batch, 2: 176 us, 1 = everything on one stream: 426 us, 4 = copies share a stream: 459 us).
-    // RAFTQ_STEP_STREAMS overrides it for A/B runs.
+    // Round 2 of that A/B (profiles/r01/step_result_copy_ab.txt): the runtime's own D2H memcpy instead of our kernel
+    // (382-394 us), the copy split into 2-32 short kernels (177-185 us), the walk writing straight into mapped host
+    // memory (186 us) -- none beat 2; those variants are no longer in the code.  RAFTQ_STEP_STREAMS = 1..4 overrides.
     if (const char* m = std::getenv("RAFTQ_STEP_STREAMS")) h->step_stream_mode = std::atoi(m);
   }
   if (!sl.ev_in) {
@@ -123,7 +127,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   // the 16-byte {touched count, bad flag} tail sits right behind the result records: one copy moves both
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
                o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes), o_next = carve(n * 4);
-  const size_t o_nh = o_outs + n * sizeof(StepOutRec);
+  const size_t o_nh = o_outs + tail_off(n, h->step_compact ? sizeof(StepOutC) : sizeof(StepOutRec));
   // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
   size_t w_cub_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wcub = 0;
@@ -163,7 +167,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   }
   uint8_t* base = (uint8_t*)sl.dev;
   s->msgs = (MsgRec*)(base + o_msgs);
-  s->outs = (StepOutRec*)(base + o_outs);
+  s->outs = base + o_outs;
   s->keys_in = (uint64_t*)(base + o_ki);
   s->keys_out = (uint64_t*)(base + o_ko);
   s->order_in = (uint32_t*)(base + o_oi);
@@ -277,8 +281,28 @@ int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   if (!out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results: null argument");
+  if (h->step_last_out && h->step_last_rec != sizeof(StepOutRec))
+    return fail(h, RAFTQ_ESTATE, "raftq_step_results: the last batch has compact records (raftq_step_results_c)");
   *out = (const raftq_step_out_t*)h->step_last_out;
   *n = h->step_last_n;
+  return RAFTQ_OK;
+}
+
+int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results_c: null argument");
+  if (h->step_last_out && h->step_last_rec != sizeof(StepOutC))
+    return fail(h, RAFTQ_ESTATE, "raftq_step_results_c: the last batch has full records (raftq_step_results)");
+  *out = (const raftq_step_out_c_t*)h->step_last_out;
+  *n = h->step_last_n;
+  return RAFTQ_OK;
+}
+
+int raftq_step_set_compact(raftq_t* h, int on) {
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_step_set_compact")) return rc;
+  h->step_compact = on != 0;
+  h->step_last_out = nullptr;
+  h->step_last_n = 0;
   return RAFTQ_OK;
 }
 
@@ -299,7 +323,7 @@ static ListArrays list_arrays(raftq_t* h) {
 }
 
 // key -> stable radix sort -> walk, on the handle's stream (the path that takes runs of any length)
-static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, bool from_wire, StepOutRec* outs) {
+static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, bool from_wire, void* outs) {
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
@@ -309,7 +333,7 @@ static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end
   HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
                                                (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
   hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
-                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, outs, n, s.n_heads,
+                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, outs, h->step_compact, n, s.n_heads,
                      (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
@@ -322,8 +346,8 @@ static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(step_link_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G, h->N, from_wire,
                      list_arrays(h), s.next, bad, h->step_stall);
-  hipLaunchKernelGGL(step_lists_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs, s.outs, n,
-                     h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped, (const unsigned int*)bad,
+  hipLaunchKernelGGL(step_lists_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs, s.outs,
+                     h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped, (const unsigned int*)bad,
                      (const unsigned int*)h->step_stall);
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
@@ -369,16 +393,15 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   // call on the handle) -> copy-out stream, chained by events
   const int mode = h->step_stream_mode;
   hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
-  // 5, 6: as 3 / 2, but the result copy is a runtime memcpy (DMA engine when the runtime picks one) instead of our kernel
-  hipStream_t s_out = (mode == 1 || mode == 2 || mode == 6 || mode == 8) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
+  hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
   HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
   if (s_in != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
   }
   // touched count + bad + skipped: the default result copy leaves them zeroed behind it (step_d2h_kernel zero_tail)
-  const bool fused_tail = mode == 2 || mode == 3;
-  if (!sl.tail_zeroed || sl.tail_n != n || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
+  const uint32_t rec = h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
+  if (!sl.tail_zeroed || sl.tail_n != n || sl.tail_rec != rec || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
   sl.tail_zeroed = false;
   if (wire) {
     // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe.  (s.w_bad only counts
@@ -394,45 +417,27 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   if (lists) {
     if (int rc = enqueue_list_walk(h, s, n, wire != nullptr)) return rc;
   } else {
-    // 8: the walk writes its result records straight into the pinned, device-mapped result area (no copy kernel)
-    if (int rc = enqueue_sorted_walk(h, s, n, end_bit, wire != nullptr, mode == 8 ? (StepOutRec*)sl.out_d : s.outs)) return rc;
+    if (int rc = enqueue_sorted_walk(h, s, n, end_bit, wire != nullptr, s.outs)) return rc;
   }
   if (s_out != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
     HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
   }
-  const uint64_t out_quads = n * 4 + 1;  // records + the 16-byte tail
-  if (mode == 5 || mode == 6) {
-    HIPCHK(h, hipMemcpyAsync(sl.out_h, s.outs, (size_t)out_quads * 16, hipMemcpyDeviceToHost, s_out));
-  } else if (mode == 8 && !lists) {
-    hipLaunchKernelGGL(step_d2h_kernel, dim3(1), dim3(kBlock), 0, s_out, (const u64x2*)s.n_heads,
-                       (u64x2*)((uint8_t*)sl.out_d + (size_t)n * sizeof(StepOutRec)), (uint64_t)1);
-    HIPCHK(h, hipGetLastError());
-  } else if (mode == 7) {
-    // the result copy as several short kernels on its own stream: a kernel with PCIe writes in flight holds back
-    // kernel starts on the other queues only until it retires, so short ones let the next batch's chain interleave
-    static const int chunks = [] { const char* c = std::getenv("RAFTQ_STEP_D2H_CHUNKS"); return c ? std::max(1, std::atoi(c)) : 8; }();
-    const uint64_t per = (out_quads + chunks - 1) / chunks;
-    for (uint64_t q0 = 0; q0 < out_quads; q0 += per) {
-      const uint64_t nq = std::min(per, out_quads - q0);
-      hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                         s_out, (const u64x2*)s.outs + q0, (u64x2*)sl.out_d + q0, nq);
-    }
-    HIPCHK(h, hipGetLastError());
-  } else {
-    hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads, fused_tail);
-    HIPCHK(h, hipGetLastError());
-    sl.tail_zeroed = fused_tail;  // holds for the next batch of the same size in the same scratch
-    sl.tail_n = n;
-    sl.tail_dev = sl.dev;
-  }
+  const uint64_t out_quads = tail_off(n, rec) / 16 + 1;  // records + the 16-byte tail
+  hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads, true);
+  HIPCHK(h, hipGetLastError());
+  sl.tail_zeroed = true;  // holds for the next batch of the same size and format in the same scratch
+  sl.tail_n = n;
+  sl.tail_rec = rec;
+  sl.tail_dev = sl.dev;
   HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
   sl.n = n;
   sl.busy = true;
   sl.lists = lists;
   sl.replayed = false;
   sl.end_bit = end_bit;
+  sl.rec = rec;
   sl.w_nbytes = wire ? wire->nbytes : 0;
   sl.wire = wire != nullptr;
   sl.w_msgs_d = s.msgs;
@@ -538,7 +543,7 @@ static int replay_stalled(raftq_t* h, int first_slot) {
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, sl.wire, sl.w_nbytes)) return rc;
     hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
     if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.wire, s.outs)) return rc;
-    const uint64_t out_quads = sl.n * 4 + 1;
+    const uint64_t out_quads = tail_off(sl.n, sl.rec) / 16 + 1;
     hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, h->stream, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
     HIPCHK(h, hipGetLastError());
@@ -562,7 +567,7 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   h->step_last_slot = (int)(h->step_collected & 1);
   h->step_collected++;
   const uint64_t n = sl.n;
-  const uint8_t* tail = (const uint8_t*)sl.out_h + (size_t)n * sizeof(StepOutRec);
+  const uint8_t* tail = (const uint8_t*)sl.out_h + tail_off(n, sl.rec);
   unsigned long long heads;
   unsigned int bad_h, skipped_h;
   std::memcpy(&skipped_h, tail + 12, 4);
@@ -582,7 +587,12 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   }
   h->step_last_out = sl.out_h;
   h->step_last_n = n;
-  if (out) std::memcpy(out, sl.out_h, (size_t)n * sizeof(StepOutRec));
+  h->step_last_rec = sl.rec;
+  if (out) {
+    if (sl.rec != sizeof(StepOutRec))
+      return fail(h, RAFTQ_EINVAL, "raftq_step_collect: compact result records are read in place (raftq_step_results_c), pass out = NULL");
+    std::memcpy(out, sl.out_h, (size_t)n * sizeof(StepOutRec));
+  }
   if (counts) {
     counts->n_msgs = n;
     counts->n_groups_touched = heads;
@@ -600,6 +610,8 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
   h->step_last_n = 0;
   if (n == 0) return RAFTQ_OK;
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_batch: null messages");
+  if (out && h->step_compact)
+    return fail(h, RAFTQ_EINVAL, "raftq_step_batch: compact result records are read in place (raftq_step_results_c), pass out = NULL");
   if (int rc = raftq_step_submit(h, msgs, n)) return rc;
   return raftq_step_collect(h, out, counts);
 }

@@ -34,7 +34,12 @@ struct StepOutRec {  // == raftq_step_out_t
 struct LogDeltaRec {  // == raftq_log_delta_t
   uint64_t group, last_index, last_term, commit_to;
 };
-static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32, "record layout");
+struct StepOutC {  // == raftq_step_out_c_t: the result record without what the caller's own batch already says
+  uint64_t term, index, commit, aux;
+  uint8_t vote, lead, type, reject, flags, role, pad[2];
+};
+static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32 && sizeof(StepOutC) == 40,
+              "record layout");
 
 struct NodeArrays {
   uint8_t* role;
@@ -58,6 +63,28 @@ constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCam
                   kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7;
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
+
+// result record i, in the handle's format.  Compact drops group and addressee (= msgs[i].group / .from) and folds
+// log_term / last_index into one slot: log_term is only set by the two result types whose index IS last_index.
+__device__ __forceinline__ void put_result(void* out, uint64_t i, const StepOutRec& o, bool compact) {
+  if (!compact) {
+    static_cast<StepOutRec*>(out)[i] = o;
+    return;
+  }
+  StepOutC c;
+  c.term = o.term;
+  c.index = o.index;
+  c.commit = o.commit;
+  c.aux = (o.type == kOutCampaign || o.type == kOutBecameLeader) ? o.log_term : o.last_index;
+  c.vote = (uint8_t)o.vote;
+  c.lead = (uint8_t)o.lead;
+  c.type = o.type;
+  c.reject = o.reject;
+  c.flags = o.flags;
+  c.role = o.role;
+  c.pad[0] = c.pad[1] = 0;
+  static_cast<StepOutC*>(out)[i] = c;
+}
 
 // zero the batch's {touched-group count, bad flag} (a plain kernel: no runtime blit in the chain)
 static __global__ void step_reset_kernel(unsigned long long* flags) {
@@ -273,8 +300,8 @@ struct Node {
 
 static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
                                                       const uint64_t* __restrict__ keys_sorted,
-                                                      const uint32_t* __restrict__ order, StepOutRec* __restrict__ out,
-                                                      uint64_t n, unsigned long long* n_heads,
+                                                      const uint32_t* __restrict__ order, void* __restrict__ out,
+                                                      bool compact, uint64_t n, unsigned long long* n_heads,
                                                       const unsigned int* bad) {
   if (*bad) return;  // a malformed record somewhere in the batch: nothing is applied
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -293,7 +320,7 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
     const MsgRec m = msgs[i];
     StepOutRec o;
     node.step(m, o);
-    out[i] = o;
+    put_result(out, i, o, compact);
   }
   node.store();
 }
@@ -343,7 +370,7 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
 }
 
 static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
-                                                                   StepOutRec* __restrict__ out, uint64_t n,
+                                                                   void* __restrict__ out, bool compact, uint64_t n,
                                                                    uint64_t n_groups, ListArrays l,
                                                                    const uint32_t* __restrict__ next,
                                                                    unsigned long long* n_heads, unsigned int* tail_skipped,
@@ -374,7 +401,7 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
   if (c == 1) {
     StepOutRec o;
     node.step(msgs[i], o);
-    out[i] = o;
+    put_result(out, i, o, compact);
   } else {
     uint32_t pos[kMaxRun];
     uint32_t p = l.head[g];
@@ -391,7 +418,7 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
       const MsgRec m = msgs[pos[k]];
       StepOutRec o;
       node.step(m, o);
-      out[pos[k]] = o;
+      put_result(out, pos[k], o, compact);
     }
   }
   node.store();

@@ -31,8 +31,11 @@ MSG_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("log_term", "<u8"), ("ind
 OUT_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("log_term", "<u8"), ("commit", "<u8"),
                    ("last_index", "<u8"), ("to", "<u4"), ("vote", "<u4"), ("lead", "<u4"), ("type", "u1"),
                    ("reject", "u1"), ("flags", "u1"), ("role", "u1")])
+# raftq_step_out_c_t: the 40-byte result record (raftq_step_set_compact)
+OUT_C_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("aux", "<u8"), ("vote", "u1"), ("lead", "u1"),
+                     ("type", "u1"), ("reject", "u1"), ("flags", "u1"), ("role", "u1"), ("_pad", "u1", (2,))])
 LOG_DELTA_DT = np.dtype([("group", "<u8"), ("last_index", "<u8"), ("last_term", "<u8"), ("commit_to", "<u8")])
-assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32
+assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32 and OUT_C_DT.itemsize == 40
 
 
 def pack_msgs(group, type, term=0, frm=0, index=0, log_term=0, commit=0, reject=0, reject_hint=0) -> np.ndarray:
@@ -44,13 +47,31 @@ def pack_msgs(group, type, term=0, frm=0, index=0, log_term=0, commit=0, reject=
     return a
 
 
+def expand_compact(msgs: np.ndarray, recs: np.ndarray) -> np.ndarray:
+    """raftq_step_out_c_t[] + the batch it answers -> raftq_step_out_t[] (exact: see include/raftq_step.h)"""
+    o = np.zeros(len(recs), dtype=OUT_DT)
+    o["group"], o["to"] = msgs["group"], msgs["from"]
+    for k in ("term", "index", "commit", "vote", "lead", "type", "reject", "flags", "role"):
+        o[k] = recs[k]
+    tip = (recs["type"] == OUT_CAMPAIGN) | (recs["type"] == OUT_BECAME_LEADER)  # index IS the last index there
+    o["log_term"] = np.where(tip, recs["aux"], 0)
+    o["last_index"] = np.where(tip, recs["index"], recs["aux"])
+    return o
+
+
 class NodeEngine(QuorumEngine):
     """G raft groups' node state on one GPU + batched Step."""
 
     def __init__(self, n_groups: int, n_peers: int, self_peer: int = 0, device: int = 0):
         super().__init__(n_groups, n_peers, device=device)
+        self.compact = False
         self.self_peer = int(self_peer)
         self._chk(self._lib.raftq_set_self(self._h, self.self_peer))
+
+    def set_compact(self, on: bool = True) -> None:
+        """result records in the 40-byte format from now on (no batch may be in flight)"""
+        self._chk(self._lib.raftq_step_set_compact(self._h, int(on)))
+        self.compact = bool(on)
 
     def load_node(self, term=None, vote=None, lead=None, last_index=None, last_term=None) -> None:
         def arr(x, dt):
@@ -117,14 +138,17 @@ class NodeEngine(QuorumEngine):
         self._chk(self._lib.raftq_step_submit(self._h, _ptr(msgs), len(msgs)))
 
     def step_collect(self, copy: bool = True):
-        """results of the oldest batch in flight -> (raftq_step_out_t[], n_groups_touched); with
+        """results of the oldest batch in flight -> (records, n_groups_touched): raftq_step_out_t[], or
+        raftq_step_out_c_t[] while the compact format is on (expand_compact() restores the full records); with
         copy=False the array is a view of pinned memory, valid until the next submit"""
         c = _lib.StepCounts()
         self._chk(self._lib.raftq_step_collect(self._h, None, C.byref(c)))
         p, k = C.c_void_p(None), C.c_uint64(0)
-        self._chk(self._lib.raftq_step_results(self._h, C.byref(p), C.byref(k)))
-        buf = (C.c_char * (k.value * OUT_DT.itemsize)).from_address(p.value)
-        a = np.frombuffer(buf, dtype=OUT_DT, count=k.value)
+        dt = OUT_C_DT if self.compact else OUT_DT
+        fn = self._lib.raftq_step_results_c if self.compact else self._lib.raftq_step_results
+        self._chk(fn(self._h, C.byref(p), C.byref(k)))
+        buf = (C.c_char * (k.value * dt.itemsize)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=k.value)
         return (a.copy() if copy else a), int(c.n_groups_touched)
 
     def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> np.ndarray:

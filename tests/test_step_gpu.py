@@ -299,3 +299,48 @@ def test_list_walk_equals_sorted_walk_and_orders_stalled_batches(NodeEngine, ora
         assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))
         _stepgen.assert_same_state(e, s)
     srt.close()
+
+
+def test_compact_result_records_expand_to_the_full_ones(NodeEngine, oracle):
+    """raftq_step_set_compact: 40-byte result records (what the caller's batch already says is not repeated).
+    Expanded with the batch they answer they are the oracle's 64-byte records, byte for byte -- list walk, stall
+    replays and the sorted walk alike, two batches in flight; switching back restores the full format."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(57)
+    G, N = 3000, 5
+    s = _stepgen.random_state(rng, G, N, 2)
+    with NodeEngine(G, N, 2) as e:
+        _stepgen.load_engine(e, s)
+        e.set_compact(True)
+        prev = None
+        kinds = set()
+        for it in range(14):
+            hot = rng.choice(G, 30) if it % 3 == 0 else None  # runs of ~100 -> the replay path
+            m = _stepgen.random_batch(rng, s, int(rng.integers(1, 5000)), hot_groups=hot)
+            want = s.step_batch(m)
+            e.step_submit(m)
+            if prev is not None:
+                got, touched = e.step_collect()
+                assert got.dtype == S.OUT_C_DT and np.array_equal(S.expand_compact(prev[0], got), prev[1]) and touched == prev[2]
+                kinds |= set(np.unique(got["type"]).tolist())
+            prev = (m, want, len(np.unique(m["group"])))
+        got, touched = e.step_collect()
+        assert np.array_equal(S.expand_compact(prev[0], got), prev[1]) and touched == prev[2]
+        assert {S.OUT_CAMPAIGN, S.OUT_BECAME_LEADER, S.OUT_PROGRESS, S.OUT_VOTE_RESP} <= kinds  # aux was used both ways
+        _stepgen.assert_same_state(e, s)
+        m = _stepgen.random_batch(rng, s, 100)
+        with pytest.raises(RaftqError) as ei:
+            e.step_batch(m)  # the synchronous form with a caller-owned 64-byte array: refused, nothing applied
+        assert ei.value.code == _lib.RAFTQ_EINVAL
+        _stepgen.assert_same_state(e, s)
+        e.step_submit(m)
+        with pytest.raises(RaftqError):
+            e.set_compact(False)  # not with a batch in flight
+        got, _ = e.step_collect()
+        assert np.array_equal(S.expand_compact(m, got), s.step_batch(m))
+        e.set_compact(False)
+        m = _stepgen.random_batch(rng, s, 2000)
+        assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))
+        _stepgen.assert_same_state(e, s)

@@ -258,3 +258,27 @@ def test_campaign_semantics(oracle):
     assert list(r) == [1, 2, 0, 1] and list(e) == [0, 6, 7, 0]
     assert v[:, 0].tolist() == [1, 0, 0] and v[:, 3].tolist() == [1, 0, 0]
     assert v[:, 1].tolist() == [2, 2, 2] and v[:, 2].tolist() == [2, 2, 2]
+
+
+@pytest.mark.parametrize("case", KAT["upstream_TestCommit_recalled"]["cases"])
+def test_upstream_testcommit_table_as_recalled(oracle, case):
+    """etcd's own raft_test.go TestCommit table, as recalled (the module is absent: alignment evidence, not a pin).
+    Checked three ways: the reference-shaped sort loop + a term lookup in the case's log, the oracle's full-log
+    function, and the compact gate the kernels use."""
+    from raftsql_amd import synth
+
+    match, terms, sm, want = case["matches"], case["log_terms"], case["sm_term"], case["w"]
+    n = len(match)
+    mci = sorted(match, reverse=True)[n // 2]
+    term_of = terms[mci - 1] if 1 <= mci <= len(terms) else 0
+    assert (mci if (mci > 0 and term_of == sm) else 0) == want
+    # compact gate: first index of sm_term in the log (0 = none)
+    first = next((i + 1 for i, t in enumerate(terms) if t == sm), 0)
+    m = np.array(match, np.uint64).reshape(n, 1)
+    out, _ = oracle.commit_advance(m, np.zeros(1, np.uint64), True, np.array([first], np.uint64))
+    assert int(out[0]) == want
+    # the oracle's full-log lookup on a run-length log built from the case
+    starts = [i + 1 for i, t in enumerate(terms) if i == 0 or terms[i - 1] != t]
+    rterms = [terms[s - 1] for s in starts]
+    got = mci if (mci > 0 and oracle.log_term(starts, rterms, len(terms), mci) == sm) else 0
+    assert got == want

@@ -121,6 +121,15 @@ def test_hand_derived_known_answers(gpu_engine_cls):
             out, cnt = e.vote_tally()
             assert int(out[0]) == case["outcome"], case
             assert (cnt.n_won, cnt.n_lost) == (int(case["outcome"] == 1), int(case["outcome"] == 2))
+    # etcd's own TestCommit table as recalled (see kat.json): through the gated sweep with the compact gate
+    for case in kat["upstream_TestCommit_recalled"]["cases"]:
+        m = np.array(case["matches"], dtype=np.uint64)[:, None]
+        first = next((i + 1 for i, t in enumerate(case["log_terms"]) if t == case["sm_term"]), 0)
+        with gpu_engine_cls(1, m.shape[0]) as e:
+            e.load_match(m, np.zeros(1, dtype=np.uint64))
+            e.load_terms(np.array([case["sm_term"]], dtype=np.uint64), np.array([first], dtype=np.uint64))
+            out, _ = e.commit_advance(gated=True)
+            assert int(out[0]) == case["w"], case
 
 
 def test_golden_small_fixtures(gpu_engine_cls):

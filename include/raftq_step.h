@@ -128,8 +128,8 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 
 /* pipelined form: up to TWO batches in flight.  raftq_step_submit enqueues a batch and returns
  * at once; raftq_step_collect blocks for the oldest batch in flight and hands out its results.
- * Batches are applied in submission order; the H2D copy of batch k+1 and the D2H copy of batch
- * k-1 overlap the kernels of batch k (three streams).  raftq_step_batch == submit + collect.
+ * Batches are applied in submission order; the H2D copy of batch k+1 overlaps the kernels and the
+ * result copy of batch k.  raftq_step_batch == submit + collect.
  * A malformed batch is reported by ITS collect and applies nothing; a batch submitted behind it
  * is still applied.  While batches are in flight every other call that reads or changes group
  * state (sweeps, Tick, deltas, raftq_apply_log_deltas, raftq_load_* / raftq_read_*) returns RAFTQ_ESTATE:

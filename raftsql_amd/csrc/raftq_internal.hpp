@@ -74,8 +74,8 @@ struct raftq {
   int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)
   uint64_t step_replays = 0;       // batches that went through the sorted path after a stall
   // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
-  // (pinned staging in, device scratch, pinned results out), pipelined over three streams so the
-  // H2D of batch k+1 and the D2H of batch k-1 overlap the kernels of batch k
+  // (pinned staging in, device scratch, pinned results out), pipelined over two streams (DMA in | kernels +
+  // result copy): the H2D of batch k+1 overlaps the kernels and the result copy of batch k
   struct StepSlot {
     void* in_h = nullptr;          // pinned staging (what raftq_step_stage hands out)
     size_t in_bytes = 0;

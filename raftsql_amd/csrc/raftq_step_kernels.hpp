@@ -1,11 +1,14 @@
 // raftq_step_kernels.hpp -- device code of the batched raft Step (include/raftq_step.h).
 //
 // etcd's raft.Step is a per-group sequential state machine; what is parallel is the G
-// groups.  A batch is therefore (1) keyed by group, (2) stably radix-sorted by that key
-// (hipCUB; arrival order inside a group survives), and (3) walked by step_kernel with one
-// lane per *run* of equal keys: the lane at the head of a run gathers its group's scalar
-// state into registers, applies the run's messages in order and scatters the state back.
-// Different runs touch different groups, so there are no atomics and the result is
+// groups.  A batch is therefore grouped by raft group with the arrival order kept, and one
+// lane per group gathers its group's scalar state into registers, applies the group's
+// messages in order and scatters the state back.  Two ways to group (same bytes out):
+//   list walk (default):  step_link_kernel threads every message onto its group's list with
+//       three atomics, the lane of the group's first message orders and walks it (2b / 3b)
+//   sorted walk (fallback for long runs): (1) keys, (2) hipCUB stable radix sort of
+//       (group, position), (3) step_kernel: one lane per run of equal keys
+// Different lanes touch different groups, so there are no atomics on state and the result is
 // identical to calling Step message by message (tests/test_step_gpu.py).
 //
 // Restates (2015-era etcd raft, reached from raft.go:268-270 / :223-224): Step, stepLeader,

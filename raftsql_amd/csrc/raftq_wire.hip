@@ -59,6 +59,18 @@ int ensure_pin(raftq_t* h) {
 
 unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / kBlock); }
 
+// chain[i] = pair[0] . pair[1] . ... . pair[i]; tot: scratch for ceil(n / kBlock) pairs
+int crc_chain_scan(raftq_t* h, const CrcPair* pair, CrcPair* chain, uint64_t n, CrcPair* tot) {
+  const unsigned nb = blocks_for(n);
+  hipLaunchKernelGGL(crc_scan_blocks_kernel, dim3(nb), dim3(kBlock), 0, h->stream, pair, chain, n, tot);
+  if (nb > 1) {
+    hipLaunchKernelGGL(crc_scan_totals_kernel, dim3(1), dim3(kBlock), 0, h->stream, tot, (uint64_t)nb);
+    hipLaunchKernelGGL(crc_scan_apply_kernel, dim3(nb), dim3(kBlock), 0, h->stream, chain, n, (const CrcPair*)tot);
+  }
+  HIPCHK(h, hipGetLastError());
+  return RAFTQ_OK;
+}
+
 int h2d(raftq_t* h, void* dst, const void* src, size_t bytes) {
   if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
   return RAFTQ_OK;
@@ -237,16 +249,14 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (!recs || (pool_bytes && !pool) || (cap && !out)) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  size_t cub_sum = 0, cub_crc = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_sum, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+  size_t cub_bytes = 0;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                              (int)(n + 1), h->stream));
-  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(nullptr, cub_crc, (const CrcPair*)nullptr, (CrcPair*)nullptr, CrcCompose(),
-                                              (int)n, h->stream));
-  size_t cub_bytes = std::max(cub_sum, cub_crc);
   Carver c;
   const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
                o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
-               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_cub = c.take(cub_bytes);
+               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_cub = c.take(cub_bytes),
+               o_tot = c.take((size_t)blocks_for(n) * sizeof(CrcPair));
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   uint8_t* base = (uint8_t*)h->wire_dev;
   WalRec* d_recs = (WalRec*)(base + o_recs);
@@ -264,12 +274,10 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   hipLaunchKernelGGL(wal_enc_crc_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
                      (const uint8_t*)d_pool, pool_bytes, (const uint32_t*)d_pcrc, prev_crc, d_pair, d_bad);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(base + o_cub, cub_bytes, (const CrcPair*)d_pair, d_chain, CrcCompose(),
-                                              (int)n, h->stream));
+  if (int rc = crc_chain_scan(h, d_pair, d_chain, n, (CrcPair*)(base + o_tot))) return rc;
   hipLaunchKernelGGL(wal_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
                      (const CrcPair*)d_chain, d_sizes);
   HIPCHK(h, hipGetLastError());
-  cub_bytes = std::max(cub_sum, cub_crc);
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_sizes, d_off, (int)(n + 1),
                                              h->stream));
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
@@ -315,13 +323,10 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   if ((!bytes && nbytes) || !frame_off || !recs) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  size_t cub_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(nullptr, cub_bytes, (const CrcPair*)nullptr, (CrcPair*)nullptr, CrcCompose(),
-                                              (int)n, h->stream));
   Carver c;
   const size_t o_bytes = c.take(nbytes), o_off = c.take((n + 1) * 8), o_recs = c.take(n * sizeof(WalRec)),
                o_span = c.take(n * sizeof(WalSpan)), o_pair = c.take(n * 8), o_chain = c.take(n * 8),
-               o_tail = c.take(32), o_cub = c.take(cub_bytes);
+               o_tail = c.take(32), o_tot = c.take((size_t)blocks_for(n) * sizeof(CrcPair));
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   uint8_t* base = (uint8_t*)h->wire_dev;
   uint8_t* d_bytes = base + o_bytes;
@@ -339,8 +344,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   hipLaunchKernelGGL(wal_dec_long_crc_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                      (const uint8_t*)d_bytes, n, (const WalSpan*)d_span, prev_crc, d_pair);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipcub::DeviceScan::InclusiveScan(base + o_cub, cub_bytes, (const CrcPair*)d_pair, d_chain, CrcCompose(),
-                                              (int)n, h->stream));
+  if (int rc = crc_chain_scan(h, d_pair, d_chain, n, (CrcPair*)(base + o_tot))) return rc;
   hipLaunchKernelGGL(wal_dec_check_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, d_recs, n,
                      (const CrcPair*)d_chain, prev_crc, d_first_bad);
   hipLaunchKernelGGL(wal_dec_tail_kernel, dim3(1), dim3(64), 0, h->stream, (const CrcPair*)d_chain, n, prev_crc,

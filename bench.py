@@ -512,10 +512,19 @@ def cpu_baseline(cfg, st, budget_s=12.0):
         sweeps = max(1, min(2000, int(budget_s / 4 / max(sec, 1e-6))))
         sec, _, _ = pyoracle.timed_sweeps(kind, threads, sweeps, st.match, st.committed, votes, cfg["gated"], fi)
         res[label] = dict(decisions_per_s=cfg["G"] * sweeps / sec, sweeps=sweeps, seconds=round(sec, 3), threads=threads)
+    quota = None  # a container may see every core of the box and still be throttled to a few (cgroup v2 cpu.max)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        pass
     return {
         "value": res["port_all"]["decisions_per_s"],
         "unit": "decisions/s",
         "cores": cores,
+        "cgroup_cpu_quota_cores": quota,
+        "speedup_all_threads_over_one": res["port_all"]["decisions_per_s"] / res["port_1t"]["decisions_per_s"],
         "kind": "port",
         "sample": f"{res['port_all']['sweeps']} sweeps of the same {cfg['G']} x {cfg['N']} batch "
                   f"({res['port_all']['seconds']} s), C restatement of the reference-era loop "

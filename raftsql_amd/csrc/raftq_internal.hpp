@@ -72,6 +72,7 @@ struct raftq {
   unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
   bool step_compact = false;       // result records in the 40-byte format (raftq_step_set_compact)
   int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)
+  uint32_t step_stalls_in_a_row = 0, step_sorted_left = 0;  // back-off from the list walk under hot-group traffic
   uint64_t step_replays = 0;       // batches that went through the sorted path after a stall
   // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
   // (pinned staging in, device scratch, pinned results out), pipelined over two streams (DMA in | kernels +

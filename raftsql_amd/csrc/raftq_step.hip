@@ -413,7 +413,10 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     // Step reads only the headers.  The entry headers (count -> scan -> second parse) are produced when
     // raftq_step_wire_msgs / _entries first asks for them: fetch_wire below.
   }
-  const bool lists = h->step_walk_mode == 1;
+  // traffic that keeps producing long runs (a few very hot groups) would stall and replay every batch: after two
+  // stalls in a row the next 16 batches go straight to the sorted walk, then the list walk is tried again
+  if (h->step_sorted_left) --h->step_sorted_left;
+  const bool lists = h->step_walk_mode == 1 && h->step_sorted_left == 0;
   if (lists) {
     if (int rc = enqueue_list_walk(h, s, n, wire != nullptr)) return rc;
   } else {
@@ -575,6 +578,9 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
     // this batch has a run longer than the list walk takes: nothing of it, nor of the batch submitted behind it,
     // was applied.  Replay them in submission order through the sorted walk, then let the list walk resume.
     if (int rc = replay_stalled(h, (int)((h->step_collected - 1) & 1))) return rc;
+    if (++h->step_stalls_in_a_row >= 2) h->step_sorted_left = 16;
+  } else if (sl.lists && !sl.replayed) {
+    h->step_stalls_in_a_row = 0;
   }
   std::memcpy(&heads, tail, 8);
   std::memcpy(&bad_h, tail + 8, 4);

@@ -79,6 +79,17 @@ def test_argument_validation_without_device(lib):
     assert lib.raftq_wal_decode(None, None, 0, None, 0, 0, None, None) == _lib.RAFTQ_EINVAL
     assert lib.raftq_step_submit_wire(None, None, 0, None, 0) == _lib.RAFTQ_EINVAL
     assert lib.raftq_wire_scan_frames(None, 8, 1, None, 0, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_step_set_compact(None, 1) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_step_results_c(None, None, None) == _lib.RAFTQ_EINVAL
+    p = C.c_void_p(None)
+    assert lib.raftq_host_alloc(None, 64) == _lib.RAFTQ_EINVAL and lib.raftq_host_alloc(C.byref(p), 0) == _lib.RAFTQ_EINVAL
+    lib.raftq_host_free(None)  # no-op
+    from raftsql_amd import node
+
+    nl = node._load()
+    assert nl.raftq_node_wal_enable(None) == _lib.RAFTQ_EINVAL
+    assert nl.raftq_node_wal_poll(None, None, 0, None) == _lib.RAFTQ_EINVAL
+    assert nl.raftq_node_replay_wal(None, None, 0, 0, None) == _lib.RAFTQ_EINVAL
 
 
 def test_no_silent_cpu_fallback(lib):

@@ -457,8 +457,9 @@ def node_measure(device, G=32768, N=3, rounds=6):
     base = [nd.stats() for nd in c.nodes]
     t0 = time.perf_counter()
     for r in range(rounds):
-        for g in range(G):
-            c.nodes[int(lead[g])].propose(g, b"INSERT INTO t (v) VALUES (%d)" % r)
+        for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
+            mine = np.nonzero(lead == p)[0]
+            nd.propose_batch(mine, [b"INSERT INTO t (v) VALUES (%d)" % r] * len(mine))
         want = (r + 1) * G
         for _ in range(40):
             c.step(tick=False)

@@ -117,6 +117,10 @@ int raftq_node_wal_enable(raftq_node_t* n);
 int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed);
 
 int raftq_node_propose(raftq_node_t* n, uint64_t group, const void* data, uint32_t len);
+/* the same for k proposals at once: proposal i is blob[offsets[i], offsets[i + 1]) for group groups[i] (one lock
+ * acquisition instead of k -- the batching goroutine of a G-group server drains its ProposeC's into one call) */
+int raftq_node_propose_batch(raftq_node_t* n, const uint64_t* groups, const uint64_t* offsets /*[k+1]*/, const void* blob,
+                             uint64_t k);
 int raftq_node_tick(raftq_node_t* n);
 int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len);
 /* one Ready-loop iteration for all groups; *n_published = entries put on commit channels */

@@ -738,6 +738,24 @@ int raftq_node_propose(raftq_node_t* n, uint64_t group, const void* data, uint32
   return RAFTQ_OK;
 }
 
+int raftq_node_propose_batch(raftq_node_t* n, const uint64_t* groups, const uint64_t* offsets, const void* blob, uint64_t k) {
+  if (!n) return RAFTQ_EINVAL;
+  if (k == 0) return RAFTQ_OK;
+  if (!groups || !offsets || (!blob && offsets[k] != offsets[0])) return nfail(n, RAFTQ_EINVAL, "propose_batch: null argument");
+  for (uint64_t i = 0; i < k; ++i)
+    if (groups[i] >= n->G || offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xffffffffull)
+      return nfail(n, RAFTQ_EINVAL, "propose_batch: group out of range or offsets not ascending; nothing was queued");
+  std::lock_guard<std::mutex> lk(n->mu);
+  if (!n->started || n->closed) {
+    n->errtext = n->closed ? "propose: node is closed" : "propose: node not started";
+    return RAFTQ_ESTATE;
+  }
+  n->proposals.reserve(n->proposals.size() + (size_t)k);
+  for (uint64_t i = 0; i < k; ++i)
+    n->proposals.emplace_back(groups[i], std::string((const char*)blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i])));
+  return RAFTQ_OK;
+}
+
 int raftq_node_tick(raftq_node_t* n) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> lk(n->mu);

@@ -37,6 +37,7 @@ _SIGS = [
     ("raftq_node_wal_poll", C.c_int, [_P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_node_start", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("raftq_node_propose", C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32]),
+    ("raftq_node_propose_batch", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]),
     ("raftq_node_tick", C.c_int, [_P]),
     ("raftq_node_deliver", C.c_int, [_P, C.c_void_p, C.c_uint64]),
     ("raftq_node_advance", C.c_int, [_P, C.POINTER(C.c_uint64)]),
@@ -126,6 +127,14 @@ class RaftNode:
     # -- the crank ----------------------------------------------------------
     def propose(self, group: int, data: bytes) -> None:
         self._chk(self._lib.raftq_node_propose(self._p, group, data, len(data)))
+
+    def propose_batch(self, groups, payloads) -> None:
+        """one call for many proposals (raftq_node_propose_batch): payloads[i] goes to groups[i]"""
+        g = np.ascontiguousarray(groups, dtype=np.uint64)
+        off = np.zeros(len(payloads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(p) for p in payloads])
+        blob = b"".join(payloads)
+        self._chk(self._lib.raftq_node_propose_batch(self._p, g.ctypes.data, off.ctypes.data, blob, len(payloads)))
 
     def tick(self) -> None:
         self._chk(self._lib.raftq_node_tick(self._p))

@@ -539,3 +539,29 @@ def test_replay_wal_refuses_a_corrupt_segment(Cluster):
             assert "CRC" in str(ei.value) or "parse" in str(ei.value) or "place" in str(ei.value)
         finally:
             nd.destroy()
+
+
+def test_propose_batch_is_propose_k_times(Cluster):
+    from raftsql_amd.engine import RaftqError
+
+    c = Cluster(8, 3)
+    try:
+        c.start()
+        elect(c)
+        lead = c.leaders()
+        for p, nd in enumerate(c.nodes):
+            mine = [int(g) for g in np.nonzero(lead == p)[0]]
+            nd.propose_batch(mine + mine, [b"a%d" % g for g in mine] + [b"" if g % 2 else b"b%d" % g for g in mine])
+        c.settle()
+        c.run(2)
+        c.settle()
+        for nd in c.nodes:
+            for g in range(8):
+                want = [b"a%d" % g] + ([] if g % 2 else [b"b%d" % g])  # an empty payload is never published (raft.go:85-87)
+                assert [d for d in nd.drain(g) if d is not None] == want
+        with pytest.raises(RaftqError):
+            c.nodes[0].propose_batch([0, 8], [b"x", b"no such group"])  # refused as a whole
+        c.settle()
+        assert all(nd.drain(0) == [] for nd in c.nodes)
+    finally:
+        c.close()

@@ -344,3 +344,24 @@ def test_compact_result_records_expand_to_the_full_ones(NodeEngine, oracle):
         m = _stepgen.random_batch(rng, s, 2000)
         assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))
         _stepgen.assert_same_state(e, s)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 7])
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+def test_step_golden_fixture_on_the_gpu(NodeEngine, n, walk, monkeypatch):
+    """tests/golden/step_golden.npz (frozen oracle answers; batch 1 holds runs of ~60) through both walks: every
+    result record and the final state, byte for byte -- no oracle call in this test."""
+    from tests.test_step_oracle import load_step_golden
+
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    self_peer, s, batches, final = load_step_golden(n)
+    with NodeEngine(s.G, n, self_peer) as e:
+        _stepgen.load_engine(e, s)
+        for m, want in batches:
+            got, _ = e.step_batch(m)
+            assert got.tobytes() == want.tobytes()
+        node = e.read_node()
+        for k in ("term", "vote", "lead", "last_index", "last_term", "first_idx", "role", "elapsed", "committed"):
+            assert np.array_equal(node[k], final[k]), k
+        assert np.array_equal(e.read_match(), final["match"]) and np.array_equal(e.read_votes(), final["votes"])

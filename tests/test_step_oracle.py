@@ -2,6 +2,8 @@
 the Raft rules (Raft paper 5.1-5.4; etcd raft's Step / stepX of the 2015 era) and
 against invariants under random traffic.  PARITY UNPINNED: the reference's tests hold no
 vector for this path, so these scenarios ARE the pin."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
@@ -238,3 +240,33 @@ def test_c_oracle_agrees_with_the_object_shaped_python_statement(seed, N, self_p
                 (o["term"], o["commit"], o["last_index"], o["vote"], o["lead"], o["role"]), (i, m[i], o)
         for g in range(G):
             assert R.matches_node_state(rafts[g], s, g), g
+
+
+GOLD_STEP = os.path.join(os.path.dirname(__file__), "golden", "step_golden.npz")
+_STATE_KEYS = ("term", "vote", "lead", "last_index", "last_term", "first_idx", "role", "elapsed", "committed", "match", "votes")
+
+
+def load_step_golden(n):
+    """-> (self_peer, initial NodeState, [(msgs, outs)], final-state dict) of tests/golden/step_golden.npz"""
+    from raftsql_amd import step as S
+
+    z = np.load(GOLD_STEP)
+    p = f"n{n}_"
+    self_peer = int(z[p + "self"][0])
+    s = pyoracle.NodeState(z[p + "init_term"].shape[0], n, self_peer)
+    for k in _STATE_KEYS:
+        getattr(s, k)[...] = z[p + "init_" + k]
+    batches = [(np.ascontiguousarray(z[p + f"msgs{b}"]).view(S.MSG_DT).reshape(-1),
+                np.ascontiguousarray(z[p + f"outs{b}"]).view(S.OUT_DT).reshape(-1)) for b in range(3)]
+    return self_peer, s, batches, {k: z[p + "final_" + k] for k in _STATE_KEYS}
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 7])
+def test_step_golden_fixture(n):
+    """The committed Step fixture (generator: tests/golden/make_step_golden.py): the oracle of this checkout still
+    produces the frozen result records and final state, byte for byte."""
+    _, s, batches, final = load_step_golden(n)
+    for m, want in batches:
+        assert s.step_batch(m).tobytes() == want.tobytes()
+    for k, v in final.items():
+        assert np.array_equal(getattr(s, k), v), k

@@ -282,3 +282,19 @@ def test_upstream_testcommit_table_as_recalled(oracle, case):
     rterms = [terms[s - 1] for s in starts]
     got = mci if (mci > 0 and oracle.log_term(starts, rterms, len(terms), mci) == sm) else 0
     assert got == want
+
+
+@pytest.mark.parametrize("case", KAT["upstream_TestLeaderElection_recalled"]["cases"])
+def test_upstream_testleaderelection_table_as_recalled(oracle, case):
+    """etcd's TestLeaderElection as recalled (alignment evidence, not a pin): through the vote tally and through Step
+    (MsgHup, then a granting MsgVoteResp from every member that answers)."""
+    votes = case["votes"]
+    n = len(votes)
+    out, won, lost = oracle.vote_tally(np.array(votes, np.uint8).reshape(n, 1))
+    assert (int(out[0]), won, lost) == (case["outcome"], case["outcome"], 0)
+    from raftsql_amd import step as S
+
+    s = pyoracle.NodeState(1, n, 0)
+    msgs = [S.pack_msgs([0], S.MSG_HUP)] + [S.pack_msgs([0], S.MSG_VOTE_RESP, term=1, frm=p) for p in range(1, n) if votes[p]]
+    s.step_batch(np.concatenate(msgs))
+    assert int(s.term[0]) == 1 and int(s.role[0]) == (2 if case["outcome"] else 1)

@@ -121,6 +121,12 @@ def test_hand_derived_known_answers(gpu_engine_cls):
             out, cnt = e.vote_tally()
             assert int(out[0]) == case["outcome"], case
             assert (cnt.n_won, cnt.n_lost) == (int(case["outcome"] == 1), int(case["outcome"] == 2))
+    for case in kat["upstream_TestLeaderElection_recalled"]["cases"]:  # as recalled: the tally decides leader / candidate
+        v = np.array(case["votes"], dtype=np.uint8)[:, None]
+        with gpu_engine_cls(1, v.shape[0]) as e:
+            e.load_votes(v)
+            out, _ = e.vote_tally()
+            assert int(out[0]) == case["outcome"], case
     # etcd's own TestCommit table as recalled (see kat.json): through the gated sweep with the compact gate
     for case in kat["upstream_TestCommit_recalled"]["cases"]:
         m = np.array(case["matches"], dtype=np.uint64)[:, None]

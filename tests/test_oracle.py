@@ -294,7 +294,7 @@ def test_upstream_testleaderelection_table_as_recalled(oracle, case):
     assert (int(out[0]), won, lost) == (case["outcome"], case["outcome"], 0)
     from raftsql_amd import step as S
 
-    s = pyoracle.NodeState(1, n, 0)
+    s = oracle.NodeState(1, n, 0)
     msgs = [S.pack_msgs([0], S.MSG_HUP)] + [S.pack_msgs([0], S.MSG_VOTE_RESP, term=1, frm=p) for p in range(1, n) if votes[p]]
     s.step_batch(np.concatenate(msgs))
     assert int(s.term[0]) == 1 and int(s.role[0]) == (2 if case["outcome"] else 1)

@@ -27,6 +27,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this image needs dmabuf IPC (RCCL communicator set-up fails with
+# "hipIpcGetMemHandle: invalid argument" otherwise); the launcher exports it, keep it if it did not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
 HBM_COPY_CEILING_GBPS = 6290.0

@@ -2,18 +2,31 @@
 """bench.py -- quorum decisions/sec of the MI355X batched multi-raft sweep.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE
-JSON line on rank 0.  A "step" is one pass of the hot path (commit-advance +
-RequestVote tally) over one batch of G groups x N peers already resident in
-HBM.  Default workload = BASELINE.json configs[2], the configuration the
-metric and north_star's target are quoted on: 1M groups x 5 peers, commit +
-vote.  Multi-GPU is weak scaling: every rank owns its own G groups, no
-data-path collective; `value` is the whole-job aggregate.
+JSON line on rank 0.  The hot path is commit-advance + RequestVote tally over
+groups already resident in HBM.  Default workload = BASELINE.json configs[2],
+the configuration the metric and north_star's target are quoted on: batches of
+1M groups x 5 peers, commit + vote.
 
-HBM honesty: one batch of 1M x 5 is 65 MB, smaller than the
-256 MiB Infinity Cache, so re-sweeping ONE batch measures L3.  The timed loop
-therefore rotates through K independent batches totalling >= --rotate-bytes
-(default 1.5 GiB); the single-batch (cache-resident) rate is reported beside
-it as `l3_resident`.
+A STEP is one pass of the hot path over EVERY resident batch: the GPU holds
+`--batches` independent 1M x 5 batches (default 33 = 2 GiB, 8x the 256 MiB
+Infinity Cache -- the rotating-set protocol of SURVEY.md 8d / F9, as round 1),
+swept by ONE dispatch through a sweep set (raftq_set_sweep_async: grid =
+tiles x batches).  `decisions = groups_per_batch x batches x steps`.  Two
+reasons for this definition: (1) HBM honesty -- one batch is 65 MB, so
+re-sweeping ONE batch measures L3; a pass over 2 GiB cannot hit; (2) the launch
+loop lives in the library, not in Python: one C call and one kernel per step, so
+kernel time / wall time is ~0.99 whatever --steps is (round 1's figure was
+host-launch-bound at the driver's --steps 20).  Beside it: `per_batch_us`,
+`single_launch` (the same batches as one launch each, from one C call --
+round 1's shape), `footprint_curve` (the same step over 64 / 128 / 240 resident
+batches, up to 15.6 GB: the per-batch time rises ~3 % over that range) and
+`l3_resident` (one batch re-swept: a cache figure, never `value`).
+
+Multi-GPU is weak scaling: every GPU owns its own batches, no data-path
+collective; `value` is the whole-job aggregate.  Under torchrun
+(WORLD_SIZE set) it is one process per GPU; launched directly with --gpus N it
+drives N devices from this process (one set and stream per device, host-side
+sums) and REFUSES to run if fewer than N devices are visible.
 """
 from __future__ import annotations
 
@@ -62,49 +75,88 @@ def sweep_flags(cfg) -> int:
     return f
 
 
-def side_measure(cfg_id, rotate_bytes, steps, stream_ptr, dist, device=0):
-    """Short single-GPU measurement of another BASELINE config (rank 0, N=1)."""
-    from raftsql_amd import _lib, synth
-
-    cfg = CONFIGS[cfg_id]
-    rd, wr = bytes_per_decision(cfg)
-    nb = max(2, int(np.ceil(rotate_bytes / (cfg["G"] * (rd + wr)))))
-    engines, _ = build_batches(cfg, nb, 0, synth.SEED_BASE + cfg_id, stream_ptr, device)
-    flags = sweep_flags(cfg) | _lib.SWEEP_STREAM
-    for i in range(steps // 4):
-        engines[i % nb].step_async(flags)
-    wall, ev = timed_loop(engines, flags, steps, dist.World(), dist)
-    for e in engines:
-        e.close()
-    us = ev * 1e3 / steps
-    return {
-        "workload": cfg["name"],
-        "decisions_per_s": cfg["G"] * steps / wall,
-        "launch_us": us,
-        "GBps": (rd + wr) * cfg["G"] / (us * 1e-6) / 1e9,
-        "frac": (rd + wr) * cfg["G"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-        "bytes_per_decision": {"read": rd, "write": wr},
-        "batches_rotated": nb,
-    }
-
-
-def build_batches(cfg, n_batches, rank, seed_base, stream_ptr, device=0):
+def build_batches(cfg, n_batches, rank, seed_base, device=0, distinct=8):
+    """n_batches engines of cfg's shape on `device`: `distinct` of them hold independently generated
+    data (counter-based: offset group ids, per rank), the rest are device-to-device clones of those
+    (raftq_clone_state) -- different HBM addresses, so a pass over all of them cannot hit in cache, and
+    the sweep's arithmetic is branch-free, so its speed does not depend on the values."""
     from raftsql_amd import synth
     from raftsql_amd.engine import QuorumEngine
 
-    engines = []
-    first_state = None
+    distinct = max(1, min(distinct, n_batches))
+    engines, first_state = [], None
     for b in range(n_batches):
-        # distinct data per batch and per rank (counter-based: offset the group ids)
-        off = (rank * n_batches + b) * cfg["G"]
-        st = synth.make_groups(cfg["G"], cfg["N"], seed=seed_base, with_terms=cfg["gated"], group_offset=off)
         e = QuorumEngine(cfg["G"], cfg["N"], device=device)
-        e.set_stream(stream_ptr)
-        e.load_state(st)
+        if b < distinct:
+            off = (rank * distinct + b) * cfg["G"]
+            st = synth.make_groups(cfg["G"], cfg["N"], seed=seed_base, with_terms=cfg["gated"], group_offset=off)
+            e.load_state(st)
+            if b == 0:
+                first_state = st
+        else:
+            e.clone_state_from(engines[b % distinct])
         engines.append(e)
-        if b == 0:
-            first_state = st
     return engines, first_state
+
+
+def sync_devices(devices):
+    import torch
+
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+
+
+def timed_steps(sets, devices, flags, steps, world, dist, launcher=None):
+    """Barrier + sync, K steps (a step = one pass over every batch of every set), barrier + sync.
+    -> (wall_s, [event_ms per set]).  The HIP events sit on each set's own stream."""
+    dist.barrier(world)
+    sync_devices(devices)
+    t0 = time.perf_counter()
+    for s in sets:
+        s.timer_begin()
+    if launcher is None:
+        for _ in range(steps):
+            for s in sets:
+                s.sweep_async(flags)
+    else:
+        for _ in range(steps):
+            for s in sets:
+                launcher(s, flags)
+    ev_ms = [s.timer_end() for s in sets]
+    sync_devices(devices)
+    dist.barrier(world)
+    wall = time.perf_counter() - t0
+    return wall, ev_ms
+
+
+def measure_config(cfg_id, n_batches, steps, warmup, device, dist, rank=0, distinct=3, policy_flag=None):
+    """Short single-GPU measurement of a BASELINE config through a sweep set (rank 0)."""
+    from raftsql_amd import _lib, synth
+    from raftsql_amd.engine import SweepSet
+
+    cfg = CONFIGS[cfg_id]
+    rd, wr = bytes_per_decision(cfg)
+    engines, _ = build_batches(cfg, n_batches, rank, synth.SEED_BASE + cfg_id, device, distinct)
+    flags = sweep_flags(cfg) | (_lib.SWEEP_STREAM if policy_flag is None else policy_flag)
+    with SweepSet(engines) as s:
+        for _ in range(warmup):
+            s.sweep_async(flags)
+        wall, ev = timed_steps([s], [device], flags, steps, dist.World(), dist)
+    for e in engines:
+        e.close()
+    us = ev[0] * 1e3 / steps
+    nbytes = (rd + wr) * cfg["G"] * n_batches
+    return {
+        "workload": cfg["name"],
+        "batches": n_batches,
+        "decisions_per_s": cfg["G"] * n_batches * steps / wall,
+        "launch_us": us,
+        "per_batch_us": us / n_batches,
+        "GBps": nbytes / (us * 1e-6) / 1e9,
+        "read_GBps": rd * cfg["G"] * n_batches / (us * 1e-6) / 1e9,
+        "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+        "bytes_per_decision": {"read": rd, "write": wr},
+    }
 
 
 def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
@@ -484,24 +536,6 @@ def node_measure(device, G=32768, N=3, rounds=6):
             "s_per_wave": dt / rounds}
 
 
-def timed_loop(engines, flags, steps, world, dist):
-    """Barrier + sync, K steps, barrier + sync.  -> (wall_s, event_ms)."""
-    import torch
-
-    k = len(engines)
-    dist.barrier(world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    engines[0].timer_begin()
-    for i in range(steps):
-        engines[i % k].step_async(flags)
-    ev_ms = engines[0].timer_end()
-    torch.cuda.synchronize()
-    dist.barrier(world)
-    wall = time.perf_counter() - t0
-    return wall, ev_ms
-
-
 def cpu_baseline(cfg, st, budget_s=12.0):
     """The oracle timed on this box's host cores (rank 0, N=1 only)."""
     from oracle import pyoracle
@@ -539,73 +573,114 @@ def cpu_baseline(cfg, st, budget_s=12.0):
     }
 
 
+def plan_devices(gpus: int, forced_device, visible: int, world_size: int, local_rank: int) -> list[int]:
+    """The GPU indices THIS process drives.  Under torchrun: one (its local rank).  Launched directly:
+    all `gpus` of them.  Never fewer than asked for: a job that cannot get its GPUs fails loudly.
+    `forced_device` (testing only) maps every rank onto one GPU."""
+    gpus = max(1, int(gpus))
+    if world_size > 1:
+        if world_size != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world_size}: the launcher and the flag disagree")
+        d = local_rank if forced_device is None else forced_device
+        if d >= visible:
+            raise SystemExit(f"local rank {local_rank}: GPU {d} is not visible ({visible} present)")
+        return [d]
+    if forced_device is not None:
+        if forced_device >= visible:
+            raise SystemExit(f"--device {forced_device} is not visible ({visible} present)")
+        return [forced_device] * gpus
+    if gpus > visible:
+        raise SystemExit(f"--gpus {gpus} but only {visible} GPU(s) visible: refusing to report {gpus} GPUs' worth of "
+                         "work from fewer devices")
+    return list(range(gpus))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
-    ap.add_argument("--rotate-bytes", type=float, default=1.5 * 2**30)
-    ap.add_argument("--variant", choices=["reg", "lds"], default="reg")
+    ap.add_argument("--batches", type=int, default=None,
+                    help="independent resident batches per GPU swept by one step (default: 2 GiB worth -- 8x the "
+                         "Infinity Cache -- 33 for config 3; the footprint curve up to 16 GB is in `footprint_curve`)")
+    ap.add_argument("--distinct", type=int, default=8, help="batches with independently generated data; the rest are clones")
+    ap.add_argument("--mode", choices=["grid", "persistent"], default="grid", help="launch shape of the set sweep")
     ap.add_argument("--policy", choices=["stream", "cached", "auto"], default="stream",
-                    help="cache policy of the rotating loop: no batch stays cached between its sweeps, so stream")
+                    help="cache policy: no batch stays cached between its sweeps, so stream")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
-                    help="torch.distributed backend for N>1 (default nccl = RCCL); gloo is for testing the "
+                    help="torch.distributed backend under torchrun (default nccl = RCCL); gloo is for testing the "
                          "multi-process path on a box with fewer GPUs than ranks")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index on every rank (testing only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the l3_resident / other-config side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     args = ap.parse_args()
 
     import torch
 
     from raftsql_amd import _lib, dist, synth
+    from raftsql_amd.engine import SweepSet, sweep_many_async
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the quorum sweep has no CPU path (only the oracle baseline does)")
     world = dist.init_from_env(args.backend)
-    if world.size != max(1, args.gpus) and world.size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world.size}")
-    device = world.local_rank if args.device is None else args.device
-    if device >= torch.cuda.device_count():
-        raise SystemExit(f"rank {world.rank}: GPU {device} not visible ({torch.cuda.device_count()} present)")
-    torch.cuda.set_device(device)
+    devices = plan_devices(args.gpus, args.device, torch.cuda.device_count(), world.size, world.local_rank)
+    n_gpus = world.size * len(devices) if world.size > 1 else len(devices)
+    torch.cuda.set_device(devices[0])
     _lib.load()
-    stream = torch.cuda.Stream()
 
     cfg = CONFIGS[args.config]
     rd, wr = bytes_per_decision(cfg)
-    set_bytes = cfg["G"] * (rd + wr)
-    n_batches = max(2, int(np.ceil(args.rotate_bytes / set_bytes)))
-    flags = sweep_flags(cfg) | (_lib.SWEEP_LDS if args.variant == "lds" else 0)
-    base_flags = flags
-    flags |= {"stream": _lib.SWEEP_STREAM, "cached": _lib.SWEEP_CACHED, "auto": 0}[args.policy]
-    engines, st0 = build_batches(cfg, n_batches, world.rank, synth.SEED_BASE + args.config, stream.cuda_stream, device)
+    batch_bytes = cfg["G"] * (rd + wr)
+    n_batches = args.batches or max(8, int(np.ceil(2 * 2**30 / batch_bytes)))
+    flags = sweep_flags(cfg) | {"stream": _lib.SWEEP_STREAM, "cached": _lib.SWEEP_CACHED, "auto": 0}[args.policy]
+    base_flags = sweep_flags(cfg)
 
-    # correctness gate before any timing: tallies of batch 0 against numpy
-    c = engines[0].sweep(flags)
+    sets, all_engines, st0 = [], [], None
+    for i, d in enumerate(devices):
+        shard = world.rank * len(devices) + i  # which slice of the whole job's groups this GPU owns
+        engines, st = build_batches(cfg, n_batches, shard, synth.SEED_BASE + args.config, d, args.distinct)
+        if i == 0:
+            st0 = st
+        all_engines.append(engines)
+        s = SweepSet(engines)
+        s.set_mode(_lib.SET_PERSISTENT if args.mode == "persistent" else _lib.SET_GRID)
+        sets.append(s)
+
+    # correctness gate before any timing: per-batch tallies of the first set against numpy
+    per, tot = sets[0].sweep(flags)
     srt = np.sort(st0.match, axis=0)[cfg["N"] - synth.quorum(cfg["N"])]
     adv = srt > st0.committed
     if cfg["gated"]:
         adv &= (st0.first_idx_cur_term != 0) & (srt >= st0.first_idx_cur_term)
-    if c.n_changed != int(adv.sum()):
-        raise SystemExit(f"tally mismatch before timing: {c.n_changed} != {int(adv.sum())}")
+    distinct = max(1, min(args.distinct, n_batches))
+    if per[0].n_changed != int(adv.sum()) or any(per[b].n_changed != per[b % distinct].n_changed for b in range(n_batches)):
+        raise SystemExit(f"tally mismatch before timing: {per[0].n_changed} != {int(adv.sum())} (or a clone differs)")
 
-    for i in range(args.warmup):
-        engines[i % n_batches].step_async(flags)
-    wall, ev_ms = timed_loop(engines, flags, args.steps, world, dist)
+    for _ in range(args.warmup):
+        for s in sets:
+            s.sweep_async(flags)
+    wall, ev_ms = timed_steps(sets, devices, flags, args.steps, world, dist)
     wall_max = dist.max_over_ranks(world, wall)
-    ev_max = dist.max_over_ranks(world, ev_ms)
+    ev_local = max(ev_ms)
+    ev_max = dist.max_over_ranks(world, ev_local)
 
-    decisions = cfg["G"] * args.steps * world.size
+    groups_per_gpu = cfg["G"] * n_batches
+    decisions = groups_per_gpu * args.steps * n_gpus
     value = decisions / wall_max
-    launch_us = ev_ms * 1e3 / args.steps
-    achieved = (rd + wr) * cfg["G"] / (launch_us * 1e-6) / 1e9
+    launch_us = ev_local * 1e3 / args.steps  # one dispatch per step per GPU
+    bytes_per_launch = (rd + wr) * groups_per_gpu
+    achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+    pol = {"stream": 3, "cached": 0, "auto": 3}[args.policy]  # the set's footprint is far beyond the streaming threshold
+    gpl = 4 if args.mode == "persistent" else (8 if cfg["N"] <= 5 else 2)  # raftq_capi.hip set_gpl()
+    kname = ("raftqk::sweep_persist_kernel" if args.mode == "persistent" else "raftqk::sweep_set_kernel") + \
+        "<%d, %d, true, %s, %s, %d, true%s>" % (cfg["N"], gpl, str(cfg["gated"]).lower(), str(cfg["votes"]).lower(), pol,
+                                                ", 1" if args.mode == "persistent" else ", 256")
     out = {
         "metric": "quorum decisions/sec (commit+vote) across G groups",
         "value": value,
         "unit": "decisions/s",
-        "n_gpus": world.size,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall_max * 1e3 / args.steps,
@@ -616,13 +691,18 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": cfg["name"],
-            "groups_per_gpu": cfg["G"],
+            "step": "one pass of the hot path over every resident batch of a GPU, ONE dispatch (sweep set)",
+            "groups_per_batch": cfg["G"],
             "peers": cfg["N"],
-            "batches_rotated": n_batches,
-            "rotating_bytes_per_gpu": n_batches * set_bytes,
-            "variant": args.variant,
+            "batches_per_gpu": n_batches,
+            "groups_per_gpu": groups_per_gpu,
+            "distinct_batches": distinct,
+            "resident_bytes_per_gpu": n_batches * batch_bytes,
+            "launches_per_step": 1,
+            "dispatch": args.mode,
             "cache_policy": args.policy,
-            "parallelism": f"groups sharded x{world.size}, no collective",
+            "parallelism": f"groups sharded x{n_gpus}, no collective; " +
+                           ("one process per GPU (torchrun)" if world.size > 1 else "one process, one set + stream per GPU"),
         },
         "roofline": {
             "bound": "hbm",
@@ -631,80 +711,157 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "raftqk::sweep_kernel" if args.variant == "reg" else "raftqk::sweep_lds_kernel",
+            "kernel": kname,
             "launch_us": launch_us,
-            "bytes_per_launch": (rd + wr) * cfg["G"],
+            "per_batch_us": launch_us / n_batches,
+            "bytes_per_launch": bytes_per_launch,
             "bytes_per_decision": {"read": rd, "write": wr},
-            "achieved_read_GBps": rd * cfg["G"] / (launch_us * 1e-6) / 1e9,
+            "achieved_read_GBps": rd * groups_per_gpu / (launch_us * 1e-6) / 1e9,
+            "frac_read_of_peak": rd * groups_per_gpu / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
             "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBPS,
+            "kernel_time_over_wall": launch_us / (wall_max * 1e6 / args.steps),
             "event_ms_max_over_ranks": ev_max,
         },
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
+        # PMC traffic is measured in separate rocprofv3 --pmc passes (tools/pmc_traffic.py); it is only quoted
+        # when it was taken on the kernel this run launches, scaled from its batch count to ours
         try:
-            t = json.load(open(pmc))
-            out["roofline"]["traffic"] = t.get(f"config{args.config}", {}).get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = t.get("source")
-        except Exception:
-            pass
+            t = json.load(open(pmc)).get(f"config{args.config}", {})
+            if t.get("kernel") == kname and t.get("hbm_bytes_per_batch"):
+                out["roofline"]["traffic"] = t["hbm_bytes_per_batch"] * n_batches
+                out["roofline"]["traffic_over_algorithmic"] = t["hbm_bytes_per_batch"] / batch_bytes
+                out["roofline"]["traffic_measured_at"] = t.get("measured_at")
+            else:
+                out["roofline"]["traffic_note"] = "no PMC record for this kernel (%s recorded)" % t.get("kernel")
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["traffic_note"] = f"pmc_traffic.json unreadable: {e}"
 
-    if world.rank == 0 and not args.no_extras:
-        # cache-resident regime: one batch re-swept (fits the 256 MiB Infinity Cache)
+    extras = world.rank == 0 and not args.no_extras
+    if extras:
+        s0, e0, d0 = sets[0], all_engines[0], devices[0]
+        k = max(2, min(args.steps, 40))
+        # (a) the same batches as one launch EACH (raftq_sweep_many_async: the launch loop is in C, every launch on
+        # the set's stream): what a host without a set gets -- the figure round 1 reported
+        for _ in range(2):
+            sweep_many_async(e0, flags)
+        w1, e1 = timed_steps([s0], [d0], flags, k, dist.World(), dist, launcher=lambda s, f: sweep_many_async(e0, f))
+        us1 = e1[0] * 1e3 / (k * n_batches)
+        out["single_launch"] = {
+            "what": "one launch per 1M-group batch, launch loop in C (raftq_sweep_many_async), same stream",
+            "kernel": "raftqk::sweep_kernel", "launch_us": us1, "launches_per_step": n_batches,
+            "decisions_per_s": groups_per_gpu * k / w1, "GBps": batch_bytes / (us1 * 1e-6) / 1e9,
+            "read_GBps": rd * cfg["G"] / (us1 * 1e-6) / 1e9, "frac": batch_bytes / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "kernel_time_over_wall": e1[0] * 1e-3 / w1,
+        }
+        # (b) the other launch shape of the set
+        other = _lib.SET_GRID if args.mode == "persistent" else _lib.SET_PERSISTENT
+        s0.set_mode(other)
+        for _ in range(3):
+            s0.sweep_async(flags)
+        w2, e2 = timed_steps([s0], [d0], flags, k, dist.World(), dist)
+        s0.set_mode(_lib.SET_PERSISTENT if args.mode == "persistent" else _lib.SET_GRID)
+        us2 = e2[0] * 1e3 / k
+        out["other_dispatch"] = {
+            "dispatch": "grid" if args.mode == "persistent" else "persistent", "launch_us": us2,
+            "per_batch_us": us2 / n_batches, "GBps": bytes_per_launch / (us2 * 1e-6) / 1e9,
+            "frac": bytes_per_launch / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS, "decisions_per_s": groups_per_gpu * k / w2,
+        }
+        # (c) cache-resident regime: ONE batch re-swept (fits the 256 MiB Infinity Cache)
         cflags = base_flags | _lib.SWEEP_CACHED
-        for _ in range(50):
-            engines[0].step_async(cflags)
-        w1, e1 = timed_loop(engines[:1], cflags, min(args.steps, 2000), dist.World(), dist)
-        k1 = min(args.steps, 2000)
+        one = [e0[0]] * 100
+        for _ in range(2):
+            sweep_many_async(one, cflags)
+        w3, e3 = timed_steps([s0], [d0], cflags, 10, dist.World(), dist, launcher=lambda s, f: sweep_many_async(one, f))
+        us3 = e3[0] * 1e3 / 1000
         out["l3_resident"] = {
-            "decisions_per_s": cfg["G"] * k1 / w1,
-            "launch_us": e1 * 1e3 / k1,
-            "GBps": (rd + wr) * cfg["G"] / (e1 * 1e-3 / k1) / 1e9,
+            "launch_us": us3, "decisions_per_s": cfg["G"] * 1000 / w3, "GBps": batch_bytes / (us3 * 1e-6) / 1e9,
             "note": "one 65 MB batch re-swept: served from Infinity Cache, NOT an HBM figure",
         }
-    if world.rank == 0 and not args.no_extras:
-        # the same rotating loop with the batches alternating between two streams: batches are
-        # independent handles, so the ramp of one sweep overlaps the drain of the previous one.  Wall
-        # clock only (per-kernel durations overlap, so this is not a roofline.achieved figure).
-        s2 = torch.cuda.Stream()
-        for i, e in enumerate(engines):
-            e.set_stream((stream if i % 2 == 0 else s2).cuda_stream)
-        for i in range(200):
-            engines[i % n_batches].step_async(flags)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            engines[i % n_batches].step_async(flags)
-        torch.cuda.synchronize()
-        w2 = time.perf_counter() - t0
-        for e in engines:
-            e.set_stream(stream.cuda_stream)
-        out["two_streams"] = {"decisions_per_s": cfg["G"] * args.steps / w2, "us_per_step": w2 * 1e6 / args.steps,
-                              "GBps": (rd + wr) * cfg["G"] * args.steps / w2 / 1e9,
-                              "note": "same workload, batches alternate between two HIP streams (wall clock)"}
-    if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
+    if world.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, st0)
     elif world.rank == 0:
         out["cpu_baseline"] = None
-    for e in engines:
-        e.close()
-    if world.rank == 0 and world.size == 1 and not args.no_extras:
-        # side measurements never take the headline line down with them
-        def guarded(fn, *a, **k):
-            try:
-                return fn(*a, **k)
-            except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
-                return {"error": f"{type(e).__name__}: {e}"}
+    for s in sets:
+        s.close()
+    if extras:
+        # (d) the same step over larger resident populations (clones: other HBM addresses, same arithmetic)
+        from raftsql_amd.engine import QuorumEngine
 
-        out["pipeline"] = guarded(pipeline_measure, cfg, device)
-        out["tick"] = guarded(tick_measure, cfg, device)
-        out["step"] = guarded(step_measure, cfg, device, with_cpu=not args.no_cpu_baseline)
-        out["wire"] = guarded(wire_measure, cfg, device, with_cpu=not args.no_cpu_baseline)
-        out["node"] = guarded(node_measure, device)
-        out["other_configs"] = {
-            f"config{c}": guarded(side_measure, c, args.rotate_bytes, 1000, stream.cuda_stream, dist, device)
-            for c in sorted(CONFIGS) if c != args.config
-        }
+        e0, d0, curve = all_engines[0], devices[0], []
+        for kk in (64, 128, 240):
+            if kk <= n_batches:
+                continue
+            while len(e0) < kk:
+                e = QuorumEngine(cfg["G"], cfg["N"], device=d0)
+                e.clone_state_from(e0[len(e0) % distinct])
+                e0.append(e)
+            with SweepSet(e0[:kk]) as sk:
+                for _ in range(2):
+                    sk.sweep_async(flags)
+                _, ek = timed_steps([sk], [d0], flags, 8, dist.World(), dist)
+            us = ek[0] * 1e3 / 8
+            curve.append({"batches": kk, "resident_GB": kk * batch_bytes / 1e9, "per_batch_us": us / kk,
+                          "GBps": kk * batch_bytes / (us * 1e-6) / 1e9, "frac": kk * batch_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+        out["footprint_curve"] = curve
+    for engines in all_engines:
+        for e in engines:
+            e.close()
+    sets, all_engines = [], []
+
+    def guarded(fn, *a, **k):  # side measurements never take the headline line down with them
+        try:
+            return fn(*a, **k)
+        except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    if n_gpus > 1 and not args.no_extras:
+        # BASELINE configs[3] as a whole job: 2M groups x 7 peers per GPU (16M x 7 over 8), same step definition
+        c4 = CONFIGS[4]
+        rd4, wr4 = bytes_per_decision(c4)
+        nb4 = max(4, int(round(8e9 / (c4["G"] * (rd4 + wr4)))))
+        f4 = sweep_flags(c4) | _lib.SWEEP_STREAM
+        sets4, eng4 = [], []
+        for i, d in enumerate(devices):
+            eng, _ = build_batches(c4, nb4, world.rank * len(devices) + i, synth.SEED_BASE + 4, d, 2)
+            eng4.append(eng)
+            sets4.append(SweepSet(eng))
+        k4 = max(2, min(args.steps, 40))
+        for _ in range(2):
+            for s in sets4:
+                s.sweep_async(f4)
+        w4, e4 = timed_steps(sets4, devices, f4, k4, world, dist)
+        w4 = dist.max_over_ranks(world, w4)
+        us4 = dist.max_over_ranks(world, max(e4)) * 1e3 / k4
+        for s in sets4:
+            s.close()
+        for eng in eng4:
+            for e in eng:
+                e.close()
+        if world.rank == 0:
+            out["config4_whole_job"] = {
+                "workload": f"{c4['G'] * n_gpus} groups x 7 peers sharded over {n_gpus} GPU(s), commit + vote "
+                            f"({nb4} resident batches of 2M x 7 per GPU, one dispatch per step per GPU)",
+                "decisions_per_s": c4["G"] * nb4 * k4 * n_gpus / w4, "launch_us_max": us4, "per_batch_us": us4 / nb4,
+                "GBps_per_gpu": (rd4 + wr4) * c4["G"] * nb4 / (us4 * 1e-6) / 1e9,
+                "frac_per_gpu": (rd4 + wr4) * c4["G"] * nb4 / (us4 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            }
+    if world.rank == 0 and n_gpus == 1 and not args.no_extras:
+        d0 = devices[0]
+        out["other_configs"] = {}
+        for c in sorted(CONFIGS):
+            if c == args.config:
+                continue
+            cc = CONFIGS[c]
+            r_, w_ = bytes_per_decision(cc)
+            nb = max(4, int(round(6e9 / (cc["G"] * (r_ + w_)))))
+            out["other_configs"][f"config{c}"] = guarded(measure_config, c, nb, 30, 3, d0, dist)
+        out["pipeline"] = guarded(pipeline_measure, cfg, d0)
+        out["tick"] = guarded(tick_measure, cfg, d0)
+        out["step"] = guarded(step_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
+        out["wire"] = guarded(wire_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
+        out["node"] = guarded(node_measure, d0)
     dist.barrier(world)
     if world.rank == 0:
         print(json.dumps(out))

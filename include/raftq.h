@@ -216,6 +216,50 @@ int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_del
                 raftq_vote_delta_t** vote_deltas);
 int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed);
 
+/* ---- sweep sets: many handles, one dispatch --------------------------------
+ * A host that runs more groups than it wants in one handle (several tenants, several
+ * shards of one keyspace, 1M-group batches of a larger population) sweeps them together:
+ * the G-fold Ready loop of raft.go:220-245 once more over K handles.  A set takes K
+ * handles of one shape (same device, peer count and padded group count) and evaluates
+ * them in ONE kernel launch (grid = tiles x K, the members' array pointers come from a
+ * device-resident table), so the fixed cost of a launch boundary -- about a tenth of a
+ * 1M x 5 sweep on MI355X -- is paid once per set instead of once per member.  Results
+ * are exactly those of raftq_step_async on every member, and every per-handle call
+ * (raftq_wait counts, raftq_read_*, raftq_collect_changed, raftq_apply_*) keeps working
+ * on a member between set sweeps.
+ *   - raftq_set_create re-homes every member onto the set's own stream (so member calls
+ *     and set sweeps stay ordered); raftq_set_stream on a member is refused meanwhile;
+ *     raftq_set_destroy gives every member a fresh stream back.  Destroy the set before
+ *     its members (a member destroyed under a set makes the set refuse further calls).
+ *   - flags are raftq_step_async's (RAFTQ_SWEEP_LDS excepted), applied to every member;
+ *     a gated sweep needs terms loaded on every member.
+ *   - like a handle, a set is not thread-safe, and its members must not be used from
+ *     another thread while the set is. */
+typedef struct raftq_set raftq_set_t;
+#define RAFTQ_SET_GRID 0       /* one K-deep grid: blockIdx.y = member (default) */
+#define RAFTQ_SET_PERSISTENT 1 /* resident workgroups walk all K x tiles, next tile's loads in flight */
+int raftq_set_create(raftq_t* const* handles, uint32_t n, raftq_set_t** out);
+void raftq_set_destroy(raftq_set_t* s);
+uint32_t raftq_set_size(const raftq_set_t* s);
+const char* raftq_set_last_error(const raftq_set_t* s); /* s may be NULL: global */
+void* raftq_set_get_stream(const raftq_set_t* s);
+/* launch shape of the set's sweeps; persist_workgroups 0 keeps the current / default count */
+int raftq_set_mode(raftq_set_t* s, int mode, uint32_t persist_workgroups);
+/* enqueue one pass over every member on the set's stream */
+int raftq_set_sweep_async(raftq_set_t* s, unsigned flags);
+/* block until the set's stream is idle; tallies of each member's most recent sweep into
+ * per_member[raftq_set_size] and / or their sum into *total (either may be NULL) */
+int raftq_set_wait(raftq_set_t* s, raftq_counts_t* per_member, raftq_counts_t* total);
+int raftq_set_timer_begin(raftq_set_t* s);
+int raftq_set_timer_end(raftq_set_t* s, float* elapsed_ms);
+/* the same K sweeps as K launches (raftq_step_async on every handle in turn, each on its
+ * own stream): the host loop of a caller without a set, in one call */
+int raftq_sweep_many_async(raftq_t* const* handles, uint32_t n, unsigned flags);
+/* device-to-device copy of the quorum state (match, commit index, term gate, votes) of
+ * `src` into `dst` (same device, groups and peers): fork a population without a host
+ * round trip.  Tick / Step node state is not copied. */
+int raftq_clone_state(raftq_t* dst, raftq_t* src);
+
 /* ---- measurement hooks (bench harness) --------------------------------- */
 /* HIP events recorded on the handle's own stream, so the elapsed time covers
  * exactly the kernels enqueued between begin and end. */

@@ -22,6 +22,7 @@ SWEEP_LDS = 0x10
 SWEEP_CHANGED = 0x20
 SWEEP_STREAM = 0x40
 SWEEP_CACHED = 0x80
+SET_GRID, SET_PERSISTENT = 0, 1
 
 MAX_PEERS = 9
 
@@ -84,6 +85,18 @@ _SIGS = [
                               C.POINTER(C.c_uint64), C.POINTER(Counts)]),
     ("raftq_stage", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("raftq_last_advances", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_set_create", C.c_int, [C.POINTER(_H), C.c_uint32, C.POINTER(_H)]),
+    ("raftq_set_destroy", None, [_H]),
+    ("raftq_set_size", C.c_uint32, [_H]),
+    ("raftq_set_last_error", C.c_char_p, [_H]),
+    ("raftq_set_get_stream", C.c_void_p, [_H]),
+    ("raftq_set_mode", C.c_int, [_H, C.c_int, C.c_uint32]),
+    ("raftq_set_sweep_async", C.c_int, [_H, C.c_uint]),
+    ("raftq_set_wait", C.c_int, [_H, C.c_void_p, C.POINTER(Counts)]),
+    ("raftq_set_timer_begin", C.c_int, [_H]),
+    ("raftq_set_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
+    ("raftq_sweep_many_async", C.c_int, [C.POINTER(_H), C.c_uint32, C.c_uint]),
+    ("raftq_clone_state", C.c_int, [_H, _H]),
     ("raftq_timer_begin", C.c_int, [_H]),
     ("raftq_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
     ("raftq_host_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_uint64]),

@@ -55,18 +55,39 @@ def lib_sources() -> list[str]:
     ]
 
 
-def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = False) -> str:
+def _flags() -> list[str]:
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = False, log: list | None = None) -> str:
+    """libraftq.so from its five translation units: compiled concurrently (one hipcc per unit), then linked.
+    `log` (a list) receives the exact command lines."""
     srcs = lib_sources()
     if not force and not _stale(LIB, srcs):
         return LIB
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    for k, v in (defines or {}).items():
-        cmd.append(f"-D{k}={v}")
-    cmd += ["-o", LIB] + srcs[:N_UNITS]
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    defs = [f"-D{k}={v}" for k, v in (defines or {}).items()]
+    procs, objs = [], []
+    for src in srcs[:N_UNITS]:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [_hipcc()] + _flags() + defs + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        if log is not None:
+            log.append(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    if log is not None:
+        log.append(" ".join(link))
+    subprocess.check_call(link)
+    os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
@@ -96,10 +117,25 @@ def build_tuner2(force: bool = False) -> str | None:
     return out
 
 
+def build_tuner3(force: bool = False) -> str | None:
+    """Third tuner: launch-shape A/B of round 2 (single / set / persistent / LDS ring; profiles/r02/tune3_*.jsonl)."""
+    src = os.path.join(CSRC, "raftq_tune3.hip")
+    out = TUNER + "3"
+    if not os.path.exists(src):
+        return None
+    if not force and not _stale(out, [src, os.path.join(CSRC, "raftq_kernels.hpp")]):
+        return out
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "-o", out, src]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_lib(force=force)
     build_tuner(force=force)
     build_tuner2(force=force)
+    build_tuner3(force=force)
 
 
 if __name__ == "__main__":

@@ -57,17 +57,46 @@ using raftq_detail::fail;
 
 namespace {
 
+// What a sweep launch covers: one handle (args by value), or a set of K handles through a device-resident
+// table of their SweepArgs -- as one K-deep grid (blockIdx.y = member) or as a persistent grid that walks all
+// K x tiles tiles.
+struct SweepLaunch {
+  const SweepArgs* one = nullptr;  // single handle
+  const SweepArgs* tab = nullptr;  // set: device table [members]
+  uint32_t members = 1;
+  uint32_t want_bits = 0;
+  uint32_t persist_wgs = 0;        // > 0: persistent walk with this many workgroups
+  uint64_t gpad = 0;
+};
+
 // nt: 0 = cached loads and stores, 1 = non-temporal loads, normal stores, 3 = both non-temporal
-template <int N, bool COMMIT, bool GATED, bool VOTES>
-hipError_t launch_reg(const SweepArgs& a, uint64_t gpad, int nt, hipStream_t s) {
-  const dim3 grid((unsigned)(gpad / kTile));
-  if (nt == 3)
-    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kLdNT | kStNT, true>), grid, dim3(kBlock), 0, s, a);
-  else if (nt == 1)
-    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, kLdNT, true>), grid, dim3(kBlock), 0, s, a);
-  else
-    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, 0, true>), grid, dim3(kBlock), 0, s, a);
+// Tile size of the K-deep set grid, per peer count (profiles/r02/tune3_focus_*.jsonl, medians of 9 interleaved
+// runs): 2048-group tiles (GPL 8) win for N <= 5 (10.92 vs 11.15 us per 1M x 5 batch), 512-group tiles (GPL 2)
+// from N = 6 up, where the 8-group register set would not fit 5 waves per SIMD (N = 7: 29.0 vs 30.2 us).
+constexpr int set_gpl(int n_peers) { return n_peers <= 5 ? 8 : 2; }
+
+template <int N, bool COMMIT, bool GATED, bool VOTES, int POLICY>
+hipError_t launch_pol(const SweepLaunch& L, hipStream_t s) {
+  const unsigned tiles = (unsigned)(L.gpad / kTile);
+  if (L.tab == nullptr) {
+    hipLaunchKernelGGL((sweep_kernel<N, kGPL, COMMIT, GATED, VOTES, POLICY, true>), dim3(tiles), dim3(kBlock), 0, s, *L.one);
+  } else if (L.persist_wgs == 0) {
+    constexpr int G = set_gpl(N);
+    hipLaunchKernelGGL((sweep_set_kernel<N, G, COMMIT, GATED, VOTES, POLICY, true>),
+                       dim3((unsigned)(L.gpad / ((uint64_t)kBlock * G)), L.members), dim3(kBlock), 0, s, L.tab, L.want_bits);
+  } else {
+    const uint32_t total = tiles * L.members;
+    hipLaunchKernelGGL((sweep_persist_kernel<N, kGPL, COMMIT, GATED, VOTES, POLICY, true>),
+                       dim3(std::min<uint32_t>(L.persist_wgs, total)), dim3(kBlock), 0, s, L.tab, tiles, total, L.want_bits);
+  }
   return hipGetLastError();
+}
+
+template <int N, bool COMMIT, bool GATED, bool VOTES>
+hipError_t launch_reg(const SweepLaunch& L, int nt, hipStream_t s) {
+  if (nt == 3) return launch_pol<N, COMMIT, GATED, VOTES, kLdNT | kStNT>(L, s);
+  if (nt == 1) return launch_pol<N, COMMIT, GATED, VOTES, kLdNT>(L, s);
+  return launch_pol<N, COMMIT, GATED, VOTES, 0>(L, s);
 }
 
 template <int N, bool GATED, bool VOTES>
@@ -81,30 +110,31 @@ hipError_t launch_lds(const SweepArgs& a, uint64_t gpad, hipStream_t s) {
 }
 
 template <int N>
-hipError_t launch_n(const SweepArgs& a, uint64_t gpad, unsigned flags, int nt, hipStream_t s) {
+hipError_t launch_n(const SweepLaunch& L, unsigned flags, int nt, hipStream_t s) {
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool gated = flags & RAFTQ_SWEEP_GATED;
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
   if ((flags & RAFTQ_SWEEP_LDS) && commit) {
-    if (gated) return votes ? launch_lds<N, true, true>(a, gpad, s) : launch_lds<N, true, false>(a, gpad, s);
-    return votes ? launch_lds<N, false, true>(a, gpad, s) : launch_lds<N, false, false>(a, gpad, s);
+    if (L.tab) return hipErrorInvalidValue;  // the LDS A/B variant sweeps one handle at a time
+    if (gated) return votes ? launch_lds<N, true, true>(*L.one, L.gpad, s) : launch_lds<N, true, false>(*L.one, L.gpad, s);
+    return votes ? launch_lds<N, false, true>(*L.one, L.gpad, s) : launch_lds<N, false, false>(*L.one, L.gpad, s);
   }
-  if (commit && gated) return votes ? launch_reg<N, true, true, true>(a, gpad, nt, s) : launch_reg<N, true, true, false>(a, gpad, nt, s);
-  if (commit) return votes ? launch_reg<N, true, false, true>(a, gpad, nt, s) : launch_reg<N, true, false, false>(a, gpad, nt, s);
-  return launch_reg<N, false, false, true>(a, gpad, nt, s);
+  if (commit && gated) return votes ? launch_reg<N, true, true, true>(L, nt, s) : launch_reg<N, true, true, false>(L, nt, s);
+  if (commit) return votes ? launch_reg<N, true, false, true>(L, nt, s) : launch_reg<N, true, false, false>(L, nt, s);
+  return launch_reg<N, false, false, true>(L, nt, s);
 }
 
-hipError_t launch_sweep(uint32_t N, const SweepArgs& a, uint64_t gpad, unsigned flags, int nt, hipStream_t s) {
+hipError_t launch_sweep(uint32_t N, const SweepLaunch& L, unsigned flags, int nt, hipStream_t s) {
   switch (N) {
-    case 1: return launch_n<1>(a, gpad, flags, nt, s);
-    case 2: return launch_n<2>(a, gpad, flags, nt, s);
-    case 3: return launch_n<3>(a, gpad, flags, nt, s);
-    case 4: return launch_n<4>(a, gpad, flags, nt, s);
-    case 5: return launch_n<5>(a, gpad, flags, nt, s);
-    case 6: return launch_n<6>(a, gpad, flags, nt, s);
-    case 7: return launch_n<7>(a, gpad, flags, nt, s);
-    case 8: return launch_n<8>(a, gpad, flags, nt, s);
-    case 9: return launch_n<9>(a, gpad, flags, nt, s);
+    case 1: return launch_n<1>(L, flags, nt, s);
+    case 2: return launch_n<2>(L, flags, nt, s);
+    case 3: return launch_n<3>(L, flags, nt, s);
+    case 4: return launch_n<4>(L, flags, nt, s);
+    case 5: return launch_n<5>(L, flags, nt, s);
+    case 6: return launch_n<6>(L, flags, nt, s);
+    case 7: return launch_n<7>(L, flags, nt, s);
+    case 8: return launch_n<8>(L, flags, nt, s);
+    case 9: return launch_n<9>(L, flags, nt, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -252,6 +282,15 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
 
 void raftq_destroy(raftq_t* h) {
   if (!h) return;
+  if (h->in_set) {  // destroyed under its set: the set refuses further sweeps instead of touching freed memory
+    raftq_set_t* s = h->in_set;
+    s->broken = true;
+    s->members.erase(std::remove(s->members.begin(), s->members.end(), h), s->members.end());
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(s->stream);
+    h->stream = nullptr;
+    h->own_stream = false;
+  }
   if (h->prof_n && std::getenv("RAFTQ_PROFILE"))
     std::fprintf(stderr,
                  "[raftq] cycle phases, avg us over %llu calls: stage/validate %.1f | enqueue scatter %.1f | enqueue sweep "
@@ -291,6 +330,7 @@ void raftq_destroy(raftq_t* h) {
 
 int raftq_set_stream(raftq_t* h, void* stream) {
   if (int rc = use_device_idle(h, "raftq_set_stream")) return rc;
+  if (h->in_set) return fail(h, RAFTQ_ESTATE, "raftq_set_stream: the handle is a member of a sweep set, which owns its stream");
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->own_stream) HIPCHK(h, hipStreamDestroy(h->stream));
   h->stream = (hipStream_t)stream;
@@ -465,49 +505,81 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
   return check_deltas(h);
 }
 
-int raftq_step_async(raftq_t* h, unsigned flags) {
-  if (int rc = use_device_idle(h, "raftq_step_async")) return rc;
+// ---- one sweep = validate flags -> fill SweepArgs -> launch -> per-handle bookkeeping.  The three host-side
+// pieces are shared by raftq_step_async (one handle per launch) and raftq_set_sweep_async (a set per launch).
+static int sweep_check(raftq_t* h, unsigned flags, const char* who) {
   const unsigned known = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_VOTES | RAFTQ_SWEEP_NO_ADOPT |
                          RAFTQ_SWEEP_LDS | RAFTQ_SWEEP_CHANGED | RAFTQ_SWEEP_STREAM | RAFTQ_SWEEP_CACHED;
-  if (flags & ~known) return fail(h, RAFTQ_EINVAL, "raftq_step_async: unknown flag");
+  const std::string w(who);
+  if (flags & ~known) return fail(h, RAFTQ_EINVAL, w + ": unknown flag");
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool votes = flags & RAFTQ_SWEEP_VOTES;
-  if (!commit && !votes) return fail(h, RAFTQ_EINVAL, "raftq_step_async: nothing to sweep");
+  if (!commit && !votes) return fail(h, RAFTQ_EINVAL, w + ": nothing to sweep");
   if ((flags & RAFTQ_SWEEP_GATED) && !h->have_terms)
-    return fail(h, RAFTQ_ESTATE, "raftq_step_async: gated sweep before raftq_load_terms");
+    return fail(h, RAFTQ_ESTATE, w + ": gated sweep before raftq_load_terms");
   if ((flags & RAFTQ_SWEEP_STREAM) && (flags & RAFTQ_SWEEP_CACHED))
-    return fail(h, RAFTQ_EINVAL, "raftq_step_async: RAFTQ_SWEEP_STREAM and RAFTQ_SWEEP_CACHED are exclusive");
+    return fail(h, RAFTQ_EINVAL, w + ": RAFTQ_SWEEP_STREAM and RAFTQ_SWEEP_CACHED are exclusive");
   if ((flags & RAFTQ_SWEEP_CHANGED) && !commit)
-    return fail(h, RAFTQ_EINVAL, "raftq_step_async: RAFTQ_SWEEP_CHANGED needs a commit sweep");
+    return fail(h, RAFTQ_EINVAL, w + ": RAFTQ_SWEEP_CHANGED needs a commit sweep");
+  return RAFTQ_OK;
+}
+
+static SweepArgs sweep_args(const raftq_t* h, int cur, bool want_bits) {
   SweepArgs a;
   a.match = h->match;
-  a.committed = h->committed[h->cur];
-  a.committed_out = h->committed[h->cur ^ 1];
+  a.committed = h->committed[cur];
+  a.committed_out = h->committed[cur ^ 1];
   a.first_idx = h->first_idx;
   a.votes = h->votes;
   a.outcome = h->outcome;
-  a.changed_bits = (flags & RAFTQ_SWEEP_CHANGED) ? h->changed_bits : nullptr;
+  a.changed_bits = want_bits ? h->changed_bits : nullptr;
   a.partials = h->partials;
   a.ld = h->ld;
-  const bool lds = (flags & RAFTQ_SWEEP_LDS) && commit;
-  const int gpl = lds ? kLdsGPL : kGPL;
-  const uint64_t footprint = h->ld * (8ull * h->N + 24 + h->N + 1);
-  // Streaming policy (profiles/r01/tune_policy_ld_vs_ldst.txt): loads always non-temporal; stores too only
-  // once the state outgrows ~128 MiB (2M x 7: -1.7 % with NT stores; 1M x 3/5/9: +1-2 % without them,
-  // and +9 % when the state is cache-resident, because the written commit indices are re-read next sweep)
+  return a;
+}
+
+static uint64_t sweep_footprint(const raftq_t* h) { return h->ld * (8ull * h->N + 24 + h->N + 1); }
+
+// Streaming policy (profiles/r01/tune_policy_ld_vs_ldst.txt): loads always non-temporal; stores too only
+// once the state outgrows ~128 MiB (2M x 7: -1.7 % with NT stores; 1M x 3/5/9: +1-2 % without them,
+// and +9 % when the state is cache-resident, because the written commit indices are re-read next sweep)
+static int sweep_policy(unsigned flags, uint64_t footprint) {
   const bool stream = (flags & RAFTQ_SWEEP_STREAM) ? true
                       : (flags & RAFTQ_SWEEP_CACHED) ? false
                                                      : footprint >= RAFTQ_AUTO_STREAM_BYTES;
-  const int nt = !stream ? 0 : footprint >= RAFTQ_AUTO_STREAM_BYTES ? 3 : 1;
-  HIPCHK(h, launch_sweep(h->N, a, h->gpad, flags, nt, h->stream));
+  return !stream ? 0 : footprint >= RAFTQ_AUTO_STREAM_BYTES ? 3 : 1;
+}
+
+static void sweep_done(raftq_t* h, unsigned flags, int gpl) {
+  const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   h->n_partials = h->gpad / ((uint64_t)kBlock * gpl) * kWaves;
   h->last_flags = flags;
   h->last_gpl = gpl;
   if (commit) {
-    h->last_old = a.committed;
-    h->last_new = a.committed_out;
+    h->last_old = h->committed[h->cur];
+    h->last_new = h->committed[h->cur ^ 1];
     if (!(flags & RAFTQ_SWEEP_NO_ADOPT)) h->cur ^= 1;
   }
+}
+
+int raftq_step_async(raftq_t* h, unsigned flags) {
+  if (int rc = use_device_idle(h, "raftq_step_async")) return rc;
+  if (int rc = sweep_check(h, flags, "raftq_step_async")) return rc;
+  const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+  const SweepArgs a = sweep_args(h, h->cur, flags & RAFTQ_SWEEP_CHANGED);
+  const bool lds = (flags & RAFTQ_SWEEP_LDS) && commit;
+  SweepLaunch L;
+  L.one = &a;
+  L.gpad = h->gpad;
+  HIPCHK(h, launch_sweep(h->N, L, flags, sweep_policy(flags, sweep_footprint(h)), h->stream));
+  sweep_done(h, flags, lds ? kLdsGPL : kGPL);
+  return RAFTQ_OK;
+}
+
+int raftq_sweep_many_async(raftq_t* const* handles, uint32_t n, unsigned flags) {
+  if (!handles && n) return fail(nullptr, RAFTQ_EINVAL, "raftq_sweep_many_async: null handle array");
+  for (uint32_t i = 0; i < n; ++i)
+    if (int rc = raftq_step_async(handles[i], flags)) return rc;
   return RAFTQ_OK;
 }
 
@@ -722,12 +794,21 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap) {
   if (take_cap) {
     const int gpl = h->last_gpl;
     const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
-    if (gpl == kGPL)
-      hipLaunchKernelGGL((compact_changed_kernel<kGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
-                         h->offsets, h->last_old, h->last_new, h->adv_d, take_cap);
-    else
-      hipLaunchKernelGGL((compact_changed_kernel<kLdsGPL>), grid, dim3(kBlock), 0, h->stream, h->changed_bits,
-                         h->offsets, h->last_old, h->last_new, h->adv_d, take_cap);
+    // the compaction mirrors the geometry of the sweep that wrote the bitmap and the per-wave counts
+    switch (gpl) {
+      case 2:
+        hipLaunchKernelGGL((compact_changed_kernel<2>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
+                           h->last_old, h->last_new, h->adv_d, take_cap);
+        break;
+      case 8:
+        hipLaunchKernelGGL((compact_changed_kernel<8>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
+                           h->last_old, h->last_new, h->adv_d, take_cap);
+        break;
+      default:
+        static_assert(kGPL == 4 && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
+        hipLaunchKernelGGL((compact_changed_kernel<4>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
+                           h->last_old, h->last_new, h->adv_d, take_cap);
+    }
   }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
@@ -871,6 +952,236 @@ int raftq_host_alloc(void** p, uint64_t bytes) {
 
 void raftq_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"
+
+// ---- sweep sets (include/raftq.h "sweep sets") ---------------------------------------------
+namespace {
+thread_local std::string g_set_err;
+int sfail(raftq_set_t* s, int code, const std::string& msg) {
+  g_set_err = msg;
+  if (s) s->err = msg;
+  return fail(nullptr, code, msg);
+}
+#define SETCHK(s, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      return sfail((s), _e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP,                           \
+                   std::string(#expr) + ": " + hipGetErrorString(_e));                                    \
+  } while (0)
+
+int set_ready(raftq_set_t* s, const char* who) {
+  if (!s) return sfail(nullptr, RAFTQ_EINVAL, std::string(who) + ": null set");
+  if (s->broken) return sfail(s, RAFTQ_ESTATE, std::string(who) + ": a member of the set was destroyed");
+  SETCHK(s, hipSetDevice(s->device));
+  return RAFTQ_OK;
+}
+
+void set_fill_table(const raftq_set_t* s, int cur, std::vector<SweepArgs>& t) {
+  t.resize(s->members.size());
+  for (size_t i = 0; i < s->members.size(); ++i)
+    t[i] = sweep_args(s->members[i], cur < 0 ? s->members[i]->cur : cur, true);
+}
+}  // namespace
+
+extern "C" {
+
+int raftq_set_create(raftq_t* const* handles, uint32_t n, raftq_set_t** out) {
+  if (!out) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_create: null out");
+  *out = nullptr;
+  if (!handles || n == 0) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_create: empty set");
+  if (n > 65535) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_create: at most 65535 members");
+  for (uint32_t i = 0; i < n; ++i) {
+    raftq_t* h = handles[i];
+    if (!h) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_create: null member");
+    if (h->in_set) return sfail(nullptr, RAFTQ_ESTATE, "raftq_set_create: a handle is already a member of a set");
+    if (h->device != handles[0]->device || h->N != handles[0]->N || h->gpad != handles[0]->gpad)
+      return sfail(nullptr, RAFTQ_EINVAL,
+                   "raftq_set_create: members must share the device, the peer count and the (padded) group count");
+    if (h->step_collected != h->step_submitted)
+      return sfail(nullptr, RAFTQ_ESTATE, "raftq_set_create: a member has Step batches in flight");
+    for (uint32_t k = 0; k < i; ++k)
+      if (handles[k] == h) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_create: duplicate member");
+  }
+  raftq_set_t* s = new (std::nothrow) raftq_set();
+  if (!s) return sfail(nullptr, RAFTQ_ENOMEM, "raftq_set_create: host allocation failed");
+  s->device = handles[0]->device;
+  s->N = handles[0]->N;
+  s->gpad = handles[0]->gpad;
+  if (const char* e = std::getenv("RAFTQ_SET_MODE")) s->mode = std::atoi(e) == 1 ? 1 : 0;
+  auto bail = [&](int rc) {
+    std::string keep = s->err;
+    raftq_set_destroy(s);
+    g_set_err = keep;
+    return rc;
+  };
+  hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc((void**)&s->tab[k], (size_t)n * sizeof(SweepArgs));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->counts_d, (size_t)n * 32);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->counts_h, (size_t)n * 32, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+  if (e != hipSuccess)
+    return bail(sfail(s, e == hipErrorOutOfMemory ? RAFTQ_ENOMEM : RAFTQ_EHIP, std::string("raftq_set_create: ") + hipGetErrorString(e)));
+  // re-home every member onto the set's stream: loads, deltas and per-member read-backs stay ordered with the
+  // set's sweeps without any event traffic
+  for (uint32_t i = 0; i < n; ++i) {
+    raftq_t* h = handles[i];
+    e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && h->own_stream) e = hipStreamDestroy(h->stream);
+    if (e != hipSuccess) return bail(sfail(s, RAFTQ_EHIP, std::string("raftq_set_create: ") + hipGetErrorString(e)));
+    h->stream = s->stream;
+    h->own_stream = false;
+    h->in_set = s;
+    s->members.push_back(h);
+  }
+  for (int cur = 0; cur < 2; ++cur) {
+    set_fill_table(s, cur, s->tab_host);
+    e = hipMemcpy(s->tab[cur], s->tab_host.data(), (size_t)n * sizeof(SweepArgs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(sfail(s, RAFTQ_EHIP, std::string("raftq_set_create: ") + hipGetErrorString(e)));
+  }
+  int cus = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
+  s->persist_wgs = (uint32_t)std::max(cus, 1) * 3u;  // 3 resident 256-thread workgroups per CU (161 VGPRs)
+  if (const char* w = std::getenv("RAFTQ_SET_PERSIST_WGS")) s->persist_wgs = (uint32_t)std::max(1, std::atoi(w));
+  *out = s;
+  return RAFTQ_OK;
+}
+
+void raftq_set_destroy(raftq_set_t* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (raftq_t* h : s->members) {  // members live on: each gets a stream of its own back
+    h->in_set = nullptr;
+    h->stream = nullptr;
+    h->own_stream = false;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess) h->own_stream = true;
+  }
+  for (int k = 0; k < 3; ++k) (void)hipFree(s->tab[k]);
+  (void)hipFree(s->counts_d);
+  if (s->counts_h) (void)hipHostFree(s->counts_h);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+uint32_t raftq_set_size(const raftq_set_t* s) { return s ? (uint32_t)s->members.size() : 0; }
+const char* raftq_set_last_error(const raftq_set_t* s) { return s ? s->err.c_str() : g_set_err.c_str(); }
+void* raftq_set_get_stream(const raftq_set_t* s) { return s ? (void*)s->stream : nullptr; }
+
+int raftq_set_mode(raftq_set_t* s, int mode, uint32_t persist_workgroups) {
+  if (!s) return sfail(nullptr, RAFTQ_EINVAL, "raftq_set_mode: null set");
+  if (mode != RAFTQ_SET_GRID && mode != RAFTQ_SET_PERSISTENT) return sfail(s, RAFTQ_EINVAL, "raftq_set_mode: unknown mode");
+  s->mode = mode;
+  if (persist_workgroups) s->persist_wgs = persist_workgroups;
+  return RAFTQ_OK;
+}
+
+int raftq_set_sweep_async(raftq_set_t* s, unsigned flags) {
+  if (int rc = set_ready(s, "raftq_set_sweep_async")) return rc;
+  if (flags & RAFTQ_SWEEP_LDS) return sfail(s, RAFTQ_EINVAL, "raftq_set_sweep_async: RAFTQ_SWEEP_LDS sweeps one handle at a time");
+  uint64_t footprint = 0;
+  int cur = s->members[0]->cur;
+  for (raftq_t* h : s->members) {
+    if (h->step_collected != h->step_submitted)
+      return sfail(s, RAFTQ_ESTATE, "raftq_set_sweep_async: a member has Step batches in flight; collect them first");
+    if (int rc = sweep_check(h, flags, "raftq_set_sweep_async")) return sfail(s, rc, h->err);
+    footprint += sweep_footprint(h);
+    if (h->cur != cur) cur = -1;
+  }
+  const SweepArgs* tab = s->tab[cur < 0 ? 2 : cur];
+  if (cur < 0) {  // members disagree on which commit buffer is current: build this launch's table
+    set_fill_table(s, -1, s->tab_host);
+    SETCHK(s, hipMemcpyAsync(s->tab[2], s->tab_host.data(), s->tab_host.size() * sizeof(SweepArgs), hipMemcpyHostToDevice,
+                             s->stream));
+  }
+  SweepLaunch L;
+  L.tab = tab;
+  L.members = (uint32_t)s->members.size();
+  L.want_bits = (flags & RAFTQ_SWEEP_CHANGED) ? 1u : 0u;
+  L.persist_wgs = s->mode == RAFTQ_SET_PERSISTENT ? s->persist_wgs : 0u;
+  L.gpad = s->gpad;
+  // a set that streams, streams its stores too: with many members in one dispatch non-temporal stores are worth
+  // 5-9 % (profiles/r02/tune3_focus_*.jsonl: 10.92 vs 11.78 us per batch), unlike one 1M-group launch at a time
+  int nt = sweep_policy(flags, footprint);
+  if (nt == 1) nt = 3;
+  SETCHK(s, launch_sweep(s->N, L, flags, nt, s->stream));
+  const int gpl = s->mode == RAFTQ_SET_PERSISTENT ? kGPL : set_gpl((int)s->N);
+  for (raftq_t* h : s->members) sweep_done(h, flags, gpl);
+  s->swept = true;
+  s->last_flags = flags;
+  return RAFTQ_OK;
+}
+
+int raftq_set_wait(raftq_set_t* s, raftq_counts_t* per_member, raftq_counts_t* total) {
+  if (int rc = set_ready(s, "raftq_set_wait")) return rc;
+  const bool want = per_member || total;
+  const size_t n = s->members.size();
+  if (want) {
+    if (!s->swept) return sfail(s, RAFTQ_ESTATE, "raftq_set_wait: no set sweep to report on");
+    // the tallies of the LAST sweep of every member (a member swept on its own since then reports that sweep)
+    set_fill_table(s, -1, s->tab_host);
+    SETCHK(s, hipMemcpyAsync(s->tab[2], s->tab_host.data(), n * sizeof(SweepArgs), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(set_counts_kernel, dim3((unsigned)n), dim3(kBlock), 0, s->stream, (const SweepArgs*)s->tab[2],
+                       s->members[0]->n_partials, s->counts_d);
+    SETCHK(s, hipGetLastError());
+    SETCHK(s, hipMemcpyAsync(s->counts_h, s->counts_d, n * 32, hipMemcpyDeviceToHost, s->stream));
+  }
+  SETCHK(s, hipStreamSynchronize(s->stream));
+  if (want) {
+    raftq_counts_t t{0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+      const unsigned f = s->members[i]->last_flags;
+      const bool commit = f & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
+      const bool votes = f & RAFTQ_SWEEP_VOTES;
+      raftq_counts_t c{commit ? s->counts_h[4 * i] : 0, votes ? s->counts_h[4 * i + 1] : 0, votes ? s->counts_h[4 * i + 2] : 0};
+      if (per_member) per_member[i] = c;
+      t.n_changed += c.n_changed;
+      t.n_won += c.n_won;
+      t.n_lost += c.n_lost;
+    }
+    if (total) *total = t;
+  }
+  return RAFTQ_OK;
+}
+
+int raftq_set_timer_begin(raftq_set_t* s) {
+  if (int rc = set_ready(s, "raftq_set_timer_begin")) return rc;
+  SETCHK(s, hipEventRecord(s->ev0, s->stream));
+  return RAFTQ_OK;
+}
+
+int raftq_set_timer_end(raftq_set_t* s, float* elapsed_ms) {
+  if (int rc = set_ready(s, "raftq_set_timer_end")) return rc;
+  if (!elapsed_ms) return sfail(s, RAFTQ_EINVAL, "raftq_set_timer_end: null argument");
+  SETCHK(s, hipEventRecord(s->ev1, s->stream));
+  SETCHK(s, hipEventSynchronize(s->ev1));
+  SETCHK(s, hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
+  return RAFTQ_OK;
+}
+
+int raftq_clone_state(raftq_t* dst, raftq_t* src) {
+  if (int rc = use_device_idle(dst, "raftq_clone_state")) return rc;
+  if (!src) return fail(dst, RAFTQ_EINVAL, "raftq_clone_state: null source");
+  if (src == dst) return RAFTQ_OK;
+  if (src->device != dst->device || src->N != dst->N || src->G != dst->G)
+    return fail(dst, RAFTQ_EINVAL, "raftq_clone_state: source and destination must have the same device, groups and peers");
+  if (src->step_collected != src->step_submitted)
+    return fail(dst, RAFTQ_ESTATE, "raftq_clone_state: the source has Step batches in flight");
+  HIPCHK(dst, hipStreamSynchronize(src->stream));
+  const uint64_t ld = dst->ld;
+  HIPCHK(dst, hipMemcpyAsync(dst->match, src->match, (size_t)dst->N * ld * 8, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->committed[dst->cur], src->committed[src->cur], ld * 8, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->first_idx, src->first_idx, ld * 8, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->votes, src->votes, (size_t)dst->N * ld, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipStreamSynchronize(dst->stream));
+  dst->have_terms = src->have_terms;
+  return RAFTQ_OK;
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "raftq.h"
 #include "raftq_kernels.hpp"
@@ -14,6 +15,7 @@ struct raftq {
   uint32_t N = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  struct raftq_set* in_set = nullptr;  // member of a sweep set: the set owns the stream
   uint64_t* match = nullptr;
   uint64_t* committed[2] = {nullptr, nullptr};
   int cur = 0;
@@ -128,6 +130,29 @@ struct raftq {
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};
   uint64_t prof_n = 0;
+};
+
+
+// A set of handles of one shape on one GPU, swept by a single dispatch (raftq_set_*).
+struct raftq_set {
+  int device = 0;
+  uint32_t N = 0;
+  uint64_t gpad = 0;
+  std::vector<raftq_t*> members;
+  hipStream_t stream = nullptr;       // the set's stream; every member is re-homed onto it
+  // device tables of the members' SweepArgs: [0] every member reads commit buffer 0, [1] buffer 1,
+  // [2] rebuilt per launch when the members' buffers differ (someone swept a member on its own)
+  raftqk::SweepArgs* tab[3] = {nullptr, nullptr, nullptr};
+  std::vector<raftqk::SweepArgs> tab_host;  // pageable on purpose: hipMemcpyAsync stages it before returning
+  uint64_t* counts_d = nullptr;       // [members][4] {changed, won, lost, 0}, reduced on the device
+  uint64_t* counts_h = nullptr;       // pinned
+  bool swept = false;
+  bool broken = false;                // a member was destroyed under the set
+  unsigned last_flags = 0;
+  int mode = 0;                       // 0 = K-deep grid, 1 = persistent walk (RAFTQ_SET_MODE / raftq_set_mode)
+  uint32_t persist_wgs = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
 };
 
 

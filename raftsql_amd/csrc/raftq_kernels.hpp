@@ -125,6 +125,30 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
   __builtin_nontemporal_store(v, p);
 }
 
+// The set kernels read their array pointers from a table in memory, where the compiler cannot see that they
+// point to global memory and would fall back to flat_load / flat_store (which tie up lgkmcnt as well and make
+// every wait a vmcnt(0)).  These state the address space.
+#define RAFTQ_GLOBAL __attribute__((address_space(1)))
+template <bool NT, typename T>
+__device__ __forceinline__ T ldg(const T* p) {
+  const RAFTQ_GLOBAL T* g = (const RAFTQ_GLOBAL T*)p;
+  if constexpr (NT) return __builtin_nontemporal_load(g);
+  else return *g;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stg(T* p, T v) {
+  RAFTQ_GLOBAL T* g = (RAFTQ_GLOBAL T*)p;
+  if constexpr (NT) __builtin_nontemporal_store(v, g);
+  else *g = v;
+}
+// uint4 is a class type in HIP (no assignment through an address-space-qualified pointer): store it as a native vector
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stg_u4(uint4* p, uint4 v) {
+  u32x4 t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(RAFTQ_GLOBAL u32x4*)p = t;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -148,55 +172,67 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 // is a measurement-only ablation (tuner) that drops the output stores.
 constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
 
-template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
-static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
+// A tile's inputs in registers: filled by tile_load (every load issued, nothing waited for), consumed by
+// tile_finish.  Split so that a persistent kernel can have the next tile's loads in flight while it finishes
+// the current one (sweep_persist_kernel); the one-tile kernels call them back to back.
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES>
+struct TileRegs {
+  static constexpr int kRounds = GPL / 2;
+  u64x2 m[COMMIT ? kRounds : 1][N];
+  u64x2 c[COMMIT ? kRounds : 1];
+  u64x2 f[COMMIT && GATED ? kRounds : 1];
+  uint64_t vv[VOTES ? N : 1];
+};
+
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, int BLOCK = kBlock>
+__device__ __forceinline__ void tile_load(TileRegs<N, GPL, COMMIT, GATED, VOTES>& r, const SweepArgs& a,
+                                          const uint32_t tile) {
   constexpr bool NT = (POLICY & kLdNT) != 0;
+  constexpr int kTile = BLOCK * GPL;
+  constexpr int kRounds = GPL / 2;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)tile * kTile;
+  // vote rows first: their loads fly while the commit part computes
+  constexpr int kVoteLanes = kTile / 8;  // lanes that own 8 groups each
+  if constexpr (VOTES) {
+    if (tid < kVoteLanes) {  // wave-uniform (kVoteLanes % 64 == 0)
+      const uint64_t g = tile0 + 8ull * tid;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        r.vv[p] = ldg<NT>(reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g));
+      }
+    }
+  }
+  if constexpr (COMMIT) {
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        r.m[j][p] = ldg<NT>(reinterpret_cast<const u64x2*>(a.match + (uint64_t)p * a.ld + g));
+      }
+      r.c[j] = ldg<NT>(reinterpret_cast<const u64x2*>(a.committed + g));
+      if constexpr (GATED) r.f[j] = ldg<NT>(reinterpret_cast<const u64x2*>(a.first_idx + g));
+    }
+  }
+}
+
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
+__device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED, VOTES>& r, const SweepArgs& a,
+                                            const uint32_t tile) {
   constexpr bool STNT = (POLICY & kStNT) != 0;
   constexpr bool NOSTORE = (POLICY & kNoStore) != 0;
   constexpr int kTile = BLOCK * GPL;
   constexpr int kWavesB = BLOCK / 64;
   constexpr int kRounds = GPL / 2;
   const uint32_t tid = threadIdx.x;
-  const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+  const uint64_t tile0 = (uint64_t)tile * kTile;
   uint32_t n_changed = 0;  // wave-uniform
   uint32_t won_lost = 0;   // per lane: won | lost << 16
-
-  // vote rows first: their loads fly while the commit part computes
-  constexpr int kVoteLanes = kTile / 8;  // lanes that own 8 groups each
-  const bool vote_lane = VOTES && tid < kVoteLanes;  // wave-uniform (kVoteLanes % 64 == 0)
-  uint64_t vv[N];
-  if constexpr (VOTES) {
-    if (vote_lane) {
-      const uint64_t g = tile0 + 8ull * tid;
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g);
-        vv[p] = NT ? ld_stream(src) : *src;
-      }
-    }
-  }
+  constexpr int kVoteLanes = kTile / 8;
+  const bool vote_lane = VOTES && tid < kVoteLanes;
 
   if constexpr (COMMIT) {
-    u64x2 m[kRounds][N];
-    u64x2 c[kRounds];
-    u64x2 f[kRounds];
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) {
-      const uint64_t g = tile0 + (uint64_t)(tid >> 6) * (64 * GPL) + (uint64_t)j * 128 + 2 * (tid & 63);
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const u64x2* src = reinterpret_cast<const u64x2*>(a.match + (uint64_t)p * a.ld + g);
-        m[j][p] = NT ? ld_stream(src) : *src;
-      }
-      {
-        const u64x2* src = reinterpret_cast<const u64x2*>(a.committed + g);
-        c[j] = NT ? ld_stream(src) : *src;
-      }
-      if constexpr (GATED) {
-        const u64x2* src = reinterpret_cast<const u64x2*>(a.first_idx + g);
-        f[j] = NT ? ld_stream(src) : *src;
-      }
-    }
     // (A/B, profiles/r01/tune_sched_barrier.txt: forcing every load ahead of the first compare with
     // a sched_barrier is SLOWER -- 12.5 vs 12.3 us at N=5, 50 vs 30 us at N=7 from register
     // pressure; hipcc's own split of 8 loads up front + 4 interleaved is kept.)
@@ -206,8 +242,8 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
       uint64_t v0[N], v1[N];
 #pragma unroll
       for (int p = 0; p < N; ++p) {
-        v0[p] = m[j][p].x;
-        v1[p] = m[j][p].y;
+        v0[p] = r.m[j][p].x;
+        v1[p] = r.m[j][p].y;
       }
       uint64_t mci0, mci1;
       if constexpr (N == 1) {
@@ -218,10 +254,10 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
         mci1 = select_quorum_network<N>(v1);
       }
       u64x2 o;
-      o.x = maybe_commit<GATED>(mci0, c[j].x, GATED ? f[j].x : 0);
-      o.y = maybe_commit<GATED>(mci1, c[j].y, GATED ? f[j].y : 0);
-      const bool ch0 = o.x != c[j].x;
-      const bool ch1 = o.y != c[j].y;
+      o.x = maybe_commit<GATED>(mci0, r.c[j].x, GATED ? r.f[j].x : 0);
+      o.y = maybe_commit<GATED>(mci1, r.c[j].y, GATED ? r.f[j].y : 0);
+      const bool ch0 = o.x != r.c[j].x;
+      const bool ch1 = o.y != r.c[j].y;
       const uint64_t b0 = __ballot(ch0);
       const uint64_t b1 = __ballot(ch1);
       n_changed += __popcll(b0) + __popcll(b1);
@@ -232,14 +268,13 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
           u64x2 w;
           w.x = b0;
           w.y = b1;
-          *reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)) = w;
+          stg<false>(reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)), w);
         }
       }
-      u64x2* dst = reinterpret_cast<u64x2*>(a.committed_out + g);
       if constexpr (NOSTORE) {
         asm volatile("" ::"v"(o.x), "v"(o.y));
       } else {
-        if (STNT) st_stream(dst, o); else *dst = o;
+        stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
       }
     }
   }
@@ -250,8 +285,8 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
       uint64_t granted = 0, rejected = 0;  // per-byte counters, <= N <= 9
 #pragma unroll
       for (int p = 0; p < N; ++p) {
-        granted += bytes_equal(vv[p], 0x0101010101010101ull);
-        rejected += bytes_equal(vv[p], 0x0202020202020202ull);
+        granted += bytes_equal(r.vv[p], 0x0101010101010101ull);
+        rejected += bytes_equal(r.vv[p], 0x0202020202020202ull);
       }
       constexpr uint64_t q = N / 2 + 1;
       constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
@@ -259,11 +294,10 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
       const uint64_t won = ((granted + bias) & k80) >> 7;    // 0x01 where granted >= q
       const uint64_t lost = ((rejected + bias) & k80) >> 7;  // exclusive with won (g+r <= N < 2q)
       const uint64_t out = won | ((lost & ~won) << 1);
-      uint64_t* dst = reinterpret_cast<uint64_t*>(a.outcome + g);
       if constexpr (NOSTORE) {
         asm volatile("" ::"v"(out));
       } else {
-        if (STNT) st_stream(dst, out); else *dst = out;
+        stg<STNT>(reinterpret_cast<uint64_t*>(a.outcome + g), out);
       }
       won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
     }
@@ -271,13 +305,116 @@ static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
 
   const uint32_t wl = VOTES ? wave_sum_u32(won_lost) : 0u;
   if ((tid & 63) == 0) {
-    uint4 r;
-    r.x = n_changed;
-    r.y = wl & 0xffffu;
-    r.z = wl >> 16;
-    r.w = 0;
-    a.partials[(uint64_t)blockIdx.x * kWavesB + (tid >> 6)] = r;
+    uint4 t;
+    t.x = n_changed;
+    t.y = wl & 0xffffu;
+    t.z = wl >> 16;
+    t.w = 0;
+    stg_u4(a.partials + ((uint64_t)tile * kWavesB + (tid >> 6)), t);
   }
+}
+
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
+__device__ __forceinline__ void sweep_tile(const SweepArgs& a, const uint32_t tile) {
+  TileRegs<N, GPL, COMMIT, GATED, VOTES> r;
+  tile_load<N, GPL, COMMIT, GATED, VOTES, POLICY, BLOCK>(r, a, tile);
+  tile_finish<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS, BLOCK>(r, a, tile);
+}
+
+// One handle per launch: blockIdx.x = tile.
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
+static __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a) {
+  sweep_tile<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS, BLOCK>(a, blockIdx.x);
+}
+
+// A set of handles per launch (raftq_set_sweep_async): blockIdx.y = member, blockIdx.x = tile.  Every member has
+// the same N and padded size; its array pointers come from a device-resident table (wave-uniform: scalar loads).
+// One dispatch over K members costs one launch boundary instead of K -- at 1M groups per member the boundary
+// (ramp + drain of a 65 MB burst) is 10 % of a sweep (profiles/r02).
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int BLOCK = kBlock>
+static __global__ __launch_bounds__(BLOCK) void sweep_set_kernel(const SweepArgs* __restrict__ tab, uint32_t want_bits) {
+  SweepArgs a = tab[blockIdx.y];
+  if (!want_bits) a.changed_bits = nullptr;
+  sweep_tile<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS, BLOCK>(a, blockIdx.x);
+}
+
+// Persistent form of the set sweep: gridDim.x workgroups stay resident and walk the K x tiles_per_member tiles
+// of the set with stride gridDim.x, the loads of the NEXT tile issued before the current one is finished, so a
+// lane always has a tile's worth of HBM requests in flight and no workgroup is ever being launched or retired
+// while the sweep runs.  Same arithmetic, same outputs, same per-wave partials as sweep_set_kernel.
+template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, bool BITS, int MINW = 1>
+static __global__ __launch_bounds__(kBlock, MINW) void sweep_persist_kernel(const SweepArgs* __restrict__ tab,
+                                                                      uint32_t tiles_per_member, uint32_t total_tiles,
+                                                                      uint32_t want_bits) {
+  using Regs = TileRegs<N, GPL, COMMIT, GATED, VOTES>;
+  const uint32_t stride = gridDim.x;
+  uint32_t t = blockIdx.x;
+  if (t >= total_tiles) return;
+  auto locate = [&](uint32_t lin, SweepArgs& a, uint32_t& tile) {
+    const uint32_t m = lin / tiles_per_member;
+    tile = lin - m * tiles_per_member;
+    a = tab[m];
+    if (!want_bits) a.changed_bits = nullptr;
+  };
+  // Two register sets, A and B, used alternately (no copies: a copy would have to wait for the data), and every
+  // finish is preceded in straight-line code by the other set's loads, so the wait in front of a tile's
+  // arithmetic is vmcnt(one tile of loads), never vmcnt(0) -- a lane always has a tile of requests in flight.
+  Regs A, B;
+  SweepArgs aA, aB;
+  uint32_t tileA, tileB;
+  locate(t, aA, tileA);
+  tile_load<N, GPL, COMMIT, GATED, VOTES, POLICY>(A, aA, tileA);
+  while (true) {
+    t += stride;
+    if (t >= total_tiles) {
+      tile_finish<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS>(A, aA, tileA);
+      break;
+    }
+    locate(t, aB, tileB);
+    tile_load<N, GPL, COMMIT, GATED, VOTES, POLICY>(B, aB, tileB);
+    tile_finish<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS>(A, aA, tileA);
+    t += stride;
+    if (t >= total_tiles) {
+      tile_finish<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS>(B, aB, tileB);
+      break;
+    }
+    locate(t, aA, tileA);
+    tile_load<N, GPL, COMMIT, GATED, VOTES, POLICY>(A, aA, tileA);
+    tile_finish<N, GPL, COMMIT, GATED, VOTES, POLICY, BITS>(B, aB, tileB);
+  }
+}
+
+// Per-member tallies of a set sweep: one workgroup per member sums that member's per-wave partials
+// into {changed, won, lost, 0} (u64) -- one small D2H copy for the whole set instead of one per member.
+static __global__ __launch_bounds__(kBlock) void set_counts_kernel(const SweepArgs* __restrict__ tab, uint64_t n_partials,
+                                                                    uint64_t* __restrict__ out) {
+  __shared__ uint64_t red[3][kWaves];
+  const uint4* p = tab[blockIdx.x].partials;
+  uint64_t c = 0, w = 0, l = 0;
+  for (uint64_t i = threadIdx.x; i < n_partials; i += kBlock) {
+    const uint4 v = p[i];
+    c += v.x;
+    w += v.y;
+    l += v.z;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c += __shfl_xor(c, o, 64);
+    w += __shfl_xor(w, o, 64);
+    l += __shfl_xor(l, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = c;
+    red[1][threadIdx.x >> 6] = w;
+    red[2][threadIdx.x >> 6] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    uint64_t t = 0;
+    for (int k = 0; k < kWaves; ++k) t += red[threadIdx.x][k];
+    out[(uint64_t)blockIdx.x * 4 + threadIdx.x] = t;
+  }
+  if (threadIdx.x == 3) out[(uint64_t)blockIdx.x * 4 + 3] = 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,481 @@
+// raftq_tune3.hip -- round-2 A/B of the sweep's LAUNCH SHAPE on MI355X (measurement tool, not part of
+// libraftq.so).  Round 1 found the 1M x 5 sweep bound by its launch boundary, not by bytes (12.0 us from
+// HBM vs 10.9 us from the Infinity Cache).  This tuner times one "rotation" -- K independent 1M-group
+// members, 1.6 GB, HBM regime -- through:
+//   single   K launches of the shipped sweep_kernel (round 1's figure)
+//   set      ONE launch, grid = tiles x K, members' pointers from a device table (sweep_set_kernel)
+//   persist  ONE launch of resident workgroups walking all K x tiles, next tile's loads in flight
+//            (sweep_persist_kernel, compiler-scheduled register ping-pong)
+//   ring     ONE launch, resident workgroups, each WAVE streams its tiles HBM -> LDS with
+//            global_load_lds (nt) through a ring of R slots and runs the network out of LDS
+//            (the loader shape MI355X_MICROARCH.md measures at 6.4-6.8 TB/s)
+// plus the K-curve of `set`, store-less ceilings, and the other BASELINE shapes.  Every variant's
+// commit indices, outcomes and tallies are compared with `single` on two members before it is timed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "raftq_kernels.hpp"
+
+using namespace raftqk;
+
+#define CK(x)                                                                            \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                           \
+    }                                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// ring: per-wave LDS ring fed by LDS-DMA.  GPL = 4 (tile = 1024 groups, a wave owns 256 of them: two rounds
+// of 128 for the commit part, 4 vote bytes per lane per peer row).  Slot layout per wave (bytes):
+//   [j][p] match rows (2 x N KiB) | [j] committed (2 KiB, stored as row N of round j) | [p] vote rows (N x 256 B)
+typedef __attribute__((address_space(3))) void lds_void3_t;
+typedef const __attribute__((address_space(1))) void global_cvoid3_t;
+
+__device__ __forceinline__ uint32_t bytes_equal32(uint32_t v, uint32_t pattern) {
+  const uint32_t k7f = 0x7f7f7f7fu;
+  const uint32_t x = v ^ pattern;
+  uint32_t y = (x & k7f) + k7f;
+  y = ~(y | x | k7f);
+  return y >> 7;
+}
+
+template <int N, int R, int AUX, bool GATED>
+__global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __restrict__ tab, uint32_t tiles_per_member,
+                                                            uint32_t total_tiles) {
+  constexpr int GPL = 4, kRounds = 2;
+  constexpr int kRows = N + 1 + (GATED ? 1 : 0);
+  constexpr int kSlot = kRounds * kRows * 1024 + N * 256;
+  constexpr int L = kRounds * kRows + N;  // LDS-DMA instructions per tile per wave
+  static_assert((R - 1) * L <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* wbase = smem + (size_t)wave * R * kSlot;
+  const uint32_t stride = gridDim.x;
+  const uint32_t first = blockIdx.x;
+  if (first >= total_tiles) return;
+  const uint32_t n_mine = (total_tiles - first + stride - 1) / stride;
+
+  auto issue = [&](uint32_t i) {
+    const uint32_t lin = first + i * stride;
+    const uint32_t m = lin / tiles_per_member, tile = lin - m * tiles_per_member;
+    const SweepArgs a = tab[m];
+    unsigned char* sb = wbase + (size_t)(i % R) * kSlot;
+    const uint64_t tile0 = (uint64_t)tile * 1024 + (uint64_t)wave * 256;
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint64_t g = tile0 + (uint64_t)j * 128 + 2 * lane;
+#pragma unroll
+      for (int p = 0; p < N; ++p)
+        __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(a.match + (uint64_t)p * a.ld + g),
+                                         (lds_void3_t*)(sb + (j * kRows + p) * 1024), 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(a.committed + g), (lds_void3_t*)(sb + (j * kRows + N) * 1024), 16,
+                                       0, AUX);
+      if constexpr (GATED)
+        __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(a.first_idx + g),
+                                         (lds_void3_t*)(sb + (j * kRows + N + 1) * 1024), 16, 0, AUX);
+    }
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+      __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(a.votes + (uint64_t)p * a.ld + tile0 + 4 * lane),
+                                       (lds_void3_t*)(sb + kRounds * kRows * 1024 + p * 256), 4, 0, AUX);
+  };
+
+  for (uint32_t i = 0; i + 1 < (uint32_t)R && i < n_mine; ++i) issue(i);
+
+  for (uint32_t i = 0; i < n_mine; ++i) {
+    if (i + R - 1 < n_mine) {
+      issue(i + R - 1);
+      // R-1 newer tiles (and the stores of older ones) may stay in flight; everything older has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * L) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const uint32_t lin = first + i * stride;
+    const uint32_t m = lin / tiles_per_member, tile = lin - m * tiles_per_member;
+    const SweepArgs a = tab[m];
+    const unsigned char* sb = wbase + (size_t)(i % R) * kSlot;
+    const uint64_t tile0 = (uint64_t)tile * 1024 + (uint64_t)wave * 256;
+    uint32_t n_changed = 0;
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+      const uint64_t g = tile0 + (uint64_t)j * 128 + 2 * lane;
+      uint64_t v0[N], v1[N];
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const u64x2 t = *reinterpret_cast<const u64x2*>(sb + (j * kRows + p) * 1024 + lane * 16);
+        v0[p] = t.x;
+        v1[p] = t.y;
+      }
+      const u64x2 c = *reinterpret_cast<const u64x2*>(sb + (j * kRows + N) * 1024 + lane * 16);
+      u64x2 f;
+      f.x = f.y = 0;
+      if constexpr (GATED) f = *reinterpret_cast<const u64x2*>(sb + (j * kRows + N + 1) * 1024 + lane * 16);
+      const uint64_t mci0 = select_quorum_network<N>(v0), mci1 = select_quorum_network<N>(v1);
+      u64x2 o;
+      o.x = maybe_commit<GATED>(mci0, c.x, f.x);
+      o.y = maybe_commit<GATED>(mci1, c.y, f.y);
+      const uint64_t b0 = __ballot(o.x != c.x), b1 = __ballot(o.y != c.y);
+      n_changed += __popcll(b0) + __popcll(b1);
+      if (a.changed_bits != nullptr && lane == 0) {
+        u64x2 w;
+        w.x = b0;
+        w.y = b1;
+        stg<false>(reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)), w);
+      }
+      stg<true>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
+    }
+    uint32_t granted = 0, rejected = 0;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(sb + kRounds * kRows * 1024 + p * 256 + lane * 4);
+      granted += bytes_equal32(v, 0x01010101u);
+      rejected += bytes_equal32(v, 0x02020202u);
+    }
+    constexpr uint32_t q = N / 2 + 1;
+    constexpr uint32_t bias = (0x80u - q) * 0x01010101u;
+    const uint32_t won = ((granted + bias) & 0x80808080u) >> 7;
+    const uint32_t lost = (((rejected + bias) & 0x80808080u) >> 7) & ~won;
+    stg<true>(reinterpret_cast<uint32_t*>(a.outcome + tile0 + 4 * lane), won | (lost << 1));
+    const uint32_t wl = wave_sum_u32((uint32_t)__popc(won) | ((uint32_t)__popc(lost) << 16));
+    if (lane == 0) {
+      uint4 r;
+      r.x = n_changed;
+      r.y = wl & 0xffffu;
+      r.z = wl >> 16;
+      r.w = 0;
+      stg_u4(a.partials + ((uint64_t)tile * 4 + wave), r);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(uint64_t* p, uint64_t n, uint64_t seed, uint64_t mask, uint64_t add) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p[i] = (z & mask) + add;
+  }
+}
+__global__ void fill_votes_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 29;
+    const unsigned u = (unsigned)(z % 10);
+    p[i] = u < 3 ? 0 : (u < 8 ? 1 : 2);
+  }
+}
+
+struct Member {
+  uint8_t* arena;
+  SweepArgs a;
+};
+
+// the product's shape: rows padded to a multiple of 2048 groups plus the 288-group stagger
+static Member make_member(int N, uint64_t G, uint64_t seed) {
+  Member s;
+  const uint64_t ld = G + 288;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 4095) / 4096 * 4096; return o; };
+  const size_t o_m = carve((size_t)N * ld * 8), o_c = carve(ld * 8), o_co = carve(ld * 8), o_f = carve(ld * 8),
+               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4));
+  CK(hipMalloc(&s.arena, off));
+  s.a.match = (uint64_t*)(s.arena + o_m);
+  s.a.committed = (uint64_t*)(s.arena + o_c);
+  s.a.committed_out = (uint64_t*)(s.arena + o_co);
+  s.a.first_idx = (uint64_t*)(s.arena + o_f);
+  s.a.votes = s.arena + o_v;
+  s.a.outcome = s.arena + o_o;
+  s.a.changed_bits = nullptr;
+  s.a.partials = (uint4*)(s.arena + o_p);
+  s.a.ld = ld;
+  const uint64_t base = 1ull << 30;
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.match, (uint64_t)N * ld, seed, 2047ull, base);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.committed, ld, seed + 1, 1023ull, base + 512);
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.first_idx, ld, seed + 2, 2047ull, base);
+  hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, (uint8_t*)s.a.votes, (uint64_t)N * ld, seed + 3);
+  return s;
+}
+
+struct Ctx {
+  int N;
+  uint64_t G;
+  std::vector<Member> mem;
+  SweepArgs* tab;  // device table of all members
+  hipStream_t st;
+  int cus;
+};
+
+typedef void (*rot_fn)(const Ctx&, uint32_t K, int param);
+
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
+static void rot_single(const Ctx& c, uint32_t K, int) {
+  for (uint32_t k = 0; k < K; ++k)
+    hipLaunchKernelGGL((sweep_kernel<N, GPL, true, GATED, VOTES, POLICY, true>), dim3((unsigned)(c.G / (256 * GPL))), dim3(256), 0,
+                       c.st, c.mem[k].a);
+}
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
+static void rot_set(const Ctx& c, uint32_t K, int) {
+  hipLaunchKernelGGL((sweep_set_kernel<N, GPL, true, GATED, VOTES, POLICY, true>), dim3((unsigned)(c.G / (256 * GPL)), K),
+                     dim3(256), 0, c.st, (const SweepArgs*)c.tab, 0u);
+}
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY, int MINW>
+static void rot_persist(const Ctx& c, uint32_t K, int wg_per_cu) {
+  const uint32_t tiles = (uint32_t)(c.G / (256 * GPL));
+  hipLaunchKernelGGL((sweep_persist_kernel<N, GPL, true, GATED, VOTES, POLICY, true, MINW>), dim3(c.cus * wg_per_cu), dim3(256), 0,
+                     c.st, (const SweepArgs*)c.tab, tiles, tiles * K, 0u);
+}
+template <int N, int R, int AUX, bool GATED>
+static void rot_ring(const Ctx& c, uint32_t K, int wg_per_cu) {
+  constexpr int kRows = N + 1 + (GATED ? 1 : 0);
+  constexpr size_t lds = (size_t)4 * R * (2 * kRows * 1024 + N * 256);
+  static bool once = false;
+  if (!once) {
+    CK(hipFuncSetAttribute((const void*)sweep_ring_kernel<N, R, AUX, GATED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  const uint32_t tiles = (uint32_t)(c.G / 1024);
+  hipLaunchKernelGGL((sweep_ring_kernel<N, R, AUX, GATED>), dim3(c.cus * wg_per_cu), dim3(256), lds, c.st, (const SweepArgs*)c.tab,
+                     tiles, tiles * K);
+}
+
+struct Variant {
+  const char* name;
+  int N, gated, votes;
+  uint64_t G;
+  int param;       // workgroups per CU for the persistent shapes
+  const char* note;
+  rot_fn fn;
+  bool is_ref;
+};
+
+static double bytes_per_group(int N, int gated, int votes) {
+  return 8.0 * N + 8 + 8 + (gated ? 8 : 0) + (votes ? N + 1 : 0);
+}
+
+int main(int argc, char** argv) {
+  int reps = 40;
+  const char* only = nullptr;
+  if (argc > 1) reps = atoi(argv[1]);
+  if (argc > 2) only = argv[2];
+  const uint32_t k_override = argc > 3 ? (uint32_t)atoi(argv[3]) : 0;  // members per rotation (default: 1.6 GB worth)
+  const int n_only = argc > 4 ? atoi(argv[4]) : 0;                       // restrict to one peer count
+  CK(hipSetDevice(0));
+  Ctx c;
+  CK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+  CK(hipDeviceGetAttribute(&c.cus, hipDeviceAttributeMultiprocessorCount, 0));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const uint64_t M1 = 1ull << 20, M2 = 2ull << 20;
+#define SINGLE(N, GPL, GA, VO, P) rot_single<N, GPL, GA, VO, P>
+#define SETV(N, GPL, GA, VO, P) rot_set<N, GPL, GA, VO, P>
+  const std::vector<Variant> variants = {
+      // ---- config 3: 1M x 5, commit + votes
+      {"single", 5, 0, 1, M1, 0, "K launches, nt loads (shipped r01)", SINGLE(5, 4, false, true, 1), true},
+      {"single", 5, 0, 1, M1, 0, "K launches, nt loads+stores", SINGLE(5, 4, false, true, 3), false},
+      {"set", 5, 0, 1, M1, 0, "GPL4 nt loads", SETV(5, 4, false, true, 1), false},
+      {"set", 5, 0, 1, M1, 0, "GPL4 nt loads+stores", SETV(5, 4, false, true, 3), false},
+      {"set", 5, 0, 1, M1, 0, "GPL2 nt loads+stores", SETV(5, 2, false, true, 3), false},
+      {"set", 5, 0, 1, M1, 0, "GPL8 nt loads+stores", SETV(5, 8, false, true, 3), false},
+      {"set", 5, 0, 1, M1, 0, "GPL4 cached", SETV(5, 4, false, true, 0), false},
+      {"set", 5, 0, 1, M1, 0, "GPL4 nt, NO STORES (ceiling)", SETV(5, 4, false, true, 3 | kNoStore), false},
+      {"persist", 5, 0, 1, M1, 1, "GPL4 nt l+s, 1 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
+      {"persist", 5, 0, 1, M1, 2, "GPL4 nt l+s, 2 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
+      {"persist", 5, 0, 1, M1, 3, "GPL4 nt l+s, 3 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
+      {"persist", 5, 0, 1, M1, 3, "GPL4 nt loads, 3 WG/CU", (rot_persist<5, 4, false, true, 1, 1>), false},
+      {"persist", 5, 0, 1, M1, 4, "GPL2 nt l+s, 4 WG/CU", (rot_persist<5, 2, false, true, 3, 1>), false},
+      {"persist", 5, 0, 1, M1, 6, "GPL2 nt l+s, 6 WG/CU", (rot_persist<5, 2, false, true, 3, 1>), false},
+      {"ring", 5, 0, 1, M1, 1, "R2 nt (aux 2), 1 WG/CU", (rot_ring<5, 2, 2, false>), false},
+      {"ring", 5, 0, 1, M1, 1, "R3 nt (aux 2), 1 WG/CU", (rot_ring<5, 3, 2, false>), false},
+      {"ring", 5, 0, 1, M1, 1, "R3 default policy, 1 WG/CU", (rot_ring<5, 3, 0, false>), false},
+      {"ring", 5, 0, 1, M1, 2, "R2 nt, 2 WG/CU (queued)", (rot_ring<5, 2, 2, false>), false},
+      // ---- config 5: 1M x 5 gated
+      {"single", 5, 1, 0, M1, 0, "K launches", SINGLE(5, 4, true, false, 1), true},
+      {"set", 5, 1, 0, M1, 0, "GPL4 nt loads+stores", SETV(5, 4, true, false, 3), false},
+      {"persist", 5, 1, 0, M1, 3, "GPL4 nt l+s, 3 WG/CU", (rot_persist<5, 4, true, false, 3, 1>), false},
+      // ---- config 2: 1M x 3 commit
+      {"single", 3, 0, 0, M1, 0, "K launches", SINGLE(3, 4, false, false, 1), true},
+      {"set", 3, 0, 0, M1, 0, "GPL4 nt loads+stores", SETV(3, 4, false, false, 3), false},
+      {"set", 3, 0, 0, M1, 0, "GPL8 nt loads+stores", SETV(3, 8, false, false, 3), false},
+      {"persist", 3, 0, 0, M1, 4, "GPL4 nt l+s, 4 WG/CU", (rot_persist<3, 4, false, false, 3, 1>), false},
+      // ---- config 4 shard: 2M x 7 commit + votes
+      {"single", 7, 0, 1, M2, 0, "K launches, nt loads+stores", SINGLE(7, 4, false, true, 3), true},
+      {"set", 7, 0, 1, M2, 0, "GPL4 nt loads+stores", SETV(7, 4, false, true, 3), false},
+      {"set", 7, 0, 1, M2, 0, "GPL2 nt loads+stores", SETV(7, 2, false, true, 3), false},
+      {"persist", 7, 0, 1, M2, 2, "GPL4 nt l+s, 2 WG/CU", (rot_persist<7, 4, false, true, 3, 1>), false},
+      {"ring", 7, 0, 1, M2, 1, "R2 nt, 1 WG/CU", (rot_ring<7, 2, 2, false>), false},
+      // ---- "focus": tile size x store policy of the set shape, timed interleaved (median of 9) per family
+      {"focus", 5, 0, 1, M1, 0, "single GPL4 P1", SINGLE(5, 4, false, true, 1), true},
+      {"focus", 5, 0, 1, M1, 0, "set GPL2 P1", SETV(5, 2, false, true, 1), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL2 P3", SETV(5, 2, false, true, 3), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL4 P1", SETV(5, 4, false, true, 1), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL4 P3", SETV(5, 4, false, true, 3), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 P1", SETV(5, 8, false, true, 1), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
+      {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
+      {"focus", 5, 1, 0, M1, 0, "set GPL2 P3", SETV(5, 2, true, false, 3), false},
+      {"focus", 5, 1, 0, M1, 0, "set GPL4 P3", SETV(5, 4, true, false, 3), false},
+      {"focus", 5, 1, 0, M1, 0, "set GPL8 P3", SETV(5, 8, true, false, 3), false},
+      {"focus", 5, 1, 0, M1, 0, "set GPL4 P1", SETV(5, 4, true, false, 1), false},
+      {"focus", 3, 0, 0, M1, 0, "single GPL4 P1", SINGLE(3, 4, false, false, 1), true},
+      {"focus", 3, 0, 0, M1, 0, "set GPL2 P3", SETV(3, 2, false, false, 3), false},
+      {"focus", 3, 0, 0, M1, 0, "set GPL4 P3", SETV(3, 4, false, false, 3), false},
+      {"focus", 3, 0, 0, M1, 0, "set GPL8 P3", SETV(3, 8, false, false, 3), false},
+      {"focus", 3, 0, 0, M1, 0, "set GPL8 P1", SETV(3, 8, false, false, 1), false},
+      {"focus", 7, 0, 1, M2, 0, "single GPL4 P3", SINGLE(7, 4, false, true, 3), true},
+      {"focus", 7, 0, 1, M2, 0, "set GPL2 P3", SETV(7, 2, false, true, 3), false},
+      {"focus", 7, 0, 1, M2, 0, "set GPL4 P3", SETV(7, 4, false, true, 3), false},
+      {"focus", 7, 0, 1, M2, 0, "set GPL2 P1", SETV(7, 2, false, true, 1), false},
+      {"focus", 9, 0, 1, M1, 0, "single GPL4 P3", SINGLE(9, 4, false, true, 3), true},
+      {"focus", 9, 0, 1, M1, 0, "set GPL2 P3", SETV(9, 2, false, true, 3), false},
+      {"focus", 9, 0, 1, M1, 0, "set GPL4 P3", SETV(9, 4, false, true, 3), false},
+  };
+  const bool focus = only && !strcmp(only, "focus");
+  struct Timed { const Variant* v; std::vector<double> us; };
+  std::vector<Timed> family;  // verified focus variants of the current (N, G, gated, votes) family
+  auto flush_family = [&](uint32_t K) {
+    if (family.empty()) return;
+    for (int rep = 0; rep < 9; ++rep)
+      for (auto& t : family) {
+        for (int w = 0; w < 2; ++w) t.v->fn(c, K, t.v->param);
+        CK(hipEventRecord(e0, c.st));
+        for (int i = 0; i < reps; ++i) t.v->fn(c, K, t.v->param);
+        CK(hipEventRecord(e1, c.st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t.us.push_back(1e3 * ms / reps / K);
+      }
+    for (auto& t : family) {
+      std::sort(t.us.begin(), t.us.end());
+      const double med = t.us[t.us.size() / 2], bpg = bytes_per_group(t.v->N, t.v->gated, t.v->votes);
+      printf("{\"kernel\":\"focus\",\"N\":%d,\"G\":%llu,\"gated\":%d,\"votes\":%d,\"K\":%u,\"note\":\"%s\",\"us_per_batch_median\":%.3f,"
+             "\"us_min\":%.3f,\"us_max\":%.3f,\"GBps_median\":%.1f,\"frac_of_8TBps\":%.4f}\n",
+             t.v->N, (unsigned long long)t.v->G, t.v->gated, t.v->votes, K, t.v->note, med, t.us.front(), t.us.back(),
+             t.v->G * bpg / med / 1e3, t.v->G * bpg / med / 1e3 / 8000.0);
+    }
+    fflush(stdout);
+    family.clear();
+  };
+  int curN = -1;
+  uint64_t curG = 0;
+  uint32_t K = 0;
+  c.tab = nullptr;
+  std::vector<uint64_t> ref_c[2];
+  std::vector<uint8_t> ref_o[2];
+  uint64_t ref_tally[3] = {0, 0, 0};
+  int ref_gated = -1, ref_votes = -1;
+  auto tallies = [&](uint32_t k, uint64_t G, uint64_t out[3]) {
+    std::vector<uint4> p(G / 128);  // >= any variant's wave count; zeroed before each checked run
+    CK(hipMemcpy(p.data(), c.mem[k].a.partials, p.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = 0;
+    for (auto& v : p) { out[0] += v.x; out[1] += v.y; out[2] += v.z; }
+  };
+  for (const Variant& v : variants) {
+    if (focus != !strcmp(v.name, "focus")) continue;
+    if (!focus && only && !strstr(v.name, only) && !v.is_ref) continue;
+    if (n_only && v.N != n_only) continue;
+    if (focus && v.is_ref) flush_family(K);
+    if (v.N != curN || v.G != curG) {
+      for (auto& m : c.mem) (void)hipFree(m.arena);
+      c.mem.clear();
+      if (c.tab) (void)hipFree(c.tab);
+      K = (uint32_t)(1.6 * 1024 * 1024 * 1024 / (v.G * (8.0 * v.N + 16 + v.N + 1))) + 1;
+      if (k_override) K = k_override;
+      std::vector<SweepArgs> host;
+      for (uint32_t k = 0; k < K; ++k) {
+        c.mem.push_back(make_member(v.N, v.G, 5000 * v.N + k));
+        host.push_back(c.mem.back().a);
+      }
+      CK(hipMalloc((void**)&c.tab, K * sizeof(SweepArgs)));
+      CK(hipMemcpy(c.tab, host.data(), K * sizeof(SweepArgs), hipMemcpyHostToDevice));
+      CK(hipDeviceSynchronize());
+      c.N = v.N; c.G = v.G; curN = v.N; curG = v.G;
+      ref_gated = ref_votes = -1;
+    }
+    // ---- correctness on members 0 and K-1 against the family's `single` reference
+    const uint32_t probe[2] = {0, K - 1};
+    for (int i = 0; i < 2; ++i) {
+      CK(hipMemsetAsync(c.mem[probe[i]].a.committed_out, 0xEE, v.G * 8, c.st));
+      CK(hipMemsetAsync(c.mem[probe[i]].a.outcome, 0xEE, v.G, c.st));
+      CK(hipMemsetAsync(c.mem[probe[i]].a.partials, 0, v.G / 128 * sizeof(uint4), c.st));
+    }
+    v.fn(c, K, v.param);
+    CK(hipStreamSynchronize(c.st));
+    CK(hipGetLastError());
+    bool ok = true;
+    uint64_t tl[3];
+    tallies(K - 1, v.G, tl);
+    for (int i = 0; i < 2; ++i) {
+      std::vector<uint64_t> cc(v.G);
+      std::vector<uint8_t> oo(v.G);
+      CK(hipMemcpy(cc.data(), c.mem[probe[i]].a.committed_out, v.G * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(oo.data(), c.mem[probe[i]].a.outcome, v.G, hipMemcpyDeviceToHost));
+      if (v.is_ref) {
+        ref_c[i] = cc; ref_o[i] = oo;
+      } else {
+        const bool nostore = strstr(v.note, "NO STORES") != nullptr;
+        if (!nostore) {
+          ok = ok && ref_gated == v.gated && ref_votes == v.votes && memcmp(ref_c[i].data(), cc.data(), v.G * 8) == 0;
+          if (v.votes) ok = ok && memcmp(ref_o[i].data(), oo.data(), v.G) == 0;
+        }
+      }
+    }
+    if (v.is_ref) {
+      ref_gated = v.gated; ref_votes = v.votes;
+      memcpy(ref_tally, tl, sizeof tl);
+    } else {
+      ok = ok && tl[0] == ref_tally[0] && (!v.votes || (tl[1] == ref_tally[1] && tl[2] == ref_tally[2]));
+    }
+    if (!ok) {
+      printf("{\"kernel\":\"%s\",\"N\":%d,\"note\":\"%s\",\"MISMATCH\":true}\n", v.name, v.N, v.note);
+      fflush(stdout);
+      continue;
+    }
+    if (focus) {
+      family.push_back(Timed{&v, {}});
+      continue;
+    }
+    // ---- timing: `reps` rotations (K members each), two repeats; plus the K-curve for the plain set shape
+    std::vector<uint32_t> ks = {K};
+    if (!strcmp(v.name, "set") && strstr(v.note, "GPL4 nt loads+stores") && v.N == 5 && !v.gated) ks = {1, 2, 4, 8, 16, K};
+    for (uint32_t kk : ks) {
+      for (int rep = 0; rep < 2; ++rep) {
+        for (int w = 0; w < 3; ++w) v.fn(c, kk, v.param);
+        CK(hipEventRecord(e0, c.st));
+        const int r = kk == K ? reps : reps * (int)(K / kk);
+        for (int i = 0; i < r; ++i) v.fn(c, kk, v.param);
+        CK(hipEventRecord(e1, c.st));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us_rot = 1e3 * ms / r, us_batch = us_rot / kk;
+        printf("{\"kernel\":\"%s\",\"N\":%d,\"G\":%llu,\"gated\":%d,\"votes\":%d,\"K\":%u,\"wg_per_cu\":%d,\"note\":\"%s\",\"rep\":%d,"
+               "\"us_per_rotation\":%.2f,\"us_per_batch\":%.3f,\"GBps\":%.1f,\"frac_of_8TBps\":%.4f,\"Gdec_per_s\":%.2f}\n",
+               v.name, v.N, (unsigned long long)v.G, v.gated, v.votes, kk, v.param, v.note, rep, us_rot, us_batch,
+               v.G * bytes_per_group(v.N, v.gated, v.votes) / us_batch / 1e3,
+               v.G * bytes_per_group(v.N, v.gated, v.votes) / us_batch / 1e3 / 8000.0, v.G / us_batch / 1e3);
+        fflush(stdout);
+      }
+    }
+  }
+  flush_family(K);
+  return 0;
+}

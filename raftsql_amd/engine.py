@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import (SWEEP_CACHED, SWEEP_CHANGED, SWEEP_COMMIT, SWEEP_GATED, SWEEP_LDS, SWEEP_NO_ADOPT,
                    SWEEP_STREAM, SWEEP_VOTES, Advance, Counts, Delta, RaftqError, VoteDelta)
 
-__all__ = ["QuorumEngine", "SweepCounts", "device_count", "RaftqError", "pinned_empty", "pinned_copy", "SWEEP_COMMIT", "SWEEP_GATED",
+__all__ = ["QuorumEngine", "SweepSet", "sweep_many_async", "SweepCounts", "device_count", "RaftqError", "pinned_empty", "pinned_copy", "SWEEP_COMMIT", "SWEEP_GATED",
            "SWEEP_VOTES", "SWEEP_NO_ADOPT", "SWEEP_LDS", "SWEEP_CHANGED", "SWEEP_STREAM", "SWEEP_CACHED"]
 
 
@@ -349,6 +349,10 @@ class QuorumEngine:
         g = np.ascontiguousarray(groups, dtype=np.uint64)
         self._chk(self._lib.raftq_campaign(self._h, _ptr(g) if len(g) else None, len(g), self_peer))
 
+    def clone_state_from(self, src: "QuorumEngine") -> None:
+        """Device-to-device copy of src's quorum state (raftq_clone_state)."""
+        self._chk(self._lib.raftq_clone_state(self._h, src._h))
+
     # -- measurement ------------------------------------------------------
     def timer_begin(self) -> None:
         self._chk(self._lib.raftq_timer_begin(self._h))
@@ -357,3 +361,89 @@ class QuorumEngine:
         ms = C.c_float(0.0)
         self._chk(self._lib.raftq_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class SweepSet:
+    """K QuorumEngines of one shape on one GPU, swept by ONE dispatch (raftq_set_*).
+
+    Results are those of sweeping every member on its own; the members stay usable
+    (read-backs, deltas, per-member counts) between set sweeps.  Close the set before
+    its members."""
+
+    def __init__(self, engines):
+        self._lib = _lib.load()
+        self.engines = list(engines)
+        n = len(self.engines)
+        arr = (C.c_void_p * max(n, 1))(*[e._h.value for e in self.engines])
+        self._s = C.c_void_p(None)
+        rc = self._lib.raftq_set_create(arr if n else None, n, C.byref(self._s))
+        if rc != 0:
+            self._s = C.c_void_p(None)
+            raise RaftqError(rc, (self._lib.raftq_set_last_error(None) or b"raftq_set_create failed").decode())
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise RaftqError(rc, (self._lib.raftq_set_last_error(self._s) or b"?").decode())
+
+    def close(self) -> None:
+        if getattr(self, "_s", None) is not None and self._s.value:
+            self._lib.raftq_set_destroy(self._s)
+            self._s = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.raftq_set_size(self._s))
+
+    def get_stream(self) -> int:
+        return int(self._lib.raftq_set_get_stream(self._s) or 0)
+
+    def set_mode(self, mode: int, persist_workgroups: int = 0) -> None:
+        self._chk(self._lib.raftq_set_mode(self._s, int(mode), int(persist_workgroups)))
+
+    def sweep_async(self, flags: int) -> None:
+        self._chk(self._lib.raftq_set_sweep_async(self._s, flags))
+
+    def wait(self, want_counts: bool = False):
+        """-> None | (per-member [SweepCounts], total SweepCounts)"""
+        if not want_counts:
+            self._chk(self._lib.raftq_set_wait(self._s, None, None))
+            return None
+        n = len(self.engines)
+        per = (Counts * n)()
+        tot = Counts()
+        self._chk(self._lib.raftq_set_wait(self._s, C.cast(per, C.c_void_p), C.byref(tot)))
+        return ([SweepCounts(int(c.n_changed), int(c.n_won), int(c.n_lost)) for c in per],
+                SweepCounts(int(tot.n_changed), int(tot.n_won), int(tot.n_lost)))
+
+    def sweep(self, flags: int):
+        self.sweep_async(flags)
+        return self.wait(want_counts=True)
+
+    def timer_begin(self) -> None:
+        self._chk(self._lib.raftq_set_timer_begin(self._s))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0.0)
+        self._chk(self._lib.raftq_set_timer_end(self._s, C.byref(ms)))
+        return float(ms.value)
+
+
+def sweep_many_async(engines, flags: int) -> None:
+    """raftq_sweep_many_async: the K launches of K handles from one C call."""
+    lib = _lib.load()
+    n = len(engines)
+    arr = (C.c_void_p * max(n, 1))(*[e._h.value for e in engines])
+    rc = lib.raftq_sweep_many_async(arr, n, flags)
+    if rc != 0:
+        raise RaftqError(rc, (lib.raftq_last_error(None) or b"?").decode())

@@ -81,6 +81,14 @@ def test_argument_validation_without_device(lib):
     assert lib.raftq_wire_scan_frames(None, 8, 1, None, 0, None, None) == _lib.RAFTQ_EINVAL
     assert lib.raftq_step_set_compact(None, 1) == _lib.RAFTQ_EINVAL
     assert lib.raftq_step_results_c(None, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_set_create(None, 0, C.byref(h)) == _lib.RAFTQ_EINVAL and lib.raftq_set_create(None, 3, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_set_sweep_async(None, 1) == _lib.RAFTQ_EINVAL and lib.raftq_set_wait(None, None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_set_mode(None, 0, 0) == _lib.RAFTQ_EINVAL and lib.raftq_set_size(None) == 0
+    assert lib.raftq_set_timer_begin(None) == _lib.RAFTQ_EINVAL and lib.raftq_set_timer_end(None, None) == _lib.RAFTQ_EINVAL
+    assert lib.raftq_sweep_many_async(None, 2, 1) == _lib.RAFTQ_EINVAL and lib.raftq_sweep_many_async(None, 0, 1) == _lib.RAFTQ_OK
+    assert lib.raftq_clone_state(None, None) == _lib.RAFTQ_EINVAL
+    lib.raftq_set_destroy(None)  # no-op
+    assert b"set" in lib.raftq_set_last_error(None)
     p = C.c_void_p(None)
     assert lib.raftq_host_alloc(None, 64) == _lib.RAFTQ_EINVAL and lib.raftq_host_alloc(C.byref(p), 0) == _lib.RAFTQ_EINVAL
     lib.raftq_host_free(None)  # no-op

@@ -12,7 +12,27 @@ package raftq
 #cgo CFLAGS: -I${SRCDIR}/../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../raftsql_amd -lraftq -Wl,-rpath,${SRCDIR}/../../raftsql_amd
 #include <stdlib.h>
+#include <string.h>
 #include "raftq.h"
+
+// The handle-less error text (raftq_last_error(NULL), raftq_set_last_error(NULL)) is thread-local in the
+// library, and a goroutine may change OS thread between two cgo calls.  These helpers make the failing call
+// and the fetch of its text ONE cgo call, so the text always belongs to the call (ADVICE r01).
+static int raftq_create_msg(int device, uint64_t groups, uint32_t peers, raftq_t** out, char* msg, size_t cap) {
+  int rc = raftq_create(device, groups, peers, out);
+  if (rc != RAFTQ_OK && cap) { strncpy(msg, raftq_last_error(NULL), cap - 1); msg[cap - 1] = 0; }
+  return rc;
+}
+static int raftq_device_count_msg(int* n, char* msg, size_t cap) {
+  int rc = raftq_device_count(n);
+  if (rc != RAFTQ_OK && cap) { strncpy(msg, raftq_last_error(NULL), cap - 1); msg[cap - 1] = 0; }
+  return rc;
+}
+static int raftq_set_create_msg(raftq_t* const* hs, uint32_t n, raftq_set_t** out, char* msg, size_t cap) {
+  int rc = raftq_set_create(hs, n, out);
+  if (rc != RAFTQ_OK && cap) { strncpy(msg, raftq_set_last_error(NULL), cap - 1); msg[cap - 1] = 0; }
+  return rc;
+}
 */
 import "C"
 
@@ -78,8 +98,9 @@ func (e *Engine) err(rc C.int) error {
 // DeviceCount reports the GPUs libraftq can see.
 func DeviceCount() (int, error) {
 	var n C.int
-	if rc := C.raftq_device_count(&n); rc != C.RAFTQ_OK {
-		return 0, errors.New(C.GoString(C.raftq_last_error(nil)))
+	var msg [256]C.char
+	if rc := C.raftq_device_count_msg(&n, &msg[0], 256); rc != C.RAFTQ_OK {
+		return 0, errors.New(C.GoString(&msg[0]))
 	}
 	return int(n), nil
 }
@@ -87,8 +108,9 @@ func DeviceCount() (int, error) {
 // New allocates zeroed state for groups x peers on `device`.
 func New(device int, groups uint64, peers uint32) (*Engine, error) {
 	var h *C.raftq_t
-	if rc := C.raftq_create(C.int(device), C.uint64_t(groups), C.uint32_t(peers), &h); rc != C.RAFTQ_OK {
-		return nil, fmt.Errorf("raftq: %d: %s", int(rc), C.GoString(C.raftq_last_error(nil)))
+	var msg [256]C.char
+	if rc := C.raftq_create_msg(C.int(device), C.uint64_t(groups), C.uint32_t(peers), &h, &msg[0], 256); rc != C.RAFTQ_OK {
+		return nil, fmt.Errorf("raftq: %d: %s", int(rc), C.GoString(&msg[0]))
 	}
 	return &Engine{h: h, Groups: groups, Peers: peers}, nil
 }
@@ -174,4 +196,88 @@ func (e *Engine) ReadCommitted(out []uint64) error {
 // ReadOutcome copies the vote outcome of every group.
 func (e *Engine) ReadOutcome(out []uint8) error {
 	return e.err(C.raftq_read_outcome(e.h, (*C.uint8_t)(unsafe.Pointer(&out[0]))))
+}
+
+// ---- sweep sets (include/raftq.h "sweep sets"): K engines of one shape, ONE dispatch per sweep -------------
+
+// Set launch shapes (mirror RAFTQ_SET_*).
+const (
+	SetGrid       = 0
+	SetPersistent = 1
+)
+
+// Set sweeps its member engines with a single kernel launch.  Close the Set before its members.
+type Set struct {
+	s       *C.raftq_set_t
+	Members []*Engine
+}
+
+// NewSet re-homes every member onto the set's stream (raftq_set_create).
+func NewSet(members []*Engine) (*Set, error) {
+	if len(members) == 0 {
+		return nil, errors.New("raftq: empty set")
+	}
+	// the handle array lives in C memory: Go pointers to Go pointers must not cross cgo
+	arr := (*[1 << 28]*C.raftq_t)(C.malloc(C.size_t(len(members)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	for i, e := range members {
+		arr[i] = e.h
+	}
+	var s *C.raftq_set_t
+	var msg [256]C.char
+	if rc := C.raftq_set_create_msg((**C.raftq_t)(unsafe.Pointer(arr)), C.uint32_t(len(members)), &s, &msg[0], 256); rc != C.RAFTQ_OK {
+		return nil, fmt.Errorf("raftq: %d: %s", int(rc), C.GoString(&msg[0]))
+	}
+	return &Set{s: s, Members: members}, nil
+}
+
+func (s *Set) err(rc C.int) error {
+	if rc == C.RAFTQ_OK {
+		return nil
+	}
+	return fmt.Errorf("raftq: %d: %s", int(rc), C.GoString(C.raftq_set_last_error(s.s)))
+}
+
+// Close gives every member a stream of its own back (raftq_set_destroy).
+func (s *Set) Close() { C.raftq_set_destroy(s.s); s.s = nil }
+
+// Mode selects the launch shape; workgroups 0 keeps the default residency of the persistent walk.
+func (s *Set) Mode(mode int, workgroups uint32) error {
+	return s.err(C.raftq_set_mode(s.s, C.int(mode), C.uint32_t(workgroups)))
+}
+
+// SweepAsync enqueues one pass over every member: the G-fold Ready loop of raft.go:220-245, K-fold.
+func (s *Set) SweepAsync(flags uint) error { return s.err(C.raftq_set_sweep_async(s.s, C.uint(flags))) }
+
+// Wait blocks until the set's stream is idle; perMember (len == members, or nil) and total receive the tallies.
+func (s *Set) Wait(perMember []Counts, total *Counts) error {
+	var pm *C.raftq_counts_t
+	if perMember != nil {
+		pm = (*C.raftq_counts_t)(unsafe.Pointer(&perMember[0]))
+	}
+	return s.err(C.raftq_set_wait(s.s, pm, (*C.raftq_counts_t)(unsafe.Pointer(total))))
+}
+
+// SweepMany is the same K sweeps as K launches (raftq_sweep_many_async): for callers without a Set.
+func SweepMany(engines []*Engine, flags uint) error {
+	for _, e := range engines {
+		if err := e.StepAsync(flags); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
+// CloneStateFrom copies src's quorum state device-to-device (raftq_clone_state).
+func (e *Engine) CloneStateFrom(src *Engine) error { return e.err(C.raftq_clone_state(e.h, src.h)) }
+
+// CollectBeats lists the leader groups the last Tick sent MsgBeat to (raftq_collect_beats).
+func (e *Engine) CollectBeats(out []uint64) (uint64, error) {
+	var n C.uint64_t
+	var p *C.uint64_t
+	if len(out) > 0 {
+		p = (*C.uint64_t)(unsafe.Pointer(&out[0]))
+	}
+	rc := C.raftq_collect_beats(e.h, p, C.uint64_t(len(out)), &n)
+	return uint64(n), e.err(rc)
 }

@@ -67,6 +67,12 @@ extern "C" {
 #define RAFTQ_SWEEP_STREAM 0x40u /* force non-temporal streaming accesses */
 #define RAFTQ_SWEEP_CACHED 0x80u /* force normal cached accesses */
 
+/* raftq_cycle / raftq_cycle_packed only: the caller vouches for the ranges of its match deltas (a driver that built
+ * the records itself), so the library validates and scatters them in ONE pass straight from the pinned batch.  A
+ * record that is out of range after all is dropped on its own: the rest of the turn is applied, every output is
+ * filled in, and the call still returns RAFTQ_EINVAL.  Without the flag a turn is all-or-nothing. */
+#define RAFTQ_CYCLE_TRUSTED 0x100u
+
 typedef struct raftq raftq_t;
 
 /* per-sweep tallies (reduced from per-wave partials when waited for) */
@@ -107,6 +113,19 @@ typedef struct raftq_advance {
   uint64_t old_commit;
   uint64_t new_commit;
 } raftq_advance_t;
+
+/* the same two records in 16 bytes, for handles of at most 2^32 groups (raftq_cycle_packed): the batching turn
+ * is bound by PCIe both ways, and these are a third fewer bytes each way */
+typedef struct raftq_delta16 {
+  uint64_t match;
+  uint32_t group;
+  uint32_t peer;
+} raftq_delta16_t;
+typedef struct raftq_advance16 {
+  uint64_t new_commit;
+  uint32_t group;
+  uint32_t advanced_by; /* new_commit - old_commit, saturated at 2^32 - 1 (then old_commit is not recoverable) */
+} raftq_advance16_t;
 
 /* ---- library / device ------------------------------------------------- */
 int raftq_abi_version(void);
@@ -189,6 +208,8 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts);
 int raftq_read_tick(raftq_t* h, uint8_t* action /*[G]*/, uint32_t* elapsed /*[G]*/, uint8_t* role /*[G]*/);
 /* ascending list of the groups the last raftq_tick sent MsgHup to */
 int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
+/* ascending list of the leader groups the last raftq_tick sent MsgBeat to (they owe a heartbeat round) */
+int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
 /* becomeCandidate for `n` distinct groups: role = candidate, elapsed = 0, votes
  * cleared, the candidate's own slot (`self_peer`) granted.  Term bookkeeping is
  * the caller's (raftq_apply_term_deltas). */
@@ -215,6 +236,18 @@ int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas,
 int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta_t** deltas,
                 raftq_vote_delta_t** vote_deltas);
 int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed);
+
+/* The batching turn with the 16-byte records (handles of at most 2^32 groups).  Same semantics as raftq_cycle /
+ * raftq_stage / raftq_last_advances; match deltas arrive as raftq_delta16_t, the advance list leaves as
+ * raftq_advance16_t.  A turn is all-or-nothing in every form: one out-of-range record of either kind and no
+ * record of the call is applied, the sweep it ran is not adopted, RAFTQ_EINVAL. */
+int raftq_cycle_packed(raftq_t* h, const raftq_delta16_t* deltas, uint64_t n_deltas,
+                       const raftq_vote_delta_t* vote_deltas, uint64_t n_vote_deltas, unsigned flags,
+                       raftq_advance16_t* advances_out, uint64_t cap, uint64_t* n_advanced,
+                       raftq_counts_t* counts);
+int raftq_stage_packed(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta16_t** deltas,
+                       raftq_vote_delta_t** vote_deltas);
+int raftq_last_advances_packed(raftq_t* h, const raftq_advance16_t** list, uint64_t* n_listed);
 
 /* ---- sweep sets: many handles, one dispatch --------------------------------
  * A host that runs more groups than it wants in one handle (several tenants, several

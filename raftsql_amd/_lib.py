@@ -22,6 +22,7 @@ SWEEP_LDS = 0x10
 SWEEP_CHANGED = 0x20
 SWEEP_STREAM = 0x40
 SWEEP_CACHED = 0x80
+CYCLE_TRUSTED = 0x100
 SET_GRID, SET_PERSISTENT = 0, 1
 
 MAX_PEERS = 9
@@ -80,11 +81,16 @@ _SIGS = [
     ("raftq_tick", C.c_int, [_H, C.POINTER(TickCounts)]),
     ("raftq_read_tick", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_collect_hups", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_collect_beats", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_campaign", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint32]),
     ("raftq_cycle", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_uint64), C.POINTER(Counts)]),
     ("raftq_stage", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("raftq_last_advances", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_cycle_packed", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
+                                     C.POINTER(C.c_uint64), C.POINTER(Counts)]),
+    ("raftq_stage_packed", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("raftq_last_advances_packed", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_set_create", C.c_int, [C.POINTER(_H), C.c_uint32, C.POINTER(_H)]),
     ("raftq_set_destroy", None, [_H]),
     ("raftq_set_size", C.c_uint32, [_H]),

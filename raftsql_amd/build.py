@@ -131,11 +131,21 @@ def build_tuner3(force: bool = False) -> str | None:
     return out
 
 
-def build_all(force: bool = False) -> None:
-    build_lib(force=force)
-    build_tuner(force=force)
-    build_tuner2(force=force)
-    build_tuner3(force=force)
+def build_all(force: bool = False, log: list | None = None) -> None:
+    """The library and the three tuners, concurrently (every piece is its own hipcc process)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(4) as ex:
+        futs = [ex.submit(build_lib, force, None, False, log), ex.submit(build_tuner, force), ex.submit(build_tuner2, force),
+                ex.submit(build_tuner3, force)]
+        for f in futs:
+            f.result()
+
+
+def toolchain() -> dict:
+    """What built the binaries: recorded beside the ISA report (profiles/rNN/isa_sweep.txt)."""
+    v = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    return {"hipcc": _hipcc(), "version": v, "flags": _flags()}
 
 
 if __name__ == "__main__":

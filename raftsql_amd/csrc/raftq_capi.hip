@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -259,6 +260,7 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     if ((rc = alloc((void**)&h->changed_bits, h->gpad / 8))) break;
     if ((rc = alloc((void**)&h->partials, h->max_partials * sizeof(uint4)))) break;
     if ((rc = alloc((void**)&h->offsets, (h->max_partials + 1) * 8))) break;
+    if ((rc = alloc((void**)&h->compact_arrived, 64))) break;
     e = hipHostMalloc((void**)&h->h_partials, h->max_partials * sizeof(uint4), hipHostMallocDefault);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
     e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocMapped);
@@ -308,6 +310,7 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->changed_bits);
   (void)hipFree(h->partials);
   (void)hipFree(h->offsets);
+  (void)hipFree(h->compact_arrived);
   (void)hipFree(h->claim);
   (void)hipFree(h->delta_dev);
   (void)hipFree(h->delta_bad);
@@ -315,6 +318,7 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->elapsed);
   (void)hipFree(h->action);
   (void)hipFree(h->hup_bits);
+  (void)hipFree(h->beat_bits);
   (void)hipFree(h->tick_partials);
   raftq_detail::free_node_state(h);
   raftq_detail::free_wire_state(h);
@@ -410,58 +414,72 @@ static int check_deltas(raftq_t* h) {
   return rc;
 }
 
-// enqueue only (no sync): copy into the pinned staging area at byte offset `off` unless the caller filled it in
-// place (raftq_stage), then device-side: bring the records into HBM validating them, scatter.  The verdict of the
-// validation is read by check_deltas() after the caller's sync.  Shared by raftq_apply_* and raftq_cycle.
-static int enqueue_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n, size_t off) {
-  static_assert(sizeof(DeltaRec) == sizeof(raftq_delta_t), "ABI struct mismatch");
-  raftq_delta_t* dst = (raftq_delta_t*)((uint8_t*)h->stage_h + off);
-  if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(raftq_delta_t));
+}  // extern "C" (templates need C++ linkage)
+
+// enqueue only (no sync): copy the batch(es) into the pinned staging area unless the caller filled it in place
+// (raftq_stage), then device-side: bring the records into HBM validating them (both kinds first), then scatter.
+// Every scatter kernel checks the verdict of BOTH kinds, so one bad record of either kind withholds the whole
+// call (raftq_cycle: all or nothing).  The verdict is read by check_deltas() after the caller's sync.
+// Shared by raftq_apply_* and raftq_cycle*; Rec is the match-delta layout (24-byte or packed 16-byte).
+template <typename Rec, typename AbiRec>
+static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_vote_delta_t* vd, uint64_t nv, size_t off_votes,
+                          bool trusted = false) {
+  static_assert(sizeof(Rec) == sizeof(AbiRec), "ABI struct mismatch");
+  static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
+  if (nv > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
+  if (n) {
+    AbiRec* dst = (AbiRec*)h->stage_h;
+    if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(AbiRec));
+  }
+  if (nv) {
+    raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+    if ((const void*)vd != (const void*)dst) std::memcpy(dst, vd, (size_t)nv * sizeof(raftq_vote_delta_t));
+    if (!h->claim) {
+      const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
+      HIPCHK(h, hipMalloc((void**)&h->claim, bytes));
+      HIPCHK(h, hipMemsetAsync(h->claim, 0xff, bytes, h->stream));
+    }
+  }
   // match and vote records share the device buffer: votes go behind the matches (same offsets as in staging)
   if (int rc = ensure_delta_dev(h, h->stage_bytes)) return rc;
-  const unsigned long long epoch = ++h->delta_epoch;
-  h->delta_check[0] = epoch;
-  DeltaRec* dev = (DeltaRec*)((uint8_t*)h->delta_dev + off);
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(deltas_in_kernel, grid, dim3(kBlock), 0, h->stream, (const DeltaRec*)((uint8_t*)h->stage_d + off), dev, n,
-                     h->G, h->N, h->delta_bad, h->d_total + 1, epoch);
-  hipLaunchKernelGGL(apply_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->match, h->ld, (const DeltaRec*)dev, n,
-                     (const unsigned long long*)h->delta_bad, epoch);
+  const unsigned long long em = n ? ++h->delta_epoch : kNoEpoch, ev = nv ? ++h->delta_epoch : kNoEpoch;
+  h->delta_check[0] = n ? em : 0;
+  h->delta_check[1] = nv ? ev : 0;
+  Rec* dev_m = (Rec*)h->delta_dev;
+  VoteDeltaRec* dev_v = (VoteDeltaRec*)((uint8_t*)h->delta_dev + off_votes);
+  const unsigned long long* bad = h->delta_bad;
+  const dim3 gm((unsigned)((n + kBlock - 1) / kBlock)), gv((unsigned)((nv + kBlock - 1) / kBlock));
+  if (n && trusted)
+    hipLaunchKernelGGL((deltas_in_apply_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->stage_d, n, h->match, h->ld,
+                       h->G, h->N, h->delta_bad, h->d_total + 1, em);
+  else if (n)
+    hipLaunchKernelGGL((deltas_in_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->stage_d, dev_m, n, h->G, h->N,
+                       h->delta_bad, h->d_total + 1, em);
+  if (nv)
+    hipLaunchKernelGGL(vote_deltas_in_kernel, gv, dim3(kBlock), 0, h->stream,
+                       (const VoteDeltaRec*)((uint8_t*)h->stage_d + off_votes), dev_v, nv, h->G, h->N, h->delta_bad + 1,
+                       h->d_total + 2, ev);
+  if (n && !trusted)
+    hipLaunchKernelGGL((apply_deltas_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, h->match, h->ld, (const Rec*)dev_m, n, bad, em,
+                       ev);
+  if (nv) {
+    hipLaunchKernelGGL(vote_claim_kernel, gv, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv, bad, em,
+                       ev);
+    hipLaunchKernelGGL(vote_apply_kernel, gv, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv,
+                       bad, em, ev);
+  }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
 
-static int enqueue_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n, size_t off) {
-  static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
-  if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
-  raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off);
-  if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(raftq_vote_delta_t));
-  if (!h->claim) {
-    const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
-    HIPCHK(h, hipMalloc((void**)&h->claim, bytes));
-    HIPCHK(h, hipMemsetAsync(h->claim, 0xff, bytes, h->stream));
-  }
-  if (int rc = ensure_delta_dev(h, h->stage_bytes)) return rc;
-  const unsigned long long epoch = ++h->delta_epoch;
-  h->delta_check[1] = epoch;
-  VoteDeltaRec* dev = (VoteDeltaRec*)((uint8_t*)h->delta_dev + off);
-  const unsigned long long* bad = h->delta_bad + 1;
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(vote_deltas_in_kernel, grid, dim3(kBlock), 0, h->stream, (const VoteDeltaRec*)((uint8_t*)h->stage_d + off),
-                     dev, n, h->G, h->N, h->delta_bad + 1, h->d_total + 2, epoch);
-  hipLaunchKernelGGL(vote_claim_kernel, grid, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev, n, bad, epoch);
-  hipLaunchKernelGGL(vote_apply_kernel, grid, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, (const VoteDeltaRec*)dev, n,
-                     bad, epoch);
-  HIPCHK(h, hipGetLastError());
-  return RAFTQ_OK;
-}
+extern "C" {
 
 int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
   if (int rc = use_device_idle(h, "raftq_apply_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: null argument");
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
-  if (int rc = enqueue_deltas(h, d, n, 0)) return rc;
+  if (int rc = enqueue_ingest<DeltaRec>(h, d, n, nullptr, 0, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging area is reused by the next call
   return check_deltas(h);
 }
@@ -500,7 +518,7 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: null argument");
   if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
-  if (int rc = enqueue_vote_deltas(h, d, n, 0)) return rc;
+  if (int rc = enqueue_ingest<DeltaRec>(h, (const raftq_delta_t*)nullptr, 0, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return check_deltas(h);
 }
@@ -671,6 +689,7 @@ int raftq_detail::ensure_tick_state(raftq_t* h) {
   if (int rc = alloc((void**)&h->elapsed, h->ld * 4)) return rc;
   if (int rc = alloc((void**)&h->action, h->ld)) return rc;
   if (int rc = alloc((void**)&h->hup_bits, h->gpad / 8)) return rc;
+  if (int rc = alloc((void**)&h->beat_bits, h->gpad / 8)) return rc;
   if (int rc = alloc((void**)&h->tick_partials, h->gpad / 256 * sizeof(uint4))) return rc;
   return RAFTQ_OK;
 }
@@ -708,6 +727,7 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
   a.elapsed = h->elapsed;
   a.action = h->action;
   a.hup_bits = h->hup_bits;
+  a.beat_bits = h->beat_bits;
   a.partials = h->tick_partials;
   a.n_groups = h->G;
   a.seed = h->tick_seed;
@@ -742,21 +762,22 @@ int raftq_read_tick(raftq_t* h, uint8_t* action, uint32_t* elapsed, uint8_t* rol
   return RAFTQ_OK;
 }
 
-int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) {
-  if (int rc = use_device_idle(h, "raftq_collect_hups")) return rc;
-  if (!n) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null count");
-  if (!h->ticked) return fail(h, RAFTQ_ESTATE, "raftq_collect_hups: no raftq_tick yet");
-  if (cap && !groups) return fail(h, RAFTQ_EINVAL, "raftq_collect_hups: null out with cap > 0");
+// ascending list of the groups the last raftq_tick flagged: field 0 = MsgHup, 1 = MsgBeat
+static int collect_tick_list(raftq_t* h, const char* who, int field, uint64_t* groups, uint64_t cap, uint64_t* n) {
+  if (int rc = use_device_idle(h, who)) return rc;
+  if (!n) return fail(h, RAFTQ_EINVAL, std::string(who) + ": null count");
+  if (!h->ticked) return fail(h, RAFTQ_ESTATE, std::string(who) + ": no raftq_tick yet");
+  if (cap && !groups) return fail(h, RAFTQ_EINVAL, std::string(who) + ": null out with cap > 0");
   const uint64_t take_cap = std::min<uint64_t>(cap, h->G);
   // the advance buffer doubles as the (smaller) group-id list: 8 B of every 24
   if (take_cap)
     if (int rc = ensure_adv(h, (take_cap + 2) / 3 + 1)) return rc;
   const uint64_t nw = h->gpad / 256;
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets,
-                     h->d_total);
+                     h->d_total, field);
   if (take_cap)
     hipLaunchKernelGGL(compact_hups_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream,
-                       h->hup_bits, h->offsets, (uint64_t*)h->adv_d, take_cap);
+                       field ? h->beat_bits : h->hup_bits, h->offsets, (uint64_t*)h->adv_d, take_cap);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint64_t total = *h->h_total;
@@ -765,6 +786,14 @@ int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) 
   if (take) std::memcpy(groups, h->adv_h, take * 8);
   h->adv_listed = 0;
   return RAFTQ_OK;
+}
+
+int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) {
+  return collect_tick_list(h, "raftq_collect_hups", 0, groups, cap, n);
+}
+
+int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) {
+  return collect_tick_list(h, "raftq_collect_beats", 1, groups, cap, n);
 }
 
 int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self_peer) {
@@ -787,32 +816,47 @@ int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self
 
 // enqueue scan + compaction of the last RAFTQ_SWEEP_CHANGED sweep; the kernels
 // write the total and up to `take_cap` entries straight into pinned host memory.
-static int enqueue_collect(raftq_t* h, uint64_t take_cap) {
-  static_assert(sizeof(Advance) == sizeof(raftq_advance_t), "ABI struct mismatch");
-  hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->partials, h->n_partials,
-                     h->offsets, h->d_total);
-  if (take_cap) {
-    const int gpl = h->last_gpl;
-    const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
-    // the compaction mirrors the geometry of the sweep that wrote the bitmap and the per-wave counts
-    switch (gpl) {
-      case 2:
-        hipLaunchKernelGGL((compact_changed_kernel<2>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
-                           h->last_old, h->last_new, h->adv_d, take_cap);
-        break;
-      case 8:
-        hipLaunchKernelGGL((compact_changed_kernel<8>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
-                           h->last_old, h->last_new, h->adv_d, take_cap);
-        break;
-      default:
-        static_assert(kGPL == 4 && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
-        hipLaunchKernelGGL((compact_changed_kernel<4>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->offsets,
-                           h->last_old, h->last_new, h->adv_d, take_cap);
-    }
+}  // extern "C" (templates need C++ linkage)
+
+// scan-free compaction of the last RAFTQ_SWEEP_CHANGED sweep (compact_changed_kernel computes its own offsets):
+// total and up to `take_cap` entries go straight into pinned host memory.  want_flag: also publish a completion
+// flag the host can poll (returns its value in h->compact_epoch).
+template <typename Adv>
+static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
+  static_assert(sizeof(Advance) == sizeof(raftq_advance_t) && sizeof(Advance16) == sizeof(raftq_advance16_t), "ABI struct mismatch");
+  const int gpl = h->last_gpl;
+  const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
+  Adv* out = (Adv*)h->adv_d;  // the pinned list holds either layout (sized for the larger one)
+  // the compaction mirrors the geometry of the sweep that wrote the bitmap and the per-wave counts
+  switch (gpl) {
+    case 2:
+      hipLaunchKernelGGL((compact_changed_kernel<2, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
+                         h->last_old, h->last_new, out, take_cap, h->d_total);
+      break;
+    case 8:
+      hipLaunchKernelGGL((compact_changed_kernel<8, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
+                         h->last_old, h->last_new, out, take_cap, h->d_total);
+      break;
+    default:
+      static_assert(kGPL == 4 && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
+      hipLaunchKernelGGL((compact_changed_kernel<4, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
+                         h->last_old, h->last_new, out, take_cap, h->d_total);
   }
   HIPCHK(h, hipGetLastError());
+  h->compact_epoch_armed = 0;
+  if (want_flag && h->stream_write_ok) {
+    // a write-value packet behind the kernel: the command processor stores the epoch into the pinned flag word
+    // once the compaction (and its end-of-kernel release) has completed -- no extra kernel, no interrupt
+    const uint64_t epoch = ++h->compact_epoch;
+    if (hipStreamWriteValue64(h->stream, (void*)(h->d_total + 3), epoch, 0) == hipSuccess)
+      h->compact_epoch_armed = epoch;
+    else
+      h->stream_write_ok = false;  // not supported here: turns end in the blocking wait
+  }
   return RAFTQ_OK;
 }
+
+extern "C" {
 
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
   if (int rc = use_device_idle(h, "raftq_collect_changed")) return rc;
@@ -823,12 +867,13 @@ int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64
   const uint64_t take_cap = std::min<uint64_t>(cap, h->G);
   if (take_cap)
     if (int rc = ensure_adv(h, take_cap)) return rc;
-  if (int rc = enqueue_collect(h, take_cap)) return rc;
+  if (int rc = enqueue_collect<Advance>(h, take_cap, false)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint64_t total = *h->h_total;
   *n = total;
   const uint64_t take = std::min(total, take_cap);
   h->adv_listed = take;
+  h->adv_packed = false;
   if (take) std::memcpy(out, h->adv_h, take * sizeof(Advance));
   return RAFTQ_OK;
 }
@@ -850,54 +895,93 @@ int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_del
 int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   if (!list || !n_listed) return fail(h, RAFTQ_EINVAL, "raftq_last_advances: null argument");
+  if (h->adv_listed && h->adv_packed)
+    return fail(h, RAFTQ_ESTATE, "raftq_last_advances: the last list was produced in the packed layout");
   *list = (const raftq_advance_t*)h->adv_h;
   *n_listed = h->adv_listed;
   return RAFTQ_OK;
 }
 
-int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
-                uint64_t n_vote_deltas, unsigned flags, raftq_advance_t* advances_out, uint64_t cap,
-                uint64_t* n_advanced, raftq_counts_t* counts) {
-  if (int rc = use_device_idle(h, "raftq_cycle")) return rc;
+}  // extern "C" (templates need C++ linkage)
+
+// The end of a batching turn.  A turn is ~55 us of device work, so the wake-up of a blocking
+// hipStreamSynchronize (interrupt + reschedule, ~8 us) is a visible slice of it.  When the turn ends in a
+// compaction, a stream write-value packet behind that kernel stores a completion epoch into pinned host memory:
+// the host polls the word -- bounded, then falls back to the blocking wait.
+// (Polling hipStreamQuery instead was measured SLOWER than blocking: 88 vs 80 us per turn, profiles/r02.)
+// RAFTQ_CYCLE_WAIT=block restores the plain blocking wait.
+static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
+  static const bool poll = [] {
+    const char* e = std::getenv("RAFTQ_CYCLE_WAIT");
+    return !(e && std::strcmp(e, "block") == 0);
+  }();
+  if (poll && flag_epoch) {
+    volatile uint64_t* flag = h->h_total + 3;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+      if (*flag == flag_epoch) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return hipSuccess;
+      }
+      if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+    }
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
+// One batching turn (raft.go:227-235 for every group at once): ingest -> sweep -> advance list, one wait.
+// Rec / AbiRec: layout of the match deltas; Adv / AbiAdv: layout of the advance list.
+template <typename Rec, typename Adv, typename AbiRec, typename AbiAdv>
+static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
+                      uint64_t n_vote_deltas, unsigned flags, AbiAdv* advances_out, uint64_t cap, uint64_t* n_advanced,
+                      raftq_counts_t* counts) {
+  if (int rc = use_device_idle(h, who)) return rc;
   if ((n_deltas && !deltas) || (n_vote_deltas && !vote_deltas))
-    return fail(h, RAFTQ_EINVAL, "raftq_cycle: null array with non-zero length");
+    return fail(h, RAFTQ_EINVAL, std::string(who) + ": null array with non-zero length");
+  if (int rc = sweep_check(h, flags & ~RAFTQ_CYCLE_TRUSTED, who)) return rc;  // before anything is enqueued: a refused turn applies nothing
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool want_list = commit && (advances_out || n_advanced || cap);
   if (want_list) flags |= RAFTQ_SWEEP_CHANGED;
-  const size_t off_votes = vote_stage_offset(n_deltas);
+  const size_t off_votes = ((size_t)n_deltas * sizeof(AbiRec) + 255) / 256 * 256;
   if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
   const uint64_t take_cap = want_list ? std::min<uint64_t>(cap, h->G) : 0;
   if (take_cap)
     if (int rc = ensure_adv(h, take_cap)) return rc;
-  // everything below is enqueued back to back on the handle's stream; one sync at the end
+  // everything below is enqueued back to back on the handle's stream; one wait at the end
   using clk = std::chrono::steady_clock;
   auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t0 = clk::now();
-  if (n_deltas)
-    if (int rc = enqueue_deltas(h, deltas, n_deltas, 0)) return rc;
-  if (n_vote_deltas)
-    if (int rc = enqueue_vote_deltas(h, vote_deltas, n_vote_deltas, off_votes)) return rc;
+  const bool trusted = flags & RAFTQ_CYCLE_TRUSTED;
+  flags &= ~RAFTQ_CYCLE_TRUSTED;
+  if (n_deltas || n_vote_deltas)
+    if (int rc = enqueue_ingest<Rec>(h, deltas, n_deltas, vote_deltas, n_vote_deltas, off_votes, trusted)) return rc;
   const auto t1 = clk::now();
+  const int cur_before = h->cur;
   if (int rc = raftq_step_async(h, flags)) return rc;
   const auto t2 = clk::now();
+  const bool flag_wake = want_list && !counts;  // the compaction is the last thing on the stream: it can say "done"
   if (want_list)
-    if (int rc = enqueue_collect(h, take_cap)) return rc;
+    if (int rc = enqueue_collect<Adv>(h, take_cap, flag_wake)) return rc;
   if (counts)
     HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost,
                              h->stream));
   const auto t3 = clk::now();
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_turn(h, flag_wake ? h->compact_epoch_armed : 0));
   const auto t4 = clk::now();
   h->prof[1] += us(t0, t1);
   h->prof[2] += us(t1, t2);
   h->prof[3] += us(t2, t3);
   h->prof[4] += us(t3, t4);
   h->prof_n++;
-  if (int rc = check_deltas(h)) {  // the device found a record out of range: none of the batch was scattered
+  const int verdict = check_deltas(h);
+  if (verdict != RAFTQ_OK && !trusted) {
+    // the device found a record out of range: no record of either kind was scattered, and the sweep that ran on
+    // the unchanged state is not adopted either -- the handle is exactly where it was before the call
+    h->cur = cur_before;
     if (n_advanced) *n_advanced = 0;
     if (counts) *counts = raftq_counts_t{0, 0, 0};
     h->adv_listed = 0;
-    return rc;
+    return verdict;
   }
   if (counts) {
     uint64_t c = 0, w = 0, l = 0;
@@ -915,9 +999,48 @@ int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, cons
     if (n_advanced) *n_advanced = total;
     const uint64_t take = std::min(total, take_cap);
     h->adv_listed = take;
-    // advances_out == NULL: the caller reads the pinned list in place (raftq_last_advances)
-    if (take && advances_out) std::memcpy(advances_out, h->adv_h, take * sizeof(Advance));
+    h->adv_packed = sizeof(Adv) == sizeof(Advance16);
+    // advances_out == NULL: the caller reads the pinned list in place (raftq_last_advances*)
+    if (take && advances_out) std::memcpy(advances_out, h->adv_h, take * sizeof(Adv));
   }
+  return verdict;  // RAFTQ_CYCLE_TRUSTED: a dropped record is still reported, with every output filled in
+}
+
+extern "C" {
+
+int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
+                uint64_t n_vote_deltas, unsigned flags, raftq_advance_t* advances_out, uint64_t cap,
+                uint64_t* n_advanced, raftq_counts_t* counts) {
+  return cycle_impl<DeltaRec, Advance>(h, "raftq_cycle", deltas, n_deltas, vote_deltas, n_vote_deltas, flags, advances_out, cap,
+                                       n_advanced, counts);
+}
+
+int raftq_cycle_packed(raftq_t* h, const raftq_delta16_t* deltas, uint64_t n_deltas, const raftq_vote_delta_t* vote_deltas,
+                       uint64_t n_vote_deltas, unsigned flags, raftq_advance16_t* advances_out, uint64_t cap,
+                       uint64_t* n_advanced, raftq_counts_t* counts) {
+  if (h && h->G > (1ull << 32))
+    return fail(h, RAFTQ_EINVAL, "raftq_cycle_packed: the packed records carry 32-bit group ids (handle has more than 2^32 groups)");
+  return cycle_impl<Delta16Rec, Advance16>(h, "raftq_cycle_packed", deltas, n_deltas, vote_deltas, n_vote_deltas, flags,
+                                           advances_out, cap, n_advanced, counts);
+}
+
+int raftq_stage_packed(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_delta16_t** deltas,
+                       raftq_vote_delta_t** vote_deltas) {
+  if (int rc = use_device_idle(h, "raftq_stage_packed")) return rc;
+  const size_t off_votes = ((size_t)n_deltas * sizeof(raftq_delta16_t) + 255) / 256 * 256;
+  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  if (deltas) *deltas = (raftq_delta16_t*)h->stage_h;
+  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+  return RAFTQ_OK;
+}
+
+int raftq_last_advances_packed(raftq_t* h, const raftq_advance16_t** list, uint64_t* n_listed) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!list || !n_listed) return fail(h, RAFTQ_EINVAL, "raftq_last_advances_packed: null argument");
+  if (h->adv_listed && !h->adv_packed)
+    return fail(h, RAFTQ_ESTATE, "raftq_last_advances_packed: the last list was produced in the 24-byte layout");
+  *list = (const raftq_advance16_t*)h->adv_h;
+  *n_listed = h->adv_listed;
   return RAFTQ_OK;
 }
 

@@ -38,6 +38,11 @@ struct raftq {
   raftqk::Advance* adv_d = nullptr;
   uint64_t adv_cap = 0;
   uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
+  bool adv_packed = false;     // ... in the 16-byte layout (raftq_cycle_packed)
+  unsigned int* compact_arrived = nullptr;  // (spare device word)
+  uint64_t compact_epoch = 0;  // completion-flag values handed to hipStreamWriteValue64 (h_total[3])
+  uint64_t compact_epoch_armed = 0;  // epoch the current turn's wait may poll for (0 = blocking wait)
+  bool stream_write_ok = true; // hipStreamWriteValue64 works on this stack
   uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
   // sparse ingest: device copy of the batch (validated on the way in) and the "bad batch" epoch words
   void* delta_dev = nullptr;
@@ -50,6 +55,7 @@ struct raftq {
   uint32_t* elapsed = nullptr;  // [ld]
   uint8_t* action = nullptr;    // [ld]
   uint64_t* hup_bits = nullptr; // [gpad/64]
+  uint64_t* beat_bits = nullptr; // [gpad/64]
   uint4* tick_partials = nullptr;  // [gpad/256]
   uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
   uint64_t tick_seed = 0x1000, tick_no = 0;

@@ -532,11 +532,24 @@ struct DeltaRec {      // == raftq_delta_t
   uint64_t group, match;
   uint32_t peer, pad;
 };
+struct Delta16Rec {    // == raftq_delta16_t: the same update in 16 bytes for handles of fewer than 2^32 groups --
+  uint64_t match;      // a third less PCIe traffic on the ingest side (the ingest is PCIe-bound)
+  uint32_t group, peer;
+};
 struct VoteDeltaRec {  // == raftq_vote_delta_t
   uint64_t group;
   uint32_t peer;
   uint8_t vote, pad[3];
 };
+
+// A batch's verdict is kept per kind in two device words (epoch of the last bad batch).  The scatter kernels of
+// ONE call check the words of every kind that call brought (kNoEpoch = that kind is not part of the call), so a
+// bad vote record also withholds the match deltas that came with it: a cycle applies everything or nothing.
+constexpr unsigned long long kNoEpoch = ~0ull;
+__device__ __forceinline__ bool batch_is_bad(const unsigned long long* bad, unsigned long long epoch_match,
+                                             unsigned long long epoch_votes) {
+  return bad[0] == epoch_match || bad[1] == epoch_votes;
+}
 
 // Progress.maybeUpdate only ever raises Match, so a batch of MsgAppResp
 // deltas is an order-independent atomic max.
@@ -544,14 +557,15 @@ struct VoteDeltaRec {  // == raftq_vote_delta_t
 // read over PCIe brings them into HBM and range-checks them on the way.  A bad record stamps this batch's epoch
 // into *bad_epoch (device) and *bad_host (mapped host word): pass 2 then applies nothing, and the host reports
 // RAFTQ_EINVAL after its sync -- the all-or-nothing rule of the ABI without a 65K-iteration host loop (36 us).
-static __global__ __launch_bounds__(kBlock) void deltas_in_kernel(const DeltaRec* __restrict__ src, DeltaRec* __restrict__ dst,
+template <typename Rec>
+static __global__ __launch_bounds__(kBlock) void deltas_in_kernel(const Rec* __restrict__ src, Rec* __restrict__ dst,
                                                                   uint64_t n, uint64_t n_groups, uint32_t n_peers,
                                                                   unsigned long long* bad_epoch, uint64_t* bad_host,
                                                                   unsigned long long epoch) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool bad = false;
   if (i < n) {
-    const DeltaRec r = src[i];
+    const Rec r = src[i];
     dst[i] = r;
     bad = r.group >= n_groups || r.peer >= n_peers;
   }
@@ -561,14 +575,37 @@ static __global__ __launch_bounds__(kBlock) void deltas_in_kernel(const DeltaRec
   }
 }
 
+// RAFTQ_CYCLE_TRUSTED: the caller vouches for the ranges (a driver that built the records itself), so validation
+// and scatter are ONE pass straight from the pinned batch -- no HBM copy, no second launch.  A record that is out
+// of range after all is dropped on its own and reported; the others are applied.
+template <typename Rec>
+static __global__ __launch_bounds__(kBlock) void deltas_in_apply_kernel(const Rec* __restrict__ src, uint64_t n, uint64_t* match,
+                                                                        uint64_t ld, uint64_t n_groups, uint32_t n_peers,
+                                                                        unsigned long long* bad_epoch, uint64_t* bad_host,
+                                                                        unsigned long long epoch) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const Rec r = src[i];
+    bad = r.group >= n_groups || r.peer >= n_peers;
+    if (!bad)
+      atomicMax(reinterpret_cast<unsigned long long*>(match + (uint64_t)r.peer * ld + r.group), (unsigned long long)r.match);
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) {
+    atomicMax(bad_epoch, epoch);
+    *bad_host = epoch;
+  }
+}
+
+template <typename Rec>
 static __global__ __launch_bounds__(kBlock) void apply_deltas_kernel(uint64_t* match, uint64_t ld,
-                                                              const DeltaRec* __restrict__ d, uint64_t n,
-                                                              const unsigned long long* bad_epoch,
-                                                              unsigned long long epoch) {
-  if (*bad_epoch == epoch) return;  // a record of this batch is out of range: nothing is applied
+                                                              const Rec* __restrict__ d, uint64_t n,
+                                                              const unsigned long long* bad,
+                                                              unsigned long long epoch_match, unsigned long long epoch_votes) {
+  if (batch_is_bad(bad, epoch_match, epoch_votes)) return;  // a record of this call is out of range: nothing is applied
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const DeltaRec r = d[i];
+  const Rec r = d[i];
   atomicMax(reinterpret_cast<unsigned long long*>(match + (uint64_t)r.peer * ld + r.group),
             (unsigned long long)r.match);
 }
@@ -613,9 +650,9 @@ static __global__ __launch_bounds__(kBlock) void vote_deltas_in_kernel(const Vot
 
 static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* claim, uint64_t ld,
                                                             const VoteDeltaRec* __restrict__ d, uint64_t n,
-                                                            const unsigned long long* bad_epoch,
-                                                            unsigned long long epoch) {
-  if (*bad_epoch == epoch) return;
+                                                            const unsigned long long* bad, unsigned long long epoch_match,
+                                                            unsigned long long epoch_votes) {
+  if (batch_is_bad(bad, epoch_match, epoch_votes)) return;
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const VoteDeltaRec r = d[i];
@@ -624,9 +661,9 @@ static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* cla
 
 static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
                                                             const VoteDeltaRec* __restrict__ d, uint64_t n,
-                                                            const unsigned long long* bad_epoch,
-                                                            unsigned long long epoch) {
-  if (*bad_epoch == epoch) return;
+                                                            const unsigned long long* bad, unsigned long long epoch_match,
+                                                            unsigned long long epoch_votes) {
+  if (batch_is_bad(bad, epoch_match, epoch_votes)) return;
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const VoteDeltaRec r = d[i];
@@ -654,52 +691,119 @@ static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* vote
 // already left per-wave change counts in partials[].x; scan_partials_kernel
 // turns them into exclusive offsets (one workgroup, the array is small), then
 // every wave of compact_changed_kernel ranks its own bits with popcounts.
-struct Advance {
+struct Advance {       // == raftq_advance_t
   uint64_t group, old_commit, new_commit;
 };
+struct Advance16 {     // == raftq_advance16_t: 16 bytes back over PCIe instead of 24 (handles of < 2^32 groups);
+  uint64_t new_commit; // old_commit = new_commit - advanced_by, exact unless advanced_by saturated at 2^32 - 1
+  uint32_t group, advanced_by;
+};
+__device__ __forceinline__ Advance make_advance(Advance*, uint64_t g, uint64_t o, uint64_t n) { return Advance{g, o, n}; }
+__device__ __forceinline__ Advance16 make_advance(Advance16*, uint64_t g, uint64_t o, uint64_t n) {
+  const uint64_t by = n - o;
+  return Advance16{n, (uint32_t)g, by > 0xfffffffeull ? 0xffffffffu : (uint32_t)by};
+}
 
-static __global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* partials, uint64_t n_waves,
-                                                             uint64_t* offsets, uint64_t* total) {
-  __shared__ uint64_t warp_tot[16];
-  __shared__ uint64_t carry;
+// One workgroup, one pass over memory for the common sizes: thread t owns the contiguous chunk
+// [t*per, (t+1)*per) of the per-wave counts (per = ceil(n/1024): 4 for 1M groups at 256-group waves), sums it
+// with every load issued up front, the 1024 chunk sums are scanned by wave shuffles + one LDS hop, and the chunk's
+// exclusive offsets are written from registers (chunks up to 8 items; longer ones are re-read).  `field` picks
+// the counter: 0 = .x (changed groups / MsgHup), 1 = .y (MsgBeat).  7.2 -> ~3 us for 4096 counts: the old form
+// walked the array in four dependent load -> scan -> barrier rounds.
+static __global__ __launch_bounds__(1024) void scan_partials_kernel(const uint4* __restrict__ partials, uint64_t n_waves,
+                                                             uint64_t* __restrict__ offsets, uint64_t* total, int field) {
+  __shared__ uint64_t wave_tot[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (uint64_t base = 0; base < n_waves; base += 1024) {
-    const uint64_t i = base + tid;
-    uint64_t x = i < n_waves ? partials[i].x : 0;
-    uint64_t incl = x;
+  const uint64_t per = (n_waves + 1023) / 1024;
+  const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n_waves ? lo + per : n_waves;
+  const uint32_t* p32 = reinterpret_cast<const uint32_t*>(partials) + field;
+  constexpr int kKeep = 8;
+  uint32_t keep[kKeep];
+  uint64_t sum = 0;
+  if (per <= kKeep) {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t y = __shfl_up(incl, o, 64);
-      if (lane >= (uint32_t)o) incl += y;
-    }
-    if (lane == 63) warp_tot[w] = incl;
-    __syncthreads();
-    uint64_t pre = carry;
-    for (uint32_t k = 0; k < w; ++k) pre += warp_tot[k];
-    if (i < n_waves) offsets[i] = pre + incl - x;
-    __syncthreads();
-    if (tid == 1023) carry = pre + incl;
-    __syncthreads();
+    for (int k = 0; k < kKeep; ++k) keep[k] = (uint64_t)k < per && lo + k < hi ? p32[(lo + k) * 4] : 0u;
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) sum += keep[k];
+  } else {
+    for (uint64_t i = lo; i < hi; ++i) sum += p32[i * 4];
   }
-  if (tid == 0) *total = carry;
+  uint64_t incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
+  }
+  if (lane == 63) wave_tot[w] = incl;
+  __syncthreads();
+  uint64_t pre = 0;
+  for (uint32_t k = 0; k < w; ++k) pre += wave_tot[k];
+  uint64_t run = pre + incl - sum;  // exclusive offset of this thread's chunk
+  if (per <= kKeep) {
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k)
+      if ((uint64_t)k < per && lo + k < hi) {
+        offsets[lo + k] = run;
+        run += keep[k];
+      }
+  } else {
+    for (uint64_t i = lo; i < hi; ++i) {
+      offsets[i] = run;
+      run += p32[i * 4];
+    }
+  }
+  if (tid == 1023) *total = pre + incl;
 }
 
 // Mirrors the sweep's geometry: wave `wv` of block `b` owns the 64*GPL
 // consecutive groups from b*kTile + wv*64*GPL and produced, for each round j,
 // one {even, odd} word pair for the 128 groups at + j*128 -- so (block, wave,
 // round, lane, parity) order IS ascending group order.
-template <int GPL>
+// No separate scan launch: a workgroup computes the exclusive offset of its first wave itself, as the sum of the
+// per-wave counts of every wave before it (<= 8192 L2-resident words, read by all 256 threads with the loads
+// issued eight at a time), which is cheaper than the 5 us single-workgroup scan kernel plus the launch boundary it
+// replaces.  The last workgroup also publishes the total.  (A first form had every workgroup
+// __threadfence_system() and count itself in so that the last one could raise a completion flag for the host:
+// the fence writes back and invalidates the L2 -- 127 us instead of 13.  The flag is now a stream write-value
+// packet behind the kernel, raftq_capi.hip wait_turn.)
+template <int GPL, typename Adv>
 static __global__ __launch_bounds__(kBlock) void compact_changed_kernel(const uint64_t* changed_bits,
-                                                                 const uint64_t* offsets,
+                                                                 const uint4* __restrict__ partials,
                                                                  const uint64_t* old_commit,
                                                                  const uint64_t* new_commit,
-                                                                 Advance* out, uint64_t cap) {
+                                                                 Adv* out, uint64_t cap, uint64_t* total) {
   constexpr int kTile = kBlock * GPL;
   constexpr int kRounds = GPL / 2;
+  __shared__ uint64_t red[kWaves];
+  __shared__ uint32_t mine[kWaves];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint64_t pos = offsets[(uint64_t)blockIdx.x * kWaves + wave];
+  // exclusive prefix of the change counts of all waves of earlier workgroups
+  const uint32_t first_wave = blockIdx.x * kWaves;
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(partials);  // .x of entry i = word 4 i
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  uint32_t i = tid;
+  for (; i + 3 * kBlock < first_wave; i += 4 * kBlock) {
+    a0 += cnt[4 * (uint64_t)i];
+    a1 += cnt[4 * (uint64_t)(i + kBlock)];
+    a2 += cnt[4 * (uint64_t)(i + 2 * kBlock)];
+    a3 += cnt[4 * (uint64_t)(i + 3 * kBlock)];
+  }
+  for (; i < first_wave; i += kBlock) a0 += cnt[4 * (uint64_t)i];
+  uint64_t acc = (uint64_t)a0 + a1 + a2 + a3;  // per-thread partial sums stay below 2^32 (counts <= 256 per wave)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) red[wave] = acc;
+  if (tid < kWaves) mine[tid] = cnt[4 * (uint64_t)(first_wave + tid)];
+  __syncthreads();
+  uint64_t pos = 0;
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) pos += red[k];
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    uint64_t t = pos;
+    for (int k = 0; k < kWaves; ++k) t += mine[k];
+    *total = t;
+  }
+  for (uint32_t k = 0; k < wave; ++k) pos += mine[k];
   const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int j = 0; j < kRounds; ++j) {
@@ -710,11 +814,11 @@ static __global__ __launch_bounds__(kBlock) void compact_changed_kernel(const ui
     const uint64_t rank = __popcll(b0 & below) + __popcll(b1 & below);
     if (e) {
       const uint64_t g = g0 + 2 * lane, s = pos + rank;
-      if (s < cap) out[s] = Advance{g, old_commit[g], new_commit[g]};
+      if (s < cap) out[s] = make_advance((Adv*)nullptr, g, old_commit[g], new_commit[g]);
     }
     if (o) {
       const uint64_t g = g0 + 2 * lane + 1, s = pos + rank + (e ? 1 : 0);
-      if (s < cap) out[s] = Advance{g, old_commit[g], new_commit[g]};
+      if (s < cap) out[s] = make_advance((Adv*)nullptr, g, old_commit[g], new_commit[g]);
     }
     pos += __popcll(b0) + __popcll(b1);
   }
@@ -733,6 +837,7 @@ struct TickArgs {
   uint32_t* elapsed;     // in/out
   uint8_t* action;       // 0 none, 1 MsgHup, 2 MsgBeat
   uint64_t* hup_bits;    // [gpad/64]
+  uint64_t* beat_bits;   // [gpad/64] same layout, MsgBeat groups
   uint4* partials;       // [gpad/256] {hup, beat, 0, 0} per wave
   uint64_t n_groups;     // padding groups never act
   uint64_t seed, tick_no;
@@ -755,7 +860,7 @@ static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
   uint32_t e[4] = {el.x, el.y, el.z, el.w};
   uint32_t acts = 0;
   uint32_t n_hup = 0, n_beat = 0;  // wave-uniform
-  uint64_t hb[4];
+  uint64_t hb[4], bb[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t role = (roles >> (8 * k)) & 0xffu;
@@ -768,8 +873,9 @@ static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
     e[k] = !valid ? e[k] : (act ? 0u : v);
     acts |= act << (8 * k);
     hb[k] = __ballot(act == 1u);
+    bb[k] = __ballot(act == 2u);
     n_hup += __popcll(hb[k]);
-    n_beat += __popcll(__ballot(act == 2u));
+    n_beat += __popcll(bb[k]);
   }
   el.x = e[0]; el.y = e[1]; el.z = e[2]; el.w = e[3];
   *reinterpret_cast<uint4*>(a.elapsed + g) = el;
@@ -780,6 +886,9 @@ static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
     lo.x = hb[0]; lo.y = hb[1]; hi.x = hb[2]; hi.y = hb[3];
     *reinterpret_cast<u64x2*>(a.hup_bits + w0) = lo;
     *reinterpret_cast<u64x2*>(a.hup_bits + w0 + 2) = hi;
+    lo.x = bb[0]; lo.y = bb[1]; hi.x = bb[2]; hi.y = bb[3];
+    *reinterpret_cast<u64x2*>(a.beat_bits + w0) = lo;
+    *reinterpret_cast<u64x2*>(a.beat_bits + w0 + 2) = hi;
     uint4 r;
     r.x = n_hup; r.y = n_beat; r.z = 0; r.w = 0;
     a.partials[(uint64_t)blockIdx.x * kWaves + wave] = r;

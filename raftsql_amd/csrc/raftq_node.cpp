@@ -145,7 +145,7 @@ struct raftq_node {
   std::mutex turn_mu;  // one advance() at a time
   raftq_node_stats_t stats{};
   // scratch of advance()
-  std::vector<uint8_t> action;
+  std::vector<uint64_t> tick_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
   std::vector<raftq_log_delta_t> deltas;
   std::vector<uint64_t> delta_commit;
 };
@@ -329,6 +329,10 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vec
       if (g.log[idx - 1].term != im.ents[k].term) {
         g.log.resize(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
         g.wal_upto = std::min<uint64_t>(g.wal_upto, idx - 1);  // the WAL gets the replacement entries again
+        // replayWAL published the whole log, committed or not (raft.go:122-134), so `applied` may sit beyond the
+        // truncation point: the replacement entries at those indices must reach the commit channel once they
+        // commit (the reference re-publishes them through rd.Entries), so the cursor comes back with the log
+        g.applied = std::min<uint64_t>(g.applied, idx - 1);
         n->shared_group = ~0ull;
         break;
       }
@@ -630,7 +634,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   try {
     n->groups.resize(n_groups);
     n->outbound.resize(n_peers);
-    n->action.resize(n_groups);
+    n->tick_list.resize(std::min<uint64_t>(n_groups, 4096));
   } catch (...) {
     raftq_destroy(n->h);
     delete n;
@@ -901,18 +905,33 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   ph.next(raftq_node::kPhTick);
   for (uint32_t t = 0; t < ticks; ++t) {
     lk.unlock();
+    // the device compacts the two short lists (ascending group ids); no G-byte read-back and no loop over every
+    // group under the lock (O(G) host work per 100 ms tick at 1M groups)
     int rc = raftq_tick(n->h, nullptr);
-    if (rc == RAFTQ_OK) rc = raftq_read_tick(n->h, n->action.data(), nullptr, nullptr);
+    uint64_t n_hup = 0, n_beat = 0;
+    if (rc == RAFTQ_OK) rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
+    if (rc == RAFTQ_OK && n_hup > n->tick_list.size()) {
+      n->tick_list.resize(n_hup);
+      rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
+    }
     if (rc != RAFTQ_OK) return poison(n, rc, "tick");
     lk.lock();
-    for (uint64_t gi = 0; gi < n->G; ++gi) {
-      if (n->action[gi] == 1) {
-        InMsg im;
-        im.h = header(n, gi, RAFTQ_MSG_HUP, 0);
-        hups.push_back(std::move(im));
-      } else if (n->action[gi] == 2 && n->groups[gi].role == RAFTQ_ROLE_LEADER) {
-        bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat has no state effect: host only
-      }
+    for (uint64_t i = 0; i < n_hup; ++i) {
+      InMsg im;
+      im.h = header(n, n->tick_list[i], RAFTQ_MSG_HUP, 0);
+      hups.push_back(std::move(im));
+    }
+    lk.unlock();
+    rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
+    if (rc == RAFTQ_OK && n_beat > n->tick_list.size()) {
+      n->tick_list.resize(n_beat);
+      rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
+    }
+    if (rc != RAFTQ_OK) return poison(n, rc, "tick");
+    lk.lock();
+    for (uint64_t i = 0; i < n_beat; ++i) {
+      const uint64_t gi = n->tick_list[i];
+      if (n->groups[gi].role == RAFTQ_ROLE_LEADER) bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat: host only
     }
   }
   if (!hups.empty()) {

@@ -132,8 +132,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
   size_t w_cub_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wcub = 0;
   if (wire) {
-    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, w_cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                               (int)(n + 1), h->stream));
+    w_cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan (raftq_wire_kernels.hpp)
     o_wfr = carve((n + 1) * 8 + wire_nbytes + 16);
     o_wcnt = carve((n + 1) * 8);
     o_wbase = carve((n + 1) * 8);
@@ -476,8 +475,7 @@ static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSl
     // message order, ent_first of every message), kept out of the Step chain because Step does not need it
     Scratch s;
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, true, sl.w_nbytes)) return rc;
-    size_t wb = s.w_cub_bytes;
-    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(s.w_cub, wb, (const uint64_t*)s.w_cnt, s.w_base, (int)(sl.n + 1), st));
+    HIPCHK(h, exclusive_sum_u64((const uint64_t*)s.w_cnt, s.w_base, sl.n + 1, (uint64_t*)s.w_cub, st));
     hipLaunchKernelGGL(wire_dec_ents_kernel, dim3((unsigned)((sl.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        (const uint8_t*)s.w_stream, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base,
                        s.w_ents, s.w_ents_cap);
@@ -631,8 +629,12 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   if (int rc = ensure_node_state(h)) return rc;
   const size_t off_out = align256((size_t)n * sizeof(raftq_log_delta_t));
   if (int rc = ensure_staging(h, off_out + (size_t)n * 8)) return rc;
-  // records of one group apply in order: the k-th record of a group goes into launch k
+  // records of one group apply in order: the k-th record of a group goes into launch k.  One counting sort
+  // on the round number buckets the batch in O(n) whatever the skew (a hot group repeated k times used to cost
+  // k passes over the batch); launches stay one per round.
+  if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: batch too large (n must fit 32 bits)");
   std::vector<uint32_t> round, pos_of;  // pos_of[staged position] = caller's index
+  std::vector<uint64_t> round_start;    // staged position where round r begins (+ the end)
   uint32_t n_rounds = 1;
   try {
     round.resize(n);
@@ -644,6 +646,9 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
       round[i] = r;
       n_rounds = std::max(n_rounds, r + 1);
     }
+    round_start.assign((size_t)n_rounds + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) round_start[round[i] + 1]++;
+    for (uint32_t r = 0; r < n_rounds; ++r) round_start[r + 1] += round_start[r];
   } catch (...) {
     return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
   }
@@ -651,15 +656,16 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
   uint64_t* out_h = (uint64_t*)((uint8_t*)h->stage_h + off_out);
   uint64_t* out_d = (uint64_t*)((uint8_t*)h->stage_d + off_out);
-  uint64_t pos = 0;
+  {
+    std::vector<uint64_t> fill(round_start.begin(), round_start.end() - 1);  // stable: caller order within a round
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t pos = fill[round[i]]++;
+      pos_of[pos] = (uint32_t)i;
+      dst[pos] = d[i];
+    }
+  }
   for (uint32_t r = 0; r < n_rounds; ++r) {
-    const uint64_t start = pos;
-    for (uint64_t i = 0; i < n; ++i)
-      if (round[i] == r) {
-        pos_of[pos] = (uint32_t)i;
-        dst[pos++] = d[i];
-      }
-    const uint64_t m = pos - start;
+    const uint64_t start = round_start[r], m = round_start[r + 1] - start;
     if (m == 0) continue;
     hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
                        node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m,

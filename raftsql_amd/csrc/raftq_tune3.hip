@@ -181,6 +181,20 @@ __global__ void fill_votes_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
   }
 }
 
+// streaming copy of a KNOWN byte count with the sweep's access width (16 B per lane, non-temporal): the
+// calibration target for the FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py)
+__global__ __launch_bounds__(256) void copy_ref_kernel(const u64x2* __restrict__ in, uint64_t n_in, u64x2* __restrict__ out,
+                                                        uint64_t n_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  u64x2 acc = {0, 0};
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_in; k += stride) {
+    const u64x2 v = __builtin_nontemporal_load(in + k);
+    acc ^= v;
+    if (k < n_out) __builtin_nontemporal_store(v, out + k);
+  }
+  if (acc.x == 0x123456789abcdefull && acc.y == 1) out[0] = acc;  // keep the loads alive
+}
+
 struct Member {
   uint8_t* arena;
   SweepArgs a;
@@ -346,6 +360,22 @@ int main(int argc, char** argv) {
       {"focus", 9, 0, 1, M1, 0, "set GPL2 P3", SETV(9, 2, false, true, 3), false},
       {"focus", 9, 0, 1, M1, 0, "set GPL4 P3", SETV(9, 4, false, true, 3), false},
   };
+  if (only && !strcmp(only, "calib")) {
+    // 20 launches, each reading 53 MiB-units and writing 9 of a different member (rotating: cache-cold)
+    const uint64_t G = M1;
+    std::vector<Member> mem;
+    for (int k = 0; k < 27; ++k) mem.push_back(make_member(5, G, 7000 + k));
+    CK(hipDeviceSynchronize());
+    const uint64_t n_in = G * 53 / 16, n_out = G * 9 / 16;
+    for (int r = 0; r < 25; ++r) {
+      const Member& m = mem[r % mem.size()];
+      hipLaunchKernelGGL(copy_ref_kernel, dim3(2048), dim3(256), 0, c.st, (const u64x2*)m.a.match, n_in, (u64x2*)m.a.committed_out, n_out);
+    }
+    CK(hipStreamSynchronize(c.st));
+    printf("{\"kernel\":\"copy_ref\",\"launches\":25,\"read_bytes\":%llu,\"write_bytes\":%llu}\n", (unsigned long long)(n_in * 16),
+           (unsigned long long)(n_out * 16));
+    return 0;
+  }
   const bool focus = only && !strcmp(only, "focus");
   struct Timed { const Variant* v; std::vector<double> us; };
   std::vector<Timed> family;  // verified focus variants of the current (N, G, gated, votes) family

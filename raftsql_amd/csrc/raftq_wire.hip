@@ -6,7 +6,6 @@
 #include "raftq_wire.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -63,10 +62,8 @@ unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / k
 int crc_chain_scan(raftq_t* h, const CrcPair* pair, CrcPair* chain, uint64_t n, CrcPair* tot) {
   const unsigned nb = blocks_for(n);
   hipLaunchKernelGGL(crc_scan_blocks_kernel, dim3(nb), dim3(kBlock), 0, h->stream, pair, chain, n, tot);
-  if (nb > 1) {
-    hipLaunchKernelGGL(crc_scan_totals_kernel, dim3(1), dim3(kBlock), 0, h->stream, tot, (uint64_t)nb);
+  if (nb > 1)
     hipLaunchKernelGGL(crc_scan_apply_kernel, dim3(nb), dim3(kBlock), 0, h->stream, chain, n, (const CrcPair*)tot);
-  }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
@@ -124,9 +121,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: null argument");
   if (n > kMaxItems || n_ents > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  size_t cub_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (int)(n + 1), h->stream));
+  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_msgs = c.take(n * sizeof(WireMsg)), o_ents = c.take(n_ents * sizeof(WireEnt)),
                o_pool = c.take(pool_bytes), o_sizes = c.take((n + 1) * 8), o_off = c.take((n + 1) * 8),
@@ -145,8 +140,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
                      (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_sizes, d_off, (int)(n + 1),
-                                             h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_cub), h->stream));
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -188,9 +182,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (int rc = ensure_pin(h)) return rc;
   // an entry costs its message at least two bytes (tag, length), so this many can never be exceeded
   const uint64_t dev_cap = std::min<uint64_t>(ents_cap, nbytes / 2 + 1);
-  size_t cub_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (int)(n + 1), h->stream));
+  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_stream = c.take(nbytes), o_off = c.take((n + 1) * 8), o_msgs = c.take(n * sizeof(WireMsg)),
                o_cnt = c.take((n + 1) * 8), o_base = c.take((n + 1) * 8), o_bad = c.take(8), o_cub = c.take(cub_bytes);
@@ -208,8 +200,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   hipLaunchKernelGGL(wire_dec_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      nbytes, (const uint64_t*)d_off, n, d_msgs, d_cnt, d_bad);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_cnt, d_base, (int)(n + 1),
-                                             h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_cnt, d_base, n + 1, (uint64_t*)(base + o_cub), h->stream));
   hipLaunchKernelGGL(wire_dec_ents_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
                      dev_cap);
@@ -249,9 +240,7 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (!recs || (pool_bytes && !pool) || (cap && !out)) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  size_t cub_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (int)(n + 1), h->stream));
+  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
                o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
@@ -278,8 +267,7 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   hipLaunchKernelGGL(wal_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
                      (const CrcPair*)d_chain, d_sizes);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(base + o_cub, cub_bytes, (const uint64_t*)d_sizes, d_off, (int)(n + 1),
-                                             h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_cub), h->stream));
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));

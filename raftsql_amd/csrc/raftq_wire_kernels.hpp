@@ -94,8 +94,8 @@ struct CrcCompose {  // (l then r)
 };
 
 // ---- inclusive scan of CrcPair under CrcCompose (the running CRC of a WAL segment) ------------------
-// Three launches: every 256-item block scans itself (shuffle scan per wave, the four wave totals through LDS) and
-// publishes its total; one block scans the block totals; every block folds its predecessors' total into its items.
+// Two launches: every 256-item block scans itself (shuffle scan per wave, the four wave totals through LDS) and
+// publishes its total; then every block composes its predecessors' totals and folds them into its items.
 // The generic library scan leaves 16 workgroups of 4K items for a 64K-record batch and spends 40 us there
 // (the operator is two 32-step shift-xor multiplications); this shape spreads the same work over 256 workgroups.
 constexpr CrcPair kCrcIdentity = {0u, 0x80000000u};
@@ -141,38 +141,98 @@ static __global__ __launch_bounds__(kBlock) void crc_scan_blocks_kernel(const Cr
   if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
 }
 
-// block_tot[0, nb) -> its exclusive scan in place (block b receives the composition of blocks 0 .. b-1)
-static __global__ __launch_bounds__(kBlock) void crc_scan_totals_kernel(CrcPair* __restrict__ block_tot, uint64_t nb) {
+// Every block composes the totals of the blocks before it ITSELF (in order: the operator is not commutative) and
+// folds the result into its items.  This replaces the single-block pass over the totals, which took 23 us on its
+// own for 256 totals (profiles/r02/wire_kernel_stats.csv) -- one block's worth of the two-multiplication operator
+// with the whole chip waiting for it.  block_tot holds the raw per-block totals of crc_scan_blocks_kernel.
+static __global__ __launch_bounds__(kBlock) void crc_scan_apply_kernel(CrcPair* __restrict__ out, uint64_t n,
+                                                                       const CrcPair* __restrict__ block_tot) {
+  if (blockIdx.x == 0) return;  // nothing precedes the first block
   __shared__ CrcPair wave_tot[kWaves];
   CrcCompose op;
   CrcPair carry = kCrcIdentity;
-  for (uint64_t base = 0; base < nb; base += kBlock) {
-    const uint64_t i = base + threadIdx.x;
-    const CrcPair mine = i < nb ? block_tot[i] : kCrcIdentity;
+  for (uint32_t base = 0; base < blockIdx.x; base += kBlock) {
+    const uint32_t j = base + threadIdx.x;
     CrcPair total;
-    const CrcPair incl = crc_block_inclusive(mine, wave_tot, &total);
-    // exclusive = carry . (inclusive of the previous item): shift by one through LDS-free shuffles is not enough
-    // across waves, so recompute: exclusive_i = carry . incl_{i-1}; take incl_{i-1} from the left neighbour
-    CrcPair left;
-    left.c = __shfl_up(incl.c, 1);
-    left.p = __shfl_up(incl.p, 1);
-    __shared__ CrcPair wave_last[kWaves];
-    if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) left = threadIdx.x == 0 ? kCrcIdentity : wave_last[(threadIdx.x >> 6) - 1];
-    if (i < nb) block_tot[i] = op(carry, left);
+    (void)crc_block_inclusive(j < blockIdx.x ? block_tot[j] : kCrcIdentity, wave_tot, &total);
     carry = op(carry, total);
-    __syncthreads();  // wave_tot / wave_last are reused by the next chunk
+    __syncthreads();  // wave_tot is reused by the next chunk
   }
-}
-
-static __global__ __launch_bounds__(kBlock) void crc_scan_apply_kernel(CrcPair* __restrict__ out, uint64_t n,
-                                                                       const CrcPair* __restrict__ block_pre) {
-  if (blockIdx.x == 0) return;  // nothing precedes the first block
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  CrcCompose op;
-  out[i] = op(block_pre[blockIdx.x], out[i]);
+  out[i] = op(carry, out[i]);
+}
+
+// ---------------------------------------------------------------------------
+// Exclusive prefix sum of u64 (frame sizes -> frame offsets, entry counts -> entry bases), hand-written for the
+// same reason as the CRC scan above: the library scan's default tile leaves a 64K-item batch to 16 workgroups
+// and costs 15 us of launch + operator latency for 0.5 MB of data.  Two launches:
+//   scan_sum_local_kernel: a workgroup owns kScanTile = 2048 consecutive items (8 per thread: two 32-byte loads),
+//     scans them in registers + wave shuffles + one LDS hop, writes the tile-local exclusive sums and its total;
+//   scan_sum_add_kernel:   every workgroup adds up the totals of the tiles before it (<= a few thousand
+//     L2-resident words) and adds that to its tile -- no third launch to scan the totals.
+// out[n_items - 1] ends up holding the sum of everything before the last item; callers pass n + 1 items with a
+// zero last item so that out[n] is the grand total (as they did with the library scan).
+constexpr int kScanPer = 8;
+constexpr int kScanTile = kBlock * kScanPer;
+
+static __global__ __launch_bounds__(kBlock) void scan_sum_local_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                        uint64_t n, uint64_t* __restrict__ tile_tot) {
+  __shared__ uint64_t wave_tot[kWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)tid * kScanPer;
+  uint64_t v[kScanPer];
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) v[k] = base + k < n ? in[base + k] : 0;
+  uint64_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) sum += v[k];
+  uint64_t incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
+  }
+  if (lane == 63) wave_tot[w] = incl;
+  __syncthreads();
+  uint64_t run = incl - sum;
+  for (uint32_t k = 0; k < w; ++k) run += wave_tot[k];
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (tid == kBlock - 1) tile_tot[blockIdx.x] = run;
+}
+
+static __global__ __launch_bounds__(kBlock) void scan_sum_add_kernel(uint64_t* __restrict__ out, uint64_t n,
+                                                                      const uint64_t* __restrict__ tile_tot) {
+  if (blockIdx.x == 0) return;  // nothing precedes the first tile
+  __shared__ uint64_t red[kWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint64_t acc = 0;
+  for (uint32_t i = tid; i < blockIdx.x; i += kBlock) acc += tile_tot[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) red[w] = acc;
+  __syncthreads();
+  uint64_t pre = 0;
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) pre += red[k];
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)tid * kScanPer;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k)
+    if (base + k < n) out[base + k] += pre;
+}
+
+// host side of the scan: bytes of scratch for the tile totals, and the two launches
+static inline size_t scan_sum_scratch_bytes(uint64_t n_items) { return (size_t)((n_items + kScanTile - 1) / kScanTile) * 8 + 8; }
+static inline hipError_t exclusive_sum_u64(const uint64_t* in, uint64_t* out, uint64_t n_items, uint64_t* tile_tot, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  const unsigned nb = (unsigned)((n_items + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(scan_sum_local_kernel, dim3(nb), dim3(kBlock), 0, st, in, out, n_items, tile_tot);
+  if (nb > 1) hipLaunchKernelGGL(scan_sum_add_kernel, dim3(nb), dim3(kBlock), 0, st, out, n_items, (const uint64_t*)tile_tot);
+  return hipGetLastError();
 }
 
 // 256-entry byte table in LDS, built by the block (256 threads)

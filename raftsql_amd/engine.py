@@ -178,6 +178,57 @@ class QuorumEngine:
     _VDELTA_DT = np.dtype([("group", "<u8"), ("peer", "<u4"), ("vote", "u1"), ("_pad", "u1", (3,))])
     _ADV_DT = np.dtype([("group", "<u8"), ("old_commit", "<u8"), ("new_commit", "<u8")])
 
+    _DELTA16_DT = np.dtype([("match", "<u8"), ("group", "<u4"), ("peer", "<u4")])
+    _ADV16_DT = np.dtype([("new_commit", "<u8"), ("group", "<u4"), ("advanced_by", "<u4")])
+
+    @classmethod
+    def pack_deltas16(cls, group, peer, match) -> np.ndarray:
+        """AoS array layout-identical to raftq_delta16_t[] (handles of at most 2^32 groups)."""
+        a = np.zeros(len(group), dtype=cls._DELTA16_DT)
+        a["group"], a["match"], a["peer"] = group, match, peer
+        return a
+
+    def stage_packed(self, n_deltas: int, n_vote_deltas: int = 0):
+        """raftq_stage_packed: pinned staging for 16-byte match deltas (+ vote deltas)."""
+        pd, pv = C.c_void_p(None), C.c_void_p(None)
+        self._chk(self._lib.raftq_stage_packed(self._h, n_deltas, n_vote_deltas, C.byref(pd), C.byref(pv)))
+
+        def view(ptr, n, dt):
+            if n == 0:
+                return np.empty(0, dtype=dt)
+            buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dt, count=n)
+
+        return view(pd, n_deltas, self._DELTA16_DT), view(pv, n_vote_deltas, self._VDELTA_DT)
+
+    def last_advances_packed(self) -> np.ndarray:
+        p, n = C.c_void_p(None), C.c_uint64(0)
+        self._chk(self._lib.raftq_last_advances_packed(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.empty(0, dtype=self._ADV16_DT)
+        buf = (C.c_char * (n.value * self._ADV16_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=self._ADV16_DT, count=n.value)
+
+    def cycle_packed(self, flags: int, deltas: Optional[np.ndarray] = None, vote_deltas: Optional[np.ndarray] = None,
+                     cap: Optional[int] = None, inplace: bool = False, want_counts: bool = True):
+        """raftq_cycle_packed.  -> (advances [raftq_advance16_t] | None when inplace, n_advanced_total, SweepCounts | None)"""
+        nd = 0 if deltas is None else len(deltas)
+        nv = 0 if vote_deltas is None else len(vote_deltas)
+        if nd:
+            assert deltas.dtype == self._DELTA16_DT and deltas.flags.c_contiguous
+        if nv:
+            assert vote_deltas.dtype == self._VDELTA_DT and vote_deltas.flags.c_contiguous
+        cap = (self.n_groups if cap is None else int(cap))
+        out = None if inplace else np.empty(cap, dtype=self._ADV16_DT)
+        n = C.c_uint64(0)
+        c = Counts()
+        self._chk(self._lib.raftq_cycle_packed(
+            self._h, _ptr(deltas) if nd else None, nd, _ptr(vote_deltas) if nv else None, nv, flags,
+            _ptr(out) if (out is not None and cap) else None, cap, C.byref(n), C.byref(c) if want_counts else None))
+        total = int(n.value)
+        cnt = SweepCounts(int(c.n_changed), int(c.n_won), int(c.n_lost)) if want_counts else None
+        return (None if inplace else out[: min(total, cap)]), total, cnt
+
     @classmethod
     def pack_deltas(cls, group, peer, match) -> np.ndarray:
         """AoS array layout-identical to raftq_delta_t[] (build once, reuse)."""
@@ -343,6 +394,14 @@ class QuorumEngine:
         out = np.empty(cap, dtype=np.uint64)
         n = C.c_uint64(0)
         self._chk(self._lib.raftq_collect_hups(self._h, _ptr(out) if cap else None, cap, C.byref(n)))
+        return out[: min(cap, int(n.value))], int(n.value)
+
+    def collect_beats(self, cap: Optional[int] = None):
+        """-> (ascending leader groups the last tick sent MsgBeat to, their count)"""
+        cap = self.n_groups if cap is None else int(cap)
+        out = np.empty(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._chk(self._lib.raftq_collect_beats(self._h, _ptr(out) if cap else None, cap, C.byref(n)))
         return out[: min(cap, int(n.value))], int(n.value)
 
     def campaign(self, groups, self_peer: int = 0) -> None:

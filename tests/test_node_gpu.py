@@ -178,6 +178,52 @@ def test_partitioned_leader_cannot_commit_and_rejoins(Cluster):
         c.close()
 
 
+def test_restart_with_an_uncommitted_tail_that_gets_overwritten(Cluster):
+    """A node restarts with logged-but-uncommitted entries: replayWAL publishes them all (raft.go:122-134).  When
+    the new leader overwrites that tail, the REPLACEMENT entries at the same indices must still reach the commit
+    channel once they commit (`applied` stayed beyond the truncation point and they were lost)."""
+    c = Cluster(2, 5, seed=11)
+    try:
+        c.start()
+        elect(c)
+        g = 1
+        old = int(c.leaders()[g])
+        c.nodes[old].propose(g, b"a")
+        c.settle()
+        for q in range(5):
+            if q != old:
+                c.cut.add((old, q))
+        c.nodes[old].propose(g, b"lost1")  # two entries that reach nobody
+        c.nodes[old].propose(g, b"lost2")
+        c.run(2)
+        st = c.nodes[old].status(g)
+        assert st.commit == st.last_index - 2
+        logs = c.stop(old)
+        assert [d for _, d in logs[g] if d] == [b"a", b"lost1", b"lost2"]
+        for _ in range(80):
+            c.step()
+            l2 = [p for p in range(5) if p != old and c.nodes[p].status(g).role == 2]
+            if l2:
+                break
+        assert l2, "majority side elected no leader"
+        new = l2[0]
+        c.nodes[new].propose(g, b"b")  # lands on an index the old leader filled with lost1 / lost2
+        c.settle()
+        c.nodes[new].propose(g, b"c")
+        c.settle()
+        assert c.nodes[new].status(g).last_index == st.last_index + 1  # noop(t2), b, c over lost1, lost2
+        c.cut.clear()
+        nd = c.restart(old, logs, restore_hard_state=True)
+        assert nd.drain(g) == [b"a", b"lost1", b"lost2", None]  # the replay, exactly as the reference does it
+        c.run(8)
+        c.settle()
+        assert nd.drain(g) == [b"b", b"c"], "replacement entries below the replay cursor were not published"
+        assert [d for _, d in nd.log(g) if d] == [b"a", b"b", b"c"]
+        check_safety(c)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("seed,from_wal", [(1, False), (2, False), (3, False), (4, True), (5, True)])
 def test_chaos_safety_and_convergence(Cluster, seed, from_wal):
     """Random message loss, partitions, stops and restarts (WAL + HardState restored; from_wal: from the

@@ -395,6 +395,123 @@ def test_cycle_zero_copy_staging(gpu_engine_cls, oracle):
         assert np.array_equal(e.read_match(), ref_match)
 
 
+def test_cycle_packed_records_equal_the_24_byte_form(gpu_engine_cls, oracle):
+    """raftq_cycle_packed (16-byte deltas in, 16-byte advances out) is raftq_cycle with fewer bytes on the bus:
+    two handles fed the same traffic in the two layouts agree on every word, turn by turn, and with the oracle."""
+    rng = np.random.default_rng(41)
+    n, G = 5, 70001
+    st = _state(G, n, 6400, adversarial=False)
+    with gpu_engine_cls(G, n) as a, gpu_engine_cls(G, n) as b:
+        for e in (a, b):
+            e.load_state(st)
+        ref_match, ref_commit = st.match.copy(), st.committed.copy()
+        for turn in range(4):
+            nd, nv = 30000 + turn, 2000
+            dg = rng.integers(0, G, nd).astype(np.uint64)
+            dp = rng.integers(0, n, nd).astype(np.uint32)
+            dm = (ref_commit[dg.astype(np.int64)] + rng.integers(0, 3000, nd).astype(np.uint64)).astype(np.uint64)
+            vd = a.pack_vote_deltas(rng.integers(0, G, nv).astype(np.uint64), rng.integers(0, n, nv).astype(np.uint32),
+                                    rng.integers(1, 3, nv).astype(np.uint8))
+            gated = turn == 1  # the last turns are ungated, so that nothing is left pending for the tail of the test
+            flags = SWEEP_COMMIT | SWEEP_VOTES | (SWEEP_GATED if gated else 0)
+            adv24, tot24, c24 = a.cycle(flags, a.pack_deltas(dg, dp, dm), vd)
+            if turn < 2:
+                adv16, tot16, c16 = b.cycle_packed(flags, b.pack_deltas16(dg, dp, dm), vd)
+            else:  # zero-copy form: staged in place, list read in place
+                d, v = b.stage_packed(nd, nv)
+                d[:] = b.pack_deltas16(dg, dp, dm)
+                v[:] = vd
+                _, tot16, c16 = b.cycle_packed(flags, d, v, cap=G, inplace=True)
+                adv16 = b.last_advances_packed().copy()
+                with pytest.raises(Exception):
+                    b.last_advances()  # the list is in the packed layout: the 24-byte accessor refuses it
+            ref_match = oracle.apply_deltas(ref_match, dg, dp, dm)
+            new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit, gated, st.first_idx_cur_term)
+            assert tot24 == tot16 == n_ch and c24 == c16
+            assert np.array_equal(adv16["group"].astype(np.uint64), adv24["group"])
+            assert np.array_equal(adv16["new_commit"], adv24["new_commit"])
+            assert np.array_equal(adv16["new_commit"] - adv16["advanced_by"].astype(np.uint64), adv24["old_commit"])
+            assert np.array_equal(a.read_committed(), new_commit) and np.array_equal(b.read_committed(), new_commit)
+            assert np.array_equal(a.read_match(), b.read_match()) and np.array_equal(a.read_votes(), b.read_votes())
+            ref_commit = new_commit
+        # an advance of 2^32 or more saturates advanced_by (old_commit is then not recoverable from the record)
+        g0 = np.zeros(1, dtype=np.uint64)
+        for p in range(n):
+            b.apply_deltas(g0, np.full(1, p, np.uint32), ref_commit[:1] + np.uint64(1 << 33))
+        adv, tot, _ = b.cycle_packed(SWEEP_COMMIT)
+        assert tot == 1 and adv["group"][0] == 0 and adv["advanced_by"][0] == 0xFFFFFFFF
+        assert adv["new_commit"][0] == ref_commit[0] + np.uint64(1 << 33)
+
+
+def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
+    """One bad record of EITHER kind and the turn applies nothing of either kind, adopts nothing and says so
+    (a bad vote batch used to let the match deltas through and the sweep's advances were adopted but
+    reported as zero).  The next good turn then reports every advance, including the ones pending before."""
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(43)
+    n, G = 3, 30000
+    st = _state(G, n, 6500, adversarial=False)
+    with gpu_engine_cls(G, n) as e:
+        e.load_state(st)
+        ref_match, ref_commit, ref_votes = st.match.copy(), st.committed.copy(), st.votes.copy()
+        pending = oracle.commit_advance(ref_match, ref_commit)[1]
+        assert pending > 0  # the loaded state already holds advances no sweep has adopted yet
+        dg = rng.integers(0, G, 5000).astype(np.uint64)
+        dp = rng.integers(0, n, 5000).astype(np.uint32)
+        dm = ref_commit[dg.astype(np.int64)] + rng.integers(1, 1000, 5000).astype(np.uint64)
+        good_d = e.pack_deltas(dg, dp, dm)
+        vg = rng.integers(0, G, 800).astype(np.uint64)
+        good_v = e.pack_vote_deltas(vg, rng.integers(0, n, 800).astype(np.uint32), rng.integers(1, 3, 800).astype(np.uint8))
+        bad_v = good_v.copy()
+        bad_v["vote"][400] = 3
+        bad_d = good_d.copy()
+        bad_d["peer"][123] = n
+        for d, v in ((good_d, bad_v), (bad_d, good_v), (bad_d, bad_v)):
+            with pytest.raises(RaftqError) as ei:
+                e.cycle(SWEEP_COMMIT | SWEEP_VOTES, d, v)
+            assert ei.value.code == -1
+            assert np.array_equal(e.read_match(), ref_match) and np.array_equal(e.read_votes(), ref_votes)
+            assert np.array_equal(e.read_committed(), ref_commit), "a refused turn must not adopt the sweep it ran"
+        with pytest.raises(RaftqError):
+            e.cycle_packed(SWEEP_COMMIT | SWEEP_VOTES, e.pack_deltas16(dg, np.full(5000, n, np.uint32), dm), good_v)
+        assert np.array_equal(e.read_committed(), ref_commit) and np.array_equal(e.read_match(), ref_match)
+        # the good turn: everything applied, and every advance (pending ones included) is listed
+        adv, total, cnt = e.cycle(SWEEP_COMMIT | SWEEP_VOTES, good_d, good_v)
+        ref_match = oracle.apply_deltas(ref_match, dg, dp, dm)
+        ref_votes = oracle.apply_vote_deltas(ref_votes, good_v["group"].copy(), good_v["peer"].copy(), good_v["vote"].copy())
+        new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+        idx = np.nonzero(new_commit != ref_commit)[0]
+        assert total == n_ch == len(idx) >= pending and np.array_equal(adv["group"], idx.astype(np.uint64))
+        assert np.array_equal(adv["old_commit"], ref_commit[idx]) and np.array_equal(adv["new_commit"], new_commit[idx])
+        assert np.array_equal(e.read_votes(), ref_votes) and np.array_equal(e.read_committed(), new_commit)
+        # RAFTQ_CYCLE_TRUSTED: one pass, a bad record is dropped on its own, the turn still happens and says EINVAL
+        from raftsql_amd._lib import CYCLE_TRUSTED
+        ref_commit = new_commit
+        dm2 = ref_commit[dg.astype(np.int64)] + rng.integers(1, 1000, 5000).astype(np.uint64)
+        d2 = e.pack_deltas(dg, dp, dm2)
+        d2["group"][77] = G + 5
+        keep = np.arange(5000) != 77
+        with pytest.raises(RaftqError) as ei:
+            e.cycle(SWEEP_COMMIT | CYCLE_TRUSTED, d2, None)
+        assert ei.value.code == -1
+        ref_match = oracle.apply_deltas(ref_match, dg[keep], dp[keep], dm2[keep])
+        new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+        assert np.array_equal(e.read_match(), ref_match) and np.array_equal(e.read_committed(), new_commit)
+        adv = e.last_advances()
+        idx = np.nonzero(new_commit != ref_commit)[0]
+        assert np.array_equal(adv["group"], idx.astype(np.uint64)) and np.array_equal(adv["new_commit"], new_commit[idx])
+        # and a clean trusted turn in the packed layout equals the oracle
+        ref_commit = new_commit
+        dm3 = ref_commit[dg.astype(np.int64)] + rng.integers(1, 1000, 5000).astype(np.uint64)
+        adv, total, _ = e.cycle_packed(SWEEP_COMMIT | CYCLE_TRUSTED, e.pack_deltas16(dg, dp, dm3), None)
+        ref_match = oracle.apply_deltas(ref_match, dg, dp, dm3)
+        new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+        idx = np.nonzero(new_commit != ref_commit)[0]
+        assert total == n_ch and np.array_equal(adv["group"].astype(np.uint64), idx.astype(np.uint64))
+        assert np.array_equal(adv["new_commit"], new_commit[idx]) and np.array_equal(e.read_committed(), new_commit)
+
+
 def test_timer_and_stream(gpu_engine_cls):
     import torch
 
@@ -431,8 +548,12 @@ def test_tick_parity(gpu_engine_cls, oracle, G):
                 assert np.array_equal(got_role, role)
                 hups, n = e.collect_hups()
                 assert n == rh and np.array_equal(hups, np.nonzero(ref_act == 1)[0].astype(np.uint64))
+                beats, nb = e.collect_beats()
+                assert nb == rb and np.array_equal(beats, np.nonzero(ref_act == 2)[0].astype(np.uint64))
             hups2, n2 = e.collect_hups(cap=2)
             assert n2 == rh and len(hups2) == min(2, rh)
+            beats2, nb2 = e.collect_beats(cap=3)
+            assert nb2 == rb and np.array_equal(beats2, np.nonzero(ref_act == 2)[0][:3].astype(np.uint64))
 
 
 def test_election_round_trip(gpu_engine_cls, oracle):

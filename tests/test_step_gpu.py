@@ -52,6 +52,38 @@ def test_step_parity_hot_groups(NodeEngine, oracle, N, self_peer):
             _stepgen.assert_same_state(e, s)
 
 
+def test_log_deltas_with_one_hot_group(NodeEngine, oracle):
+    """One group reporting its tail thousands of times in a batch (a leader appending in a tight loop) among
+    ordinary traffic: records of a group apply in order, the result is the oracle's, and the host side
+    buckets the rounds in one pass (it used to rescan the batch once per repeat)."""
+    import time
+
+    rng = np.random.default_rng(99)
+    G, N = 3000, 3
+    s = _stepgen.random_state(rng, G, N, 0)
+    with NodeEngine(G, N, self_peer=0) as e:
+        _stepgen.load_engine(e, s)
+        n_hot, n_cold = 5000, 4000
+        g = np.concatenate([np.full(n_hot, 17), rng.integers(0, G, n_cold)]).astype(np.uint64)
+        p = rng.permutation(len(g))
+        g = g[p]
+        # k-th report of a group raises its tail by k
+        order = np.argsort(g, kind="stable")
+        ranks = np.empty(len(g), dtype=np.int64)
+        gs = g[order]
+        start = np.concatenate([[0], np.nonzero(gs[1:] != gs[:-1])[0] + 1])
+        ranks[order] = np.arange(len(g)) - np.repeat(start, np.diff(np.concatenate([start, [len(g)]])))
+        li = s.last_index[g] + ranks.astype(np.uint64)
+        lt = np.maximum(s.last_term[g], s.term[g] * (s.role[g] == 2))
+        ct = np.where(rng.random(len(g)) < 0.5, 0, s.committed[g] + rng.integers(0, 3, len(g)).astype(np.uint64))
+        t0 = time.perf_counter()
+        got = e.apply_log_deltas(g, li, lt, ct)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got, s.apply_log_deltas(g, li, lt, ct))
+        _stepgen.assert_same_state(e, s)
+        assert dt < 20.0, dt  # 5,000 rounds = 5,000 small launches, but no longer 5,000 passes over the batch
+
+
 def test_step_then_dense_sweep_agree(NodeEngine, oracle):
     """After Step has moved match / first_idx, the dense gated sweep and the in-lane
     maybeCommit are the same function: a sweep right after a batch advances nothing."""

@@ -57,10 +57,12 @@ CONFIGS = {
 }
 
 
-def bytes_per_decision(cfg) -> tuple[int, int]:
-    """(read, write) algorithmic bytes per group -- DESIGN.md 'bytes per decision'."""
-    rd = 8 * cfg["N"] + 8 + (8 if cfg["gated"] else 0) + (cfg["N"] if cfg["votes"] else 0)
-    wr = 8 + (1 if cfg["votes"] else 0)
+def bytes_per_decision(cfg) -> tuple[float, float]:
+    """(read, write) algorithmic bytes per group -- DESIGN.md 'bytes per decision'.  The RequestVote state is one
+    packed word per group (2 bits per peer: 2 B for N <= 8, 4 B for N = 9) and the outcome 2 bits (0.25 B)."""
+    vote_rd = (2 if cfg["N"] <= 8 else 4) if cfg["votes"] else 0
+    rd = 8 * cfg["N"] + 8 + (8 if cfg["gated"] else 0) + vote_rd
+    wr = 8 + (0.25 if cfg["votes"] else 0)
     return rd, wr
 
 
@@ -716,7 +718,7 @@ def main():
             "batches_per_gpu": n_batches,
             "groups_per_gpu": groups_per_gpu,
             "distinct_batches": distinct,
-            "resident_bytes_per_gpu": n_batches * batch_bytes,
+            "resident_bytes_per_gpu": int(n_batches * batch_bytes),
             "launches_per_step": 1,
             "dispatch": args.mode,
             "cache_policy": args.policy,
@@ -733,7 +735,7 @@ def main():
             "kernel": kname,
             "launch_us": launch_us,
             "per_batch_us": launch_us / n_batches,
-            "bytes_per_launch": bytes_per_launch,
+            "bytes_per_launch": bytes_per_launch,  # algorithmic: (read + write) B per decision x groups per dispatch
             "bytes_per_decision": {"read": rd, "write": wr},
             "achieved_read_GBps": rd * groups_per_gpu / (launch_us * 1e-6) / 1e9,
             "frac_read_of_peak": rd * groups_per_gpu / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,

@@ -194,6 +194,30 @@ using raftq_detail::use_device;
 using raftq_detail::use_device_idle;
 using raftq_detail::ensure_tick_state;
 
+// host <-> device form of the RequestVote state.  The ABI speaks one byte per (peer, group); the device keeps one
+// word per group, 2 bits per peer.  Bytes other than 1 / 2 are "no response" (include/raftq.h) and load as 00.
+template <typename W>
+static void pack_votes(const uint8_t* votes, uint64_t G, uint32_t N, W* out) {
+  for (uint64_t g = 0; g < G; ++g) out[g] = 0;
+  for (uint32_t p = 0; p < N; ++p) {
+    const uint8_t* row = votes + (size_t)p * G;
+    for (uint64_t g = 0; g < G; ++g) {
+      const uint8_t v = row[g];
+      out[g] = (W)(out[g] | (W)((v == 1 ? 1u : v == 2 ? 2u : 0u) << (2 * p)));
+    }
+  }
+}
+template <typename W>
+static void unpack_votes(const W* in, uint64_t G, uint32_t N, uint8_t* votes) {
+  for (uint32_t p = 0; p < N; ++p) {
+    uint8_t* row = votes + (size_t)p * G;
+    for (uint64_t g = 0; g < G; ++g) {
+      const uint32_t f = ((uint32_t)in[g] >> (2 * p)) & 3u;
+      row[g] = f == 3u ? 0 : (uint8_t)f;
+    }
+  }
+}
+
 extern "C" {
 
 int raftq_abi_version(void) { return RAFTQ_ABI_VERSION; }
@@ -255,8 +279,9 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     if ((rc = alloc((void**)&h->committed[0], ld * 8))) break;
     if ((rc = alloc((void**)&h->committed[1], ld * 8))) break;
     if ((rc = alloc((void**)&h->first_idx, ld * 8))) break;
-    if ((rc = alloc((void**)&h->votes, (size_t)n_peers * ld))) break;
-    if ((rc = alloc((void**)&h->outcome, ld))) break;
+    // RequestVote state: one packed word per group (2 bits per peer), outcomes 2 bits per group
+    if ((rc = alloc((void**)&h->votes, (size_t)vote_word_bytes((int)n_peers) * ld))) break;
+    if ((rc = alloc((void**)&h->outcome, ld / 4 + 64))) break;
     if ((rc = alloc((void**)&h->changed_bits, h->gpad / 8))) break;
     if ((rc = alloc((void**)&h->partials, h->max_partials * sizeof(uint4)))) break;
     if ((rc = alloc((void**)&h->offsets, (h->max_partials + 1) * 8))) break;
@@ -378,7 +403,16 @@ int raftq_load_terms(raftq_t* h, const uint64_t* cur_term, const uint64_t* first
 int raftq_load_votes(raftq_t* h, const uint8_t* votes) {
   if (int rc = use_device_idle(h, "raftq_load_votes")) return rc;
   if (!votes) return fail(h, RAFTQ_EINVAL, "raftq_load_votes: null argument");
-  HIPCHK(h, hipMemcpy2DAsync(h->votes, h->ld, votes, h->G, h->G, h->N, hipMemcpyHostToDevice, h->stream));
+  const size_t wb = (size_t)vote_word_bytes((int)h->N);
+  std::vector<uint8_t> packed;
+  try {
+    packed.resize(h->G * wb);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_load_votes: host allocation failed");
+  }
+  if (wb == 2) pack_votes(votes, h->G, h->N, reinterpret_cast<uint16_t*>(packed.data()));
+  else pack_votes(votes, h->G, h->N, reinterpret_cast<uint32_t*>(packed.data()));
+  HIPCHK(h, hipMemcpyAsync(h->votes, packed.data(), packed.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
 }
@@ -465,8 +499,8 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   if (nv) {
     hipLaunchKernelGGL(vote_claim_kernel, gv, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv, bad, em,
                        ev);
-    hipLaunchKernelGGL(vote_apply_kernel, gv, dim3(kBlock), 0, h->stream, h->votes, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv,
-                       bad, em, ev);
+    hipLaunchKernelGGL(vote_apply_kernel, gv, dim3(kBlock), 0, h->stream, h->votes, h->N > 8 ? 1 : 0, h->claim, h->ld,
+                       (const VoteDeltaRec*)dev_v, nv, bad, em, ev);
   }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
@@ -556,7 +590,7 @@ static SweepArgs sweep_args(const raftq_t* h, int cur, bool want_bits) {
   return a;
 }
 
-static uint64_t sweep_footprint(const raftq_t* h) { return h->ld * (8ull * h->N + 24 + h->N + 1); }
+static uint64_t sweep_footprint(const raftq_t* h) { return h->ld * (8ull * h->N + 24 + vote_word_bytes((int)h->N) + 1); }
 
 // Streaming policy (profiles/r01/tune_policy_ld_vs_ldst.txt): loads always non-temporal; stores too only
 // once the state outgrows ~128 MiB (2M x 7: -1.7 % with NT stores; 1M x 3/5/9: +1-2 % without them,
@@ -637,8 +671,15 @@ int raftq_read_committed(raftq_t* h, uint64_t* out) {
 int raftq_read_outcome(raftq_t* h, uint8_t* out) {
   if (int rc = use_device_idle(h, "raftq_read_outcome")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_outcome: null argument");
-  HIPCHK(h, hipMemcpyAsync(out, h->outcome, h->G, hipMemcpyDeviceToHost, h->stream));
+  std::vector<uint8_t> packed;
+  try {
+    packed.resize((h->G + 3) / 4);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_read_outcome: host allocation failed");
+  }
+  HIPCHK(h, hipMemcpyAsync(packed.data(), h->outcome, packed.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (uint64_t g = 0; g < h->G; ++g) out[g] = (uint8_t)((packed[g >> 2] >> (2 * (g & 3))) & 3u);  // 2 bits per group
   return RAFTQ_OK;
 }
 
@@ -653,8 +694,17 @@ int raftq_read_match(raftq_t* h, uint64_t* out) {
 int raftq_read_votes(raftq_t* h, uint8_t* out) {
   if (int rc = use_device_idle(h, "raftq_read_votes")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_votes: null argument");
-  HIPCHK(h, hipMemcpy2DAsync(out, h->G, h->votes, h->ld, h->G, h->N, hipMemcpyDeviceToHost, h->stream));
+  const size_t wb = (size_t)vote_word_bytes((int)h->N);
+  std::vector<uint8_t> packed;
+  try {
+    packed.resize(h->G * wb);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_read_votes: host allocation failed");
+  }
+  HIPCHK(h, hipMemcpyAsync(packed.data(), h->votes, packed.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (wb == 2) unpack_votes(reinterpret_cast<const uint16_t*>(packed.data()), h->G, h->N, out);
+  else unpack_votes(reinterpret_cast<const uint32_t*>(packed.data()), h->G, h->N, out);
   return RAFTQ_OK;
 }
 
@@ -808,7 +858,7 @@ int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self
   if (int rc = ensure_staging(h, (size_t)n * 8)) return rc;
   std::memcpy(h->stage_h, groups, n * 8);
   hipLaunchKernelGGL(campaign_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                     h->role, h->elapsed, h->votes, h->ld, h->N, self_peer, (const uint64_t*)h->stage_d, n);
+                     h->role, h->elapsed, h->votes, h->N, self_peer, (const uint64_t*)h->stage_d, n);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
@@ -1301,7 +1351,8 @@ int raftq_clone_state(raftq_t* dst, raftq_t* src) {
   HIPCHK(dst, hipMemcpyAsync(dst->match, src->match, (size_t)dst->N * ld * 8, hipMemcpyDeviceToDevice, dst->stream));
   HIPCHK(dst, hipMemcpyAsync(dst->committed[dst->cur], src->committed[src->cur], ld * 8, hipMemcpyDeviceToDevice, dst->stream));
   HIPCHK(dst, hipMemcpyAsync(dst->first_idx, src->first_idx, ld * 8, hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(dst, hipMemcpyAsync(dst->votes, src->votes, (size_t)dst->N * ld, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->votes, src->votes, (size_t)vote_word_bytes((int)dst->N) * ld, hipMemcpyDeviceToDevice,
+                             dst->stream));
   HIPCHK(dst, hipStreamSynchronize(dst->stream));
   dst->have_terms = src->have_terms;
   return RAFTQ_OK;

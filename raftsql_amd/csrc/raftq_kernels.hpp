@@ -1,6 +1,6 @@
 // raftq_kernels.hpp -- CDNA4 (gfx950) device code of the batched multi-raft
 // quorum sweep.  Hand-written HIP, wave64, no MFMA: the path is integer
-// selection over uint64 log indices and byte compares over votes, bound by
+// selection over uint64 log indices and bit counts over packed votes, bound by
 // HBM bandwidth (DESIGN.md "Kernels").
 //
 // What it computes, per raft group g (restating etcd/raft, the dependency the
@@ -11,7 +11,11 @@
 //
 // HBM layout (peer-major SoA, every row padded to `ld` groups, ld % 2048 == 0,
 // padding zero-filled so a full tile is always safe to process):
-//   match[p*ld + g] u64 | committed[g] u64 | first_idx[g] u64 | votes[p*ld + g] u8
+//   match[p*ld + g] u64 | committed[g] u64 | first_idx[g] u64
+//   votes[g]: ONE word per group, 2 bits per peer (peer p = bits 2p, 2p+1: 00 no response, 01 granted,
+//             10 rejected); 16-bit words for N <= 8, 32-bit for N = 9 | outcome: 2 bits per group
+//   (round 1 kept N byte rows and a byte of outcome: 5 + 1 B per decision at N = 5 instead of 2 + 0.25,
+//    and N more row streams per wave -- measured 10.07 vs 10.79 us per 1M x 5 batch, profiles/r02)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,8 +34,8 @@ struct SweepArgs {
   const uint64_t* committed;   // [ld]   current commit index
   uint64_t* committed_out;     // [ld]   shadow buffer (may alias committed)
   const uint64_t* first_idx;   // [ld]   first index of cur_term, 0 = none
-  const uint8_t* votes;        // [N][ld]
-  uint8_t* outcome;            // [ld]
+  const uint8_t* votes;        // [ld] packed vote words (vote_word_bytes(N) each)
+  uint8_t* outcome;            // [ld / 4] 2 bits per group
   uint64_t* changed_bits;      // [ld/64] lane-ordered bitmap, or nullptr
   uint4* partials;             // [ld/kTile * kWaves] {changed, won, lost, 0}
   uint64_t ld;
@@ -116,6 +120,24 @@ __device__ __forceinline__ uint64_t bytes_equal(uint64_t v, uint64_t pattern) {
   return y >> 7;
 }
 
+// ---------------------------------------------------------------------------
+// Packed RequestVote state: one word per group, 2 bits per peer.
+__host__ __device__ constexpr int vote_word_bytes(int n_peers) { return n_peers <= 8 ? 2 : 4; }
+typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+
+// raft.poll over one group's word -> 2-bit outcome (0 pending, 1 won, 2 lost).  A field of 11 is never
+// stored (loads canonicalise, ingest writes 01 / 10 only); it would count as "no response" here all the same.
+template <int N>
+__device__ __forceinline__ uint32_t poll_word(uint32_t w) {
+  constexpr uint32_t kLow = 0x55555555u & ((N >= 16) ? 0xffffffffu : ((1u << (2 * N)) - 1u));
+  constexpr uint32_t q = N / 2 + 1;
+  const uint32_t granted = __popc(w & ~(w >> 1) & kLow);
+  const uint32_t rejected = __popc((w >> 1) & ~w & kLow);
+  const uint32_t won = granted >= q ? 1u : 0u;
+  const uint32_t lost = (won == 0u && rejected >= q) ? 2u : 0u;
+  return won | lost;
+}
+
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
   return __builtin_nontemporal_load(p);
@@ -140,6 +162,23 @@ __device__ __forceinline__ void stg(T* p, T v) {
   RAFTQ_GLOBAL T* g = (RAFTQ_GLOBAL T*)p;
   if constexpr (NT) __builtin_nontemporal_store(v, g);
   else *g = v;
+}
+// a bulk store with explicit gfx950 cache-policy bits (tuner only; the product uses stg<>)
+template <int MOD, typename T>
+__device__ __forceinline__ void st_mod(T* p, T v) {
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8, "dwordx4 / dwordx2 stores only");
+#define RAFTQ_ST(suffix)                                                                                  \
+  if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off" suffix ::"v"(p), "v"(v) : "memory"); \
+  else asm volatile("global_store_dwordx2 %0, %1, off" suffix ::"v"(p), "v"(v) : "memory")
+  if constexpr (MOD == 1) { RAFTQ_ST(" nt"); }
+  else if constexpr (MOD == 2) { RAFTQ_ST(" sc1"); }
+  else if constexpr (MOD == 3) { RAFTQ_ST(" sc0 sc1"); }
+  else if constexpr (MOD == 4) { RAFTQ_ST(" sc1 nt"); }
+  else if constexpr (MOD == 5) { RAFTQ_ST(" sc0 sc1 nt"); }
+  else if constexpr (MOD == 6) { RAFTQ_ST(" sc0"); }
+  else if constexpr (MOD == 7) { RAFTQ_ST(" sc0 nt"); }
+  else { RAFTQ_ST(""); }
+#undef RAFTQ_ST
 }
 // uint4 is a class type in HIP (no assignment through an address-space-qualified pointer): store it as a native vector
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -171,6 +210,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 // POLICY bits: kLdNT (non-temporal loads), kStNT (non-temporal stores); kNoStore
 // is a measurement-only ablation (tuner) that drops the output stores.
 constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
+// bits 4-6 (measurement only, raftq_tune3): the cache-policy bits of the two bulk stores spelled out per
+// instruction -- 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1, 6 sc0, 7 nt sc0 (0: as kStNT says)
+constexpr int kStModShift = 4;
 
 // A tile's inputs in registers: filled by tile_load (every load issued, nothing waited for), consumed by
 // tile_finish.  Split so that a persistent kernel can have the next tile's loads in flight while it finishes
@@ -181,7 +223,7 @@ struct TileRegs {
   u64x2 m[COMMIT ? kRounds : 1][N];
   u64x2 c[COMMIT ? kRounds : 1];
   u64x2 f[COMMIT && GATED ? kRounds : 1];
-  uint64_t vv[VOTES ? N : 1];
+  u32x4p vw[VOTES ? (N <= 8 ? 1 : 2) : 1];  // the 8 vote words of the lane's 8 groups
 };
 
 template <int N, int GPL, bool COMMIT, bool GATED, bool VOTES, int POLICY, int BLOCK = kBlock>
@@ -192,15 +234,13 @@ __device__ __forceinline__ void tile_load(TileRegs<N, GPL, COMMIT, GATED, VOTES>
   constexpr int kRounds = GPL / 2;
   const uint32_t tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)tile * kTile;
-  // vote rows first: their loads fly while the commit part computes
+  // vote words first: their loads fly while the commit part computes
   constexpr int kVoteLanes = kTile / 8;  // lanes that own 8 groups each
   if constexpr (VOTES) {
     if (tid < kVoteLanes) {  // wave-uniform (kVoteLanes % 64 == 0)
-      const uint64_t g = tile0 + 8ull * tid;
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        r.vv[p] = ldg<NT>(reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g));
-      }
+      const uint8_t* src = a.votes + (tile0 + 8ull * tid) * vote_word_bytes(N);  // 16 B (N <= 8) or 32 B of words
+      r.vw[0] = ldg<NT>(reinterpret_cast<const u32x4p*>(src));
+      if constexpr (N > 8) r.vw[1] = ldg<NT>(reinterpret_cast<const u32x4p*>(src + 16));
     }
   }
   if constexpr (COMMIT) {
@@ -222,6 +262,7 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
                                             const uint32_t tile) {
   constexpr bool STNT = (POLICY & kStNT) != 0;
   constexpr bool NOSTORE = (POLICY & kNoStore) != 0;
+  constexpr int STMOD = (POLICY >> kStModShift) & 7;
   constexpr int kTile = BLOCK * GPL;
   constexpr int kWavesB = BLOCK / 64;
   constexpr int kRounds = GPL / 2;
@@ -274,7 +315,8 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
       if constexpr (NOSTORE) {
         asm volatile("" ::"v"(o.x), "v"(o.y));
       } else {
-        stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
+        if constexpr (STMOD != 0) st_mod<STMOD>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
+        else stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
       }
     }
   }
@@ -282,24 +324,29 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
   if constexpr (VOTES) {
     if (vote_lane) {
       const uint64_t g = tile0 + 8ull * tid;
-      uint64_t granted = 0, rejected = 0;  // per-byte counters, <= N <= 9
+      uint32_t out = 0, n_won = 0, n_lost = 0;
 #pragma unroll
-      for (int p = 0; p < N; ++p) {
-        granted += bytes_equal(r.vv[p], 0x0101010101010101ull);
-        rejected += bytes_equal(r.vv[p], 0x0202020202020202ull);
+      for (int k = 0; k < 8; ++k) {
+        uint32_t w;
+        if constexpr (N <= 8) {
+          const uint32_t pair = k < 2 ? r.vw[0].x : k < 4 ? r.vw[0].y : k < 6 ? r.vw[0].z : r.vw[0].w;
+          w = (k & 1) ? pair >> 16 : pair & 0xffffu;
+        } else {
+          w = k == 0 ? r.vw[0].x : k == 1 ? r.vw[0].y : k == 2 ? r.vw[0].z : k == 3 ? r.vw[0].w
+            : k == 4 ? r.vw[1].x : k == 5 ? r.vw[1].y : k == 6 ? r.vw[1].z : r.vw[1].w;
+        }
+        const uint32_t oc = poll_word<N>(w);
+        out |= oc << (2 * k);
+        n_won += oc & 1u;
+        n_lost += oc >> 1;
       }
-      constexpr uint64_t q = N / 2 + 1;
-      constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
-      const uint64_t k80 = 0x8080808080808080ull;
-      const uint64_t won = ((granted + bias) & k80) >> 7;    // 0x01 where granted >= q
-      const uint64_t lost = ((rejected + bias) & k80) >> 7;  // exclusive with won (g+r <= N < 2q)
-      const uint64_t out = won | ((lost & ~won) << 1);
+      uint16_t* dst = reinterpret_cast<uint16_t*>(a.outcome + (g >> 2));  // 8 groups = 16 bits
       if constexpr (NOSTORE) {
         asm volatile("" ::"v"(out));
       } else {
-        stg<STNT>(reinterpret_cast<uint64_t*>(a.outcome + g), out);
+        stg<STNT>(dst, (uint16_t)out);
       }
-      won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
+      won_lost = n_won | (n_lost << 16);
     }
   }
 
@@ -495,22 +542,30 @@ static __global__ __launch_bounds__(kBlock) void sweep_lds_kernel(SweepArgs a) {
 
   if constexpr (VOTES) {
     constexpr int kVoteLanes = kTile / 8;
-    if (tid < kVoteLanes) {
+    if (tid < kVoteLanes) {  // the vote words are not staged: 2 (4) bytes per group, one 16 (32) byte load per lane
       const uint64_t g = tile0 + 8ull * tid;
-      uint64_t granted = 0, rejected = 0;
+      const uint8_t* src = a.votes + g * vote_word_bytes(N);
+      uint32_t words[8];
+      if constexpr (N <= 8) {
+        const u32x4p v = *reinterpret_cast<const u32x4p*>(src);
+        const uint32_t pr[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.votes + (uint64_t)p * a.ld + g);
-        granted += bytes_equal(v, 0x0101010101010101ull);
-        rejected += bytes_equal(v, 0x0202020202020202ull);
+        for (int k = 0; k < 8; ++k) words[k] = (k & 1) ? pr[k >> 1] >> 16 : pr[k >> 1] & 0xffffu;
+      } else {
+        const u32x4p v0 = *reinterpret_cast<const u32x4p*>(src), v1 = *reinterpret_cast<const u32x4p*>(src + 16);
+        words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+        words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
       }
-      constexpr uint64_t q = N / 2 + 1;
-      constexpr uint64_t bias = (0x80ull - q) * 0x0101010101010101ull;
-      const uint64_t k80 = 0x8080808080808080ull;
-      const uint64_t won = ((granted + bias) & k80) >> 7;
-      const uint64_t lost = ((rejected + bias) & k80) >> 7;
-      *reinterpret_cast<uint64_t*>(a.outcome + g) = won | ((lost & ~won) << 1);
-      won_lost = (uint32_t)__popcll(won) | ((uint32_t)__popcll(lost & ~won) << 16);
+      uint32_t out = 0, n_won = 0, n_lost = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t oc = poll_word<N>(words[k]);
+        out |= oc << (2 * k);
+        n_won += oc & 1u;
+        n_lost += oc >> 1;
+      }
+      *reinterpret_cast<uint16_t*>(a.outcome + (g >> 2)) = (uint16_t)out;
+      won_lost = n_won | (n_lost << 16);
     }
   }
   const uint32_t wl = VOTES ? wave_sum_u32(won_lost) : 0u;
@@ -659,7 +714,7 @@ static __global__ __launch_bounds__(kBlock) void vote_claim_kernel(uint32_t* cla
   atomicMin(claim + (uint64_t)r.peer * ld + r.group, (uint32_t)i);
 }
 
-static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, uint32_t* claim, uint64_t ld,
+static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* votes, int wide, uint32_t* claim, uint64_t ld,
                                                             const VoteDeltaRec* __restrict__ d, uint64_t n,
                                                             const unsigned long long* bad, unsigned long long epoch_match,
                                                             unsigned long long epoch_votes) {
@@ -669,15 +724,16 @@ static __global__ __launch_bounds__(kBlock) void vote_apply_kernel(uint8_t* vote
   const VoteDeltaRec r = d[i];
   const uint64_t slot = (uint64_t)r.peer * ld + r.group;
   if (claim[slot] != (uint32_t)i) return;  // an earlier record of this batch owns the slot
-  // neighbouring slots share a 32-bit word and may be written by other lanes: CAS the byte in
-  unsigned int* word = reinterpret_cast<unsigned int*>(votes + (slot & ~3ull));
-  const unsigned sh = (unsigned)(slot & 3ull) * 8u;
+  // the group's vote word: 2 bits per peer.  Other peers' fields of the same word -- and, with 16-bit words, the
+  // neighbouring group's word -- may be written by other lanes: CAS the field into the enclosing 32-bit word
+  unsigned int* word = reinterpret_cast<unsigned int*>(votes) + (wide ? r.group : r.group >> 1);
+  const unsigned sh = (wide ? 0u : (unsigned)(r.group & 1ull) * 16u) + 2u * r.peer;
   const unsigned nv = (unsigned)r.vote << sh;
   unsigned old = *word;
   while (true) {
-    const unsigned cur = (old >> sh) & 0xffu;
+    const unsigned cur = (old >> sh) & 3u;
     if (cur == 1u || cur == 2u) break;  // answered in an earlier batch
-    const unsigned seen = atomicCAS(word, old, (old & ~(0xffu << sh)) | nv);
+    const unsigned seen = atomicCAS(word, old, (old & ~(3u << sh)) | nv);
     if (seen == old) break;
     old = seen;
   }
@@ -915,16 +971,18 @@ static __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint6
 }
 
 // becomeCandidate for a list of (distinct) groups: role = candidate, elapsed = 0,
-// every vote slot cleared, the candidate's own slot granted.  Byte stores.
+// every vote slot cleared, the candidate's own slot granted: one store of the group's vote word.
 static __global__ __launch_bounds__(kBlock) void campaign_kernel(uint8_t* role, uint32_t* elapsed, uint8_t* votes,
-                                                          uint64_t ld, uint32_t n_peers, uint32_t self_peer,
+                                                          uint32_t n_peers, uint32_t self_peer,
                                                           const uint64_t* __restrict__ groups, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint64_t g = groups[i];
   role[g] = 1;
   elapsed[g] = 0;
-  for (uint32_t p = 0; p < n_peers; ++p) votes[(uint64_t)p * ld + g] = p == self_peer ? 1 : 0;
+  // every slot cleared, the candidate's own granted: the whole vote word in one store
+  if (n_peers <= 8) reinterpret_cast<uint16_t*>(votes)[g] = (uint16_t)(1u << (2 * self_peer));
+  else reinterpret_cast<uint32_t*>(votes)[g] = 1u << (2 * self_peer);
 }
 
 }  // namespace raftqk

@@ -55,7 +55,7 @@ struct NodeArrays {
   uint64_t* committed;
   uint64_t* first_idx;
   uint64_t* match;  // [N][ld]
-  uint8_t* votes;   // [N][ld]
+  uint8_t* votes;   // [ld] packed vote words: 2 bits per peer, 16-bit words (N <= 8) or 32-bit (N = 9)
   uint64_t ld;
   uint32_t n_peers, self;
 };
@@ -128,20 +128,23 @@ struct Node {
   uint64_t g;
   uint64_t term, last_index, last_term, committed, first_idx;
   uint32_t vote, lead, elapsed;
+  uint32_t vw;  // the group's vote word (raft.votes as 2 bits per peer): loaded once, stored once
   uint8_t role;
 
   __device__ Node(const NodeArrays& arr, uint64_t group) : a(arr), g(group) {
     term = a.term[g]; last_index = a.last_index[g]; last_term = a.last_term[g];
     committed = a.committed[g]; first_idx = a.first_idx[g];
     vote = a.vote[g]; lead = a.lead[g]; elapsed = a.elapsed[g]; role = a.role[g];
+    vw = a.n_peers <= 8 ? (uint32_t)reinterpret_cast<const uint16_t*>(a.votes)[g] : reinterpret_cast<const uint32_t*>(a.votes)[g];
   }
   __device__ void store() const {
     a.term[g] = term; a.last_index[g] = last_index; a.last_term[g] = last_term;
     a.committed[g] = committed; a.first_idx[g] = first_idx;
     a.vote[g] = vote; a.lead[g] = lead; a.elapsed[g] = elapsed; a.role[g] = role;
+    if (a.n_peers <= 8) reinterpret_cast<uint16_t*>(a.votes)[g] = (uint16_t)vw;
+    else reinterpret_cast<uint32_t*>(a.votes)[g] = vw;
   }
   __device__ uint64_t& match(uint32_t p) const { return a.match[(uint64_t)p * a.ld + g]; }
-  __device__ uint8_t& votes(uint32_t p) const { return a.votes[(uint64_t)p * a.ld + g]; }
   __device__ uint32_t quorum() const { return a.n_peers / 2 + 1; }
 
   // raft.reset(term)
@@ -149,10 +152,8 @@ struct Node {
     if (term != t) { term = t; vote = 0; }
     lead = 0;
     elapsed = 0;
-    for (uint32_t p = 0; p < a.n_peers; ++p) {
-      votes(p) = 0;
-      match(p) = p == a.self ? last_index : 0;
-    }
+    vw = 0;
+    for (uint32_t p = 0; p < a.n_peers; ++p) match(p) = p == a.self ? last_index : 0;
   }
   __device__ void become_follower(uint64_t t, uint32_t new_lead) {
     reset(t);
@@ -200,14 +201,12 @@ struct Node {
   }
   // raft.poll: the first response of a peer wins; returns {granted, recorded}
   __device__ void poll(uint32_t from, bool granted, uint32_t& n_granted, uint32_t& n_recorded) {
-    const uint8_t cur = votes(from);
-    if (cur != 1 && cur != 2) votes(from) = granted ? 1 : 2;
-    n_granted = n_recorded = 0;
-    for (uint32_t p = 0; p < a.n_peers; ++p) {
-      const uint8_t v = votes(p);
-      n_granted += v == 1;
-      n_recorded += (v == 1 || v == 2);
-    }
+    const uint32_t cur = (vw >> (2 * from)) & 3u;
+    if (cur != 1 && cur != 2) vw = (vw & ~(3u << (2 * from))) | ((granted ? 1u : 2u) << (2 * from));
+    const uint32_t low = 0x55555555u & ((1u << (2 * a.n_peers)) - 1u);
+    const uint32_t g1 = vw & ~(vw >> 1) & low, r1 = (vw >> 1) & ~vw & low;
+    n_granted = __popc(g1);
+    n_recorded = __popc(g1 | r1);
   }
   __device__ void commit_to(uint64_t tocommit) {
     if (tocommit > last_index) tocommit = last_index;

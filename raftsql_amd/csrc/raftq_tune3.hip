@@ -37,6 +37,10 @@ using namespace raftqk;
 // ring: per-wave LDS ring fed by LDS-DMA.  GPL = 4 (tile = 1024 groups, a wave owns 256 of them: two rounds
 // of 128 for the commit part, 4 vote bytes per lane per peer row).  Slot layout per wave (bytes):
 //   [j][p] match rows (2 x N KiB) | [j] committed (2 KiB, stored as row N of round j) | [p] vote rows (N x 256 B)
+struct ByteVotes {       // round 1's vote layout, kept for the ring variant only (see below)
+  const uint8_t* votes8;  // [N][ld]
+  uint8_t* outcome8;      // [ld]
+};
 typedef __attribute__((address_space(3))) void lds_void3_t;
 typedef const __attribute__((address_space(1))) void global_cvoid3_t;
 
@@ -49,8 +53,8 @@ __device__ __forceinline__ uint32_t bytes_equal32(uint32_t v, uint32_t pattern) 
 }
 
 template <int N, int R, int AUX, bool GATED>
-__global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __restrict__ tab, uint32_t tiles_per_member,
-                                                            uint32_t total_tiles) {
+__global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __restrict__ tab, const ByteVotes* __restrict__ btab,
+                                                            uint32_t tiles_per_member, uint32_t total_tiles) {
   constexpr int GPL = 4, kRounds = 2;
   constexpr int kRows = N + 1 + (GATED ? 1 : 0);
   constexpr int kSlot = kRounds * kRows * 1024 + N * 256;
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
     const uint32_t lin = first + i * stride;
     const uint32_t m = lin / tiles_per_member, tile = lin - m * tiles_per_member;
     const SweepArgs a = tab[m];
+    const ByteVotes bv = btab[m];
     unsigned char* sb = wbase + (size_t)(i % R) * kSlot;
     const uint64_t tile0 = (uint64_t)tile * 1024 + (uint64_t)wave * 256;
 #pragma unroll
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
     }
 #pragma unroll
     for (int p = 0; p < N; ++p)
-      __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(a.votes + (uint64_t)p * a.ld + tile0 + 4 * lane),
+      __builtin_amdgcn_global_load_lds((global_cvoid3_t*)(bv.votes8 + (uint64_t)p * a.ld + tile0 + 4 * lane),
                                        (lds_void3_t*)(sb + kRounds * kRows * 1024 + p * 256), 4, 0, AUX);
   };
 
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
     const uint32_t lin = first + i * stride;
     const uint32_t m = lin / tiles_per_member, tile = lin - m * tiles_per_member;
     const SweepArgs a = tab[m];
+    const ByteVotes bv = btab[m];
     const unsigned char* sb = wbase + (size_t)(i % R) * kSlot;
     const uint64_t tile0 = (uint64_t)tile * 1024 + (uint64_t)wave * 256;
     uint32_t n_changed = 0;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
     constexpr uint32_t bias = (0x80u - q) * 0x01010101u;
     const uint32_t won = ((granted + bias) & 0x80808080u) >> 7;
     const uint32_t lost = (((rejected + bias) & 0x80808080u) >> 7) & ~won;
-    stg<true>(reinterpret_cast<uint32_t*>(a.outcome + tile0 + 4 * lane), won | (lost << 1));
+    stg<true>(reinterpret_cast<uint32_t*>(bv.outcome8 + tile0 + 4 * lane), won | (lost << 1));
     const uint32_t wl = wave_sum_u32((uint32_t)__popc(won) | ((uint32_t)__popc(lost) << 16));
     if (lane == 0) {
       uint4 r;
@@ -154,6 +160,27 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
       r.w = 0;
       stg_u4(a.partials + ((uint64_t)tile * 4 + wave), r);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The shipped layout keeps the RequestVote state as ONE packed word per group (2 bits per peer) and the outcome in
+// 2 bits (raftq_kernels.hpp).  It started here as an A/B against round 1's N byte rows + byte outcome (VERDICT r01
+// item 2(c)): 10.07 vs 10.79 us per 1M x 5 batch, 26.2 vs 29.1 us per 2M x 7 (profiles/r02/tune3_packed_votes.jsonl)
+// -- more than the byte count alone predicts (58.25 vs 62 B), because N row streams per wave become one.  The byte
+// rows live on in this tool only for the LDS-ring variant, which was measured in that layout.
+
+template <typename W>
+__global__ void pack_votes_kernel(const uint8_t* votes, uint64_t ld, int n, uint64_t groups, W* out) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < groups; g += stride) {
+    uint32_t w = 0;
+    for (int p = 0; p < n; ++p) {
+      const uint8_t v = votes[(uint64_t)p * ld + g];
+      w |= (uint32_t)(v == 1 ? 1u : v == 2 ? 2u : 0u) << (2 * p);
+    }
+    out[g] = (W)w;
   }
 }
 
@@ -197,7 +224,8 @@ __global__ __launch_bounds__(256) void copy_ref_kernel(const u64x2* __restrict__
 
 struct Member {
   uint8_t* arena;
-  SweepArgs a;
+  SweepArgs a;   // votes / outcome in the shipped packed layout
+  ByteVotes bv;  // the same votes as byte rows (ring variant)
 };
 
 // the product's shape: rows padded to a multiple of 2048 groups plus the 288-group stagger
@@ -207,14 +235,17 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 4095) / 4096 * 4096; return o; };
   const size_t o_m = carve((size_t)N * ld * 8), o_c = carve(ld * 8), o_co = carve(ld * 8), o_f = carve(ld * 8),
-               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4));
+               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4)), o_v16 = carve(ld * 4),
+               o_o2 = carve(ld / 4 + 64);
   CK(hipMalloc(&s.arena, off));
   s.a.match = (uint64_t*)(s.arena + o_m);
   s.a.committed = (uint64_t*)(s.arena + o_c);
   s.a.committed_out = (uint64_t*)(s.arena + o_co);
   s.a.first_idx = (uint64_t*)(s.arena + o_f);
-  s.a.votes = s.arena + o_v;
-  s.a.outcome = s.arena + o_o;
+  s.bv.votes8 = s.arena + o_v;
+  s.bv.outcome8 = s.arena + o_o;
+  s.a.votes = s.arena + o_v16;
+  s.a.outcome = s.arena + o_o2;
   s.a.changed_bits = nullptr;
   s.a.partials = (uint4*)(s.arena + o_p);
   s.a.ld = ld;
@@ -222,7 +253,12 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.match, (uint64_t)N * ld, seed, 2047ull, base);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.committed, ld, seed + 1, 1023ull, base + 512);
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.first_idx, ld, seed + 2, 2047ull, base);
-  hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, (uint8_t*)s.a.votes, (uint64_t)N * ld, seed + 3);
+  hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, (uint8_t*)s.bv.votes8, (uint64_t)N * ld, seed + 3);
+  CK(hipMemsetAsync(s.arena + o_v16, 0, ld * 4, 0));
+  if (N <= 8)
+    hipLaunchKernelGGL(pack_votes_kernel<uint16_t>, dim3(2048), dim3(256), 0, 0, s.bv.votes8, ld, N, ld, (uint16_t*)(s.arena + o_v16));
+  else
+    hipLaunchKernelGGL(pack_votes_kernel<uint32_t>, dim3(2048), dim3(256), 0, 0, s.bv.votes8, ld, N, ld, (uint32_t*)(s.arena + o_v16));
   return s;
 }
 
@@ -231,6 +267,7 @@ struct Ctx {
   uint64_t G;
   std::vector<Member> mem;
   SweepArgs* tab;  // device table of all members
+  ByteVotes* btab;
   hipStream_t st;
   int cus;
 };
@@ -265,7 +302,7 @@ static void rot_ring(const Ctx& c, uint32_t K, int wg_per_cu) {
   }
   const uint32_t tiles = (uint32_t)(c.G / 1024);
   hipLaunchKernelGGL((sweep_ring_kernel<N, R, AUX, GATED>), dim3(c.cus * wg_per_cu), dim3(256), lds, c.st, (const SweepArgs*)c.tab,
-                     tiles, tiles * K);
+                     (const ByteVotes*)c.btab, tiles, tiles * K);
 }
 
 struct Variant {
@@ -279,7 +316,7 @@ struct Variant {
 };
 
 static double bytes_per_group(int N, int gated, int votes) {
-  return 8.0 * N + 8 + 8 + (gated ? 8 : 0) + (votes ? N + 1 : 0);
+  return 8.0 * N + 8 + 8 + (gated ? 8 : 0) + (votes ? (N <= 8 ? 2 : 4) + 0.25 : 0);  // shipped packed layout
 }
 
 int main(int argc, char** argv) {
@@ -342,6 +379,14 @@ int main(int argc, char** argv) {
       {"focus", 5, 0, 1, M1, 0, "set GPL4 P3", SETV(5, 4, false, true, 3), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P1", SETV(5, 8, false, true, 1), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt(asm)", SETV(5, 8, false, true, 1 | (1 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc1", SETV(5, 8, false, true, 1 | (2 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc0sc1", SETV(5, 8, false, true, 1 | (3 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc1", SETV(5, 8, false, true, 1 | (4 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc0sc1", SETV(5, 8, false, true, 1 | (5 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc0", SETV(5, 8, false, true, 1 | (6 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc0", SETV(5, 8, false, true, 1 | (7 << 4)), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 ld:plain st:nt", SETV(5, 8, false, true, 2), false},
       {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
       {"focus", 5, 1, 0, M1, 0, "set GPL2 P3", SETV(5, 2, true, false, 3), false},
       {"focus", 5, 1, 0, M1, 0, "set GPL4 P3", SETV(5, 4, true, false, 3), false},
@@ -407,6 +452,7 @@ int main(int argc, char** argv) {
   uint64_t curG = 0;
   uint32_t K = 0;
   c.tab = nullptr;
+  c.btab = nullptr;
   std::vector<uint64_t> ref_c[2];
   std::vector<uint8_t> ref_o[2];
   uint64_t ref_tally[3] = {0, 0, 0};
@@ -429,12 +475,17 @@ int main(int argc, char** argv) {
       K = (uint32_t)(1.6 * 1024 * 1024 * 1024 / (v.G * (8.0 * v.N + 16 + v.N + 1))) + 1;
       if (k_override) K = k_override;
       std::vector<SweepArgs> host;
+      std::vector<ByteVotes> phost;
       for (uint32_t k = 0; k < K; ++k) {
         c.mem.push_back(make_member(v.N, v.G, 5000 * v.N + k));
         host.push_back(c.mem.back().a);
+        phost.push_back(c.mem.back().bv);
       }
       CK(hipMalloc((void**)&c.tab, K * sizeof(SweepArgs)));
       CK(hipMemcpy(c.tab, host.data(), K * sizeof(SweepArgs), hipMemcpyHostToDevice));
+      if (c.btab) (void)hipFree(c.btab);
+      CK(hipMalloc((void**)&c.btab, K * sizeof(ByteVotes)));
+      CK(hipMemcpy(c.btab, phost.data(), K * sizeof(ByteVotes), hipMemcpyHostToDevice));
       CK(hipDeviceSynchronize());
       c.N = v.N; c.G = v.G; curN = v.N; curG = v.G;
       ref_gated = ref_votes = -1;
@@ -443,7 +494,8 @@ int main(int argc, char** argv) {
     const uint32_t probe[2] = {0, K - 1};
     for (int i = 0; i < 2; ++i) {
       CK(hipMemsetAsync(c.mem[probe[i]].a.committed_out, 0xEE, v.G * 8, c.st));
-      CK(hipMemsetAsync(c.mem[probe[i]].a.outcome, 0xEE, v.G, c.st));
+      CK(hipMemsetAsync(c.mem[probe[i]].a.outcome, 0xEE, v.G / 4, c.st));
+      CK(hipMemsetAsync(c.mem[probe[i]].bv.outcome8, 0xEE, v.G, c.st));
       CK(hipMemsetAsync(c.mem[probe[i]].a.partials, 0, v.G / 128 * sizeof(uint4), c.st));
     }
     v.fn(c, K, v.param);
@@ -456,7 +508,13 @@ int main(int argc, char** argv) {
       std::vector<uint64_t> cc(v.G);
       std::vector<uint8_t> oo(v.G);
       CK(hipMemcpy(cc.data(), c.mem[probe[i]].a.committed_out, v.G * 8, hipMemcpyDeviceToHost));
-      CK(hipMemcpy(oo.data(), c.mem[probe[i]].a.outcome, v.G, hipMemcpyDeviceToHost));
+      if (!strcmp(v.name, "ring")) {  // the ring variant keeps round 1's byte layout
+        CK(hipMemcpy(oo.data(), c.mem[probe[i]].bv.outcome8, v.G, hipMemcpyDeviceToHost));
+      } else {                        // shipped layout: 2 bits per group, expanded to a byte each for the comparison
+        std::vector<uint8_t> o2(v.G / 4);
+        CK(hipMemcpy(o2.data(), c.mem[probe[i]].a.outcome, v.G / 4, hipMemcpyDeviceToHost));
+        for (uint64_t g = 0; g < v.G; ++g) oo[g] = (uint8_t)((o2[g / 4] >> (2 * (g % 4))) & 3u);
+      }
       if (v.is_ref) {
         ref_c[i] = cc; ref_o[i] = oo;
       } else {

@@ -43,9 +43,9 @@ def check_line(d, n_gpus, steps, warmup):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["bytes_per_decision"] == {"read": 53, "write": 9} and r["bytes_per_launch"] == 62 * cfg["groups_per_gpu"]
+    assert r["bytes_per_decision"] == {"read": 50, "write": 8.25} and r["bytes_per_launch"] == 58.25 * cfg["groups_per_gpu"]
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6
-    assert abs(r["achieved_read_GBps"] - r["achieved"] * 53 / 62) / r["achieved"] < 1e-6
+    assert abs(r["achieved_read_GBps"] - r["achieved"] * 50 / 58.25) / r["achieved"] < 1e-6
     assert "sweep_set_kernel<5, 8, true, false, true, 3, true, 256>" in r["kernel"]
     assert 0.3 < r["frac"] < 1.0
     return cfg, r
@@ -77,7 +77,7 @@ def test_bench_extras_and_other_configs(gpu_engine_cls):
 
 
 def test_bench_gated_config_as_headline(gpu_engine_cls):
-    d = run_bench("--steps", "10", "--warmup", "2", "--config", "5", "--no-extras", "--no-cpu-baseline", "--batches", "18")
+    d = run_bench("--steps", "10", "--warmup", "2", "--config", "5", "--no-extras", "--no-cpu-baseline", "--batches", "20")
     assert "config5" in d["config"]["workload"] and d["roofline"]["bytes_per_decision"] == {"read": 56, "write": 8}
     assert d["roofline"]["frac"] > 0.3 and "true, true, false" in d["roofline"]["kernel"]
 
@@ -87,7 +87,7 @@ def test_bench_two_gpus_worth_from_one_process_and_refusal(gpu_engine_cls):
     instead of printing n_gpus: 1.  --device maps both onto GPU 0 (testing only)."""
     import torch
 
-    d = run_bench("--gpus", "2", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "17")
+    d = run_bench("--gpus", "2", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "20")
     cfg, r = check_line(d, 2, 6, 2)
     assert "one process" in cfg["parallelism"] and "config4_whole_job" in d
     assert d["config4_whole_job"]["decisions_per_s"] > 1e9
@@ -101,7 +101,7 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2",
-                        "--steps", "6", "--warmup", "2", "--device", "0", "--backend", "gloo", "--no-extras", "--batches", "17"],
+                        "--steps", "6", "--warmup", "2", "--device", "0", "--backend", "gloo", "--no-extras", "--batches", "20"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

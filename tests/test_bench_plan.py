@@ -42,7 +42,7 @@ def test_plan_devices_under_torchrun_is_one_device_per_rank():
 def test_bytes_per_decision_is_the_design_table():
     import bench
 
-    want = {2: (32, 8), 3: (53, 9), 4: (71, 9), 5: (56, 8)}
+    want = {2: (32, 8), 3: (50, 8.25), 4: (66, 8.25), 5: (56, 8)}  # packed votes: 2 B in, 0.25 B out (r01: N in, 1 out)
     for c, rw in want.items():
         assert bench.bytes_per_decision(bench.CONFIGS[c]) == rw
 

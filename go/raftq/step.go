@@ -127,3 +127,50 @@ func (e *Engine) ApplyLogDeltas(d []LogDelta, committed []uint64) error {
 	}
 	return e.err(C.raftq_apply_log_deltas(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d)), pc))
 }
+
+// LoadRoles sets role[g] (0 follower, 1 candidate, 2 leader) and, optionally, the election clocks.
+func (e *Engine) LoadRoles(role []uint8, elapsed []uint32) error {
+	var pe *C.uint32_t
+	if elapsed != nil {
+		pe = (*C.uint32_t)(unsafe.Pointer(&elapsed[0]))
+	}
+	return e.err(C.raftq_load_roles(e.h, (*C.uint8_t)(unsafe.Pointer(&role[0])), pe))
+}
+
+// LoadNode bulk-loads the per-group node scalars Step works on (raftq_load_node); lead may be nil.
+func (e *Engine) LoadNode(term []uint64, vote, lead []uint32, lastIndex, lastTerm []uint64) error {
+	var pl *C.uint32_t
+	if lead != nil {
+		pl = (*C.uint32_t)(unsafe.Pointer(&lead[0]))
+	}
+	return e.err(C.raftq_load_node(e.h, (*C.uint64_t)(unsafe.Pointer(&term[0])), (*C.uint32_t)(unsafe.Pointer(&vote[0])), pl,
+		(*C.uint64_t)(unsafe.Pointer(&lastIndex[0])), (*C.uint64_t)(unsafe.Pointer(&lastTerm[0]))))
+}
+
+// NodeState is a host copy of everything Step keeps per group (tests, snapshots).
+type NodeState struct {
+	Term, LastIndex, LastTerm, FirstIdx, Committed []uint64
+	Vote, Lead, Elapsed                            []uint32
+	Role                                           []uint8
+	Match                                          []uint64 // [p*G + g]
+}
+
+// ReadNode copies the node state back (raftq_read_node + raftq_read_tick + raftq_read_committed + raftq_read_match).
+func (e *Engine) ReadNode() (*NodeState, error) {
+	g := int(e.Groups)
+	s := &NodeState{Term: make([]uint64, g), LastIndex: make([]uint64, g), LastTerm: make([]uint64, g), FirstIdx: make([]uint64, g),
+		Committed: make([]uint64, g), Vote: make([]uint32, g), Lead: make([]uint32, g), Elapsed: make([]uint32, g),
+		Role: make([]uint8, g), Match: make([]uint64, g*int(e.Peers))}
+	if err := e.err(C.raftq_read_node(e.h, (*C.uint64_t)(unsafe.Pointer(&s.Term[0])), (*C.uint32_t)(unsafe.Pointer(&s.Vote[0])),
+		(*C.uint32_t)(unsafe.Pointer(&s.Lead[0])), (*C.uint64_t)(unsafe.Pointer(&s.LastIndex[0])),
+		(*C.uint64_t)(unsafe.Pointer(&s.LastTerm[0])), (*C.uint64_t)(unsafe.Pointer(&s.FirstIdx[0])))); err != nil {
+		return nil, err
+	}
+	if err := e.err(C.raftq_read_tick(e.h, nil, (*C.uint32_t)(unsafe.Pointer(&s.Elapsed[0])), (*C.uint8_t)(unsafe.Pointer(&s.Role[0])))); err != nil {
+		return nil, err
+	}
+	if err := e.ReadCommitted(s.Committed); err != nil {
+		return nil, err
+	}
+	return s, e.err(C.raftq_read_match(e.h, (*C.uint64_t)(unsafe.Pointer(&s.Match[0]))))
+}

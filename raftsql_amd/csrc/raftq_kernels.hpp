@@ -163,23 +163,6 @@ __device__ __forceinline__ void stg(T* p, T v) {
   if constexpr (NT) __builtin_nontemporal_store(v, g);
   else *g = v;
 }
-// a bulk store with explicit gfx950 cache-policy bits (tuner only; the product uses stg<>)
-template <int MOD, typename T>
-__device__ __forceinline__ void st_mod(T* p, T v) {
-  static_assert(sizeof(T) == 16 || sizeof(T) == 8, "dwordx4 / dwordx2 stores only");
-#define RAFTQ_ST(suffix)                                                                                  \
-  if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off" suffix ::"v"(p), "v"(v) : "memory"); \
-  else asm volatile("global_store_dwordx2 %0, %1, off" suffix ::"v"(p), "v"(v) : "memory")
-  if constexpr (MOD == 1) { RAFTQ_ST(" nt"); }
-  else if constexpr (MOD == 2) { RAFTQ_ST(" sc1"); }
-  else if constexpr (MOD == 3) { RAFTQ_ST(" sc0 sc1"); }
-  else if constexpr (MOD == 4) { RAFTQ_ST(" sc1 nt"); }
-  else if constexpr (MOD == 5) { RAFTQ_ST(" sc0 sc1 nt"); }
-  else if constexpr (MOD == 6) { RAFTQ_ST(" sc0"); }
-  else if constexpr (MOD == 7) { RAFTQ_ST(" sc0 nt"); }
-  else { RAFTQ_ST(""); }
-#undef RAFTQ_ST
-}
 // uint4 is a class type in HIP (no assignment through an address-space-qualified pointer): store it as a native vector
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stg_u4(uint4* p, uint4 v) {
@@ -210,9 +193,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 // POLICY bits: kLdNT (non-temporal loads), kStNT (non-temporal stores); kNoStore
 // is a measurement-only ablation (tuner) that drops the output stores.
 constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
-// bits 4-6 (measurement only, raftq_tune3): the cache-policy bits of the two bulk stores spelled out per
-// instruction -- 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1, 6 sc0, 7 nt sc0 (0: as kStNT says)
-constexpr int kStModShift = 4;
+// (The other gfx950 cache-policy bits of the bulk stores -- sc0 / sc1 with and without nt -- were swept in round 2
+// through inline-asm stores: plain `nt` is the best, every other combination is equal or up to 7 % slower,
+// profiles/r02/tune3_focus_store_policy_and_packed_votes_n5.jsonl.  The asm variants are not kept: stores the
+// compiler does not see break its own vmcnt accounting for the loads around them.)
 
 // A tile's inputs in registers: filled by tile_load (every load issued, nothing waited for), consumed by
 // tile_finish.  Split so that a persistent kernel can have the next tile's loads in flight while it finishes
@@ -262,7 +246,6 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
                                             const uint32_t tile) {
   constexpr bool STNT = (POLICY & kStNT) != 0;
   constexpr bool NOSTORE = (POLICY & kNoStore) != 0;
-  constexpr int STMOD = (POLICY >> kStModShift) & 7;
   constexpr int kTile = BLOCK * GPL;
   constexpr int kWavesB = BLOCK / 64;
   constexpr int kRounds = GPL / 2;
@@ -315,8 +298,7 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
       if constexpr (NOSTORE) {
         asm volatile("" ::"v"(o.x), "v"(o.y));
       } else {
-        if constexpr (STMOD != 0) st_mod<STMOD>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
-        else stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
+        stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
       }
     }
   }

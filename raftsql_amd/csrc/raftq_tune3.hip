@@ -379,13 +379,6 @@ int main(int argc, char** argv) {
       {"focus", 5, 0, 1, M1, 0, "set GPL4 P3", SETV(5, 4, false, true, 3), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P1", SETV(5, 8, false, true, 1), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt(asm)", SETV(5, 8, false, true, 1 | (1 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc1", SETV(5, 8, false, true, 1 | (2 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc0sc1", SETV(5, 8, false, true, 1 | (3 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc1", SETV(5, 8, false, true, 1 | (4 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc0sc1", SETV(5, 8, false, true, 1 | (5 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:sc0", SETV(5, 8, false, true, 1 | (6 << 4)), false},
-      {"focus", 5, 0, 1, M1, 0, "set GPL8 st:nt sc0", SETV(5, 8, false, true, 1 | (7 << 4)), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 ld:plain st:nt", SETV(5, 8, false, true, 2), false},
       {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
       {"focus", 5, 1, 0, M1, 0, "set GPL2 P3", SETV(5, 2, true, false, 3), false},

@@ -397,3 +397,60 @@ def test_step_golden_fixture_on_the_gpu(NodeEngine, n, walk, monkeypatch):
         for k in ("term", "vote", "lead", "last_index", "last_term", "first_idx", "role", "elapsed", "committed"):
             assert np.array_equal(node[k], final[k]), k
         assert np.array_equal(e.read_match(), final["match"]) and np.array_equal(e.read_votes(), final["votes"])
+
+
+# ---- etcd's own Step tables as recalled, through the batched Step on the GPU ----------------------------------
+from tests.test_step_oracle import _RECALLED, run_recalled_case  # noqa: E402
+
+
+def test_upstream_step_tables_as_recalled_gpu(NodeEngine):
+    """tests/golden/kat.json "upstream_step_tables_recalled" (TestRecvMsgVote, TestAllServerStepdown,
+    TestStepIgnoreOldTermMsg, TestHandleHeartbeat, TestLeaderAppResp as recalled) straight through raftq_step_batch:
+    no oracle involved, the expected values are the tables'."""
+    engines = {}
+
+    def make_state(n, self_peer, init, match):
+        s = pyoracle_state(n, self_peer, init, match)
+        key = (n, self_peer)
+        if key not in engines:
+            engines[key] = NodeEngine(1, n, self_peer)
+        e = engines[key]
+        _stepgen.load_engine(e, s)
+        return e
+
+    def pyoracle_state(n, self_peer, init, match):
+        from oracle import pyoracle  # only as a convenient container for the start state
+
+        s = pyoracle.NodeState(1, n, self_peer)
+        for k, v in init.items():
+            getattr(s, k)[0] = v
+        if match is not None:
+            s.match[:, 0] = match
+        return s
+
+    def read_state(e):
+        d = e.read_node()
+        d["match"] = e.read_match()
+        return d
+
+    try:
+        for case in _RECALLED["cases"]:
+            run_recalled_case(case, make_state, lambda e, m: e.step_batch(m)[0], read_state)
+    finally:
+        for e in engines.values():
+            e.close()
+
+
+def test_upstream_is_election_timeout_window_as_recalled_gpu(gpu_engine_cls):
+    """TestIsElectionTimeout as recalled, as a property of the batched Tick (see the oracle twin of this test)."""
+    t = _RECALLED["TestIsElectionTimeout"]
+    G = 40000
+    with gpu_engine_cls(G, 3) as e:
+        e.set_timers(t["election_tick"], 1, 0xABCDEF)
+        for row in t["rows"]:
+            e.load_roles(np.zeros(G, np.uint8), np.full(G, row["elapse"] - 1, np.uint32))
+            n_hup, _ = e.tick()
+            got = n_hup / G
+            if row["round"]:
+                got = np.floor(got * 10 + 0.5) / 10.0
+            assert got == row["p"], (row, n_hup / G)

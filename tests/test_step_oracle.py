@@ -270,3 +270,70 @@ def test_step_golden_fixture(n):
         assert s.step_batch(m).tobytes() == want.tobytes()
     for k, v in final.items():
         assert np.array_equal(getattr(s, k), v), k
+
+
+# ---- etcd's own Step tables, as recalled (tests/golden/kat.json "upstream_step_tables_recalled") ---------------
+import json as _json
+
+_KAT = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat.json")))
+_RECALLED = _KAT["upstream_step_tables_recalled"]
+
+
+def run_recalled_case(case, make_state, step, read_state):
+    """Shared by the oracle test here and the GPU test (tests/test_step_gpu.py): build the start state, feed the
+    messages, compare what the table says."""
+    n, g = case["n"], 0
+    init = dict(case.get("init", {}))
+    match = init.pop("match", None)
+    st = make_state(n, case["self"], init, match)
+    msgs = list(case.get("setup", [])) + list(case["msgs"])
+    outs = []
+    for m in msgs:
+        mm = np.zeros(1, dtype=pyoracle.STEP_MSG_DT)
+        mm["group"] = g
+        for k_, v in m.items():
+            mm[k_] = v
+        outs.append(step(st, mm)[0])
+    outs = outs[len(case.get("setup", [])):]
+    for o, w in zip(outs, case["want_out"]):
+        for k_, v in w.items():
+            assert int(o[k_]) == v, (case["table"], case["row"], k_, int(o[k_]), v)
+    got = read_state(st)
+    for k_, v in case["want_state"].items():
+        have = int(got["match"][1][0]) if k_ == "match1" else int(got[k_][0])
+        assert have == v, (case["table"], case["row"], k_, have, v)
+
+
+@pytest.mark.parametrize("case", _RECALLED["cases"], ids=lambda c: f"{c['table']}-{c['row']}")
+def test_upstream_step_tables_as_recalled(case):
+    def make_state(n, self_peer, init, match):
+        s = pyoracle.NodeState(1, n, self_peer)
+        for k_, v in init.items():
+            getattr(s, k_)[0] = v
+        if match is not None:
+            s.match[:, 0] = match
+        return s
+
+    def read_state(s):
+        d = {k_: getattr(s, k_) for k_, _ in pyoracle.NodeState.FIELDS}
+        d["match"] = s.match
+        return d
+
+    run_recalled_case(case, make_state, lambda s, m: s.step_batch(m), read_state)
+
+
+def test_upstream_is_election_timeout_window_as_recalled(oracle):
+    """TestIsElectionTimeout as recalled: with electionTimeout 10, a follower whose clock shows `elapse` times out
+    with probability (elapse - 10) / 10 clamped to [0, 1] (0, 0.3, 0.5, 0.8, 1 for 5, 13, 15, 18, 20).  The engine's
+    randomised window draws from splitmix64 instead of Go's math/rand (unpinned by construction), so this is the
+    distributional property, over 40,000 groups: Tick increments the clock first, so the clock starts at elapse - 1."""
+    t = _RECALLED["TestIsElectionTimeout"]
+    G = 40000
+    for row in t["rows"]:
+        role = np.zeros(G, np.uint8)
+        el = np.full(G, row["elapse"] - 1, np.uint32)
+        _, act, n_hup, _ = oracle.tick(role, el, t["election_tick"], 1, 0xABCDEF, 3)
+        got = n_hup / G
+        if row["round"]:
+            got = np.floor(got * 10 + 0.5) / 10.0
+        assert got == row["p"], (row, n_hup / G)

@@ -24,5 +24,12 @@ done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $P/pmc -o sq1 -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $P/pmc_sq1.err
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_ANY --kernel-trace --output-format csv -d $P/pmc -o sq2 -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $P/pmc_sq2.err
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $P/pmc -o tcc -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $P/pmc_tcc.err
-find $P -name "*.csv" | head -50
+# 4. the rows either side of the sweep: one batching turn, the codecs, Step
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/cycle -o cycle -- python tools/profile_cycle.py > $P/cycle.out 2> $P/cycle.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/wire -o wire -- python tools/profile_wire.py > $P/wire.out 2> $P/wire.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/step -o step -- python tools/profile_step.py > $P/step.out 2> $P/step.err
+# 5. the full bench line (extras, CPU baseline) and smoke(), not under the profiler
+python bench.py --gpus 1 --steps 20 --warmup 5 > $P/bench_n1.json 2> $P/bench_n1.err
+python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke.out 2>&1
+python bench.py --gpus 2 --device 0 --steps 10 --warmup 3 --no-cpu-baseline --batches 20 > $P/bench_2gpus_worth_one_process.json 2> $P/bench_2gpus.err
 du -sh $P

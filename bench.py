@@ -226,8 +226,9 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
             assert len(adv) == total
     e.close()
     return {
-        "what": "raftq_cycle: PCIe-in deltas -> scatter -> full sweep of G groups -> compacted advance list out "
-                "(zero-copy staging; wall time of the call incl. its one sync)",
+        "what": "raftq_cycle: acks in -> scatter -> full sweep of G groups -> compacted advance list out over PCIe (zero-copy "
+                "staging: the producer writes the records into the handle's ack buffer -- device memory behind a large BAR, "
+                "pinned host memory otherwise -- before the call; wall time of the call incl. its one wait)",
         "groups": G, "peers": N, "deltas_per_cycle": nd, "advanced_per_cycle": adv_total / cycles,
         "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
         "decisions_per_s": G * cycles / t_total,

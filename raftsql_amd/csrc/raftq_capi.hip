@@ -157,7 +157,45 @@ int raftq_detail::ensure_staging(raftq_t* h, size_t bytes) {
   return RAFTQ_OK;
 }
 
+int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
+  if (bytes <= h->ingest_bytes) return RAFTQ_OK;
+  size_t want = std::max(bytes, h->ingest_bytes * 2);
+  want = std::max<size_t>(want, 1 << 20);
+  if (h->ingest_h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->ingest_in_device) HIPCHK(h, hipFree(h->ingest_h));
+    else HIPCHK(h, hipHostFree(h->ingest_h));
+    h->ingest_h = h->ingest_d = nullptr;
+    h->ingest_bytes = 0;
+  }
+  if (h->bar_staging) {
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) == hipSuccess) {
+      h->ingest_h = h->ingest_d = p;
+      h->ingest_in_device = true;
+      h->ingest_bytes = want;
+      return RAFTQ_OK;
+    }
+    (void)hipGetLastError();
+    h->bar_staging = false;  // no fine-grained device memory here: pinned host memory from now on
+  }
+  HIPCHK(h, hipHostMalloc(&h->ingest_h, want, hipHostMallocMapped));
+  HIPCHK(h, hipHostGetDevicePointer(&h->ingest_d, h->ingest_h, 0));
+  h->ingest_in_device = false;
+  h->ingest_bytes = want;
+  return RAFTQ_OK;
+}
+
 namespace {
+// the producer's stores into a device-resident ack buffer are write-combined: drain them before the doorbell
+inline void publish_ingest(const raftq_t* h) {
+#if defined(__x86_64__)
+  if (h->ingest_in_device) __builtin_ia32_sfence();
+#else
+  (void)h;
+#endif
+}
+
 int ensure_adv(raftq_t* h, uint64_t entries) {
   if (entries <= h->adv_cap) return RAFTQ_OK;
   uint64_t want = std::max<uint64_t>(entries, h->adv_cap * 2);
@@ -190,6 +228,7 @@ int raftq_detail::use_device_idle(raftq_t* h, const char* who) {
   return RAFTQ_OK;
 }
 using raftq_detail::ensure_staging;
+using raftq_detail::ensure_ingest;
 using raftq_detail::use_device;
 using raftq_detail::use_device_idle;
 using raftq_detail::ensure_tick_state;
@@ -275,6 +314,12 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); break; }
     h->own_stream = true;
+    {
+      int large_bar = 0;
+      (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);
+      const char* st = std::getenv("RAFTQ_STAGE");
+      h->bar_staging = large_bar == 1 && !(st && std::strcmp(st, "host") == 0);
+    }
     if ((rc = alloc((void**)&h->match, (size_t)n_peers * ld * 8))) break;
     if ((rc = alloc((void**)&h->committed[0], ld * 8))) break;
     if ((rc = alloc((void**)&h->committed[1], ld * 8))) break;
@@ -348,6 +393,7 @@ void raftq_destroy(raftq_t* h) {
   raftq_detail::free_node_state(h);
   raftq_detail::free_wire_state(h);
   if (h->stage_h) (void)hipHostFree(h->stage_h);
+  if (h->ingest_h) (void)(h->ingest_in_device ? hipFree(h->ingest_h) : hipHostFree(h->ingest_h));
   if (h->adv_h) (void)hipHostFree(h->adv_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
   if (h->h_total) (void)hipHostFree(h->h_total);
@@ -462,11 +508,11 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
   if (nv > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
   if (n) {
-    AbiRec* dst = (AbiRec*)h->stage_h;
+    AbiRec* dst = (AbiRec*)h->ingest_h;
     if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(AbiRec));
   }
   if (nv) {
-    raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+    raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->ingest_h + off_votes);
     if ((const void*)vd != (const void*)dst) std::memcpy(dst, vd, (size_t)nv * sizeof(raftq_vote_delta_t));
     if (!h->claim) {
       const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
@@ -475,7 +521,8 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
     }
   }
   // match and vote records share the device buffer: votes go behind the matches (same offsets as in staging)
-  if (int rc = ensure_delta_dev(h, h->stage_bytes)) return rc;
+  publish_ingest(h);
+  if (int rc = ensure_delta_dev(h, h->ingest_bytes)) return rc;
   const unsigned long long em = n ? ++h->delta_epoch : kNoEpoch, ev = nv ? ++h->delta_epoch : kNoEpoch;
   h->delta_check[0] = n ? em : 0;
   h->delta_check[1] = nv ? ev : 0;
@@ -484,14 +531,14 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   const unsigned long long* bad = h->delta_bad;
   const dim3 gm((unsigned)((n + kBlock - 1) / kBlock)), gv((unsigned)((nv + kBlock - 1) / kBlock));
   if (n && trusted)
-    hipLaunchKernelGGL((deltas_in_apply_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->stage_d, n, h->match, h->ld,
+    hipLaunchKernelGGL((deltas_in_apply_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->ingest_d, n, h->match, h->ld,
                        h->G, h->N, h->delta_bad, h->d_total + 1, em);
   else if (n)
-    hipLaunchKernelGGL((deltas_in_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->stage_d, dev_m, n, h->G, h->N,
+    hipLaunchKernelGGL((deltas_in_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->ingest_d, dev_m, n, h->G, h->N,
                        h->delta_bad, h->d_total + 1, em);
   if (nv)
     hipLaunchKernelGGL(vote_deltas_in_kernel, gv, dim3(kBlock), 0, h->stream,
-                       (const VoteDeltaRec*)((uint8_t*)h->stage_d + off_votes), dev_v, nv, h->G, h->N, h->delta_bad + 1,
+                       (const VoteDeltaRec*)((uint8_t*)h->ingest_d + off_votes), dev_v, nv, h->G, h->N, h->delta_bad + 1,
                        h->d_total + 2, ev);
   if (n && !trusted)
     hipLaunchKernelGGL((apply_deltas_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, h->match, h->ld, (const Rec*)dev_m, n, bad, em,
@@ -512,7 +559,7 @@ int raftq_apply_deltas(raftq_t* h, const raftq_delta_t* d, uint64_t n) {
   if (int rc = use_device_idle(h, "raftq_apply_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_deltas: null argument");
-  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
+  if (int rc = ensure_ingest(h, (size_t)n * sizeof(raftq_delta_t))) return rc;
   if (int rc = enqueue_ingest<DeltaRec>(h, d, n, nullptr, 0, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging area is reused by the next call
   return check_deltas(h);
@@ -551,7 +598,7 @@ int raftq_apply_vote_deltas(raftq_t* h, const raftq_vote_delta_t* d, uint64_t n)
   if (int rc = use_device_idle(h, "raftq_apply_vote_deltas")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_vote_deltas: null argument");
-  if (int rc = ensure_staging(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
+  if (int rc = ensure_ingest(h, (size_t)n * sizeof(raftq_vote_delta_t))) return rc;
   if (int rc = enqueue_ingest<DeltaRec>(h, (const raftq_delta_t*)nullptr, 0, d, n, 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return check_deltas(h);
@@ -936,9 +983,9 @@ int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_del
                 raftq_vote_delta_t** vote_deltas) {
   if (int rc = use_device_idle(h, "raftq_stage")) return rc;
   const size_t off_votes = vote_stage_offset(n_deltas);
-  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
-  if (deltas) *deltas = (raftq_delta_t*)h->stage_h;
-  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+  if (int rc = ensure_ingest(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  if (deltas) *deltas = (raftq_delta_t*)h->ingest_h;
+  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->ingest_h + off_votes);
   return RAFTQ_OK;
 }
 
@@ -993,7 +1040,7 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
   const bool want_list = commit && (advances_out || n_advanced || cap);
   if (want_list) flags |= RAFTQ_SWEEP_CHANGED;
   const size_t off_votes = ((size_t)n_deltas * sizeof(AbiRec) + 255) / 256 * 256;
-  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  if (int rc = ensure_ingest(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
   const uint64_t take_cap = want_list ? std::min<uint64_t>(cap, h->G) : 0;
   if (take_cap)
     if (int rc = ensure_adv(h, take_cap)) return rc;
@@ -1078,9 +1125,9 @@ int raftq_stage_packed(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, ra
                        raftq_vote_delta_t** vote_deltas) {
   if (int rc = use_device_idle(h, "raftq_stage_packed")) return rc;
   const size_t off_votes = ((size_t)n_deltas * sizeof(raftq_delta16_t) + 255) / 256 * 256;
-  if (int rc = ensure_staging(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
-  if (deltas) *deltas = (raftq_delta16_t*)h->stage_h;
-  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->stage_h + off_votes);
+  if (int rc = ensure_ingest(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  if (deltas) *deltas = (raftq_delta16_t*)h->ingest_h;
+  if (vote_deltas) *vote_deltas = (raftq_vote_delta_t*)((uint8_t*)h->ingest_h + off_votes);
   return RAFTQ_OK;
 }
 

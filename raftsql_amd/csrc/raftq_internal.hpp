@@ -34,6 +34,17 @@ struct raftq {
   void* stage_h = nullptr;      // delta staging (host pointer)
   void* stage_d = nullptr;      // same memory, device pointer
   size_t stage_bytes = 0;
+  // The batching turn's ack buffer (raftq_stage*, raftq_cycle*, raftq_apply_[vote_]deltas).  On a device whose memory
+  // the host can address (large BAR) it lives IN HBM: the producer's stores are posted PCIe writes that land in device
+  // memory as the acks arrive (45 GB/s measured from one core), and the ingest kernel reads HBM instead of pulling the
+  // batch over PCIe in 64-byte requests (35 GB/s, 30 of a turn's 52 kernel-us).  Fine-grained, so the GPU never serves
+  // it from a stale L2 line.  The host only ever WRITES it (reads over the BAR are uncached and slow), which is why
+  // calls that read results back from staging keep the pinned buffer above.  Elsewhere it is pinned host memory.
+  void* ingest_h = nullptr;     // what the host writes
+  void* ingest_d = nullptr;     // what the kernels read (same pointer when the buffer is device memory)
+  size_t ingest_bytes = 0;
+  bool ingest_in_device = false;
+  bool bar_staging = false;     // decided at create: large BAR present and not disabled (RAFTQ_STAGE=host)
   raftqk::Advance* adv_h = nullptr;     // compacted advance list (host pointer)
   raftqk::Advance* adv_d = nullptr;
   uint64_t adv_cap = 0;
@@ -166,7 +177,8 @@ namespace raftq_detail {
 int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
 int use_device_idle(raftq_t* h, const char* who);  // + no Step batch in flight (RAFTQ_ESTATE otherwise)
-int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped delta staging
+int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped staging (term deltas, campaign lists, log deltas)
+int ensure_ingest(raftq_t* h, size_t bytes);    // the ack buffer of the batching turn: device memory behind a large BAR, else pinned
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)
 void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations (called by raftq_destroy)

@@ -544,10 +544,12 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
     hipLaunchKernelGGL((apply_deltas_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, h->match, h->ld, (const Rec*)dev_m, n, bad, em,
                        ev);
   if (nv) {
-    hipLaunchKernelGGL(vote_claim_kernel, gv, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv, bad, em,
-                       ev);
+    // trusted match deltas are dropped one by one, never as a batch: their verdict does not gate the votes
+    const unsigned long long em_gate = trusted ? kNoEpoch : em;
+    hipLaunchKernelGGL(vote_claim_kernel, gv, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv, bad,
+                       em_gate, ev);
     hipLaunchKernelGGL(vote_apply_kernel, gv, dim3(kBlock), 0, h->stream, h->votes, h->N > 8 ? 1 : 0, h->claim, h->ld,
-                       (const VoteDeltaRec*)dev_v, nv, bad, em, ev);
+                       (const VoteDeltaRec*)dev_v, nv, bad, em_gate, ev);
   }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;

@@ -494,9 +494,14 @@ def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
         d2 = e.pack_deltas(dg, dp, dm2)
         d2["group"][77] = G + 5
         keep = np.arange(5000) != 77
+        v2 = e.pack_vote_deltas(rng.integers(0, G, 300).astype(np.uint64), rng.integers(0, n, 300).astype(np.uint32),
+                                rng.integers(1, 3, 300).astype(np.uint8))
         with pytest.raises(RaftqError) as ei:
-            e.cycle(SWEEP_COMMIT | CYCLE_TRUSTED, d2, None)
+            e.cycle(SWEEP_COMMIT | CYCLE_TRUSTED, d2, v2)
         assert ei.value.code == -1
+        # the dropped match record does not take the vote deltas of the turn with it (found by tools/soak_r02.py)
+        ref_votes = oracle.apply_vote_deltas(ref_votes, v2["group"].copy(), v2["peer"].copy(), v2["vote"].copy())
+        assert np.array_equal(e.read_votes(), ref_votes)
         ref_match = oracle.apply_deltas(ref_match, dg[keep], dp[keep], dm2[keep])
         new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
         assert np.array_equal(e.read_match(), ref_match) and np.array_equal(e.read_committed(), new_commit)

@@ -926,20 +926,28 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
   const int gpl = h->last_gpl;
   const dim3 grid((unsigned)(h->gpad / ((uint64_t)kBlock * gpl)));
   Adv* out = (Adv*)h->adv_d;  // the pinned list holds either layout (sized for the larger one)
+  // Up to 16K waves (4M groups at 256 per wave) every compaction workgroup sums its predecessors' counts itself;
+  // beyond that the quadratic total would show, so the one-workgroup scan runs first and hands in the offsets.
+  const uint64_t* wave_offsets = nullptr;
+  if (h->n_partials > (1u << 14)) {
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->partials, h->n_partials, h->offsets,
+                       h->d_total, 0);
+    wave_offsets = h->offsets;
+  }
   // the compaction mirrors the geometry of the sweep that wrote the bitmap and the per-wave counts
   switch (gpl) {
     case 2:
       hipLaunchKernelGGL((compact_changed_kernel<2, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
-                         h->last_old, h->last_new, out, take_cap, h->d_total);
+                         h->last_old, h->last_new, out, take_cap, h->d_total, wave_offsets);
       break;
     case 8:
       hipLaunchKernelGGL((compact_changed_kernel<8, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
-                         h->last_old, h->last_new, out, take_cap, h->d_total);
+                         h->last_old, h->last_new, out, take_cap, h->d_total, wave_offsets);
       break;
     default:
       static_assert(kGPL == 4 && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
       hipLaunchKernelGGL((compact_changed_kernel<4, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
-                         h->last_old, h->last_new, out, take_cap, h->d_total);
+                         h->last_old, h->last_new, out, take_cap, h->d_total, wave_offsets);
   }
   HIPCHK(h, hipGetLastError());
   h->compact_epoch_armed = 0;
@@ -1243,6 +1251,7 @@ int raftq_set_create(raftq_t* const* handles, uint32_t n, raftq_set_t** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc((void**)&s->tab[k], (size_t)n * sizeof(SweepArgs));
   if (e == hipSuccess) e = hipMalloc((void**)&s->counts_d, (size_t)n * 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->np_d, (size_t)n * 8);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->counts_h, (size_t)n * 32, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
   if (e == hipSuccess) e = hipEventCreate(&s->ev1);
@@ -1285,6 +1294,7 @@ void raftq_set_destroy(raftq_set_t* s) {
   }
   for (int k = 0; k < 3; ++k) (void)hipFree(s->tab[k]);
   (void)hipFree(s->counts_d);
+  (void)hipFree(s->np_d);
   if (s->counts_h) (void)hipHostFree(s->counts_h);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1349,8 +1359,12 @@ int raftq_set_wait(raftq_set_t* s, raftq_counts_t* per_member, raftq_counts_t* t
     // the tallies of the LAST sweep of every member (a member swept on its own since then reports that sweep)
     set_fill_table(s, -1, s->tab_host);
     SETCHK(s, hipMemcpyAsync(s->tab[2], s->tab_host.data(), n * sizeof(SweepArgs), hipMemcpyHostToDevice, s->stream));
+    // number of per-wave partials of every member's last sweep (pageable source: staged before the call returns)
+    s->np_host.resize(n);
+    for (size_t i = 0; i < n; ++i) s->np_host[i] = s->members[i]->n_partials;
+    SETCHK(s, hipMemcpyAsync(s->np_d, s->np_host.data(), n * 8, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(set_counts_kernel, dim3((unsigned)n), dim3(kBlock), 0, s->stream, (const SweepArgs*)s->tab[2],
-                       s->members[0]->n_partials, s->counts_d);
+                       (const uint64_t*)s->np_d, s->counts_d);
     SETCHK(s, hipGetLastError());
     SETCHK(s, hipMemcpyAsync(s->counts_h, s->counts_d, n * 32, hipMemcpyDeviceToHost, s->stream));
   }

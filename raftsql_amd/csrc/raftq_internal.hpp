@@ -162,6 +162,8 @@ struct raftq_set {
   raftqk::SweepArgs* tab[3] = {nullptr, nullptr, nullptr};
   std::vector<raftqk::SweepArgs> tab_host;  // pageable on purpose: hipMemcpyAsync stages it before returning
   uint64_t* counts_d = nullptr;       // [members][4] {changed, won, lost, 0}, reduced on the device
+  uint64_t* np_d = nullptr;           // [members] number of per-wave partials of each member's last sweep
+  std::vector<uint64_t> np_host;
   uint64_t* counts_h = nullptr;       // pinned
   bool swept = false;
   bool broken = false;                // a member was destroyed under the set

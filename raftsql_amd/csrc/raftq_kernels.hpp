@@ -415,10 +415,12 @@ static __global__ __launch_bounds__(kBlock, MINW) void sweep_persist_kernel(cons
 
 // Per-member tallies of a set sweep: one workgroup per member sums that member's per-wave partials
 // into {changed, won, lost, 0} (u64) -- one small D2H copy for the whole set instead of one per member.
-static __global__ __launch_bounds__(kBlock) void set_counts_kernel(const SweepArgs* __restrict__ tab, uint64_t n_partials,
+static __global__ __launch_bounds__(kBlock) void set_counts_kernel(const SweepArgs* __restrict__ tab,
+                                                                    const uint64_t* __restrict__ n_partials_of,
                                                                     uint64_t* __restrict__ out) {
   __shared__ uint64_t red[3][kWaves];
   const uint4* p = tab[blockIdx.x].partials;
+  const uint64_t n_partials = n_partials_of[blockIdx.x];  // a member swept on its own since may have another tile size
   uint64_t c = 0, w = 0, l = 0;
   for (uint64_t i = threadIdx.x; i < n_partials; i += kBlock) {
     const uint4 v = p[i];
@@ -809,29 +811,37 @@ static __global__ __launch_bounds__(kBlock) void compact_changed_kernel(const ui
                                                                  const uint4* __restrict__ partials,
                                                                  const uint64_t* old_commit,
                                                                  const uint64_t* new_commit,
-                                                                 Adv* out, uint64_t cap, uint64_t* total) {
+                                                                 Adv* out, uint64_t cap, uint64_t* total,
+                                                                 const uint64_t* __restrict__ wave_offsets) {
   constexpr int kTile = kBlock * GPL;
   constexpr int kRounds = GPL / 2;
   __shared__ uint64_t red[kWaves];
   __shared__ uint32_t mine[kWaves];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // exclusive prefix of the change counts of all waves of earlier workgroups
-  const uint32_t first_wave = blockIdx.x * kWaves;
+  // exclusive prefix of the change counts of all waves of earlier workgroups.  Summing them here costs
+  // O(workgroups^2) loads over the launch, fine up to a few million groups per handle; the host hands in
+  // scan_partials_kernel's offsets instead when the handle is larger (wave_offsets != nullptr).
+  const uint64_t first_wave = (uint64_t)blockIdx.x * kWaves;
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(partials);  // .x of entry i = word 4 i
-  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  uint32_t i = tid;
-  for (; i + 3 * kBlock < first_wave; i += 4 * kBlock) {
-    a0 += cnt[4 * (uint64_t)i];
-    a1 += cnt[4 * (uint64_t)(i + kBlock)];
-    a2 += cnt[4 * (uint64_t)(i + 2 * kBlock)];
-    a3 += cnt[4 * (uint64_t)(i + 3 * kBlock)];
-  }
-  for (; i < first_wave; i += kBlock) a0 += cnt[4 * (uint64_t)i];
-  uint64_t acc = (uint64_t)a0 + a1 + a2 + a3;  // per-thread partial sums stay below 2^32 (counts <= 256 per wave)
+  uint64_t acc = 0;
+  if (wave_offsets == nullptr) {
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint64_t i = tid;
+    for (; i + 3 * kBlock < first_wave; i += 4 * kBlock) {
+      a0 += cnt[4 * i];
+      a1 += cnt[4 * (i + kBlock)];
+      a2 += cnt[4 * (i + 2 * kBlock)];
+      a3 += cnt[4 * (i + 3 * kBlock)];
+    }
+    for (; i < first_wave; i += kBlock) a0 += cnt[4 * i];
+    acc = (uint64_t)a0 + a1 + a2 + a3;  // per-thread partial sums stay below 2^32 on this path (< 2^24 waves, <= 512 each)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  } else if (lane == 0 && wave == 0) {
+    acc = wave_offsets[first_wave];
+  }
   if (lane == 0) red[wave] = acc;
-  if (tid < kWaves) mine[tid] = cnt[4 * (uint64_t)(first_wave + tid)];
+  if (tid < kWaves) mine[tid] = cnt[4 * (first_wave + tid)];
   __syncthreads();
   uint64_t pos = 0;
 #pragma unroll

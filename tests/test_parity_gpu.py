@@ -519,6 +519,26 @@ def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
         assert np.array_equal(adv["new_commit"], new_commit[idx]) and np.array_equal(e.read_committed(), new_commit)
 
 
+def test_changed_list_of_a_large_handle(gpu_engine_cls, oracle):
+    """Above 16K waves per sweep (4M groups) the compaction takes its offsets from the one-workgroup scan instead of
+    summing its predecessors' counts in every workgroup: same list, both through collect_changed and through a turn."""
+    rng = np.random.default_rng(77)
+    G, n = 5_000_000, 3
+    committed = rng.integers(1, 1 << 40, G).astype(np.uint64)
+    match = committed[None, :] + rng.integers(0, 5, (n, G)).astype(np.uint64) - np.uint64(2)
+    with gpu_engine_cls(G, n) as e:
+        e.load_match(match, committed)
+        e.step_async(SWEEP_COMMIT | SWEEP_CHANGED | SWEEP_NO_ADOPT)
+        adv, total = e.collect_changed()
+        want, n_ch = oracle.commit_advance(match, committed)
+        idx = np.nonzero(want != committed)[0]
+        assert total == n_ch == len(idx) and np.array_equal(adv["group"], idx.astype(np.uint64))
+        assert np.array_equal(adv["old_commit"], committed[idx]) and np.array_equal(adv["new_commit"], want[idx])
+        adv16, total16, _ = e.cycle_packed(SWEEP_COMMIT, None, None)
+        assert total16 == n_ch and np.array_equal(adv16["group"].astype(np.uint64), idx.astype(np.uint64))
+        assert np.array_equal(adv16["new_commit"], want[idx])
+
+
 def test_timer_and_stream(gpu_engine_cls):
     import torch
 

@@ -116,6 +116,12 @@ def test_set_with_members_on_different_commit_buffers(gpu_engine_cls, oracle):
         for k, (e, w, c) in enumerate(zip(es, want, per)):
             assert np.array_equal(e.read_committed(), w["ung"]) and np.array_equal(e.read_outcome(), w["oc"])
             assert c.n_changed == (0 if k == 1 else w["n_ung"])  # es[1] had advanced already
+        # tallies of "each member's most recent sweep": a member swept on its own in between (another tile size, so
+        # another number of per-wave partials) reports that sweep
+        c3 = es[3].sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT)
+        per_w, tot_w = s.wait(want_counts=True)
+        assert (per_w[3].n_changed, per_w[3].n_won, per_w[3].n_lost) == (c3.n_changed, c3.n_won, c3.n_lost) == (0, want[3]["w"], want[3]["l"])
+        assert per_w[0].n_changed == want[0]["n_ung"]
         # now the buffers disagree the other way round; a second set sweep finds nothing to advance
         per, tot = s.sweep(SWEEP_COMMIT | SWEEP_NO_ADOPT)
         assert tot.n_changed == 0

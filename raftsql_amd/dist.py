@@ -37,6 +37,9 @@ def init_from_env(backend: str | None = None) -> World:
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
+        # (No fallback to gloo if the communicator cannot be built: a fallback that only SOME ranks take hangs the
+        # job -- tried in round 2, two ranks on one GPU sat in different rendezvous for the whole time limit.  A rank
+        # that cannot join fails loudly and torchrun tears the job down.)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=size,
                                 device_id=torch.device("cuda", local_rank))

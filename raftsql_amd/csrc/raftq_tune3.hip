@@ -164,6 +164,22 @@ __global__ __launch_bounds__(256, 1) void sweep_ring_kernel(const SweepArgs* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
+// xcd: the set grid with an XCD-aware tile order.  Consecutive workgroup ids go round-robin to the 8 XCDs, so in the
+// plain grid every XCD touches every 2 MB page of every row; here workgroup id w works on tile (w % 8) * (T / 8) + w / 8
+// of the K x tiles sequence, i.e. every XCD streams one contiguous eighth (its own pages, its own L2 / TLB working set).
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
+__global__ __launch_bounds__(256) void sweep_set_xcd_kernel(const SweepArgs* __restrict__ tab, uint32_t tiles_per_member,
+                                                            uint32_t total_tiles) {
+  const uint32_t w = blockIdx.x;
+  const uint32_t per = total_tiles >> 3;  // total_tiles % 8 == 0 (tiles per member is a multiple of 8)
+  const uint32_t lin = (w & 7u) * per + (w >> 3);
+  const uint32_t m = lin / tiles_per_member;
+  SweepArgs a = tab[m];
+  a.changed_bits = nullptr;
+  sweep_tile<N, GPL, true, GATED, VOTES, POLICY, true>(a, lin - m * tiles_per_member);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The shipped layout keeps the RequestVote state as ONE packed word per group (2 bits per peer) and the outcome in
 // 2 bits (raftq_kernels.hpp).  It started here as an A/B against round 1's N byte rows + byte outcome (VERDICT r01
 // item 2(c)): 10.07 vs 10.79 us per 1M x 5 batch, 26.2 vs 29.1 us per 2M x 7 (profiles/r02/tune3_packed_votes.jsonl)
@@ -291,6 +307,12 @@ static void rot_persist(const Ctx& c, uint32_t K, int wg_per_cu) {
   hipLaunchKernelGGL((sweep_persist_kernel<N, GPL, true, GATED, VOTES, POLICY, true, MINW>), dim3(c.cus * wg_per_cu), dim3(256), 0,
                      c.st, (const SweepArgs*)c.tab, tiles, tiles * K, 0u);
 }
+template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
+static void rot_set_xcd(const Ctx& c, uint32_t K, int) {
+  const uint32_t tiles = (uint32_t)(c.G / (256 * GPL));
+  hipLaunchKernelGGL((sweep_set_xcd_kernel<N, GPL, GATED, VOTES, POLICY>), dim3(tiles * K), dim3(256), 0, c.st, (const SweepArgs*)c.tab,
+                     tiles, tiles * K);
+}
 template <int N, int R, int AUX, bool GATED>
 static void rot_ring(const Ctx& c, uint32_t K, int wg_per_cu) {
   constexpr int kRows = N + 1 + (GATED ? 1 : 0);
@@ -380,6 +402,8 @@ int main(int argc, char** argv) {
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P1", SETV(5, 8, false, true, 1), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 ld:plain st:nt", SETV(5, 8, false, true, 2), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 XCD-contiguous", (rot_set_xcd<5, 8, false, true, 3>), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL4 P3 XCD-contiguous", (rot_set_xcd<5, 4, false, true, 3>), false},
       {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
       {"focus", 5, 1, 0, M1, 0, "set GPL2 P3", SETV(5, 2, true, false, 3), false},
       {"focus", 5, 1, 0, M1, 0, "set GPL4 P3", SETV(5, 4, true, false, 3), false},

@@ -303,9 +303,9 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     dt_copy = time.perf_counter() - t0
     # (b) zero-copy form: the batch is produced straight into the pinned staging area (as a
     # network receive loop would) and the result records are read in place
-    staged = e.step_stage(msgs_per_batch)
     touched, dt = 0, 0.0
     for b in bs[1 + half:]:
+        staged = e.step_stage(msgs_per_batch)  # the staging of the slot this batch will use (slots alternate)
         staged[:] = b  # producing the batch is the caller's cost, not the call's
         t0 = time.perf_counter()
         _, k = e.step_inplace(staged)
@@ -350,8 +350,9 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     e.step_collect(copy=False)
     e.set_compact(False)
     out = {"what": "raftq_step_batch: batched raft.Step (MsgAppResp / MsgHeartbeatResp / MsgVote mix) over "
-                   "device-resident node state; wall time of the call incl. PCIe both ways (64 B in + 64 B out per "
-                   "message) and its one sync; zero-copy staging form",
+                   "device-resident node state; wall time of the call incl. its one sync; zero-copy staging form: the producer "
+                   "writes the 64-byte records into raftq_step_stage()'s buffer (device memory behind a large BAR, pinned host "
+                   "memory otherwise) before the call, 64-byte results come back over PCIe",
            "groups": G, "peers": N, "msgs_per_batch": msgs_per_batch, "us_per_batch": dt / nb * 1e6,
            "msgs_per_s": msgs_per_batch * nb / dt, "groups_touched_per_batch": touched / nb,
            "us_per_batch_copying_form": dt_copy / half * 1e6,

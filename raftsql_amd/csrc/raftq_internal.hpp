@@ -97,8 +97,10 @@ struct raftq {
   // (pinned staging in, device scratch, pinned results out), pipelined over two streams (DMA in | kernels +
   // result copy): the H2D of batch k+1 overlaps the kernels and the result copy of batch k
   struct StepSlot {
-    void* in_h = nullptr;          // pinned staging (what raftq_step_stage hands out)
+    void* in_h = nullptr;          // pinned staging: the copying forms (caller-owned arrays, received frames) go through it
     size_t in_bytes = 0;
+    void* in_bar = nullptr;        // what raftq_step_stage hands out behind a large BAR: fine-grained DEVICE memory the
+    size_t in_bar_bytes = 0;       // producer writes in place (posted PCIe writes); the batch then never needs a DMA
     void* dev = nullptr;           // device scratch: msgs, keys, order, outs, sort temp, flags
     size_t dev_bytes = 0;
     void* out_h = nullptr;         // pinned, device-mapped result records + {touched-group count, bad flag}

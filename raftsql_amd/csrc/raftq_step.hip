@@ -201,6 +201,36 @@ int ensure_slot_staging(raftq_t* h, raftq::StepSlot& sl, uint64_t n, size_t raw_
   return RAFTQ_OK;
 }
 
+// the in-place staging of raftq_step_stage: device memory the host can write (large BAR), else the pinned buffer
+int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out) {
+  const size_t bytes = (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
+  if (h->bar_staging) {
+    if (bytes > sl.in_bar_bytes) {
+      if (sl.in_bar) {
+        HIPCHK(h, hipFree(sl.in_bar));
+        sl.in_bar = nullptr;
+        sl.in_bar_bytes = 0;
+      }
+      const size_t want = std::max(bytes * 2, (size_t)1 << 20);
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) == hipSuccess) {
+        sl.in_bar = p;
+        sl.in_bar_bytes = want;
+      } else {
+        (void)hipGetLastError();
+        h->bar_staging = false;
+      }
+    }
+    if (sl.in_bar) {
+      *out = sl.in_bar;
+      return RAFTQ_OK;
+    }
+  }
+  if (int rc = ensure_slot_staging(h, sl, n)) return rc;
+  *out = sl.in_h;
+  return RAFTQ_OK;
+}
+
 }  // namespace
 
 void raftq_detail::free_node_state(raftq_t* h) {
@@ -217,6 +247,7 @@ void raftq_detail::free_node_state(raftq_t* h) {
     if (sl.ev_out && sl.busy) (void)hipEventSynchronize(sl.ev_out);
     (void)hipFree(sl.dev);
     if (sl.in_h) (void)hipHostFree(sl.in_h);
+    if (sl.in_bar) (void)hipFree(sl.in_bar);
     if (sl.out_h) (void)hipHostFree(sl.out_h);
     if (sl.w_pin) (void)hipHostFree(sl.w_pin);
     if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
@@ -272,8 +303,9 @@ int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");
   raftq::StepSlot& sl = h->step_slot[h->step_submitted & 1];  // the slot the next submit will use
   if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage: two batches already in flight; collect one first");
-  if (int rc = ensure_slot_staging(h, sl, n)) return rc;
-  *msgs = (raftq_msg_t*)sl.in_h;
+  void* p = nullptr;
+  if (int rc = ensure_slot_bar(h, sl, n, &p)) return rc;
+  *msgs = (raftq_msg_t*)p;
   return RAFTQ_OK;
 }
 
@@ -365,6 +397,8 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   int end_bit = 1;
   while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
   size_t in_bytes;
+  bool staged_in_device = false;
+  const void* device_src = nullptr;
   if (wire) {
     // staging = [frame offsets][stream bytes]: one DMA moves both
     in_bytes = (size_t)(n + 1) * 8 + (size_t)wire->nbytes;
@@ -373,8 +407,19 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     if (wire->nbytes) std::memcpy((uint8_t*)sl.in_h + (size_t)(n + 1) * 8, wire->stream, (size_t)wire->nbytes);
   } else {
     in_bytes = (size_t)n * sizeof(raftq_msg_t);
-    // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into it
-    if ((const void*)msgs != sl.in_h) {
+    // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into the pinned one
+    // (either slot's device staging counts: a caller that keeps filling the buffer raftq_step_stage gave it for an
+    // earlier batch must not be served by a host memcpy that READS device memory over the BAR -- 43 ms for 4 MB)
+    for (const raftq::StepSlot& t : h->step_slot)
+      if (t.in_bar && (const uint8_t*)msgs >= (const uint8_t*)t.in_bar &&
+          (const uint8_t*)msgs + in_bytes <= (const uint8_t*)t.in_bar + t.in_bar_bytes)
+        device_src = msgs;
+    if (device_src) {
+      staged_in_device = true;
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();  // the producer's write-combined stores into device memory, before the doorbell
+#endif
+    } else if ((const void*)msgs != sl.in_h) {
       if (int rc = ensure_slot_staging(h, sl, n)) return rc;
       std::memcpy(sl.in_h, msgs, in_bytes);
     } else if (in_bytes > sl.in_bytes) {
@@ -393,7 +438,10 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   const int mode = h->step_stream_mode;
   hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
   hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
-  HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
+  // in: one DMA over PCIe from the pinned staging -- or, when the producer wrote the batch straight into device
+  // memory, a device-to-device copy into the slot's scratch (the replay path needs the batch there; 4 MB in ~3 us)
+  if (staged_in_device) HIPCHK(h, hipMemcpyAsync((void*)s.msgs, device_src, in_bytes, hipMemcpyDeviceToDevice, s_in));
+  else HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
   if (s_in != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));

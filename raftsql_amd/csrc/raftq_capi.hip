@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <csetjmp>
+#include <csignal>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -157,6 +159,36 @@ int raftq_detail::ensure_staging(raftq_t* h, size_t bytes) {
   return RAFTQ_OK;
 }
 
+// Can this process really store into `p` (device memory behind the BAR)?  hipDeviceAttributeIsLargeBar says the
+// aperture exists; whether this container may touch it is found out once, with the fault caught, instead of by the
+// first producer.  Not thread-safe against other users of SIGSEGV / SIGBUS handlers: it runs once per handle, at the
+// first staging request.
+namespace {
+sigjmp_buf g_probe_jmp;
+void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+}  // namespace
+bool raftq_detail::host_can_write(void* p, size_t bytes) {
+  struct sigaction sa, old_segv, old_bus;
+  std::memset(&sa, 0, sizeof sa);
+  sa.sa_handler = probe_fault;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &old_segv);
+  sigaction(SIGBUS, &sa, &old_bus);
+  bool ok = false;
+  if (sigsetjmp(g_probe_jmp, 1) == 0) {
+    volatile uint64_t* q = (volatile uint64_t*)p;
+    q[0] = 0;
+    q[bytes / 8 - 1] = 0;
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#endif
+    ok = true;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr);
+  sigaction(SIGBUS, &old_bus, nullptr);
+  return ok;
+}
+
 int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
   if (bytes <= h->ingest_bytes) return RAFTQ_OK;
   size_t want = std::max(bytes, h->ingest_bytes * 2);
@@ -171,13 +203,17 @@ int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
   if (h->bar_staging) {
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) == hipSuccess) {
-      h->ingest_h = h->ingest_d = p;
-      h->ingest_in_device = true;
-      h->ingest_bytes = want;
-      return RAFTQ_OK;
+      if (h->bar_probed || host_can_write(p, want)) {
+        h->bar_probed = true;
+        h->ingest_h = h->ingest_d = p;
+        h->ingest_in_device = true;
+        h->ingest_bytes = want;
+        return RAFTQ_OK;
+      }
+      (void)hipFree(p);
     }
     (void)hipGetLastError();
-    h->bar_staging = false;  // no fine-grained device memory here: pinned host memory from now on
+    h->bar_staging = false;  // no host-writable device memory here: pinned host memory from now on
   }
   HIPCHK(h, hipHostMalloc(&h->ingest_h, want, hipHostMallocMapped));
   HIPCHK(h, hipHostGetDevicePointer(&h->ingest_d, h->ingest_h, 0));

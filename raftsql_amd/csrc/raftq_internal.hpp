@@ -45,6 +45,7 @@ struct raftq {
   size_t ingest_bytes = 0;
   bool ingest_in_device = false;
   bool bar_staging = false;     // decided at create: large BAR present and not disabled (RAFTQ_STAGE=host)
+  bool bar_probed = false;      // a host store into such memory has been tried (and survived) on this handle
   raftqk::Advance* adv_h = nullptr;     // compacted advance list (host pointer)
   raftqk::Advance* adv_d = nullptr;
   uint64_t adv_cap = 0;
@@ -182,6 +183,7 @@ int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
 int use_device_idle(raftq_t* h, const char* who);  // + no Step batch in flight (RAFTQ_ESTATE otherwise)
 int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped staging (term deltas, campaign lists, log deltas)
+bool host_can_write(void* p, size_t bytes);     // one guarded store into [p, p + bytes): false if it faults
 int ensure_ingest(raftq_t* h, size_t bytes);    // the ack buffer of the batching turn: device memory behind a large BAR, else pinned
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)

@@ -213,10 +213,13 @@ int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out) {
       }
       const size_t want = std::max(bytes * 2, (size_t)1 << 20);
       void* p = nullptr;
-      if (hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) == hipSuccess) {
+      if (hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained) == hipSuccess &&
+          (h->bar_probed || raftq_detail::host_can_write(p, want))) {
+        h->bar_probed = true;
         sl.in_bar = p;
         sl.in_bar_bytes = want;
       } else {
+        if (p) (void)hipFree(p);
         (void)hipGetLastError();
         h->bar_staging = false;
       }

@@ -208,7 +208,8 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts);
 int raftq_read_tick(raftq_t* h, uint8_t* action /*[G]*/, uint32_t* elapsed /*[G]*/, uint8_t* role /*[G]*/);
 /* ascending list of the groups the last raftq_tick sent MsgHup to */
 int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
-/* ascending list of the leader groups the last raftq_tick sent MsgBeat to (they owe a heartbeat round) */
+/* ascending list of the leader groups the last raftq_tick sent MsgBeat to: they owe their followers a heartbeat
+ * round (etcd tickHeartbeat -> Step(MsgBeat) -> bcastHeartbeat, reached from rc.node.Tick(), raft.go:223-224) */
 int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
 /* becomeCandidate for `n` distinct groups: role = candidate, elapsed = 0, votes
  * cleared, the candidate's own slot (`self_peer`) granted.  Term bookkeeping is
@@ -226,9 +227,12 @@ int raftq_cycle(raftq_t* h, const raftq_delta_t* deltas, uint64_t n_deltas,
                 raftq_advance_t* advances_out, uint64_t cap, uint64_t* n_advanced,
                 raftq_counts_t* counts);
 
-/* zero-copy variants: raftq_stage returns pinned, device-visible host buffers
- * with room for the given counts; fill them and pass the SAME pointers to
- * raftq_cycle and no staging copy is made.  They stay valid until the next
+/* zero-copy variants: raftq_stage returns the handle's ack buffer with room for the
+ * given counts -- fine-grained DEVICE memory when the host can address it (large BAR:
+ * the handlers' stores land in HBM as the acks arrive and the turn never pulls them
+ * over PCIe), pinned device-visible host memory otherwise (or with RAFTQ_STAGE=host).
+ * WRITE-ONLY for the host: reads of device memory over the BAR are uncached and slow.
+ * Fill it and pass the SAME pointers to raftq_cycle and no staging copy is made.  They stay valid until the next
  * raftq_stage / raftq_apply_* / raftq_destroy on the handle.  With
  * advances_out == NULL and cap > 0, raftq_cycle leaves the advance list in
  * pinned memory; raftq_last_advances returns it (valid until the next
@@ -237,7 +241,8 @@ int raftq_stage(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, raftq_del
                 raftq_vote_delta_t** vote_deltas);
 int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_listed);
 
-/* The batching turn with the 16-byte records (handles of at most 2^32 groups).  Same semantics as raftq_cycle /
+/* The batching turn -- one iteration of the Ready loop (raft.go:227-235) for every group -- with the 16-byte
+ * records (handles of at most 2^32 groups).  Same semantics as raftq_cycle /
  * raftq_stage / raftq_last_advances; match deltas arrive as raftq_delta16_t, the advance list leaves as
  * raftq_advance16_t.  A turn is all-or-nothing in every form: one out-of-range record of either kind and no
  * record of the call is applied, the sweep it ran is not adopted, RAFTQ_EINVAL. */

@@ -138,8 +138,11 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n);
 int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_step_counts_t* counts /*|NULL*/);
 
-/* zero-copy variants.  raftq_step_stage returns the pinned staging array the NEXT submit will use,
- * with room for n messages: fill it in place and pass the SAME pointer to raftq_step_submit /
+/* zero-copy variants.  raftq_step_stage returns the staging array the NEXT submit will use (the two slots
+ * alternate: ask again for every batch), with room for n messages -- fine-grained DEVICE memory when the host
+ * can address it (large BAR: the receive path's stores land in HBM and the batch needs no inbound DMA), pinned
+ * host memory otherwise (or with RAFTQ_STAGE=host); write-only for the host either way (reads of device
+ * memory over the BAR are uncached).  Fill it in place and pass the SAME pointer to raftq_step_submit /
  * raftq_step_batch and no host copy is made (valid until that submit).  With out == NULL the result
  * records stay in pinned memory; raftq_step_results returns those of the batch collected last
  * (valid until the next raftq_step_submit / raftq_step_batch). */

@@ -180,6 +180,44 @@ __global__ __launch_bounds__(256) void sweep_set_xcd_kernel(const SweepArgs* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
+// tiled: round 1 measured a workgroup-tiled match layout ([tile][N][T]: a workgroup's N rows are ONE contiguous
+// N*T*8-byte chunk instead of N rows megabytes apart) within +-1.5 % of the peer-major rows -- but in the
+// launch-bound regime of one 1M-group launch at a time.  Here it is again under the set dispatch, where the launch
+// boundary no longer hides what the memory system does.  Only the match rows move; everything else as shipped.
+template <int N, int GPL, bool VOTES, int POLICY>
+__global__ __launch_bounds__(256) void sweep_set_tiled_kernel(const SweepArgs* __restrict__ tab, const uint64_t* const* __restrict__ match_t) {
+  constexpr int T = 256 * GPL, kRounds = GPL / 2;
+  constexpr bool NT = (POLICY & kLdNT) != 0;
+  SweepArgs a = tab[blockIdx.y];
+  a.changed_bits = nullptr;
+  const uint64_t* mt = match_t[blockIdx.y];
+  const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+  const uint64_t tile0 = (uint64_t)tile * T;
+  TileRegs<N, GPL, true, false, VOTES> r;
+  if constexpr (VOTES) {
+    if (tid < T / 8) r.vw[0] = ldg<NT>(reinterpret_cast<const u32x4p*>(a.votes + (tile0 + 8ull * tid) * vote_word_bytes(N)));
+  }
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint32_t in_tile = (tid >> 6) * (64 * GPL) + j * 128 + 2 * (tid & 63);
+#pragma unroll
+    for (int p = 0; p < N; ++p) r.m[j][p] = ldg<NT>(reinterpret_cast<const u64x2*>(mt + ((uint64_t)tile * N + p) * T + in_tile));
+    r.c[j] = ldg<NT>(reinterpret_cast<const u64x2*>(a.committed + tile0 + in_tile));
+  }
+  tile_finish<N, GPL, true, false, VOTES, POLICY, true>(r, a, tile);
+}
+
+template <typename E>
+__global__ void retile_kernel(const E* src, E* dst, uint64_t G, uint64_t ld, int N, int T) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, n = (uint64_t)N * G;
+  for (; i < n; i += stride) {
+    const uint64_t p = i / G, g = i % G;
+    dst[((g / T) * N + p) * T + g % T] = src[p * ld + g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The shipped layout keeps the RequestVote state as ONE packed word per group (2 bits per peer) and the outcome in
 // 2 bits (raftq_kernels.hpp).  It started here as an A/B against round 1's N byte rows + byte outcome (VERDICT r01
 // item 2(c)): 10.07 vs 10.79 us per 1M x 5 batch, 26.2 vs 29.1 us per 2M x 7 (profiles/r02/tune3_packed_votes.jsonl)
@@ -242,6 +280,7 @@ struct Member {
   uint8_t* arena;
   SweepArgs a;   // votes / outcome in the shipped packed layout
   ByteVotes bv;  // the same votes as byte rows (ring variant)
+  uint64_t* match_t8;  // match rows re-laid workgroup-tiled for 2048-group tiles (tiled variant)
 };
 
 // the product's shape: rows padded to a multiple of 2048 groups plus the 288-group stagger
@@ -251,7 +290,7 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 4095) / 4096 * 4096; return o; };
   const size_t o_m = carve((size_t)N * ld * 8), o_c = carve(ld * 8), o_co = carve(ld * 8), o_f = carve(ld * 8),
-               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4)), o_v16 = carve(ld * 4),
+               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4)), o_v16 = carve(ld * 4), o_mt = carve((size_t)N * G * 8),
                o_o2 = carve(ld / 4 + 64);
   CK(hipMalloc(&s.arena, off));
   s.a.match = (uint64_t*)(s.arena + o_m);
@@ -271,6 +310,8 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.first_idx, ld, seed + 2, 2047ull, base);
   hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, (uint8_t*)s.bv.votes8, (uint64_t)N * ld, seed + 3);
   CK(hipMemsetAsync(s.arena + o_v16, 0, ld * 4, 0));
+  s.match_t8 = (uint64_t*)(s.arena + o_mt);
+  hipLaunchKernelGGL(retile_kernel<uint64_t>, dim3(2048), dim3(256), 0, 0, s.a.match, s.match_t8, G, ld, N, 2048);
   if (N <= 8)
     hipLaunchKernelGGL(pack_votes_kernel<uint16_t>, dim3(2048), dim3(256), 0, 0, s.bv.votes8, ld, N, ld, (uint16_t*)(s.arena + o_v16));
   else
@@ -284,6 +325,7 @@ struct Ctx {
   std::vector<Member> mem;
   SweepArgs* tab;  // device table of all members
   ByteVotes* btab;
+  uint64_t** mtab;  // per-member tiled match arrays
   hipStream_t st;
   int cus;
 };
@@ -306,6 +348,11 @@ static void rot_persist(const Ctx& c, uint32_t K, int wg_per_cu) {
   const uint32_t tiles = (uint32_t)(c.G / (256 * GPL));
   hipLaunchKernelGGL((sweep_persist_kernel<N, GPL, true, GATED, VOTES, POLICY, true, MINW>), dim3(c.cus * wg_per_cu), dim3(256), 0,
                      c.st, (const SweepArgs*)c.tab, tiles, tiles * K, 0u);
+}
+template <int N, bool VOTES, int POLICY>
+static void rot_set_tiled(const Ctx& c, uint32_t K, int) {
+  hipLaunchKernelGGL((sweep_set_tiled_kernel<N, 8, VOTES, POLICY>), dim3((unsigned)(c.G / 2048), K), dim3(256), 0, c.st,
+                     (const SweepArgs*)c.tab, (const uint64_t* const*)c.mtab);
 }
 template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
 static void rot_set_xcd(const Ctx& c, uint32_t K, int) {
@@ -402,6 +449,7 @@ int main(int argc, char** argv) {
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P1", SETV(5, 8, false, true, 1), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 ld:plain st:nt", SETV(5, 8, false, true, 2), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 TILED match", (rot_set_tiled<5, true, 3>), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 XCD-contiguous", (rot_set_xcd<5, 8, false, true, 3>), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL4 P3 XCD-contiguous", (rot_set_xcd<5, 4, false, true, 3>), false},
       {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
@@ -414,10 +462,13 @@ int main(int argc, char** argv) {
       {"focus", 3, 0, 0, M1, 0, "set GPL4 P3", SETV(3, 4, false, false, 3), false},
       {"focus", 3, 0, 0, M1, 0, "set GPL8 P3", SETV(3, 8, false, false, 3), false},
       {"focus", 3, 0, 0, M1, 0, "set GPL8 P1", SETV(3, 8, false, false, 1), false},
+      {"focus", 3, 0, 0, M1, 0, "set GPL8 P3 TILED match", (rot_set_tiled<3, false, 3>), false},
       {"focus", 7, 0, 1, M2, 0, "single GPL4 P3", SINGLE(7, 4, false, true, 3), true},
       {"focus", 7, 0, 1, M2, 0, "set GPL2 P3", SETV(7, 2, false, true, 3), false},
       {"focus", 7, 0, 1, M2, 0, "set GPL4 P3", SETV(7, 4, false, true, 3), false},
       {"focus", 7, 0, 1, M2, 0, "set GPL2 P1", SETV(7, 2, false, true, 1), false},
+      {"focus", 7, 0, 1, M2, 0, "set GPL8 P3 TILED match", (rot_set_tiled<7, true, 3>), false},
+      {"focus", 7, 0, 1, M2, 0, "set GPL8 P3", SETV(7, 8, false, true, 3), false},
       {"focus", 9, 0, 1, M1, 0, "single GPL4 P3", SINGLE(9, 4, false, true, 3), true},
       {"focus", 9, 0, 1, M1, 0, "set GPL2 P3", SETV(9, 2, false, true, 3), false},
       {"focus", 9, 0, 1, M1, 0, "set GPL4 P3", SETV(9, 4, false, true, 3), false},
@@ -470,6 +521,7 @@ int main(int argc, char** argv) {
   uint32_t K = 0;
   c.tab = nullptr;
   c.btab = nullptr;
+  c.mtab = nullptr;
   std::vector<uint64_t> ref_c[2];
   std::vector<uint8_t> ref_o[2];
   uint64_t ref_tally[3] = {0, 0, 0};
@@ -493,13 +545,18 @@ int main(int argc, char** argv) {
       if (k_override) K = k_override;
       std::vector<SweepArgs> host;
       std::vector<ByteVotes> phost;
+      std::vector<uint64_t*> mhost;
       for (uint32_t k = 0; k < K; ++k) {
         c.mem.push_back(make_member(v.N, v.G, 5000 * v.N + k));
         host.push_back(c.mem.back().a);
         phost.push_back(c.mem.back().bv);
+        mhost.push_back(c.mem.back().match_t8);
       }
       CK(hipMalloc((void**)&c.tab, K * sizeof(SweepArgs)));
       CK(hipMemcpy(c.tab, host.data(), K * sizeof(SweepArgs), hipMemcpyHostToDevice));
+      if (c.mtab) (void)hipFree(c.mtab);
+      CK(hipMalloc((void**)&c.mtab, K * sizeof(uint64_t*)));
+      CK(hipMemcpy(c.mtab, mhost.data(), K * sizeof(uint64_t*), hipMemcpyHostToDevice));
       if (c.btab) (void)hipFree(c.btab);
       CK(hipMalloc((void**)&c.btab, K * sizeof(ByteVotes)));
       CK(hipMemcpy(c.btab, phost.data(), K * sizeof(ByteVotes), hipMemcpyHostToDevice));

@@ -1,5 +1,5 @@
 /* A C host (what cgo sees) driving the whole boundary on a GPU: sweep, sparse ingest + advance list, batched Step,
- * stream frames and a WAL segment -- no Python, no C++ in the caller.  Built with gcc -std=c99 and run by
+ * stream frames and a WAL segment, sweep sets and the packed batching turn -- no Python, no C++ in the caller.  Built with gcc -std=c99 and run by
  * tests/test_abi_gpu.py on the GPU box.  Expected values are worked out by hand below (3 groups x 3 peers). */
 #include <stdio.h>
 #include <stdlib.h>
@@ -103,6 +103,51 @@ int main(void) {
     wal[woff[1] + 14] ^= 1; /* a flipped bit in the entry: its CRC no longer matches */
     CHECK(raftq_wal_decode(h, wal, lc.bytes, woff, 3, 0, rb, &lc) == RAFTQ_OK && lc.n_valid == 1);
     CHECK((rb[1].flags & (RAFTQ_WAL_F_BADCRC | RAFTQ_WAL_F_MALFORMED)) != 0);
+  }
+  /* sweep sets: two handles of one shape, ONE dispatch; then a batching turn in the packed 16-byte records written
+   * in place into the handle's ack buffer (device memory behind a large BAR).  Hand-derived, 2 groups x 3 peers:
+   *   a: match {4,8 | 4,2 | 1,8}  committed {1,5}  -> 2nd largest {4,8}: both advance
+   *   b: match {6,3 | 2,3 | 6,9}  committed {6,1}  -> 2nd largest {6,3}: group 1 advances
+   *   votes a: group 0 {1,1,0} won, group 1 {1,2,2} lost;  b: all pending */
+  {
+    raftq_t *a = NULL, *b = NULL, *both[2];
+    raftq_set_t* set = NULL;
+    uint64_t ma[6] = {4, 8, 4, 2, 1, 8}, ca[2] = {1, 5}, mb[6] = {6, 3, 2, 3, 6, 9}, cb[2] = {6, 1}, got[2];
+    uint8_t va[6] = {1, 1, 1, 2, 0, 2}, vb[6] = {1, 1, 0, 0, 0, 0}, oc[2];
+    raftq_counts_t per[2], tot;
+    raftq_delta16_t* acks = NULL;
+    const raftq_advance16_t* list = NULL;
+    uint64_t n_adv = 0, n_listed = 0;
+    CHECK(raftq_create(0, 2, 3, &a) == RAFTQ_OK && raftq_create(0, 2, 3, &b) == RAFTQ_OK);
+    CHECK(raftq_load_match(a, ma, ca) == RAFTQ_OK && raftq_load_votes(a, va) == RAFTQ_OK);
+    CHECK(raftq_load_match(b, mb, cb) == RAFTQ_OK && raftq_load_votes(b, vb) == RAFTQ_OK);
+    both[0] = a, both[1] = b;
+    CHECK(raftq_set_create(both, 2, &set) == RAFTQ_OK && raftq_set_size(set) == 2);
+    CHECK(raftq_set_stream(a, NULL) == RAFTQ_ESTATE); /* the set owns its members' stream */
+    CHECK(raftq_set_sweep_async(set, RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_VOTES) == RAFTQ_OK);
+    CHECK(raftq_set_wait(set, per, &tot) == RAFTQ_OK);
+    CHECK(per[0].n_changed == 2 && per[0].n_won == 1 && per[0].n_lost == 1 && per[1].n_changed == 1 && per[1].n_won == 0);
+    CHECK(tot.n_changed == 3 && tot.n_won == 1 && tot.n_lost == 1);
+    CHECK(raftq_read_committed(a, got) == RAFTQ_OK && got[0] == 4 && got[1] == 8);
+    CHECK(raftq_read_committed(b, got) == RAFTQ_OK && got[0] == 6 && got[1] == 3);
+    CHECK(raftq_read_outcome(a, oc) == RAFTQ_OK && oc[0] == 1 && oc[1] == 2);
+    CHECK(raftq_set_mode(set, RAFTQ_SET_PERSISTENT, 2) == RAFTQ_OK); /* same answers from the resident walk */
+    CHECK(raftq_set_sweep_async(set, RAFTQ_SWEEP_COMMIT) == RAFTQ_OK && raftq_set_wait(set, NULL, &tot) == RAFTQ_OK && tot.n_changed == 0);
+    /* a turn on member b between set sweeps: peers 0 and 1 of group 0 acknowledge 7 -> 2nd largest 7 > 6 */
+    CHECK(raftq_stage_packed(b, 2, 0, &acks, NULL) == RAFTQ_OK && acks != NULL);
+    acks[0].group = 0, acks[0].peer = 0, acks[0].match = 7;
+    acks[1].group = 0, acks[1].peer = 1, acks[1].match = 7;
+    CHECK(raftq_cycle_packed(b, acks, 2, NULL, 0, RAFTQ_SWEEP_COMMIT | RAFTQ_CYCLE_TRUSTED, NULL, 2, &n_adv, NULL) == RAFTQ_OK);
+    CHECK(n_adv == 1 && raftq_last_advances_packed(b, &list, &n_listed) == RAFTQ_OK && n_listed == 1);
+    CHECK(list[0].group == 0 && list[0].new_commit == 7 && list[0].advanced_by == 1);
+    acks[1].peer = 3; /* not a peer: without TRUSTED the whole turn is refused and nothing moves */
+    acks[0].match = 50;
+    CHECK(raftq_cycle_packed(b, acks, 2, NULL, 0, RAFTQ_SWEEP_COMMIT, NULL, 2, &n_adv, NULL) == RAFTQ_EINVAL && n_adv == 0);
+    CHECK(raftq_read_committed(b, got) == RAFTQ_OK && got[0] == 7 && got[1] == 3);
+    raftq_set_destroy(set); /* members get streams of their own back */
+    CHECK(raftq_commit_advance(a, 0, got, &n_adv) == RAFTQ_OK && n_adv == 0 && got[0] == 4);
+    raftq_destroy(a);
+    raftq_destroy(b);
   }
   raftq_destroy(h);
   printf("C-HOST-GPU-OK\n");

@@ -1277,6 +1277,14 @@ int raftq_set_create(raftq_t* const* handles, uint32_t n, raftq_set_t** out) {
   s->N = handles[0]->N;
   s->gpad = handles[0]->gpad;
   if (const char* e = std::getenv("RAFTQ_SET_MODE")) s->mode = std::atoi(e) == 1 ? 1 : 0;
+  try {  // everything the set's calls will ever push into: no allocation (and no exception) after this point
+    s->members.reserve(n);
+    s->tab_host.reserve(n);
+    s->np_host.reserve(n);
+  } catch (...) {
+    delete s;
+    return sfail(nullptr, RAFTQ_ENOMEM, "raftq_set_create: host allocation failed");
+  }
   auto bail = [&](int rc) {
     std::string keep = s->err;
     raftq_set_destroy(s);

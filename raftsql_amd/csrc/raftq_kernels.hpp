@@ -193,6 +193,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 // POLICY bits: kLdNT (non-temporal loads), kStNT (non-temporal stores); kNoStore
 // is a measurement-only ablation (tuner) that drops the output stores.
 constexpr int kLdNT = 1, kStNT = 2, kNoStore = 4;
+// kNoCompute (tuner only): the selection network and the vote tally replaced by an XOR of the operands -- the same
+// loads and stores with no arithmetic between them: what the memory side alone costs in this kernel shape
+constexpr int kNoCompute = 8;
 // (The other gfx950 cache-policy bits of the bulk stores -- sc0 / sc1 with and without nt -- were swept in round 2
 // through inline-asm stores: plain `nt` is the best, every other combination is equal or up to 7 % slower,
 // profiles/r02/tune3_focus_store_policy_and_packed_votes_n5.jsonl.  The asm variants are not kept: stores the
@@ -270,7 +273,15 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
         v1[p] = r.m[j][p].y;
       }
       uint64_t mci0, mci1;
-      if constexpr (N == 1) {
+      if constexpr ((POLICY & kNoCompute) != 0) {
+        mci0 = v0[0];
+        mci1 = v1[0];
+#pragma unroll
+        for (int p = 1; p < N; ++p) {
+          mci0 ^= v0[p];
+          mci1 ^= v1[p];
+        }
+      } else if constexpr (N == 1) {
         mci0 = v0[0];
         mci1 = v1[0];
       } else {
@@ -278,8 +289,13 @@ __device__ __forceinline__ void tile_finish(const TileRegs<N, GPL, COMMIT, GATED
         mci1 = select_quorum_network<N>(v1);
       }
       u64x2 o;
-      o.x = maybe_commit<GATED>(mci0, r.c[j].x, GATED ? r.f[j].x : 0);
-      o.y = maybe_commit<GATED>(mci1, r.c[j].y, GATED ? r.f[j].y : 0);
+      if constexpr ((POLICY & kNoCompute) != 0) {
+        o.x = mci0 ^ r.c[j].x;
+        o.y = mci1 ^ r.c[j].y;
+      } else {
+        o.x = maybe_commit<GATED>(mci0, r.c[j].x, GATED ? r.f[j].x : 0);
+        o.y = maybe_commit<GATED>(mci1, r.c[j].y, GATED ? r.f[j].y : 0);
+      }
       const bool ch0 = o.x != r.c[j].x;
       const bool ch1 = o.y != r.c[j].y;
       const uint64_t b0 = __ballot(ch0);

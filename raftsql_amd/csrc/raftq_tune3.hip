@@ -207,6 +207,69 @@ __global__ __launch_bounds__(256) void sweep_set_tiled_kernel(const SweepArgs* _
   tile_finish<N, GPL, true, false, VOTES, POLICY, true>(r, a, tile);
 }
 
+// chunk: EVERYTHING a tile reads in one contiguous chunk -- [N match rows][committed][vote words], T*(8N + 8 + 2) bytes --
+// and everything it writes in another -- [committed'][outcome bits], T*8.25 bytes: one input stream and one output
+// stream per workgroup, the closest a sweep can get to the plain copy of `mix`.  T = 2048.
+struct ChunkArgs {
+  const uint8_t* in;   // [tiles][T*(8N+8+2)]
+  uint8_t* out;        // [tiles][T*8 + T/4]
+  uint4* partials;
+};
+template <int N, int POLICY>
+__global__ __launch_bounds__(256) void sweep_set_chunk_kernel(const ChunkArgs* __restrict__ tab) {
+  constexpr int GPL = 8, T = 2048, kRounds = 4;
+  constexpr size_t kIn = (size_t)T * (8 * N + 8 + 2), kOut = (size_t)T * 8 + T / 4;
+  constexpr bool NT = (POLICY & kLdNT) != 0;
+  const ChunkArgs ca = tab[blockIdx.y];
+  const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+  const uint8_t* in = ca.in + (size_t)tile * kIn;
+  uint8_t* out = ca.out + (size_t)tile * kOut;
+  TileRegs<N, GPL, true, false, true> r;
+  r.vw[0] = ldg<NT>(reinterpret_cast<const u32x4p*>(in + (size_t)T * (8 * N + 8) + 16 * tid));
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint32_t in_tile = (tid >> 6) * (64 * GPL) + j * 128 + 2 * (tid & 63);
+#pragma unroll
+    for (int p = 0; p < N; ++p) r.m[j][p] = ldg<NT>(reinterpret_cast<const u64x2*>(in + ((size_t)p * T + in_tile) * 8));
+    r.c[j] = ldg<NT>(reinterpret_cast<const u64x2*>(in + ((size_t)N * T + in_tile) * 8));
+  }
+  // finish through the shipped code: SweepArgs whose output pointers are biased so that "tile * T + x" lands in the chunk
+  SweepArgs a;
+  a.match = nullptr; a.committed = nullptr; a.first_idx = nullptr; a.votes = nullptr; a.changed_bits = nullptr;
+  a.committed_out = reinterpret_cast<uint64_t*>(out) - (size_t)tile * T;
+  a.outcome = out + (size_t)T * 8 - ((size_t)tile * T) / 4;
+  a.partials = ca.partials;
+  a.ld = 0;
+  tile_finish<N, GPL, true, false, true, POLICY, true>(r, a, tile);
+}
+
+// gather a member's shipped arrays into the chunk layout / scatter the chunk outputs back (verification only)
+template <int N>
+__global__ void to_chunks_kernel(SweepArgs a, uint64_t G, uint8_t* in) {
+  constexpr int T = 2048;
+  constexpr size_t kIn = (size_t)T * (8 * N + 8 + 2);
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < G; g += stride) {
+    uint8_t* c = in + (g / T) * kIn;
+    const uint64_t x = g % T;
+    for (int p = 0; p < N; ++p) reinterpret_cast<uint64_t*>(c)[(size_t)p * T + x] = a.match[(uint64_t)p * a.ld + g];
+    reinterpret_cast<uint64_t*>(c)[(size_t)N * T + x] = a.committed[g];
+    reinterpret_cast<uint16_t*>(c + (size_t)T * (8 * N + 8))[x] = reinterpret_cast<const uint16_t*>(a.votes)[g];
+  }
+}
+__global__ void from_chunks_kernel(const uint8_t* out, uint64_t G, uint64_t* committed_out, uint8_t* outcome) {
+  constexpr int T = 2048;
+  constexpr size_t kOut = (size_t)T * 8 + T / 4;
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < G; g += stride) {
+    const uint8_t* c = out + (g / T) * kOut;
+    committed_out[g] = reinterpret_cast<const uint64_t*>(c)[g % T];
+    if ((g & 3) == 0) outcome[g >> 2] = c[(size_t)T * 8 + (g % T) / 4];
+  }
+}
+
 template <typename E>
 __global__ void retile_kernel(const E* src, E* dst, uint64_t G, uint64_t ld, int N, int T) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,11 +339,29 @@ __global__ __launch_bounds__(256) void copy_ref_kernel(const u64x2* __restrict__
   if (acc.x == 0x123456789abcdefull && acc.y == 1) out[0] = acc;  // keep the loads alive
 }
 
+// the same read : write mix as the sweep (50 B in, 8.25 B out per group at N = 5), as a plain streaming copy of every
+// member's arena in ONE launch (blockIdx.y = member): what the memory system gives this mix when nothing is computed
+// and nothing is strided -- the practical ceiling the sweep is measured against
+__global__ __launch_bounds__(256) void copy_mix_kernel(const SweepArgs* __restrict__ tab, uint64_t n_in, uint64_t n_out) {
+  const SweepArgs a = tab[blockIdx.y];
+  const u64x2* in = reinterpret_cast<const u64x2*>(a.match);
+  u64x2* out = reinterpret_cast<u64x2*>(a.committed_out);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  u64x2 acc = {0, 0};
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_in; k += stride) {
+    const u64x2 v = ldg<true>(in + k);
+    acc ^= v;
+    if (k < n_out) stg<true>(out + k, v);
+  }
+  if (acc.x == 0x123456789abcdefull && acc.y == 1) stg<false>(out, acc);  // keep the loads alive
+}
+
 struct Member {
   uint8_t* arena;
   SweepArgs a;   // votes / outcome in the shipped packed layout
   ByteVotes bv;  // the same votes as byte rows (ring variant)
   uint64_t* match_t8;  // match rows re-laid workgroup-tiled for 2048-group tiles (tiled variant)
+  ChunkArgs ck;        // everything per tile in one input / one output chunk (chunk variant; N <= 8)
 };
 
 // the product's shape: rows padded to a multiple of 2048 groups plus the 288-group stagger
@@ -290,7 +371,7 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 4095) / 4096 * 4096; return o; };
   const size_t o_m = carve((size_t)N * ld * 8), o_c = carve(ld * 8), o_co = carve(ld * 8), o_f = carve(ld * 8),
-               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4)), o_v16 = carve(ld * 4), o_mt = carve((size_t)N * G * 8),
+               o_v = carve((size_t)N * ld), o_o = carve(ld), o_p = carve(G / 128 * sizeof(uint4)), o_v16 = carve(ld * 4), o_mt = carve((size_t)N * G * 8), o_ci = carve((size_t)G * (8 * N + 8 + 2)), o_co2 = carve((size_t)G * 8 + G / 4),
                o_o2 = carve(ld / 4 + 64);
   CK(hipMalloc(&s.arena, off));
   s.a.match = (uint64_t*)(s.arena + o_m);
@@ -310,12 +391,18 @@ static Member make_member(int N, uint64_t G, uint64_t seed) {
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint64_t*)s.a.first_idx, ld, seed + 2, 2047ull, base);
   hipLaunchKernelGGL(fill_votes_kernel, dim3(2048), dim3(256), 0, 0, (uint8_t*)s.bv.votes8, (uint64_t)N * ld, seed + 3);
   CK(hipMemsetAsync(s.arena + o_v16, 0, ld * 4, 0));
+  s.ck.in = s.arena + o_ci;
+  s.ck.out = s.arena + o_co2;
+  s.ck.partials = s.a.partials;
   s.match_t8 = (uint64_t*)(s.arena + o_mt);
   hipLaunchKernelGGL(retile_kernel<uint64_t>, dim3(2048), dim3(256), 0, 0, s.a.match, s.match_t8, G, ld, N, 2048);
   if (N <= 8)
     hipLaunchKernelGGL(pack_votes_kernel<uint16_t>, dim3(2048), dim3(256), 0, 0, s.bv.votes8, ld, N, ld, (uint16_t*)(s.arena + o_v16));
   else
     hipLaunchKernelGGL(pack_votes_kernel<uint32_t>, dim3(2048), dim3(256), 0, 0, s.bv.votes8, ld, N, ld, (uint32_t*)(s.arena + o_v16));
+  if (N == 3) hipLaunchKernelGGL(to_chunks_kernel<3>, dim3(2048), dim3(256), 0, 0, s.a, G, (uint8_t*)s.ck.in);
+  if (N == 5) hipLaunchKernelGGL(to_chunks_kernel<5>, dim3(2048), dim3(256), 0, 0, s.a, G, (uint8_t*)s.ck.in);
+  if (N == 7) hipLaunchKernelGGL(to_chunks_kernel<7>, dim3(2048), dim3(256), 0, 0, s.a, G, (uint8_t*)s.ck.in);
   return s;
 }
 
@@ -326,6 +413,7 @@ struct Ctx {
   SweepArgs* tab;  // device table of all members
   ByteVotes* btab;
   uint64_t** mtab;  // per-member tiled match arrays
+  ChunkArgs* ctab;
   hipStream_t st;
   int cus;
 };
@@ -353,6 +441,10 @@ template <int N, bool VOTES, int POLICY>
 static void rot_set_tiled(const Ctx& c, uint32_t K, int) {
   hipLaunchKernelGGL((sweep_set_tiled_kernel<N, 8, VOTES, POLICY>), dim3((unsigned)(c.G / 2048), K), dim3(256), 0, c.st,
                      (const SweepArgs*)c.tab, (const uint64_t* const*)c.mtab);
+}
+template <int N, int POLICY>
+static void rot_set_chunk(const Ctx& c, uint32_t K, int) {
+  hipLaunchKernelGGL((sweep_set_chunk_kernel<N, POLICY>), dim3((unsigned)(c.G / 2048), K), dim3(256), 0, c.st, (const ChunkArgs*)c.ctab);
 }
 template <int N, int GPL, bool GATED, bool VOTES, int POLICY>
 static void rot_set_xcd(const Ctx& c, uint32_t K, int) {
@@ -415,6 +507,11 @@ int main(int argc, char** argv) {
       {"set", 5, 0, 1, M1, 0, "GPL8 nt loads+stores", SETV(5, 8, false, true, 3), false},
       {"set", 5, 0, 1, M1, 0, "GPL4 cached", SETV(5, 4, false, true, 0), false},
       {"set", 5, 0, 1, M1, 0, "GPL4 nt, NO STORES (ceiling)", SETV(5, 4, false, true, 3 | kNoStore), false},
+      {"set", 5, 0, 1, M1, 0, "GPL8 nt, NO STORES (ceiling)", SETV(5, 8, false, true, 3 | kNoStore), false},
+      {"set", 5, 0, 1, M1, 0, "GPL8 nt, NO STORES NO COMPUTE", SETV(5, 8, false, true, 3 | kNoStore | kNoCompute), false},
+      {"set", 5, 0, 1, M1, 0, "GPL8 nt, NO COMPUTE (loads + stores only)", SETV(5, 8, false, true, 3 | kNoCompute), false},
+      {"set", 5, 0, 1, M1, 0, "GPL2 nt, NO COMPUTE (loads + stores only)", SETV(5, 2, false, true, 3 | kNoCompute), false},
+      {"set", 5, 0, 1, M1, 0, "GPL8 nt loads+stores (again)", SETV(5, 8, false, true, 3), false},
       {"persist", 5, 0, 1, M1, 1, "GPL4 nt l+s, 1 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
       {"persist", 5, 0, 1, M1, 2, "GPL4 nt l+s, 2 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
       {"persist", 5, 0, 1, M1, 3, "GPL4 nt l+s, 3 WG/CU", (rot_persist<5, 4, false, true, 3, 1>), false},
@@ -450,6 +547,7 @@ int main(int argc, char** argv) {
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3", SETV(5, 8, false, true, 3), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 ld:plain st:nt", SETV(5, 8, false, true, 2), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 TILED match", (rot_set_tiled<5, true, 3>), false},
+      {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 CHUNK (one stream in, one out)", (rot_set_chunk<5, 3>), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL8 P3 XCD-contiguous", (rot_set_xcd<5, 8, false, true, 3>), false},
       {"focus", 5, 0, 1, M1, 0, "set GPL4 P3 XCD-contiguous", (rot_set_xcd<5, 4, false, true, 3>), false},
       {"focus", 5, 1, 0, M1, 0, "single GPL4 P1", SINGLE(5, 4, true, false, 1), true},
@@ -468,6 +566,7 @@ int main(int argc, char** argv) {
       {"focus", 7, 0, 1, M2, 0, "set GPL4 P3", SETV(7, 4, false, true, 3), false},
       {"focus", 7, 0, 1, M2, 0, "set GPL2 P1", SETV(7, 2, false, true, 1), false},
       {"focus", 7, 0, 1, M2, 0, "set GPL8 P3 TILED match", (rot_set_tiled<7, true, 3>), false},
+      {"focus", 7, 0, 1, M2, 0, "set GPL8 P3 CHUNK (one stream in, one out)", (rot_set_chunk<7, 3>), false},
       {"focus", 7, 0, 1, M2, 0, "set GPL8 P3", SETV(7, 8, false, true, 3), false},
       {"focus", 9, 0, 1, M1, 0, "single GPL4 P3", SINGLE(9, 4, false, true, 3), true},
       {"focus", 9, 0, 1, M1, 0, "set GPL2 P3", SETV(9, 2, false, true, 3), false},
@@ -487,6 +586,48 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(c.st));
     printf("{\"kernel\":\"copy_ref\",\"launches\":25,\"read_bytes\":%llu,\"write_bytes\":%llu}\n", (unsigned long long)(n_in * 16),
            (unsigned long long)(n_out * 16));
+    return 0;
+  }
+  if (only && !strcmp(only, "mix")) {
+    const uint64_t G = M1;
+    const uint32_t K = k_override ? k_override : 27;
+    std::vector<Member> mem;
+    std::vector<SweepArgs> host;
+    for (uint32_t k = 0; k < K; ++k) {
+      mem.push_back(make_member(5, G, 9000 + k));
+      host.push_back(mem.back().a);
+    }
+    SweepArgs* tab = nullptr;
+    CK(hipMalloc((void**)&tab, K * sizeof(SweepArgs)));
+    CK(hipMemcpy(tab, host.data(), K * sizeof(SweepArgs), hipMemcpyHostToDevice));
+    CK(hipDeviceSynchronize());
+    // per member: the packed layout's bytes (50 in / 8.25 out per group) and round 1's (53 / 9), as 16-byte elements;
+    // the match rows + committed are contiguous in the arena (43 MB + 8 MB), so n_in stays inside it
+    const struct { const char* what; double rd, wr; } mixes[] = {{"50 B in / 8.25 B out per group (packed votes)", 50, 8.25},
+                                                                 {"53 B in / 9 B out per group (round-1 layout)", 53, 9},
+                                                                 {"reads only, 50 B per group", 50, 0},
+                                                                 {"1 : 1 copy, 29 B in / 29 B out per group", 29.125, 29.125}};
+    for (const auto& mx : mixes) {
+      const uint64_t n_in = (uint64_t)(G * mx.rd / 16), n_out = (uint64_t)(G * mx.wr / 16);
+      for (int blocks : {512, 1024, 2048}) {
+        std::vector<double> us;
+        for (int rep = 0; rep < 7; ++rep) {
+          for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(copy_mix_kernel, dim3(blocks, K), dim3(256), 0, c.st, (const SweepArgs*)tab, n_in, n_out);
+          CK(hipEventRecord(e0, c.st));
+          for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(copy_mix_kernel, dim3(blocks, K), dim3(256), 0, c.st, (const SweepArgs*)tab, n_in, n_out);
+          CK(hipEventRecord(e1, c.st));
+          CK(hipEventSynchronize(e1));
+          float ms = 0;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          us.push_back(1e3 * ms / reps / K);
+        }
+        std::sort(us.begin(), us.end());
+        const double med = us[us.size() / 2], bytes = (n_in + n_out) * 16.0;
+        printf("{\"kernel\":\"copy_mix\",\"what\":\"%s\",\"K\":%u,\"blocks_per_member\":%d,\"us_per_member_median\":%.3f,\"GBps\":%.1f,"
+               "\"frac_of_8TBps\":%.4f}\n", mx.what, K, blocks, med, bytes / med / 1e3, bytes / med / 1e3 / 8000.0);
+        fflush(stdout);
+      }
+    }
     return 0;
   }
   const bool focus = only && !strcmp(only, "focus");
@@ -522,6 +663,7 @@ int main(int argc, char** argv) {
   c.tab = nullptr;
   c.btab = nullptr;
   c.mtab = nullptr;
+  c.ctab = nullptr;
   std::vector<uint64_t> ref_c[2];
   std::vector<uint8_t> ref_o[2];
   uint64_t ref_tally[3] = {0, 0, 0};
@@ -546,14 +688,19 @@ int main(int argc, char** argv) {
       std::vector<SweepArgs> host;
       std::vector<ByteVotes> phost;
       std::vector<uint64_t*> mhost;
+      std::vector<ChunkArgs> chost;
       for (uint32_t k = 0; k < K; ++k) {
         c.mem.push_back(make_member(v.N, v.G, 5000 * v.N + k));
         host.push_back(c.mem.back().a);
         phost.push_back(c.mem.back().bv);
         mhost.push_back(c.mem.back().match_t8);
+        chost.push_back(c.mem.back().ck);
       }
       CK(hipMalloc((void**)&c.tab, K * sizeof(SweepArgs)));
       CK(hipMemcpy(c.tab, host.data(), K * sizeof(SweepArgs), hipMemcpyHostToDevice));
+      if (c.ctab) (void)hipFree(c.ctab);
+      CK(hipMalloc((void**)&c.ctab, K * sizeof(ChunkArgs)));
+      CK(hipMemcpy(c.ctab, chost.data(), K * sizeof(ChunkArgs), hipMemcpyHostToDevice));
       if (c.mtab) (void)hipFree(c.mtab);
       CK(hipMalloc((void**)&c.mtab, K * sizeof(uint64_t*)));
       CK(hipMemcpy(c.mtab, mhost.data(), K * sizeof(uint64_t*), hipMemcpyHostToDevice));
@@ -573,6 +720,10 @@ int main(int argc, char** argv) {
       CK(hipMemsetAsync(c.mem[probe[i]].a.partials, 0, v.G / 128 * sizeof(uint4), c.st));
     }
     v.fn(c, K, v.param);
+    if (strstr(v.note, "CHUNK"))  // the chunk variant's outputs live in its own layout: bring them back for the comparison
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL(from_chunks_kernel, dim3(2048), dim3(256), 0, c.st, (const uint8_t*)c.mem[probe[i]].ck.out, v.G,
+                           c.mem[probe[i]].a.committed_out, c.mem[probe[i]].a.outcome);
     CK(hipStreamSynchronize(c.st));
     CK(hipGetLastError());
     bool ok = true;
@@ -592,7 +743,7 @@ int main(int argc, char** argv) {
       if (v.is_ref) {
         ref_c[i] = cc; ref_o[i] = oo;
       } else {
-        const bool nostore = strstr(v.note, "NO STORES") != nullptr;
+        const bool nostore = strstr(v.note, "NO STORES") != nullptr || strstr(v.note, "NO COMPUTE") != nullptr;
         if (!nostore) {
           ok = ok && ref_gated == v.gated && ref_votes == v.votes && memcmp(ref_c[i].data(), cc.data(), v.G * 8) == 0;
           if (v.votes) ok = ok && memcmp(ref_o[i].data(), oo.data(), v.G) == 0;
@@ -603,7 +754,8 @@ int main(int argc, char** argv) {
       ref_gated = v.gated; ref_votes = v.votes;
       memcpy(ref_tally, tl, sizeof tl);
     } else {
-      ok = ok && tl[0] == ref_tally[0] && (!v.votes || (tl[1] == ref_tally[1] && tl[2] == ref_tally[2]));
+      if (!strstr(v.note, "NO COMPUTE"))  // (a skeleton variant's tallies mean nothing)
+        ok = ok && tl[0] == ref_tally[0] && (!v.votes || (tl[1] == ref_tally[1] && tl[2] == ref_tally[2]));
     }
     if (!ok) {
       printf("{\"kernel\":\"%s\",\"N\":%d,\"note\":\"%s\",\"MISMATCH\":true}\n", v.name, v.N, v.note);

@@ -514,10 +514,10 @@ def node_measure(device, G=32768, N=3, rounds=6):
     """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
     same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
     waves of one proposal per group on its leader, cranked until every node has delivered every
-    entry on its commit channels.  Wall time, Python transport included."""
+    entry on its commit channels.  Wall time, Python transport included; the N nodes' turns run on N threads."""
     from raftsql_amd.node import Cluster
 
-    c = Cluster(G, N, device=device, seed=5)
+    c = Cluster(G, N, device=device, seed=5, threads=True)  # one thread per node, as N machines would run
     c.start()
     t0 = time.perf_counter()
     ticks = 0

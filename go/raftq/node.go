@@ -253,3 +253,28 @@ func (m *MultiRaftPipe) Close() error {
 	C.raftq_node_destroy(m.n)
 	return err
 }
+
+// NodeStatus is raft.Node.Status() for one group, as include/raftq_node.h lays it out (raftq_node_status_t).
+type NodeStatus struct {
+	Term, Commit, LastIndex, Applied uint64
+	Lead, Vote                       uint32
+	Role                             uint8
+}
+
+// Statuses returns the status of groups [first, first+count) in one cgo call (raftq_node_status_batch): what a
+// G-group host polls for leader discovery instead of G calls.
+func (m *MultiRaftPipe) Statuses(first, count uint64) ([]NodeStatus, error) {
+	if count == 0 {
+		return nil, nil
+	}
+	raw := make([]C.raftq_node_status_t, count)
+	if rc := C.raftq_node_status_batch(m.n, C.uint64_t(first), C.uint64_t(count), &raw[0]); rc != C.RAFTQ_OK {
+		return nil, nodeErr(m.n, rc)
+	}
+	out := make([]NodeStatus, count)
+	for i := range raw {
+		out[i] = NodeStatus{Term: uint64(raw[i].term), Commit: uint64(raw[i].commit), LastIndex: uint64(raw[i].last_index),
+			Applied: uint64(raw[i].applied), Lead: uint32(raw[i].lead), Vote: uint32(raw[i].vote), Role: uint8(raw[i].role)}
+	}
+	return out, nil
+}

@@ -134,6 +134,9 @@ int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len)
 int raftq_node_recv(raftq_node_t* n, uint64_t group, int timeout_ms, void* buf, uint32_t cap, uint32_t* len,
                     int* kind);
 int raftq_node_status(raftq_node_t* n, uint64_t group, raftq_node_status_t* st);
+/* raft.Node.Status() for groups [first_group, first_group + count) in one call (st[count]): what a G-group
+ * host polls instead of G calls -- leader discovery over 32,768 groups x 3 nodes was 1.4 s of ctypes calls */
+int raftq_node_status_batch(raftq_node_t* n, uint64_t first_group, uint64_t count, raftq_node_status_t* st);
 int raftq_node_stats(raftq_node_t* n, raftq_node_stats_t* st);
 int raftq_node_entry(raftq_node_t* n, uint64_t group, uint64_t index, void* buf, uint32_t cap, uint32_t* len,
                      uint64_t* term);

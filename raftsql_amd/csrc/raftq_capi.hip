@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <csetjmp>
+#include <mutex>
 #include <csignal>
 #include <chrono>
 #include <cstdlib>
@@ -168,6 +169,10 @@ sigjmp_buf g_probe_jmp;
 void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
 }  // namespace
 bool raftq_detail::host_can_write(void* p, size_t bytes) {
+  // the jump buffer and the handlers are the process's: one probe at a time (handles on different threads --
+  // the nodes of a cluster, the members of a set -- may get here together)
+  static std::mutex probe_mu;
+  std::lock_guard<std::mutex> probe_lock(probe_mu);
   struct sigaction sa, old_segv, old_bus;
   std::memset(&sa, 0, sizeof sa);
   sa.sa_handler = probe_fault;

@@ -46,6 +46,10 @@ struct raftq {
   bool ingest_in_device = false;
   bool bar_staging = false;     // decided at create: large BAR present and not disabled (RAFTQ_STAGE=host)
   bool bar_probed = false;      // a host store into such memory has been tried (and survived) on this handle
+  // raftq_apply_log_deltas' host bookkeeping, kept across calls: per-group (epoch << 32 | records seen this call)
+  std::vector<uint64_t> ld_mark, ld_start;
+  std::vector<uint32_t> ld_round, ld_pos;
+  uint32_t ld_epoch = 0;
   raftqk::Advance* adv_h = nullptr;     // compacted advance list (host pointer)
   raftqk::Advance* adv_d = nullptr;
   uint64_t adv_cap = 0;

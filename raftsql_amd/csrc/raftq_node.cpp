@@ -17,26 +17,93 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <new>
 #include <string>
-#include <unordered_set>
 #include <vector>
 
 namespace {
 
-struct Entry {
+// Entry payloads live in the node's arena: append-only chunks that never move, so a log entry, an item on a commit
+// channel and an entry of an outbound message are (pointer, length) views and nothing on the per-message path
+// allocates (round 1 kept a std::string per entry, per queued item and per decoded message: the allocator was a third
+// of raftq_node_advance's host time).  A truncated suffix leaves its bytes behind; the log is never compacted either.
+struct Arena {
+  static constexpr size_t kChunk = (size_t)4 << 20;
+  std::vector<std::unique_ptr<char[]>> chunks;
+  char* cur = nullptr;
+  size_t left = 0;
+  // a stable copy of [src, src + len); nullptr when memory ran out
+  const char* put(const void* src, size_t len) {
+    if (len == 0) return "";
+    char* at;
+    if (len > left) {
+      const size_t cap = std::max(len, kChunk);
+      char* c = new (std::nothrow) char[cap];
+      if (!c) return nullptr;
+      try {
+        chunks.emplace_back(c);
+      } catch (...) {
+        delete[] c;
+        return nullptr;
+      }
+      if (cap - len < left) {  // a large payload gets a chunk of its own; the open chunk stays open
+        std::memcpy(c, src, len);
+        return c;
+      }
+      cur = c;
+      left = cap;
+    }
+    at = cur;
+    std::memcpy(at, src, len);
+    cur += len;
+    left -= len;
+    return at;
+  }
+};
+
+struct Entry {  // a view: the log's entries point into the arena, a message's into the turn's receive buffer
   uint64_t term;
-  std::string data;
+  const char* data;
+  uint32_t len;
 };
 
 struct Item {
   int kind;
-  std::string data;
+  const char* data;
+  uint32_t len;
 };
 
-struct InMsg {
+struct InMsg {  // a received (or locally raised) message: header + its entries' range in the turn's decoded array
   raftq_msg_t h;
-  std::vector<Entry> ents;
+  uint32_t ent_first, n_ents;
+};
+
+// proposals queued by raftq_node_propose[_batch] until the next advance(): one blob, no string per proposal
+struct PropBuf {
+  std::vector<uint64_t> group, off;  // off has size() + 1 entries once anything is queued
+  std::vector<char> blob;
+  size_t size() const { return group.size(); }
+  void clear() {
+    group.clear();
+    off.clear();
+    blob.clear();
+  }
+  // room for k more proposals of `bytes` payload bytes in all; throws std::bad_alloc with nothing changed
+  void reserve_more(size_t k, size_t bytes) {
+    auto grow = [](auto& v, size_t want) {  // geometric, as push_back would: reserve(size + 1) per call is quadratic
+      if (v.capacity() < want) v.reserve(std::max(want, v.capacity() * 2));
+    };
+    grow(group, group.size() + k);
+    grow(off, off.size() + k + 1);
+    grow(blob, blob.size() + bytes);
+  }
+  void add(uint64_t g, const void* data, size_t len) {  // after reserve_more: cannot fail half-way
+    if (off.empty()) off.push_back(0);
+    group.push_back(g);
+    if (len) blob.insert(blob.end(), (const char*)data, (const char*)data + len);
+    off.push_back(blob.size());
+  }
 };
 
 // Growable page-locked byte buffer (raftq_host_alloc) for everything the codecs read or fill: the GPU
@@ -111,7 +178,12 @@ struct raftq_node {
   std::vector<Group> groups;
   std::mutex mu;  // guards in_bytes / proposals / pending_ticks / outbound / commit channels / status
   std::condition_variable cv_commit;
-  std::vector<std::pair<uint64_t, std::string>> proposals;
+  PropBuf proposals, turn_props;  // queued / being worked through by advance()
+  Arena arena;                    // entry payloads (logs, commit channels)
+  bool oom = false;               // an arena or queue allocation failed this turn: advance() ends in ENOMEM
+  // the turn's decoded inbound entries and the bytes their payloads sit in (valid inside advance())
+  const raftq_wire_ent_t* cur_ents = nullptr;
+  const uint8_t* cur_bytes = nullptr;
   uint32_t pending_ticks = 0;
   std::vector<PeerQueue> outbound;  // [peer]
   // inbound stream frames as delivered (decoded on the GPU at the next advance)
@@ -137,7 +209,7 @@ struct raftq_node {
   // RAFTQ_PROFILE=1: host time of advance()'s phases, printed at destroy
   enum { kPhDecode, kPhInbound, kPhTick, kPhStage, kPhStep, kPhApply, kPhDeltas, kPhProps, kPhWal, kPhEncode, kPhN };
   double prof[kPhN] = {0};
-  uint64_t prof_turns = 0;
+  uint64_t prof_turns = 0, prof_every = 0;  // RAFTQ_PROFILE_EVERY=k: print and reset every k turns
   bool profiling = false;
   bool started = false, closed = false;
   int error = 0;
@@ -146,6 +218,14 @@ struct raftq_node {
   raftq_node_stats_t stats{};
   // scratch of advance()
   std::vector<uint64_t> tick_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
+  std::vector<InMsg> work, batch, deferred, hups;
+  std::vector<Entry> ent_tmp;
+  std::vector<size_t> step_idx;
+  // per-group marks of one Step round: blocked (a log-changing message of the group is in this batch) and dirty
+  // (its log grew); a mark is set when it equals the round's epoch -- no hashing, no clearing
+  std::vector<uint32_t> blocked_mark, dirty_mark;
+  std::vector<uint64_t> dirty_list;
+  uint32_t epoch = 0;
   std::vector<raftq_log_delta_t> deltas;
   std::vector<uint64_t> delta_commit;
 };
@@ -215,9 +295,9 @@ void put_frame(raftq_node_t* n, uint32_t to, const raftq_msg_t& hdr, const Entry
     std::memset(&e, 0, sizeof(e));
     e.term = ents[i].term;
     e.index = hdr.type == RAFTQ_MSG_APP ? hdr.index + 1 + i : 0;
-    e.data_len = (uint32_t)ents[i].data.size();
+    e.data_len = ents[i].len;
     e.data_off = e.data_len ? n->out_pool.size : 0;
-    if (!n->out_pool.append(ents[i].data.data(), ents[i].data.size()) || !n->out_ents.append(&e, sizeof(e))) n->out_oom = true;
+    if (!n->out_pool.append(ents[i].data, ents[i].len) || !n->out_ents.append(&e, sizeof(e))) n->out_oom = true;
   }
   n->out_msgs.push_back(m);
   n->stats.msgs_sent++;
@@ -246,8 +326,8 @@ void publish(raftq_node_t* n, Group& g, uint64_t upto) {
   upto = std::min<uint64_t>(upto, g.log.size());
   for (uint64_t idx = g.applied + 1; idx <= upto; ++idx) {
     const Entry& e = g.log[idx - 1];
-    if (e.data.empty()) continue;
-    g.q.push_back(Item{RAFTQ_NODE_ENTRY, e.data});
+    if (e.len == 0) continue;
+    g.q.push_back(Item{RAFTQ_NODE_ENTRY, e.data, e.len});
     n->stats.entries_published++;
   }
   if (upto > g.applied) g.applied = upto;
@@ -273,7 +353,7 @@ void send_append(raftq_node_t* n, uint64_t gi, Group& g, uint32_t to) {
   m.commit = g.committed;
   uint64_t cnt = 0, bytes = 0;
   while (nx + cnt <= last && cnt < kMaxEntriesPerMsg && bytes < kMaxBytesPerMsg) {
-    bytes += g.log[nx + cnt - 1].data.size();
+    bytes += g.log[nx + cnt - 1].len;
     ++cnt;
   }
   put_frame(n, to, m, cnt ? &g.log[nx - 1] : nullptr, cnt);
@@ -297,24 +377,33 @@ void bcast_heartbeat(raftq_node_t* n, uint64_t gi, Group& g) {
 
 // the leader's (or a forwarded) proposal: appendEntry on the leader, forward / drop elsewhere.
 // Returns true when the log grew (the caller reports the tail and broadcasts).
-bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, std::vector<Entry>& ents) {
+// `ents` are views (into the proposal blob or the receive buffer): the leader copies the payloads into the arena.
+bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, const Entry* ents, size_t n_ents) {
   if (g.role == RAFTQ_ROLE_LEADER) {
-    for (Entry& e : ents) g.log.push_back(Entry{g.term, std::move(e.data)});
-    if (!ents.empty()) wal_touch(n, gi, g);
-    return !ents.empty();
+    for (size_t i = 0; i < n_ents; ++i) {
+      const char* at = n->arena.put(ents[i].data, ents[i].len);
+      if (!at) {
+        n->oom = true;
+        return i != 0;
+      }
+      g.log.push_back(Entry{g.term, at, ents[i].len});
+    }
+    if (n_ents) wal_touch(n, gi, g);
+    return n_ents != 0;
   }
   if (g.lead != 0 && g.lead - 1 != n->self) {  // stepFollower MsgProp: `m.To = r.lead; r.send(m)`
     raftq_msg_t m = header(n, gi, RAFTQ_MSG_PROP, 0);
-    put_frame(n, g.lead - 1, m, ents.data(), ents.size());
+    put_frame(n, g.lead - 1, m, ents, n_ents);
   } else {
-    n->stats.proposals_dropped += ents.size();  // no leader: etcd drops the proposal
+    n->stats.proposals_dropped += n_ents;  // no leader: etcd drops the proposal
   }
   return false;
 }
 
 // handleAppendEntries on the log's owner, after Step accepted the header (RAFTQ_OUT_APPEND)
-void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vector<raftq_log_delta_t>& deltas) {
+void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const InMsg& im, std::vector<raftq_log_delta_t>& deltas) {
   const raftq_msg_t& m = im.h;
+  const raftq_wire_ent_t* ents = n->cur_ents + im.ent_first;
   raftq_msg_t r = header(n, gi, RAFTQ_MSG_APP_RESP, g.term);
   if (m.index < g.committed) {  // `if m.Index < r.raftLog.committed { send MsgAppResp{Index: committed} }`
     r.index = g.committed;
@@ -323,10 +412,10 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vec
   }
   if (m.index <= g.log.size() && term_at(g, m.index) == m.log_term) {  // raftLog.maybeAppend
     size_t k = 0;
-    for (; k < im.ents.size(); ++k) {  // findConflict
+    for (; k < im.n_ents; ++k) {  // findConflict
       const uint64_t idx = m.index + 1 + k;
       if (idx > g.log.size()) break;
-      if (g.log[idx - 1].term != im.ents[k].term) {
+      if (g.log[idx - 1].term != ents[k].term) {
         g.log.resize(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
         g.wal_upto = std::min<uint64_t>(g.wal_upto, idx - 1);  // the WAL gets the replacement entries again
         // replayWAL published the whole log, committed or not (raft.go:122-134), so `applied` may sit beyond the
@@ -337,9 +426,16 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, InMsg& im, std::vec
         break;
       }
     }
-    for (; k < im.ents.size(); ++k) g.log.push_back(std::move(im.ents[k]));
+    for (; k < im.n_ents; ++k) {
+      const char* at = n->arena.put(n->cur_bytes + ents[k].data_off, ents[k].data_len);
+      if (!at) {  // out of memory: the node poisons itself at the end of this turn; do not acknowledge what is not stored
+        n->oom = true;
+        return;
+      }
+      g.log.push_back(Entry{ents[k].term, at, ents[k].data_len});
+    }
     wal_touch(n, gi, g);
-    const uint64_t lastnewi = m.index + im.ents.size();
+    const uint64_t lastnewi = m.index + im.n_ents;
     r.index = lastnewi;
     put_frame(n, m.from, r, nullptr, 0);
     raftq_log_delta_t d;
@@ -372,7 +468,7 @@ int flush_deltas(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 }
 
 // what one Step result means for the node (the "Ready" consequences of one message)
-void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
+void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const InMsg& im) {
   Group& g = n->groups[o.group];
   const uint64_t gi = o.group;
   g.term = o.term;
@@ -414,7 +510,7 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, InMsg& im) {
       g.log.resize(std::min<uint64_t>(g.log.size(), o.index - 1));
       g.wal_upto = std::min<uint64_t>(g.wal_upto, g.log.size());
       n->shared_group = ~0ull;
-      g.log.push_back(Entry{o.term, std::string()});
+      g.log.push_back(Entry{o.term, "", 0});
       wal_touch(n, gi, g);
       g.next.assign(n->N, o.index);  // reset(): Next = lastIndex + 1 (before the empty entry)
       g.match.assign(n->N, 0);
@@ -546,7 +642,7 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   recs.clear();
   pool.clear();
   bool oom = false;
-  auto put = [&](uint8_t kind, uint64_t group, uint64_t term, uint64_t index, uint32_t vote, const std::string* data) {
+  auto put = [&](uint8_t kind, uint64_t group, uint64_t term, uint64_t index, uint32_t vote, const Entry* data) {
     raftq_wal_rec_t r;
     std::memset(&r, 0, sizeof(r));
     r.kind = kind;
@@ -554,10 +650,10 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     r.term = term;
     r.index = index;
     r.vote = vote;
-    if (data && !data->empty()) {
-      r.data_len = (uint32_t)data->size();
+    if (data && data->len) {
+      r.data_len = data->len;
       r.data_off = pool.size;
-      oom |= !pool.append(data->data(), data->size());
+      oom |= !pool.append(data->data, data->len);
     }
     oom |= !recs.append(&r, sizeof(r));
   };
@@ -571,7 +667,7 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     g.wal_dirty = false;
     for (uint64_t idx = g.wal_upto + 1; idx <= g.log.size(); ++idx) {
       const Entry& e = g.log[idx - 1];
-      put(RAFTQ_WAL_ENTRY, gi, e.term, idx, 0, &e.data);
+      put(RAFTQ_WAL_ENTRY, gi, e.term, idx, 0, &e);
     }
     g.wal_upto = g.log.size();
     const bool empty_hs = g.term == 0 && g.vote == 0 && g.committed == 0;  // `if !raft.IsEmptyHardState(st)`
@@ -603,10 +699,12 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 
 // one entry into a group's log under the WAL's rule (wal.ReadAll: a later entry with an index already
 // seen replaces it and everything after it)
-bool log_put(Group& g, uint64_t index, uint64_t term, const char* data, uint32_t len) {
+bool log_put(raftq_node_t* n, Group& g, uint64_t index, uint64_t term, const char* data, uint32_t len) {
   if (index == 0 || index > g.log.size() + 1) return false;
   if (index <= g.log.size()) g.log.resize(index - 1);
-  g.log.push_back(Entry{term, std::string(data, len)});
+  const char* at = n->arena.put(data, len);
+  if (!at) return false;
+  g.log.push_back(Entry{term, at, len});
   return true;
 }
 
@@ -631,10 +729,13 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   n->N = n_peers;
   n->self = self_peer;
   n->profiling = std::getenv("RAFTQ_PROFILE") != nullptr;
+  if (const char* ev = std::getenv("RAFTQ_PROFILE_EVERY")) n->prof_every = std::strtoull(ev, nullptr, 10);
   try {
     n->groups.resize(n_groups);
     n->outbound.resize(n_peers);
     n->tick_list.resize(std::min<uint64_t>(n_groups, 4096));
+    n->blocked_mark.assign(n_groups, 0);
+    n->dirty_mark.assign(n_groups, 0);
   } catch (...) {
     raftq_destroy(n->h);
     delete n;
@@ -662,7 +763,12 @@ int raftq_node_replay(raftq_node_t* n, uint64_t group, const uint64_t* terms, co
       return RAFTQ_EINVAL;
     }
     prev = terms[i];
-    g.log.push_back(Entry{terms[i], std::string((const char*)data[i], lens[i])});
+    const char* at = n->arena.put(data[i], lens[i]);
+    if (!at) {
+      n->errtext = "replay: host allocation failed";
+      return RAFTQ_ENOMEM;
+    }
+    g.log.push_back(Entry{terms[i], at, lens[i]});
   }
   return RAFTQ_OK;
 }
@@ -707,7 +813,7 @@ int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat
       Group& g = n->groups[gi];
       // replayWAL (raft.go:122-134): every logged entry goes out, then the nil sentinel
       publish(n, g, g.log.size());
-      g.q.push_back(Item{RAFTQ_NODE_SENTINEL, std::string()});
+      g.q.push_back(Item{RAFTQ_NODE_SENTINEL, "", 0});
       g.term = term[gi] = g.hs_term;
       g.vote = vote[gi] = g.hs_vote;
       g.committed = committed[gi] = std::min<uint64_t>(g.hs_commit, g.log.size());
@@ -738,7 +844,13 @@ int raftq_node_propose(raftq_node_t* n, uint64_t group, const void* data, uint32
     n->errtext = n->closed ? "propose: node is closed" : "propose: node not started";
     return RAFTQ_ESTATE;
   }
-  n->proposals.emplace_back(group, std::string((const char*)data, len));
+  try {
+    n->proposals.reserve_more(1, len);
+  } catch (...) {
+    n->errtext = "propose: host allocation failed";
+    return RAFTQ_ENOMEM;
+  }
+  n->proposals.add(group, data, len);
   return RAFTQ_OK;
 }
 
@@ -754,9 +866,13 @@ int raftq_node_propose_batch(raftq_node_t* n, const uint64_t* groups, const uint
     n->errtext = n->closed ? "propose: node is closed" : "propose: node not started";
     return RAFTQ_ESTATE;
   }
-  n->proposals.reserve(n->proposals.size() + (size_t)k);
-  for (uint64_t i = 0; i < k; ++i)
-    n->proposals.emplace_back(groups[i], std::string((const char*)blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i])));
+  try {
+    n->proposals.reserve_more((size_t)k, (size_t)(offsets[k] - offsets[0]));
+  } catch (...) {
+    n->errtext = "propose_batch: host allocation failed; nothing was queued";
+    return RAFTQ_ENOMEM;
+  }
+  for (uint64_t i = 0; i < k; ++i) n->proposals.add(groups[i], (const char*)blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
   return RAFTQ_OK;
 }
 
@@ -802,6 +918,15 @@ int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len) {
 }
 
 namespace {
+void dump_profile(raftq_node_t* n) {
+  static const char* names[raftq_node::kPhN] = {"decode", "inbound", "tick", "stage", "step", "apply", "deltas", "props", "wal", "encode"};
+  std::fprintf(stderr, "[raftq_node %u] advance phases, total ms over %llu turns (%llu msgs stepped so far):", n->self,
+               (unsigned long long)n->prof_turns, (unsigned long long)n->stats.msgs_stepped);
+  for (int i = 0; i < raftq_node::kPhN; ++i) std::fprintf(stderr, " %s %.1f", names[i], n->prof[i] / 1e3);
+  std::fprintf(stderr, "\n");
+  std::fill(n->prof, n->prof + raftq_node::kPhN, 0.0);
+  n->prof_turns = 0;
+}
 struct Phase {  // accumulates wall time into n->prof[which] when RAFTQ_PROFILE is set
   raftq_node_t* n;
   int which;
@@ -825,8 +950,12 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   std::lock_guard<std::mutex> turn(n->turn_mu);
   Phase ph(n, raftq_node::kPhDecode);
   if (n->profiling) n->prof_turns++;
-  std::vector<InMsg> work;
-  std::vector<std::pair<uint64_t, std::string>> props;
+  std::vector<InMsg>& work = n->work;
+  work.clear();
+  PropBuf& props = n->turn_props;
+  props.clear();
+  n->cur_ents = nullptr;
+  n->cur_bytes = nullptr;
   PinBuf& in_bytes = n->turn_bytes;  // the half of the inbound double buffer this turn decodes
   std::vector<uint64_t>& in_off = n->turn_off;
   in_bytes.clear();
@@ -838,7 +967,7 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     if (n->error) return n->error;
     in_bytes.swap(n->in_bytes);
     in_off.swap(n->in_off);
-    props.swap(n->proposals);
+    std::swap(props, n->proposals);
     ticks = n->pending_ticks;
     n->pending_ticks = 0;
   }
@@ -864,6 +993,9 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "wire_decode");
     ph.next(raftq_node::kPhInbound);
+    n->cur_ents = we;
+    n->cur_bytes = in_bytes.p;
+    work.reserve(nf);
     for (uint64_t i = 0; i < nf; ++i) {
       const raftq_wire_msg_t& m = wm[i];
       const bool kind_ok = m.type == RAFTQ_MSG_PROP || m.type == RAFTQ_MSG_APP || m.type == RAFTQ_MSG_APP_RESP ||
@@ -884,12 +1016,9 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
       im.h.from = m.from;
       im.h.type = m.type;
       im.h.reject = m.reject;
-      im.ents.reserve(m.n_ents);
-      for (uint32_t k = 0; k < m.n_ents; ++k) {
-        const raftq_wire_ent_t& e = we[m.ent_first + k];
-        im.ents.push_back(Entry{e.term, std::string((const char*)in_bytes.p + e.data_off, e.data_len)});
-      }
-      work.push_back(std::move(im));
+      im.ent_first = m.ent_first;
+      im.n_ents = m.n_ents;
+      work.push_back(im);
     }
   }
   // The commit channels, the status mirror and the outbound queues are only written below, under
@@ -897,11 +1026,12 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   std::unique_lock<std::mutex> lk(n->mu);
   const uint64_t published0 = n->stats.entries_published;
   n->stats.frames_dropped += dropped;
-  bool did = !work.empty() || !props.empty() || ticks != 0 || dropped != 0;
+  bool did = !work.empty() || props.size() != 0 || ticks != 0 || dropped != 0;
 
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
-  std::vector<InMsg> hups;
+  std::vector<InMsg>& hups = n->hups;
+  hups.clear();
   ph.next(raftq_node::kPhTick);
   for (uint32_t t = 0; t < ticks; ++t) {
     lk.unlock();
@@ -919,7 +1049,8 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     for (uint64_t i = 0; i < n_hup; ++i) {
       InMsg im;
       im.h = header(n, n->tick_list[i], RAFTQ_MSG_HUP, 0);
-      hups.push_back(std::move(im));
+      im.ent_first = im.n_ents = 0;
+      hups.push_back(im);
     }
     lk.unlock();
     rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
@@ -935,44 +1066,68 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     }
   }
   if (!hups.empty()) {
-    for (InMsg& im : work) hups.push_back(std::move(im));
+    hups.insert(hups.end(), work.begin(), work.end());
     work.swap(hups);
   }
 
   // -- rc.Process -> Step, in rounds.  A message that changes a group's log (MsgApp, MsgProp) must
   // be the last one of its group in a Step batch: what follows it has to see the new log tail.
-  std::vector<InMsg> batch, deferred;
-  std::unordered_set<uint64_t> blocked, dirty;
+  std::vector<InMsg>& batch = n->batch;
+  std::vector<InMsg>& deferred = n->deferred;
+  std::vector<uint64_t>& dirty = n->dirty_list;
+  auto next_epoch = [&] {  // a fresh value no mark holds
+    if (++n->epoch == 0) {
+      std::fill(n->blocked_mark.begin(), n->blocked_mark.end(), 0u);
+      std::fill(n->dirty_mark.begin(), n->dirty_mark.end(), 0u);
+      n->epoch = 1;
+    }
+    return n->epoch;
+  };
+  // the views of one inbound MsgProp's entries (payloads stay in the receive buffer)
+  auto prop_entries = [&](const InMsg& im) -> const Entry* {
+    n->ent_tmp.clear();
+    for (uint32_t k = 0; k < im.n_ents; ++k) {
+      const raftq_wire_ent_t& e = n->cur_ents[im.ent_first + k];
+      n->ent_tmp.push_back(Entry{e.term, (const char*)n->cur_bytes + e.data_off, e.data_len});
+    }
+    return n->ent_tmp.data();
+  };
+  // report the grown logs' tails, publish what that committed, then bcastAppend
+  auto flush_dirty = [&]() -> int {
+    for (uint64_t gi : dirty) {
+      Group& g = n->groups[gi];
+      raftq_log_delta_t d{gi, g.log.size(), g.term, 0};
+      n->deltas.push_back(d);
+    }
+    if (int rc = flush_deltas(n, lk)) return rc;
+    for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
+    return RAFTQ_OK;
+  };
   while (!work.empty()) {
     ph.next(raftq_node::kPhStage);
     batch.clear();
     deferred.clear();
-    blocked.clear();
     dirty.clear();
-    for (InMsg& im : work) {
-      if (blocked.count(im.h.group)) {
-        deferred.push_back(std::move(im));
+    const uint32_t ep = next_epoch();
+    size_t n_step = 0;
+    for (const InMsg& im : work) {
+      if (n->blocked_mark[im.h.group] == ep) {
+        deferred.push_back(im);
         continue;
       }
-      if (im.h.type == RAFTQ_MSG_PROP || im.h.type == RAFTQ_MSG_APP) blocked.insert(im.h.group);
-      batch.push_back(std::move(im));
+      if (im.h.type == RAFTQ_MSG_PROP || im.h.type == RAFTQ_MSG_APP) n->blocked_mark[im.h.group] = ep;
+      n_step += im.h.type != RAFTQ_MSG_PROP;  // MsgProp never reaches Step; everything else does, in arrival order
+      batch.push_back(im);
     }
-    // MsgProp never reaches Step; everything else does, in arrival order
-    std::vector<size_t> idx;  // batch position of each stepped message
     raftq_msg_t* staged = nullptr;
     lk.unlock();
-    size_t n_step = 0;
-    for (const InMsg& im : batch) n_step += im.h.type != RAFTQ_MSG_PROP;
     const raftq_step_out_t* outs = nullptr;
     if (n_step) {
       int rc = raftq_step_stage(n->h, n_step, &staged);
       if (rc != RAFTQ_OK) return poison(n, rc, "step_stage");
-      idx.reserve(n_step);
-      for (size_t i = 0; i < batch.size(); ++i)
-        if (batch[i].h.type != RAFTQ_MSG_PROP) {
-          staged[idx.size()] = batch[i].h;
-          idx.push_back(i);
-        }
+      size_t k = 0;
+      for (const InMsg& im : batch)
+        if (im.h.type != RAFTQ_MSG_PROP) staged[k++] = im.h;
       ph.next(raftq_node::kPhStep);
       rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
       uint64_t n_out = 0;
@@ -984,43 +1139,40 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     n->stats.msgs_stepped += n_step;
     // consequences, in arrival order (stepped results and proposals interleaved as they came)
     size_t k = 0;
-    for (size_t i = 0; i < batch.size(); ++i) {
-      InMsg& im = batch[i];
+    for (const InMsg& im : batch) {
       if (im.h.type == RAFTQ_MSG_PROP) {
         Group& g = n->groups[im.h.group];
-        if (handle_proposal(n, im.h.group, g, im.ents)) dirty.insert(im.h.group);
+        if (handle_proposal(n, im.h.group, g, prop_entries(im), im.n_ents) && n->dirty_mark[im.h.group] != ep) {
+          n->dirty_mark[im.h.group] = ep;
+          dirty.push_back(im.h.group);
+        }
       } else {
         apply_result(n, outs[k++], im);
       }
     }
     ph.next(raftq_node::kPhDeltas);
-    for (uint64_t gi : dirty) {
-      Group& g = n->groups[gi];
-      raftq_log_delta_t d{gi, g.log.size(), g.term, 0};
-      n->deltas.push_back(d);
-    }
-    if (int rc = flush_deltas(n, lk)) return poison(n, rc, "apply_log_deltas");
-    for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
+    if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
     work.swap(deferred);
   }
   ph.next(raftq_node::kPhProps);
 
   // -- proposeC (raft.go:211-215)
-  if (!props.empty()) {
+  if (props.size()) {
     dirty.clear();
-    for (auto& pr : props) {
-      Group& g = n->groups[pr.first];
-      std::vector<Entry> one;
-      one.push_back(Entry{0, std::move(pr.second)});
-      if (handle_proposal(n, pr.first, g, one)) dirty.insert(pr.first);
+    const uint32_t ep = next_epoch();
+    for (size_t i = 0; i < props.size(); ++i) {
+      const uint64_t gi = props.group[i];
+      const Entry one{0, props.blob.data() + props.off[i], (uint32_t)(props.off[i + 1] - props.off[i])};
+      if (handle_proposal(n, gi, n->groups[gi], &one, 1) && n->dirty_mark[gi] != ep) {
+        n->dirty_mark[gi] = ep;
+        dirty.push_back(gi);
+      }
     }
-    for (uint64_t gi : dirty) {
-      Group& g = n->groups[gi];
-      raftq_log_delta_t d{gi, g.log.size(), g.term, 0};
-      n->deltas.push_back(d);
-    }
-    if (int rc = flush_deltas(n, lk)) return poison(n, rc, "apply_log_deltas");
-    for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
+    if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
+  }
+  if (n->oom) {
+    lk.unlock();
+    return poison(n, RAFTQ_ENOMEM, "entry storage");
   }
   // -- wal.Save before transport.Send (raft.go:228-230): the caller persists what raftq_node_wal_poll
   // hands out before it transmits what raftq_node_poll hands out
@@ -1033,6 +1185,10 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   lk.unlock();
   if (pub) n->cv_commit.notify_all();
   if (n_published) *n_published = pub;
+  if (n->profiling && n->prof_every && n->prof_turns >= n->prof_every) {
+    ph.next(raftq_node::kPhEncode);
+    dump_profile(n);
+  }
   return RAFTQ_OK;
 }
 
@@ -1102,7 +1258,7 @@ int raftq_node_replay_wal(raftq_node_t* n, const void* wal, uint64_t len, int re
   for (uint64_t i = 0; i < nf; ++i) {
     const raftq_wal_rec_t& r = recs[i];
     if (r.kind == RAFTQ_WAL_ENTRY) {
-      if (r.group >= n->G || !log_put(n->groups[r.group], r.index, r.term, base + r.data_off, r.data_len)) {
+      if (r.group >= n->G || !log_put(n, n->groups[r.group], r.index, r.term, base + r.data_off, r.data_len)) {
         n->errtext = "replay_wal: entry record " + std::to_string(i) + " has no place in its group's log";
         return RAFTQ_EINVAL;
       }
@@ -1144,8 +1300,8 @@ int raftq_node_recv(raftq_node_t* n, uint64_t group, int timeout_ms, void* buf, 
   if (g.qhead < g.q.size()) {
     Item& it = g.q[g.qhead];
     *kind = it.kind;
-    if (len) *len = (uint32_t)it.data.size();
-    if (buf && cap) std::memcpy(buf, it.data.data(), std::min<size_t>(cap, it.data.size()));
+    if (len) *len = it.len;
+    if (buf && cap) std::memcpy(buf, it.data, std::min<size_t>(cap, it.len));
     g.qhead++;
     if (g.qhead == g.q.size()) {
       g.q.clear();
@@ -1174,6 +1330,25 @@ int raftq_node_status(raftq_node_t* n, uint64_t group, raftq_node_status_t* st) 
   return RAFTQ_OK;
 }
 
+int raftq_node_status_batch(raftq_node_t* n, uint64_t first_group, uint64_t count, raftq_node_status_t* st) {
+  if (!n || (count && !st)) return RAFTQ_EINVAL;
+  if (first_group > n->G || count > n->G - first_group) return nfail(n, RAFTQ_EINVAL, "status_batch: range out of bounds");
+  std::lock_guard<std::mutex> lk(n->mu);
+  for (uint64_t i = 0; i < count; ++i) {
+    const Group& g = n->groups[first_group + i];
+    raftq_node_status_t& o = st[i];
+    std::memset(&o, 0, sizeof(o));
+    o.term = g.term;
+    o.commit = g.committed;
+    o.last_index = g.log.size();
+    o.applied = g.applied;
+    o.lead = g.lead;
+    o.vote = g.vote;
+    o.role = g.role;
+  }
+  return RAFTQ_OK;
+}
+
 int raftq_node_stats(raftq_node_t* n, raftq_node_stats_t* st) {
   if (!n || !st) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> lk(n->mu);
@@ -1192,9 +1367,9 @@ int raftq_node_entry(raftq_node_t* n, uint64_t group, uint64_t index, void* buf,
     return RAFTQ_EINVAL;
   }
   const Entry& e = g.log[index - 1];
-  if (len) *len = (uint32_t)e.data.size();
+  if (len) *len = e.len;
   if (term) *term = e.term;
-  if (buf && cap) std::memcpy(buf, e.data.data(), std::min<size_t>(cap, e.data.size()));
+  if (buf && cap) std::memcpy(buf, e.data, std::min<size_t>(cap, e.len));
   return RAFTQ_OK;
 }
 
@@ -1216,12 +1391,7 @@ const char* raftq_node_last_error(const raftq_node_t* n) { return n ? n->errtext
 void raftq_node_destroy(raftq_node_t* n) {
   if (!n) return;
   raftq_node_close(n);
-  if (n->profiling && n->prof_turns) {
-    static const char* names[raftq_node::kPhN] = {"decode", "inbound", "tick", "stage", "step", "apply", "deltas", "props", "wal", "encode"};
-    std::fprintf(stderr, "[raftq_node %u] advance phases, total ms over %llu turns:", n->self, (unsigned long long)n->prof_turns);
-    for (int i = 0; i < raftq_node::kPhN; ++i) std::fprintf(stderr, " %s %.1f", names[i], n->prof[i] / 1e3);
-    std::fprintf(stderr, "\n");
-  }
+  if (n->profiling && n->prof_turns) dump_profile(n);
   raftq_destroy(n->h);
   delete n;
 }

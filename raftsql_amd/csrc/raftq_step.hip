@@ -680,26 +680,35 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   if (int rc = ensure_node_state(h)) return rc;
   const size_t off_out = align256((size_t)n * sizeof(raftq_log_delta_t));
   if (int rc = ensure_staging(h, off_out + (size_t)n * 8)) return rc;
-  // records of one group apply in order: the k-th record of a group goes into launch k.  One counting sort
-  // on the round number buckets the batch in O(n) whatever the skew (a hot group repeated k times used to cost
-  // k passes over the batch); launches stay one per round.
   if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: batch too large (n must fit 32 bits)");
-  std::vector<uint32_t> round, pos_of;  // pos_of[staged position] = caller's index
-  std::vector<uint64_t> round_start;    // staged position where round r begins (+ the end)
+  // The common batch names every group once: one round, caller order, no bookkeeping.  Whether it does is found
+  // with a per-group mark (epoch << 32 | records seen this call) -- an array lookup per record, not a hash map:
+  // the map this replaces was most of the call's host time at 10^4 records (raftq_node's "deltas" phase).
+  std::vector<uint32_t>& round = h->ld_round;    // per record: its round
+  std::vector<uint32_t>& pos_of = h->ld_pos;     // pos_of[staged position] = caller's index
+  std::vector<uint64_t>& round_start = h->ld_start;  // staged position where round r begins (+ the end)
   uint32_t n_rounds = 1;
   try {
+    if (h->ld_mark.size() != h->G) h->ld_mark.assign(h->G, 0);
+    if (++h->ld_epoch == 0) {
+      std::fill(h->ld_mark.begin(), h->ld_mark.end(), 0ull);
+      h->ld_epoch = 1;
+    }
+    const uint64_t ep = (uint64_t)h->ld_epoch << 32;
     round.resize(n);
-    pos_of.resize(n);
-    std::unordered_map<uint64_t, uint32_t> seen;
-    seen.reserve((size_t)n * 2);
     for (uint64_t i = 0; i < n; ++i) {
-      const uint32_t r = seen[d[i].group]++;
+      uint64_t& mk = h->ld_mark[d[i].group];
+      const uint32_t r = (mk >> 32) == h->ld_epoch ? (uint32_t)mk : 0;
+      mk = ep | (r + 1);
       round[i] = r;
       n_rounds = std::max(n_rounds, r + 1);
     }
-    round_start.assign((size_t)n_rounds + 1, 0);
-    for (uint64_t i = 0; i < n; ++i) round_start[round[i] + 1]++;
-    for (uint32_t r = 0; r < n_rounds; ++r) round_start[r + 1] += round_start[r];
+    if (n_rounds > 1) {
+      pos_of.resize(n);
+      round_start.assign((size_t)n_rounds + 1, 0);
+      for (uint64_t i = 0; i < n; ++i) round_start[round[i] + 1]++;
+      for (uint32_t r = 0; r < n_rounds; ++r) round_start[r + 1] += round_start[r];
+    }
   } catch (...) {
     return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
   }
@@ -707,8 +716,23 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
   uint64_t* out_h = (uint64_t*)((uint8_t*)h->stage_h + off_out);
   uint64_t* out_d = (uint64_t*)((uint8_t*)h->stage_d + off_out);
+  auto launch = [&](uint64_t start, uint64_t m) {
+    hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m,
+                       committed_out ? out_d + start : (uint64_t*)nullptr);
+  };
+  if (n_rounds == 1) {
+    std::memcpy(dst, d, (size_t)n * sizeof(raftq_log_delta_t));
+    launch(0, n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (committed_out) std::memcpy(committed_out, out_h, (size_t)n * 8);
+    return RAFTQ_OK;
+  }
   {
-    std::vector<uint64_t> fill(round_start.begin(), round_start.end() - 1);  // stable: caller order within a round
+    // records of one group apply in order: the k-th record of a group goes into launch k.  One counting sort on
+    // the round number buckets the batch in O(n) whatever the skew; stable, so caller order within a round
+    std::vector<uint64_t> fill(round_start.begin(), round_start.end() - 1);
     for (uint64_t i = 0; i < n; ++i) {
       const uint64_t pos = fill[round[i]]++;
       pos_of[pos] = (uint32_t)i;
@@ -718,9 +742,7 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   for (uint32_t r = 0; r < n_rounds; ++r) {
     const uint64_t start = round_start[r], m = round_start[r + 1] - start;
     if (m == 0) continue;
-    hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m,
-                       committed_out ? out_d + start : (uint64_t*)nullptr);
+    launch(start, m);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));

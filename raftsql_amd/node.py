@@ -23,6 +23,11 @@ class Status(C.Structure):
                 ("lead", C.c_uint32), ("vote", C.c_uint32), ("role", C.c_uint8), ("_pad", C.c_uint8 * 7)]
 
 
+STATUS_DTYPE = np.dtype([("term", "<u8"), ("commit", "<u8"), ("last_index", "<u8"), ("applied", "<u8"), ("lead", "<u4"),
+                         ("vote", "<u4"), ("role", "u1"), ("_pad", "u1", 7)])
+assert STATUS_DTYPE.itemsize == C.sizeof(Status)
+
+
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("turns", "msgs_stepped", "msgs_sent", "entries_published", "hard_states",
                                           "proposals_dropped", "frames_dropped", "wal_records")]
@@ -45,6 +50,7 @@ _SIGS = [
     ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int)]),
     ("raftq_node_status", C.c_int, [_P, C.c_uint64, C.POINTER(Status)]),
+    ("raftq_node_status_batch", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("raftq_node_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("raftq_node_entry", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint64)]),
@@ -184,6 +190,14 @@ class RaftNode:
         self._chk(self._lib.raftq_node_status(self._p, group, C.byref(st)))
         return st
 
+    def statuses(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """raft.Node.Status() of `count` groups from `first` in one call: a structured array with the fields of
+        `Status` (term, commit, last_index, applied, lead, vote, role)"""
+        count = self.n_groups - first if count is None else count
+        out = np.zeros(count, dtype=STATUS_DTYPE)
+        self._chk(self._lib.raftq_node_status_batch(self._p, first, count, out.ctypes.data))
+        return out
+
     def stats(self) -> dict:
         st = Stats()
         self._chk(self._lib.raftq_node_stats(self._p, C.byref(st)))
@@ -199,7 +213,7 @@ class RaftNode:
         return [self.entry(group, i) for i in range(1, int(self.status(group).last_index) + 1)]
 
     def roles(self) -> np.ndarray:
-        return np.array([self.status(g).role for g in range(self.n_groups)], dtype=np.uint8)
+        return self.statuses()["role"].copy()
 
     def close(self) -> int:
         if self._p.value:
@@ -233,8 +247,16 @@ class Cluster:
     `cut` holds (a, b) pairs whose traffic is dropped in both directions."""
 
     def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7,
-                 wal: bool = False):
+                 wal: bool = False, threads: bool = False):
         self.G, self.N, self.device, self.election_tick, self.seed = n_groups, n_peers, device, election_tick, seed
+        # threads=True: every node's turn (tick, advance, WAL poll, outbound poll) runs on its own thread, as N
+        # machines would; the library calls release the GIL and each node has its own engine handle and stream.
+        # The transport (deliver) stays on the caller's thread, after all turns: what a turn receives is the same.
+        self._pool = None
+        if threads:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=n_peers)
         self.nodes: list[Optional[RaftNode]] = [RaftNode(n_groups, n_peers, p, device) for p in range(n_peers)]
         # wal=True: every node produces its WAL (raftq_node_wal_enable); self.wal[p] is node p's "disk"
         self.wal_on = wal
@@ -252,23 +274,29 @@ class Cluster:
         for p, nd in enumerate(self.nodes):
             nd.start(self.election_tick, 1, seed=self.seed + 1000 * p)
 
+    def _turn(self, p: int, tick: bool):
+        """one iteration of node p's serveChannels loop -> (published, its outbound bytes per addressee)"""
+        nd = self.nodes[p]
+        if tick:
+            nd.tick()
+        published = nd.advance()
+        if self.wal_on:
+            self.wal[p] += nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
+        return published, [nd.poll(q) if q != p else b"" for q in range(self.N)]
+
     def step(self, tick: bool = True) -> int:
+        live = [p for p in range(self.N) if p not in self.down]
+        if self._pool is not None:
+            turns = list(self._pool.map(lambda p: self._turn(p, tick), live))
+        else:
+            turns = [self._turn(p, tick) for p in live]
         published = 0
-        for p, nd in enumerate(self.nodes):
-            if p in self.down:
-                continue
-            if tick:
-                nd.tick()
-            published += nd.advance()
-            if self.wal_on:
-                self.wal[p] += nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
-        for p, nd in enumerate(self.nodes):
-            if p in self.down:
-                continue
+        for p, (pub, out) in zip(live, turns):
+            published += pub
             for q in range(self.N):
                 if q == p:
                     continue
-                frames = nd.poll(q)
+                frames = out[q]
                 if q in self.down or (p, q) in self.cut or (q, p) in self.cut:
                     continue  # lost on the wire
                 if self.loss and frames and self._rng.random() < self.loss:
@@ -296,10 +324,10 @@ class Cluster:
         for p, nd in enumerate(self.nodes):
             if p in self.down:
                 continue
-            for g in range(self.G):
-                st = nd.status(g)
-                if st.role == ROLE_LEADER and st.term >= best[g]:
-                    out[g], best[g] = p, st.term
+            st = nd.statuses()
+            take = (st["role"] == ROLE_LEADER) & (st["term"] >= best)
+            out[take] = p
+            best[take] = st["term"][take]
         return out
 
     def stop(self, p: int) -> list[list[tuple[int, bytes]]]:
@@ -307,10 +335,10 @@ class Cluster:
         would also hold are kept in self.hard_states[p] as (term, vote, commit) per group"""
         nd = self.nodes[p]
         logs = [nd.log(g) for g in range(self.G)]
-        sts = [nd.status(g) for g in range(self.G)]
+        sts = nd.statuses()
         if not hasattr(self, "hard_states"):
             self.hard_states = {}
-        self.hard_states[p] = [(int(st.term), int(st.vote), int(st.commit)) for st in sts]
+        self.hard_states[p] = [(int(st["term"]), int(st["vote"]), int(st["commit"])) for st in sts]
         assert nd.close() == 0
         nd.destroy()
         self.down.add(p)
@@ -341,6 +369,9 @@ class Cluster:
         return nd
 
     def close(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         for p, nd in enumerate(self.nodes):
             if nd is not None and p not in self.down:
                 nd.destroy()

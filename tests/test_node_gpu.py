@@ -611,3 +611,90 @@ def test_propose_batch_is_propose_k_times(Cluster):
         assert all(nd.drain(0) == [] for nd in c.nodes)
     finally:
         c.close()
+
+
+def test_status_batch_is_status_g_times(Cluster):
+    """raftq_node_status_batch: the same seven fields as raftq_node_status for every group of a range, in one
+    call; ranges are checked."""
+    from raftsql_amd.engine import RaftqError
+
+    c = Cluster(300, 3, seed=4)
+    try:
+        c.start()
+        elect(c, max_ticks=200)
+        lead = c.leaders()
+        for g in range(0, 300, 3):
+            c.nodes[int(lead[g])].propose(g, b"s%d" % g)
+        c.settle()
+        for nd in c.nodes:
+            st = nd.statuses()
+            assert st.shape == (300,)
+            for g in range(300):
+                one = nd.status(g)
+                for f in ("term", "commit", "last_index", "applied", "lead", "vote", "role"):
+                    assert int(st[f][g]) == int(getattr(one, f)), (g, f)
+            part = nd.statuses(17, 40)
+            assert part.tobytes() == st[17:57].tobytes()
+            assert nd.statuses(300, 0).shape == (0,)
+            with pytest.raises(RaftqError):
+                nd.statuses(290, 11)
+            assert np.array_equal(nd.roles(), st["role"])
+    finally:
+        c.close()
+
+
+def test_threaded_cluster_is_the_serial_cluster(Cluster):
+    """Cluster(threads=True) runs every node's turn on its own thread (what N machines do); the transport still
+    moves the bytes after all turns, so the run is the serial run: same leaders, same logs, same statistics."""
+    runs = []
+    for threads in (False, True):
+        c = Cluster(1500, 3, seed=21, threads=threads)
+        try:
+            c.start()
+            elect(c, max_ticks=200)
+            lead = c.leaders()
+            for r in range(3):
+                for p, nd in enumerate(c.nodes):
+                    mine = np.nonzero(lead == p)[0]
+                    nd.propose_batch(mine, [b"r%d g%d" % (r, g) for g in mine])
+                c.settle()
+                c.run(2)
+            c.settle()
+            check_safety(c)
+            runs.append((lead.copy(), [nd.statuses().tobytes() for nd in c.nodes], [nd.stats() for nd in c.nodes],
+                         [[nd.drain(g) for g in range(0, 1500, 37)] for nd in c.nodes]))
+        finally:
+            c.close()
+    a, b = runs
+    assert np.array_equal(a[0], b[0])
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    assert all(ch == [None, b"r0 g%d" % g, b"r1 g%d" % g, b"r2 g%d" % g] for g, ch in zip(range(0, 1500, 37), a[3][0]))
+
+
+def test_many_proposals_per_group_in_one_turn(Cluster):
+    """A burst of 200 proposals for ONE group (and one each for the others) in one turn: the entries keep their
+    order through the arena-backed log, MsgApp batching and the per-group rounds of the log-tail report."""
+    c = Cluster(16, 3, seed=9)
+    try:
+        c.start()
+        elect(c, max_ticks=200)
+        lead = c.leaders()
+        hot = 5
+        burst = [b"hot-%03d-" % i + b"x" * (i % 50) for i in range(200)]
+        nd = c.nodes[int(lead[hot])]
+        nd.propose_batch([hot] * len(burst), burst)
+        for g in range(16):
+            if g != hot:
+                c.nodes[int(lead[g])].propose(g, b"cold%d" % g)
+        c.settle()
+        c.run(2)
+        c.settle()
+        for node in c.nodes:
+            assert [d for d in node.drain(hot) if d is not None] == burst
+            for g in range(16):
+                if g != hot:
+                    assert [d for d in node.drain(g) if d is not None] == [b"cold%d" % g]
+            assert [e[1] for e in node.log(hot)][-200:] == burst
+        check_safety(c)
+    finally:
+        c.close()

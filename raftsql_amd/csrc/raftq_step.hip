@@ -5,17 +5,16 @@
 #include "raftq_step.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <unordered_map>
 #include <vector>
 
 #include "raftq_internal.hpp"
 #include "raftq_step_kernels.hpp"
 #include "raftq_wire.h"
+#include "raftq_sort_kernels.hpp"
 #include "raftq_wire_kernels.hpp"
 
 using namespace raftqk;
@@ -81,8 +80,8 @@ struct Scratch {
   uint32_t *order_in, *order_out;
   uint32_t* next;  // sort-free walk: list links
   unsigned long long* n_heads;
-  void* cub_temp;
-  size_t cub_bytes;
+  void* sort_scratch;
+  size_t sort_bytes;
   // raftq_step_submit_wire only: the staged frames and what the decoder needs
   uint64_t* w_off;       // [n + 1] frame offsets, the stream bytes right behind them
   uint8_t* w_stream;
@@ -90,8 +89,8 @@ struct Scratch {
   unsigned long long* w_bad;
   WireEnt* w_ents;
   uint64_t w_ents_cap;
-  void* w_cub;
-  size_t w_cub_bytes;
+  void* w_scan;
+  size_t w_scan_bytes;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -118,27 +117,25 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
     HIPCHK(h, hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
   }
-  size_t cub_bytes = 0;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, end_bit,
-                                               h->stream));
+  (void)end_bit;
+  const size_t sort_bytes = raftqk::radix_plan(n).bytes;  // digit counts of the hand-written radix sort (raftq_sort_kernels.hpp)
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
   // the 16-byte {touched count, bad flag} tail sits right behind the result records: one copy moves both
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
-               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_cub = carve(cub_bytes), o_next = carve(n * 4);
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_sort = carve(sort_bytes), o_next = carve(n * 4);
   const size_t o_nh = o_outs + tail_off(n, h->step_compact ? sizeof(StepOutC) : sizeof(StepOutRec));
   // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
-  size_t w_cub_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wcub = 0;
+  size_t w_scan_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wscan = 0;
   if (wire) {
-    w_cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan (raftq_wire_kernels.hpp)
+    w_scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan (raftq_wire_kernels.hpp)
     o_wfr = carve((n + 1) * 8 + wire_nbytes + 16);
     o_wcnt = carve((n + 1) * 8);
     o_wbase = carve((n + 1) * 8);
     o_wbad = carve(8);
     o_wents = carve(w_ents_cap * sizeof(WireEnt));
-    o_wcub = carve(w_cub_bytes);
+    o_wscan = carve(w_scan_bytes);
   }
   if (off > sl.dev_bytes) {  // the slot is idle (its previous batch was collected): safe to regrow
     if (sl.dev) {
@@ -173,8 +170,8 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   s->order_out = (uint32_t*)(base + o_oo);
   s->next = (uint32_t*)(base + o_next);
   s->n_heads = (unsigned long long*)(base + o_nh);
-  s->cub_temp = base + o_cub;
-  s->cub_bytes = cub_bytes;
+  s->sort_scratch = base + o_sort;
+  s->sort_bytes = sort_bytes;
   s->w_off = (uint64_t*)(base + o_wfr);
   s->w_stream = base + o_wfr + (n + 1) * 8;
   s->w_cnt = (uint64_t*)(base + o_wcnt);
@@ -182,8 +179,8 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   s->w_bad = (unsigned long long*)(base + o_wbad);
   s->w_ents = (WireEnt*)(base + o_wents);
   s->w_ents_cap = w_ents_cap;
-  s->w_cub = base + o_wcub;
-  s->w_cub_bytes = w_cub_bytes;
+  s->w_scan = base + o_wscan;
+  s->w_scan_bytes = w_scan_bytes;
   return RAFTQ_OK;
 }
 
@@ -363,12 +360,11 @@ static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
                      h->G, h->N, bad, from_wire);
   HIPCHK(h, hipGetLastError());
-  size_t cub_bytes = s.cub_bytes;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(s.cub_temp, cub_bytes, (const uint64_t*)s.keys_in, s.keys_out,
-                                               (const uint32_t*)s.order_in, s.order_out, (int)n, 0, end_bit, h->stream));
+  int in_b = 0;  // which pair of buffers the sorted (group, batch position) pairs end up in
+  HIPCHK(h, raftqk::radix_sort_pairs(h->stream, s.sort_scratch, s.keys_in, s.order_in, s.keys_out, s.order_out, n, end_bit, &in_b));
   hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
-                     (const uint64_t*)s.keys_out, (const uint32_t*)s.order_out, outs, h->step_compact, n, s.n_heads,
-                     (const unsigned int*)bad);
+                     (const uint64_t*)(in_b ? s.keys_out : s.keys_in), (const uint32_t*)(in_b ? s.order_out : s.order_in), outs,
+                     h->step_compact, n, s.n_heads, (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
@@ -526,7 +522,7 @@ static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSl
     // message order, ent_first of every message), kept out of the Step chain because Step does not need it
     Scratch s;
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, true, sl.w_nbytes)) return rc;
-    HIPCHK(h, exclusive_sum_u64((const uint64_t*)s.w_cnt, s.w_base, sl.n + 1, (uint64_t*)s.w_cub, st));
+    HIPCHK(h, exclusive_sum_u64((const uint64_t*)s.w_cnt, s.w_base, sl.n + 1, (uint64_t*)s.w_scan, st));
     hipLaunchKernelGGL(wire_dec_ents_kernel, dim3((unsigned)((sl.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        (const uint8_t*)s.w_stream, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base,
                        s.w_ents, s.w_ents_cap);

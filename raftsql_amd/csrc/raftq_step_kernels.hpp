@@ -6,8 +6,8 @@
 // messages in order and scatters the state back.  Two ways to group (same bytes out):
 //   list walk (default):  step_link_kernel threads every message onto its group's list with
 //       three atomics, the lane of the group's first message orders and walks it (2b / 3b)
-//   sorted walk (fallback for long runs): (1) keys, (2) hipCUB stable radix sort of
-//       (group, position), (3) step_kernel: one lane per run of equal keys
+//   sorted walk (fallback for long runs): (1) keys, (2) stable radix sort of (group, position)
+//       (raftq_sort_kernels.hpp), (3) step_kernel: one lane per run of equal keys
 // Different lanes touch different groups, so there are no atomics on state and the result is
 // identical to calling Step message by message (tests/test_step_gpu.py).
 //
@@ -328,7 +328,7 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
 }
 
 // ---- (2b, 3b) the same walk WITHOUT the sort.  Inbound traffic rarely brings more than a few messages
-// of one group in one batch, so grouping by a full stable sort (7 hipCUB launches, 55 us of a 95 us kernel
+// of one group in one batch, so grouping by a full stable sort (4-12 launches, 40-60 us of a 95 us kernel
 // chain at 64K messages) is the wrong tool.  step_link_kernel threads every message onto its group's list
 // with three atomics on group-indexed arrays (exchange the list head, count, minimum batch position);
 // the lane of a group's FIRST message then owns the group: it gathers the list (arbitrary order), sorts

@@ -23,7 +23,7 @@ static_assert(sizeof(raftq_wire_msg_t) == sizeof(WireMsg) && sizeof(raftq_wire_e
 
 namespace {
 
-constexpr uint64_t kMaxItems = 0x7ffffffeull;  // hipCUB item counts are int
+constexpr uint64_t kMaxItems = 0x7ffffffeull;  // batch positions travel as 31-bit values
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -121,11 +121,11 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: null argument");
   if (n > kMaxItems || n_ents > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
+  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_msgs = c.take(n * sizeof(WireMsg)), o_ents = c.take(n_ents * sizeof(WireEnt)),
                o_pool = c.take(pool_bytes), o_sizes = c.take((n + 1) * 8), o_off = c.take((n + 1) * 8),
-               o_bad = c.take(8), o_cub = c.take(cub_bytes);
+               o_bad = c.take(8), o_scan = c.take(scan_bytes);
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   uint8_t* base = (uint8_t*)h->wire_dev;
   WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
@@ -140,7 +140,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
                      (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_cub), h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -182,10 +182,10 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (int rc = ensure_pin(h)) return rc;
   // an entry costs its message at least two bytes (tag, length), so this many can never be exceeded
   const uint64_t dev_cap = std::min<uint64_t>(ents_cap, nbytes / 2 + 1);
-  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
+  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_stream = c.take(nbytes), o_off = c.take((n + 1) * 8), o_msgs = c.take(n * sizeof(WireMsg)),
-               o_cnt = c.take((n + 1) * 8), o_base = c.take((n + 1) * 8), o_bad = c.take(8), o_cub = c.take(cub_bytes);
+               o_cnt = c.take((n + 1) * 8), o_base = c.take((n + 1) * 8), o_bad = c.take(8), o_scan = c.take(scan_bytes);
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, dev_cap * sizeof(WireEnt) + 16)) return rc;
   uint8_t* base = (uint8_t*)h->wire_dev;
@@ -200,7 +200,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   hipLaunchKernelGGL(wire_dec_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      nbytes, (const uint64_t*)d_off, n, d_msgs, d_cnt, d_bad);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_cnt, d_base, n + 1, (uint64_t*)(base + o_cub), h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_cnt, d_base, n + 1, (uint64_t*)(base + o_scan), h->stream));
   hipLaunchKernelGGL(wire_dec_ents_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
                      dev_cap);
@@ -240,11 +240,11 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (!recs || (pool_bytes && !pool) || (cap && !out)) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  const size_t cub_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
+  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
                o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
-               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_cub = c.take(cub_bytes),
+               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_scan = c.take(scan_bytes),
                o_tot = c.take((size_t)blocks_for(n) * sizeof(CrcPair));
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   uint8_t* base = (uint8_t*)h->wire_dev;
@@ -267,7 +267,7 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   hipLaunchKernelGGL(wal_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
                      (const CrcPair*)d_chain, d_sizes);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_cub), h->stream));
+  HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));

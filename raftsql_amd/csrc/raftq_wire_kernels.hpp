@@ -11,8 +11,8 @@
 //     (16 B per lane per step) and CRCs the long ones cooperatively.
 //   * CRC-32C: per-record CRCs are independent (LDS table, one lane per record; 64 lanes per long
 //     record).  The running CRC that chains the records of a WAL segment is a scan over affine maps
-//     x -> x * X^(8 len) + crc in GF(2)[X]/P: an associative, non-commutative operator (hipCUB
-//     DeviceScan).  A crcType record that re-seeds the chain is the constant map (multiplier 0).
+//     x -> x * X^(8 len) + crc in GF(2)[X]/P: an associative, non-commutative operator (a hand-written
+//     two-launch scan, below).  A crcType record that re-seeds the chain is the constant map (multiplier 0).
 // Bound: PCIe (the ABI takes and returns host buffers) -- these kernels are a few us per 64K
 // records; DESIGN.md 4.10 has the measured split.
 #pragma once

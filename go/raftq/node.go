@@ -278,3 +278,14 @@ func (m *MultiRaftPipe) Statuses(first, count uint64) ([]NodeStatus, error) {
 	}
 	return out, nil
 }
+
+// Campaign is raft.Node.Campaign for the given groups: each gets a local MsgHup at the next turn of the crank.
+func (m *MultiRaftPipe) Campaign(groups []uint64) error {
+	if len(groups) == 0 {
+		return nil
+	}
+	if rc := C.raftq_node_campaign(m.n, (*C.uint64_t)(unsafe.Pointer(&groups[0])), C.uint64_t(len(groups))); rc != C.RAFTQ_OK {
+		return nodeErr(m.n, rc)
+	}
+	return nil
+}

@@ -122,6 +122,11 @@ int raftq_node_propose(raftq_node_t* n, uint64_t group, const void* data, uint32
 int raftq_node_propose_batch(raftq_node_t* n, const uint64_t* groups, const uint64_t* offsets /*[k+1]*/, const void* blob,
                              uint64_t k);
 int raftq_node_tick(raftq_node_t* n);
+/* raft.Node.Campaign(ctx) for k groups: each gets a local MsgHup at the next raftq_node_advance(), before the messages
+ * received since and whatever the election timers raise.  The reference never calls it (raft.go uses Propose / Tick /
+ * Ready / Advance / Step / Stop); it is here so that message-driven scenarios -- etcd's own raft_test.go network tests
+ * (tests/test_node_scenarios_gpu.py) -- can elect a chosen node without waiting for a randomised timer. */
+int raftq_node_campaign(raftq_node_t* n, const uint64_t* groups, uint64_t k);
 int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len);
 /* one Ready-loop iteration for all groups; *n_published = entries put on commit channels */
 int raftq_node_advance(raftq_node_t* n, uint64_t* n_published);

@@ -185,6 +185,7 @@ struct raftq_node {
   const raftq_wire_ent_t* cur_ents = nullptr;
   const uint8_t* cur_bytes = nullptr;
   uint32_t pending_ticks = 0;
+  std::vector<uint64_t> pending_hups, turn_hups;  // raftq_node_campaign: groups to raise MsgHup for at the next advance
   std::vector<PeerQueue> outbound;  // [peer]
   // inbound stream frames as delivered (decoded on the GPU at the next advance)
   PinBuf in_bytes;
@@ -876,6 +877,26 @@ int raftq_node_propose_batch(raftq_node_t* n, const uint64_t* groups, const uint
   return RAFTQ_OK;
 }
 
+int raftq_node_campaign(raftq_node_t* n, const uint64_t* groups, uint64_t k) {
+  if (!n) return RAFTQ_EINVAL;
+  if (k == 0) return RAFTQ_OK;
+  if (!groups) return nfail(n, RAFTQ_EINVAL, "campaign: null argument");
+  for (uint64_t i = 0; i < k; ++i)
+    if (groups[i] >= n->G) return nfail(n, RAFTQ_EINVAL, "campaign: group out of range; nothing was queued");
+  std::lock_guard<std::mutex> lk(n->mu);
+  if (!n->started || n->closed) {
+    n->errtext = "campaign: node not running";
+    return RAFTQ_ESTATE;
+  }
+  try {
+    n->pending_hups.insert(n->pending_hups.end(), groups, groups + k);
+  } catch (...) {
+    n->errtext = "campaign: host allocation failed";
+    return RAFTQ_ENOMEM;
+  }
+  return RAFTQ_OK;
+}
+
 int raftq_node_tick(raftq_node_t* n) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> lk(n->mu);
@@ -970,6 +991,8 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     std::swap(props, n->proposals);
     ticks = n->pending_ticks;
     n->pending_ticks = 0;
+    n->turn_hups.clear();
+    n->turn_hups.swap(n->pending_hups);
   }
   // -- rafthttp's messageDecoder + Message.Unmarshal for everything received since the last turn, on
   // the GPU (raftq_wire_decode).  Frames that do not parse, are not addressed to this node's slot, come
@@ -1026,12 +1049,18 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
   std::unique_lock<std::mutex> lk(n->mu);
   const uint64_t published0 = n->stats.entries_published;
   n->stats.frames_dropped += dropped;
-  bool did = !work.empty() || props.size() != 0 || ticks != 0 || dropped != 0;
+  bool did = !work.empty() || props.size() != 0 || ticks != 0 || dropped != 0 || !n->turn_hups.empty();
 
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
   std::vector<InMsg>& hups = n->hups;
   hups.clear();
+  for (uint64_t gi : n->turn_hups) {  // rc.node.Campaign: MsgHup through Step, ahead of what the timers raise
+    InMsg im;
+    im.h = header(n, gi, RAFTQ_MSG_HUP, 0);
+    im.ent_first = im.n_ents = 0;
+    hups.push_back(im);
+  }
   ph.next(raftq_node::kPhTick);
   for (uint32_t t = 0; t < ticks; ++t) {
     lk.unlock();

@@ -43,6 +43,7 @@ _SIGS = [
     ("raftq_node_start", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("raftq_node_propose", C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint32]),
     ("raftq_node_propose_batch", C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]),
+    ("raftq_node_campaign", C.c_int, [_P, C.c_void_p, C.c_uint64]),
     ("raftq_node_tick", C.c_int, [_P]),
     ("raftq_node_deliver", C.c_int, [_P, C.c_void_p, C.c_uint64]),
     ("raftq_node_advance", C.c_int, [_P, C.POINTER(C.c_uint64)]),
@@ -141,6 +142,11 @@ class RaftNode:
         off[1:] = np.cumsum([len(p) for p in payloads])
         blob = b"".join(payloads)
         self._chk(self._lib.raftq_node_propose_batch(self._p, g.ctypes.data, off.ctypes.data, blob, len(payloads)))
+
+    def campaign(self, groups) -> None:
+        """raft.Node.Campaign for these groups: a local MsgHup each at the next advance()"""
+        g = np.ascontiguousarray(np.atleast_1d(groups), dtype=np.uint64)
+        self._chk(self._lib.raftq_node_campaign(self._p, g.ctypes.data, len(g)))
 
     def tick(self) -> None:
         self._chk(self._lib.raftq_node_tick(self._p))

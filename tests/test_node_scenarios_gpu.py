@@ -1,0 +1,313 @@
+"""GPU: etcd's own multi-node scenarios (raft_test.go's `network` tests), AS RECALLED, through raftq_node clusters.
+
+The module the reference imports (github.com/coreos/etcd/raft, raft.go:27-34) is absent here and so are its tests; the
+scenarios below are written from memory of the 2015-era raft_test.go -- alignment evidence, not a pin (oracle
+headers: "parity unpinned").  They matter for the hot path because what they assert is the commit index: when the q-th
+largest match may advance it, and when the term gate (raft paper 5.4.2) must hold it back.
+
+Upstream's `network` is message-driven: `send(m)` delivers m and everything it causes until nothing is in flight; no
+timer ever fires; `cut` / `isolate` / `ignore(type)` / `recover` shape the fabric; a `nopStepper` peer swallows
+everything.  `Net` below is that fabric over raftq_node: every scenario runs on G groups at once (each group an
+independent copy of the scenario), so each `send` is one batched Step / encode / decode per node on the GPU.  Peer ids
+are upstream's (1-based); node slot = id - 1."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HUP, BEAT, PROP, APP, APP_RESP, VOTE, VOTE_RESP, SNAP, HEARTBEAT, HEARTBEAT_RESP = range(10)
+FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
+G = 24
+
+
+class Net:
+    def __init__(self, n, nop=()):
+        from raftsql_amd.node import Cluster
+
+        self.c = Cluster(G, n, seed=3)
+        self.c.start()
+        self.n, self.nop = n, set(nop)
+        self.cuts, self.ignored = set(), set()
+        self.groups = np.arange(G, dtype=np.uint64)
+
+    def close(self):
+        self.c.close()
+
+    def node(self, i):
+        return self.c.nodes[i - 1]
+
+    def live(self):
+        return [i for i in range(1, self.n + 1) if i not in self.nop]
+
+    # -- the fabric ---------------------------------------------------------------------------------------------
+    def cut(self, a, b):
+        self.cuts |= {(a, b), (b, a)}
+
+    def isolate(self, a):
+        for b in range(1, self.n + 1):
+            if b != a:
+                self.cut(a, b)
+
+    def ignore(self, t):
+        self.ignored.add(t)
+
+    def recover(self):
+        self.cuts.clear()
+        self.ignored.clear()
+
+    def _filter(self, blob):
+        from oracle import pywire as W
+
+        off, used = W.scan_frames(blob, big_endian=True)
+        assert used == len(blob)
+        mm, _, bad = W.wire_decode(blob, off)
+        assert bad == 0
+        keep = [blob[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1) if int(mm[i]["type"]) not in self.ignored]
+        return b"".join(keep)
+
+    def pump(self):
+        """deliver until nothing is in flight (upstream: network.send's loop)"""
+        for _ in range(400):
+            moved = False
+            for i in self.live():
+                self.node(i).advance()
+            for i in self.live():
+                for j in range(1, self.n + 1):
+                    if j == i:
+                        continue
+                    blob = self.node(i).poll(j - 1)
+                    if not blob:
+                        continue
+                    moved = True
+                    if j in self.nop or (i, j) in self.cuts:
+                        continue
+                    if self.ignored:
+                        blob = self._filter(blob)
+                    self.node(j).deliver(blob)
+            if not moved:
+                return
+        raise AssertionError("the network did not quiesce")
+
+    # -- upstream's send(...) of the local message kinds ------------------------------------------------------------
+    def hup(self, i):
+        self.node(i).campaign(self.groups)
+        self.pump()
+
+    def beat(self, i):
+        self.node(i).tick()  # heartbeatTick = 1: a tick on a leader is MsgBeat
+        self.pump()
+
+    def prop(self, i, data):
+        self.node(i).propose_batch(self.groups, [data] * G)
+        self.pump()
+
+    def inject(self, to, msgs, ents=None):
+        from oracle import pywire as W
+
+        stream, _ = W.wire_encode(msgs, ents)
+        self.node(to).deliver(stream.tobytes())
+        self.pump()
+
+    # -- what the assertions read -----------------------------------------------------------------------------------
+    def status(self, i):
+        return self.node(i).statuses()
+
+    def expect(self, i, role=None, term=None, commit=None, log=None):
+        st = self.status(i)
+        if role is not None:
+            assert np.all(st["role"] == role), (i, "role", np.unique(st["role"]))
+        if term is not None:
+            assert np.all(st["term"] == term), (i, "term", np.unique(st["term"]))
+        if commit is not None:
+            assert np.all(st["commit"] == commit), (i, "commit", np.unique(st["commit"]))
+        if log is not None:
+            for g in (0, G // 2, G - 1):
+                assert self.node(i).log(g) == log, (i, g, self.node(i).log(g))
+            assert np.all(st["last_index"] == len(log))
+
+
+@pytest.fixture()
+def net(gpu_engine_cls):
+    made = []
+
+    def make(n, nop=()):
+        made.append(Net(n, nop))
+        return made[-1]
+
+    yield make
+    for m in made:
+        m.close()
+
+
+def test_single_node_candidate_and_commit(net):
+    """TestSingleNodeCandidate / TestSingleNodeCommit: one node elects itself; two proposals -> committed = 3."""
+    tt = net(1)
+    tt.hup(1)
+    tt.expect(1, role=LEADER, term=1, commit=1)
+    tt.prop(1, b"some data")
+    tt.prop(1, b"some data")
+    tt.expect(1, commit=3, log=[(1, b""), (1, b"some data"), (1, b"some data")])
+
+
+def test_log_replication(net):
+    """TestLogReplication: (a) one proposal -> committed 2 everywhere; (b) proposal, a second node takes over, another
+    proposal -> committed 4 everywhere, and the committed non-empty entries are the proposals in order."""
+    tt = net(3)
+    tt.hup(1)
+    tt.prop(1, b"somedata")
+    for i in (1, 2, 3):
+        tt.expect(i, commit=2, log=[(1, b""), (1, b"somedata")])
+    tt2 = net(3)
+    tt2.hup(1)
+    tt2.prop(1, b"somedata")
+    tt2.hup(2)
+    tt2.prop(2, b"somedata2")
+    want = [(1, b""), (1, b"somedata"), (2, b""), (2, b"somedata2")]
+    for i in (1, 2, 3):
+        tt2.expect(i, commit=4, log=want)
+        assert [d for d in tt2.node(i).drain(0) if d is not None] == [b"somedata", b"somedata2"]
+    tt2.expect(2, role=LEADER, term=2)
+    tt2.expect(1, role=FOLLOWER, term=2)
+
+
+def test_commit_without_new_term_entry(net):
+    """TestCommitWithoutNewTermEntry: entries of term 1 that reached only 2 of 5 peers commit once the next leader's own
+    entry (becomeLeader's empty one, term 2) is on a quorum -- by counting that entry, they ride along."""
+    tt = net(5)
+    tt.hup(1)
+    tt.cut(1, 3)
+    tt.cut(1, 4)
+    tt.cut(1, 5)
+    tt.prop(1, b"some data")
+    tt.prop(1, b"some data")
+    tt.expect(1, role=LEADER, commit=1)
+    tt.recover()
+    tt.hup(2)  # term 2; its empty entry is index 4
+    tt.expect(1, commit=4)
+    for i in range(1, 6):
+        tt.expect(i, commit=4, log=[(1, b""), (1, b"some data"), (1, b"some data"), (2, b"")])
+
+
+def test_cannot_commit_without_new_term_entry(net):
+    """TestCannotCommitWithoutNewTermEntry: the same start, but the new leader's MsgApp are lost: holding a quorum of
+    VOTES it must not commit the old term's entries (raft 5.4.2: the term gate of the commit-index advance); after the
+    fabric heals, a heartbeat round and one proposal in its own term carry everything: committed = 5."""
+    tt = net(5)
+    tt.hup(1)
+    tt.cut(1, 3)
+    tt.cut(1, 4)
+    tt.cut(1, 5)
+    tt.prop(1, b"some data")
+    tt.prop(1, b"some data")
+    tt.expect(1, commit=1)
+    tt.recover()
+    tt.ignore(APP)  # "avoid committing ChangeTerm proposal"
+    tt.hup(2)
+    tt.expect(2, role=LEADER, term=2, commit=1)  # no log entries from the previous term are committed
+    tt.recover()
+    tt.beat(2)  # "send heartbeat; reset wait"
+    tt.prop(2, b"some data")
+    tt.expect(2, commit=5)
+    for i in range(1, 6):
+        tt.expect(i, log=[(1, b""), (1, b"some data"), (1, b"some data"), (2, b""), (2, b"some data")])
+
+
+def test_dueling_candidates(net):
+    """TestDuelingCandidates: 1 and 3 cannot see each other; 1 wins term 1 with 2's vote, 3 stays a candidate; healed,
+    3 campaigns again with an empty log: term 2 everywhere, nobody votes for it -- 1 steps down, 3 gives up on a quorum
+    of rejections.  Logs: 1 and 2 keep the term-1 entry (committed), 3's stays empty."""
+    tt = net(3)
+    tt.cut(1, 3)
+    tt.hup(1)
+    tt.hup(3)
+    tt.expect(1, role=LEADER, term=1)
+    tt.expect(3, role=CANDIDATE, term=1)
+    tt.recover()
+    tt.hup(3)
+    tt.expect(1, role=FOLLOWER, term=2, commit=1, log=[(1, b"")])
+    tt.expect(2, role=FOLLOWER, term=2, commit=1, log=[(1, b"")])
+    tt.expect(3, role=FOLLOWER, term=2, commit=0, log=[])
+
+
+def test_candidate_concede(net):
+    """TestCandidateConcede: an isolated candidate (term 1) meets the leader the others elected in the same term: the
+    heartbeat makes it a follower, the next MsgApp brings its log level."""
+    tt = net(3)
+    tt.isolate(1)
+    tt.hup(1)
+    tt.hup(3)
+    tt.expect(1, role=CANDIDATE, term=1)
+    tt.expect(3, role=LEADER, term=1)
+    tt.recover()
+    tt.beat(3)  # "send heartbeat; reset wait"
+    tt.prop(3, b"force follower")  # flushes a MsgApp out to 1
+    tt.beat(3)  # "flush out commit"
+    tt.expect(1, role=FOLLOWER, term=1)
+    for i in (1, 2, 3):
+        tt.expect(i, commit=2, log=[(1, b""), (1, b"force follower")])
+
+
+def test_old_messages(net):
+    """TestOldMessages: leadership goes 1 -> 2 -> 1 (terms 1, 2, 3); a MsgApp of term 2 arriving at the term-3 leader
+    is ignored; a proposal then commits at index 4."""
+    from oracle import pywire as W
+
+    tt = net(3)
+    tt.hup(1)
+    tt.hup(2)
+    tt.hup(1)
+    tt.expect(1, role=LEADER, term=3)
+    msgs = np.zeros(G, W.WIRE_MSG_DT)
+    ents = np.zeros(G, W.WIRE_ENT_DT)
+    msgs["group"], msgs["term"], msgs["type"], msgs["from"], msgs["to"] = np.arange(G), 2, APP, 1, 0
+    msgs["ent_first"], msgs["n_ents"] = np.arange(G), 1
+    ents["term"], ents["index"] = 2, 3
+    tt.inject(1, msgs, ents)  # "pretend we're an old leader trying to make progress; this entry is expected to be ignored"
+    tt.prop(1, b"somedata")
+    for i in (1, 2, 3):
+        tt.expect(i, commit=4, log=[(1, b""), (2, b""), (3, b""), (3, b"somedata")])
+
+
+@pytest.mark.parametrize("n,nop,success", [(3, (), True), (3, (3,), True), (3, (2, 3), False), (4, (2, 3), False),
+                                           (5, (2, 3), True)])
+def test_proposal(net, n, nop, success):
+    """TestProposal: a proposal on node 1 commits exactly when a quorum of real peers exists; without one node 1 stays a
+    candidate and the proposal is dropped ("no leader").  Term 1 everywhere."""
+    tt = net(n, nop)
+    tt.hup(1)
+    tt.prop(1, b"somedata")
+    want = [(1, b""), (1, b"somedata")] if success else []
+    for i in tt.live():
+        tt.expect(i, term=1, log=want, commit=2 if success else 0)
+    if not success:
+        tt.expect(1, role=CANDIDATE)
+        assert tt.node(1).stats()["proposals_dropped"] == G
+
+
+@pytest.mark.parametrize("nop", [(), (3,)])
+def test_proposal_by_proxy(net, nop):
+    """TestProposalByProxy: a proposal handed to a follower is forwarded to the leader and commits."""
+    tt = net(3, nop)
+    tt.hup(1)
+    tt.prop(2, b"somedata")
+    for i in tt.live():
+        tt.expect(i, term=1, commit=2, log=[(1, b""), (1, b"somedata")])
+    assert tt.node(2).stats()["proposals_dropped"] == 0
+
+
+def test_campaign_argument_checks(net):
+    from raftsql_amd.engine import RaftqError
+
+    tt = net(3)
+    with pytest.raises(RaftqError):
+        tt.node(1).campaign([0, G])  # refused as a whole
+    tt.pump()
+    tt.expect(1, role=FOLLOWER, term=0)
+    tt.node(1).campaign(np.zeros(0, np.uint64))  # nothing to do
+    tt.node(1).campaign([5])
+    tt.pump()
+    st = tt.status(1)
+    assert st["role"][5] == LEADER and np.count_nonzero(st["role"] == LEADER) == 1
+    tt.node(1).campaign([5])  # already leader: the MsgHup is ignored
+    tt.pump()
+    assert tt.status(1)["term"][5] == 1

@@ -311,3 +311,68 @@ def test_campaign_argument_checks(net):
     tt.node(1).campaign([5])  # already leader: the MsgHup is ignored
     tt.pump()
     assert tt.status(1)["term"][5] == 1
+
+
+def test_handle_msg_app_table(gpu_engine_cls):
+    """TestHandleMsgApp as recalled: a follower at term 2 holding entries (index 1, term 1), (2, 2) receives one MsgApp;
+    the table fixes lastIndex, commit index and the Reject flag of the single MsgAppResp it answers with.  The eleven
+    rows run as eleven groups of one node, one batch.  (Upstream calls handleAppendEntries directly, so three rows carry
+    Term 1 on a term-2 node; through Step such a message would be dropped as stale -- they are sent with Term 2 here,
+    which handleAppendEntries never looks at.)"""
+    from oracle import pywire as W
+    from raftsql_amd.node import RaftNode
+
+    #        logTerm index commit entries[(index, term)]      wIndex wCommit wReject
+    rows = [(3, 2, 3, [], 2, 0, True),   # previous log mismatch
+            (3, 3, 3, [], 2, 0, True),   # previous log non-exist
+            (1, 1, 1, [], 2, 1, False),
+            (0, 0, 1, [(1, 2)], 1, 1, False),
+            (2, 2, 3, [(3, 2), (4, 2)], 4, 3, False),
+            (2, 2, 4, [(3, 2)], 3, 3, False),
+            (1, 1, 4, [(2, 2)], 2, 2, False),
+            (1, 1, 3, [], 2, 1, False),          # match entry 1, commit up to last new entry 1
+            (1, 1, 3, [(2, 2)], 2, 2, False),    # match entry 1, commit up to last new entry 2
+            (2, 2, 3, [], 2, 2, False),          # match entry 2, commit up to last new entry 2
+            (2, 2, 4, [], 2, 2, False)]          # commit up to log.last()
+    k = len(rows)
+    nd = RaftNode(k, 3, 0)
+    try:
+        for g in range(k):
+            nd.replay(g, [(1, b"one"), (2, b"two")])
+            nd.set_hard_state(g, 2, 0, 0)  # becomeFollower(2, None)
+        nd.start(10, 1, seed=1)
+        n_ents = sum(len(r[3]) for r in rows)
+        msgs, ents = np.zeros(k, W.WIRE_MSG_DT), np.zeros(n_ents, W.WIRE_ENT_DT)
+        pool, at = b"", 0
+        for g, (lt, idx, commit, es, *_rest) in enumerate(rows):
+            msgs[g] = (g, 2, lt, idx, commit, 0, 1, APP, 0, 0, 0, at, len(es))
+            for (ei, et) in es:
+                data = b"new-%d-%d" % (g, ei)
+                ents[at] = (et, ei, len(pool), len(data), 0)
+                pool += data
+                at += 1
+        stream, _ = W.wire_encode(msgs, ents, pool)
+        nd.deliver(stream.tobytes())
+        nd.advance()
+        st = nd.statuses()
+        out = nd.poll(1)
+        off, used = W.scan_frames(out, big_endian=True)
+        assert used == len(out) and len(off) - 1 == k  # exactly one answer per row
+        mm, _, bad = W.wire_decode(out, off)
+        assert bad == 0
+        by_group = {int(m["group"]): m for m in mm}
+        for g, (lt, idx, commit, es, w_index, w_commit, w_reject) in enumerate(rows):
+            assert int(st["last_index"][g]) == w_index, (g, "lastIndex", int(st["last_index"][g]))
+            assert int(st["commit"][g]) == w_commit, (g, "commit", int(st["commit"][g]))
+            m = by_group[g]
+            assert int(m["type"]) == APP_RESP and bool(m["reject"]) == w_reject, (g, m)
+            if w_reject:
+                assert int(m["index"]) == idx and int(m["reject_hint"]) == 2  # Index: m.Index, RejectHint: lastIndex
+            else:
+                assert int(m["index"]) == idx + len(es)                       # Index: lastnewi
+        # the entries themselves: row 3 replaced a conflicting entry 1, rows 4-5 extended the log
+        assert nd.log(3) == [(2, b"new-3-1")]
+        assert nd.log(4) == [(1, b"one"), (2, b"two"), (2, b"new-4-3"), (2, b"new-4-4")]
+        assert nd.log(6) == [(1, b"one"), (2, b"two")]  # entry 2 matched: the log keeps its own copy
+    finally:
+        nd.destroy()

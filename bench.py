@@ -348,6 +348,27 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
         e.step_collect(copy=False)
     dt_pipe_compact = time.perf_counter() - t0
     e.step_collect(copy=False)
+    # (e) the producer's side counted: every batch is WRITTEN into the staging area (a receive loop's stores -- over the
+    # BAR into HBM when the staging is device memory) and then submitted, two in flight, compact results; first as
+    # 64-byte records, then as 40-byte packed ones (raftq_step_submit_packed: the records are widened on the device)
+    import ctypes
+
+    def produce(b, packed):  # one memcpy of the finished records: what the last stage of a receive loop costs at least
+        st = e.step_stage_packed(msgs_per_batch) if packed else e.step_stage(msgs_per_batch)
+        ctypes.memmove(st.ctypes.data, b.ctypes.data, b.nbytes)
+        (e.step_submit_packed if packed else e.step_submit)(st)
+
+    produced = {}
+    for packed in (False, True):
+        src = [S.pack_msgs40(b) for b in bs[1:6]] if packed else bs[1:6]  # a short rotation: sources stay in the CPU's L3
+        produce(src[0], packed)
+        t0 = time.perf_counter()
+        for _ in range(16):
+            for b in src[1:]:
+                produce(b, packed)
+                e.step_collect(copy=False)
+        produced[packed] = (time.perf_counter() - t0) / (16 * (len(src) - 1))
+        e.step_collect(copy=False)
     e.set_compact(False)
     out = {"what": "raftq_step_batch: batched raft.Step (MsgAppResp / MsgHeartbeatResp / MsgVote mix) over "
                    "device-resident node state; wall time of the call incl. its one sync; zero-copy staging form: the producer "
@@ -362,7 +383,13 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                          "us_per_batch_caller_owned_arrays": dt_pipe / (batches - 1) * 1e6,
                          "compact_results": {"what": "40-byte result records (raftq_step_set_compact)",
                                              "us_per_batch": dt_pipe_compact / reps * 1e6,
-                                             "msgs_per_s": msgs_per_batch * reps / dt_pipe_compact}}}
+                                             "msgs_per_s": msgs_per_batch * reps / dt_pipe_compact},
+                         "producer_included": {
+                             "what": "every batch copied into the staging area by one host thread (memcpy of finished records, "
+                                     "sources L3-resident), then submitted (two in flight, compact results): 64-byte records "
+                                     "vs 40-byte packed ones (raftq_step_submit_packed); bound by that host copy",
+                             "us_per_batch_64B": produced[False] * 1e6, "msgs_per_s_64B": msgs_per_batch / produced[False],
+                             "us_per_batch_40B": produced[True] * 1e6, "msgs_per_s_40B": msgs_per_batch / produced[True]}}}
     e.close()
     if with_cpu:
         from oracle import pyoracle  # cpu_baseline leg: the sequential restatement, one thread

@@ -149,6 +149,26 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_ste
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n);
 
+/* Packed inbound records: 40 instead of 64 bytes per message cross PCIe (or the BAR) on the way IN -- a pipelined
+ * Step is bound by exactly that transfer.  No message kind Step accepts carries both a LogTerm and a RejectHint, so
+ * the two share a field; the group id takes 32 bits (handles of 2^32 groups or more refuse the packed calls).  The
+ * records are widened to raftq_msg_t on the device before Step reads them: the results, the order and the
+ * all-or-nothing rule are those of raftq_step_submit on the widened batch. */
+typedef struct raftq_msg40 {
+  uint32_t group;
+  uint8_t from;         /* sender's peer slot */
+  uint8_t type;         /* RAFTQ_MSG_* */
+  uint8_t reject;
+  uint8_t _pad;         /* 0 */
+  uint64_t term;
+  uint64_t index;
+  uint64_t aux;         /* m.RejectHint on MsgAppResp, m.LogTerm on every other kind */
+  uint64_t commit;
+} raftq_msg40_t;        /* 40 bytes */
+/* as raftq_step_stage / raftq_step_submit; collect with raftq_step_collect (packed and plain batches may alternate) */
+int raftq_step_stage_packed(raftq_t* h, uint64_t n, raftq_msg40_t** msgs);
+int raftq_step_submit_packed(raftq_t* h, const raftq_msg40_t* msgs, uint64_t n);
+
 /* Compact result records: 40 instead of 64 bytes per message cross PCIe (the result copy is what a pipelined
  * batch waits for).  Record i answers msgs[i], so its group and addressee (= msgs[i].group, msgs[i].from) are not
  * repeated; `aux` is log_term for RAFTQ_OUT_CAMPAIGN / RAFTQ_OUT_BECAME_LEADER -- whose `index` is the last index --

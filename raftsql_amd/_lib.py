@@ -125,6 +125,8 @@ _STEP_SIGS = [
     ("raftq_step_submit", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_step_collect", C.c_int, [_H, C.c_void_p, C.POINTER(StepCounts)]),
     ("raftq_step_stage", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("raftq_step_stage_packed", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("raftq_step_submit_packed", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_step_results", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_step_set_compact", C.c_int, [_H, C.c_int]),
     ("raftq_step_results_c", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

@@ -75,6 +75,7 @@ NodeArrays node_arrays(raftq_t* h) {
 // device scratch of one batch, carved from a single allocation
 struct Scratch {
   MsgRec* msgs;
+  void* msgs40;  // packed inbound records as they arrived (raftq_step_submit_packed), widened into msgs on the device
   void* outs;  // StepOutRec[n] or StepOutC[n], then the 16-byte tail at tail_off(n, rec)
   uint64_t *keys_in, *keys_out;
   uint32_t *order_in, *order_out;
@@ -123,7 +124,8 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
   // the 16-byte {touched count, bad flag} tail sits right behind the result records: one copy moves both
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
-               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_sort = carve(sort_bytes), o_next = carve(n * 4);
+               o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_sort = carve(sort_bytes), o_next = carve(n * 4),
+               o_m40 = carve(n * sizeof(raftqk::Msg40Rec));
   const size_t o_nh = o_outs + tail_off(n, h->step_compact ? sizeof(StepOutC) : sizeof(StepOutRec));
   // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
@@ -163,6 +165,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   }
   uint8_t* base = (uint8_t*)sl.dev;
   s->msgs = (MsgRec*)(base + o_msgs);
+  s->msgs40 = base + o_m40;
   s->outs = base + o_outs;
   s->keys_in = (uint64_t*)(base + o_ki);
   s->keys_out = (uint64_t*)(base + o_ko);
@@ -383,7 +386,10 @@ static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from
   return RAFTQ_OK;
 }
 
-static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const WireSrc* wire, const char* who) {
+// rec_bytes: sizeof(raftq_msg_t), or sizeof(raftq_msg40_t) for packed records (widened on the device)
+static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* wire, const char* who,
+                       size_t rec_bytes = sizeof(raftq_msg_t)) {
+  const bool packed = rec_bytes != sizeof(raftq_msg_t);
   if (int rc = use_device(h)) return rc;
   if (n == 0 || (!wire && !msgs)) return fail(h, RAFTQ_EINVAL, std::string(who) + ": empty batch");
   if (n > 0x7ffffffeull) return fail(h, RAFTQ_EINVAL, std::string(who) + ": batch too large (2^31 - 2 messages at most)");
@@ -405,7 +411,7 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
     std::memcpy(sl.in_h, wire->frame_off, (size_t)(n + 1) * 8);
     if (wire->nbytes) std::memcpy((uint8_t*)sl.in_h + (size_t)(n + 1) * 8, wire->stream, (size_t)wire->nbytes);
   } else {
-    in_bytes = (size_t)n * sizeof(raftq_msg_t);
+    in_bytes = (size_t)n * rec_bytes;
     // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into the pinned one
     // (either slot's device staging counts: a caller that keeps filling the buffer raftq_step_stage gave it for an
     // earlier batch must not be served by a host memcpy that READS device memory over the BAR -- 43 ms for 4 MB)
@@ -439,8 +445,9 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
   // in: one DMA over PCIe from the pinned staging -- or, when the producer wrote the batch straight into device
   // memory, a device-to-device copy into the slot's scratch (the replay path needs the batch there; 4 MB in ~3 us)
-  if (staged_in_device) HIPCHK(h, hipMemcpyAsync((void*)s.msgs, device_src, in_bytes, hipMemcpyDeviceToDevice, s_in));
-  else HIPCHK(h, hipMemcpyAsync(wire ? (void*)s.w_off : (void*)s.msgs, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
+  void* in_dst = wire ? (void*)s.w_off : packed ? s.msgs40 : (void*)s.msgs;
+  if (staged_in_device) HIPCHK(h, hipMemcpyAsync(in_dst, device_src, in_bytes, hipMemcpyDeviceToDevice, s_in));
+  else HIPCHK(h, hipMemcpyAsync(in_dst, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
   if (s_in != h->stream) {
     HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
@@ -449,6 +456,11 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
   const uint32_t rec = h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
   if (!sl.tail_zeroed || sl.tail_n != n || sl.tail_rec != rec || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
   sl.tail_zeroed = false;
+  if (packed) {
+    hipLaunchKernelGGL(raftqk::step_unpack40_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                       (const raftqk::Msg40Rec*)s.msgs40, s.msgs, n);
+    HIPCHK(h, hipGetLastError());
+  }
   if (wire) {
     // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe.  (s.w_bad only counts
     // malformed frames for raftq_wire_decode's callers; here a malformed frame fails the batch through its flag byte.)
@@ -501,6 +513,16 @@ static int submit_impl(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, const Wi
 
 int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n) {
   return submit_impl(h, msgs, n, nullptr, "raftq_step_submit");
+}
+
+int raftq_step_stage_packed(raftq_t* h, uint64_t n, raftq_msg40_t** msgs) {
+  static_assert(sizeof(raftq_msg40_t) == sizeof(raftqk::Msg40Rec), "ABI struct mismatch");
+  return raftq_step_stage(h, n, (raftq_msg_t**)msgs);  // a staging area for n 64-byte records holds n packed ones
+}
+
+int raftq_step_submit_packed(raftq_t* h, const raftq_msg40_t* msgs, uint64_t n) {
+  if (h && h->G > 0x100000000ull) return fail(h, RAFTQ_EINVAL, "raftq_step_submit_packed: group ids of this handle do not fit 32 bits");
+  return submit_impl(h, msgs, n, nullptr, "raftq_step_submit_packed", sizeof(raftq_msg40_t));
 }
 
 int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n) {

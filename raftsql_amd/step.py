@@ -35,7 +35,11 @@ OUT_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("log_te
 OUT_C_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("aux", "<u8"), ("vote", "u1"), ("lead", "u1"),
                      ("type", "u1"), ("reject", "u1"), ("flags", "u1"), ("role", "u1"), ("_pad", "u1", (2,))])
 LOG_DELTA_DT = np.dtype([("group", "<u8"), ("last_index", "<u8"), ("last_term", "<u8"), ("commit_to", "<u8")])
+# raftq_msg40_t: the 40-byte inbound record (raftq_step_submit_packed); aux = reject_hint on MsgAppResp, log_term otherwise
+MSG40_DT = np.dtype([("group", "<u4"), ("from", "u1"), ("type", "u1"), ("reject", "u1"), ("_pad", "u1"), ("term", "<u8"),
+                     ("index", "<u8"), ("aux", "<u8"), ("commit", "<u8")])
 assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32 and OUT_C_DT.itemsize == 40
+assert MSG40_DT.itemsize == 40
 
 
 def pack_msgs(group, type, term=0, frm=0, index=0, log_term=0, commit=0, reject=0, reject_hint=0) -> np.ndarray:
@@ -44,6 +48,17 @@ def pack_msgs(group, type, term=0, frm=0, index=0, log_term=0, commit=0, reject=
     a = np.zeros(n, dtype=MSG_DT)
     a["group"], a["type"], a["term"], a["from"] = group, type, term, frm
     a["index"], a["log_term"], a["commit"], a["reject"], a["reject_hint"] = index, log_term, commit, reject, reject_hint
+    return a
+
+
+def pack_msgs40(msgs: np.ndarray, out: np.ndarray | None = None) -> np.ndarray:
+    """raftq_msg_t[] -> raftq_msg40_t[] (into `out` when given, e.g. a staging array).  Exact for every batch in which
+    no MsgAppResp carries a log_term and no other kind a reject_hint (Step reads neither)."""
+    a = np.zeros(len(msgs), dtype=MSG40_DT) if out is None else out
+    for k in ("group", "from", "type", "reject", "term", "index", "commit"):
+        a[k] = msgs[k]
+    a["_pad"] = 0
+    a["aux"] = np.where(msgs["type"] == MSG_APP_RESP, msgs["reject_hint"], msgs["log_term"])
     return a
 
 
@@ -136,6 +151,20 @@ class NodeEngine(QuorumEngine):
         """enqueue a batch (raftq_step_submit); at most two may be in flight"""
         assert msgs.dtype == MSG_DT and msgs.flags.c_contiguous and len(msgs) > 0
         self._chk(self._lib.raftq_step_submit(self._h, _ptr(msgs), len(msgs)))
+
+    def step_stage_packed(self, n: int) -> np.ndarray:
+        """staging array for n PACKED messages (raftq_step_stage_packed): fill in place, pass to step_submit_packed()"""
+        p = C.c_void_p(None)
+        self._chk(self._lib.raftq_step_stage_packed(self._h, int(n), C.byref(p)))
+        if n == 0:
+            return np.empty(0, dtype=MSG40_DT)
+        buf = (C.c_char * (n * MSG40_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MSG40_DT, count=n)
+
+    def step_submit_packed(self, msgs40: np.ndarray) -> None:
+        """enqueue a batch of 40-byte records (raftq_step_submit_packed); collect with step_collect()"""
+        assert msgs40.dtype == MSG40_DT and msgs40.flags.c_contiguous and len(msgs40) > 0
+        self._chk(self._lib.raftq_step_submit_packed(self._h, _ptr(msgs40), len(msgs40)))
 
     def step_collect(self, copy: bool = True):
         """results of the oldest batch in flight -> (records, n_groups_touched): raftq_step_out_t[], or

@@ -454,3 +454,71 @@ def test_upstream_is_election_timeout_window_as_recalled_gpu(gpu_engine_cls):
             if row["round"]:
                 got = np.floor(got * 10 + 0.5) / 10.0
             assert got == row["p"], (row, n_hup / G)
+
+
+def _widened(m):
+    """what raftq_step_submit_packed makes of a batch: LogTerm and RejectHint share the packed record's aux field"""
+    from raftsql_amd import step as S
+
+    w = m.copy()
+    resp = m["type"] == S.MSG_APP_RESP
+    w["log_term"] = np.where(resp, 0, m["log_term"])
+    w["reject_hint"] = np.where(resp, m["reject_hint"], 0)
+    return w
+
+
+def test_step_packed_inbound_records(NodeEngine, oracle):
+    """raftq_step_submit_packed: 40-byte inbound records, widened on the device -- the results, the order, the stall/replay
+    path for hot groups and the all-or-nothing rule are those of raftq_step_submit on the widened batch; packed and
+    plain batches share the two-deep pipeline; the staged (zero-copy) form takes packed records as well."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(77)
+    G, N = 5000, 5
+    s = _stepgen.random_state(rng, G, N, 2)
+    with NodeEngine(G, N, 2) as e:
+        _stepgen.load_engine(e, s)
+        prev = None
+        for it in range(14):
+            n = int(rng.integers(1, 7000))
+            m = _stepgen.random_batch(rng, s, n, hot_groups=rng.choice(G, 20) if it % 4 == 1 else None)
+            if it % 3 == 2:  # a plain batch between packed ones
+                want = s.step_batch(m)
+                e.step_submit(m)
+            else:
+                want = s.step_batch(_widened(m))
+                if it % 2:
+                    e.step_submit_packed(S.pack_msgs40(m))
+                else:  # zero-copy: pack straight into the staging array
+                    staged = e.step_stage_packed(n)
+                    S.pack_msgs40(m, out=staged)
+                    e.step_submit_packed(staged)
+            if prev is not None:
+                got, touched = e.step_collect()
+                assert np.array_equal(got, prev[0]) and touched == prev[1], it
+            prev = (want, len(np.unique(m["group"])))
+        got, touched = e.step_collect()
+        assert np.array_equal(got, prev[0]) and touched == prev[1]
+        _stepgen.assert_same_state(e, s)
+        # a malformed packed batch fails alone and applies nothing
+        bad = S.pack_msgs40(_stepgen.random_batch(rng, s, 64))
+        bad["type"][5] = 7  # MsgSnap: not a kind Step takes
+        good = _stepgen.random_batch(rng, s, 64)
+        e.step_submit_packed(bad)
+        e.step_submit_packed(S.pack_msgs40(good))
+        with pytest.raises(RaftqError):
+            e.step_collect()
+        assert np.array_equal(e.step_collect()[0], s.step_batch(_widened(good)))
+        _stepgen.assert_same_state(e, s)
+        # compact result records answer packed batches too
+        e.set_compact(True)
+        m = _stepgen.random_batch(rng, s, 3000)
+        want = s.step_batch(_widened(m))
+        e.step_submit_packed(S.pack_msgs40(m))
+        recs, _ = e.step_collect()
+        assert np.array_equal(S.expand_compact(m, recs), want)
+        e.set_compact(False)
+        _stepgen.assert_same_state(e, s)
+        with pytest.raises(AssertionError):
+            e.step_submit_packed(m)  # the mirror refuses the wrong record type

@@ -174,3 +174,34 @@ func (e *Engine) ReadNode() (*NodeState, error) {
 	}
 	return s, e.err(C.raftq_read_match(e.h, (*C.uint64_t)(unsafe.Pointer(&s.Match[0]))))
 }
+
+// Msg40 is layout-identical to raftq_msg40_t: the 40-byte inbound record.  Aux is m.RejectHint on MsgAppResp and
+// m.LogTerm on every other kind (no kind Step takes carries both).
+type Msg40 struct {
+	Group  uint32
+	From   uint8
+	Type   uint8
+	Reject uint8
+	_      uint8
+	Term   uint64
+	Index  uint64
+	Aux    uint64
+	Commit uint64
+}
+
+// StepStagePacked returns the staging slice the next SubmitPacked will use, with room for n packed messages.
+func (e *Engine) StepStagePacked(n int) ([]Msg40, error) {
+	var p *C.raftq_msg40_t
+	if rc := C.raftq_step_stage_packed(e.h, C.uint64_t(n), &p); rc != C.RAFTQ_OK {
+		return nil, e.err(rc)
+	}
+	return unsafe.Slice((*Msg40)(unsafe.Pointer(p)), n), nil
+}
+
+// StepSubmitPacked enqueues a batch of packed records (at most two batches in flight); collect it like any other.
+func (e *Engine) StepSubmitPacked(msgs []Msg40) error {
+	if len(msgs) == 0 {
+		return nil
+	}
+	return e.err(C.raftq_step_submit_packed(e.h, (*C.raftq_msg40_t)(unsafe.Pointer(&msgs[0])), C.uint64_t(len(msgs))))
+}

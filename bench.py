@@ -270,6 +270,8 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     leader of many groups sees: MsgAppResp acks (75 %), MsgHeartbeatResp (20 %), a few MsgVote of a
     higher term (the leader steps down) and stale-term stragglers.  Wall time of the call, PCIe
     both ways included (64 B in + 64 B out per message)."""
+    import ctypes
+
     from raftsql_amd import step as S
 
     G, N = cfg["G"], cfg["N"]
@@ -316,43 +318,48 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     # k+1 overlaps the kernels of batch k.  Caller-owned arrays first, then the zero-copy form: both
     # staging slots are filled once and resubmitted (acks that no longer move anything -- the rate of
     # the machinery, without Python's cost of producing 4 MB of records per batch).
+    # Three batches may be in flight: a batch's result records leave inside the walk kernel of the batch behind it.
     t0 = time.perf_counter()
     e.step_submit(bs[1])
-    for b in bs[2:]:
+    e.step_submit(bs[2])
+    for b in bs[3:]:
         e.step_submit(b)
         e.step_collect(copy=False)
     e.step_collect(copy=False)
-    dt_pipe = time.perf_counter() - t0
-    for b in bs[1:3]:
-        st = e.step_stage(msgs_per_batch)
-        st[:] = b
-        e.step_submit(st)
     e.step_collect(copy=False)
+    dt_pipe = time.perf_counter() - t0
+
+    def prime():  # fill all three staging slots once, leave two batches in flight
+        for b in bs[1:4]:
+            st = e.step_stage(msgs_per_batch)
+            ctypes.memmove(st.ctypes.data, b.ctypes.data, b.nbytes)
+            e.step_submit(st)
+        e.step_collect(copy=False)
+
+    def drain():
+        e.step_collect(copy=False)
+        e.step_collect(copy=False)
+
+    prime()
     reps = 3 * batches
     t0 = time.perf_counter()
     for _ in range(reps):
         e.step_submit(e.step_stage(msgs_per_batch))
         e.step_collect(copy=False)
     dt_pipe_staged = time.perf_counter() - t0
-    e.step_collect(copy=False)
+    drain()
     # (d) the same with 40-byte result records (raftq_step_set_compact): the result copy is what a batch waits for
     e.set_compact(True)
-    for b in bs[1:3]:
-        st = e.step_stage(msgs_per_batch)
-        st[:] = b
-        e.step_submit(st)
-    e.step_collect(copy=False)
+    prime()
     t0 = time.perf_counter()
     for _ in range(reps):
         e.step_submit(e.step_stage(msgs_per_batch))
         e.step_collect(copy=False)
     dt_pipe_compact = time.perf_counter() - t0
-    e.step_collect(copy=False)
+    drain()
     # (e) the producer's side counted: every batch is WRITTEN into the staging area (a receive loop's stores -- over the
     # BAR into HBM when the staging is device memory) and then submitted, two in flight, compact results; first as
     # 64-byte records, then as 40-byte packed ones (raftq_step_submit_packed: the records are widened on the device)
-    import ctypes
-
     def produce(b, packed):  # one memcpy of the finished records: what the last stage of a receive loop costs at least
         st = e.step_stage_packed(msgs_per_batch) if packed else e.step_stage(msgs_per_batch)
         ctypes.memmove(st.ctypes.data, b.ctypes.data, b.nbytes)
@@ -362,13 +369,14 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
     for packed in (False, True):
         src = [S.pack_msgs40(b) for b in bs[1:6]] if packed else bs[1:6]  # a short rotation: sources stay in the CPU's L3
         produce(src[0], packed)
+        produce(src[1], packed)
         t0 = time.perf_counter()
         for _ in range(16):
             for b in src[1:]:
                 produce(b, packed)
                 e.step_collect(copy=False)
         produced[packed] = (time.perf_counter() - t0) / (16 * (len(src) - 1))
-        e.step_collect(copy=False)
+        drain()
     e.set_compact(False)
     out = {"what": "raftq_step_batch: batched raft.Step (MsgAppResp / MsgHeartbeatResp / MsgVote mix) over "
                    "device-resident node state; wall time of the call incl. its one sync; zero-copy staging form: the producer "
@@ -377,7 +385,7 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
            "groups": G, "peers": N, "msgs_per_batch": msgs_per_batch, "us_per_batch": dt / nb * 1e6,
            "msgs_per_s": msgs_per_batch * nb / dt, "groups_touched_per_batch": touched / nb,
            "us_per_batch_copying_form": dt_copy / half * 1e6,
-           "pipelined": {"what": "two batches in flight (submit/collect), zero-copy staging",
+           "pipelined": {"what": "three batches in flight (submit/collect), zero-copy staging",
                          "us_per_batch": dt_pipe_staged / reps * 1e6,
                          "msgs_per_s": msgs_per_batch * reps / dt_pipe_staged,
                          "us_per_batch_caller_owned_arrays": dt_pipe / (batches - 1) * 1e6,
@@ -386,7 +394,7 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                                              "msgs_per_s": msgs_per_batch * reps / dt_pipe_compact},
                          "producer_included": {
                              "what": "every batch copied into the staging area by one host thread (memcpy of finished records, "
-                                     "sources L3-resident), then submitted (two in flight, compact results): 64-byte records "
+                                     "sources L3-resident), then submitted (three in flight, compact results): 64-byte records "
                                      "vs 40-byte packed ones (raftq_step_submit_packed); bound by that host copy",
                              "us_per_batch_64B": produced[False] * 1e6, "msgs_per_s_64B": msgs_per_batch / produced[False],
                              "us_per_batch_40B": produced[True] * 1e6, "msgs_per_s_40B": msgs_per_batch / produced[True]}}}

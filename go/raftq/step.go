@@ -198,7 +198,7 @@ func (e *Engine) StepStagePacked(n int) ([]Msg40, error) {
 	return unsafe.Slice((*Msg40)(unsafe.Pointer(p)), n), nil
 }
 
-// StepSubmitPacked enqueues a batch of packed records (at most two batches in flight); collect it like any other.
+// StepSubmitPacked enqueues a batch of packed records (at most three batches in flight); collect it like any other.
 func (e *Engine) StepSubmitPacked(msgs []Msg40) error {
 	if len(msgs) == 0 {
 		return nil

@@ -126,8 +126,11 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step_out_t* out,
                      raftq_step_counts_t* counts);
 
-/* pipelined form: up to TWO batches in flight.  raftq_step_submit enqueues a batch and returns
+/* pipelined form: up to THREE batches in flight.  raftq_step_submit enqueues a batch and returns
  * at once; raftq_step_collect blocks for the oldest batch in flight and hands out its results.
+ * (A batch's result records leave the device inside the walk kernel of the batch submitted behind it -- a copy kernel
+ * of their own would hold that batch's kernels back -- or at its own collect when nothing is behind it: keep a batch
+ * on the device and one being handed over while waiting for a third, and the copy, the walk and the host overlap.)
  * Batches are applied in submission order; the H2D copy of batch k+1 overlaps the kernels and the
  * result copy of batch k.  raftq_step_batch == submit + collect.
  * A malformed batch is reported by ITS collect and applies nothing; a batch submitted behind it

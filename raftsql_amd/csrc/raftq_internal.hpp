@@ -101,6 +101,10 @@ struct raftq {
   // raftq_step_batch / _submit / _collect: two batches may be in flight, each in its own slot
   // (pinned staging in, device scratch, pinned results out), pipelined over two streams (DMA in | kernels +
   // result copy): the H2D of batch k+1 overlaps the kernels and the result copy of batch k
+  // Batches of the pipelined Step in flight at most.  Three, because a batch's result copy rides in the walk kernel of
+  // the batch behind it (see copy_pending): while the host waits for batch k it must be able to have batch k+1 on the
+  // device AND be handing over batch k+2 -- with two slots that form lost to round 1's (profiles/r02/step_deferred_copy_ab.txt).
+  static constexpr int kStepSlots = 3;
   struct StepSlot {
     void* in_h = nullptr;          // pinned staging: the copying forms (caller-owned arrays, received frames) go through it
     size_t in_bytes = 0;
@@ -116,6 +120,11 @@ struct raftq {
     bool busy = false;
     bool lists = false;            // submitted through the sort-free walk
     bool replayed = false;         // already re-run through the sorted path (after a stall)
+    // the batch's result copy has not been enqueued yet: it rides in the NEXT batch's walk kernel (a copy kernel of its
+    // own keeps that batch's kernels from starting until it retires), or is launched by the batch's collect
+    bool copy_pending = false;
+    const void* outs_d = nullptr;  // device result records of this batch (in `dev`)
+    uint64_t out_quads = 0;        // ... in 16-byte units, tail included
     int end_bit = 0;
     uint32_t rec = 64;             // bytes per result record of this batch (64, or 40 compact)
     bool tail_zeroed = false;      // the device copy of the 16-byte result tail is known to be zero (for tail_n, tail_dev)
@@ -134,11 +143,12 @@ struct raftq {
     size_t w_pin_bytes = 0;
     bool w_msgs_fetched = false, w_ents_fetched = false;
     uint64_t w_n_ents = 0;
-  } step_slot[2];
+  } step_slot[kStepSlots];
   int step_last_slot = -1;         // slot of the last collected batch
-  uint64_t step_submitted = 0, step_collected = 0;  // slot of batch k = k & 1
+  uint64_t step_submitted = 0, step_collected = 0;  // slot of batch k = k % kStepSlots
   hipStream_t step_s_in = nullptr, step_s_out = nullptr;
   int step_stream_mode = 2;
+  bool step_defer_copy = true;     // RAFTQ_STEP_DEFER_COPY=0: every batch launches its own result copy (round 1's form; for A/B)
   const void* step_last_out = nullptr;  // results of the last collected batch
   uint64_t step_last_n = 0;
   uint32_t step_last_rec = 64;

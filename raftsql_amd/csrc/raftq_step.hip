@@ -112,6 +112,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
     // (382-394 us), the copy split into 2-32 short kernels (177-185 us), the walk writing straight into mapped host
     // memory (186 us) -- none beat 2; those variants are no longer in the code.  RAFTQ_STEP_STREAMS = 1..4 overrides.
     if (const char* m = std::getenv("RAFTQ_STEP_STREAMS")) h->step_stream_mode = std::atoi(m);
+    if (const char* m = std::getenv("RAFTQ_STEP_DEFER_COPY")) h->step_defer_copy = std::atoi(m) != 0;
   }
   if (!sl.ev_in) {
     HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
@@ -247,7 +248,8 @@ void raftq_detail::free_node_state(raftq_t* h) {
   (void)hipFree(h->lst_min);
   (void)hipFree(h->step_stall);
   for (auto& sl : h->step_slot) {
-    if (sl.ev_out && sl.busy) (void)hipEventSynchronize(sl.ev_out);
+    if (sl.busy && sl.copy_pending && h->stream) (void)hipStreamSynchronize(h->stream);  // its kernels; the copy never ran
+    else if (sl.ev_out && sl.busy) (void)hipEventSynchronize(sl.ev_out);
     (void)hipFree(sl.dev);
     if (sl.in_h) (void)hipHostFree(sl.in_h);
     if (sl.in_bar) (void)hipFree(sl.in_bar);
@@ -304,8 +306,8 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
   if (int rc = use_device(h)) return rc;
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");
-  raftq::StepSlot& sl = h->step_slot[h->step_submitted & 1];  // the slot the next submit will use
-  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage: two batches already in flight; collect one first");
+  raftq::StepSlot& sl = h->step_slot[h->step_submitted % raftq::kStepSlots];  // the slot the next submit will use
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage: three batches already in flight; collect one first");
   void* p = nullptr;
   if (int rc = ensure_slot_bar(h, sl, n, &p)) return rc;
   *msgs = (raftq_msg_t*)p;
@@ -373,16 +375,35 @@ static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end
 }
 
 // link -> walk (and empty) the per-group lists: two launches, no sort (raftq_step_kernels.hpp 2b / 3b)
-static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from_wire) {
+static unsigned d2h_blocks(uint64_t quads) { return (unsigned)std::min<uint64_t>(64, (quads + kBlock - 1) / kBlock); }
+
+// `carry`: a slot whose result copy is still pending rides in this batch's walk kernel (nullptr: nothing to carry)
+static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from_wire, raftq::StepSlot* carry) {
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   unsigned int* skipped = bad + 1;  // the last word of the 16-byte tail behind the result records
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(step_link_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G, h->N, from_wire,
+  const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+  const unsigned cp_blocks = carry ? d2h_blocks(carry->out_quads) : 0;
+  hipLaunchKernelGGL(step_link_kernel, dim3(blocks), dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G, h->N, from_wire,
                      list_arrays(h), s.next, bad, h->step_stall);
-  hipLaunchKernelGGL(step_lists_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs, s.outs,
-                     h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped, (const unsigned int*)bad,
-                     (const unsigned int*)h->step_stall);
+  hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + cp_blocks), dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
+                     s.outs, h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped,
+                     (const unsigned int*)bad, (const unsigned int*)h->step_stall, (const u64x2*)(carry ? carry->outs_d : nullptr),
+                     (u64x2*)(carry ? carry->out_d : nullptr), carry ? carry->out_quads : 0, cp_blocks);
   HIPCHK(h, hipGetLastError());
+  if (carry) {
+    HIPCHK(h, hipEventRecord(carry->ev_out, h->stream));
+    carry->copy_pending = false;
+  }
+  return RAFTQ_OK;
+}
+
+// the slot's result records (and tail) -> its pinned host buffer, as a kernel of its own
+static int enqueue_result_copy(raftq_t* h, raftq::StepSlot& sl, hipStream_t st) {
+  hipLaunchKernelGGL(step_d2h_kernel, dim3(d2h_blocks(sl.out_quads)), dim3(kBlock), 0, st, (const u64x2*)sl.outs_d, (u64x2*)sl.out_d,
+                     sl.out_quads, true);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(sl.ev_out, st));
+  sl.copy_pending = false;
   return RAFTQ_OK;
 }
 
@@ -395,9 +416,9 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   if (n > 0x7ffffffeull) return fail(h, RAFTQ_EINVAL, std::string(who) + ": batch too large (2^31 - 2 messages at most)");
   if (wire && ((!wire->stream && wire->nbytes) || !wire->frame_off))
     return fail(h, RAFTQ_EINVAL, std::string(who) + ": null argument");
-  const int slot_no = (int)(h->step_submitted & 1);
+  const int slot_no = (int)(h->step_submitted % raftq::kStepSlots);
   raftq::StepSlot& sl = h->step_slot[slot_no];
-  if (sl.busy) return fail(h, RAFTQ_ESTATE, std::string(who) + ": two batches already in flight; collect one first");
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, std::string(who) + ": three batches already in flight; collect one first");
   if (int rc = ensure_node_state(h)) return rc;
   int end_bit = 1;
   while (end_bit < 64 && (h->G >> end_bit) != 0) ++end_bit;
@@ -475,24 +496,41 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   // stalls in a row the next 16 batches go straight to the sorted walk, then the list walk is tried again
   if (h->step_sorted_left) --h->step_sorted_left;
   const bool lists = h->step_walk_mode == 1 && h->step_sorted_left == 0;
+  // Result copies.  With everything on the handle's stream (the default topology) a batch's copy is DEFERRED: it rides in
+  // the walk kernel of the batch submitted behind it, or is launched by its own collect if none is.  The batch submitted
+  // just before this one may be waiting for exactly that.
+  // Only for batches that arrived in device memory (raftq_step_stage behind a large BAR): a batch that needs an inbound
+  // DMA is better off with its own copy kernel -- the DMA of the batch after next cannot start while a kernel is writing
+  // to host memory either, and the fused kernel writes for longer (measured: caller-owned arrays 157 us per batch with
+  // their own copy kernels, 189 us deferred; staged batches 101 -> 77 us; profiles/r02/step_deferred_copy_ab.txt).
+  const bool defer = s_out == h->stream && h->step_defer_copy && staged_in_device;
+  raftq::StepSlot* carry = nullptr;
+  if (h->step_submitted > h->step_collected) {
+    raftq::StepSlot& prev = h->step_slot[(h->step_submitted - 1) % raftq::kStepSlots];
+    if (prev.busy && prev.copy_pending) carry = &prev;
+  }
   if (lists) {
-    if (int rc = enqueue_list_walk(h, s, n, wire != nullptr)) return rc;
+    if (int rc = enqueue_list_walk(h, s, n, wire != nullptr, carry)) return rc;
   } else {
+    if (carry)
+      if (int rc = enqueue_result_copy(h, *carry, h->stream)) return rc;
     if (int rc = enqueue_sorted_walk(h, s, n, end_bit, wire != nullptr, s.outs)) return rc;
   }
-  if (s_out != h->stream) {
-    HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
+  sl.outs_d = s.outs;
+  sl.out_quads = tail_off(n, rec) / 16 + 1;  // records + the 16-byte tail
+  if (defer) {
+    sl.copy_pending = true;
+  } else {
+    if (s_out != h->stream) {
+      HIPCHK(h, hipEventRecord(sl.ev_comp, h->stream));
+      HIPCHK(h, hipStreamWaitEvent(s_out, sl.ev_comp, 0));
+    }
+    if (int rc = enqueue_result_copy(h, sl, s_out)) return rc;
   }
-  const uint64_t out_quads = tail_off(n, rec) / 16 + 1;  // records + the 16-byte tail
-  hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s_out, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads, true);
-  HIPCHK(h, hipGetLastError());
-  sl.tail_zeroed = true;  // holds for the next batch of the same size and format in the same scratch
+  sl.tail_zeroed = true;  // (once the copy has run) holds for the next batch of the same size and format in the same scratch
   sl.tail_n = n;
   sl.tail_rec = rec;
   sl.tail_dev = sl.dev;
-  HIPCHK(h, hipEventRecord(sl.ev_out, s_out));
   sl.n = n;
   sl.busy = true;
   sl.lists = lists;
@@ -601,23 +639,27 @@ int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t*
   return RAFTQ_OK;
 }
 
-// first_slot's batch reported `skipped`; the other slot may hold a later batch that is still in flight
-static int replay_stalled(raftq_t* h, int first_slot) {
-  for (int k = 0; k < 2; ++k) {
-    raftq::StepSlot& sl = h->step_slot[(first_slot + k) & 1];
-    if (k == 1) {
+// batch `first` (already taken out of flight by its collect) reported `skipped`; the batches submitted behind it are
+// still in flight and were skipped as well: all of them go through the sorted walk again, in submission order
+static int replay_stalled(raftq_t* h, uint64_t first) {
+  for (uint64_t b = first; b < h->step_submitted; ++b) {
+    raftq::StepSlot& sl = h->step_slot[b % raftq::kStepSlots];
+    if (b != first) {
       if (!sl.busy) break;
-      HIPCHK(h, hipEventSynchronize(sl.ev_out));  // it ran behind the stalled batch: skipped as well
+      // its copy, if one was enqueued (it rode in the batch behind it), must be over before the replay's own lands in
+      // the same host buffer; a pending one is simply replaced by the replay's
+      if (!sl.copy_pending) HIPCHK(h, hipEventSynchronize(sl.ev_out));
     }
     Scratch s;
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, sl.wire, sl.w_nbytes)) return rc;
     hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
     if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.wire, s.outs)) return rc;
     const uint64_t out_quads = tail_off(sl.n, sl.rec) / 16 + 1;
-    hipLaunchKernelGGL(step_d2h_kernel, dim3((unsigned)std::min<uint64_t>(64, (out_quads + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, h->stream, (const u64x2*)s.outs, (u64x2*)sl.out_d, out_quads);
+    hipLaunchKernelGGL(step_d2h_kernel, dim3(d2h_blocks(out_quads)), dim3(kBlock), 0, h->stream, (const u64x2*)s.outs,
+                       (u64x2*)sl.out_d, out_quads);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(sl.ev_out, h->stream));
+    sl.copy_pending = false;
     sl.tail_zeroed = false;
     sl.replayed = true;
     h->step_replays++;
@@ -631,10 +673,12 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   if (int rc = use_device(h)) return rc;
   if (counts) counts->n_msgs = counts->n_groups_touched = 0;
   if (h->step_collected == h->step_submitted) return fail(h, RAFTQ_ESTATE, "raftq_step_collect: nothing in flight");
-  raftq::StepSlot& sl = h->step_slot[h->step_collected & 1];
+  raftq::StepSlot& sl = h->step_slot[h->step_collected % raftq::kStepSlots];
+  if (sl.copy_pending)  // nothing was submitted behind this batch: its results leave now
+    if (int rc = enqueue_result_copy(h, sl, h->stream)) return rc;
   HIPCHK(h, hipEventSynchronize(sl.ev_out));
   sl.busy = false;
-  h->step_last_slot = (int)(h->step_collected & 1);
+  h->step_last_slot = (int)(h->step_collected % raftq::kStepSlots);
   h->step_collected++;
   const uint64_t n = sl.n;
   const uint8_t* tail = (const uint8_t*)sl.out_h + tail_off(n, sl.rec);
@@ -644,7 +688,7 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out, raftq_step_counts_t* c
   if (skipped_h) {
     // this batch has a run longer than the list walk takes: nothing of it, nor of the batch submitted behind it,
     // was applied.  Replay them in submission order through the sorted walk, then let the list walk resume.
-    if (int rc = replay_stalled(h, (int)((h->step_collected - 1) & 1))) return rc;
+    if (int rc = replay_stalled(h, h->step_collected - 1)) return rc;
     if (++h->step_stalls_in_a_row >= 2) h->step_sorted_left = 16;
   } else if (sl.lists && !sl.replayed) {
     h->step_stalls_in_a_row = 0;

@@ -406,8 +406,23 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
                                                                    uint64_t n_groups, ListArrays l,
                                                                    const uint32_t* __restrict__ next,
                                                                    unsigned long long* n_heads, unsigned int* tail_skipped,
-                                                                   const unsigned int* bad, const unsigned int* stall) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                                   const unsigned int* bad, const unsigned int* stall,
+                                                                   const u64x2* cp_src, u64x2* cp_dst, uint64_t cp_quads,
+                                                                   uint32_t cp_blocks) {
+  // The first cp_blocks workgroups carry the PREVIOUS batch's result records to the host (step_d2h_kernel's loop, its
+  // zero_tail form).  As a kernel of its own that copy holds back this batch's kernels until it retires -- measured in
+  // round 1, profiles/r01/step_pipeline_trace.txt -- so a pipelined batch cost walk + copy; inside the walk kernel the two
+  // overlap: the copy is PCIe-bound, the walk HBM-latency-bound.
+  if (blockIdx.x < cp_blocks) {
+    const uint64_t stride = (uint64_t)cp_blocks * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < cp_quads; q += stride) {
+      const u64x2 v = cp_src[q];
+      __builtin_nontemporal_store(v, cp_dst + q);
+      if (q == cp_quads - 1) const_cast<u64x2*>(cp_src)[q] = u64x2{0, 0};
+    }
+    return;
+  }
+  const uint64_t i = (uint64_t)(blockIdx.x - cp_blocks) * kBlock + threadIdx.x;
   const bool stalled = *stall != 0;  // this batch, or one before it that has not been replayed yet, needs the sorted path
   if (stalled || *bad) {             // (*bad: a malformed record somewhere in the batch) -- nothing is applied;
     if (stalled && i == 0) *tail_skipped = 1u;

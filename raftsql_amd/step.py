@@ -148,7 +148,7 @@ class NodeEngine(QuorumEngine):
         return np.frombuffer(buf, dtype=OUT_DT, count=k.value), int(c.n_groups_touched)
 
     def step_submit(self, msgs: np.ndarray) -> None:
-        """enqueue a batch (raftq_step_submit); at most two may be in flight"""
+        """enqueue a batch (raftq_step_submit); at most three may be in flight"""
         assert msgs.dtype == MSG_DT and msgs.flags.c_contiguous and len(msgs) > 0
         self._chk(self._lib.raftq_step_submit(self._h, _ptr(msgs), len(msgs)))
 

@@ -233,16 +233,20 @@ def test_step_pipelined_submit_collect(NodeEngine, oracle):
         _stepgen.assert_same_state(e, s)
         with pytest.raises(RaftqError):
             e.step_collect()  # nothing in flight
-        a, b, c3 = (_stepgen.random_batch(rng, s, 100) for _ in range(3))
+        a, b, c3, d4 = (_stepgen.random_batch(rng, s, 100) for _ in range(4))
         e.step_submit(a)
         e.step_submit(b)
+        e.step_submit(c3)  # three may be in flight
         with pytest.raises(RaftqError) as ei:
-            e.step_submit(c3)
+            e.step_submit(d4)
         assert ei.value.code == _lib.RAFTQ_ESTATE
         with pytest.raises(RaftqError):
-            e.step_batch(c3)  # the synchronous form refuses to jump the queue
-        wa, wb = s.step_batch(a), s.step_batch(b)
+            e.step_stage(10)  # no staging slot is free either
+        with pytest.raises(RaftqError):
+            e.step_batch(d4)  # the synchronous form refuses to jump the queue
+        wa, wb, wc = s.step_batch(a), s.step_batch(b), s.step_batch(c3)
         assert np.array_equal(e.step_collect()[0], wa) and np.array_equal(e.step_collect()[0], wb)
+        assert np.array_equal(e.step_collect()[0], wc)
         # a malformed batch fails alone; the batch behind it still applies
         bad = _stepgen.random_batch(rng, s, 50)
         bad["group"][7] = G
@@ -326,6 +330,30 @@ def test_list_walk_equals_sorted_walk_and_orders_stalled_batches(NodeEngine, ora
             srt.step_batch(b)
         _stepgen.assert_same_state(e, s)
         _stepgen.assert_same_state(srt, s)
+        # three in flight: the stalled batch first, second, third; all three; and a steady three-deep stream in which
+        # every batch's results ride in the next batch's walk kernel (or, behind a stall, in its replay)
+        triples = [(run_of(40, 31), run_of(5, 31), run_of(6, 31)), (run_of(5, 32), run_of(40, 32), run_of(6, 32)),
+                   (run_of(5, 33), run_of(6, 33), run_of(40, 33)), (run_of(40, 34), run_of(50, 34), run_of(60, 34))]
+        for abc in triples:
+            want = [s.step_batch(m) for m in abc]
+            for m in abc:
+                e.step_submit(m)
+            for w in want:
+                assert np.array_equal(e.step_collect()[0], w)
+            for m in abc:
+                srt.step_batch(m)
+        _stepgen.assert_same_state(e, s)
+        _stepgen.assert_same_state(srt, s)
+        pending = []
+        for it in range(24):
+            m = run_of(40, 41) if it in (5, 6, 13, 20) else _stepgen.random_batch(rng, s, int(rng.integers(1, 2500)))
+            pending.append(s.step_batch(m))
+            e.step_submit(m)
+            if len(pending) == 3:
+                assert np.array_equal(e.step_collect()[0], pending.pop(0)), it
+        while pending:
+            assert np.array_equal(e.step_collect()[0], pending.pop(0))
+        _stepgen.assert_same_state(e, s)
         # and the list walk resumes after a replay: a sparse batch behind it all
         m = _stepgen.random_batch(rng, s, 3000)
         assert np.array_equal(e.step_batch(m)[0], s.step_batch(m))

@@ -123,6 +123,7 @@ struct raftq {
     // the batch's result copy has not been enqueued yet: it rides in the NEXT batch's walk kernel (a copy kernel of its
     // own keeps that batch's kernels from starting until it retires), or is launched by the batch's collect
     bool copy_pending = false;
+    const void* msgs_in_place = nullptr;  // the walk read this batch's records where the producer wrote them (in_bar), not in `dev`
     const void* outs_d = nullptr;  // device result records of this batch (in `dev`)
     uint64_t out_quads = 0;        // ... in 16-byte units, tail included
     int end_bit = 0;

@@ -464,14 +464,37 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   const int mode = h->step_stream_mode;
   hipStream_t s_in = mode == 1 ? h->stream : h->step_s_in;
   hipStream_t s_out = (mode == 1 || mode == 2) ? h->stream : mode == 4 ? h->step_s_in : h->step_s_out;
-  // in: one DMA over PCIe from the pinned staging -- or, when the producer wrote the batch straight into device
-  // memory, a device-to-device copy into the slot's scratch (the replay path needs the batch there; 4 MB in ~3 us)
-  void* in_dst = wire ? (void*)s.w_off : packed ? s.msgs40 : (void*)s.msgs;
-  if (staged_in_device) HIPCHK(h, hipMemcpyAsync(in_dst, device_src, in_bytes, hipMemcpyDeviceToDevice, s_in));
-  else HIPCHK(h, hipMemcpyAsync(in_dst, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
-  if (s_in != h->stream) {
-    HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+  // in: one DMA over PCIe from the pinned staging.  A batch the producer wrote straight into device memory needs neither
+  // a DMA nor a copy: the kernels read it where it lies (the slot's staging stays untouched until the slot's next batch,
+  // which is after this one's collect -- the replay path reads it there as well).  Round 2 first kept a device-to-device
+  // copy into the slot's scratch; with the result copy inside the walk kernel that 3 us blit sat on the critical path,
+  // held back like every other kernel while a kernel writes to host memory (rocprof: 2.4 .. 75 us).
+  sl.msgs_in_place = nullptr;
+  const void* packed_src = s.msgs40;
+  const bool own_staging = staged_in_device && (const uint8_t*)device_src >= (const uint8_t*)sl.in_bar &&
+                           (const uint8_t*)device_src + in_bytes <= (const uint8_t*)sl.in_bar + sl.in_bar_bytes;
+  if (own_staging) {
+    if (packed) packed_src = device_src;
+    else {
+      s.msgs = (MsgRec*)const_cast<void*>(device_src);
+      sl.msgs_in_place = device_src;
+    }
+  } else if (staged_in_device) {
+    // another slot's staging (a caller that kept an earlier batch's pointer): that buffer may be handed out again while
+    // this batch is in flight, so the records are copied into this slot's scratch, device to device
+    void* in_dst = packed ? s.msgs40 : (void*)s.msgs;
+    HIPCHK(h, hipMemcpyAsync(in_dst, device_src, in_bytes, hipMemcpyDeviceToDevice, s_in));
+    if (s_in != h->stream) {
+      HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    }
+  } else {
+    void* in_dst = wire ? (void*)s.w_off : packed ? s.msgs40 : (void*)s.msgs;
+    HIPCHK(h, hipMemcpyAsync(in_dst, sl.in_h, in_bytes, hipMemcpyHostToDevice, s_in));
+    if (s_in != h->stream) {
+      HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    }
   }
   // touched count + bad + skipped: the default result copy leaves them zeroed behind it (step_d2h_kernel zero_tail)
   const uint32_t rec = h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
@@ -479,7 +502,7 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   sl.tail_zeroed = false;
   if (packed) {
     hipLaunchKernelGGL(raftqk::step_unpack40_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                       (const raftqk::Msg40Rec*)s.msgs40, s.msgs, n);
+                       (const raftqk::Msg40Rec*)packed_src, s.msgs, n);
     HIPCHK(h, hipGetLastError());
   }
   if (wire) {
@@ -652,6 +675,7 @@ static int replay_stalled(raftq_t* h, uint64_t first) {
     }
     Scratch s;
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, sl.wire, sl.w_nbytes)) return rc;
+    if (sl.msgs_in_place) s.msgs = (MsgRec*)const_cast<void*>(sl.msgs_in_place);
     hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
     if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.wire, s.outs)) return rc;
     const uint64_t out_quads = tail_off(sl.n, sl.rec) / 16 + 1;

@@ -550,3 +550,34 @@ def test_step_packed_inbound_records(NodeEngine, oracle):
         _stepgen.assert_same_state(e, s)
         with pytest.raises(AssertionError):
             e.step_submit_packed(m)  # the mirror refuses the wrong record type
+
+
+def test_step_staged_pointer_reused_for_a_later_batch(NodeEngine, oracle):
+    """A staging array is walked where the producer wrote it (no copy) when it is the submitting slot's own; a caller
+    that hands in an EARLIER batch's staging array again (the slots rotate: that array belongs to another slot now)
+    still gets the right answer -- those records are copied device to device first."""
+    rng = np.random.default_rng(58)
+    G, N = 2048, 3
+    s = _stepgen.random_state(rng, G, N, 0)
+    with NodeEngine(G, N, 0) as e:
+        _stepgen.load_engine(e, s)
+        n = 1500
+        m = _stepgen.random_batch(rng, s, n)
+        p0 = e.step_stage(n)
+        p0[:] = m
+        got, _ = e.step_inplace(p0)  # slot 0, in place
+        assert np.array_equal(got, s.step_batch(m))
+        got, _ = e.step_inplace(p0)  # the same array again: slot 1 is submitting, the records are in slot 0's staging
+        assert np.array_equal(got, s.step_batch(m))
+        # pipelined: slot 2 in place, slot 0 in place, then slot 2's array again while its own batch is still in flight
+        a, b = _stepgen.random_batch(rng, s, n), _stepgen.random_batch(rng, s, n)
+        pa = e.step_stage(n)
+        pa[:] = a
+        e.step_submit(pa)
+        pb = e.step_stage(n)
+        pb[:] = b
+        e.step_submit(pb)
+        e.step_submit(pa)
+        for mm in (a, b, a):
+            assert np.array_equal(e.step_collect()[0], s.step_batch(mm))
+        _stepgen.assert_same_state(e, s)

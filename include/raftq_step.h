@@ -146,7 +146,9 @@ int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_ste
  * can address it (large BAR: the receive path's stores land in HBM and the batch needs no inbound DMA), pinned
  * host memory otherwise (or with RAFTQ_STAGE=host); write-only for the host either way (reads of device
  * memory over the BAR are uncached).  Fill it in place and pass the SAME pointer to raftq_step_submit /
- * raftq_step_batch and no host copy is made (valid until that submit).  With out == NULL the result
+ * raftq_step_batch and no host copy is made -- behind a large BAR no copy at all: the batch is walked where it was
+ * written, so the array belongs to the library from that submit until the batch is collected (do not write to it
+ * again; raftq_step_stage hands out another slot's array for the next batch).  With out == NULL the result
  * records stay in pinned memory; raftq_step_results returns those of the batch collected last
  * (valid until the next raftq_step_submit / raftq_step_batch). */
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs);

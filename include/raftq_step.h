@@ -141,7 +141,7 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 int raftq_step_submit(raftq_t* h, const raftq_msg_t* msgs, uint64_t n);
 int raftq_step_collect(raftq_t* h, raftq_step_out_t* out /*[n]|NULL*/, raftq_step_counts_t* counts /*|NULL*/);
 
-/* zero-copy variants.  raftq_step_stage returns the staging array the NEXT submit will use (the two slots
+/* zero-copy variants.  raftq_step_stage returns the staging array the NEXT submit will use (the three slots
  * alternate: ask again for every batch), with room for n messages -- fine-grained DEVICE memory when the host
  * can address it (large BAR: the receive path's stores land in HBM and the batch needs no inbound DMA), pinned
  * host memory otherwise (or with RAFTQ_STAGE=host); write-only for the host either way (reads of device

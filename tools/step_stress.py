@@ -1,6 +1,7 @@
 """Randomised soak of the pipelined Step (list walk + stall replay) against the sequential oracle: batches of
-random size, with and without long per-group runs, submitted two deep with random collect timing, from records and
-from frames.  Not part of the suite (minutes); run it after touching raftq_step.hip."""
+random size, with and without long per-group runs, submitted up to three deep with random collect timing: from
+caller-owned records, from the staging array in place (walked where written, result copy riding in the next batch's
+walk kernel), as 40-byte packed records (copied or staged), and from frames.  Not part of the suite (minutes); run it after touching raftq_step.hip."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
@@ -12,7 +13,7 @@ from tests import _stepgen
 pyoracle.build()
 seconds = float(os.environ.get("SECONDS_BUDGET", "60"))
 t_end = time.time() + seconds
-n_batches = n_msgs = n_long = 0
+n_batches = n_msgs = n_long = n_staged = 0
 seed = int(os.environ.get("SEED", "1"))
 while time.time() < t_end:
     seed += 1
@@ -31,6 +32,33 @@ while time.time() < t_end:
                 k = min(n, int(rng.integers(28, 40)))
                 m["group"][rng.choice(n, k, replace=False)] = int(rng.integers(0, G))
             n_long += int(np.bincount(m["group"].astype(np.int64)).max() > 32)
+            mode = rng.random()
+            if mode < 0.5:  # staged in place / packed: the device-memory paths of round 2
+                packed = rng.random() < 0.5
+                if packed:
+                    w = m.copy()
+                    resp = m["type"] == S.MSG_APP_RESP
+                    w["log_term"] = np.where(resp, 0, m["log_term"])
+                    w["reject_hint"] = np.where(resp, m["reject_hint"], 0)
+                    want = s.step_batch(w)
+                    if rng.random() < 0.5:
+                        st = e.step_stage_packed(n)
+                        S.pack_msgs40(m, out=st)
+                        e.step_submit_packed(st)
+                    else:
+                        e.step_submit_packed(S.pack_msgs40(m))
+                else:
+                    want = s.step_batch(m)
+                    st = e.step_stage(n)
+                    st[:] = m
+                    e.step_submit(st)
+                pending.append(want)
+                n_batches += 1; n_msgs += n; n_staged += 1
+                while len(pending) == 3 or (pending and rng.random() < 0.4):
+                    got, _ = e.step_collect()
+                    wv = pending.pop(0)
+                    assert got.tobytes() == wv.tobytes(), (seed, it)
+                continue
             want = s.step_batch(m)
             if rng.random() < 0.3 and N > 1:  # through the wire
                 wm = np.zeros(n, W.WIRE_MSG_DT)
@@ -47,7 +75,7 @@ while time.time() < t_end:
                 e.step_submit(m)
             pending.append(want)
             n_batches += 1; n_msgs += n
-            while len(pending) == 2 or (pending and rng.random() < 0.5):
+            while len(pending) == 3 or (pending and rng.random() < 0.4):
                 got, _ = e.step_collect()
                 w = pending.pop(0)
                 assert got.tobytes() == w.tobytes(), (seed, it)
@@ -55,4 +83,5 @@ while time.time() < t_end:
             got, _ = e.step_collect()
             assert got.tobytes() == pending.pop(0).tobytes(), seed
         _stepgen.assert_same_state(e, s)
-print("step stress ok: %d batches, %d messages, %d batches with a run > 32, last seed %d" % (n_batches, n_msgs, n_long, seed))
+print("step stress ok: %d batches (%d staged in device memory / packed), %d messages, %d batches with a run > 32, last seed %d"
+      % (n_batches, n_staged, n_msgs, n_long, seed))

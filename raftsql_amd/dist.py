@@ -6,8 +6,14 @@ a MAX over ranks of the wall time and a SUM of the per-rank tallies.  Backend
 """
 from __future__ import annotations
 
+import datetime
 import os
 from dataclasses import dataclass
+
+
+# a rank that cannot reach the others gives up after this long instead of sitting in the rendezvous for torch's default
+# half hour (the job's only collectives are a handful of barriers and 8-byte reductions)
+_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("RAFTQ_DIST_TIMEOUT_S", "300")))
 
 
 @dataclass
@@ -41,14 +47,14 @@ def init_from_env(backend: str | None = None) -> World:
         # job -- tried in round 2, two ranks on one GPU sat in different rendezvous for the whole time limit.  A rank
         # that cannot join fails loudly and torchrun tears the job down.)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=size,
+        dist.init_process_group("nccl", rank=rank, world_size=size, timeout=_TIMEOUT,
                                 device_id=torch.device("cuda", local_rank))
         # first collective creates the communicator: do it here, outside any timed region
         warm = torch.zeros(1, device=torch.device("cuda", local_rank))
         dist.all_reduce(warm)
         torch.cuda.synchronize()
     else:
-        dist.init_process_group(backend, rank=rank, world_size=size)
+        dist.init_process_group(backend, rank=rank, world_size=size, timeout=_TIMEOUT)
     return World(rank, local_rank, size, backend)
 
 

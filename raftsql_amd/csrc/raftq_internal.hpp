@@ -149,6 +149,7 @@ struct raftq {
   uint64_t step_submitted = 0, step_collected = 0;  // slot of batch k = k % kStepSlots
   hipStream_t step_s_in = nullptr, step_s_out = nullptr;
   int step_stream_mode = 2;
+  int step_link_share = 25;        // per cent of a carried result copy that rides in the link kernel (the rest: the walk kernel)
   bool step_defer_copy = true;     // RAFTQ_STEP_DEFER_COPY=0: every batch launches its own result copy (round 1's form; for A/B)
   const void* step_last_out = nullptr;  // results of the last collected batch
   uint64_t step_last_n = 0;

@@ -113,6 +113,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
     // memory (186 us) -- none beat 2; those variants are no longer in the code.  RAFTQ_STEP_STREAMS = 1..4 overrides.
     if (const char* m = std::getenv("RAFTQ_STEP_STREAMS")) h->step_stream_mode = std::atoi(m);
     if (const char* m = std::getenv("RAFTQ_STEP_DEFER_COPY")) h->step_defer_copy = std::atoi(m) != 0;
+    if (const char* m = std::getenv("RAFTQ_STEP_LINK_SHARE")) h->step_link_share = std::min(100, std::max(0, std::atoi(m)));
   }
   if (!sl.ev_in) {
     HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
@@ -382,13 +383,18 @@ static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   unsigned int* skipped = bad + 1;  // the last word of the 16-byte tail behind the result records
   const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
-  const unsigned cp_blocks = carry ? d2h_blocks(carry->out_quads) : 0;
-  hipLaunchKernelGGL(step_link_kernel, dim3(blocks), dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G, h->N, from_wire,
-                     list_arrays(h), s.next, bad, h->step_stall);
-  hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + cp_blocks), dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
-                     s.outs, h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads, skipped,
-                     (const unsigned int*)bad, (const unsigned int*)h->step_stall, (const u64x2*)(carry ? carry->outs_d : nullptr),
-                     (u64x2*)(carry ? carry->out_d : nullptr), carry ? carry->out_quads : 0, cp_blocks);
+  // the carried copy is split over this batch's two kernels roughly as their own durations are (link ~ 1/5 of the chain)
+  raftqk::CopyRide in_link{nullptr, nullptr, 0, 0, 0, 0}, in_walk = in_link;
+  if (carry) {
+    const uint64_t quads = carry->out_quads, cut = quads * (uint64_t)h->step_link_share / 100;
+    in_link = {(const u64x2*)carry->outs_d, (u64x2*)carry->out_d, 0, cut, quads - 1, cut ? d2h_blocks(cut) : 0u};
+    in_walk = {(const u64x2*)carry->outs_d, (u64x2*)carry->out_d, cut, quads, quads - 1, d2h_blocks(quads - cut)};
+  }
+  hipLaunchKernelGGL(step_link_kernel, dim3(blocks + in_link.blocks), dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G,
+                     h->N, from_wire, list_arrays(h), s.next, bad, h->step_stall, in_link);
+  hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + in_walk.blocks), dim3(kBlock), 0, h->stream, node_arrays(h),
+                     (const MsgRec*)s.msgs, s.outs, h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads,
+                     skipped, (const unsigned int*)bad, (const unsigned int*)h->step_stall, in_walk);
   HIPCHK(h, hipGetLastError());
   if (carry) {
     HIPCHK(h, hipEventRecord(carry->ev_out, h->stream));

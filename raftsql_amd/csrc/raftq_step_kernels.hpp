@@ -376,11 +376,36 @@ struct ListArrays {
   uint32_t* minp;  // [ld] smallest batch position of the group
 };
 
+// A slice [q0, q1) of the PREVIOUS batch's result records on its way to the host, carried by the first `blocks`
+// workgroups of a kernel of THIS batch (step_d2h_kernel's loop).  As a kernel of its own that copy holds back this
+// batch's kernels until it retires -- measured in round 1, profiles/r01/step_pipeline_trace.txt -- so a pipelined batch
+// cost walk + copy; inside this batch's kernels the two overlap (the copy is PCIe-bound, the kernels HBM-latency-bound).
+// The slice that ends the records also clears the device copy of the tail for the slot's next batch (zero_tail).
+struct CopyRide {
+  const u64x2* src;
+  u64x2* dst;
+  uint64_t q0, q1, q_last;  // q_last: index of the tail quad
+  uint32_t blocks;
+};
+
+__device__ __forceinline__ void copy_ride(const CopyRide& c) {
+  const uint64_t stride = (uint64_t)c.blocks * kBlock;
+  for (uint64_t q = c.q0 + (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < c.q1; q += stride) {
+    const u64x2 v = c.src[q];
+    __builtin_nontemporal_store(v, c.dst + q);
+    if (q == c.q_last) const_cast<u64x2*>(c.src)[q] = u64x2{0, 0};
+  }
+}
+
 static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* __restrict__ msgs, uint64_t n,
                                                                   uint64_t n_groups, uint32_t n_peers, bool from_wire,
                                                                   ListArrays l, uint32_t* __restrict__ next,
-                                                                  unsigned int* bad, unsigned int* stall) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                                  unsigned int* bad, unsigned int* stall, CopyRide ride) {
+  if (blockIdx.x < ride.blocks) {
+    copy_ride(ride);
+    return;
+  }
+  const uint64_t i = (uint64_t)(blockIdx.x - ride.blocks) * kBlock + threadIdx.x;
   bool is_bad = false, too_long = false;
   if (i < n) {
     const uint64_t g = msgs[i].group;
@@ -406,23 +431,12 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
                                                                    uint64_t n_groups, ListArrays l,
                                                                    const uint32_t* __restrict__ next,
                                                                    unsigned long long* n_heads, unsigned int* tail_skipped,
-                                                                   const unsigned int* bad, const unsigned int* stall,
-                                                                   const u64x2* cp_src, u64x2* cp_dst, uint64_t cp_quads,
-                                                                   uint32_t cp_blocks) {
-  // The first cp_blocks workgroups carry the PREVIOUS batch's result records to the host (step_d2h_kernel's loop, its
-  // zero_tail form).  As a kernel of its own that copy holds back this batch's kernels until it retires -- measured in
-  // round 1, profiles/r01/step_pipeline_trace.txt -- so a pipelined batch cost walk + copy; inside the walk kernel the two
-  // overlap: the copy is PCIe-bound, the walk HBM-latency-bound.
-  if (blockIdx.x < cp_blocks) {
-    const uint64_t stride = (uint64_t)cp_blocks * kBlock;
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < cp_quads; q += stride) {
-      const u64x2 v = cp_src[q];
-      __builtin_nontemporal_store(v, cp_dst + q);
-      if (q == cp_quads - 1) const_cast<u64x2*>(cp_src)[q] = u64x2{0, 0};
-    }
+                                                                   const unsigned int* bad, const unsigned int* stall, CopyRide ride) {
+  if (blockIdx.x < ride.blocks) {  // the rest of the previous batch's results (see CopyRide)
+    copy_ride(ride);
     return;
   }
-  const uint64_t i = (uint64_t)(blockIdx.x - cp_blocks) * kBlock + threadIdx.x;
+  const uint64_t i = (uint64_t)(blockIdx.x - ride.blocks) * kBlock + threadIdx.x;
   const bool stalled = *stall != 0;  // this batch, or one before it that has not been replayed yet, needs the sorted path
   if (stalled || *bad) {             // (*bad: a malformed record somewhere in the batch) -- nothing is applied;
     if (stalled && i == 0) *tail_skipped = 1u;

@@ -376,3 +376,82 @@ def test_handle_msg_app_table(gpu_engine_cls):
         assert nd.log(6) == [(1, b"one"), (2, b"two")]  # entry 2 matched: the log keeps its own copy
     finally:
         nd.destroy()
+
+
+def test_leader_cycle(net):
+    """TestLeaderCycle: each node in turn campaigns and is elected; the others follow."""
+    tt = net(3)
+    for term, campaigner in enumerate((1, 2, 3), start=1):
+        tt.hup(campaigner)
+        for i in (1, 2, 3):
+            tt.expect(i, role=LEADER if i == campaigner else FOLLOWER, term=term)
+
+
+def test_leader_sync_follower_log_figure_7(gpu_engine_cls):
+    """TestLeaderSyncFollowerLog (raft_paper_test.go; the six follower logs of Figure 7 of the raft paper): a leader whose
+    log is (1,1,1,4,4,5,5,6,6,6) by term is elected at term 9 over a follower whose log is missing entries, has extra
+    uncommitted entries, or both; after one proposal the follower's log is the leader's.  The six cases are six groups
+    of one three-node cluster (the third node swallows everything, as upstream's nopStepper does; its vote is injected).
+    What is exercised: the reject / RejectHint back-off of the leader's replication cursor and the follower's
+    findConflict-and-truncate -- host logic of raftq_node -- around the batched Step."""
+    from oracle import pywire as W
+    from raftsql_amd.node import Cluster
+
+    lead_terms = [1, 1, 1, 4, 4, 5, 5, 6, 6, 6]
+    followers = [[1, 1, 1, 4, 4, 5, 5, 6, 6],
+                 [1, 1, 1, 4],
+                 [1, 1, 1, 4, 4, 5, 5, 6, 6, 6, 6],
+                 [1, 1, 1, 4, 4, 5, 5, 6, 6, 6, 7, 7],
+                 [1, 1, 1, 4, 4, 4, 4],
+                 [1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 3]]
+    k, term = len(followers), 8
+    c = Cluster(k, 3, seed=2)
+    try:
+        for g in range(k):
+            # an entry is identified by (index, term): the same payload wherever the two logs agree on both
+            c.nodes[0].replay(g, [(t, b"e%d.%d" % (i, t)) for i, t in enumerate(lead_terms, 1)])
+            c.nodes[0].set_hard_state(g, term, 0, len(lead_terms))
+            c.nodes[1].replay(g, [(t, b"e%d.%d" % (i, t)) for i, t in enumerate(followers[g], 1)])
+            c.nodes[1].set_hard_state(g, term - 1, 0, 0)
+        c.start()
+        live = (0, 1)
+
+        def pump():
+            for _ in range(400):
+                moved = False
+                for p in live:
+                    c.nodes[p].advance()
+                for p in live:
+                    for q in range(3):
+                        if q == p:
+                            continue
+                        blob = c.nodes[p].poll(q)
+                        if blob:
+                            moved = True
+                            if q in live:
+                                c.nodes[q].deliver(blob)
+                if not moved:
+                    return
+            raise AssertionError("did not quiesce")
+
+        groups = np.arange(k, dtype=np.uint64)
+        c.nodes[0].campaign(groups)
+        pump()
+        # "The election occurs in the term after the one we loaded": the third member's vote
+        v = np.zeros(k, W.WIRE_MSG_DT)
+        v["group"], v["term"], v["type"], v["from"], v["to"] = groups, term + 1, VOTE_RESP, 2, 0
+        stream, _ = W.wire_encode(v)
+        c.nodes[0].deliver(stream.tobytes())
+        pump()
+        st = c.nodes[0].statuses()
+        assert np.all(st["role"] == LEADER) and np.all(st["term"] == term + 1)
+        c.nodes[0].propose_batch(groups, [b""] * k)  # upstream proposes an empty entry
+        pump()
+        want_terms = lead_terms + [term + 1, term + 1]  # + becomeLeader's empty entry + the proposal
+        for g in range(k):
+            a, b = c.nodes[0].log(g), c.nodes[1].log(g)
+            assert [t for t, _ in a] == want_terms, (g, a)
+            assert b == a, (g, [t for t, _ in b])
+        assert np.all(c.nodes[1].statuses()["commit"] == len(want_terms))
+    finally:
+        c.close()

@@ -455,3 +455,68 @@ def test_leader_sync_follower_log_figure_7(gpu_engine_cls):
         assert np.all(c.nodes[1].statuses()["commit"] == len(want_terms))
     finally:
         c.close()
+
+
+def test_follower_tables_of_the_paper_tests(gpu_engine_cls):
+    """raft_paper_test.go's follower-side tables as recalled, one group per row, one batch: TestFollowerAppendEntries (4 rows:
+    the log after the MsgApp), TestFollowerCheckMsgApp (5 rows: Index / Reject / RejectHint of the answer) and
+    TestFollowerCommitEntry (4 rows: the commit index and what reaches the commit channel)."""
+    from oracle import pywire as W
+    from raftsql_amd.node import RaftNode
+
+    base = [(1, b"e1.1"), (2, b"e2.2")]
+    rows = []  # (initial log, hard state (term, commit), msg (term, log_term, index, commit), entries [(index, term, data)], check)
+    for index, term, ents, wents in [(2, 2, [(3, 3)], [1, 2, 3]), (1, 1, [(2, 3), (3, 4)], [1, 3, 4]), (0, 0, [(1, 1)], [1, 2]),
+                                     (0, 0, [(1, 3)], [3])]:
+        rows.append((base, (2, 0), (2, term, index, 0), [(i, t, b"e%d.%d" % (i, t)) for i, t in ents], ("log_terms", wents)))
+    for term, index, windex, wreject, whint in [(0, 0, 1, False, 0), (1, 1, 1, False, 0), (2, 2, 2, False, 0), (1, 2, 2, True, 2),
+                                                (3, 3, 3, True, 2)]:
+        rows.append((base, (2, 1), (2, term, index, 0), [], ("resp", (windex, wreject, whint))))
+    for ents, commit in [([b"some data"], 1), ([b"some data", b"some data2"], 2), ([b"some data2", b"some data"], 2),
+                         ([b"some data", b"some data2"], 1)]:
+        rows.append(([], (1, 0), (1, 0, 0, commit), [(i, 1, d) for i, d in enumerate(ents, 1)], ("commit", (commit, ents[:commit]))))
+    k = len(rows)
+    nd = RaftNode(k, 3, 0)
+    try:
+        for g, (log, (hs_term, hs_commit), *_rest) in enumerate(rows):
+            if log:
+                nd.replay(g, log)
+            nd.set_hard_state(g, hs_term, 0, hs_commit)
+        nd.start(10, 1, seed=1)
+        replayed = [nd.drain(g) for g in range(k)]  # replayWAL's entries and the nil sentinel
+        assert all(r[-1] is None for r in replayed)
+        msgs = np.zeros(k, W.WIRE_MSG_DT)
+        ents = np.zeros(sum(len(r[3]) for r in rows), W.WIRE_ENT_DT)
+        pool, at = b"", 0
+        for g, (_log, _hs, (term, log_term, index, commit), es, _chk) in enumerate(rows):
+            msgs[g] = (g, term, log_term, index, commit, 0, 1, APP, 0, 0, 0, at, len(es))
+            for (ei, et, data) in es:
+                ents[at] = (et, ei, len(pool), len(data), 0)
+                pool += data
+                at += 1
+        stream, _ = W.wire_encode(msgs, ents, pool)
+        nd.deliver(stream.tobytes())
+        nd.advance()
+        st = nd.statuses()
+        out = nd.poll(1)
+        off, used = W.scan_frames(out, big_endian=True)
+        mm, _, bad = W.wire_decode(out, off)
+        assert used == len(out) and bad == 0 and len(mm) == k
+        by_group = {int(m["group"]): m for m in mm}
+        for g, (*_x, (kind, want)) in enumerate(rows):
+            m = by_group[g]
+            assert int(m["type"]) == APP_RESP and int(m["term"]) == rows[g][2][0]
+            if kind == "log_terms":
+                assert [t for t, _ in nd.log(g)] == want, (g, nd.log(g))
+                assert not m["reject"]
+            elif kind == "resp":
+                windex, wreject, whint = want
+                assert (int(m["index"]), bool(m["reject"])) == (windex, wreject), (g, m)
+                if wreject:
+                    assert int(m["reject_hint"]) == whint
+            else:
+                wcommit, wents = want
+                assert int(st["commit"][g]) == wcommit, (g, int(st["commit"][g]))
+                assert nd.drain(g) == wents, g  # nextEnts: exactly the committed prefix, in order
+    finally:
+        nd.destroy()

@@ -55,6 +55,8 @@ def pack_msgs40(msgs: np.ndarray, out: np.ndarray | None = None) -> np.ndarray:
     """raftq_msg_t[] -> raftq_msg40_t[] (into `out` when given, e.g. a staging array).  Exact for every batch in which
     no MsgAppResp carries a log_term and no other kind a reject_hint (Step reads neither)."""
     a = np.zeros(len(msgs), dtype=MSG40_DT) if out is None else out
+    if len(msgs) and (int(msgs["group"].max()) >> 32 or int(msgs["from"].max()) >> 8):
+        raise ValueError("pack_msgs40: a group id or sender slot does not fit the packed record")
     for k in ("group", "from", "type", "reject", "term", "index", "commit"):
         a[k] = msgs[k]
     a["_pad"] = 0

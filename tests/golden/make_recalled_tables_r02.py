@@ -1,7 +1,7 @@
 """Adds more of etcd's own tables, AS RECALLED, to kat.json -> "upstream_step_tables_recalled" (round 2).
 
 raft_paper_test.go (2015-era): TestLeaderAcknowledgeCommit, TestLeaderOnlyCommitsLogFromCurrentTerm, TestVoter, TestFollowerVote,
-TestLeaderElectionInOneRoundRPC.  The module is absent from this machine: these rows are what the builder remembers of
+TestLeaderElectionInOneRoundRPC; log_test.go: TestIsUpToDate.  The module is absent from this machine: these rows are what the builder remembers of
 upstream's expectations -- alignment evidence, not a pin.  Where upstream reaches the state under test through calls that
 are the host's here (becomeLeader's and MsgProp's appendEntry), the row starts from that state: the comments say which.
 Run once; idempotent (rows of these tables are replaced).  Member ids 1..n map to slots 0..n-1."""
@@ -71,14 +71,24 @@ for i, (size, votes, state) in enumerate(rows):
                           [{"type": VOTE_RESP, "term": 1, "from": k - 1, "reject": int(not v)} for k, v in votes.items()],
                   "want_out": [], "want_state": {"role": state, "term": 1}})
 
+# TestIsUpToDate (log_test.go): a log ending (index 3, term 3); a candidate's (lastIndex, term) is up to date iff its term is
+# greater, or equal with lastIndex >= 3.  Reached through Step as a MsgVote of a higher term: granted iff up to date.
+rows = [(2, 4, True), (3, 4, True), (4, 4, True), (2, 2, False), (3, 2, False), (4, 2, False), (2, 3, False), (3, 3, True), (4, 3, True)]
+for i, (last_index, term, up_to_date) in enumerate(rows):
+    cases.append({"table": "TestIsUpToDate", "row": i, "n": 3, "self": 0,
+                  "init": {"role": FOLLOWER, "term": 3, "vote": 0, "last_index": 3, "last_term": 3},
+                  "msgs": [{"type": VOTE, "term": 5, "from": 1, "index": last_index, "log_term": term}],
+                  "want_out": [{"type": OUT_VOTE_RESP, "reject": int(not up_to_date), "to": 1}],
+                  "want_state": {"term": 5, "vote": 2 if up_to_date else 0}})
+
 kat = json.load(open(PATH))
 rec = kat["upstream_step_tables_recalled"]
 mine = {c["table"] for c in cases}
 rec["cases"] = [c for c in rec["cases"] if c["table"] not in mine] + cases
 note = (" Round 2 (tests/golden/make_recalled_tables_r02.py) adds raft_paper_test.go's TestLeaderAcknowledgeCommit, "
-        "TestLeaderOnlyCommitsLogFromCurrentTerm, TestVoter, TestFollowerVote and TestLeaderElectionInOneRoundRPC; rows whose "
+        "TestLeaderOnlyCommitsLogFromCurrentTerm, TestVoter, TestFollowerVote, TestLeaderElectionInOneRoundRPC and log_test.go's "
+        "TestIsUpToDate; rows whose "
         "upstream setup appends to the log (the host's job here) start from the state that setup produces.")
-if "Round 2 (tests/golden/make_recalled_tables_r02.py)" not in rec["_note"]:
-    rec["_note"] += note
+rec["_note"] = rec["_note"].split(" Round 2 (tests/golden/make_recalled_tables_r02.py)")[0] + note
 json.dump(kat, open(PATH, "w"), indent=1)
 print(len(cases), "rows written;", len(rec["cases"]), "recalled rows in all")

@@ -520,3 +520,69 @@ def test_follower_tables_of_the_paper_tests(gpu_engine_cls):
                 assert nd.drain(g) == wents, g  # nextEnts: exactly the committed prefix, in order
     finally:
         nd.destroy()
+
+
+def test_log_maybe_append_table(gpu_engine_cls):
+    """log_test.go's TestLogMaybeAppend as recalled, through handleAppendEntries on a follower holding (1,1), (2,2), (3,3) with
+    commit index 1: one group per row, one batch.  wlasti is the Index of the MsgAppResp (lastnewi), wappend = not rejected,
+    wcommit the commit index afterwards -- never above lastnewi, never decreasing.  (Upstream's row that conflicts with a
+    committed entry panics there and is left out; its (0, 0) row meets handleAppendEntries' `m.Index < committed` answer
+    first: Index = committed.)"""
+    from oracle import pywire as W
+    from raftsql_amd.node import RaftNode
+
+    li, lt, commit = 3, 3, 1
+    #        logTerm index committed  ents [(index, term)]          wlasti  wappend wcommit
+    rows = [(lt - 1, li, li, [(li + 1, 4)], 0, False, commit),        # not match: term is different
+            (lt, li + 1, li, [(li + 2, 4)], 0, False, commit),        # not match: index out of bound
+            (lt, li, li, [], li, True, li),                           # match with the last existing entry
+            (lt, li, li + 1, [], li, True, li),                       # do not increase commit higher than lastnewi
+            (lt, li, li - 1, [], li, True, li - 1),                   # commit up to the commit in the message
+            (lt, li, 0, [], li, True, commit),                        # commit do not decrease
+            (0, 0, li, [], commit, True, commit),                     # (see the docstring)
+            (lt, li, li, [(li + 1, 4)], li + 1, True, li),
+            (lt, li, li + 1, [(li + 1, 4)], li + 1, True, li + 1),
+            (lt, li, li + 2, [(li + 1, 4)], li + 1, True, li + 1),    # do not increase commit higher than lastnewi
+            (lt, li, li + 2, [(li + 1, 4), (li + 2, 4)], li + 2, True, li + 2),
+            (lt - 1, li - 1, li, [(li, 4)], li, True, li),            # match with the entry in the middle
+            (lt - 2, li - 2, li, [(li - 1, 4)], li - 1, True, li - 1),
+            (lt - 2, li - 2, li, [(li - 1, 4), (li, 4)], li, True, li)]
+    k = len(rows)
+    nd = RaftNode(k, 3, 0)
+    try:
+        for g in range(k):
+            nd.replay(g, [(1, b"e1.1"), (2, b"e2.2"), (3, b"e3.3")])
+            nd.set_hard_state(g, 4, 0, commit)
+        nd.start(10, 1, seed=1)
+        msgs = np.zeros(k, W.WIRE_MSG_DT)
+        ents = np.zeros(sum(len(r[3]) for r in rows), W.WIRE_ENT_DT)
+        pool, at = b"", 0
+        for g, (log_term, index, committed, es, *_w) in enumerate(rows):
+            msgs[g] = (g, 4, log_term, index, committed, 0, 1, APP, 0, 0, 0, at, len(es))
+            for (ei, et) in es:
+                data = b"e%d.%d" % (ei, et)
+                ents[at] = (et, ei, len(pool), len(data), 0)
+                pool += data
+                at += 1
+        stream, _ = W.wire_encode(msgs, ents, pool)
+        nd.deliver(stream.tobytes())
+        nd.advance()
+        st = nd.statuses()
+        out = nd.poll(1)
+        off, used = W.scan_frames(out, big_endian=True)
+        mm, _, bad = W.wire_decode(out, off)
+        assert used == len(out) and bad == 0 and len(mm) == k
+        by_group = {int(m["group"]): m for m in mm}
+        for g, (log_term, index, committed, es, wlasti, wappend, wcommit) in enumerate(rows):
+            m = by_group[g]
+            assert bool(m["reject"]) == (not wappend), (g, m)
+            if wappend:
+                assert int(m["index"]) == wlasti, (g, int(m["index"]))
+                want_log = [1, 2, 3][:min(3, es[0][0] - 1) if es else 3] + [t for _, t in es]
+                assert [t for t, _ in nd.log(g)] == want_log, (g, nd.log(g))
+            else:
+                assert int(m["index"]) == index and int(m["reject_hint"]) == li
+                assert [t for t, _ in nd.log(g)] == [1, 2, 3]
+            assert int(st["commit"][g]) == wcommit, (g, int(st["commit"][g]))
+    finally:
+        nd.destroy()

@@ -107,7 +107,7 @@ struct PropBuf {
 };
 
 // Growable page-locked byte buffer (raftq_host_alloc) for everything the codecs read or fill: the GPU
-// moves such memory by direct DMA.  Measured on MI355X (tools/wire_fresh_buffers.py): a 64K-frame decode
+// moves such memory by direct DMA.  Measured on MI355X (tests/soak/wire_fresh_buffers.py): a 64K-frame decode
 // into freshly allocated pageable arrays takes 2.8 ms, into the same pinned arrays every turn 0.21 ms.
 struct PinBuf {
   uint8_t* p = nullptr;

@@ -499,7 +499,7 @@ def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
         with pytest.raises(RaftqError) as ei:
             e.cycle(SWEEP_COMMIT | CYCLE_TRUSTED, d2, v2)
         assert ei.value.code == -1
-        # the dropped match record does not take the vote deltas of the turn with it (found by tools/soak_r02.py)
+        # the dropped match record does not take the vote deltas of the turn with it (found by tests/soak/soak_r02.py)
         ref_votes = oracle.apply_vote_deltas(ref_votes, v2["group"].copy(), v2["peer"].copy(), v2["vote"].copy())
         assert np.array_equal(e.read_votes(), ref_votes)
         ref_match = oracle.apply_deltas(ref_match, dg[keep], dp[keep], dm2[keep])

@@ -114,12 +114,26 @@ def test_no_silent_cpu_fallback(lib):
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "raftsql_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "pyoracle" not in txt and "raftq_oracle" not in txt, f
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's CPU legs may execute it.
+    Nothing under raftsql_amd/, include/, go/ or tools/ may name it; bench.py and __graft_entry__.py import it inside
+    functions only (never at module level, so importing either never loads the oracle)."""
+    import re
+
+    for top in ("raftsql_amd", "include", "go", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".go", ".sh")):
+                    path = os.path.join(dirpath, f)
+                    txt = open(path).read()
+                    if f.endswith((".py", ".sh")):
+                        assert "pyoracle" not in txt and "raftq_oracle" not in txt and "pywire" not in txt, path
+                        assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), path
+                    else:  # compiled sources may mention the oracle in a comment, never include or link it
+                        assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', txt), path
+                        assert "rq_oracle_" not in txt and "liboracle" not in txt, path
+    for f in ("bench.py", "__graft_entry__.py"):
+        txt = open(os.path.join(ROOT, f)).read()
+        assert not re.search(r"^(from|import)\s+oracle\b", txt, flags=re.M), f  # module level
 
 
 def test_headers_are_plain_c99_and_link_from_c(lib, tmp_path):

@@ -190,3 +190,14 @@ func (e *Engine) WalReadAll(data []byte, frameOff []uint64, prevCrc uint32, recs
 		C.uint64_t(n), C.uint32_t(prevCrc), (*C.raftq_wal_rec_t)(unsafe.Pointer(&recs[0])), &c)
 	return uint64(c.n_valid), uint32(c.last_crc), e.err(rc)
 }
+
+// StepStageWire returns the arrays the next StepSubmitWire will take, with room for nCap frames and nbytesCap stream
+// bytes (raftq_step_stage_wire): device memory behind a large BAR -- fill them in place and submit slices of them.
+func (e *Engine) StepStageWire(nCap, nbytesCap int) (frameOff []uint64, stream []byte, err error) {
+	var po *C.uint64_t
+	var ps unsafe.Pointer
+	if rc := C.raftq_step_stage_wire(e.h, C.uint64_t(nCap), C.uint64_t(nbytesCap), &po, &ps); rc != C.RAFTQ_OK {
+		return nil, nil, e.err(rc)
+	}
+	return unsafe.Slice((*uint64)(unsafe.Pointer(po)), nCap+1), unsafe.Slice((*byte)(ps), nbytesCap), nil
+}

@@ -124,6 +124,13 @@ int raftq_wire_scan_frames(const void* buf, uint64_t nbytes, int big_endian, uin
  * msgs[i].ent_first / n_ents through raftq_step_wire_msgs -- both in pinned memory, valid until
  * the next submit into that slot. */
 int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n);
+/* Zero-copy form: the arrays the NEXT raftq_step_submit_wire will take, with room for n_cap frames and nbytes_cap stream
+ * bytes -- fine-grained device memory behind a large BAR (the receive path's stores, or a NIC's, land in HBM and the
+ * frames are decoded where they lie: no DMA, no copy), pinned host memory otherwise; write-only for the host either
+ * way.  Fill frame_off[0..n] and the stream, pass the SAME two pointers to raftq_step_submit_wire.  The arrays belong to
+ * the library from that submit until the batch is collected; asking for a slot's arrays again ends the validity of
+ * raftq_step_wire_msgs / _entries for the batch that was decoded in them. */
+int raftq_step_stage_wire(raftq_t* h, uint64_t n_cap, uint64_t nbytes_cap, uint64_t** frame_off, void** stream);
 int raftq_step_wire_msgs(raftq_t* h, const raftq_wire_msg_t** msgs, uint64_t* n);
 int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t* n_ents);
 

@@ -123,6 +123,9 @@ struct raftq {
     // the batch's result copy has not been enqueued yet: it rides in the NEXT batch's walk kernel (a copy kernel of its
     // own keeps that batch's kernels from starting until it retires), or is launched by the batch's collect
     bool copy_pending = false;
+    const void* w_off_in_place = nullptr;     // raftq_step_stage_wire: the decoder read the frame boundaries / the stream where
+    const void* w_stream_in_place = nullptr;  // the producer wrote them (in_bar)
+    size_t w_stage_stream_off = 0;            // where raftq_step_stage_wire put the stream within the slot's staging
     const void* msgs_in_place = nullptr;  // the walk read this batch's records where the producer wrote them (in_bar), not in `dev`
     const void* outs_d = nullptr;  // device result records of this batch (in `dev`)
     uint64_t out_quads = 0;        // ... in 16-byte units, tail included

@@ -204,8 +204,8 @@ int ensure_slot_staging(raftq_t* h, raftq::StepSlot& sl, uint64_t n, size_t raw_
 }
 
 // the in-place staging of raftq_step_stage: device memory the host can write (large BAR), else the pinned buffer
-int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out) {
-  const size_t bytes = (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
+int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out, size_t raw_bytes = 0) {
+  const size_t bytes = raw_bytes ? raw_bytes : (size_t)std::max<uint64_t>(n, 1) * sizeof(raftq_msg_t);
   if (h->bar_staging) {
     if (bytes > sl.in_bar_bytes) {
       if (sl.in_bar) {
@@ -231,7 +231,7 @@ int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out) {
       return RAFTQ_OK;
     }
   }
-  if (int rc = ensure_slot_staging(h, sl, n)) return rc;
+  if (int rc = ensure_slot_staging(h, sl, n, raw_bytes)) return rc;
   *out = sl.in_h;
   return RAFTQ_OK;
 }
@@ -307,8 +307,11 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
   if (int rc = use_device(h)) return rc;
   if (!msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");
-  raftq::StepSlot& sl = h->step_slot[h->step_submitted % raftq::kStepSlots];  // the slot the next submit will use
+  const int slot_no = (int)(h->step_submitted % raftq::kStepSlots);
+  raftq::StepSlot& sl = h->step_slot[slot_no];  // the slot the next submit will use
   if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage: three batches already in flight; collect one first");
+  // a wire batch decoded in place in this slot has its stream in the buffer the producer is about to overwrite
+  if (h->step_last_slot == slot_no && sl.w_off_in_place) h->step_last_slot = -1;
   void* p = nullptr;
   if (int rc = ensure_slot_bar(h, sl, n, &p)) return rc;
   *msgs = (raftq_msg_t*)p;
@@ -431,12 +434,32 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   size_t in_bytes;
   bool staged_in_device = false;
   const void* device_src = nullptr;
+  // raftq_step_stage_wire's arrays, filled in place: in device memory the decoder reads them where they lie; in pinned
+  // host memory two DMAs take them (the boundaries and the stream are not adjacent there)
+  bool wire_staged = false;
   if (wire) {
-    // staging = [frame offsets][stream bytes]: one DMA moves both
     in_bytes = (size_t)(n + 1) * 8 + (size_t)wire->nbytes;
-    if (int rc = ensure_slot_staging(h, sl, n, in_bytes)) return rc;
-    std::memcpy(sl.in_h, wire->frame_off, (size_t)(n + 1) * 8);
-    if (wire->nbytes) std::memcpy((uint8_t*)sl.in_h + (size_t)(n + 1) * 8, wire->stream, (size_t)wire->nbytes);
+    const uint8_t* fo = (const uint8_t*)wire->frame_off;
+    const uint8_t* sb = (const uint8_t*)wire->stream;
+    auto inside = [&](const void* base, size_t cap) {
+      const uint8_t* b = (const uint8_t*)base;
+      return b && fo == b && sb == b + sl.w_stage_stream_off && sl.w_stage_stream_off >= (size_t)(n + 1) * 8 &&
+             sl.w_stage_stream_off + (size_t)wire->nbytes <= cap;
+    };
+    if (inside(sl.in_bar, sl.in_bar_bytes)) {
+      wire_staged = staged_in_device = true;
+      device_src = sl.in_bar;
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();
+#endif
+    } else if (inside(sl.in_h, sl.in_bytes)) {
+      wire_staged = true;
+    } else {
+      // staging = [frame offsets][stream bytes]: one DMA moves both
+      if (int rc = ensure_slot_staging(h, sl, n, in_bytes)) return rc;
+      std::memcpy(sl.in_h, wire->frame_off, (size_t)(n + 1) * 8);
+      if (wire->nbytes) std::memcpy((uint8_t*)sl.in_h + (size_t)(n + 1) * 8, wire->stream, (size_t)wire->nbytes);
+    }
   } else {
     in_bytes = (size_t)n * rec_bytes;
     // unless the caller filled this slot's staging area in place (raftq_step_stage), copy into the pinned one
@@ -476,10 +499,25 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   // copy into the slot's scratch; with the result copy inside the walk kernel that 3 us blit sat on the critical path,
   // held back like every other kernel while a kernel writes to host memory (rocprof: 2.4 .. 75 us).
   sl.msgs_in_place = nullptr;
+  sl.w_off_in_place = sl.w_stream_in_place = nullptr;
   const void* packed_src = s.msgs40;
   const bool own_staging = staged_in_device && (const uint8_t*)device_src >= (const uint8_t*)sl.in_bar &&
                            (const uint8_t*)device_src + in_bytes <= (const uint8_t*)sl.in_bar + sl.in_bar_bytes;
-  if (own_staging) {
+  if (wire && wire_staged && staged_in_device) {
+    s.w_off = (uint64_t*)const_cast<void*>(device_src);
+    s.w_stream = (uint8_t*)const_cast<void*>(device_src) + sl.w_stage_stream_off;
+    sl.w_off_in_place = s.w_off;
+    sl.w_stream_in_place = s.w_stream;
+  } else if (wire && wire_staged) {
+    HIPCHK(h, hipMemcpyAsync(s.w_off, sl.in_h, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s_in));
+    if (wire->nbytes)
+      HIPCHK(h, hipMemcpyAsync(s.w_stream, (const uint8_t*)sl.in_h + sl.w_stage_stream_off, (size_t)wire->nbytes,
+                               hipMemcpyHostToDevice, s_in));
+    if (s_in != h->stream) {
+      HIPCHK(h, hipEventRecord(sl.ev_in, s_in));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    }
+  } else if (own_staging) {
     if (packed) packed_src = device_src;
     else {
       s.msgs = (MsgRec*)const_cast<void*>(device_src);
@@ -592,6 +630,24 @@ int raftq_step_submit_packed(raftq_t* h, const raftq_msg40_t* msgs, uint64_t n) 
   return submit_impl(h, msgs, n, nullptr, "raftq_step_submit_packed", sizeof(raftq_msg40_t));
 }
 
+int raftq_step_stage_wire(raftq_t* h, uint64_t n_cap, uint64_t nbytes_cap, uint64_t** frame_off, void** stream) {
+  if (int rc = use_device(h)) return rc;
+  if (!frame_off || !stream) return fail(h, RAFTQ_EINVAL, "raftq_step_stage_wire: null argument");
+  const int slot_no = (int)(h->step_submitted % raftq::kStepSlots);
+  raftq::StepSlot& sl = h->step_slot[slot_no];  // the slot the next submit will use
+  if (sl.busy) return fail(h, RAFTQ_ESTATE, "raftq_step_stage_wire: three batches already in flight; collect one first");
+  // the slot's previous batch may still be the one raftq_step_wire_msgs / _entries would parse entries for -- from the
+  // very bytes the producer is about to overwrite
+  if (h->step_last_slot == slot_no) h->step_last_slot = -1;
+  const size_t off_bytes = align256((size_t)(n_cap + 1) * 8);
+  void* p = nullptr;
+  if (int rc = ensure_slot_bar(h, sl, n_cap, &p, off_bytes + (size_t)nbytes_cap + 16)) return rc;
+  sl.w_stage_stream_off = off_bytes;
+  *frame_off = (uint64_t*)p;
+  *stream = (uint8_t*)p + off_bytes;
+  return RAFTQ_OK;
+}
+
 int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n) {
   const WireSrc w = {stream, nbytes, frame_off};
   return submit_impl(h, nullptr, n, &w, "raftq_step_submit_wire");
@@ -611,6 +667,10 @@ static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSl
     // message order, ent_first of every message), kept out of the Step chain because Step does not need it
     Scratch s;
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, true, sl.w_nbytes)) return rc;
+    if (sl.w_off_in_place) {  // the batch was decoded where the producer wrote it; so are its entries
+      s.w_off = (uint64_t*)const_cast<void*>(sl.w_off_in_place);
+      s.w_stream = (uint8_t*)const_cast<void*>(sl.w_stream_in_place);
+    }
     HIPCHK(h, exclusive_sum_u64((const uint64_t*)s.w_cnt, s.w_base, sl.n + 1, (uint64_t*)s.w_scan, st));
     hipLaunchKernelGGL(wire_dec_ents_kernel, dim3((unsigned)((sl.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        (const uint8_t*)s.w_stream, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base,

@@ -116,6 +116,19 @@ class WireEngine(NodeEngine):
         off = np.ascontiguousarray(frame_off, np.uint64)
         self._chk(self._lib.raftq_step_submit_wire(self._h, _p(s), len(s), _ptr(off), len(off) - 1))
 
+    def step_stage_wire(self, n_cap: int, nbytes_cap: int):
+        """the arrays the next step_submit_wire_staged() takes (raftq_step_stage_wire) -> (frame_off uint64[n_cap + 1],
+        stream uint8[nbytes_cap]); views of device memory behind a large BAR: write-only"""
+        po, ps = C.c_void_p(None), C.c_void_p(None)
+        self._chk(self._lib.raftq_step_stage_wire(self._h, int(n_cap), int(nbytes_cap), C.byref(po), C.byref(ps)))
+        off = np.frombuffer((C.c_char * ((n_cap + 1) * 8)).from_address(po.value), dtype=np.uint64, count=n_cap + 1)
+        stream = np.frombuffer((C.c_char * max(nbytes_cap, 1)).from_address(ps.value), dtype=np.uint8, count=nbytes_cap)
+        return off, stream
+
+    def step_submit_wire_staged(self, off: np.ndarray, stream: np.ndarray, n: int, nbytes: int) -> None:
+        """submit the first n frames / nbytes bytes of step_stage_wire()'s arrays, in place"""
+        self._chk(self._lib.raftq_step_submit_wire(self._h, stream.ctypes.data, int(nbytes), off.ctypes.data, int(n)))
+
     def step_wire_msgs(self) -> np.ndarray:
         p, k = C.c_void_p(None), C.c_uint64(0)
         self._chk(self._lib.raftq_step_wire_msgs(self._h, C.byref(p), C.byref(k)))

@@ -540,3 +540,91 @@ def test_golden_fixtures(eng):
         rec["kind"], rec["data_len"] = W.WAL_METADATA, len(data)
         _, _, last = eng.wal_encode(rec, data, c["seed"])
         assert last == c["crc"], c
+
+
+def test_step_from_frames_staged_in_place():
+    """raftq_step_stage_wire: the frames are written straight into the arrays the library hands out (device memory behind
+    a large BAR) and decoded where they lie -- same results as the copying form and as Step from the decoded records,
+    three batches in flight, entries fetched afterwards; asking for a slot's arrays again ends the validity of the
+    decoded records of the batch that lived there."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+    from raftsql_amd.wire import WireEngine
+
+    G, N = 3000, 5
+    rng = np.random.default_rng(47)
+    with WireEngine(G, N, 0) as a, S.NodeEngine(G, N, 0) as b:
+        def make(n, with_entries):
+            m = _step_traffic(rng, n, G, N)
+            e, pool = np.zeros(0, W.WIRE_ENT_DT), np.zeros(1, np.uint8)
+            if with_entries:
+                app = np.nonzero(m["type"] == 3)[0]
+                m["n_ents"][app] = 2
+                m["ent_first"][app] = np.arange(len(app)) * 2
+                e = np.zeros(2 * len(app), W.WIRE_ENT_DT)
+                e["term"], e["index"], e["data_len"] = 3, np.arange(len(e)), 7
+                e["data_off"] = np.arange(len(e)) * 7
+                pool = rng.integers(0, 256, 7 * len(e) + 1, dtype=np.uint8)
+            s, off = W.wire_encode(m, e, pool)
+            rec = np.zeros(n, S.MSG_DT)
+            for k in ("group", "term", "log_term", "index", "commit", "reject_hint", "from", "type", "reject"):
+                rec[k] = m[k]
+            return s, off, rec
+
+        def submit_staged(s, off, slack=0):
+            n = len(off) - 1
+            so, ss = a.step_stage_wire(n + slack, len(s) + 3 * slack)  # capacity may exceed what is used
+            so[: n + 1] = off
+            ss[: len(s)] = s
+            a.step_submit_wire_staged(so, ss, n, len(s))
+
+        pending = []
+        for it in range(15):
+            s, off, rec = make(int(rng.integers(1, 4000)), it % 2 == 0)
+            if it % 5 == 4:
+                a.step_submit_wire(s, off)  # the copying form in between
+            else:
+                submit_staged(s, off, slack=int(rng.integers(0, 50)))
+            pending.append((b.step_batch(rec), s, off))
+            if len(pending) == 3:
+                (want, wt), ws, woff = pending.pop(0)
+                got, touched = a.step_collect()
+                assert touched == wt
+                _same(got, want, "step results (staged frames)")
+                if it % 3 == 0:  # the decoder's second pass, from the staged bytes
+                    wm, we, _ = W.wire_decode(ws, woff)
+                    _same(a.step_wire_msgs(), wm, "decoded records")
+                    _same(a.step_wire_entries(), we, "decoded entries")
+        while pending:
+            (want, wt), ws, woff = pending.pop(0)
+            got, touched = a.step_collect()
+            assert touched == wt
+            _same(got, want, "step results (staged frames)")
+        na, nb = a.read_node(), b.read_node()
+        for k in na:
+            assert np.array_equal(na[k], nb[k]), k
+        # the last collected batch's records are readable ... until its slot's arrays are asked for again
+        s, off, rec = make(500, True)
+        submit_staged(s, off)
+        a.step_collect()
+        b.step_batch(rec)
+        assert len(a.step_wire_msgs()) == 500
+        for _ in range(3):  # three stagings later the rotation is back at that slot
+            s2, off2, rec2 = make(10, False)
+            submit_staged(s2, off2)
+            a.step_collect()
+            b.step_batch(rec2)
+        assert len(a.step_wire_msgs()) == 10  # the newest batch's
+        a.step_stage_wire(10, 100)  # hands out the slot after the newest one: nothing changes for the newest batch
+        assert len(a.step_wire_msgs()) == 10
+        # a malformed staged frame fails the batch like any other
+        s, off, _ = make(100, False)
+        s = s.copy()
+        s[int(off[17]) + 8] = 0x0B
+        submit_staged(s, off)
+        with pytest.raises(RaftqError):
+            a.step_collect()
+        assert a.step_wire_msgs()[17]["flags"] == W.F_MALFORMED
+        na, nb = a.read_node(), b.read_node()
+        for k in na:
+            assert np.array_equal(na[k], nb[k]), k

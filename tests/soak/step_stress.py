@@ -70,7 +70,15 @@ while time.time() < t_end:
                     e.step_submit(m)
                 else:
                     st, off = W.wire_encode(wm)
-                    e.step_submit_wire(st, off)
+                    if rng.random() < 0.5:  # staged in device memory, decoded in place
+                        slack = int(rng.integers(0, 40))
+                        so, ss = e.step_stage_wire(n + slack, len(st) + slack)
+                        so[: n + 1] = off
+                        ss[: len(st)] = st
+                        e.step_submit_wire_staged(so, ss, n, len(st))
+                        n_staged += 1
+                    else:
+                        e.step_submit_wire(st, off)
             else:
                 e.step_submit(m)
             pending.append(want)

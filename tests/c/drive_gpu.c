@@ -104,6 +104,43 @@ int main(void) {
     CHECK(raftq_wal_decode(h, wal, lc.bytes, woff, 3, 0, rb, &lc) == RAFTQ_OK && lc.n_valid == 1);
     CHECK((rb[1].flags & (RAFTQ_WAL_F_BADCRC | RAFTQ_WAL_F_MALFORMED)) != 0);
   }
+  /* the round-2 inbound forms of Step, on the leader group 0 just elected (term 1, last index 1, committed 1):
+   *   packed 40-byte records staged in place: a heartbeat response, then a higher-term vote request the leader grants
+   *   (its log (1, 1) is not ahead of the candidate's (index 1, term 1)) -> steps down, term 2, votes for peer 1;
+   *   frames staged in place (raftq_step_stage_wire): a stale MsgAppResp of term 1 -> ignored by the follower.
+   * Three batches may be in flight: both are submitted before the first collect. */
+  {
+    raftq_msg40_t* pm = NULL;
+    raftq_wire_msg_t wm[1];
+    raftq_wire_counts_t wc;
+    unsigned char tmp[128];
+    uint64_t toff[2], *soff = NULL;
+    void* sstream = NULL;
+    const raftq_step_out_t* res = NULL;
+    uint64_t nres = 0;
+    raftq_step_counts_t sc;
+    CHECK(raftq_step_stage_packed(h, 2, &pm) == RAFTQ_OK && pm != NULL);
+    memset(pm, 0, 2 * sizeof *pm);
+    pm[0].group = 0, pm[0].type = RAFTQ_MSG_HEARTBEAT_RESP, pm[0].term = 1, pm[0].from = 2;
+    pm[1].group = 0, pm[1].type = RAFTQ_MSG_VOTE, pm[1].term = 2, pm[1].from = 1, pm[1].index = 1, pm[1].aux = 1; /* aux = LogTerm */
+    CHECK(raftq_step_submit_packed(h, pm, 2) == RAFTQ_OK);
+    memset(wm, 0, sizeof wm);
+    wm[0].type = RAFTQ_MSG_APP_RESP, wm[0].group = 0, wm[0].term = 1, wm[0].from = 2, wm[0].to = 0, wm[0].index = 1;
+    CHECK(raftq_commit_advance(h, 0, NULL, NULL) == RAFTQ_ESTATE); /* state calls wait for the collects */
+    CHECK(raftq_step_collect(h, NULL, &sc) == RAFTQ_OK && sc.n_msgs == 2 && sc.n_groups_touched == 1);
+    CHECK(raftq_step_results(h, &res, &nres) == RAFTQ_OK && nres == 2);
+    CHECK(res[0].type == RAFTQ_OUT_PROGRESS && res[0].role == RAFTQ_ROLE_LEADER && res[0].term == 1);
+    CHECK(res[1].type == RAFTQ_OUT_VOTE_RESP && res[1].reject == 0 && res[1].term == 2 && res[1].vote == 2 &&
+          res[1].role == RAFTQ_ROLE_FOLLOWER && (res[1].flags & RAFTQ_OUTF_STEPPED_DOWN) && (res[1].flags & RAFTQ_OUTF_HARDSTATE));
+    CHECK(raftq_wire_encode(h, wm, 1, NULL, 0, NULL, 0, tmp, sizeof tmp, toff, &wc) == RAFTQ_OK);
+    CHECK(raftq_step_stage_wire(h, 4, 256, &soff, &sstream) == RAFTQ_OK && soff != NULL && sstream != NULL);
+    soff[0] = toff[0], soff[1] = toff[1];
+    memcpy(sstream, tmp, (size_t)wc.bytes);
+    CHECK(raftq_step_submit_wire(h, sstream, wc.bytes, soff, 1) == RAFTQ_OK);
+    CHECK(raftq_step_collect(h, NULL, &sc) == RAFTQ_OK && sc.n_msgs == 1);
+    CHECK(raftq_step_results(h, &res, &nres) == RAFTQ_OK && nres == 1);
+    CHECK(res[0].type == RAFTQ_OUT_NONE && res[0].term == 2 && res[0].role == RAFTQ_ROLE_FOLLOWER);
+  }
   /* sweep sets: two handles of one shape, ONE dispatch; then a batching turn in the packed 16-byte records written
    * in place into the handle's ack buffer (device memory behind a large BAR).  Hand-derived, 2 groups x 3 peers:
    *   a: match {4,8 | 4,2 | 1,8}  committed {1,5}  -> 2nd largest {4,8}: both advance

@@ -586,3 +586,85 @@ def test_log_maybe_append_table(gpu_engine_cls):
             assert int(st["commit"][g]) == wcommit, (g, int(st["commit"][g]))
     finally:
         nd.destroy()
+
+
+def test_leader_commit_preceding_entries(gpu_engine_cls):
+    """TestLeaderCommitPrecedingEntries (raft_paper_test.go): when a leader commits an entry of its own term, all preceding
+    entries -- including those of earlier leaders -- are committed with it.  Four starting logs (empty; (2,1); (1,1),(2,2);
+    (1,1)) as four groups of a three-node cluster whose members all hold the same log at term 2; node 1 is elected (term 3)
+    and proposes once: every node ends with log + (3, empty) + (3, "some data"), all of it committed."""
+    from raftsql_amd.node import Cluster
+
+    logs = [[], [2], [1, 2], [1]]
+    k = len(logs)
+    c = Cluster(k, 3, seed=6)
+    try:
+        for g, terms in enumerate(logs):
+            for nd in c.nodes:
+                if terms:
+                    nd.replay(g, [(t, b"e%d.%d" % (i, t)) for i, t in enumerate(terms, 1)])
+                nd.set_hard_state(g, 2, 0, 0)
+        c.start()
+        groups = np.arange(k, dtype=np.uint64)
+        c.nodes[0].campaign(groups)
+        c.settle()
+        assert np.all(c.nodes[0].statuses()["role"] == LEADER) and np.all(c.nodes[0].statuses()["term"] == 3)
+        c.nodes[0].propose_batch(groups, [b"some data"] * k)
+        c.settle()
+        c.nodes[0].tick()  # a heartbeat carries the commit index to the followers
+        c.settle()
+        for g, terms in enumerate(logs):
+            want = [(t, b"e%d.%d" % (i, t)) for i, t in enumerate(terms, 1)] + [(3, b""), (3, b"some data")]
+            for nd in c.nodes:
+                assert nd.log(g) == want, (g, nd.log(g))
+                assert int(nd.statuses()["commit"][g]) == len(want)
+    finally:
+        c.close()
+
+
+def test_follower_start_election_and_leader_bcast_beat(gpu_engine_cls):
+    """TestFollowerStartElection: after 2 x electionTimeout - 1 ticks without hearing from a leader a follower has
+    campaigned exactly once -- term + 1, candidate, voted for itself, one MsgVote to each peer carrying that term.
+    TestLeaderBcastBeat: a leader sends one MsgHeartbeat to each follower at every heartbeat tick, entries or not."""
+    from oracle import pywire as W
+    from raftsql_amd.node import RaftNode
+
+    k, et = 64, 10
+    nd = RaftNode(k, 3, 0)
+    try:
+        nd.start(et, 1, seed=99)
+        out = {1: b"", 2: b""}
+        for _ in range(2 * et - 1):
+            nd.tick()
+            nd.advance()
+            for q in (1, 2):
+                out[q] += nd.poll(q)
+        st = nd.statuses()
+        assert np.all(st["role"] == CANDIDATE) and np.all(st["term"] == 1) and np.all(st["vote"] == 1)
+        for q in (1, 2):
+            off, used = W.scan_frames(out[q], big_endian=True)
+            mm, _, bad = W.wire_decode(out[q], off)
+            assert used == len(out[q]) and bad == 0
+            assert len(mm) == k and np.all(mm["type"] == VOTE) and np.all(mm["term"] == 1) and np.all(mm["to"] == q)
+            assert sorted(mm["group"].tolist()) == list(range(k))
+        # both peers grant: leader of every group; then every tick is a heartbeat round
+        v = np.zeros(2 * k, W.WIRE_MSG_DT)
+        v["group"], v["term"], v["type"], v["to"] = np.tile(np.arange(k), 2), 1, VOTE_RESP, 0
+        v["from"] = np.repeat([1, 2], k)
+        stream, _ = W.wire_encode(v)
+        nd.deliver(stream.tobytes())
+        nd.advance()
+        assert np.all(nd.statuses()["role"] == LEADER)
+        for q in (1, 2):
+            nd.poll(q)  # becomeLeader's MsgApp
+        for _ in range(3):
+            nd.tick()
+            nd.advance()
+            for q in (1, 2):
+                blob = nd.poll(q)
+                off, used = W.scan_frames(blob, big_endian=True)
+                mm, _, bad = W.wire_decode(blob, off)
+                assert bad == 0 and len(mm) == k and np.all(mm["type"] == HEARTBEAT) and np.all(mm["n_ents"] == 0)
+                assert np.all(mm["term"] == 1) and np.all(mm["commit"] == 0)  # min(match[q] = 0, committed)
+    finally:
+        nd.destroy()

@@ -131,13 +131,30 @@ def build_tuner3(force: bool = False) -> str | None:
     return out
 
 
+SORT_CHECK = os.path.join(PKG, "raftq_sort_check")
+
+
+def build_sort_check(force: bool = False) -> str:
+    """tests/c/sort_check.hip: the radix sort of raftq_sort_kernels.hpp against std::stable_sort (tests/test_sort_gpu.py).
+    Built in-tree with everything else so that the GPU box does not need a compiler for it."""
+    src = os.path.join(ROOT, "tests", "c", "sort_check.hip")
+    deps = [src, os.path.join(CSRC, "raftq_sort_kernels.hpp"), os.path.join(CSRC, "raftq_wire_kernels.hpp"),
+            os.path.join(CSRC, "raftq_kernels.hpp")]
+    if not force and not _stale(SORT_CHECK, deps):
+        return SORT_CHECK
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-o", SORT_CHECK, src]
+    subprocess.check_call(cmd)
+    return SORT_CHECK
+
+
 def build_all(force: bool = False, log: list | None = None) -> None:
-    """The library and the three tuners, concurrently (every piece is its own hipcc process)."""
+    """The library, the three tuners and the sort checker, concurrently (every piece is its own hipcc process)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    with ThreadPoolExecutor(4) as ex:
+    with ThreadPoolExecutor(5) as ex:
         futs = [ex.submit(build_lib, force, None, False, log), ex.submit(build_tuner, force), ex.submit(build_tuner2, force),
-                ex.submit(build_tuner3, force)]
+                ex.submit(build_tuner3, force), ex.submit(build_sort_check, force)]
         for f in futs:
             f.result()
 

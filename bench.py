@@ -587,6 +587,26 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     return out
 
 
+def gpu_numa_cpus(device):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None: a G-group raft node is host work over a few tens of MB of
+    per-group state -- on the two-socket GPU box, threads that wander to the other socket cost 40 % (tools/probe/node_numa_probe.py)"""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return (cpus & os.sched_getaffinity(0)) or None
+    except Exception:
+        return None
+
+
 def node_measure(device, G=32768, N=3, rounds=6):
     """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
     same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
@@ -594,6 +614,17 @@ def node_measure(device, G=32768, N=3, rounds=6):
     entry on its commit channels.  Wall time, Python transport included; the N nodes' turns run on N threads."""
     from raftsql_amd.node import Cluster
 
+    before = os.sched_getaffinity(0)
+    near = gpu_numa_cpus(device)
+    if near:
+        os.sched_setaffinity(0, near)  # threads created below inherit it
+    try:
+        return _node_measure(Cluster, device, G, N, rounds, pinned=bool(near))
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def _node_measure(Cluster, device, G, N, rounds, pinned):
     c = Cluster(G, N, device=device, seed=5, threads=True)  # one thread per node, as N machines would run
     c.start()
     t0 = time.perf_counter()
@@ -630,7 +661,7 @@ def node_measure(device, G=32768, N=3, rounds=6):
     c.close()
     return {"what": "raftq_node x%d on one GPU, %d groups: propose on the leader -> MsgApp -> MsgAppResp -> batched "
                     "Step -> commit -> delivered on every node's commit channel" % (N, G),
-            "groups": G, "nodes": N, "election_s": t_elect, "election_ticks": ticks,
+            "groups": G, "nodes": N, "pinned_to_the_gpus_numa_node": pinned, "election_s": t_elect, "election_ticks": ticks,
             "leaders_per_node": np.bincount(lead, minlength=N).tolist(),
             "proposals_committed_everywhere_per_s": rounds * G / dt, "msgs_stepped_per_s": stepped / dt,
             "s_per_wave": dt / rounds}

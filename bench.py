@@ -751,6 +751,7 @@ def main():
                     help="torch.distributed backend under torchrun (default nccl = RCCL); gloo is for testing the "
                          "multi-process path on a box with fewer GPUs than ranks")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index on every rank (testing only)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     args = ap.parse_args()
@@ -767,6 +768,11 @@ def main():
     n_gpus = world.size * len(devices) if world.size > 1 else len(devices)
     torch.cuda.set_device(devices[0])
     _lib.load()
+    # one GPU per process: stay on the socket it hangs off (host copies into device memory, the node leg's per-group state
+    # and the CPU baseline's threads all run from there); a process driving several GPUs is left where the OS puts it
+    near = gpu_numa_cpus(devices[0]) if len(devices) == 1 and not args.no_pin else None
+    if near:
+        os.sched_setaffinity(0, near)
 
     cfg = CONFIGS[args.config]
     rd, wr = bytes_per_decision(cfg)
@@ -842,6 +848,7 @@ def main():
             "cache_policy": args.policy,
             "parallelism": f"groups sharded x{n_gpus}, no collective; " +
                            ("one process per GPU (torchrun)" if world.size > 1 else "one process, one set + stream per GPU"),
+            "host_affinity": "the GPU's NUMA node (%d CPUs)" % len(near) if near else "unpinned",
         },
         "roofline": {
             "bound": "hbm",

@@ -56,3 +56,30 @@ def test_bench_without_a_gpu_fails_loudly():
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n, "--steps", "2"], capture_output=True,
                            text=True, timeout=300, cwd=ROOT)
         assert p.returncode != 0 and "needs a GPU" in p.stderr and "{" not in p.stdout
+
+
+def test_numa_pinning_helper_degrades_quietly():
+    """bench.gpu_numa_cpus: None when there is no GPU / no sysfs entry -- the bench then simply does not pin."""
+    import bench
+
+    assert bench.gpu_numa_cpus(0) is None or len(bench.gpu_numa_cpus(0)) > 0
+
+
+def test_pack_msgs40_layout_and_ranges():
+    """raftq_msg40_t as the host mirror packs it: aux is the RejectHint on MsgAppResp and the LogTerm otherwise; ids that
+    do not fit are refused."""
+    import numpy as np
+    import pytest
+
+    from raftsql_amd import step as S
+
+    m = S.pack_msgs(np.array([7, 8, 9], np.uint64), np.array([S.MSG_APP_RESP, S.MSG_VOTE, S.MSG_HEARTBEAT], np.uint8), term=5,
+                    frm=2, index=11, log_term=4, commit=3, reject=1, reject_hint=10)
+    p = S.pack_msgs40(m)
+    assert p.dtype.itemsize == 40 and p.tobytes()[:8] == bytes([7, 0, 0, 0, 2, S.MSG_APP_RESP, 1, 0])
+    assert p["aux"].tolist() == [10, 4, 4] and p["term"].tolist() == [5, 5, 5] and p["commit"].tolist() == [3, 3, 3]
+    out = np.zeros(3, S.MSG40_DT)
+    assert S.pack_msgs40(m, out=out) is out and out.tobytes() == p.tobytes()
+    m["group"][1] = 1 << 32
+    with pytest.raises(ValueError):
+        S.pack_msgs40(m)

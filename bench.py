@@ -81,24 +81,63 @@ def build_batches(cfg, n_batches, rank, seed_base, device=0, distinct=8):
     """n_batches engines of cfg's shape on `device`: `distinct` of them hold independently generated
     data (counter-based: offset group ids, per rank), the rest are device-to-device clones of those
     (raftq_clone_state) -- different HBM addresses, so a pass over all of them cannot hit in cache, and
-    the sweep's arithmetic is branch-free, so its speed does not depend on the values."""
+    the sweep's arithmetic is branch-free, so its speed does not depend on the values.
+    -> (engines, [the `distinct` host states])"""
     from raftsql_amd import synth
     from raftsql_amd.engine import QuorumEngine
 
     distinct = max(1, min(distinct, n_batches))
-    engines, first_state = [], None
+    engines, states = [], []
     for b in range(n_batches):
         e = QuorumEngine(cfg["G"], cfg["N"], device=device)
         if b < distinct:
             off = (rank * distinct + b) * cfg["G"]
             st = synth.make_groups(cfg["G"], cfg["N"], seed=seed_base, with_terms=cfg["gated"], group_offset=off)
             e.load_state(st)
-            if b == 0:
-                first_state = st
+            states.append(st)
         else:
             e.clone_state_from(engines[b % distinct])
         engines.append(e)
-    return engines, first_state
+    return engines, states
+
+
+def numpy_expectation(cfg, st):
+    """What one sweep of cfg over `st` must produce, in plain numpy (NOT the oracle: bench.py's gate must not lean on
+    test infrastructure): -> (new commit index [G], vote outcome [G] | None, n_changed)."""
+    from raftsql_amd import synth
+
+    N = cfg["N"]
+    srt = np.sort(st.match, axis=0)[N - synth.quorum(N)]  # q-th largest
+    adv = srt > st.committed
+    if cfg["gated"]:
+        adv &= (st.first_idx_cur_term != 0) & (srt >= st.first_idx_cur_term)
+    new = np.where(adv, srt, st.committed)
+    oc = None
+    if cfg["votes"]:
+        granted, rejected = (st.votes == 1).sum(axis=0), (st.votes == 2).sum(axis=0)
+        q = synth.quorum(N)
+        oc = np.where(granted >= q, 1, np.where(rejected >= q, 2, 0)).astype(np.uint8)
+    return new, oc, int(adv.sum())
+
+
+def gate_set(cfg, s, engines, states, flags, where):
+    """Correctness gate before any timing, on EVERY device's set: per-member tallies of all members, and the whole
+    result arrays of the first member, of one clone and of the last member, against numpy."""
+    distinct = len(states)
+    want = [numpy_expectation(cfg, st) for st in states]
+    per, tot = s.sweep(flags)
+    for b, c in enumerate(per):
+        if c.n_changed != want[b % distinct][2]:
+            raise SystemExit(f"{where}: tally mismatch before timing: member {b} advanced {c.n_changed} groups, numpy says "
+                             f"{want[b % distinct][2]}")
+    check = sorted({0, min(distinct, len(engines) - 1), len(engines) - 1})  # member 0, the first clone, the last member
+    for b in check:
+        new, oc, _ = want[b % distinct]
+        if not np.array_equal(engines[b].read_committed(), new):
+            raise SystemExit(f"{where}: member {b}: commit indices differ from numpy before timing")
+        if oc is not None and not np.array_equal(engines[b].read_outcome(), oc):
+            raise SystemExit(f"{where}: member {b}: vote outcomes differ from numpy before timing")
+    return {"members_tallied": len(per), "members_compared_in_full": check, "n_changed_total": int(tot.n_changed)}
 
 
 def sync_devices(devices):
@@ -108,23 +147,52 @@ def sync_devices(devices):
         torch.cuda.synchronize(d)
 
 
-def timed_steps(sets, devices, flags, steps, world, dist, launcher=None):
+def timed_steps(sets, devices, flags, steps, world, dist, launcher=None, cpus_of=None):
     """Barrier + sync, K steps (a step = one pass over every batch of every set), barrier + sync.
-    -> (wall_s, [event_ms per set]).  The HIP events sit on each set's own stream."""
+    -> (wall_s, [event_ms per set]).  The HIP events sit on each set's own stream.
+    One process driving several devices (launched directly with --gpus N) gives every device its own launch thread,
+    pinned to that GPU's NUMA node (`cpus_of[i]`), so no device waits for another one's launch calls; the threads
+    are released together and joined inside the timed region."""
     dist.barrier(world)
     sync_devices(devices)
-    t0 = time.perf_counter()
-    for s in sets:
-        s.timer_begin()
-    if launcher is None:
+    go = launcher if launcher is not None else (lambda s, f: s.sweep_async(f))
+    if len(sets) == 1:
+        t0 = time.perf_counter()
+        sets[0].timer_begin()
         for _ in range(steps):
-            for s in sets:
-                s.sweep_async(flags)
+            go(sets[0], flags)
+        ev_ms = [sets[0].timer_end()]
     else:
-        for _ in range(steps):
-            for s in sets:
-                launcher(s, flags)
-    ev_ms = [s.timer_end() for s in sets]
+        import threading
+
+        ev_ms, errs = [0.0] * len(sets), []
+        start = threading.Barrier(len(sets) + 1)
+
+        def drive(i):
+            try:
+                if cpus_of and cpus_of[i]:
+                    os.sched_setaffinity(0, cpus_of[i])  # pid 0 = the calling thread
+                start.wait()
+                sets[i].timer_begin()
+                for _ in range(steps):
+                    go(sets[i], flags)
+                ev_ms[i] = sets[i].timer_end()
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+                try:
+                    start.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+
+        th = [threading.Thread(target=drive, args=(i,)) for i in range(len(sets))]
+        for t in th:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
     sync_devices(devices)
     dist.barrier(world)
     wall = time.perf_counter() - t0
@@ -138,9 +206,10 @@ def measure_config(cfg_id, n_batches, steps, warmup, device, dist, rank=0, disti
 
     cfg = CONFIGS[cfg_id]
     rd, wr = bytes_per_decision(cfg)
-    engines, _ = build_batches(cfg, n_batches, rank, synth.SEED_BASE + cfg_id, device, distinct)
+    engines, states = build_batches(cfg, n_batches, rank, synth.SEED_BASE + cfg_id, device, distinct)
     flags = sweep_flags(cfg) | (_lib.SWEEP_STREAM if policy_flag is None else policy_flag)
     with SweepSet(engines) as s:
+        gate_set(cfg, s, engines, states, flags, cfg["name"])
         for _ in range(warmup):
             s.sweep_async(flags)
         wall, ev = timed_steps([s], [device], flags, steps, dist.World(), dist)
@@ -763,7 +832,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the quorum sweep has no CPU path (only the oracle baseline does)")
-    world = dist.init_from_env(args.backend)
+    world = dist.init_from_env(args.backend, device=args.device)
     devices = plan_devices(args.gpus, args.device, torch.cuda.device_count(), world.size, world.local_rank)
     n_gpus = world.size * len(devices) if world.size > 1 else len(devices)
     torch.cuda.set_device(devices[0])
@@ -781,34 +850,37 @@ def main():
     flags = sweep_flags(cfg) | {"stream": _lib.SWEEP_STREAM, "cached": _lib.SWEEP_CACHED, "auto": 0}[args.policy]
     base_flags = sweep_flags(cfg)
 
-    sets, all_engines, st0 = [], [], None
+    sets, all_engines, st0, gates = [], [], None, []
     for i, d in enumerate(devices):
         shard = world.rank * len(devices) + i  # which slice of the whole job's groups this GPU owns
-        engines, st = build_batches(cfg, n_batches, shard, synth.SEED_BASE + args.config, d, args.distinct)
+        engines, states = build_batches(cfg, n_batches, shard, synth.SEED_BASE + args.config, d, args.distinct)
         if i == 0:
-            st0 = st
+            st0 = states[0]
         all_engines.append(engines)
         s = SweepSet(engines)
         s.set_mode(_lib.SET_PERSISTENT if args.mode == "persistent" else _lib.SET_GRID)
         sets.append(s)
-
-    # correctness gate before any timing: per-batch tallies of the first set against numpy
-    per, tot = sets[0].sweep(flags)
-    srt = np.sort(st0.match, axis=0)[cfg["N"] - synth.quorum(cfg["N"])]
-    adv = srt > st0.committed
-    if cfg["gated"]:
-        adv &= (st0.first_idx_cur_term != 0) & (srt >= st0.first_idx_cur_term)
+        # correctness gate before any timing, on every device of every rank: every member's tally and the whole result
+        # arrays of member 0, one clone and the last member, against numpy
+        gates.append(gate_set(cfg, s, engines, states, flags, f"rank {world.rank} device {d}"))
     distinct = max(1, min(args.distinct, n_batches))
-    if per[0].n_changed != int(adv.sum()) or any(per[b].n_changed != per[b % distinct].n_changed for b in range(n_batches)):
-        raise SystemExit(f"tally mismatch before timing: {per[0].n_changed} != {int(adv.sum())} (or a clone differs)")
+    # the tallies of the whole job, summed over ranks (host side, a few bytes -- the job's only reduction besides the clock)
+    local_changed = sum(g["n_changed_total"] for g in gates)
+    job_changed, job_sets = dist.sum_over_ranks(world, [local_changed, len(sets)])
+    cpus_of = None if args.no_pin or len(devices) == 1 else [gpu_numa_cpus(d) for d in devices]
 
     for _ in range(args.warmup):
         for s in sets:
             s.sweep_async(flags)
-    wall, ev_ms = timed_steps(sets, devices, flags, args.steps, world, dist)
+    wall, ev_ms = timed_steps(sets, devices, flags, args.steps, world, dist, cpus_of=cpus_of)
     wall_max = dist.max_over_ranks(world, wall)
     ev_local = max(ev_ms)
     ev_max = dist.max_over_ranks(world, ev_local)
+    # what every rank saw, for the line: its devices, its clock, each of its dispatches' average duration
+    per_rank = dist.gather_over_ranks(world, {"rank": world.rank, "devices": devices, "wall_ms": wall * 1e3,
+                                              "launch_us": [ms * 1e3 / args.steps for ms in ev_ms]})
+    if n_gpus != job_sets:
+        raise SystemExit(f"{n_gpus} GPUs' worth asked for, {job_sets} sets were swept")
 
     groups_per_gpu = cfg["G"] * n_batches
     decisions = groups_per_gpu * args.steps * n_gpus
@@ -848,7 +920,10 @@ def main():
             "cache_policy": args.policy,
             "parallelism": f"groups sharded x{n_gpus}, no collective; " +
                            ("one process per GPU (torchrun)" if world.size > 1 else "one process, one set + stream per GPU"),
-            "host_affinity": "the GPU's NUMA node (%d CPUs)" % len(near) if near else "unpinned",
+            "host_affinity": ("the GPU's NUMA node (%d CPUs)" % len(near) if near else
+                              "one launch thread per device, each on its GPU's NUMA node" if cpus_of and any(cpus_of) else "unpinned"),
+            "rendezvous": {"backend": world.backend, "barrier": world.barrier_kind, "note": world.note},
+            "ranks_seen": [r["rank"] for r in per_rank],
         },
         "roofline": {
             "bound": "hbm",
@@ -867,7 +942,15 @@ def main():
             "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBPS,
             "kernel_time_over_wall": launch_us / (wall_max * 1e6 / args.steps),
             "event_ms_max_over_ranks": ev_max,
+            # every GPU of the job on its own: the average duration of its dispatches and the fraction of peak it reaches
+            "launch_us_per_gpu": [u for r in per_rank for u in r["launch_us"]],
+            "frac_per_gpu": [bytes_per_launch / (u * 1e-6) / 1e9 / HBM_PEAK_GBPS for r in per_rank for u in r["launch_us"]],
+            "wall_ms_per_rank": [r["wall_ms"] for r in per_rank],
         },
+        "gate": {"what": "before timing, on every device of every rank: every member's tally and the whole commit / outcome "
+                         "arrays of member 0, the first clone and the last member, against numpy",
+                 "sets_gated": job_sets, "members_compared_in_full_per_set": gates[0]["members_compared_in_full"],
+                 "groups_advanced_per_step_whole_job": job_changed},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

@@ -209,8 +209,11 @@ def vote_tally(votes):
     return out, int(w.value), int(l.value)
 
 
-def apply_deltas(match, d_group, d_peer, d_match):
-    match = np.ascontiguousarray(match, dtype=np.uint64).copy()
+def apply_deltas(match, d_group, d_peer, d_match, inplace: bool = False):
+    """-> match with the deltas applied (a copy, unless `inplace` and the array is already contiguous u64)."""
+    match = np.ascontiguousarray(match, dtype=np.uint64)
+    if not inplace:
+        match = match.copy()
     N, G = match.shape
     dg = np.ascontiguousarray(d_group, dtype=np.uint64)
     dp = np.ascontiguousarray(d_peer, dtype=np.uint32)

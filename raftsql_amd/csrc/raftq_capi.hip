@@ -459,8 +459,10 @@ void* raftq_get_stream(const raftq_t* h) { return h ? (void*)h->stream : nullptr
 int raftq_load_match(raftq_t* h, const uint64_t* match, const uint64_t* committed) {
   if (int rc = use_device_idle(h, "raftq_load_match")) return rc;
   if (!match && !committed) return fail(h, RAFTQ_EINVAL, "raftq_load_match: nothing to load");
+  // one copy per peer row: a row of a large handle is wider than the 2D copy's pitch limit (2^31 - 1 bytes)
   if (match)
-    HIPCHK(h, hipMemcpy2DAsync(h->match, h->ld * 8, match, h->G * 8, h->G * 8, h->N, hipMemcpyHostToDevice, h->stream));
+    for (uint32_t p = 0; p < h->N; ++p)
+      HIPCHK(h, hipMemcpyAsync(h->match + (size_t)p * h->ld, match + (size_t)p * h->G, h->G * 8, hipMemcpyHostToDevice, h->stream));
   if (committed)
     HIPCHK(h, hipMemcpyAsync(h->committed[h->cur], committed, h->G * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -776,7 +778,8 @@ int raftq_read_outcome(raftq_t* h, uint8_t* out) {
 int raftq_read_match(raftq_t* h, uint64_t* out) {
   if (int rc = use_device_idle(h, "raftq_read_match")) return rc;
   if (!out) return fail(h, RAFTQ_EINVAL, "raftq_read_match: null argument");
-  HIPCHK(h, hipMemcpy2DAsync(out, h->G * 8, h->match, h->ld * 8, h->G * 8, h->N, hipMemcpyDeviceToHost, h->stream));
+  for (uint32_t p = 0; p < h->N; ++p)  // row by row, as raftq_load_match
+    HIPCHK(h, hipMemcpyAsync(out + (size_t)p * h->G, h->match + (size_t)p * h->ld, h->G * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
 }

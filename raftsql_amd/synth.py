@@ -79,6 +79,9 @@ class GroupState:
         return s
 
 
+_CHUNK = 1 << 17  # groups per generator chunk: every temporary of a chunk stays cache-resident
+
+
 def make_groups(
     n_groups: int,
     n_peers: int,
@@ -89,8 +92,52 @@ def make_groups(
     """Synthetic state for groups [group_offset, group_offset + n_groups).
 
     Counter-based, so any shard of a larger job generates exactly the rows the
-    whole job would (ranks never exchange inputs).
+    whole job would (ranks never exchange inputs) -- and so a large state is
+    generated as cache-sized chunks on a few threads and is still the same bytes
+    (tests/test_oracle.py::test_synth_chunks_are_the_whole).
     """
+    G = int(n_groups)
+    if G <= _CHUNK:
+        return _make_groups_one(G, n_peers, seed, with_terms, group_offset)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    N = int(n_peers)
+    bounds = list(range(0, G, _CHUNK)) + [G]
+    st = GroupState(G, N, np.empty((N, G), np.uint64), np.empty(G, np.uint64), np.empty((N, G), np.uint8))
+    if with_terms:
+        st.cur_term, st.first_idx_cur_term = np.empty(G, np.uint64), np.empty(G, np.uint64)
+        st.last_index, st.run_off = np.empty(G, np.uint64), np.zeros(G + 1, np.uint64)
+    runs = [None] * (len(bounds) - 1)
+
+    def work(k: int) -> None:
+        g0, g1 = bounds[k], bounds[k + 1]
+        c = _make_groups_one(g1 - g0, N, seed, with_terms, group_offset + g0)
+        st.match[:, g0:g1], st.committed[g0:g1], st.votes[:, g0:g1] = c.match, c.committed, c.votes
+        if with_terms:
+            st.cur_term[g0:g1], st.first_idx_cur_term[g0:g1] = c.cur_term, c.first_idx_cur_term
+            st.last_index[g0:g1] = c.last_index
+            st.run_off[g0 + 1 : g1 + 1] = c.run_off[1:]  # chunk-local; made global below
+            runs[k] = (c.run_start, c.run_term)
+
+    try:
+        n_thr = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n_thr = os.cpu_count() or 1
+    with ThreadPoolExecutor(max(1, min(16, n_thr))) as ex:
+        list(ex.map(work, range(len(runs))))
+    if with_terms:
+        base = np.uint64(0)
+        for k in range(len(runs)):
+            g0, g1 = bounds[k], bounds[k + 1]
+            st.run_off[g0 + 1 : g1 + 1] += base
+            base = st.run_off[g1]
+        st.run_start = np.concatenate([r[0] for r in runs])
+        st.run_term = np.concatenate([r[1] for r in runs])
+    return st
+
+
+def _make_groups_one(n_groups: int, n_peers: int, seed: int, with_terms: bool, group_offset: int) -> GroupState:
     G, N = int(n_groups), int(n_peers)
     if not (1 <= N <= 16):
         raise ValueError("n_peers out of range")

@@ -82,30 +82,61 @@ def test_bench_gated_config_as_headline(gpu_engine_cls):
     assert d["roofline"]["frac"] > 0.3 and "true, true, false" in d["roofline"]["kernel"]
 
 
-def test_bench_two_gpus_worth_from_one_process_and_refusal(gpu_engine_cls):
-    """`--gpus N` launched directly drives N devices itself; with fewer than N visible it must fail loudly
-    instead of printing n_gpus: 1.  --device maps both onto GPU 0 (testing only)."""
+def test_bench_four_gpus_worth_from_one_process_and_refusal(gpu_engine_cls):
+    """`--gpus N` launched directly drives N devices itself (one launch thread per device); with fewer than N visible it
+    must fail loudly instead of printing n_gpus: 1.  --device maps all four onto GPU 0 (testing only)."""
     import torch
 
-    d = run_bench("--gpus", "2", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "20")
-    cfg, r = check_line(d, 2, 6, 2)
+    d = run_bench("--gpus", "4", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "12")
+    cfg, r = check_line(d, 4, 6, 2)
     assert "one process" in cfg["parallelism"] and "config4_whole_job" in d
     assert d["config4_whole_job"]["decisions_per_s"] > 1e9
+    assert len(r["launch_us_per_gpu"]) == 4 and len(r["frac_per_gpu"]) == 4 and all(f > 0.05 for f in r["frac_per_gpu"])
+    assert d["gate"]["sets_gated"] == 4 and d["gate"]["groups_advanced_per_step_whole_job"] > 4 * 12 * (1 << 18)
+    assert cfg["ranks_seen"] == [0] and cfg["rendezvous"]["backend"] == "none"
     if torch.cuda.device_count() < 8:
         p = run_bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extras", expect_rc=1)
         assert "refusing" in (p.stderr + p.stdout)
 
 
-def test_bench_two_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):
-    """The driver's N > 1 launch line (torch.distributed.run, one process per GPU), both ranks on GPU 0 over gloo."""
+def _torchrun_bench(nproc, port, *args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2",
-                        "--steps", "6", "--warmup", "2", "--device", "0", "--backend", "gloo", "--no-extras", "--batches", "20"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
+                        *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
-    cfg, _ = check_line(d, 2, 6, 2)
-    assert "torchrun" in cfg["parallelism"]
+    return json.loads(lines[0])
+
+
+def test_bench_four_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):
+    """The driver's N > 1 launch line (torch.distributed.run, one process per GPU) at its default arguments for the
+    rendezvous: gloo group + shared-memory barrier, no RCCL anywhere.  All four ranks on GPU 0 (testing only)."""
+    d = _torchrun_bench(4, 29533, "--steps", "6", "--warmup", "2", "--device", "0", "--no-extras", "--batches", "12")
+    cfg, r = check_line(d, 4, 6, 2)
+    assert "torchrun" in cfg["parallelism"] and cfg["ranks_seen"] == [0, 1, 2, 3]
+    assert cfg["rendezvous"] == {"backend": "gloo", "barrier": "shm", "note": ""}
+    assert len(r["launch_us_per_gpu"]) == 4 and len(r["wall_ms_per_rank"]) == 4 and d["gate"]["sets_gated"] == 4
+
+
+def test_bench_rccl_asked_for_where_it_cannot_work(gpu_engine_cls):
+    """`--backend nccl` with two ranks mapped onto ONE device: RCCL refuses that.  Every rank must agree -- before any
+    RCCL rendezvous -- to stay on gloo, finish the job, and say why (a communicator failure must not
+    sink a run whose data path needs no collective)."""
+    d = _torchrun_bench(2, 29534, "--steps", "4", "--warmup", "1", "--device", "0", "--backend", "nccl", "--no-extras",
+                        "--batches", "12")
+    cfg, _ = check_line(d, 2, 4, 1)
+    assert cfg["rendezvous"]["backend"] == "gloo" and "nccl asked for, gloo used" in cfg["rendezvous"]["note"]
+    assert "shares GPU 0" in cfg["rendezvous"]["note"]
+
+
+def test_bench_rccl_leg_on_hardware_with_one_rank(gpu_engine_cls):
+    """The opt-in RCCL leg on this box's one GPU: torchrun with one rank and `--backend nccl` walks the whole rendezvous
+    (gloo group, pre-checks, RCCL group beside it, warm-up all-reduce, RCCL barriers around the timed region, RCCL
+    reductions) -- a one-rank communicator, so no xGMI traffic, but the RCCL code path on real hardware."""
+    d = _torchrun_bench(1, 29535, "--steps", "4", "--warmup", "1", "--backend", "nccl", "--no-extras", "--batches", "12",
+                        "--no-cpu-baseline")
+    cfg, _ = check_line(d, 1, 4, 1)
+    assert cfg["rendezvous"] == {"backend": "nccl", "barrier": "nccl", "note": ""}, cfg["rendezvous"]
+    assert cfg["ranks_seen"] == [0]

@@ -673,8 +673,8 @@ static int fetch_wire(raftq_t* h, bool want_ents, const char* who, raftq::StepSl
     }
     HIPCHK(h, exclusive_sum_u64((const uint64_t*)s.w_cnt, s.w_base, sl.n + 1, (uint64_t*)s.w_scan, st));
     hipLaunchKernelGGL(wire_dec_ents_kernel, dim3((unsigned)((sl.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       (const uint8_t*)s.w_stream, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs, (const uint64_t*)s.w_base,
-                       s.w_ents, s.w_ents_cap);
+                       (const uint8_t*)s.w_stream, sl.w_nbytes, (const uint64_t*)s.w_off, sl.n, (WireMsg*)s.msgs,
+                       (const uint64_t*)s.w_base, s.w_ents, s.w_ents_cap);
     HIPCHK(h, hipGetLastError());
     // learn the entry count, size the pinned block for both arrays (so a pointer handed out for the messages
     // stays valid when the entries are asked for later)

@@ -202,7 +202,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_cnt, d_base, n + 1, (uint64_t*)(base + o_scan), h->stream));
   hipLaunchKernelGGL(wire_dec_ents_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
-                     (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
+                     nbytes, (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
                      dev_cap);
   HIPCHK(h, hipGetLastError());
   if (int rc = d2h(h, msgs, d_msgs, n * sizeof(WireMsg))) return rc;

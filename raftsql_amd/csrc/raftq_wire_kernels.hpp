@@ -20,29 +20,10 @@
 #include <stdint.h>
 
 #include "raftq_kernels.hpp"
+#include "raftq_wire_parse.hpp"
 
 namespace raftqk {
 
-struct WireMsg {  // == raftq_wire_msg_t; the first 46 bytes are MsgRec's
-  uint64_t group, term, log_term, index, commit, reject_hint;
-  uint32_t from;
-  uint8_t type, reject, to, flags;
-  uint32_t ent_first, n_ents;
-};
-struct WireEnt {  // == raftq_wire_ent_t
-  uint64_t term, index, data_off;
-  uint32_t data_len, type;
-};
-struct WalRec {  // == raftq_wal_rec_t
-  uint64_t group, term, index, data_off;
-  uint32_t data_len, vote, crc;
-  uint8_t kind, entry_type, flags, pad;
-};
-static_assert(sizeof(WireMsg) == 64 && sizeof(WireEnt) == 32 && sizeof(WalRec) == 48, "record layout");
-
-constexpr uint8_t kWireMalformed = 1, kWireSnapshot = 2, kWireGroup = 4;
-constexpr uint8_t kWalMetadata = 1, kWalEntry = 2, kWalState = 3, kWalCrc = 4, kWalSnapshot = 5;
-constexpr uint8_t kWalMalformed = 1, kWalBadCrc = 2, kWalGroup = 4;
 constexpr uint32_t kCoopBytes = 512;  // payloads longer than this are CRC'd by a whole wave
 
 // ---- CRC-32C (Castagnoli, reflected 0x82f63b78; bit 31 of a word is x^0) -------------------------
@@ -259,11 +240,6 @@ __device__ __forceinline__ uint32_t crc_varint(const uint32_t* tab, uint32_t raw
 __device__ __forceinline__ uint32_t crc_field(const uint32_t* tab, uint32_t raw, uint8_t tag, uint64_t v) {
   return crc_varint(tab, crc_byte(tab, raw, tag), v);
 }
-__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
-  uint64_t w;
-  __builtin_memcpy(&w, p, 8);
-  return w;
-}
 __device__ inline uint32_t crc_span(const uint32_t* tab, uint32_t raw, const uint8_t* p, uint64_t n) {
   uint64_t i = 0;
   for (; i + 8 <= n; i += 8) {
@@ -357,109 +333,12 @@ struct Sink {
   }
 };
 
-// the Unmarshal varint loop.  Returns bytes consumed, 0 = malformed (truncated or > 10 bytes).
-__device__ inline uint32_t get_varint(const uint8_t* p, uint64_t n, uint64_t* v) {
-  if (n >= 8) {
-    uint64_t w = load_u64(p);
-    const uint64_t stop = ~w & 0x8080808080808080ull;  // bit 7 of every byte that ends a varint
-    if (stop) {
-      const uint32_t len = ((uint32_t)__ffsll((long long)stop)) >> 3;  // 1..8
-      if (len < 8) w &= (1ull << (8 * len)) - 1;
-      w &= 0x7f7f7f7f7f7f7f7full;
-      w = ((w & 0x7f007f007f007f00ull) >> 1) | (w & 0x007f007f007f007full);
-      w = ((w & 0x3fff00003fff0000ull) >> 2) | (w & 0x00003fff00003fffull);
-      w = ((w & 0x0fffffff00000000ull) >> 4) | (w & 0x000000000fffffffull);
-      *v = w;
-      return len;
-    }
-  }
-  uint64_t r = 0;
-  for (uint32_t i = 0; i < n && i < 10; ++i) {
-    const uint8_t b = p[i];
-    r |= (uint64_t)(b & 0x7f) << (7 * i);  // the 10th byte's high bits fall off, as in Go
-    if (b < 0x80) {
-      *v = r;
-      return i + 1;
-    }
-  }
-  return 0;
-}
-
-// skipRaft: bytes of one unknown field's value, 0 = malformed
-__device__ inline uint64_t skip_value(const uint8_t* p, uint64_t n, uint32_t wt) {
-  uint64_t v;
-  if (wt == 0) return get_varint(p, n, &v);
-  if (wt == 1) return n >= 8 ? 8 : 0;
-  if (wt == 5) return n >= 4 ? 4 : 0;
-  if (wt == 2) {
-    const uint32_t k = get_varint(p, n, &v);
-    if (!k || v > n - k) return 0;
-    return k + v;
-  }
-  return 0;  // groups and the two unassigned wire types
-}
-
-// one field key; false = malformed
-struct Key {
-  uint64_t fn;
-  uint32_t wt;
-};
-__device__ __forceinline__ bool get_key(const uint8_t* p, uint64_t n, uint64_t& i, Key& k) {
-  uint64_t key;
-  const uint32_t used = get_varint(p + i, n - i, &key);
-  if (!used) return false;
-  i += used;
-  k.wt = (uint32_t)(key & 7);
-  k.fn = key >> 3;
-  return k.fn != 0;  // "illegal tag 0"
-}
-
 // ---- raftpb.Entry -----------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint64_t entry_size(uint32_t type, uint64_t term, uint64_t index, uint32_t data_len) {
   uint64_t n = 3 + sov(type) + sov(term) + sov(index);
   if (data_len) n += 1 + sov(data_len) + data_len;
   return n;
-}
-
-// Entry.Unmarshal.  base = offset of p[0] in the enclosing buffer.  group == nullptr: field 5 is unknown.
-__device__ inline bool parse_entry(const uint8_t* p, uint64_t n, uint64_t base, WireEnt& e, uint64_t* group,
-                                   bool* has_group) {
-  e.term = e.index = e.data_off = 0;
-  e.data_len = e.type = 0;
-  uint64_t i = 0;
-  while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return false;
-    if (k.fn <= 3 || (k.fn == 5 && group)) {
-      if (k.wt != 0) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used) return false;
-      i += used;
-      if (k.fn == 1) e.type = (uint32_t)v;
-      else if (k.fn == 2) e.term = v;
-      else if (k.fn == 3) e.index = v;
-      else {
-        *group = v;
-        *has_group = true;
-      }
-    } else if (k.fn == 4) {
-      if (k.wt != 2) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used || v > n - i - used || v > 0xffffffffull) return false;
-      i += used;
-      e.data_off = base + i;
-      e.data_len = (uint32_t)v;
-      i += v;
-    } else {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return false;
-      i += used;
-    }
-  }
-  if (e.data_len == 0) e.data_off = 0;
-  return true;
 }
 
 // ---- raftpb.Message ---------------------------------------------------------------------------------
@@ -472,129 +351,6 @@ __device__ __forceinline__ uint64_t msg_head_size(const WireMsg& m) {
 // commit, the empty snapshot (10 bytes), reject (2), rejectHint, group
 __device__ __forceinline__ uint64_t msg_tail_size(const WireMsg& m) {
   return 1 + sov(m.commit) + 10 + 2 + 1 + sov(m.reject_hint) + 1 + sov(m.group);
-}
-
-// SnapshotMetadata{1 conf_state (message), 2 index, 3 term}: 1 = something set, 0 = all empty, -1 = malformed
-__device__ inline int snapshot_meta_nonempty(const uint8_t* p, uint64_t n) {
-  uint64_t i = 0;
-  int nonempty = 0;
-  while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return -1;
-    if (k.fn > 3) {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return -1;
-      i += used;
-      continue;
-    }
-    const bool is_len = k.fn == 1;
-    if (k.wt != (is_len ? 2u : 0u)) return -1;
-    const uint32_t used = get_varint(p + i, n - i, &v);
-    if (!used) return -1;
-    i += used;
-    if (is_len) {
-      if (v > n - i) return -1;
-      i += v;
-    }
-    if (v) nonempty = 1;
-  }
-  return nonempty;
-}
-// Snapshot{1 data (bytes), 2 metadata (message)}
-__device__ inline int snapshot_nonempty(const uint8_t* p, uint64_t n) {
-  uint64_t i = 0;
-  int nonempty = 0;
-  while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return -1;
-    if (k.fn > 2) {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return -1;
-      i += used;
-      continue;
-    }
-    if (k.wt != 2) return -1;
-    const uint32_t used = get_varint(p + i, n - i, &v);
-    if (!used) return -1;
-    i += used;
-    if (v > n - i) return -1;
-    if (k.fn == 2) {
-      const int r = snapshot_meta_nonempty(p + i, v);
-      if (r < 0) return -1;
-      nonempty |= r;
-    } else if (v) {
-      nonempty = 1;
-    }
-    i += v;
-  }
-  return nonempty;
-}
-
-__device__ __forceinline__ uint32_t id_to_slot(uint64_t id, uint32_t none) {
-  return id == 0 || id - 1 >= none ? none : (uint32_t)(id - 1);
-}
-
-// Message.Unmarshal over p[0, n).  ents != nullptr: entry k of this message goes to ents[ent_base + k]
-// when that is below ents_cap.  false = malformed.
-__device__ inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t base, WireMsg& m, WireEnt* ents,
-                                 uint64_t ent_base, uint64_t ents_cap) {
-  m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
-  m.from = 0xffffffffu;
-  m.type = m.reject = m.flags = 0;
-  m.to = 0xff;
-  m.ent_first = m.n_ents = 0;
-  uint64_t i = 0;
-  while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return false;
-    if (k.fn > 12) {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return false;
-      i += used;
-      continue;
-    }
-    const bool is_len = k.fn == 7 || k.fn == 9;
-    if (k.wt != (is_len ? 2u : 0u)) return false;  // "wrong wireType"
-    const uint32_t used = get_varint(p + i, n - i, &v);
-    if (!used) return false;
-    i += used;
-    if (is_len && v > n - i) return false;  // io.ErrUnexpectedEOF
-    switch (k.fn) {
-      case 1: m.type = (uint32_t)v > 255 ? 255 : (uint8_t)v; break;
-      case 2: m.to = (uint8_t)id_to_slot(v, 0xff); break;
-      case 3: m.from = id_to_slot(v, 0xffffffffu); break;
-      case 4: m.term = v; break;
-      case 5: m.log_term = v; break;
-      case 6: m.index = v; break;
-      case 7: {
-        WireEnt e;
-        if (!parse_entry(p + i, v, base + i, e, nullptr, nullptr)) return false;
-        const uint64_t slot = ent_base + m.n_ents;
-        if (ents && slot < ents_cap) ents[slot] = e;
-        ++m.n_ents;
-        i += v;
-        break;
-      }
-      case 8: m.commit = v; break;
-      case 9: {
-        const int r = snapshot_nonempty(p + i, v);
-        if (r < 0) return false;
-        if (r) m.flags |= kWireSnapshot;
-        i += v;
-        break;
-      }
-      case 10: m.reject = v != 0; break;
-      case 11: m.reject_hint = v; break;
-      default:  // 12
-        m.group = v;
-        m.flags |= kWireGroup;
-        break;
-    }
-  }
-  return true;
 }
 
 // ---- kernels: raftpb.Message -> rafthttp stream frames -----------------------------------------
@@ -690,30 +446,22 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_payload_kernel(const W
 
 // ---- kernels: stream frames -> raftpb.Message headers ----------------------------------------------
 
-// frame extent + length word; body = [a + 8, b)
-__device__ __forceinline__ bool frame_body(const uint8_t* buf, uint64_t nbytes, uint64_t a, uint64_t b, bool big_endian) {
-  if (!(a <= b && b <= nbytes && b - a >= 8)) return false;
-  uint64_t w = load_u64(buf + a);
-  if (big_endian) w = __builtin_bswap64(w);
-  return w == b - a - 8;
-}
-
 // pass 1: parse every frame, count its entries.  ent_cnt[n] = 0.
+// (Round 2's form of this kernel ran 4,400 instructions and 44 dependent loads per wave: 17 us for 64K frames without
+// entries, 45 us with 15 % MsgApp; raftq_wire_parse.hpp has what changed.  Staging each frame in an LDS row first had
+// changed nothing for that form: it was bound by its instruction count, not by where the bytes came from.)
 static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
                                                                  const uint64_t* __restrict__ off, uint64_t n,
                                                                  WireMsg* __restrict__ msgs,
                                                                  uint64_t* __restrict__ ent_cnt,
                                                                  unsigned long long* n_bad) {
-  // (Staging each frame in an LDS row first -- one memory latency instead of ~20 dependent reads -- was tried and
-  // changed nothing: 17.5 us for 64K 40-byte frames either way.  At one wave per SIMD the kernel is bound by the
-  // dependent ALU chain of the field loop, not by memory; profiles/r01/wire_decode_lds_ab.txt.)
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool malformed = false;
   if (i < n) {
     const uint64_t a = off[i], b = off[i + 1];
     WireMsg m;
     bool ok = frame_body(stream, nbytes, a, b, true);
-    if (ok) ok = parse_msg(stream + a + 8, b - a - 8, a + 8, m, nullptr, 0, 0);
+    if (ok) ok = parse_msg<false>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, nullptr, 0, 0, 0);
     if (!ok) {
       m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
       m.from = 0;
@@ -731,17 +479,21 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* 
   if (mb != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, (unsigned long long)__popcll(mb));
 }
 
-// pass 2: the entry headers, in message order (ent_base = exclusive scan of ent_cnt)
-static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint8_t* __restrict__ stream,
+// pass 2: the entry headers, in message order (ent_base = exclusive scan of ent_cnt).  Only frames that carry entries are
+// walked, and only as far as their last entry: what follows was validated by pass 1.
+static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
                                                                       const uint64_t* __restrict__ off, uint64_t n,
                                                                       WireMsg* __restrict__ msgs,
                                                                       const uint64_t* __restrict__ ent_base,
                                                                       WireEnt* __restrict__ ents, uint64_t ents_cap) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || msgs[i].n_ents == 0) return;
-  const uint64_t a = off[i], b = off[i + 1], first = ent_base[i];
+  if (i >= n) return;
+  const uint64_t first = ent_base[i];
+  const uint32_t cnt = (uint32_t)(ent_base[i + 1] - first);
+  if (cnt == 0) return;
+  const uint64_t a = off[i], b = off[i + 1];
   WireMsg m;
-  (void)parse_msg(stream + a + 8, b - a - 8, a + 8, m, ents, first, ents_cap);
+  (void)parse_msg<true>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, ents, first, ents_cap, cnt);
   msgs[i].ent_first = (uint32_t)first;
 }
 
@@ -904,90 +656,6 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_payload_kernel(const Wa
   uint64_t pos = off[i] + 8 + 2 + sov(r.kind) + sov(chain[i].c) + 1 + sov(dsz);
   if (r.kind == kWalEntry) pos += 3 + sov(r.entry_type) + sov(r.term) + sov(r.index) + 1 + sov(r.data_len);
   wave_copy(out + pos, pool + r.data_off, r.data_len);
-}
-
-// Record.Unmarshal + the Data unmarshal ReadAll does per type.  d_off / d_len: Record.data inside p.
-__device__ inline bool parse_wal_rec(const uint8_t* p, uint64_t n, uint64_t base, WalRec& r, uint64_t& d_off,
-                                     uint64_t& d_len) {
-  r.group = r.term = r.index = r.data_off = 0;
-  r.data_len = r.vote = r.crc = 0;
-  r.kind = r.entry_type = r.flags = r.pad = 0;
-  d_off = d_len = 0;
-  uint64_t i = 0, type = 0;
-  while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return false;
-    if (k.fn <= 2) {
-      if (k.wt != 0) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used) return false;
-      i += used;
-      if (k.fn == 1) type = v;
-      else r.crc = (uint32_t)v;
-    } else if (k.fn == 3) {
-      if (k.wt != 2) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used || v > n - i - used) return false;
-      i += used;
-      d_off = i;
-      d_len = v;
-      i += v;
-    } else {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return false;
-      i += used;
-    }
-  }
-  if (type < 1 || type > 5) return false;  // ReadAll: "unexpected block type"
-  r.kind = (uint8_t)type;
-  const uint8_t* d = p + d_off;
-  if (r.kind == kWalEntry) {
-    WireEnt e;
-    bool hg = false;
-    if (!parse_entry(d, d_len, base + d_off, e, &r.group, &hg)) return false;
-    r.term = e.term;
-    r.index = e.index;
-    r.data_off = e.data_off;
-    r.data_len = e.data_len;
-    r.entry_type = (uint8_t)e.type;
-    if (hg) r.flags |= kWalGroup;
-  } else if (r.kind == kWalState || r.kind == kWalSnapshot) {
-    const uint64_t known = r.kind == kWalState ? 4 : 2;
-    uint64_t j = 0;
-    while (j < d_len) {
-      Key k;
-      uint64_t v;
-      if (!get_key(d, d_len, j, k)) return false;
-      if (k.fn > known) {
-        const uint64_t used = skip_value(d + j, d_len - j, k.wt);
-        if (!used) return false;
-        j += used;
-        continue;
-      }
-      if (k.wt != 0) return false;
-      const uint32_t used = get_varint(d + j, d_len - j, &v);
-      if (!used) return false;
-      j += used;
-      if (r.kind == kWalState) {
-        if (k.fn == 1) r.term = v;
-        else if (k.fn == 2) r.vote = (uint32_t)v;
-        else if (k.fn == 3) r.index = v;
-        else {
-          r.group = v;
-          r.flags |= kWalGroup;
-        }
-      } else {
-        if (k.fn == 1) r.index = v;
-        else r.term = v;
-      }
-    }
-  } else if (r.kind == kWalMetadata) {
-    if (d_len > 0xffffffffull) return false;
-    r.data_off = d_len ? base + d_off : 0;
-    r.data_len = (uint32_t)d_len;
-  }
-  return true;
 }
 
 struct WalSpan {  // Record.data of record i inside the input buffer

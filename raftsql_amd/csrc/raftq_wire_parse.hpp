@@ -1,0 +1,486 @@
+// raftq_wire_parse.hpp -- the Unmarshal side of the wire / WAL codecs (include/raftq_wire.h), one frame per call.
+//
+// What runs per lane in wire_dec_kernel / wire_dec_ents_kernel / wal_dec_kernel (raftq_wire_kernels.hpp): the byte-level
+// restatement of raftpb.Message.Unmarshal, raftpb.Entry.Unmarshal and walpb.Record.Unmarshal (2015-era generated
+// code, the unmarshal behind rafthttp's message stream and w.ReadAll() -- reference call sites raft.go:268-270 and
+// raft.go:124).  Plain functions over byte pointers, compiled for the device AND for the host: the very same source is
+// built into tests/c/libwire_parse_host.so and checked against the codec oracle on the fuzz corpus without a GPU
+// (tests/test_wire_parse_host.py), so a kernel change is validated before it is sent to the GPU box.
+//
+// Round 3: Message.Unmarshal is ONE flat loop, one field per iteration, no nested loops and no
+// switch.  Round 2's form (key varint, value varint, switch on the field number, a nested Entry loop) ran at 4,400
+// dynamic instructions and 44 dependent loads per wave of 64 frames -- 17 us for 64K frames with no entries, 45 us
+// when 15 % of the frames carried entries (profiles/r03/wire_before_*): lanes that had met an Entry were one or more
+// fields behind their neighbours ever after and the wave executed every arm of the switch on every iteration.  Now
+//   * the key byte and the value varint of a field come out of ONE unaligned 8-byte load (keys of the fields both
+//     messages know are one byte; values up to 2^49 fit the other seven) through one SWAR compress;
+//   * the field is filed by predicated selects -- lanes at different fields cost nothing extra;
+//   * an Entry is a scope (its end offset) of the same loop, not a nested loop: a lane inside an Entry and a lane at a
+//     top-level field execute the same instructions;
+//   * the empty Snapshot every stock encoder emits (8 fixed body bytes) is one compare; anything else goes through the
+//     generic nested walk.
+// Everything the fast form does not cover -- multi-byte keys, 9/10-byte varints, unknown fields, the last bytes of the
+// buffer -- takes the byte-loop forms below, per field; results are identical by construction and by the fuzz tests.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RAFTQ_HD __host__ __device__
+#else
+#define RAFTQ_HD
+#endif
+
+namespace raftqk {
+
+struct WireMsg {  // == raftq_wire_msg_t; the first 46 bytes are MsgRec's
+  uint64_t group, term, log_term, index, commit, reject_hint;
+  uint32_t from;
+  uint8_t type, reject, to, flags;
+  uint32_t ent_first, n_ents;
+};
+struct WireEnt {  // == raftq_wire_ent_t
+  uint64_t term, index, data_off;
+  uint32_t data_len, type;
+};
+struct WalRec {  // == raftq_wal_rec_t
+  uint64_t group, term, index, data_off;
+  uint32_t data_len, vote, crc;
+  uint8_t kind, entry_type, flags, pad;
+};
+static_assert(sizeof(WireMsg) == 64 && sizeof(WireEnt) == 32 && sizeof(WalRec) == 48, "record layout");
+
+constexpr uint8_t kWireMalformed = 1, kWireSnapshot = 2, kWireGroup = 4;
+constexpr uint8_t kWalMetadata = 1, kWalEntry = 2, kWalState = 3, kWalCrc = 4, kWalSnapshot = 5;
+constexpr uint8_t kWalMalformed = 1, kWalBadCrc = 2, kWalGroup = 4;
+
+RAFTQ_HD inline uint64_t load_u64(const uint8_t* p) {
+  uint64_t w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+}
+// 1-based index of the lowest set bit (x != 0)
+RAFTQ_HD inline uint32_t ffs64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__ffsll((long long)x);
+#else
+  return (uint32_t)__builtin_ffsll((long long)x);
+#endif
+}
+// the 7-bit groups of the varint in the low `len` bytes of w (len 1..8), packed
+RAFTQ_HD inline uint64_t varint_compress(uint64_t w, uint32_t len) {
+  if (len < 8) w &= (1ull << (8 * len)) - 1;
+  w &= 0x7f7f7f7f7f7f7f7full;
+  w = ((w & 0x7f007f007f007f00ull) >> 1) | (w & 0x007f007f007f007full);
+  w = ((w & 0x3fff00003fff0000ull) >> 2) | (w & 0x00003fff00003fffull);
+  w = ((w & 0x0fffffff00000000ull) >> 4) | (w & 0x000000000fffffffull);
+  return w;
+}
+
+// the Unmarshal varint loop.  Returns bytes consumed, 0 = malformed (truncated or > 10 bytes).
+RAFTQ_HD inline uint32_t get_varint(const uint8_t* p, uint64_t n, uint64_t* v) {
+  if (n >= 8) {
+    const uint64_t w = load_u64(p);
+    const uint64_t stop = ~w & 0x8080808080808080ull;  // bit 7 of every byte that ends a varint
+    if (stop) {
+      const uint32_t len = ffs64(stop) >> 3;  // 1..8
+      *v = varint_compress(w, len);
+      return len;
+    }
+  }
+  uint64_t r = 0;
+  for (uint32_t i = 0; i < n && i < 10; ++i) {
+    const uint8_t b = p[i];
+    r |= (uint64_t)(b & 0x7f) << (7 * i);  // the 10th byte's high bits fall off, as in Go
+    if (b < 0x80) {
+      *v = r;
+      return i + 1;
+    }
+  }
+  return 0;
+}
+
+// skipRaft: bytes of one unknown field's value, 0 = malformed
+RAFTQ_HD inline uint64_t skip_value(const uint8_t* p, uint64_t n, uint32_t wt) {
+  uint64_t v;
+  if (wt == 0) return get_varint(p, n, &v);
+  if (wt == 1) return n >= 8 ? 8 : 0;
+  if (wt == 5) return n >= 4 ? 4 : 0;
+  if (wt == 2) {
+    const uint32_t k = get_varint(p, n, &v);
+    if (!k || v > n - k) return 0;
+    return k + v;
+  }
+  return 0;  // groups and the two unassigned wire types
+}
+
+// one field key; false = malformed
+struct Key {
+  uint64_t fn;
+  uint32_t wt;
+};
+RAFTQ_HD inline bool get_key(const uint8_t* p, uint64_t n, uint64_t& i, Key& k) {
+  uint64_t key;
+  const uint32_t used = get_varint(p + i, n - i, &key);
+  if (!used) return false;
+  i += used;
+  k.wt = (uint32_t)(key & 7);
+  k.fn = key >> 3;
+  return k.fn != 0;  // "illegal tag 0"
+}
+
+// ---- raftpb.Entry -----------------------------------------------------------------------------------
+
+// Entry.Unmarshal (the generic form: WAL records, where an Entry is the whole Record.data).  base = offset of p[0] in
+// the enclosing buffer.  group == nullptr: field 5 is unknown.
+RAFTQ_HD inline bool parse_entry(const uint8_t* p, uint64_t n, uint64_t base, WireEnt& e, uint64_t* group,
+                                 bool* has_group) {
+  e.term = e.index = e.data_off = 0;
+  e.data_len = e.type = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return false;
+    if (k.fn <= 3 || (k.fn == 5 && group)) {
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used) return false;
+      i += used;
+      if (k.fn == 1) e.type = (uint32_t)v;
+      else if (k.fn == 2) e.term = v;
+      else if (k.fn == 3) e.index = v;
+      else {
+        *group = v;
+        *has_group = true;
+      }
+    } else if (k.fn == 4) {
+      if (k.wt != 2) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used || v > n - i - used || v > 0xffffffffull) return false;
+      i += used;
+      e.data_off = base + i;
+      e.data_len = (uint32_t)v;
+      i += v;
+    } else {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return false;
+      i += used;
+    }
+  }
+  if (e.data_len == 0) e.data_off = 0;
+  return true;
+}
+
+// ---- raftpb.Message ---------------------------------------------------------------------------------
+
+// SnapshotMetadata{1 conf_state (message), 2 index, 3 term}: 1 = something set, 0 = all empty, -1 = malformed
+RAFTQ_HD inline int snapshot_meta_nonempty(const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  int nonempty = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return -1;
+    if (k.fn > 3) {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return -1;
+      i += used;
+      continue;
+    }
+    const bool is_len = k.fn == 1;
+    if (k.wt != (is_len ? 2u : 0u)) return -1;
+    const uint32_t used = get_varint(p + i, n - i, &v);
+    if (!used) return -1;
+    i += used;
+    if (is_len) {
+      if (v > n - i) return -1;
+      i += v;
+    }
+    if (v) nonempty = 1;
+  }
+  return nonempty;
+}
+// Snapshot{1 data (bytes), 2 metadata (message)}
+RAFTQ_HD inline int snapshot_nonempty(const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  int nonempty = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return -1;
+    if (k.fn > 2) {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return -1;
+      i += used;
+      continue;
+    }
+    if (k.wt != 2) return -1;
+    const uint32_t used = get_varint(p + i, n - i, &v);
+    if (!used) return -1;
+    i += used;
+    if (v > n - i) return -1;
+    if (k.fn == 2) {
+      const int r = snapshot_meta_nonempty(p + i, v);
+      if (r < 0) return -1;
+      nonempty |= r;
+    } else if (v) {
+      nonempty = 1;
+    }
+    i += v;
+  }
+  return nonempty;
+}
+
+RAFTQ_HD inline uint32_t id_to_slot(uint64_t id, uint32_t none) {
+  return id == 0 || id - 1 >= none ? none : (uint32_t)(id - 1);
+}
+
+// the body of the Snapshot a stock encoder writes for "no snapshot": 12 06 0a 00 10 00 18 00 (metadata{conf_state{},
+// index 0, term 0}), as one little-endian word
+constexpr uint64_t kEmptySnapshotBody = 0x00180010000a0612ull;
+
+// Message.Unmarshal over p[0, n) as one flat loop (see the head of this file).
+//   safe      bytes from p[0] on that may be touched by 8-byte loads (>= n; the enclosing buffer's end): a field whose
+//             8-byte window would cross it takes the byte-loop form
+//   base      offset of p[0] in the enclosing buffer (entry payload offsets are relative to that buffer)
+//   EMIT      entry k of this message goes to ents[ent_base + k] when that is below ents_cap, and the walk stops
+//             after `stop_after` entries (the count a first pass found) -- what follows them was validated then
+// false = malformed.  m.n_ents counts the entries either way; m.ent_first is the caller's.
+template <bool EMIT>
+RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint64_t base, WireMsg& m, WireEnt* ents,
+                               uint64_t ent_base, uint64_t ents_cap, uint32_t stop_after) {
+  uint64_t group = 0, term = 0, log_term = 0, index = 0, commit = 0, reject_hint = 0;
+  uint32_t from = 0xffffffffu, type = 0, reject = 0, to = 0xff, flags = 0, n_ents = 0;
+  uint64_t e_term = 0, e_index = 0, e_off = 0;  // the Entry being walked
+  uint32_t e_len = 0, e_type = 0;
+  uint64_t i = 0, lim = n;  // lim: end of the current scope -- the message, or the Entry being walked
+  bool in_ent = false;
+  bool ok = true;
+  while (true) {
+    if (i >= lim) {  // a scope ends exactly where its last field does (every step below is bounded by lim)
+      if (!in_ent) break;
+      if (EMIT) {
+        const uint64_t slot = ent_base + n_ents;
+        if (ents && slot < ents_cap) {
+          WireEnt e;
+          e.term = e_term;
+          e.index = e_index;
+          e.data_off = e_len ? e_off : 0;
+          e.data_len = e_len;
+          e.type = e_type;
+          ents[slot] = e;
+        }
+      }
+      ++n_ents;
+      in_ent = false;
+      lim = n;
+      if (EMIT && n_ents >= stop_after) break;
+      continue;
+    }
+    const uint64_t rem = lim - i;
+    uint64_t v;
+    uint32_t fn, wt;
+    const uint32_t known = in_ent ? 4u : 12u;
+    bool fast = i + 8 <= safe;
+    uint64_t w = 0;
+    if (fast) {
+      w = load_u64(p + i);
+      const uint64_t vstop = ~w & 0x8080808080808000ull;  // terminators among the seven bytes behind the key byte
+      fn = (uint32_t)(w >> 3) & 0x1fu;                    // of a one-byte key (bit 7 clear: checked next)
+      fast = (w & 0x80u) == 0 && vstop != 0 && fn != 0 && fn <= known;
+      if (fast) {
+        const uint32_t used = ffs64(vstop) >> 3;  // key + varint bytes, 2..8
+        if (used > rem) {  // the varint runs over the end of its scope: io.ErrUnexpectedEOF
+          ok = false;
+          break;
+        }
+        wt = (uint32_t)w & 7u;
+        v = varint_compress(w >> 8, used - 1);
+        i += used;
+      }
+    }
+    if (!fast) {  // byte-loop forms, bounded by the scope: long keys, long varints, unknown fields, the buffer's tail
+      Key k;
+      uint64_t j = i;
+      if (!get_key(p, lim, j, k)) {
+        ok = false;
+        break;
+      }
+      if (k.fn > known) {
+        const uint64_t used = skip_value(p + j, lim - j, k.wt);
+        if (!used) {
+          ok = false;
+          break;
+        }
+        i = j + used;
+        continue;
+      }
+      fn = (uint32_t)k.fn;
+      wt = k.wt;
+      const uint32_t used = get_varint(p + j, lim - j, &v);
+      if (!used) {
+        ok = false;
+        break;
+      }
+      i = j + used;
+    }
+    // one known field (fn, wt, v); i is behind its varint
+    const bool is_len = in_ent ? fn == 4 : (fn == 7 || fn == 9);
+    if (wt != (is_len ? 2u : 0u) || (is_len && v > lim - i)) {  // "wrong wireType" / io.ErrUnexpectedEOF
+      ok = false;
+      break;
+    }
+    if (in_ent) {
+      if (fn == 4 && v > 0xffffffffull) {
+        ok = false;
+        break;
+      }
+      e_type = fn == 1 ? (uint32_t)v : e_type;
+      e_term = fn == 2 ? v : e_term;
+      e_index = fn == 3 ? v : e_index;
+      e_off = fn == 4 ? base + i : e_off;
+      e_len = fn == 4 ? (uint32_t)v : e_len;
+      i += fn == 4 ? v : 0;
+    } else {
+      type = fn == 1 ? ((uint32_t)v > 255 ? 255u : (uint32_t)v & 0xffu) : type;
+      to = fn == 2 ? id_to_slot(v, 0xff) : to;
+      from = fn == 3 ? id_to_slot(v, 0xffffffffu) : from;
+      term = fn == 4 ? v : term;
+      log_term = fn == 5 ? v : log_term;
+      index = fn == 6 ? v : index;
+      commit = fn == 8 ? v : commit;
+      reject = fn == 10 ? (v != 0 ? 1u : 0u) : reject;
+      reject_hint = fn == 11 ? v : reject_hint;
+      group = fn == 12 ? v : group;
+      flags |= fn == 12 ? kWireGroup : 0u;
+      if (fn == 7) {  // an Entry: a scope of this loop (an empty one is complete at once, on the next turn)
+        in_ent = true;
+        lim = i + v;
+        e_term = e_index = e_off = 0;
+        e_len = e_type = 0;
+      } else if (fn == 9) {
+        int r = 0;
+        if (!(v == 8 && i + 8 <= safe && load_u64(p + i) == kEmptySnapshotBody)) {
+          r = snapshot_nonempty(p + i, v);
+          if (r < 0) {
+            ok = false;
+            break;
+          }
+        }
+        flags |= r ? kWireSnapshot : 0u;
+        i += v;
+      }
+    }
+  }
+  m.group = group;
+  m.term = term;
+  m.log_term = log_term;
+  m.index = index;
+  m.commit = commit;
+  m.reject_hint = reject_hint;
+  m.from = from;
+  m.type = (uint8_t)type;
+  m.reject = (uint8_t)reject;
+  m.to = (uint8_t)to;
+  m.flags = (uint8_t)flags;
+  m.ent_first = 0;
+  m.n_ents = n_ents;
+  return ok;
+}
+
+// ---- walpb.Record -----------------------------------------------------------------------------------
+
+// Record.Unmarshal + the Data unmarshal ReadAll does per type.  d_off / d_len: Record.data inside p.
+RAFTQ_HD inline bool parse_wal_rec(const uint8_t* p, uint64_t n, uint64_t base, WalRec& r, uint64_t& d_off,
+                                   uint64_t& d_len) {
+  r.group = r.term = r.index = r.data_off = 0;
+  r.data_len = r.vote = r.crc = 0;
+  r.kind = r.entry_type = r.flags = r.pad = 0;
+  d_off = d_len = 0;
+  uint64_t i = 0, type = 0;
+  while (i < n) {
+    Key k;
+    uint64_t v;
+    if (!get_key(p, n, i, k)) return false;
+    if (k.fn <= 2) {
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used) return false;
+      i += used;
+      if (k.fn == 1) type = v;
+      else r.crc = (uint32_t)v;
+    } else if (k.fn == 3) {
+      if (k.wt != 2) return false;
+      const uint32_t used = get_varint(p + i, n - i, &v);
+      if (!used || v > n - i - used) return false;
+      i += used;
+      d_off = i;
+      d_len = v;
+      i += v;
+    } else {
+      const uint64_t used = skip_value(p + i, n - i, k.wt);
+      if (!used) return false;
+      i += used;
+    }
+  }
+  if (type < 1 || type > 5) return false;  // ReadAll: "unexpected block type"
+  r.kind = (uint8_t)type;
+  const uint8_t* d = p + d_off;
+  if (r.kind == kWalEntry) {
+    WireEnt e;
+    bool hg = false;
+    if (!parse_entry(d, d_len, base + d_off, e, &r.group, &hg)) return false;
+    r.term = e.term;
+    r.index = e.index;
+    r.data_off = e.data_off;
+    r.data_len = e.data_len;
+    r.entry_type = (uint8_t)e.type;
+    if (hg) r.flags |= kWalGroup;
+  } else if (r.kind == kWalState || r.kind == kWalSnapshot) {
+    const uint64_t known = r.kind == kWalState ? 4 : 2;
+    uint64_t j = 0;
+    while (j < d_len) {
+      Key k;
+      uint64_t v;
+      if (!get_key(d, d_len, j, k)) return false;
+      if (k.fn > known) {
+        const uint64_t used = skip_value(d + j, d_len - j, k.wt);
+        if (!used) return false;
+        j += used;
+        continue;
+      }
+      if (k.wt != 0) return false;
+      const uint32_t used = get_varint(d + j, d_len - j, &v);
+      if (!used) return false;
+      j += used;
+      if (r.kind == kWalState) {
+        if (k.fn == 1) r.term = v;
+        else if (k.fn == 2) r.vote = (uint32_t)v;
+        else if (k.fn == 3) r.index = v;
+        else {
+          r.group = v;
+          r.flags |= kWalGroup;
+        }
+      } else {
+        if (k.fn == 1) r.index = v;
+        else r.term = v;
+      }
+    }
+  } else if (r.kind == kWalMetadata) {
+    if (d_len > 0xffffffffull) return false;
+    r.data_off = d_len ? base + d_off : 0;
+    r.data_len = (uint32_t)d_len;
+  }
+  return true;
+}
+
+// frame extent + length word; body = [a + 8, b)
+RAFTQ_HD inline bool frame_body(const uint8_t* buf, uint64_t nbytes, uint64_t a, uint64_t b, bool big_endian) {
+  if (!(a <= b && b <= nbytes && b - a >= 8)) return false;
+  uint64_t w = load_u64(buf + a);
+  if (big_endian) w = __builtin_bswap64(w);
+  return w == b - a - 8;
+}
+
+}  // namespace raftqk

@@ -25,7 +25,8 @@ def run_bench(*args, expect_rc=0):
     return json.loads(lines[0])
 
 
-def check_line(d, n_gpus, steps, warmup):
+def check_line(d, n_gpus, steps, warmup, sharing=1):
+    """sharing: how many of the job's "GPUs" were mapped onto one device (testing only): each dispatch then runs that much slower"""
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -47,7 +48,7 @@ def check_line(d, n_gpus, steps, warmup):
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6
     assert abs(r["achieved_read_GBps"] - r["achieved"] * 50 / 58.25) / r["achieved"] < 1e-6
     assert "sweep_set_kernel<5, 8, true, false, true, 3, true, 256>" in r["kernel"]
-    assert 0.3 < r["frac"] < 1.0
+    assert 0.3 / sharing < r["frac"] < 1.0
     return cfg, r
 
 
@@ -87,12 +88,12 @@ def test_bench_four_gpus_worth_from_one_process_and_refusal(gpu_engine_cls):
     must fail loudly instead of printing n_gpus: 1.  --device maps all four onto GPU 0 (testing only)."""
     import torch
 
-    d = run_bench("--gpus", "4", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "12")
-    cfg, r = check_line(d, 4, 6, 2)
+    d = run_bench("--gpus", "4", "--device", "0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--batches", "20")
+    cfg, r = check_line(d, 4, 6, 2, sharing=4)
     assert "one process" in cfg["parallelism"] and "config4_whole_job" in d
     assert d["config4_whole_job"]["decisions_per_s"] > 1e9
     assert len(r["launch_us_per_gpu"]) == 4 and len(r["frac_per_gpu"]) == 4 and all(f > 0.05 for f in r["frac_per_gpu"])
-    assert d["gate"]["sets_gated"] == 4 and d["gate"]["groups_advanced_per_step_whole_job"] > 4 * 12 * (1 << 18)
+    assert d["gate"]["sets_gated"] == 4 and d["gate"]["groups_advanced_per_step_whole_job"] > 4 * 20 * (1 << 18)
     assert cfg["ranks_seen"] == [0] and cfg["rendezvous"]["backend"] == "none"
     if torch.cuda.device_count() < 8:
         p = run_bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extras", expect_rc=1)
@@ -113,8 +114,8 @@ def _torchrun_bench(nproc, port, *args):
 def test_bench_four_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):
     """The driver's N > 1 launch line (torch.distributed.run, one process per GPU) at its default arguments for the
     rendezvous: gloo group + shared-memory barrier, no RCCL anywhere.  All four ranks on GPU 0 (testing only)."""
-    d = _torchrun_bench(4, 29533, "--steps", "6", "--warmup", "2", "--device", "0", "--no-extras", "--batches", "12")
-    cfg, r = check_line(d, 4, 6, 2)
+    d = _torchrun_bench(4, 29533, "--steps", "6", "--warmup", "2", "--device", "0", "--no-extras", "--batches", "20")
+    cfg, r = check_line(d, 4, 6, 2, sharing=4)
     assert "torchrun" in cfg["parallelism"] and cfg["ranks_seen"] == [0, 1, 2, 3]
     assert cfg["rendezvous"] == {"backend": "gloo", "barrier": "shm", "note": ""}
     assert len(r["launch_us_per_gpu"]) == 4 and len(r["wall_ms_per_rank"]) == 4 and d["gate"]["sets_gated"] == 4
@@ -125,8 +126,8 @@ def test_bench_rccl_asked_for_where_it_cannot_work(gpu_engine_cls):
     RCCL rendezvous -- to stay on gloo, finish the job, and say why (a communicator failure must not
     sink a run whose data path needs no collective)."""
     d = _torchrun_bench(2, 29534, "--steps", "4", "--warmup", "1", "--device", "0", "--backend", "nccl", "--no-extras",
-                        "--batches", "12")
-    cfg, _ = check_line(d, 2, 4, 1)
+                        "--batches", "20")
+    cfg, _ = check_line(d, 2, 4, 1, sharing=2)
     assert cfg["rendezvous"]["backend"] == "gloo" and "nccl asked for, gloo used" in cfg["rendezvous"]["note"]
     assert "shares GPU 0" in cfg["rendezvous"]["note"]
 
@@ -135,7 +136,7 @@ def test_bench_rccl_leg_on_hardware_with_one_rank(gpu_engine_cls):
     """The opt-in RCCL leg on this box's one GPU: torchrun with one rank and `--backend nccl` walks the whole rendezvous
     (gloo group, pre-checks, RCCL group beside it, warm-up all-reduce, RCCL barriers around the timed region, RCCL
     reductions) -- a one-rank communicator, so no xGMI traffic, but the RCCL code path on real hardware."""
-    d = _torchrun_bench(1, 29535, "--steps", "4", "--warmup", "1", "--backend", "nccl", "--no-extras", "--batches", "12",
+    d = _torchrun_bench(1, 29535, "--steps", "4", "--warmup", "1", "--backend", "nccl", "--no-extras", "--batches", "20",
                         "--no-cpu-baseline")
     cfg, _ = check_line(d, 1, 4, 1)
     assert cfg["rendezvous"] == {"backend": "nccl", "barrier": "nccl", "note": ""}, cfg["rendezvous"]

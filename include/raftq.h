@@ -67,10 +67,12 @@ extern "C" {
 #define RAFTQ_SWEEP_STREAM 0x40u /* force non-temporal streaming accesses */
 #define RAFTQ_SWEEP_CACHED 0x80u /* force normal cached accesses */
 
-/* raftq_cycle / raftq_cycle_packed only: the caller vouches for the ranges of its match deltas (a driver that built
- * the records itself), so the library validates and scatters them in ONE pass straight from the pinned batch.  A
- * record that is out of range after all is dropped on its own: the rest of the turn is applied, every output is
- * filled in, and the call still returns RAFTQ_EINVAL.  Without the flag a turn is all-or-nothing. */
+/* raftq_cycle / raftq_cycle_packed only: the caller vouches for the ranges of its records (a driver that built them
+ * itself), so the library validates and scatters the match deltas in ONE pass straight from the batch.  A record of
+ * EITHER kind that is out of range after all is dropped on its own -- what a trusted turn applies never depends on
+ * another record of the batch: every other match and vote record is applied, the sweep is adopted, every output is
+ * filled in, and the call returns RAFTQ_EINVAL with "that record was dropped, every other record ... was applied" in
+ * raftq_last_error().  Without the flag a turn is all-or-nothing. */
 #define RAFTQ_CYCLE_TRUSTED 0x100u
 
 typedef struct raftq raftq_t;
@@ -244,8 +246,10 @@ int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_li
 /* The batching turn -- one iteration of the Ready loop (raft.go:227-235) for every group -- with the 16-byte
  * records (handles of at most 2^32 groups).  Same semantics as raftq_cycle /
  * raftq_stage / raftq_last_advances; match deltas arrive as raftq_delta16_t, the advance list leaves as
- * raftq_advance16_t.  A turn is all-or-nothing in every form: one out-of-range record of either kind and no
- * record of the call is applied, the sweep it ran is not adopted, RAFTQ_EINVAL. */
+ * raftq_advance16_t.  Without RAFTQ_CYCLE_TRUSTED a turn is all-or-nothing in either layout: one out-of-range record
+ * of either kind and no record of the call is applied, the sweep it ran is not adopted, RAFTQ_EINVAL (with the flag:
+ * see RAFTQ_CYCLE_TRUSTED above).  Arrays passed from the handle's ack buffer must have been staged with THIS call's
+ * counts and layout (raftq_stage* with the same n_deltas / n_vote_deltas): RAFTQ_EINVAL otherwise. */
 int raftq_cycle_packed(raftq_t* h, const raftq_delta16_t* deltas, uint64_t n_deltas,
                        const raftq_vote_delta_t* vote_deltas, uint64_t n_vote_deltas, unsigned flags,
                        raftq_advance16_t* advances_out, uint64_t cap, uint64_t* n_advanced,

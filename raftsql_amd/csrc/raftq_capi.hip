@@ -9,9 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
-#include <csetjmp>
 #include <mutex>
-#include <csignal>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -160,38 +158,28 @@ int raftq_detail::ensure_staging(raftq_t* h, size_t bytes) {
   return RAFTQ_OK;
 }
 
-// Can this process really store into `p` (device memory behind the BAR)?  hipDeviceAttributeIsLargeBar says the
-// aperture exists; whether this container may touch it is found out once, with the fault caught, instead of by the
-// first producer.  Not thread-safe against other users of SIGSEGV / SIGBUS handlers: it runs once per handle, at the
-// first staging request.
-namespace {
-sigjmp_buf g_probe_jmp;
-void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
-}  // namespace
+// Can this process really store into `p` (device memory behind the BAR)?  hipDeviceAttributeIsLargeBar says the aperture
+// exists; whether the allocation is mapped writable into THIS process is read off /proc/self/maps -- no store is tried
+// and no signal handler is touched.  (Round 2 probed with a guarded store and a temporary SIGSEGV / SIGBUS handler that
+// siglongjmp'd out of the fault: undefined behaviour in a host with other threads that use those signals -- the Go
+// runtime this library is meant to sit under requires SA_ONSTACK handlers, a JVM installs its own)
 bool raftq_detail::host_can_write(void* p, size_t bytes) {
-  // the jump buffer and the handlers are the process's: one probe at a time (handles on different threads --
-  // the nodes of a cluster, the members of a set -- may get here together)
-  static std::mutex probe_mu;
-  std::lock_guard<std::mutex> probe_lock(probe_mu);
-  struct sigaction sa, old_segv, old_bus;
-  std::memset(&sa, 0, sizeof sa);
-  sa.sa_handler = probe_fault;
-  sigemptyset(&sa.sa_mask);
-  sigaction(SIGSEGV, &sa, &old_segv);
-  sigaction(SIGBUS, &sa, &old_bus);
-  bool ok = false;
-  if (sigsetjmp(g_probe_jmp, 1) == 0) {
-    volatile uint64_t* q = (volatile uint64_t*)p;
-    q[0] = 0;
-    q[bytes / 8 - 1] = 0;
-#if defined(__x86_64__)
-    __builtin_ia32_sfence();
-#endif
-    ok = true;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::FILE* f = std::fopen("/proc/self/maps", "r");
+  if (!f) return false;  // cannot tell: stay on pinned host memory
+  char line[512];
+  uintptr_t covered = lo;  // [lo, covered) is mapped writable so far (maps is sorted by address)
+  while (covered < hi && std::fgets(line, sizeof line, f)) {
+    unsigned long long a = 0, b = 0;
+    char perms[8] = {0};
+    if (std::sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3) continue;
+    if ((uintptr_t)b <= covered) continue;
+    if ((uintptr_t)a > covered) break;           // a hole in front of the next mapping
+    if (perms[0] != 'r' || perms[1] != 'w') break;  // mapped, but not for stores
+    covered = (uintptr_t)b;
   }
-  sigaction(SIGSEGV, &old_segv, nullptr);
-  sigaction(SIGBUS, &old_bus, nullptr);
-  return ok;
+  std::fclose(f);
+  return covered >= hi;
 }
 
 int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
@@ -237,6 +225,21 @@ inline void publish_ingest(const raftq_t* h) {
 #endif
 }
 
+}  // namespace
+// The buffers a kernel writes for the host to read while the kernel may still be running (the advance list, the totals,
+// the completion flag) are fine-grained: the device's stores go out over PCIe as they are issued instead of sitting in
+// its L2 until the end-of-kernel write-back.  Stated explicitly -- without the flag the choice is the runtime's
+// (HIP_HOST_COHERENT).  RAFTQ_HOST_COHERENT=0 leaves it to the runtime (A/B).
+unsigned raftq_detail::host_coherence_flag() {
+  static const unsigned f = [] {
+    const char* e = std::getenv("RAFTQ_HOST_COHERENT");
+    return e && e[0] == '0' ? 0u : (unsigned)hipHostMallocCoherent;
+  }();
+  return f;
+}
+using raftq_detail::host_coherence_flag;
+namespace {
+
 int ensure_adv(raftq_t* h, uint64_t entries) {
   if (entries <= h->adv_cap) return RAFTQ_OK;
   uint64_t want = std::max<uint64_t>(entries, h->adv_cap * 2);
@@ -247,7 +250,7 @@ int ensure_adv(raftq_t* h, uint64_t entries) {
     h->adv_h = h->adv_d = nullptr;
     h->adv_cap = 0;
   }
-  HIPCHK(h, hipHostMalloc((void**)&h->adv_h, want * sizeof(Advance), hipHostMallocMapped));
+  HIPCHK(h, hipHostMalloc((void**)&h->adv_h, want * sizeof(Advance), hipHostMallocMapped | host_coherence_flag()));
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->adv_d, h->adv_h, 0));
   h->adv_cap = want;
   return RAFTQ_OK;
@@ -374,7 +377,7 @@ int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out)
     if ((rc = alloc((void**)&h->compact_arrived, 64))) break;
     e = hipHostMalloc((void**)&h->h_partials, h->max_partials * sizeof(uint4), hipHostMallocDefault);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
-    e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocMapped);
+    e = hipHostMalloc((void**)&h->h_total, 64, hipHostMallocMapped | host_coherence_flag());
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_total, h->h_total, 0);
     if (e != hipSuccess) { rc = fail(h, RAFTQ_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); break; }
     e = hipEventCreate(&h->ev0);
@@ -527,12 +530,14 @@ static int ensure_delta_dev(raftq_t* h, size_t bytes) {
 }
 
 // after the caller's sync: did the device find a bad record in the batch(es) enqueued since the last check?
-static int check_deltas(raftq_t* h) {
+static int check_deltas(raftq_t* h, bool trusted = false) {
   int rc = RAFTQ_OK;
+  const char* what = trusted ? "; that record was dropped, every other record of the turn was applied (RAFTQ_CYCLE_TRUSTED)"
+                             : "; nothing applied";
   if (h->delta_check[0] && h->h_total[1] == h->delta_check[0])
-    rc = fail(h, RAFTQ_EINVAL, "a match delta is out of range (group >= G or peer >= N); nothing applied");
+    rc = fail(h, RAFTQ_EINVAL, std::string("a match delta is out of range (group >= G or peer >= N)") + what);
   if (h->delta_check[1] && h->h_total[2] == h->delta_check[1])
-    rc = fail(h, RAFTQ_EINVAL, "a vote delta is invalid (group/peer out of range or vote not 1/2); nothing applied");
+    rc = fail(h, RAFTQ_EINVAL, std::string("a vote delta is invalid (group/peer out of range or vote not 1/2)") + what);
   h->delta_check[0] = h->delta_check[1] = 0;
   return rc;
 }
@@ -550,13 +555,25 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   static_assert(sizeof(Rec) == sizeof(AbiRec), "ABI struct mismatch");
   static_assert(sizeof(VoteDeltaRec) == sizeof(raftq_vote_delta_t), "ABI struct mismatch");
   if (nv > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "vote delta batch too large");
+  // A pointer INTO the ack buffer must be exactly where this call's counts and record layout put that array: records
+  // staged with other counts (or through the other layout's raftq_stage*) would overlap their own destination, and
+  // reading them back out of a device-resident buffer crosses the uncached BAR.
+  auto inside = [&](const void* q) {
+    return (const uint8_t*)q >= (const uint8_t*)h->ingest_h && (const uint8_t*)q < (const uint8_t*)h->ingest_h + h->ingest_bytes;
+  };
   if (n) {
     AbiRec* dst = (AbiRec*)h->ingest_h;
-    if ((const void*)d != (const void*)dst) std::memcpy(dst, d, (size_t)n * sizeof(AbiRec));
+    if ((const void*)d != (const void*)dst) {
+      if (inside(d)) return fail(h, RAFTQ_EINVAL, "match deltas staged with other counts / another record layout than this call's");
+      std::memcpy(dst, d, (size_t)n * sizeof(AbiRec));
+    }
   }
   if (nv) {
     raftq_vote_delta_t* dst = (raftq_vote_delta_t*)((uint8_t*)h->ingest_h + off_votes);
-    if ((const void*)vd != (const void*)dst) std::memcpy(dst, vd, (size_t)nv * sizeof(raftq_vote_delta_t));
+    if ((const void*)vd != (const void*)dst) {
+      if (inside(vd)) return fail(h, RAFTQ_EINVAL, "vote deltas staged with other counts / another record layout than this call's");
+      std::memcpy(dst, vd, (size_t)nv * sizeof(raftq_vote_delta_t));
+    }
     if (!h->claim) {
       const size_t bytes = (size_t)h->N * h->ld * sizeof(uint32_t);
       HIPCHK(h, hipMalloc((void**)&h->claim, bytes));
@@ -589,10 +606,12 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   if (nv) {
     // trusted match deltas are dropped one by one, never as a batch: their verdict does not gate the votes
     const unsigned long long em_gate = trusted ? kNoEpoch : em;
+    // and a trusted turn's vote records are dropped one by one as well: what a trusted turn applies never depends on
+    // another record of the batch
     hipLaunchKernelGGL(vote_claim_kernel, gv, dim3(kBlock), 0, h->stream, h->claim, h->ld, (const VoteDeltaRec*)dev_v, nv, bad,
-                       em_gate, ev);
+                       em_gate, ev, h->G, h->N, trusted ? 1 : 0);
     hipLaunchKernelGGL(vote_apply_kernel, gv, dim3(kBlock), 0, h->stream, h->votes, h->N > 8 ? 1 : 0, h->claim, h->ld,
-                       (const VoteDeltaRec*)dev_v, nv, bad, em_gate, ev);
+                       (const VoteDeltaRec*)dev_v, nv, bad, em_gate, ev, h->G, h->N, trusted ? 1 : 0);
   }
   HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
@@ -963,7 +982,17 @@ int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self
 
 // scan-free compaction of the last RAFTQ_SWEEP_CHANGED sweep (compact_changed_kernel computes its own offsets):
 // total and up to `take_cap` entries go straight into pinned host memory.  want_flag: also publish a completion
-// flag the host can poll (returns its value in h->compact_epoch).
+// flag the host can poll (its value is left in h->compact_epoch_armed): a one-thread kernel of ours behind the
+// compaction (default), or the runtime's stream write-value packet (RAFTQ_CYCLE_FLAG=packet: a 3.4 us kernel that
+// starts 5 us after the compaction ends, profiles/r03/cycle_kernel_trace_before.txt).
+static int flag_mode() {  // 1 = raise_flag_kernel, 2 = write-value packet
+  static const int m = [] {
+    const char* e = std::getenv("RAFTQ_CYCLE_FLAG");
+    return e && std::strcmp(e, "packet") == 0 ? 2 : 1;
+  }();
+  return m;
+}
+
 template <typename Adv>
 static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
   static_assert(sizeof(Advance) == sizeof(raftq_advance_t) && sizeof(Advance16) == sizeof(raftq_advance16_t), "ABI struct mismatch");
@@ -996,13 +1025,16 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
   HIPCHK(h, hipGetLastError());
   h->compact_epoch_armed = 0;
   if (want_flag && h->stream_write_ok) {
-    // a write-value packet behind the kernel: the command processor stores the epoch into the pinned flag word
-    // once the compaction (and its end-of-kernel release) has completed -- no extra kernel, no interrupt
     const uint64_t epoch = ++h->compact_epoch;
-    if (hipStreamWriteValue64(h->stream, (void*)(h->d_total + 3), epoch, 0) == hipSuccess)
+    if (flag_mode() == 1) {
+      hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
+      HIPCHK(h, hipGetLastError());
       h->compact_epoch_armed = epoch;
-    else
+    } else if (hipStreamWriteValue64(h->stream, (void*)(h->d_total + 3), epoch, 0) == hipSuccess) {
+      h->compact_epoch_armed = epoch;
+    } else {
       h->stream_write_ok = false;  // not supported here: turns end in the blocking wait
+    }
   }
   return RAFTQ_OK;
 }
@@ -1076,6 +1108,9 @@ static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
       }
       if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
     }
+    // The flag did not land within 2 ms (a turn is ~50 us): either the device is far behind or flags do not reach the
+    // host on this stack.  Do not spin a core for 2 ms on every turn from now on: later turns of this handle block.
+    h->stream_write_ok = false;
   }
   return hipStreamSynchronize(h->stream);
 }
@@ -1094,7 +1129,16 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
   const bool want_list = commit && (advances_out || n_advanced || cap);
   if (want_list) flags |= RAFTQ_SWEEP_CHANGED;
   const size_t off_votes = ((size_t)n_deltas * sizeof(AbiRec) + 255) / 256 * 256;
-  if (int rc = ensure_ingest(h, off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256)) return rc;
+  {
+    const size_t need = off_votes + (size_t)n_vote_deltas * sizeof(raftq_vote_delta_t) + 256;
+    auto staged = [&](const void* q) {
+      return q && h->ingest_h && (const uint8_t*)q >= (const uint8_t*)h->ingest_h &&
+             (const uint8_t*)q < (const uint8_t*)h->ingest_h + h->ingest_bytes;
+    };
+    if (need > h->ingest_bytes && (staged(deltas) || staged(vote_deltas)))  // growing would free what the caller points into
+      return fail(h, RAFTQ_EINVAL, std::string(who) + ": the staged arrays were sized for fewer records than this call names");
+    if (int rc = ensure_ingest(h, need)) return rc;
+  }
   const uint64_t take_cap = want_list ? std::min<uint64_t>(cap, h->G) : 0;
   if (take_cap)
     if (int rc = ensure_adv(h, take_cap)) return rc;
@@ -1118,13 +1162,33 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
                              h->stream));
   const auto t3 = clk::now();
   HIPCHK(h, wait_turn(h, flag_wake ? h->compact_epoch_armed : 0));
+  if (flag_wake && h->compact_epoch_armed) {
+    // RAFTQ_CYCLE_CHECK=1 (tests, soaks): the completion flag must never run ahead of the data it announces -- what
+    // the host sees when the flag lands must be what it sees after a full stream synchronisation
+    static const bool check = [] { const char* e = std::getenv("RAFTQ_CYCLE_CHECK"); return e && e[0] == '1'; }();
+    if (check) {
+      auto digest = [&]() {
+        const uint64_t total = *h->h_total;
+        const uint64_t words = std::min(total, take_cap) * (sizeof(Adv) / 8);
+        uint64_t d = total * 0x9E3779B97F4A7C15ull;
+        const volatile uint64_t* w = (const volatile uint64_t*)h->adv_h;
+        for (uint64_t i = 0; i < words; ++i) d = (d ^ w[i]) * 0xBF58476D1CE4E5B9ull;
+        return d;
+      };
+      const uint64_t at_flag = digest();
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (digest() != at_flag)
+        return fail(h, RAFTQ_EHIP, std::string(who) + ": the completion flag arrived before the advance list it announces "
+                                                      "(RAFTQ_CYCLE_CHECK); set RAFTQ_CYCLE_WAIT=block on this stack");
+    }
+  }
   const auto t4 = clk::now();
   h->prof[1] += us(t0, t1);
   h->prof[2] += us(t1, t2);
   h->prof[3] += us(t2, t3);
   h->prof[4] += us(t3, t4);
   h->prof_n++;
-  const int verdict = check_deltas(h);
+  const int verdict = check_deltas(h, trusted);
   if (verdict != RAFTQ_OK && !trusted) {
     // the device found a record out of range: no record of either kind was scattered, and the sweep that ran on
     // the unchanged state is not adopted either -- the handle is exactly where it was before the call

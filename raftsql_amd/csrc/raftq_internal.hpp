@@ -45,7 +45,7 @@ struct raftq {
   size_t ingest_bytes = 0;
   bool ingest_in_device = false;
   bool bar_staging = false;     // decided at create: large BAR present and not disabled (RAFTQ_STAGE=host)
-  bool bar_probed = false;      // a host store into such memory has been tried (and survived) on this handle
+  bool bar_probed = false;      // such memory has been found mapped writable into this process (/proc/self/maps)
   // raftq_apply_log_deltas' host bookkeeping, kept across calls: per-group (epoch << 32 | records seen this call)
   std::vector<uint64_t> ld_mark, ld_start;
   std::vector<uint32_t> ld_round, ld_pos;
@@ -202,8 +202,9 @@ int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
 int use_device_idle(raftq_t* h, const char* who);  // + no Step batch in flight (RAFTQ_ESTATE otherwise)
 int ensure_staging(raftq_t* h, size_t bytes);   // pinned, device-mapped staging (term deltas, campaign lists, log deltas)
-bool host_can_write(void* p, size_t bytes);     // one guarded store into [p, p + bytes): false if it faults
+bool host_can_write(void* p, size_t bytes);     // [p, p + bytes) is mapped writable into this process (/proc/self/maps)
 int ensure_ingest(raftq_t* h, size_t bytes);    // the ack buffer of the batching turn: device memory behind a large BAR, else pinned
+unsigned host_coherence_flag();                 // hipHostMallocCoherent unless RAFTQ_HOST_COHERENT=0
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)
 void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations (called by raftq_destroy)

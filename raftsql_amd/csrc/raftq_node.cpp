@@ -966,7 +966,7 @@ struct Phase {  // accumulates wall time into n->prof[which] when RAFTQ_PROFILE 
 };
 }  // namespace
 
-int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
+static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> turn(n->turn_mu);
   Phase ph(n, raftq_node::kPhDecode);
@@ -1219,6 +1219,19 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
     dump_profile(n);
   }
   return RAFTQ_OK;
+}
+
+// One Ready-loop iteration for all groups.  The turn grows host vectors (work lists, queues, entry storage): an
+// allocation failure anywhere in it ends in the node's poisoned state and RAFTQ_ENOMEM, never in an exception crossing the
+// extern "C" boundary.
+int raftq_node_advance(raftq_node_t* n, uint64_t* n_published) {
+  try {
+    return node_advance_impl(n, n_published);
+  } catch (const std::bad_alloc&) {
+    return n ? poison(n, RAFTQ_ENOMEM, "advance (host allocation)") : RAFTQ_ENOMEM;
+  } catch (...) {
+    return n ? poison(n, RAFTQ_EHIP, "advance (unexpected exception)") : RAFTQ_EHIP;
+  }
 }
 
 int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, uint64_t* len) {

@@ -884,7 +884,12 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   {
     // records of one group apply in order: the k-th record of a group goes into launch k.  One counting sort on
     // the round number buckets the batch in O(n) whatever the skew; stable, so caller order within a round
-    std::vector<uint64_t> fill(round_start.begin(), round_start.end() - 1);
+    std::vector<uint64_t> fill;
+    try {  // a bad_alloc must not cross the extern "C" boundary
+      fill.assign(round_start.begin(), round_start.end() - 1);
+    } catch (...) {
+      return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
+    }
     for (uint64_t i = 0; i < n; ++i) {
       const uint64_t pos = fill[round[i]]++;
       pos_of[pos] = (uint32_t)i;

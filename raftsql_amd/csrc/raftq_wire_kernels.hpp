@@ -446,22 +446,82 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_payload_kernel(const W
 
 // ---- kernels: stream frames -> raftpb.Message headers ----------------------------------------------
 
+// The scalar fields of the frame a lane is parsing, in LDS: slot-major, one 8-byte column per lane (consecutive lanes,
+// consecutive banks -- a wave filing the same field is conflict-free, a wave filing different fields nearly so).
+struct LdsFile {
+  uint64_t* col;  // &file[0][tid]
+  __device__ __forceinline__ void put(uint32_t slot, uint64_t v) { col[slot * kBlock] = v; }
+  __device__ __forceinline__ uint64_t get(uint32_t slot) const { return col[slot * kBlock]; }
+};
+
+// A wave's 64 frames are one contiguous run of the stream: the wave copies it into LDS (16 bytes per lane per step)
+// and its lanes then read their frames from there -- ~64 cycles per dependent read instead of ~600 from L2.  Runs longer
+// than the wave's stage (frames with large payloads), frame offsets that are not monotonic (garbage input) and streams
+// that are not 16-byte aligned stay in global memory, per wave / per lane; the bytes are the same either way.
+constexpr uint32_t kStageBytes = 8192;  // per wave
+struct WaveStage {
+  const uint32_t* words = nullptr;  // the wave's LDS stage when the run [lo16, hi) was copied
+  uint64_t lo16 = 0, lo = 0, hi = 0;
+};
+__device__ __forceinline__ WaveStage stage_wave_frames(const uint8_t* stream, uint64_t nbytes, const uint64_t* off, uint64_t n,
+                                                       uint32_t* lds /* this wave's kStageBytes */) {
+  WaveStage st;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) & ~63ull;
+  if (i0 >= n || ((uintptr_t)stream & 15) != 0) return st;
+  const uint64_t i1 = i0 + 64 < n ? i0 + 64 : n;
+  const uint64_t lo = off[i0], hi = off[i1];
+  const uint64_t lo16 = lo & ~15ull;
+  if (!(lo <= hi && hi <= nbytes) || hi - lo16 + 16 > kStageBytes) return st;  // wave-uniform
+  const uint64_t full = (hi - lo16) >> 4;  // whole 16-byte chunks inside the buffer
+  for (uint64_t c = lane; c < full; c += 64) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stream + lo16 + (c << 4));
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(lds) + (c << 4)) = v;
+  }
+  const uint64_t tail0 = lo16 + (full << 4);  // < 16 bytes up to hi, byte by byte (the buffer may end at hi)
+  if (lane < hi - tail0) reinterpret_cast<uint8_t*>(lds)[(full << 4) + lane] = stream[tail0 + lane];
+  st.words = lds;
+  st.lo16 = lo16;
+  st.lo = lo;
+  st.hi = hi;
+  return st;
+}
+__device__ __forceinline__ ByteSrc frame_src(const WaveStage& st, const uint8_t* stream, uint64_t nbytes, uint64_t a, uint64_t b) {
+  ByteSrc src;
+  src.p = stream + a + 8;
+  src.safe = nbytes - a - 8;
+  src.words = nullptr;
+  src.shift = 0;
+  if (st.words && a >= st.lo && b <= st.hi) {  // this lane's frame lies inside the staged run
+    src.words = st.words;
+    src.shift = (uint32_t)(a + 8 - st.lo16);
+    src.safe = ~0ull;  // windows past the run's end read stale LDS bytes inside the wave's stage: never used (scope checks)
+  }
+  return src;
+}
+
 // pass 1: parse every frame, count its entries.  ent_cnt[n] = 0.
 // (Round 2's form of this kernel ran 4,400 instructions and 44 dependent loads per wave: 17 us for 64K frames without
-// entries, 45 us with 15 % MsgApp; raftq_wire_parse.hpp has what changed.  Staging each frame in an LDS row first had
-// changed nothing for that form: it was bound by its instruction count, not by where the bytes came from.)
+// entries, 45 us with 15 % MsgApp; raftq_wire_parse.hpp has what changed.)
 static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
                                                                  const uint64_t* __restrict__ off, uint64_t n,
                                                                  WireMsg* __restrict__ msgs,
                                                                  uint64_t* __restrict__ ent_cnt,
                                                                  unsigned long long* n_bad) {
+  __shared__ uint64_t file[kFileSlots * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
+  const WaveStage st = stage_wave_frames(stream, nbytes, off, n, stage[threadIdx.x >> 6]);
+  __syncthreads();
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool malformed = false;
   if (i < n) {
     const uint64_t a = off[i], b = off[i + 1];
     WireMsg m;
     bool ok = frame_body(stream, nbytes, a, b, true);
-    if (ok) ok = parse_msg<false>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, nullptr, 0, 0, 0);
+    if (ok) {
+      LdsFile f{file + threadIdx.x};
+      ok = parse_msg<false>(frame_src(st, stream, nbytes, a, b), b - a - 8, a + 8, f, m, nullptr, 0, 0, 0);
+    }
     if (!ok) {
       m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
       m.from = 0;
@@ -486,14 +546,19 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
                                                                       WireMsg* __restrict__ msgs,
                                                                       const uint64_t* __restrict__ ent_base,
                                                                       WireEnt* __restrict__ ents, uint64_t ents_cap) {
+  __shared__ uint64_t file[kFileSlots * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t first = ent_base[i];
-  const uint32_t cnt = (uint32_t)(ent_base[i + 1] - first);
+  const uint64_t first = i < n ? ent_base[i] : 0;
+  const uint32_t cnt = i < n ? (uint32_t)(ent_base[i + 1] - first) : 0u;
+  WaveStage st;
+  if (__ballot(cnt != 0) != 0) st = stage_wave_frames(stream, nbytes, off, n, stage[threadIdx.x >> 6]);  // wave-uniform
+  __syncthreads();
   if (cnt == 0) return;
   const uint64_t a = off[i], b = off[i + 1];
   WireMsg m;
-  (void)parse_msg<true>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, ents, first, ents_cap, cnt);
+  LdsFile f{file + threadIdx.x};
+  (void)parse_msg<true>(frame_src(st, stream, nbytes, a, b), b - a - 8, a + 8, f, m, ents, first, ents_cap, cnt);
   msgs[i].ent_first = (uint32_t)first;
 }
 

@@ -240,21 +240,68 @@ RAFTQ_HD inline uint32_t id_to_slot(uint64_t id, uint32_t none) {
 // index 0, term 0}), as one little-endian word
 constexpr uint64_t kEmptySnapshotBody = 0x00180010000a0612ull;
 
-// Message.Unmarshal over p[0, n) as one flat loop (see the head of this file).
-//   safe      bytes from p[0] on that may be touched by 8-byte loads (>= n; the enclosing buffer's end): a field whose
-//             8-byte window would cross it takes the byte-loop form
-//   base      offset of p[0] in the enclosing buffer (entry payload offsets are relative to that buffer)
+// Where a parse files the scalar fields it meets: slot fn for Message fields 1..12, slot 12 + fn for the fields 1..4 of
+// the Entry being walked.  One store per field instead of a chain of selects over a dozen live registers; last write wins,
+// as in the generated code.  On the device the slots are LDS words (LdsFile, raftq_wire_kernels.hpp: slot-major, one
+// column per lane, so a wave's lanes never share a bank); on the host an array.
+constexpr int kFileSlots = 17;
+struct ArrayFile {
+  uint64_t a[kFileSlots];
+  RAFTQ_HD void put(uint32_t slot, uint64_t v) { a[slot] = v; }
+  RAFTQ_HD uint64_t get(uint32_t slot) const { return a[slot]; }
+};
+
+// Where a parse reads its bytes: the frame in global memory, or -- when the kernel staged the wave's frames in LDS --
+// dword-aligned LDS words (three aligned reads and two byte-aligns make one unaligned 8-byte window).
+struct ByteSrc {
+  const uint8_t* p;        // the message in its buffer (always valid: the byte-loop forms read here)
+  uint64_t safe;           // 8-byte windows may start at offsets i with i + 8 <= safe
+#if defined(__HIPCC__)
+  const uint32_t* words;   // LDS copy, or nullptr
+  uint32_t shift;          // message byte k is LDS byte k + shift
+#endif
+  RAFTQ_HD uint64_t ld8(uint64_t i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (words) {
+      const uint32_t o = (uint32_t)i + shift;
+      const uint32_t* q = words + (o >> 2);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+      const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+      return ((uint64_t)hi << 32) | lo;
+    }
+#endif
+    return load_u64(p + i);
+  }
+};
+
+// the value of the varint in the low `len` bytes (1..7) of x
+RAFTQ_HD inline uint64_t varint_value(uint64_t x, uint32_t len) {
+  if (len <= 4) {  // up to 28 bits: the common case, in 32-bit arithmetic
+    uint32_t y = (uint32_t)x;
+    if (len < 4) y &= (1u << (8 * len)) - 1;
+    y &= 0x7f7f7f7fu;
+    y = ((y & 0x7f007f00u) >> 1) | (y & 0x007f007fu);
+    y = ((y & 0x3fff0000u) >> 2) | (y & 0x00003fffu);
+    return y;
+  }
+  return varint_compress(x, len);
+}
+
+// Message.Unmarshal over the n bytes of `src` as one flat loop (see the head of this file).
+//   base      offset of the message's first byte in the enclosing buffer (entry payload offsets are relative to that buffer)
+//   file      scratch for the scalar fields (see ArrayFile)
 //   EMIT      entry k of this message goes to ents[ent_base + k] when that is below ents_cap, and the walk stops
 //             after `stop_after` entries (the count a first pass found) -- what follows them was validated then
 // false = malformed.  m.n_ents counts the entries either way; m.ent_first is the caller's.
-template <bool EMIT>
-RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint64_t base, WireMsg& m, WireEnt* ents,
+template <bool EMIT, typename IX, typename File>
+RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File& file, WireMsg& m, WireEnt* ents,
                                uint64_t ent_base, uint64_t ents_cap, uint32_t stop_after) {
-  uint64_t group = 0, term = 0, log_term = 0, index = 0, commit = 0, reject_hint = 0;
-  uint32_t from = 0xffffffffu, type = 0, reject = 0, to = 0xff, flags = 0, n_ents = 0;
-  uint64_t e_term = 0, e_index = 0, e_off = 0;  // the Entry being walked
-  uint32_t e_len = 0, e_type = 0;
-  uint64_t i = 0, lim = n;  // lim: end of the current scope -- the message, or the Entry being walked
+  const uint8_t* p = src.p;
+  for (uint32_t s = 1; s <= 12; ++s) file.put(s, 0);  // absent fields read back as zero: type 0, to / from "none", ...
+  uint32_t flags = 0, n_ents = 0;
+  uint64_t e_off = 0;        // payload offset of the Entry being walked
+  IX i = 0, lim = n;         // lim: end of the current scope -- the message, or the Entry being walked.  IX: offsets inside
+                             // the message -- 32 bits wide for every message shorter than 2 GiB (half the address arithmetic)
   bool in_ent = false;
   bool ok = true;
   while (true) {
@@ -264,11 +311,11 @@ RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint
         const uint64_t slot = ent_base + n_ents;
         if (ents && slot < ents_cap) {
           WireEnt e;
-          e.term = e_term;
-          e.index = e_index;
-          e.data_off = e_len ? e_off : 0;
-          e.data_len = e_len;
-          e.type = e_type;
+          e.type = (uint32_t)file.get(13);
+          e.term = file.get(14);
+          e.index = file.get(15);
+          e.data_len = (uint32_t)file.get(16);
+          e.data_off = e.data_len ? e_off : 0;
           ents[slot] = e;
         }
       }
@@ -278,17 +325,16 @@ RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint
       if (EMIT && n_ents >= stop_after) break;
       continue;
     }
-    const uint64_t rem = lim - i;
+    const IX rem = lim - i;
     uint64_t v;
     uint32_t fn, wt;
     const uint32_t known = in_ent ? 4u : 12u;
-    bool fast = i + 8 <= safe;
-    uint64_t w = 0;
+    bool fast = (uint64_t)i + 8 <= src.safe;
     if (fast) {
-      w = load_u64(p + i);
+      const uint64_t w = src.ld8(i);
       const uint64_t vstop = ~w & 0x8080808080808000ull;  // terminators among the seven bytes behind the key byte
-      fn = (uint32_t)(w >> 3) & 0x1fu;                    // of a one-byte key (bit 7 clear: checked next)
-      fast = (w & 0x80u) == 0 && vstop != 0 && fn != 0 && fn <= known;
+      fn = ((uint32_t)w >> 3) & 0x1fu;                    // of a one-byte key (bit 7 clear: checked next)
+      fast = ((uint32_t)w & 0x80u) == 0 && vstop != 0 && fn != 0 && fn <= known;
       if (fast) {
         const uint32_t used = ffs64(vstop) >> 3;  // key + varint bytes, 2..8
         if (used > rem) {  // the varint runs over the end of its scope: io.ErrUnexpectedEOF
@@ -296,72 +342,61 @@ RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint
           break;
         }
         wt = (uint32_t)w & 7u;
-        v = varint_compress(w >> 8, used - 1);
+        v = varint_value(w >> 8, used - 1);
         i += used;
       }
     }
     if (!fast) {  // byte-loop forms, bounded by the scope: long keys, long varints, unknown fields, the buffer's tail
       Key k;
       uint64_t j = i;
-      if (!get_key(p, lim, j, k)) {
+      if (!get_key(p, (uint64_t)lim, j, k)) {
         ok = false;
         break;
       }
       if (k.fn > known) {
-        const uint64_t used = skip_value(p + j, lim - j, k.wt);
+        const uint64_t used = skip_value(p + j, (uint64_t)lim - j, k.wt);
         if (!used) {
           ok = false;
           break;
         }
-        i = j + used;
+        i = (IX)(j + used);
         continue;
       }
       fn = (uint32_t)k.fn;
       wt = k.wt;
-      const uint32_t used = get_varint(p + j, lim - j, &v);
+      const uint32_t used = get_varint(p + j, (uint64_t)lim - j, &v);
       if (!used) {
         ok = false;
         break;
       }
-      i = j + used;
+      i = (IX)(j + used);
     }
     // one known field (fn, wt, v); i is behind its varint
     const bool is_len = in_ent ? fn == 4 : (fn == 7 || fn == 9);
-    if (wt != (is_len ? 2u : 0u) || (is_len && v > lim - i)) {  // "wrong wireType" / io.ErrUnexpectedEOF
+    if (wt != (is_len ? 2u : 0u)) {  // "wrong wireType"
       ok = false;
       break;
     }
-    if (in_ent) {
-      if (fn == 4 && v > 0xffffffffull) {
+    file.put(fn + (in_ent ? 12u : 0u), v);
+    flags |= (!in_ent && fn == 12) ? kWireGroup : 0u;
+    if (is_len) {
+      if (v > (uint64_t)(lim - i) || (in_ent && v > 0xffffffffull)) {  // io.ErrUnexpectedEOF / a payload no Entry can hold
         ok = false;
         break;
       }
-      e_type = fn == 1 ? (uint32_t)v : e_type;
-      e_term = fn == 2 ? v : e_term;
-      e_index = fn == 3 ? v : e_index;
-      e_off = fn == 4 ? base + i : e_off;
-      e_len = fn == 4 ? (uint32_t)v : e_len;
-      i += fn == 4 ? v : 0;
-    } else {
-      type = fn == 1 ? ((uint32_t)v > 255 ? 255u : (uint32_t)v & 0xffu) : type;
-      to = fn == 2 ? id_to_slot(v, 0xff) : to;
-      from = fn == 3 ? id_to_slot(v, 0xffffffffu) : from;
-      term = fn == 4 ? v : term;
-      log_term = fn == 5 ? v : log_term;
-      index = fn == 6 ? v : index;
-      commit = fn == 8 ? v : commit;
-      reject = fn == 10 ? (v != 0 ? 1u : 0u) : reject;
-      reject_hint = fn == 11 ? v : reject_hint;
-      group = fn == 12 ? v : group;
-      flags |= fn == 12 ? kWireGroup : 0u;
-      if (fn == 7) {  // an Entry: a scope of this loop (an empty one is complete at once, on the next turn)
+      if (in_ent) {  // Entry.data
+        e_off = base + i;
+        i += (IX)v;
+      } else if (fn == 7) {  // an Entry: a scope of this loop (an empty one is complete at once, on the next turn)
         in_ent = true;
-        lim = i + v;
-        e_term = e_index = e_off = 0;
-        e_len = e_type = 0;
-      } else if (fn == 9) {
+        lim = i + (IX)v;
+        file.put(13, 0);
+        file.put(14, 0);
+        file.put(15, 0);
+        file.put(16, 0);
+      } else {  // the Snapshot
         int r = 0;
-        if (!(v == 8 && i + 8 <= safe && load_u64(p + i) == kEmptySnapshotBody)) {
+        if (!(v == 8 && (uint64_t)i + 8 <= src.safe && src.ld8(i) == kEmptySnapshotBody)) {
           r = snapshot_nonempty(p + i, v);
           if (r < 0) {
             ok = false;
@@ -369,24 +404,32 @@ RAFTQ_HD inline bool parse_msg(const uint8_t* p, uint64_t n, uint64_t safe, uint
           }
         }
         flags |= r ? kWireSnapshot : 0u;
-        i += v;
+        i += (IX)v;
       }
     }
   }
-  m.group = group;
-  m.term = term;
-  m.log_term = log_term;
-  m.index = index;
-  m.commit = commit;
-  m.reject_hint = reject_hint;
-  m.from = from;
-  m.type = (uint8_t)type;
-  m.reject = (uint8_t)reject;
-  m.to = (uint8_t)to;
+  const uint64_t type = file.get(1);
+  m.type = (uint32_t)type > 255 ? (uint8_t)255 : (uint8_t)type;
+  m.to = (uint8_t)id_to_slot(file.get(2), 0xff);
+  m.from = id_to_slot(file.get(3), 0xffffffffu);
+  m.term = file.get(4);
+  m.log_term = file.get(5);
+  m.index = file.get(6);
+  m.commit = file.get(8);
+  m.reject = file.get(10) != 0 ? 1 : 0;
+  m.reject_hint = file.get(11);
+  m.group = file.get(12);
   m.flags = (uint8_t)flags;
   m.ent_first = 0;
   m.n_ents = n_ents;
   return ok;
+}
+
+template <bool EMIT, typename File>
+RAFTQ_HD inline bool parse_msg(const ByteSrc& src, uint64_t n, uint64_t base, File& file, WireMsg& m, WireEnt* ents,
+                               uint64_t ent_base, uint64_t ents_cap, uint32_t stop_after) {
+  if (n < (1ull << 31)) return parse_msg_ix<EMIT, uint32_t>(src, (uint32_t)n, base, file, m, ents, ent_base, ents_cap, stop_after);
+  return parse_msg_ix<EMIT, uint64_t>(src, n, base, file, m, ents, ent_base, ents_cap, stop_after);
 }
 
 // ---- walpb.Record -----------------------------------------------------------------------------------

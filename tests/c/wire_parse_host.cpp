@@ -19,7 +19,9 @@ uint64_t host_wire_decode(const uint8_t* stream, uint64_t nbytes, const uint64_t
     const uint64_t a = off[i], b = off[i + 1];
     WireMsg m;
     bool ok = frame_body(stream, nbytes, a, b, true);
-    if (ok) ok = parse_msg<false>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, nullptr, 0, 0, 0);
+    ArrayFile file;
+    const ByteSrc src = {stream + a + 8, nbytes - a - 8};
+    if (ok) ok = parse_msg<false>(src, b - a - 8, a + 8, file, m, nullptr, 0, 0, 0);
     if (!ok) {
       memset(&m, 0, sizeof m);
       m.flags = kWireMalformed;
@@ -34,7 +36,9 @@ uint64_t host_wire_decode(const uint8_t* stream, uint64_t nbytes, const uint64_t
     if (cnt) {
       const uint64_t a = off[i], b = off[i + 1];
       WireMsg m;
-      (void)parse_msg<true>(stream + a + 8, b - a - 8, nbytes - a - 8, a + 8, m, ents, first, ents_cap, cnt);
+      ArrayFile file;
+      const ByteSrc src = {stream + a + 8, nbytes - a - 8};
+      (void)parse_msg<true>(src, b - a - 8, a + 8, file, m, ents, first, ents_cap, cnt);
       msgs[i].ent_first = (uint32_t)first;
     }
     first += cnt;

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# every batching turn of the test session cross-checks its completion flag: what the host reads when the flag lands must be
+# what it reads after a full stream synchronisation (raftq_capi.hip wait_turn; read once per process by the library)
+os.environ.setdefault("RAFTQ_CYCLE_CHECK", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 

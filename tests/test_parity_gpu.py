@@ -508,6 +508,42 @@ def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
         adv = e.last_advances()
         idx = np.nonzero(new_commit != ref_commit)[0]
         assert np.array_equal(adv["group"], idx.astype(np.uint64)) and np.array_equal(adv["new_commit"], new_commit[idx])
+        # a trusted turn with a bad VOTE record: that record is dropped on its own as well -- every other
+        # vote and every match delta is applied, the sweep is adopted, the outputs are filled, EINVAL says what happened
+        ref_commit = new_commit
+        dm4 = ref_commit[dg.astype(np.int64)] + rng.integers(1, 1000, 5000).astype(np.uint64)
+        v4 = e.pack_vote_deltas(rng.integers(0, G, 300).astype(np.uint64), rng.integers(0, n, 300).astype(np.uint32),
+                                rng.integers(1, 3, 300).astype(np.uint8))
+        v4["vote"][11], v4["peer"][12], v4["group"][13] = 7, n + 1, G
+        okv = ~np.isin(np.arange(300), [11, 12, 13])
+        with pytest.raises(RaftqError) as ei:
+            e.cycle(SWEEP_COMMIT | SWEEP_VOTES | CYCLE_TRUSTED, e.pack_deltas(dg, dp, dm4), v4)
+        assert ei.value.code == -1 and "was dropped, every other record" in str(ei.value)
+        ref_votes = oracle.apply_vote_deltas(ref_votes, v4["group"][okv].copy(), v4["peer"][okv].copy(), v4["vote"][okv].copy())
+        ref_match = oracle.apply_deltas(ref_match, dg, dp, dm4)
+        new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit)
+        assert np.array_equal(e.read_votes(), ref_votes) and np.array_equal(e.read_match(), ref_match)
+        assert np.array_equal(e.read_committed(), new_commit) and np.array_equal(e.read_outcome(), oracle.vote_tally(ref_votes)[0])
+        adv = e.last_advances()
+        idx = np.nonzero(new_commit != ref_commit)[0]
+        assert np.array_equal(adv["group"], idx.astype(np.uint64)) and np.array_equal(adv["new_commit"], new_commit[idx])
+        # arrays handed in from the ack buffer must have been staged for THIS call's counts and layout:
+        # another count moves the vote array, the other layout moves everything -- refused, nothing applied
+        sd, sv = e.stage(100, 50)
+        sd[:], sv[:] = e.pack_deltas(dg[:100], dp[:100], dm4[:100]), v4[20:70]
+        before = (e.read_match(), e.read_votes(), e.read_committed())
+        with pytest.raises(RaftqError) as ei:
+            e.cycle(SWEEP_COMMIT, sd[:40], sv)  # 40 match records: the votes were staged behind 100
+        assert ei.value.code == -1 and "staged with other counts" in str(ei.value)
+        with pytest.raises(RaftqError) as ei:
+            e.cycle_packed(SWEEP_COMMIT, sd[:40].view(e._DELTA16_DT)[:40], sv)
+        assert ei.value.code == -1
+        with pytest.raises(RaftqError) as ei:
+            big = np.frombuffer((np.ctypeslib.as_ctypes_type(np.uint8) * (24 * 200000)).from_address(sd.ctypes.data), dtype=e._DELTA_DT)
+            e.cycle(SWEEP_COMMIT, big, None)  # more records than the staged buffer was sized for
+        assert ei.value.code == -1 and "sized for fewer records" in str(ei.value)
+        after = (e.read_match(), e.read_votes(), e.read_committed())
+        assert all(np.array_equal(a, b) for a, b in zip(before, after))
         # and a clean trusted turn in the packed layout equals the oracle
         ref_commit = new_commit
         dm3 = ref_commit[dg.astype(np.int64)] + rng.integers(1, 1000, 5000).astype(np.uint64)

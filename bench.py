@@ -46,6 +46,20 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
 HBM_COPY_CEILING_GBPS = 6290.0
+PCIE_PEAK_GBPS = 63.0  # PCIe Gen5 x16, one direction
+
+
+def leg_roofline(bound, unit_name, units, seconds, bytes_in=0.0, bytes_out=0.0, note=""):
+    """The roofline object of a side leg, judged the way the headline is.  `bound`: what limits the
+    leg -- "pcie" (achieved = the busier direction's bytes / time against one direction's 63 GB/s), "hbm" (read + write
+    bytes / time against 8 TB/s) or "launch" (a chain of dependent launches: the bytes are given for the record, the
+    fraction is of the limit named in `vs`).  bytes_in / bytes_out are per `units` processed in `seconds`."""
+    if bound == "hbm":
+        achieved, peak = (bytes_in + bytes_out) / seconds / 1e9, HBM_PEAK_GBPS
+    else:
+        achieved, peak = max(bytes_in, bytes_out) / seconds / 1e9, PCIE_PEAK_GBPS
+    return {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "bytes_per_" + unit_name: {"in": bytes_in / units, "out": bytes_out / units}, "note": note}
 
 CONFIGS = {
     # BASELINE.json configs[i-1]; G is per GPU
@@ -302,10 +316,15 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
         "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
         "decisions_per_s": G * cycles / t_total,
         "us_per_cycle_copying_form": t_copy / cycles * 1e6,
+        "roofline": leg_roofline("pcie", "turn", cycles, t_total, 24.0 * nd * cycles, 24.0 * adv_total,
+                                 "acks in (the producer's stores, before the call) and advances out cross the link once each; "
+                                 "a turn is four dependent launches and one wait -- latency, not the link, is what it is made of"),
         "packed_records": {"what": "raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED: 16-byte deltas in (validated and scattered "
                                    "in one pass), 16-byte advances out, zero-copy staging",
                            "us_per_cycle": t_packed / cycles * 1e6, "deltas_per_s": nd * cycles / t_packed,
-                           "decisions_per_s": G * cycles / t_packed, "advanced_per_cycle": adv_packed / cycles},
+                           "decisions_per_s": G * cycles / t_packed, "advanced_per_cycle": adv_packed / cycles,
+                           "roofline": leg_roofline("pcie", "turn", cycles, t_packed, 16.0 * nd * cycles, 16.0 * adv_packed,
+                                                    "as above with the 16-byte records")},
     }
 
 
@@ -330,6 +349,9 @@ def tick_measure(cfg, device, ticks=2000):
     us = ms * 1e3 / ticks
     return {"what": "batched Tick (tickElection/tickHeartbeat) over all groups", "groups": G, "launch_us": us,
             "group_ticks_per_s": G / (us * 1e-6), "GBps": 10.0 * G / (us * 1e-6) / 1e9,
+            "roofline": leg_roofline("hbm", "group", G, us * 1e-6, 5.0 * G, 5.0 * G,
+                                     "role 1 + elapsed 4 in, elapsed 4 + action 1 out per group; 10 MB per launch is cache-resident "
+                                     "and the launch boundary is a third of the time: launch-bound at this size"),
             "last_tick": {"n_hup": hup, "n_beat": beat}}
 
 
@@ -467,6 +489,17 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                                      "vs 40-byte packed ones (raftq_step_submit_packed); bound by that host copy",
                              "us_per_batch_64B": produced[False] * 1e6, "msgs_per_s_64B": msgs_per_batch / produced[False],
                              "us_per_batch_40B": produced[True] * 1e6, "msgs_per_s_40B": msgs_per_batch / produced[True]}}}
+    M = msgs_per_batch
+    out["roofline"] = leg_roofline("pcie", "message", M * nb, dt, 64.0 * M * nb, 64.0 * M * nb,
+                                   "synchronous call: 64-byte records in (the producer's stores, before the call), 64-byte results out")
+    out["pipelined"]["roofline"] = leg_roofline("pcie", "message", M * reps, dt_pipe_staged, 0.0, 64.0 * M * reps,
+                                                "staged batches resubmitted (nothing crosses inbound), 64-byte results out")
+    out["pipelined"]["compact_results"]["roofline"] = leg_roofline(
+        "pcie", "message", M * reps, dt_pipe_compact, 0.0, 40.0 * M * reps, "staged batches resubmitted, 40-byte results out")
+    out["pipelined"]["producer_included"]["roofline_64B"] = leg_roofline(
+        "pcie", "message", M, produced[False], 64.0 * M, 40.0 * M, "every batch written into device staging by one host thread, 40-byte results out")
+    out["pipelined"]["producer_included"]["roofline_40B"] = leg_roofline(
+        "pcie", "message", M, produced[True], 40.0 * M, 40.0 * M, "40-byte packed records in, 40-byte results out")
     e.close()
     if with_cpu:
         from oracle import pyoracle  # cpu_baseline leg: the sequential restatement, one thread
@@ -557,6 +590,11 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                         "decode_us": t_dec_p * 1e6, "decode_msgs_per_s": n / t_dec_p,
                                         "bytes_over_pcie_encode": int(pm.nbytes + pe.nbytes + pp.nbytes + len(stream) + poff.nbytes),
                                         "bytes_over_pcie_decode": int(len(stream) + poff.nbytes + pmsgs.nbytes + len(ents) * 32)}}
+    mf = out["message_frames"]["pinned"]
+    enc_in, enc_out = float(pm.nbytes + pe.nbytes + pp.nbytes), float(len(stream) + poff.nbytes)
+    dec_in, dec_out = float(len(stream) + poff.nbytes), float(pmsgs.nbytes + len(ents) * 32)
+    mf["roofline_encode"] = leg_roofline("pcie", "message", n, t_enc_p, enc_in, enc_out, "records + payload pool in, frames + offsets out; page-locked buffers, one call")
+    mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out")
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)
@@ -613,6 +651,11 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                                                    "wrote them, no inbound DMA",
                                                            "us_per_batch": dt_s * 1e6, "msgs_per_s": n / dt_s,
                                                            "us_per_batch_compact": dt_sc * 1e6, "msgs_per_s_compact": n / dt_sc}}
+    sf = out["step_from_frames"]
+    sf["roofline"] = leg_roofline("pcie", "message", n, dt, float(len(s2) + off2.nbytes), 64.0 * n, "frames copied in (DMA), 64-byte results out")
+    sf["compact_results"]["roofline"] = leg_roofline("pcie", "message", n, dt_c, float(len(s2) + off2.nbytes), 40.0 * n, "frames copied in, 40-byte results out")
+    sf["staged_in_device_memory"]["roofline"] = leg_roofline("pcie", "message", n, dt_s, 0.0, 64.0 * n, "frames resubmitted where they lie, 64-byte results out")
+    sf["staged_in_device_memory"]["roofline_compact"] = leg_roofline("pcie", "message", n, dt_sc, 0.0, 40.0 * n, "frames resubmitted where they lie, 40-byte results out")
     # WAL: one Save's worth per group -- an entry (~80 B payload) and a HardState, interleaved
     r = np.zeros(n, W.WAL_REC_DT)
     r["kind"] = np.where(np.arange(n) % 2 == 0, W.WAL_ENTRY, W.WAL_STATE)
@@ -638,6 +681,9 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                          "pinned": {"encode_us": t_wenc_p * 1e6, "encode_recs_per_s": n / t_wenc_p,
                                     "decode_us": t_wdec_p * 1e6, "decode_recs_per_s": n / t_wdec_p,
                                     "decode_GBps": len(wal) / t_wdec_p / 1e9}}
+    wp = out["wal_frames"]["pinned"]
+    wp["roofline_encode"] = leg_roofline("pcie", "record", n, t_wenc_p, float(pr.nbytes + pwp.nbytes), float(len(wal) + poff.nbytes), "records + payload pool in, WAL bytes + offsets out")
+    wp["roofline_decode"] = leg_roofline("pcie", "record", n, t_wdec_p, float(len(wal) + poff.nbytes), float(precs.nbytes), "WAL bytes + offsets in, 48-byte records out")
     e.close()
     if with_cpu:
         from oracle import pywire as O  # cpu_baseline leg: the per-message loop of the codec oracle, one thread
@@ -982,6 +1028,7 @@ def main():
             "kernel": "raftqk::sweep_kernel", "launch_us": us1, "launches_per_step": n_batches,
             "decisions_per_s": groups_per_gpu * k / w1, "GBps": batch_bytes / (us1 * 1e-6) / 1e9,
             "read_GBps": rd * cfg["G"] / (us1 * 1e-6) / 1e9, "frac": batch_bytes / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "frac_read_of_peak": rd * cfg["G"] / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS,  # north_star's literal shape: one 1M x 5 launch
             "kernel_time_over_wall": e1[0] * 1e-3 / w1,
         }
         # (b) the other launch shape of the set

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraftq.so")
+# RAFTQ_LIB: another build of the same library (the sanitizer builds of raftsql_amd/build.py: libraftq_asan.so, libraftq_tsan.so)
+LIB_PATH = os.environ.get("RAFTQ_LIB") or os.path.join(_HERE, "libraftq.so")
 
 RAFTQ_OK = 0
 RAFTQ_EINVAL, RAFTQ_ENOMEM, RAFTQ_EHIP, RAFTQ_ESTATE, RAFTQ_ENODEV = -1, -2, -3, -4, -5

@@ -92,6 +92,45 @@ def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = 
     return LIB
 
 
+SANITIZERS = {"asan": "address", "ubsan": "undefined", "tsan": "thread"}
+
+
+def build_sanitized(kind: str, verbose: bool = False) -> str:
+    """libraftq_<kind>.so: the HOST side of every translation unit under AddressSanitizer + UBSan ("asan") or
+    ThreadSanitizer ("tsan") -- raftq_pipe.cpp / raftq_node.cpp (mutexes, condition variables, a background thread) and the
+    host halves of the .hip units; the device code is compiled as always (-fno-gpu-sanitize).  Loaded instead of the
+    product library with RAFTQ_LIB=<path> and the matching clang runtime preloaded (tools/sanitize_r03.sh)."""
+    san = SANITIZERS[kind]
+    out = os.path.join(PKG, f"libraftq_{kind}.so")
+    objdir = os.path.join(PKG, "build", kind)
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-fPIC", "-fno-omit-frame-pointer", f"-fsanitize={san}",
+             "-fno-gpu-sanitize", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    procs, objs = [], []
+    for src in lib_sources()[:N_UNITS]:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-fsanitize={san}", "-shared-libsan", "-o", out] + objs)
+    return out
+
+
+def sanitizer_runtime(kind: str) -> str:
+    """The clang runtime to LD_PRELOAD for a sanitized build (it must come first in the process)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+    name = {"asan": "libclang_rt.asan-x86_64.so", "tsan": "libclang_rt.tsan-x86_64.so",
+            "ubsan": "libclang_rt.ubsan_standalone-x86_64.so"}[kind]
+    return subprocess.run([clang, "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+
+
 def build_tuner(force: bool = False) -> str | None:
     src = os.path.join(CSRC, "raftq_tune.hip")
     if not os.path.exists(src):

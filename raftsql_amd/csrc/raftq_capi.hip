@@ -1392,7 +1392,7 @@ int raftq_set_create(raftq_t* const* handles, uint32_t n, raftq_set_t** out) {
   }
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
-  s->persist_wgs = (uint32_t)std::max(cus, 1) * 3u;  // 3 resident 256-thread workgroups per CU (161 VGPRs)
+  s->persist_wgs = (uint32_t)std::max(cus, 1) * 3u;  // 3 resident 256-thread workgroups per CU (144 VGPRs: profiles/r03/isa_sweep.txt)
   if (const char* w = std::getenv("RAFTQ_SET_PERSIST_WGS")) s->persist_wgs = (uint32_t)std::max(1, std::atoi(w));
   *out = s;
   return RAFTQ_OK;

@@ -463,14 +463,20 @@ struct WaveStage {
   const uint32_t* words = nullptr;  // the wave's LDS stage when the run [lo16, hi) was copied
   uint64_t lo16 = 0, lo = 0, hi = 0;
 };
-__device__ __forceinline__ WaveStage stage_wave_frames(const uint8_t* stream, uint64_t nbytes, const uint64_t* off, uint64_t n,
+// a, b: this lane's frame extent (off[i], off[i + 1]; 0, 0 for lanes past the batch) -- the wave's run is read off its
+// first and last lane's extents, so staging costs no load of its own in front of the stream's
+__device__ __forceinline__ uint64_t wave_bcast_u64(uint64_t x, int lane) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, lane), hi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ WaveStage stage_wave_frames(const uint8_t* stream, uint64_t nbytes, uint64_t a, uint64_t b, bool live,
                                                        uint32_t* lds /* this wave's kStageBytes */) {
   WaveStage st;
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) & ~63ull;
-  if (i0 >= n || ((uintptr_t)stream & 15) != 0) return st;
-  const uint64_t i1 = i0 + 64 < n ? i0 + 64 : n;
-  const uint64_t lo = off[i0], hi = off[i1];
+  const uint64_t alive = __ballot(live);
+  if (alive == 0 || ((uintptr_t)stream & 15) != 0) return st;
+  const uint64_t lo = wave_bcast_u64(a, 0);  // lane 0 is live whenever any lane is (lanes fill from the front)
+  const uint64_t hi = wave_bcast_u64(b, 63 - __builtin_clzll(alive));
   const uint64_t lo16 = lo & ~15ull;
   if (!(lo <= hi && hi <= nbytes) || hi - lo16 + 16 > kStageBytes) return st;  // wave-uniform
   const uint64_t full = (hi - lo16) >> 4;  // whole 16-byte chunks inside the buffer
@@ -499,6 +505,21 @@ __device__ __forceinline__ ByteSrc frame_src(const WaveStage& st, const uint8_t*
   }
   return src;
 }
+// frame_body() with the length word taken from the staged copy when the frame lies in it
+__device__ __forceinline__ bool frame_body_staged(const ByteSrc& src, const uint8_t* stream, uint64_t nbytes, uint64_t a, uint64_t b,
+                                                  bool big_endian) {
+  if (!(a <= b && b <= nbytes && b - a >= 8)) return false;
+  uint64_t w;
+  if (src.words) {
+    ByteSrc head = src;
+    head.shift = src.shift - 8;
+    w = head.ld8(0);
+  } else {
+    w = load_u64(stream + a);
+  }
+  if (big_endian) w = __builtin_bswap64(w);
+  return w == b - a - 8;
+}
 
 // pass 1: parse every frame, count its entries.  ent_cnt[n] = 0.
 // (Round 2's form of this kernel ran 4,400 instructions and 44 dependent loads per wave: 17 us for 64K frames without
@@ -510,17 +531,18 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_kernel(const uint8_t* 
                                                                  unsigned long long* n_bad) {
   __shared__ uint64_t file[kFileSlots * kBlock];
   __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
-  const WaveStage st = stage_wave_frames(stream, nbytes, off, n, stage[threadIdx.x >> 6]);
-  __syncthreads();
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t a = i < n ? off[i] : 0, b = i < n ? off[i + 1] : 0;
+  const WaveStage st = stage_wave_frames(stream, nbytes, a, b, i < n, stage[threadIdx.x >> 6]);
+  __syncthreads();
   bool malformed = false;
   if (i < n) {
-    const uint64_t a = off[i], b = off[i + 1];
     WireMsg m;
-    bool ok = frame_body(stream, nbytes, a, b, true);
+    const ByteSrc src = frame_src(st, stream, nbytes, a, b);
+    bool ok = frame_body_staged(src, stream, nbytes, a, b, true);
     if (ok) {
       LdsFile f{file + threadIdx.x};
-      ok = parse_msg<false>(frame_src(st, stream, nbytes, a, b), b - a - 8, a + 8, f, m, nullptr, 0, 0, 0);
+      ok = parse_msg<false>(src, b - a - 8, a + 8, f, m, nullptr, 0, 0, 0);
     }
     if (!ok) {
       m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
@@ -551,11 +573,11 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t first = i < n ? ent_base[i] : 0;
   const uint32_t cnt = i < n ? (uint32_t)(ent_base[i + 1] - first) : 0u;
+  const uint64_t a = i < n ? off[i] : 0, b = i < n ? off[i + 1] : 0;
   WaveStage st;
-  if (__ballot(cnt != 0) != 0) st = stage_wave_frames(stream, nbytes, off, n, stage[threadIdx.x >> 6]);  // wave-uniform
+  if (__ballot(cnt != 0) != 0) st = stage_wave_frames(stream, nbytes, a, b, i < n, stage[threadIdx.x >> 6]);  // wave-uniform
   __syncthreads();
   if (cnt == 0) return;
-  const uint64_t a = off[i], b = off[i + 1];
   WireMsg m;
   LdsFile f{file + threadIdx.x};
   (void)parse_msg<true>(frame_src(st, stream, nbytes, a, b), b - a - 8, a + 8, f, m, ents, first, ents_cap, cnt);

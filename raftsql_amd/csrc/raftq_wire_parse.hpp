@@ -295,7 +295,7 @@ RAFTQ_HD inline uint64_t varint_value(uint64_t x, uint32_t len) {
 // false = malformed.  m.n_ents counts the entries either way; m.ent_first is the caller's.
 template <bool EMIT, typename IX, typename File>
 RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File& file, WireMsg& m, WireEnt* ents,
-                               uint64_t ent_base, uint64_t ents_cap, uint32_t stop_after) {
+                                  uint64_t ent_base, uint64_t ents_cap, uint32_t stop_after) {
   const uint8_t* p = src.p;
   for (uint32_t s = 1; s <= 12; ++s) file.put(s, 0);  // absent fields read back as zero: type 0, to / from "none", ...
   uint32_t flags = 0, n_ents = 0;
@@ -303,8 +303,12 @@ RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File&
   IX i = 0, lim = n;         // lim: end of the current scope -- the message, or the Entry being walked.  IX: offsets inside
                              // the message -- 32 bits wide for every message shorter than 2 GiB (half the address arithmetic)
   bool in_ent = false;
-  bool ok = true;
-  while (true) {
+  bool bad = false;          // malformed: the one way out of the loop besides its end (a lane-divergent `break` per check
+                             // costs the wave a mask save / restore each; one sticky flag tested at the top costs one)
+  // (A third form -- one straight line for "known one-byte-key varint field" and a single cold block with the byte-loop
+  // forms for everything else, Entry and Snapshot fields included -- compiled to MORE instructions and ran mixed traffic at
+  // 28 us instead of 21: every Entry field then pays the generic key + varint decode.  Not kept.)
+  while (!bad) {
     if (i >= lim) {  // a scope ends exactly where its last field does (every step below is bounded by lim)
       if (!in_ent) break;
       if (EMIT) {
@@ -326,65 +330,48 @@ RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File&
       continue;
     }
     const IX rem = lim - i;
-    uint64_t v;
-    uint32_t fn, wt;
     const uint32_t known = in_ent ? 4u : 12u;
-    bool fast = (uint64_t)i + 8 <= src.safe;
+    // the one-load form: key byte + value varint out of one 8-byte window
+    const bool have = (uint64_t)i + 8 <= src.safe;
+    const uint64_t w = have ? src.ld8(i) : 0x80ull;  // (a window that cannot be read looks like a long key: byte-loop form)
+    const uint64_t vstop = ~w & 0x8080808080808000ull;  // terminators among the seven bytes behind the key byte
+    uint32_t fn = ((uint32_t)w >> 3) & 0x1fu;             // of a one-byte key (bit 7 clear: checked next)
+    uint32_t wt = (uint32_t)w & 7u;
+    const uint32_t used = vstop ? ffs64(vstop) >> 3 : 9u;  // key + varint bytes, 2..8
+    uint64_t v = varint_value(w >> 8, (used - 1) & 7u);
+    const bool fast = ((uint32_t)w & 0x80u) == 0 && vstop != 0 && fn != 0 && fn <= known;
     if (fast) {
-      const uint64_t w = src.ld8(i);
-      const uint64_t vstop = ~w & 0x8080808080808000ull;  // terminators among the seven bytes behind the key byte
-      fn = ((uint32_t)w >> 3) & 0x1fu;                    // of a one-byte key (bit 7 clear: checked next)
-      fast = ((uint32_t)w & 0x80u) == 0 && vstop != 0 && fn != 0 && fn <= known;
-      if (fast) {
-        const uint32_t used = ffs64(vstop) >> 3;  // key + varint bytes, 2..8
-        if (used > rem) {  // the varint runs over the end of its scope: io.ErrUnexpectedEOF
-          ok = false;
-          break;
-        }
-        wt = (uint32_t)w & 7u;
-        v = varint_value(w >> 8, used - 1);
-        i += used;
-      }
-    }
-    if (!fast) {  // byte-loop forms, bounded by the scope: long keys, long varints, unknown fields, the buffer's tail
+      bad = used > rem;  // the varint runs over the end of its scope: io.ErrUnexpectedEOF
+      i += (IX)used;
+    } else {  // byte-loop forms, bounded by the scope: long keys, long varints, unknown fields, the buffer's tail
       Key k;
       uint64_t j = i;
+      bool skip = false;
       if (!get_key(p, (uint64_t)lim, j, k)) {
-        ok = false;
-        break;
+        bad = true;
+      } else if (k.fn > known) {
+        const uint64_t u = skip_value(p + j, (uint64_t)lim - j, k.wt);
+        bad = u == 0;
+        i = (IX)(j + u);
+        skip = true;
+      } else {
+        fn = (uint32_t)k.fn;
+        wt = k.wt;
+        const uint32_t u = get_varint(p + j, (uint64_t)lim - j, &v);
+        bad = u == 0;
+        i = (IX)(j + u);
       }
-      if (k.fn > known) {
-        const uint64_t used = skip_value(p + j, (uint64_t)lim - j, k.wt);
-        if (!used) {
-          ok = false;
-          break;
-        }
-        i = (IX)(j + used);
-        continue;
-      }
-      fn = (uint32_t)k.fn;
-      wt = k.wt;
-      const uint32_t used = get_varint(p + j, (uint64_t)lim - j, &v);
-      if (!used) {
-        ok = false;
-        break;
-      }
-      i = (IX)(j + used);
+      if (bad || skip) continue;
     }
     // one known field (fn, wt, v); i is behind its varint
     const bool is_len = in_ent ? fn == 4 : (fn == 7 || fn == 9);
-    if (wt != (is_len ? 2u : 0u)) {  // "wrong wireType"
-      ok = false;
-      break;
-    }
+    bad |= wt != (is_len ? 2u : 0u);  // "wrong wireType"
     file.put(fn + (in_ent ? 12u : 0u), v);
     flags |= (!in_ent && fn == 12) ? kWireGroup : 0u;
-    if (is_len) {
+    if (is_len && !bad) {
       if (v > (uint64_t)(lim - i) || (in_ent && v > 0xffffffffull)) {  // io.ErrUnexpectedEOF / a payload no Entry can hold
-        ok = false;
-        break;
-      }
-      if (in_ent) {  // Entry.data
+        bad = true;
+      } else if (in_ent) {  // Entry.data
         e_off = base + i;
         i += (IX)v;
       } else if (fn == 7) {  // an Entry: a scope of this loop (an empty one is complete at once, on the next turn)
@@ -396,14 +383,9 @@ RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File&
         file.put(16, 0);
       } else {  // the Snapshot
         int r = 0;
-        if (!(v == 8 && (uint64_t)i + 8 <= src.safe && src.ld8(i) == kEmptySnapshotBody)) {
-          r = snapshot_nonempty(p + i, v);
-          if (r < 0) {
-            ok = false;
-            break;
-          }
-        }
-        flags |= r ? kWireSnapshot : 0u;
+        if (!(v == 8 && (uint64_t)i + 8 <= src.safe && src.ld8(i) == kEmptySnapshotBody)) r = snapshot_nonempty(p + i, v);
+        bad = r < 0;
+        flags |= r > 0 ? kWireSnapshot : 0u;
         i += (IX)v;
       }
     }
@@ -422,7 +404,7 @@ RAFTQ_HD inline bool parse_msg_ix(const ByteSrc& src, IX n, uint64_t base, File&
   m.flags = (uint8_t)flags;
   m.ent_first = 0;
   m.n_ents = n_ents;
-  return ok;
+  return !bad;
 }
 
 template <bool EMIT, typename File>

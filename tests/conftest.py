@@ -38,3 +38,15 @@ def gpu_engine_cls():
 
     assert device_count() >= 1, "libraftq.so sees no HIP device"
     return QuorumEngine
+
+
+@pytest.fixture(params=["device", "host"], ids=["stage-in-device-memory", "stage-in-host-memory"])
+def stage_mode(request, monkeypatch):
+    """Where the handles a test creates put their ack / inbound staging buffers (read by raftq_create): fine-grained
+    device memory behind the large BAR (the default on the MI355X box) or pinned host memory (RAFTQ_STAGE=host: every
+    machine without a host-addressable aperture).  Both forms are part of the suite the driver runs."""
+    if request.param == "host":
+        monkeypatch.setenv("RAFTQ_STAGE", "host")
+    else:
+        monkeypatch.delenv("RAFTQ_STAGE", raising=False)
+    return request.param

@@ -76,6 +76,16 @@ def test_bench_extras_and_other_configs(gpu_engine_cls):
         assert d["other_configs"][c]["frac"] > 0.3, d["other_configs"][c]
     for leg in ("pipeline", "tick", "step", "wire", "node"):
         assert "error" not in d[leg], d[leg]
+    # every side leg carries a roofline object of the headline's shape
+    legs = [d["pipeline"]["roofline"], d["pipeline"]["packed_records"]["roofline"], d["tick"]["roofline"], d["step"]["roofline"],
+            d["step"]["pipelined"]["roofline"], d["step"]["pipelined"]["compact_results"]["roofline"],
+            d["step"]["pipelined"]["producer_included"]["roofline_40B"], d["wire"]["message_frames"]["pinned"]["roofline_decode"],
+            d["wire"]["step_from_frames"]["staged_in_device_memory"]["roofline_compact"],
+            d["wire"]["wal_frames"]["pinned"]["roofline_encode"]]
+    for r in legs:
+        assert r["bound"] in ("pcie", "hbm") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert 0.0 < r["frac"] < 1.0, r
+    assert 0.3 < d["single_launch"]["frac_read_of_peak"] < 1.0
 
 
 def test_bench_gated_config_as_headline(gpu_engine_cls):

@@ -248,6 +248,7 @@ def test_error_behaviour(gpu_engine_cls):
         gpu_engine_cls(1000, 3, device=99)
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_deltas_and_changed_list(gpu_engine_cls, oracle):
     """sparse MsgAppResp ingest -> sweep -> compacted advance list."""
     rng = np.random.default_rng(7)
@@ -281,6 +282,7 @@ def test_deltas_and_changed_list(gpu_engine_cls, oracle):
             assert total2 == n_ref and np.array_equal(adv2["group"], idx[:3].astype(np.uint64))
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_vote_deltas_first_response_wins(gpu_engine_cls, oracle):
     rng = np.random.default_rng(11)
     n, G = 5, 30011
@@ -302,6 +304,7 @@ def test_vote_deltas_first_response_wins(gpu_engine_cls, oracle):
             assert np.array_equal(out, oc) and (cnt.n_won, cnt.n_lost) == (w, l)
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_cycle_pipeline_matches_oracle(gpu_engine_cls, oracle):
     """raftq_cycle = one turn of the batching goroutine: MsgAppResp + MsgVoteResp deltas in,
     one fused sweep, compacted Ready-style advance list out; several turns in a row."""
@@ -358,6 +361,7 @@ def test_cycle_pipeline_matches_oracle(gpu_engine_cls, oracle):
         assert total == n_ch and len(adv) == 7 and np.array_equal(adv["group"], idx[:7].astype(np.uint64))
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_cycle_zero_copy_staging(gpu_engine_cls, oracle):
     """raftq_stage + in-place advance list give the same answers as the copying form."""
     rng = np.random.default_rng(31)
@@ -397,6 +401,7 @@ def test_cycle_zero_copy_staging(gpu_engine_cls, oracle):
         assert np.array_equal(e.read_match(), ref_match)
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_cycle_packed_records_equal_the_24_byte_form(gpu_engine_cls, oracle):
     """raftq_cycle_packed (16-byte deltas in, 16-byte advances out) is raftq_cycle with fewer bytes on the bus:
     two handles fed the same traffic in the two layouts agree on every word, turn by turn, and with the oracle."""
@@ -445,6 +450,7 @@ def test_cycle_packed_records_equal_the_24_byte_form(gpu_engine_cls, oracle):
         assert adv["new_commit"][0] == ref_commit[0] + np.uint64(1 << 33)
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
     """One bad record of EITHER kind and the turn applies nothing of either kind, adopts nothing and says so
     (a bad vote batch used to let the match deltas through and the sweep's advances were adopted but
@@ -536,7 +542,8 @@ def test_cycle_is_all_or_nothing_across_both_kinds(gpu_engine_cls, oracle):
             e.cycle(SWEEP_COMMIT, sd[:40], sv)  # 40 match records: the votes were staged behind 100
         assert ei.value.code == -1 and "staged with other counts" in str(ei.value)
         with pytest.raises(RaftqError) as ei:
-            e.cycle_packed(SWEEP_COMMIT, sd[:40].view(e._DELTA16_DT)[:40], sv)
+            as16 = np.frombuffer((np.ctypeslib.as_ctypes_type(np.uint8) * (16 * 40)).from_address(sd.ctypes.data), dtype=e._DELTA16_DT)
+            e.cycle_packed(SWEEP_COMMIT, as16, sv)  # the same bytes as 16-byte records: the vote array moves again
         assert ei.value.code == -1
         with pytest.raises(RaftqError) as ei:
             big = np.frombuffer((np.ctypeslib.as_ctypes_type(np.uint8) * (24 * 200000)).from_address(sd.ctypes.data), dtype=e._DELTA_DT)

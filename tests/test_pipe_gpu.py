@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("stage_mode")]  # every test, both staging forms
 
 
 @pytest.fixture()

@@ -10,7 +10,7 @@ import pytest
 from raftsql_amd import _lib
 from tests import _stepgen
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("stage_mode")]  # every test, both staging forms
 
 
 @pytest.fixture(scope="module")

@@ -296,6 +296,7 @@ def _step_traffic(rng, n, n_groups, n_peers):
     return m
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_step_from_wire_equals_step_from_records():
     from raftsql_amd import step as S
     from raftsql_amd.engine import RaftqError
@@ -542,6 +543,7 @@ def test_golden_fixtures(eng):
         assert last == c["crc"], c
 
 
+@pytest.mark.usefixtures("stage_mode")
 def test_step_from_frames_staged_in_place():
     """raftq_step_stage_wire: the frames are written straight into the arrays the library hands out (device memory behind
     a large BAR) and decoded where they lie -- same results as the copying form and as Step from the decoded records,

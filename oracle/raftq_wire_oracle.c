@@ -112,7 +112,7 @@ static void put(buf_t* b, const void* src, size_t k) {
     b->n += k; /* keep counting: the caller learns the size it needs */
     return;
   }
-  memcpy(b->p + b->n, src, k);
+  if (k) memcpy(b->p + b->n, src, k); /* (k == 0 may come with src == NULL: an empty payload out of an empty pool) */
   b->n += k;
 }
 static void put_byte(buf_t* b, uint8_t v) { put(b, &v, 1); }

@@ -30,11 +30,17 @@ def oracle():
 @pytest.fixture(scope="session")
 def gpu_engine_cls():
     """QuorumEngine bound to the native library; refuses to run without it."""
+    from raftsql_amd.engine import QuorumEngine, device_count
+
+    if os.environ.get("RAFTQ_HOSTSIM") == "1":
+        # tests/test_hostsim.py: the node / pipe suites against tests/c/libraftq_hostsim.so (their host C++ under
+        # ASan + UBSan, the engine calls answered by the oracle) -- TEST ONLY, and only when RAFTQ_LIB names that library
+        assert "hostsim" in os.environ.get("RAFTQ_LIB", ""), "RAFTQ_HOSTSIM=1 without the test library"
+        return QuorumEngine
     import torch
 
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test started without a visible GPU")
-    from raftsql_amd.engine import QuorumEngine, device_count
 
     assert device_count() >= 1, "libraftq.so sees no HIP device"
     return QuorumEngine

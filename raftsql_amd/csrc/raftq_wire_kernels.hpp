@@ -53,8 +53,34 @@ struct XpowTable {
 };
 __device__ const XpowTable kXpow8{};
 
+// x^(8 n) mod P for n < 256 and x^(8 * 256 n) mod P for n < 256: a record's Data is tens of bytes, a payload hundreds --
+// the multiplier of nearly every record is ONE table read, of the rest one read more and one product.  (Round 2 multiplied
+// the x^(8 * 2^k) of every set bit of n together: 5-6 products of 32 shift-xor steps each per record -- more instructions than
+// the record's whole parse, and most of what wal_dec_kernel's 25.6 us and wal_enc_crc_kernel's 14 us were made of.)
+struct XpowBytes {
+  uint32_t lo[256], hi[256];
+  constexpr XpowBytes() : lo{}, hi{} {
+    uint32_t s = 0x80000000u;  // x^0
+    for (int i = 0; i < 256; ++i) {
+      lo[i] = s;
+      s = crc_mulmod(s, 0x00800000u);  // * x^8
+    }
+    const uint32_t step = s;  // x^(8 * 256)
+    s = 0x80000000u;
+    for (int i = 0; i < 256; ++i) {
+      hi[i] = s;
+      s = crc_mulmod(s, step);
+    }
+  }
+};
+__device__ const XpowBytes kXpowBytes{};
+
 // x^(8 n) mod P
 __device__ __forceinline__ uint32_t crc_xpow8(uint64_t n) {
+  if (n < 65536) {
+    const uint32_t lo = kXpowBytes.lo[n & 255u];
+    return n < 256 ? lo : crc_mulmod(lo, kXpowBytes.hi[n >> 8]);
+  }
   uint32_t r = 0x80000000u;
   for (int k = 0; n != 0 && k < 40; ++k, n >>= 1)
     if (n & 1u) r = crc_mulmod(r, kXpow8.v[k]);
@@ -216,13 +242,20 @@ static inline hipError_t exclusive_sum_u64(const uint64_t* in, uint64_t* out, ui
   return hipGetLastError();
 }
 
-// 256-entry byte table in LDS, built by the block (256 threads)
-__device__ __forceinline__ void crc_table_init(uint32_t* tab) {
-  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (kCastagnoli & (0u - (c & 1u)));
+// the slicing-by-8 tables (raftq_wire_parse.hpp) in LDS, built by the block (256 threads): t[k * 256 + i]
+__device__ __forceinline__ void crc_table_init(uint32_t* tab /*[kCrcTabs * 256]*/) {
+  const uint32_t i = threadIdx.x;  // blockDim.x == 256
+  uint32_t c = 0;
+  if (i < 256) {
+    crc_tables_entry(i, &c);
     tab[i] = c;
   }
+  __syncthreads();
+  if (i < 256)
+    for (int k = 1; k < kCrcTabs; ++k) {
+      c = (c >> 8) ^ tab[c & 0xffu];
+      tab[k * 256 + i] = c;
+    }
   __syncthreads();
 }
 
@@ -242,11 +275,7 @@ __device__ __forceinline__ uint32_t crc_field(const uint32_t* tab, uint32_t raw,
 }
 __device__ inline uint32_t crc_span(const uint32_t* tab, uint32_t raw, const uint8_t* p, uint64_t n) {
   uint64_t i = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint64_t w = load_u64(p + i);
-#pragma unroll
-    for (int k = 0; k < 8; ++k, w >>= 8) raw = crc_byte(tab, raw, (uint8_t)w);
-  }
+  for (; i + 8 <= n; i += 8) raw = crc_step8(tab, raw, load_u64(p + i));
   for (; i < n; ++i) raw = crc_byte(tab, raw, p[i]);
   return raw;
 }
@@ -604,14 +633,15 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_payload_crc_kernel(cons
                                                                             const uint8_t* __restrict__ pool,
                                                                             uint64_t pool_bytes,
                                                                             uint32_t* __restrict__ pcrc) {
-  __shared__ uint32_t tab[256];
-  crc_table_init(tab);
+  __shared__ uint32_t tab[kCrcTabs * 256];
   const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  if (i >= n) return;
-  const uint32_t len = recs[i].data_len;
-  const uint64_t o = recs[i].data_off;
-  if (len <= kCoopBytes || !wal_has_payload(recs[i].kind)) return;
-  if (o > pool_bytes || len > pool_bytes - o) return;  // flagged by wal_enc_crc_kernel
+  const uint32_t len = i < n ? recs[i].data_len : 0u;
+  const uint64_t o = i < n ? recs[i].data_off : 0ull;
+  // (flagged by wal_enc_crc_kernel when the payload lies outside the pool)
+  const bool work = i < n && len > kCoopBytes && wal_has_payload(recs[i].kind) && !(o > pool_bytes || len > pool_bytes - o);
+  if (!__syncthreads_or(work)) return;  // no wave of this workgroup has a long payload: not even the tables are built
+  crc_table_init(tab);
+  if (!work) return;
   const uint32_t c = wave_crc(tab, pool + o, len);
   if ((threadIdx.x & 63) == 0) pcrc[i] = c;
 }
@@ -623,7 +653,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_crc_kernel(const WalRec
                                                                     const uint32_t* __restrict__ pcrc,
                                                                     uint32_t prev_crc, CrcPair* __restrict__ pair,
                                                                     unsigned int* bad) {
-  __shared__ uint32_t tab[256];
+  __shared__ uint32_t tab[kCrcTabs * 256];
   crc_table_init(tab);
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool is_bad = false;
@@ -749,21 +779,26 @@ struct WalSpan {  // Record.data of record i inside the input buffer
   uint64_t off, len;
 };
 
-// decode, step 1: parse; CRC the short Data spans in the lane; pair[i] = the record's map
+// decode, step 1: parse; CRC the short Data spans in the lane; pair[i] = the record's map.  Round 3: the frames of a wave
+// are staged in LDS (stage_wave_frames), parsed there by the flat one-window-per-field walk and CRC'd there.
 static __global__ __launch_bounds__(kBlock) void wal_dec_kernel(const uint8_t* __restrict__ bytes, uint64_t nbytes,
                                                                 const uint64_t* __restrict__ off, uint64_t n,
                                                                 uint32_t prev_crc, WalRec* __restrict__ recs,
                                                                 WalSpan* __restrict__ span,
                                                                 CrcPair* __restrict__ pair) {
-  __shared__ uint32_t tab[256];
+  __shared__ uint32_t tab[kCrcTabs * 256];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
   crc_table_init(tab);
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t a = i < n ? off[i] : 0, b = i < n ? off[i + 1] : 0;
+  const WaveStage st = stage_wave_frames(bytes, nbytes, a, b, i < n, stage[threadIdx.x >> 6]);
+  __syncthreads();
   if (i >= n) return;
-  const uint64_t a = off[i], b = off[i + 1];
   WalRec r;
   uint64_t d_off = 0, d_len = 0;
-  bool ok = frame_body(bytes, nbytes, a, b, false);
-  if (ok) ok = parse_wal_rec(bytes + a + 8, b - a - 8, a + 8, r, d_off, d_len);
+  const ByteSrc src = frame_src(st, bytes, nbytes, a, b);
+  bool ok = frame_body_staged(src, bytes, nbytes, a, b, false);
+  if (ok) ok = parse_wal_rec(src, b - a - 8, a + 8, r, d_off, d_len);
   CrcPair me = {0u, 0x80000000u};  // a record that does not parse leaves the chain alone
   WalSpan sp = {0, 0};
   if (!ok) {
@@ -778,7 +813,7 @@ static __global__ __launch_bounds__(kBlock) void wal_dec_kernel(const uint8_t* _
     sp.off = a + 8 + d_off;
     sp.len = d_len;
     me.p = crc_xpow8(d_len);
-    if (d_len != 0 && d_len <= kCoopBytes) me.c = ~crc_span(tab, 0xffffffffu, bytes + sp.off, d_len);
+    if (d_len != 0 && d_len <= kCoopBytes) me.c = ~crc_span8(tab, 0xffffffffu, src, d_off, d_len);
   }
   if (i == 0) me.c ^= crc_mulmod(me.p, prev_crc);
   recs[i] = r;
@@ -791,12 +826,14 @@ static __global__ __launch_bounds__(kBlock) void wal_dec_long_crc_kernel(const u
                                                                          const WalSpan* __restrict__ span,
                                                                          uint32_t prev_crc,
                                                                          CrcPair* __restrict__ pair) {
-  __shared__ uint32_t tab[256];
-  crc_table_init(tab);
+  __shared__ uint32_t tab[kCrcTabs * 256];
   const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  if (i >= n) return;
-  const WalSpan sp = span[i];
-  if (sp.len <= kCoopBytes) return;
+  WalSpan sp = {0, 0};
+  if (i < n) sp = span[i];
+  const bool work = sp.len > kCoopBytes;
+  if (!__syncthreads_or(work)) return;  // no wave of this workgroup has a long Data span
+  crc_table_init(tab);
+  if (!work) return;
   uint32_t c = wave_crc(tab, bytes + sp.off, sp.len);
   if ((threadIdx.x & 63) == 0) {
     if (i == 0) c ^= crc_mulmod(pair[0].p, prev_crc);

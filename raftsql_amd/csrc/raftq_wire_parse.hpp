@@ -416,79 +416,115 @@ RAFTQ_HD inline bool parse_msg(const ByteSrc& src, uint64_t n, uint64_t base, Fi
 
 // ---- walpb.Record -----------------------------------------------------------------------------------
 
-// Record.Unmarshal + the Data unmarshal ReadAll does per type.  d_off / d_len: Record.data inside p.
-RAFTQ_HD inline bool parse_wal_rec(const uint8_t* p, uint64_t n, uint64_t base, WalRec& r, uint64_t& d_off,
-                                   uint64_t& d_len) {
+// One field of a message whose known field numbers are 1..known, at offset i of a scope that ends at lim: the key and --
+// for a known field -- the varint behind it (its value, or the length of a length-delimited field), i moved past both.
+// An unknown field is skipped whole (skipped = true).  The one-window form where it applies (one-byte key, value ending
+// within seven bytes, window inside `safe`), the byte-loop forms otherwise.  false = malformed.
+RAFTQ_HD inline bool next_field(const ByteSrc& src, uint64_t& i, uint64_t lim, uint32_t known, uint32_t& fn, uint32_t& wt, uint64_t& v,
+                                bool& skipped) {
+  skipped = false;
+  const uint64_t rem = lim - i;
+  if (i + 8 <= src.safe) {
+    const uint64_t w = src.ld8(i);
+    const uint64_t vstop = ~w & 0x8080808080808000ull;
+    const uint32_t f = ((uint32_t)w >> 3) & 0x1fu;
+    if (((uint32_t)w & 0x80u) == 0 && vstop != 0 && f != 0 && f <= known) {
+      const uint32_t used = ffs64(vstop) >> 3;
+      if (used > rem) return false;  // the varint runs over the end of its scope
+      fn = f;
+      wt = (uint32_t)w & 7u;
+      v = varint_value(w >> 8, used - 1);
+      i += used;
+      return true;
+    }
+  }
+  Key k;
+  uint64_t j = i;
+  if (!get_key(src.p, lim, j, k)) return false;
+  if (k.fn > known) {
+    const uint64_t u = skip_value(src.p + j, lim - j, k.wt);
+    if (!u) return false;
+    i = j + u;
+    skipped = true;
+    return true;
+  }
+  fn = (uint32_t)k.fn;
+  wt = k.wt;
+  const uint32_t u = get_varint(src.p + j, lim - j, &v);
+  if (!u) return false;
+  i = j + u;
+  return true;
+}
+
+// Record.Unmarshal + the Data unmarshal ReadAll does per type, over the n bytes of `src`.  d_off / d_len: Record.data
+// inside the record.  Round 3: the same one-window-per-field walk as parse_msg (the generic key / varint pair per field,
+// twice nested, was round 2's form); Record.data is parsed after the record's own fields because its type may follow it.
+RAFTQ_HD inline bool parse_wal_rec(const ByteSrc& src, uint64_t n, uint64_t base, WalRec& r, uint64_t& d_off, uint64_t& d_len) {
   r.group = r.term = r.index = r.data_off = 0;
   r.data_len = r.vote = r.crc = 0;
   r.kind = r.entry_type = r.flags = r.pad = 0;
   d_off = d_len = 0;
-  uint64_t i = 0, type = 0;
+  uint64_t i = 0, type = 0, v;
+  uint32_t fn, wt;
+  bool skipped;
   while (i < n) {
-    Key k;
-    uint64_t v;
-    if (!get_key(p, n, i, k)) return false;
-    if (k.fn <= 2) {
-      if (k.wt != 0) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used) return false;
-      i += used;
-      if (k.fn == 1) type = v;
+    if (!next_field(src, i, n, 3, fn, wt, v, skipped)) return false;
+    if (skipped) continue;
+    if (fn <= 2) {
+      if (wt != 0) return false;
+      if (fn == 1) type = v;
       else r.crc = (uint32_t)v;
-    } else if (k.fn == 3) {
-      if (k.wt != 2) return false;
-      const uint32_t used = get_varint(p + i, n - i, &v);
-      if (!used || v > n - i - used) return false;
-      i += used;
+    } else {
+      if (wt != 2 || v > n - i) return false;
       d_off = i;
       d_len = v;
       i += v;
-    } else {
-      const uint64_t used = skip_value(p + i, n - i, k.wt);
-      if (!used) return false;
-      i += used;
     }
   }
   if (type < 1 || type > 5) return false;  // ReadAll: "unexpected block type"
   r.kind = (uint8_t)type;
-  const uint8_t* d = p + d_off;
-  if (r.kind == kWalEntry) {
-    WireEnt e;
-    bool hg = false;
-    if (!parse_entry(d, d_len, base + d_off, e, &r.group, &hg)) return false;
-    r.term = e.term;
-    r.index = e.index;
-    r.data_off = e.data_off;
-    r.data_len = e.data_len;
-    r.entry_type = (uint8_t)e.type;
-    if (hg) r.flags |= kWalGroup;
-  } else if (r.kind == kWalState || r.kind == kWalSnapshot) {
-    const uint64_t known = r.kind == kWalState ? 4 : 2;
-    uint64_t j = 0;
-    while (j < d_len) {
-      Key k;
-      uint64_t v;
-      if (!get_key(d, d_len, j, k)) return false;
-      if (k.fn > known) {
-        const uint64_t used = skip_value(d + j, d_len - j, k.wt);
-        if (!used) return false;
-        j += used;
-        continue;
+  const uint64_t end = d_off + d_len;
+  uint64_t j = d_off;
+  if (r.kind == kWalEntry) {  // Entry{1 type, 2 term, 3 index, 4 data, 5 group}
+    uint64_t e_off = 0;
+    uint32_t e_len = 0;
+    while (j < end) {
+      if (!next_field(src, j, end, 5, fn, wt, v, skipped)) return false;
+      if (skipped) continue;
+      if (fn == 4) {
+        if (wt != 2 || v > end - j || v > 0xffffffffull) return false;
+        e_off = base + j;
+        e_len = (uint32_t)v;
+        j += v;
+      } else {
+        if (wt != 0) return false;
+        if (fn == 1) r.entry_type = (uint8_t)(uint32_t)v;
+        else if (fn == 2) r.term = v;
+        else if (fn == 3) r.index = v;
+        else {
+          r.group = v;
+          r.flags |= kWalGroup;
+        }
       }
-      if (k.wt != 0) return false;
-      const uint32_t used = get_varint(d + j, d_len - j, &v);
-      if (!used) return false;
-      j += used;
+    }
+    r.data_len = e_len;
+    r.data_off = e_len ? e_off : 0;
+  } else if (r.kind == kWalState || r.kind == kWalSnapshot) {
+    const uint32_t known = r.kind == kWalState ? 4 : 2;
+    while (j < end) {
+      if (!next_field(src, j, end, known, fn, wt, v, skipped)) return false;
+      if (skipped) continue;
+      if (wt != 0) return false;
       if (r.kind == kWalState) {
-        if (k.fn == 1) r.term = v;
-        else if (k.fn == 2) r.vote = (uint32_t)v;
-        else if (k.fn == 3) r.index = v;
+        if (fn == 1) r.term = v;
+        else if (fn == 2) r.vote = (uint32_t)v;
+        else if (fn == 3) r.index = v;
         else {
           r.group = v;
           r.flags |= kWalGroup;
         }
       } else {
-        if (k.fn == 1) r.index = v;
+        if (fn == 1) r.index = v;
         else r.term = v;
       }
     }
@@ -498,6 +534,49 @@ RAFTQ_HD inline bool parse_wal_rec(const uint8_t* p, uint64_t n, uint64_t base, 
     r.data_len = (uint32_t)d_len;
   }
   return true;
+}
+
+// ---- CRC-32C, eight bytes per step (slicing-by-8) ------------------------------------------------------------
+// t[k][i] (k = 0..7, 256 words each): the raw register after byte i and k further zero bytes.  The byte-at-a-time update is
+// a chain of dependent table reads -- on the device one LDS round trip per byte, 64 lanes hitting 64 random words of one
+// 1 KB table: round 2's WAL decoder spent most of its 25.6 us there; eight independent reads per eight bytes put one round
+// trip where there were eight.  Same arithmetic on the host (tests/test_wire_parse_host.py checks it against the oracle's CRC).
+constexpr int kCrcTabs = 8;
+RAFTQ_HD inline void crc_tables_entry(uint32_t i, uint32_t* col /*[kCrcTabs], stride 256*/) {
+  uint32_t c = i;
+  for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82f63b78u & (0u - (c & 1u)));
+  col[0] = c;
+}
+RAFTQ_HD inline uint32_t crc_step1(const uint32_t* t, uint32_t raw, uint8_t b) { return t[(raw ^ b) & 0xffu] ^ (raw >> 8); }
+RAFTQ_HD inline uint32_t crc_step8(const uint32_t* t, uint32_t raw, uint64_t w) {
+  const uint32_t lo = (uint32_t)w ^ raw, hi = (uint32_t)(w >> 32);
+  return t[7 * 256 + (lo & 0xffu)] ^ t[6 * 256 + ((lo >> 8) & 0xffu)] ^ t[5 * 256 + ((lo >> 16) & 0xffu)] ^ t[4 * 256 + (lo >> 24)] ^
+         t[3 * 256 + (hi & 0xffu)] ^ t[2 * 256 + ((hi >> 8) & 0xffu)] ^ t[1 * 256 + ((hi >> 16) & 0xffu)] ^ t[hi >> 24];
+}
+// the raw register over n bytes at offset `off` of what `src` reads: whole 8-byte windows, then the tail out of one more
+// window (a staged frame: bytes behind the data are inside the stage) or byte by byte (the buffer may end with the data)
+RAFTQ_HD inline uint32_t crc_span8(const uint32_t* t, uint32_t raw, const ByteSrc& src, uint64_t off, uint64_t n) {
+  uint64_t i = 0;
+  for (; i + 8 <= n; i += 8) raw = crc_step8(t, raw, src.ld8(off + i));
+  if (i < n) {
+    bool window = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    window = src.words != nullptr;
+#endif
+    if (window) {
+      uint64_t w = src.ld8(off + i);
+      for (; i < n; ++i, w >>= 8) raw = crc_step1(t, raw, (uint8_t)w);
+    } else {
+      for (; i < n; ++i) raw = crc_step1(t, raw, src.p[off + i]);
+    }
+  }
+  return raw;
+}
+// host-side table build (the device builds the same table in LDS, raftq_wire_kernels.hpp crc_table_init)
+inline void crc_tables_build(uint32_t* t /*[kCrcTabs * 256]*/) {
+  for (uint32_t i = 0; i < 256; ++i) crc_tables_entry(i, t + i);
+  for (int k = 1; k < kCrcTabs; ++k)
+    for (uint32_t i = 0; i < 256; ++i) t[k * 256 + i] = (t[(k - 1) * 256 + i] >> 8) ^ t[t[(k - 1) * 256 + i] & 0xffu];
 }
 
 // frame extent + length word; body = [a + 8, b)

@@ -55,7 +55,8 @@ void host_wal_parse(const uint8_t* bytes, uint64_t nbytes, const uint64_t* off, 
     WalRec r;
     uint64_t d_off = 0, d_len = 0;
     bool ok = frame_body(bytes, nbytes, a, b, false);
-    if (ok) ok = parse_wal_rec(bytes + a + 8, b - a - 8, a + 8, r, d_off, d_len);
+    const ByteSrc src = {bytes + a + 8, nbytes - a - 8};
+    if (ok) ok = parse_wal_rec(src, b - a - 8, a + 8, r, d_off, d_len);
     span_off[i] = span_len[i] = 0;
     if (!ok) {
       memset(&r, 0, sizeof r);
@@ -66,6 +67,18 @@ void host_wal_parse(const uint8_t* bytes, uint64_t nbytes, const uint64_t* off, 
     }
     recs[i] = r;
   }
+}
+
+// CRC-32C (standard inversions, seed `crc`) of data[0, n) by the slicing-by-8 update the kernels use
+uint32_t host_crc32c(uint32_t crc, const uint8_t* data, uint64_t n) {
+  static uint32_t tab[kCrcTabs * 256];
+  static bool built = false;
+  if (!built) {
+    crc_tables_build(tab);
+    built = true;
+  }
+  const ByteSrc src = {data, n};
+  return ~crc_span8(tab, ~crc, src, 0, n);
 }
 
 }  // extern "C"

@@ -132,6 +132,16 @@ def test_bench_four_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):
     assert len(r["launch_us_per_gpu"]) == 4 and len(r["wall_ms_per_rank"]) == 4 and d["gate"]["sets_gated"] == 4
 
 
+def test_bench_two_ranks_under_torchrun_with_the_side_legs(gpu_engine_cls):
+    """The driver's N > 1 command line has no --no-extras: rank 0 then measures its side legs while the other ranks wait at
+    the next barrier, and every rank takes part in config 4's whole job.  Two ranks on GPU 0, a small resident set."""
+    d = _torchrun_bench(2, 29536, "--steps", "4", "--warmup", "1", "--device", "0", "--batches", "10", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == [0, 1] and d["gate"]["sets_gated"] == 2
+    assert d["config4_whole_job"]["decisions_per_s"] > 1e9 and "2 GPU(s)" in d["config4_whole_job"]["workload"]
+    assert d["single_launch"]["launches_per_step"] == 10 and d["other_dispatch"]["dispatch"] == "persistent"
+    assert [c["batches"] for c in d["footprint_curve"]] == [64, 128, 240]
+
+
 def test_bench_rccl_asked_for_where_it_cannot_work(gpu_engine_cls):
     """`--backend nccl` with two ranks mapped onto ONE device: RCCL refuses that.  Every rank must agree -- before any
     RCCL rendezvous -- to stay on gloo, finish the job, and say why (a communicator failure must not

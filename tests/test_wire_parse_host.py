@@ -28,6 +28,8 @@ def _build() -> C.CDLL:
     lib = C.CDLL(LIB)
     lib.host_wire_decode.restype = C.c_uint64
     lib.host_wire_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.host_crc32c.restype = C.c_uint32
+    lib.host_crc32c.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64]
     lib.host_wal_parse.restype = None
     lib.host_wal_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -179,3 +181,18 @@ def test_wal_records_parse_like_the_oracle(host, seed):
         wr = wr.copy()
         wr["flags"] &= np.uint8(~W.WAL_F_BADCRC & 0xFF)
         G._same(gr, wr, "wal recs (mutated=%s)" % mutate)
+
+
+def test_crc32c_eight_bytes_per_step_equals_the_oracle(host):
+    """The slicing-by-8 update the kernels run (tables t[k][i], eight reads per eight bytes) against the oracle's bitwise
+    CRC-32C and RFC 3720's vectors: every length 0..70, long buffers, chained seeds."""
+    rng = np.random.default_rng(5)
+    g = json.load(open(G.GOLD))
+    for c in g["crc32c"]:
+        d = np.frombuffer(bytes.fromhex(c["data"]), np.uint8)
+        buf = np.concatenate([d, np.zeros(8, np.uint8)])
+        assert host.lib.host_crc32c(c["seed"], buf.ctypes.data, len(d)) == c["crc"], c
+    for n in list(range(0, 71)) + [255, 256, 257, 4096, 100003]:
+        d = rng.integers(0, 256, n + 8, dtype=np.uint8)
+        seed = int(rng.integers(0, 1 << 32))
+        assert host.lib.host_crc32c(seed, d.ctypes.data, n) == W.crc32c(d[:n].tobytes(), seed), n

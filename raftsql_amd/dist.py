@@ -205,11 +205,13 @@ def barrier(w: World) -> None:
         t0, spins = time.monotonic(), 0
         while int(others.min()) < gen:  # every rank only ever writes its own line, generations only grow
             spins += 1
-            if spins % 4096 == 0:
-                if time.monotonic() - t0 > _TIMEOUT_S:
+            if spins >= 20000:
+                # ~20 ms of pure spinning covers the skew at either end of a timed region; a longer wait is a rank that is
+                # busy elsewhere for seconds (rank 0 measuring its side legs): stop burning a core per waiting rank
+                time.sleep(1e-4)
+                if spins % 1000 == 0 and time.monotonic() - t0 > _TIMEOUT_S:
                     raise RuntimeError(f"rank {w.rank}: barrier {gen} timed out after {_TIMEOUT_S} s "
                                        f"(generations seen: {others.tolist()})")
-                time.sleep(0)  # give the core away once in a while (oversubscribed CPU tests)
         return
     import torch.distributed as dist
 

@@ -1018,7 +1018,7 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
                          h->last_old, h->last_new, out, take_cap, h->d_total, wave_offsets);
       break;
     default:
-      static_assert(kGPL == 4 && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
+      static_assert((kGPL == 4 || kGPL == 8) && kLdsGPL == 4, "compaction instantiations cover GPL 2, 4, 8");
       hipLaunchKernelGGL((compact_changed_kernel<4, Adv>), grid, dim3(kBlock), 0, h->stream, h->changed_bits, h->partials,
                          h->last_old, h->last_new, out, take_cap, h->d_total, wave_offsets);
   }

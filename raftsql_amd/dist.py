@@ -173,6 +173,10 @@ def init_from_env(backend: str | None = None, device: int | None = None) -> Worl
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1") and os.path.isdir("/sys/class/net/lo"):
+        # a one-node job rendezvousing on loopback: gloo's pairs go over loopback as well, whatever the box's hostname
+        # resolves to (or fails to: a container's hostname often does not resolve)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=size, timeout=_TIMEOUT)
     w = World(rank, local_rank, size, "gloo", "gloo")
     # every rank must have asked for the same thing (a flag that differs between ranks is a launcher bug: say so)

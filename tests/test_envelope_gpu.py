@@ -1,8 +1,8 @@
 """GPU: the parity envelope -- whole-array equality with the C oracle at the sizes the ABI and the bench claim,
 not only at the sizes the small suites use (VERDICT r02 "close the parity envelope"):
 
-  * ONE handle of 2^28 (+ a ragged tail) groups x 3 peers: the match rows are > 6 GiB, a row is > 2 GiB, the sweep
-    grid has > 2^17 tiles -- every 32-bit offset, pitch or tile index would show;
+  * ONE handle of 2^29 (+ a ragged tail) groups x 3 peers: the match rows are 12 GiB, ONE row is > 4 GiB (a 32-bit BYTE
+    offset inside a row would wrap), the sweep grid has > 2^19 tiles -- every 32-bit offset, pitch or tile index would show;
   * BASELINE configs[3] whole: 16M x 7 as one handle, and as the 8 counter-based shards of 2M x 7 that 8 GPUs would
     hold, swept as one set (both launch shapes);
   * the bench's own dispatch: K = 36 members of 1M x 5, SWEEP_STREAM, grid and persistent walk, every member
@@ -52,10 +52,11 @@ def tiled(base: synth.GroupState, G: int) -> synth.GroupState:
     return st
 
 
-def test_one_handle_of_2_pow_28_groups(gpu_engine_cls, oracle):
-    """raftq_create takes up to 2^40 groups; this is the largest handle parity is checked on: 2^28 + 70,001 groups x 3
-    (6.0 GiB of match rows, 2.0 GiB per row, 262,213 sweep tiles of 1,024 groups, 1.05 M per-wave tallies)."""
-    n, G = 3, (1 << 28) + 70001
+def test_one_handle_of_2_pow_29_groups(gpu_engine_cls, oracle):
+    """raftq_create takes up to 2^40 groups; this is the largest handle parity is checked on: 2^29 + 70,001 groups x 3
+    (12.0 GiB of match rows, 4.0 GiB + 547 KiB per row -- byte offsets inside a row pass 2^32 --, 524,357 sweep tiles of
+    1,024 groups, 2.1 M per-wave tallies)."""
+    n, G = 3, (1 << 29) + 70001
     base = synth.make_groups(1 << 22, n, seed=synth.SEED_BASE + 28, with_terms=True)
     st = tiled(base, G)
     del base
@@ -65,7 +66,7 @@ def test_one_handle_of_2_pow_28_groups(gpu_engine_cls, oracle):
     assert 0 < n_gat < n_ung < G and w > 0 and l > 0
     with gpu_engine_cls(G, n) as e:
         e.load_state(st)
-        assert np.array_equal(e.read_match(), st.match)  # rows of 2 GiB through the strided copies, both ways
+        assert np.array_equal(e.read_match(), st.match)  # rows of 4 GiB through the row copies, both ways
         for variant in (SWEEP_STREAM, SWEEP_LDS):
             c = e.sweep(SWEEP_COMMIT | SWEEP_VOTES | SWEEP_NO_ADOPT | variant)
             assert (c.n_changed, c.n_won, c.n_lost) == (n_ung, w, l)
@@ -99,7 +100,7 @@ def test_one_handle_of_2_pow_28_groups(gpu_engine_cls, oracle):
         assert np.array_equal(adv["group"], idx.astype(np.uint64))
         assert np.array_equal(adv["old_commit"], gat[idx]) and np.array_equal(adv["new_commit"], want[idx])
         assert np.array_equal(e.read_committed(), want)
-        # the same through the 16-byte records (32-bit group ids: 2^28 fits), a second round of acks
+        # the same through the 16-byte records (32-bit group ids: 2^29 fits), a second round of acks
         top2 = want[dg.astype(np.int64)] + bump
         d16 = e.pack_deltas16(np.concatenate([dg, dg]), np.concatenate([np.zeros(len(dg), np.uint32), np.full(len(dg), 2, np.uint32)]),
                               np.concatenate([top2, top2]))

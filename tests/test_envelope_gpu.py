@@ -217,3 +217,43 @@ def test_set_full_size_seven_and_nine_peers(gpu_engine_cls, oracle, n, G):
             assert np.array_equal(adv["new_commit"], gat[idx])
     for e in es:
         e.close()
+
+
+def test_step_and_tick_on_a_handle_of_2_pow_29_groups(oracle):
+    """The node state of 2^29 + 70,001 groups x 3 (match rows past 4 GiB, 40 GB of state in all): batched Step and Tick on
+    groups at both ends of the range -- election, votes, acks, commit -- every result record and every state word of the
+    whole handle against the sequential oracle; the MsgHup list of a Tick over all groups against the oracle's."""
+    from raftsql_amd import step as S
+
+    n, G = 3, (1 << 29) + 70001
+    rng = np.random.default_rng(29)
+    g = np.unique(np.concatenate([np.arange(0, 2000), np.arange(G - 50000, G), rng.integers(0, G, 20000)])).astype(np.uint64)
+    s = oracle.NodeState(G, n, 0)
+    with S.NodeEngine(G, n, 0) as e:
+        batches = [S.pack_msgs(g, S.MSG_HUP)]
+        for p in (2, 1):
+            batches.append(S.pack_msgs(rng.permutation(g), S.MSG_VOTE_RESP, term=1, frm=p, reject=int(p == 2)))
+        for p in (1, 2):
+            batches.append(S.pack_msgs(rng.permutation(g), S.MSG_APP_RESP, term=1, frm=p, index=1))
+        batches.append(S.pack_msgs(g[::3], S.MSG_VOTE, term=5, frm=1, index=9, log_term=4))  # a newer candidate: step down
+        for m in batches:
+            got, touched = e.step_batch(m)
+            want = s.step_batch(m)
+            assert touched == len(np.unique(m["group"])) and np.array_equal(got, want), "Step result records differ from the oracle"
+        node = e.read_node()
+        for k in ("term", "vote", "lead", "last_index", "last_term", "first_idx"):
+            assert np.array_equal(node[k], getattr(s, k)), k
+        assert np.array_equal(node["role"], s.role) and np.array_equal(node["committed"], s.committed)
+        assert np.array_equal(e.read_match(), s.match)
+        assert int((s.role == 2).sum()) == len(g) - len(g[::3]) and np.all(s.committed[g[1::3].astype(np.int64)] == 1)
+        # Tick for every group until the first election timers fire: hup / beat lists vs the oracle
+        e.set_timers(3, 1, 77)
+        el = s.elapsed
+        for t in range(5):
+            hup, beat = e.tick()
+            el, act, rh, rb = oracle.tick(s.role, el, 3, 1, 77, t)
+            assert (hup, beat) == (rh, rb), t
+        hups, nh = e.collect_hups()
+        assert nh == rh > 0 and np.array_equal(hups, np.nonzero(act == 1)[0].astype(np.uint64))
+        beats, nb = e.collect_beats(cap=1 << 16)
+        assert nb == rb and np.array_equal(beats, np.nonzero(act == 2)[0][: 1 << 16].astype(np.uint64))

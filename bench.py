@@ -726,7 +726,8 @@ def node_measure(device, G=32768, N=3, rounds=6):
     """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
     same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
     waves of one proposal per group on its leader, cranked until every node has delivered every
-    entry on its commit channels.  Wall time, Python transport included; the N nodes' turns run on N threads."""
+    entry on its commit channels.  Wall time of the whole crank (Python loop, status polls, the in-process transport
+    raftq_node_forward); the N nodes' turns run on N threads."""
     from raftsql_amd.node import Cluster
 
     before = os.sched_getaffinity(0)
@@ -740,7 +741,8 @@ def node_measure(device, G=32768, N=3, rounds=6):
 
 
 def _node_measure(Cluster, device, G, N, rounds, pinned):
-    c = Cluster(G, N, device=device, seed=5, threads=True)  # one thread per node, as N machines would run
+    # one thread per node, as N machines would run; the frames go from node to node inside the library (raftq_node_forward)
+    c = Cluster(G, N, device=device, seed=5, threads=True, native_transport=True)
     c.start()
     t0 = time.perf_counter()
     ticks = 0

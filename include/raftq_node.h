@@ -133,6 +133,13 @@ int raftq_node_advance(raftq_node_t* n, uint64_t* n_published);
 /* whole frames addressed to `to_peer`, at most cap bytes; *len = bytes written (0 = nothing queued) */
 int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, uint64_t* len);
 
+/* In-process transport: everything `from` has queued for peer `to_peer` goes straight to `to` (raftq_node_poll +
+ * raftq_node_deliver without the caller's buffer in between) -- how several nodes of one process exchange their frames
+ * (the reference's tests run three nodes in one process over loopback TCP, raftsql_test.go:11-35; here the bytes never
+ * leave the process).  to == NULL: the frames are dropped (a lost transfer, a partitioned or stopped peer).
+ * *moved (may be NULL) = bytes taken off `from`'s queue.  The two nodes' locks are never held together. */
+int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, uint64_t* moved);
+
 /* whole WAL frames produced so far, at most cap bytes; *len = bytes written (0 = nothing pending) */
 int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len);
 

@@ -1243,6 +1243,26 @@ int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, 
   return poll_queue(n, n->outbound[to_peer], true, buf, cap, len);
 }
 
+int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, uint64_t* moved) {
+  if (moved) *moved = 0;
+  if (!from) return RAFTQ_EINVAL;
+  if (to_peer >= from->N) return nfail(from, RAFTQ_EINVAL, "forward: peer out of range");
+  std::string taken;  // the queue's bytes leave under the sender's lock and arrive under the receiver's: never both held
+  try {
+    std::lock_guard<std::mutex> lk(from->mu);
+    PeerQueue& q = from->outbound[to_peer];
+    if (q.head == 0) taken.swap(q.bytes);
+    else taken.assign(q.bytes, q.head, std::string::npos);
+    q.bytes.clear();
+    q.head = 0;
+  } catch (...) {
+    return nfail(from, RAFTQ_ENOMEM, "forward: host allocation failed");
+  }
+  if (moved) *moved = taken.size();
+  if (!to || taken.empty()) return RAFTQ_OK;
+  return raftq_node_deliver(to, taken.data(), taken.size());
+}
+
 int raftq_node_wal_enable(raftq_node_t* n) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> lk(n->mu);

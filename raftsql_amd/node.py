@@ -48,6 +48,7 @@ _SIGS = [
     ("raftq_node_deliver", C.c_int, [_P, C.c_void_p, C.c_uint64]),
     ("raftq_node_advance", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("raftq_node_poll", C.c_int, [_P, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_node_forward", C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
     ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int)]),
     ("raftq_node_status", C.c_int, [_P, C.c_uint64, C.POINTER(Status)]),
@@ -123,7 +124,7 @@ class RaftNode:
             self._chk(self._lib.raftq_node_wal_poll(self._p, self._wire, len(self._wire), C.byref(n)))
             if n.value == 0:
                 return b"".join(out)
-            out.append(self._wire.raw[: n.value])
+            out.append(C.string_at(self._wire, n.value))  # (.raw would copy the whole 4 MiB buffer first)
 
     def set_hard_state(self, group: int, term: int, vote: int, commit: int) -> None:
         self._chk(self._lib.raftq_node_set_hard_state(self._p, group, term, vote, commit))
@@ -167,7 +168,15 @@ class RaftNode:
             self._chk(self._lib.raftq_node_poll(self._p, to_peer, self._wire, len(self._wire), C.byref(n)))
             if n.value == 0:
                 return b"".join(out)
-            out.append(self._wire.raw[: n.value])
+            out.append(C.string_at(self._wire, n.value))  # (.raw would copy the whole 4 MiB buffer first)
+
+    def forward(self, to_peer: int, to: "Optional[RaftNode]") -> int:
+        """raftq_node_forward: everything queued for `to_peer` goes straight to node `to` (None: dropped) -> bytes moved"""
+        n = C.c_uint64(0)
+        rc = self._lib.raftq_node_forward(self._p, to_peer, to._p if to is not None else None, C.byref(n))
+        if rc != 0:
+            (to if to is not None else self)._chk(rc)
+        return int(n.value)
 
     # -- commit channel -----------------------------------------------------
     def recv(self, group: int, timeout_ms: int = 0):
@@ -253,8 +262,11 @@ class Cluster:
     `cut` holds (a, b) pairs whose traffic is dropped in both directions."""
 
     def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7,
-                 wal: bool = False, threads: bool = False):
+                 wal: bool = False, threads: bool = False, native_transport: bool = False):
         self.G, self.N, self.device, self.election_tick, self.seed = n_groups, n_peers, device, election_tick, seed
+        # native_transport: the nodes' frames go from queue to queue inside the library (raftq_node_forward) instead of
+        # through Python bytes -- same frames, same order, same loss / partition rules (decided here, applied there)
+        self.native_transport = native_transport
         # threads=True: every node's turn (tick, advance, WAL poll, outbound poll) runs on its own thread, as N
         # machines would; the library calls release the GIL and each node has its own engine handle and stream.
         # The transport (deliver) stays on the caller's thread, after all turns: what a turn receives is the same.
@@ -281,13 +293,16 @@ class Cluster:
             nd.start(self.election_tick, 1, seed=self.seed + 1000 * p)
 
     def _turn(self, p: int, tick: bool):
-        """one iteration of node p's serveChannels loop -> (published, its outbound bytes per addressee)"""
+        """one iteration of node p's serveChannels loop -> (published, its outbound bytes per addressee | None when the
+        frames go from node to node inside the library, raftq_node_forward)"""
         nd = self.nodes[p]
         if tick:
             nd.tick()
         published = nd.advance()
         if self.wal_on:
             self.wal[p] += nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
+        if self.native_transport:
+            return published, None
         return published, [nd.poll(q) if q != p else b"" for q in range(self.N)]
 
     def step(self, tick: bool = True) -> int:
@@ -302,9 +317,15 @@ class Cluster:
             for q in range(self.N):
                 if q == p:
                     continue
+                lost = q in self.down or (p, q) in self.cut or (q, p) in self.cut  # lost on the wire
+                if out is None:  # in-process transport: the library moves the frames (or drops them)
+                    if not lost and self.loss and self._rng.random() < self.loss:
+                        lost = True
+                    self.nodes[p].forward(q, None if lost else self.nodes[q])
+                    continue
                 frames = out[q]
-                if q in self.down or (p, q) in self.cut or (q, p) in self.cut:
-                    continue  # lost on the wire
+                if lost:
+                    continue
                 if self.loss and frames and self._rng.random() < self.loss:
                     continue
                 self.nodes[q].deliver(frames)

@@ -645,10 +645,12 @@ def test_status_batch_is_status_g_times(Cluster):
 
 def test_threaded_cluster_is_the_serial_cluster(Cluster):
     """Cluster(threads=True) runs every node's turn on its own thread (what N machines do); the transport still
-    moves the bytes after all turns, so the run is the serial run: same leaders, same logs, same statistics."""
+    moves the bytes after all turns, so the run is the serial run: same leaders, same logs, same statistics -- and the
+    same again when the library moves the frames from node to node itself (native_transport, raftq_node_forward)."""
     runs = []
-    for threads in (False, True):
-        c = Cluster(1500, 3, seed=21, threads=threads)
+    for threads, native in ((False, False), (True, False), (True, True), (False, True)):
+        # native: the frames go from node to node inside the library (raftq_node_forward) instead of through Python bytes
+        c = Cluster(1500, 3, seed=21, threads=threads, native_transport=native)
         try:
             c.start()
             elect(c, max_ticks=200)
@@ -665,9 +667,10 @@ def test_threaded_cluster_is_the_serial_cluster(Cluster):
                          [[nd.drain(g) for g in range(0, 1500, 37)] for nd in c.nodes]))
         finally:
             c.close()
-    a, b = runs
-    assert np.array_equal(a[0], b[0])
-    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    a = runs[0]
+    for b in runs[1:]:
+        assert np.array_equal(a[0], b[0])
+        assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
     assert all(ch == [None, b"r0 g%d" % g, b"r1 g%d" % g, b"r2 g%d" % g] for g, ch in zip(range(0, 1500, 37), a[3][0]))
 
 
@@ -696,5 +699,38 @@ def test_many_proposals_per_group_in_one_turn(Cluster):
                     assert [d for d in node.drain(g) if d is not None] == [b"cold%d" % g]
             assert [e[1] for e in node.log(hot)][-200:] == burst
         check_safety(c)
+    finally:
+        c.close()
+
+
+def test_forward_moves_or_drops_whole_queues(Cluster):
+    """raftq_node_forward: what a node queued for a peer reaches that peer's next turn byte for byte (the same frames
+    raftq_node_poll would hand out), or -- to == NULL -- is gone; nothing is delivered twice, nothing stays queued."""
+    c = Cluster(40, 3, seed=5, native_transport=True)
+    try:
+        c.start()
+        elect(c)
+        lead = c.leaders()
+        p = int(lead[7])
+        c.nodes[p].propose(7, b"one")
+        c.nodes[p].advance()
+        others = [q for q in range(3) if q != p]
+        queued = c.nodes[p].poll(others[0])  # the frames themselves, for comparison ...
+        assert queued and c.nodes[p].poll(others[0]) == b""
+        c.nodes[others[0]].deliver(queued)   # ... delivered the classic way
+        moved = c.nodes[p].forward(others[1], c.nodes[others[1]])  # the other follower gets its copy through forward
+        assert moved == len(queued) and c.nodes[p].forward(others[1], c.nodes[others[1]]) == 0
+        c.settle()
+        assert [nd.status(7).commit for nd in c.nodes] == [c.nodes[p].status(7).commit] * 3
+        assert all(nd.drain(7)[-1] == b"one" for nd in c.nodes)
+        c.nodes[p].propose(7, b"two")
+        c.nodes[p].advance()
+        assert c.nodes[p].forward(others[0], None) > 0 and c.nodes[p].forward(others[1], None) > 0  # both transfers lost
+        assert c.nodes[p].poll(others[0]) == b"" and c.nodes[p].poll(others[1]) == b""
+        c.settle()
+        assert all(nd.drain(7) == [] for nd in c.nodes)  # nobody can have committed "two" yet
+        c.run(3)  # heartbeats find the followers behind and resend
+        c.settle()
+        assert all(nd.drain(7) == [b"two"] for nd in c.nodes)
     finally:
         c.close()

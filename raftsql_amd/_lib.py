@@ -180,6 +180,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if "hostsim" in os.path.basename(LIB_PATH) and os.environ.get("RAFTQ_HOSTSIM") != "1":
+        # tests/c/libraftq_hostsim.so answers the engine's calls with the CPU oracle so that the host C++ can run under
+        # ASan (tests/test_hostsim.py).  It is test infrastructure: the package never loads it on RAFTQ_LIB alone.
+        raise ImportError("RAFTQ_LIB names the test-only host simulation; it is only loaded together with RAFTQ_HOSTSIM=1 "
+                          "(tests/test_hostsim.py).  raftsql_amd has no CPU path.")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: run `python -m raftsql_amd.build` (needs hipcc). "

@@ -111,7 +111,16 @@ def test_bench_four_gpus_worth_from_one_process_and_refusal(gpu_engine_cls):
         assert "refusing" in (p.stderr + p.stdout)
 
 
-def _torchrun_bench(nproc, port, *args):
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _torchrun_bench(nproc, _port_hint, *args):
+    port = _free_port()  # (a fixed port would collide with whatever else runs on the box)
     env = dict({k: v for k, v in os.environ.items() if k != "RAFTQ_CYCLE_CHECK"}, MASTER_ADDR="127.0.0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),

@@ -60,8 +60,12 @@ def _build() -> str:
 
 
 def _run(tests, extra_env=None, timeout=1500):
+    import shutil
+
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() if shutil.which("gcc") else ""
+    if not (shutil.which("g++") and os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("no g++ / libasan here: the host C++ cannot be built under AddressSanitizer")
     lib = _build()
-    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
     env = dict(os.environ, RAFTQ_LIB=lib, RAFTQ_HOSTSIM="1", LD_PRELOAD=asan,
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                **(extra_env or {}))

@@ -722,12 +722,32 @@ def gpu_numa_cpus(device):
         return None
 
 
-def node_measure(device, G=32768, N=3, rounds=6):
+def one_cpu_per_l3(cpus, count):
+    """`count` CPUs out of `cpus`, each under a different L3 slice where the box has that many (sysfs), else spread evenly"""
+    cpus = sorted(cpus)
+    picked, seen = [], set()
+    for c in cpus:
+        try:
+            l3 = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read().strip()
+        except OSError:
+            l3 = str(c // 8)
+        if l3 not in seen:
+            seen.add(l3)
+            picked.append(c)
+    if len(picked) < count:
+        step = max(1, len(cpus) // count)
+        picked = cpus[::step]
+    return picked[:count]
+
+
+def node_measure(device, G=32768, N=3, rounds=24):
     """SURVEY 8f-2 end to end: N raft nodes (raftq_node, one per peer slot, all on this GPU) for the
     same G groups over an in-memory transport -- elections by batched Tick + Step, then `rounds`
-    waves of one proposal per group on its leader, cranked until every node has delivered every
-    entry on its commit channels.  Wall time of the whole crank (Python loop, status polls, the in-process transport
-    raftq_node_forward); the N nodes' turns run on N threads."""
+    waves of one proposal per group on its leader, each cranked until every node has delivered every
+    entry on its commit channels (closed loop: one wave in flight).  Wall time of the whole crank (Python loop, status
+    polls, the in-process transport raftq_node_forward); the N nodes' turns run on N threads, each on a core of its own
+    under its own L3 slice, as N machines would give them; Tick fires every 100 ms of wall time like the reference's
+    ticker (raft.go:217) -- rounds 1-2 ticked once per wave instead, a third more messages than a running cluster sees."""
     from raftsql_amd.node import Cluster
 
     before = os.sched_getaffinity(0)
@@ -735,14 +755,16 @@ def node_measure(device, G=32768, N=3, rounds=6):
     if near:
         os.sched_setaffinity(0, near)  # threads created below inherit it
     try:
-        return _node_measure(Cluster, device, G, N, rounds, pinned=bool(near))
+        return _node_measure(Cluster, device, G, N, rounds, near)
     finally:
         os.sched_setaffinity(0, before)
 
 
-def _node_measure(Cluster, device, G, N, rounds, pinned):
+def _node_measure(Cluster, device, G, N, rounds, near):
     # one thread per node, as N machines would run; the frames go from node to node inside the library (raftq_node_forward)
-    c = Cluster(G, N, device=device, seed=5, threads=True, native_transport=True)
+    cores = one_cpu_per_l3(near or os.sched_getaffinity(0), N + 1)
+    pin = cores[1:] if len(cores) == N + 1 else None  # cores[0] is left to this thread (the crank)
+    c = Cluster(G, N, device=device, seed=5, threads=True, native_transport=True, pin_cpus=pin)
     c.start()
     t0 = time.perf_counter()
     ticks = 0
@@ -757,31 +779,55 @@ def _node_measure(Cluster, device, G, N, rounds, pinned):
     c.settle()
     t_elect = time.perf_counter() - t0
     lead = c.leaders()
-    base = [nd.stats() for nd in c.nodes]
-    t0 = time.perf_counter()
-    for r in range(rounds):
-        for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
-            mine = np.nonzero(lead == p)[0]
-            nd.propose_batch(mine, [b"INSERT INTO t (v) VALUES (%d)" % r] * len(mine))
-        want = (r + 1) * G
-        for _ in range(40):
-            c.step(tick=False)
-            if all(nd.stats()["entries_published"] - b["entries_published"] >= want for nd, b in zip(c.nodes, base)):
-                break
-            if _ % 3 == 2:
-                c.step(tick=True)  # a heartbeat carries the commit index to the followers
-        else:
-            raise SystemExit("node_measure: a proposal wave did not commit everywhere")
-    dt = time.perf_counter() - t0
+    mine = [np.nonzero(lead == p)[0] for p in range(N)]
+
+    def waves(count, payload_of):
+        """-> (seconds, cluster steps, ticks fired)"""
+        base = [nd.stats() for nd in c.nodes]
+        done = [0] * N  # entries every node has put on its commit channels since `base`
+        steps = fired = 0
+        t0 = next_tick = time.perf_counter()
+        next_tick += 0.1
+        for r in range(count):
+            stmt = payload_of(r)
+            for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
+                k = len(mine[p])
+                nd.propose_blob(mine[p], np.arange(k + 1, dtype=np.uint64) * len(stmt), stmt * k)
+            want = (r + 1) * G
+            for _ in range(60):
+                due = time.perf_counter() >= next_tick
+                if due:
+                    next_tick += 0.1
+                    fired += 1
+                c.step(tick=due)
+                steps += 1
+                for p in range(N):
+                    done[p] += c.last_published[p]
+                if min(done) >= want:
+                    break
+            else:
+                raise SystemExit("node_measure: a proposal wave did not commit everywhere")
+        return time.perf_counter() - t0, steps, fired, base
+
+    waves(2, lambda r: b"INSERT INTO t (v) VALUES (-%d)" % r)  # warm-up: buffers reach their size
+    sec0 = dict(c.seconds)
+    dt, steps, fired, base = waves(rounds, lambda r: b"INSERT INTO t (v) VALUES (%d)" % r)
+    sec = {k: c.seconds[k] - sec0[k] for k in sec0}
     st = [nd.stats() for nd in c.nodes]
     stepped = sum(s["msgs_stepped"] - b["msgs_stepped"] for s, b in zip(st, base))
+    for s_, b in zip(st, base):  # the crank's own count against the nodes' counters
+        assert s_["entries_published"] - b["entries_published"] == rounds * G, (s_, b)
     c.close()
     return {"what": "raftq_node x%d on one GPU, %d groups: propose on the leader -> MsgApp -> MsgAppResp -> batched "
-                    "Step -> commit -> delivered on every node's commit channel" % (N, G),
-            "groups": G, "nodes": N, "pinned_to_the_gpus_numa_node": pinned, "election_s": t_elect, "election_ticks": ticks,
-            "leaders_per_node": np.bincount(lead, minlength=N).tolist(),
+                    "Step -> commit -> delivered on every node's commit channel; one wave in flight" % (N, G),
+            "groups": G, "nodes": N, "pinned_to_the_gpus_numa_node": bool(near), "node_thread_cpus": pin,
+            "election_s": t_elect, "election_ticks": ticks,
+            "leaders_per_node": np.bincount(lead, minlength=N).tolist(), "waves": rounds,
+            "cluster_steps_per_wave": steps / rounds, "ticks_during_waves": fired, "msgs_per_proposal": stepped / (rounds * G),
             "proposals_committed_everywhere_per_s": rounds * G / dt, "msgs_stepped_per_s": stepped / dt,
-            "s_per_wave": dt / rounds}
+            "s_per_wave": dt / rounds,
+            "ms_per_cluster_step": {"all": 1e3 * dt / steps, "node_turns_in_parallel": 1e3 * sec["turns"] / steps,
+                                    "transport": 1e3 * sec["transport"] / steps}}
 
 
 def cpu_baseline(cfg, st, budget_s=12.0):

@@ -140,6 +140,23 @@ int raftq_node_poll(raftq_node_t* n, uint32_t to_peer, void* buf, uint64_t cap, 
  * *moved (may be NULL) = bytes taken off `from`'s queue.  The two nodes' locks are never held together. */
 int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, uint64_t* moved);
 
+/* The nodes of ONE process turned in lock-step, each on a thread of its own (thread p pinned to cpus[p] when cpus != NULL
+ * and cpus[p] >= 0): what the reference's tests do with three raftNodes in one process (raftsql_test.go:11-35).
+ * nodes[p] must be peer slot p of an n-peer cluster (n <= 32) or NULL (a stopped node, never live); the crank does not
+ * own them and must be destroyed first.
+ * raftq_crank_step = for every node p with bit p of live_mask set: raftq_node_tick (when tick != 0) and
+ * raftq_node_advance, all at once; then, all at once per ADDRESSEE q, raftq_node_forward(p -> q) for every live sender p
+ * in slot order -- dropped instead when q is not live or lost[q * n + p] != 0 (lost may be NULL).  So what a node receives
+ * in a step, and in which order, does not depend on thread timing.  published[p] (may be NULL) = entries node p put on
+ * its commit channels; node_rc[p] (may be NULL) = node p's first error; returns the first non-zero of those. */
+typedef struct raftq_crank raftq_crank_t;
+int raftq_crank_create(raftq_node_t* const* nodes, uint32_t n, const int* cpus /*[n]|NULL*/, raftq_crank_t** out);
+int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost /*[n*n]|NULL*/,
+                     uint64_t* published /*[n]|NULL*/, int* node_rc /*[n]|NULL*/);
+/* wall time of all steps so far, by half: every node's turn (the slowest decides), the transport */
+void raftq_crank_seconds(const raftq_crank_t* c, double* turns, double* transport);
+void raftq_crank_destroy(raftq_crank_t* c);
+
 /* whole WAL frames produced so far, at most cap bytes; *len = bytes written (0 = nothing pending) */
 int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len);
 

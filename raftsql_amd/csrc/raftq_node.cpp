@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +21,13 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
+
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 namespace {
 
@@ -68,16 +75,52 @@ struct Entry {  // a view: the log's entries point into the arena, a message's i
   uint32_t len;
 };
 
-struct Item {
-  int kind;
+struct Item {  // 16 bytes
   const char* data;
   uint32_t len;
+  int32_t kind;
 };
 
-struct InMsg {  // a received (or locally raised) message: header + its entries' range in the turn's decoded array
-  raftq_msg_t h;
-  uint32_t ent_first, n_ents;
+// A growable array in 16 bytes (std::vector takes 24) for the two arrays every group has, so that both headers share the
+// group's one hot cache line.  Trivially copyable elements only; the first element gets room for eight (the first appends of
+// 10^5 groups are otherwise 10^5 x (1, 2, 4, 8)-element reallocations inside a turn); growth failure throws std::bad_alloc
+// like std::vector's (advance() catches it).
+template <typename T> struct TinyVec {
+  T* p = nullptr;
+  uint32_t n = 0, cap = 0;
+  TinyVec() = default;
+  TinyVec(const TinyVec&) = delete;
+  TinyVec& operator=(const TinyVec&) = delete;
+  TinyVec(TinyVec&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+  ~TinyVec() { std::free(p); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T& back() { return p[n - 1]; }
+  const T& back() const { return p[n - 1]; }
+  T* data() { return p; }
+  void clear() { n = 0; }
+  void truncate(size_t k) {
+    if (k < n) n = (uint32_t)k;
+  }
+  void push_back(const T& v) {
+    if (n == cap) {
+      if (cap >= 0x80000000u) throw std::bad_alloc();
+      const uint32_t nc = cap ? cap * 2 : 8;
+      void* q = std::realloc(p, (size_t)nc * sizeof(T));
+      if (!q) throw std::bad_alloc();
+      p = (T*)q;
+      cap = nc;
+    }
+    p[n++] = v;
+  }
 };
+
+// A received (or locally raised) message is a raftq_wire_msg_t: the decoder's record, which is also what Step takes (the
+// layouts agree in every field Step reads, raftq_wire.h).  The turn's lists hold POSITIONS: a decoded message's index in
+// the decoder's output, or kLocal | index into the turn's locally raised ones (MsgHup) -- nothing is copied per round.
+constexpr uint32_t kLocal = 0x80000000u;
 
 // proposals queued by raftq_node_propose[_batch] until the next advance(): one blob, no string per proposal
 struct PropBuf {
@@ -143,27 +186,46 @@ struct PinBuf {
   template <typename T> size_t count() const { return size / sizeof(T); }
 };
 
-struct Group {
-  std::vector<Entry> log;  // log[i] holds index i + 1 (no compaction)
-  uint64_t committed = 0, applied = 0, term = 0;
-  uint32_t lead = 0, vote = 0;
+struct alignas(64) Group {
+  // -- the cache line every message of the group touches
+  uint64_t term = 0, committed = 0, applied = 0;
+  TinyVec<Entry> log;  // log[i] holds index i + 1 (no compaction)
+  TinyVec<Item> q;     // commit channel: q[qhead ..) waits for raftq_node_recv
+  uint16_t lead = 0, vote = 0;  // 0 = None, else peer slot + 1
   uint8_t role = RAFTQ_ROLE_FOLLOWER;
-  std::vector<uint64_t> next, match;  // leader only: Progress.Next / mirror of Progress.Match
-  std::vector<Item> q;                // commit channel
-  size_t qhead = 0;
-  uint64_t hs_term = 0, hs_commit = 0;  // raftq_node_set_hard_state
+  bool leading = false;    // this node keeps the group's Progress (raftq_node::prog): it is (or was just elected) leader
+  bool wal_dirty = false;
+  // -- the rest
+  uint32_t qhead = 0;
   uint32_t hs_vote = 0;
+  uint64_t hs_term = 0, hs_commit = 0;  // raftq_node_set_hard_state
   // WAL bookkeeping (raftq_node_wal_enable): what wal.Save has been handed so far
   uint64_t wal_upto = 0;                 // entries [1, wal_upto] are in the WAL as they stand in `log`
   uint64_t wal_term = 0, wal_commit = 0;  // the last HardState record written
   uint32_t wal_vote = 0;
-  bool wal_dirty = false;
 };
+static_assert(sizeof(Group) == 128 && offsetof(Group, qhead) == 64, "a group's hot state is one cache line");
 
 // frames queued for one peer: rafthttp stream frames (u64 big-endian length | raftpb.Message), back to back
 struct PeerQueue {
   std::string bytes;
   size_t head = 0;  // bytes before `head` were polled
+  // where every frame of `bytes` ends (the encoder's offsets): raftq_node_forward hands them to the receiving node, which
+  // then has nothing to scan.  Kept only while nothing was polled from the queue (`ends_ok`).
+  std::vector<uint64_t> ends;
+  bool ends_ok = true;
+  void reset() {
+    bytes.clear();
+    ends.clear();
+    head = 0;
+    ends_ok = true;
+  }
+};
+
+// this turn's messages for one peer, in the order of the sends, and an upper bound of their encoded size
+struct OutLane {
+  std::vector<raftq_wire_msg_t> msgs;
+  uint64_t cap = 0;
 };
 
 constexpr uint64_t kMaxEntriesPerMsg = 1024;     // with kMaxBytesPerMsg: raft.Config.MaxSizePerMsg (raft.go:157)
@@ -190,15 +252,17 @@ struct raftq_node {
   // inbound stream frames as delivered (decoded on the GPU at the next advance)
   PinBuf in_bytes;
   std::vector<uint64_t> in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size]
-  // this turn's outbound messages, marshalled in one raftq_wire_encode at the end of advance()
-  std::vector<raftq_wire_msg_t> out_msgs;
+  // this turn's outbound messages, one lane per addressee, marshalled in one raftq_wire_encode at the end of advance()
+  std::vector<OutLane> out_lane;
+  // Progress.Next / Progress.Match mirror of the groups this node leads: prog[(g * N + peer) * 2 + {0: Next, 1: Match}]
+  std::vector<uint64_t> prog;
   PinBuf out_ents;  // raftq_wire_ent_t[]
   PinBuf out_pool;  // entry payload bytes
   bool out_oom = false;
   // advance()'s own scratch (only touched under turn_mu): the other half of the inbound double buffer,
   // decoded records, the sorted outbound batch and its stream
   PinBuf turn_bytes, turn_msgs, turn_ents, enc_msgs, enc_out, wal_recs, wal_pool, wal_enc;
-  std::vector<uint64_t> turn_off, enc_off;
+  std::vector<uint64_t> turn_off, enc_off, lane_first;
   // WAL (off unless raftq_node_wal_enable): encoded records waiting for raftq_node_wal_poll
   bool wal_on = false, wal_head_written = false;
   uint32_t wal_crc = 0;
@@ -208,8 +272,10 @@ struct raftq_node {
   uint64_t shared_group = ~0ull, shared_first_idx = 0, shared_cnt = 0;
   uint32_t shared_ent_first = 0;
   // RAFTQ_PROFILE=1: host time of advance()'s phases, printed at destroy
-  enum { kPhDecode, kPhInbound, kPhTick, kPhStage, kPhStep, kPhApply, kPhDeltas, kPhProps, kPhWal, kPhEncode, kPhN };
+  enum { kPhDecode, kPhInbound, kPhTick, kPhStage, kPhStep, kPhApply, kPhDeltas, kPhProps, kPhWal, kPhEncode, kPhDevDeltas,
+         kPhDevEncode, kPhN };  // the last two: the device calls inside the deltas / props and the encode phases
   double prof[kPhN] = {0};
+  struct PhaseClock* clock = nullptr;  // the running advance()'s phase clock (RAFTQ_PROFILE)
   uint64_t prof_turns = 0, prof_every = 0;  // RAFTQ_PROFILE_EVERY=k: print and reset every k turns
   bool profiling = false;
   bool started = false, closed = false;
@@ -219,9 +285,9 @@ struct raftq_node {
   raftq_node_stats_t stats{};
   // scratch of advance()
   std::vector<uint64_t> tick_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
-  std::vector<InMsg> work, batch, deferred, hups;
+  std::vector<uint32_t> work, batch, deferred;  // positions (see kLocal)
+  std::vector<raftq_wire_msg_t> local;          // the turn's locally raised messages (MsgHup)
   std::vector<Entry> ent_tmp;
-  std::vector<size_t> step_idx;
   // per-group marks of one Step round: blocked (a log-changing message of the group is in this batch) and dirty
   // (its log grew); a mark is set when it equals the round's epoch -- no hashing, no clearing
   std::vector<uint32_t> blocked_mark, dirty_mark;
@@ -229,9 +295,44 @@ struct raftq_node {
   uint32_t epoch = 0;
   std::vector<raftq_log_delta_t> deltas;
   std::vector<uint64_t> delta_commit;
+  uint64_t& next_of(uint64_t g, uint32_t peer) { return prog[(g * N + peer) * 2]; }
+  uint64_t& match_of(uint64_t g, uint32_t peer) { return prog[(g * N + peer) * 2 + 1]; }
+};
+
+struct PhaseClock {  // accumulates wall time into n->prof[which] when RAFTQ_PROFILE is set
+  raftq_node_t* n;
+  int which;
+  std::chrono::steady_clock::time_point t0;
+  PhaseClock(raftq_node_t* node, int w) : n(node), which(w) {
+    if (n->profiling) t0 = std::chrono::steady_clock::now();
+    n->clock = this;
+  }
+  void next(int w) {
+    if (!n->profiling) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    n->prof[which] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    which = w;
+    t0 = t1;
+  }
+  ~PhaseClock() {
+    next(which);
+    n->clock = nullptr;
+  }
 };
 
 namespace {
+
+// a device call inside a host phase: its time goes to its own bucket
+struct DevCall {
+  raftq_node_t* n;
+  int back;
+  DevCall(raftq_node_t* node, int bucket) : n(node), back(node->clock ? node->clock->which : 0) {
+    if (n->clock) n->clock->next(bucket);
+  }
+  ~DevCall() {
+    if (n->clock) n->clock->next(back);
+  }
+};
 
 int nfail(raftq_node_t* n, int code, const std::string& msg) {
   if (n) {
@@ -258,50 +359,54 @@ uint64_t term_at(const Group& g, uint64_t index) {
   return (index == 0 || index > g.log.size()) ? 0 : g.log[index - 1].term;
 }
 
-// r.send(m): queue one raftpb.Message for peer `to`.  Nothing is marshalled here -- the headers, entry
-// ranges and payload bytes of the whole turn go through one raftq_wire_encode at the end of advance().
-// Entries carry explicit indices on the wire: hdr.index + 1 + k for MsgApp, 0 for a forwarded MsgProp.
-void put_frame(raftq_node_t* n, uint32_t to, const raftq_msg_t& hdr, const Entry* ents, size_t n_ents) {
-  raftq_wire_msg_t m;
-  std::memset(&m, 0, sizeof(m));
-  m.group = hdr.group;
-  m.term = hdr.term;
-  m.log_term = hdr.log_term;
-  m.index = hdr.index;
-  m.commit = hdr.commit;
-  m.reject_hint = hdr.reject_hint;
-  m.from = hdr.from;
-  m.type = hdr.type;
-  m.reject = hdr.reject;
+// r.send(m): queue one raftpb.Message for peer `to`.  Nothing is marshalled here -- the headers, entry ranges and
+// payload bytes of the whole turn go through one raftq_wire_encode at the end of advance().  Returns the queued record
+// (valid until the next send to the same peer): the caller sets what the kind carries beyond group / type / term.
+raftq_wire_msg_t& send(raftq_node_t* n, uint32_t to, uint64_t group, uint8_t type, uint64_t term) {
+  OutLane& lane = n->out_lane[to];
+  lane.msgs.emplace_back();  // zeroed
+  lane.cap += 160;           // 12 varint fields + tags + the empty snapshot
+  raftq_wire_msg_t& m = lane.msgs.back();
+  m.group = group;
+  m.term = term;  // raft.send: every non-MsgProp message carries r.Term
+  m.from = n->self;
+  m.type = type;
   m.to = (uint8_t)to;
-  m.ent_first = n_ents ? (uint32_t)n->out_ents.count<raftq_wire_ent_t>() : 0;
+  n->stats.msgs_sent++;
+  return m;
+}
+
+// the entries of the message queued last for `to`.  They carry explicit indices on the wire: m.index + 1 + k for MsgApp,
+// 0 for a forwarded MsgProp.
+void attach(raftq_node_t* n, uint32_t to, raftq_wire_msg_t& m, const Entry* ents, size_t n_ents) {
+  if (n_ents == 0) return;
+  OutLane& lane = n->out_lane[to];
   m.n_ents = (uint32_t)n_ents;
   // bcastAppend sends most followers the same suffix: the encoder takes arbitrary entry ranges, so the
   // second and later messages point at the first one's entries instead of queueing copies
-  const bool app = hdr.type == RAFTQ_MSG_APP && n_ents != 0;
-  if (app && n->shared_group == hdr.group && n->shared_first_idx == hdr.index + 1 && n->shared_cnt == n_ents) {
+  const bool app = m.type == RAFTQ_MSG_APP;
+  if (app && n->shared_group == m.group && n->shared_first_idx == m.index + 1 && n->shared_cnt == n_ents) {
     m.ent_first = n->shared_ent_first;
-    n->out_msgs.push_back(m);
-    n->stats.msgs_sent++;
+    for (size_t i = 0; i < n_ents; ++i) lane.cap += 48 + ents[i].len;
     return;
   }
+  m.ent_first = (uint32_t)n->out_ents.count<raftq_wire_ent_t>();
   if (app) {
-    n->shared_group = hdr.group;
-    n->shared_first_idx = hdr.index + 1;
+    n->shared_group = m.group;
+    n->shared_first_idx = m.index + 1;
     n->shared_cnt = n_ents;
     n->shared_ent_first = m.ent_first;
   }
   for (size_t i = 0; i < n_ents; ++i) {
     raftq_wire_ent_t e;
-    std::memset(&e, 0, sizeof(e));
     e.term = ents[i].term;
-    e.index = hdr.type == RAFTQ_MSG_APP ? hdr.index + 1 + i : 0;
+    e.index = app ? m.index + 1 + i : 0;
     e.data_len = ents[i].len;
     e.data_off = e.data_len ? n->out_pool.size : 0;
+    e.type = 0;
+    lane.cap += 48 + ents[i].len;
     if (!n->out_pool.append(ents[i].data, ents[i].len) || !n->out_ents.append(&e, sizeof(e))) n->out_oom = true;
   }
-  n->out_msgs.push_back(m);
-  n->stats.msgs_sent++;
 }
 
 void wal_touch(raftq_node_t* n, uint64_t gi, Group& g) {
@@ -311,13 +416,14 @@ void wal_touch(raftq_node_t* n, uint64_t gi, Group& g) {
   }
 }
 
-raftq_msg_t header(const raftq_node_t* n, uint64_t group, uint8_t type, uint64_t term) {
-  raftq_msg_t m;
+// a locally raised message (MsgHup): term 0 marks it local
+raftq_wire_msg_t local_msg(const raftq_node_t* n, uint64_t group, uint8_t type) {
+  raftq_wire_msg_t m;
   std::memset(&m, 0, sizeof(m));
   m.group = group;
   m.type = type;
-  m.term = term;  // raft.send: every non-MsgProp message carries r.Term
   m.from = n->self;
+  m.to = (uint8_t)n->self;
   return m;
 }
 
@@ -328,10 +434,17 @@ void publish(raftq_node_t* n, Group& g, uint64_t upto) {
   for (uint64_t idx = g.applied + 1; idx <= upto; ++idx) {
     const Entry& e = g.log[idx - 1];
     if (e.len == 0) continue;
-    g.q.push_back(Item{RAFTQ_NODE_ENTRY, e.data, e.len});
+    g.q.push_back(Item{e.data, e.len, RAFTQ_NODE_ENTRY});
     n->stats.entries_published++;
   }
   if (upto > g.applied) g.applied = upto;
+}
+
+// the lines a publication of g's next entries will touch (g's own line is expected in cache): the log from `applied` on,
+// the commit channel's tail
+inline void ahead_of_publish(const Group& g) {
+  if (g.applied < g.log.size()) __builtin_prefetch(&g.log[g.applied]);
+  if (g.q.p) __builtin_prefetch(g.q.p + g.q.n, 1);
 }
 
 void note_commit(raftq_node_t* n, Group& g, uint64_t commit) {
@@ -346,9 +459,10 @@ void note_commit(raftq_node_t* n, Group& g, uint64_t commit) {
 // index.  Optimistic cursor (ProgressStateReplicate): Next jumps past what was sent.
 void send_append(raftq_node_t* n, uint64_t gi, Group& g, uint32_t to) {
   const uint64_t last = g.log.size();
-  uint64_t nx = std::max<uint64_t>(g.next[to], 1);
+  uint64_t& next = n->next_of(gi, to);
+  uint64_t nx = std::max<uint64_t>(next, 1);
   if (nx > last + 1) nx = last + 1;
-  raftq_msg_t m = header(n, gi, RAFTQ_MSG_APP, g.term);
+  raftq_wire_msg_t& m = send(n, to, gi, RAFTQ_MSG_APP, g.term);
   m.index = nx - 1;
   m.log_term = term_at(g, nx - 1);
   m.commit = g.committed;
@@ -357,8 +471,8 @@ void send_append(raftq_node_t* n, uint64_t gi, Group& g, uint32_t to) {
     bytes += g.log[nx + cnt - 1].len;
     ++cnt;
   }
-  put_frame(n, to, m, cnt ? &g.log[nx - 1] : nullptr, cnt);
-  g.next[to] = nx + cnt;
+  if (cnt) attach(n, to, m, &g.log[nx - 1], cnt);
+  next = nx + cnt;
 }
 
 void bcast_append(raftq_node_t* n, uint64_t gi, Group& g) {
@@ -370,9 +484,8 @@ void bcast_append(raftq_node_t* n, uint64_t gi, Group& g) {
 void bcast_heartbeat(raftq_node_t* n, uint64_t gi, Group& g) {
   for (uint32_t p = 0; p < n->N; ++p) {
     if (p == n->self) continue;
-    raftq_msg_t m = header(n, gi, RAFTQ_MSG_HEARTBEAT, g.term);
-    m.commit = std::min(g.match.empty() ? 0 : g.match[p], g.committed);
-    put_frame(n, p, m, nullptr, 0);
+    raftq_wire_msg_t& m = send(n, p, gi, RAFTQ_MSG_HEARTBEAT, g.term);
+    m.commit = std::min(g.leading ? n->match_of(gi, p) : 0, g.committed);
   }
 }
 
@@ -392,9 +505,9 @@ bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, const Entry* ents, 
     if (n_ents) wal_touch(n, gi, g);
     return n_ents != 0;
   }
-  if (g.lead != 0 && g.lead - 1 != n->self) {  // stepFollower MsgProp: `m.To = r.lead; r.send(m)`
-    raftq_msg_t m = header(n, gi, RAFTQ_MSG_PROP, 0);
-    put_frame(n, g.lead - 1, m, ents, n_ents);
+  if (g.lead != 0 && (uint32_t)(g.lead - 1) != n->self) {  // stepFollower MsgProp: `m.To = r.lead; r.send(m)`
+    raftq_wire_msg_t& m = send(n, g.lead - 1, gi, RAFTQ_MSG_PROP, 0);
+    attach(n, g.lead - 1, m, ents, n_ents);
   } else {
     n->stats.proposals_dropped += n_ents;  // no leader: etcd drops the proposal
   }
@@ -402,22 +515,21 @@ bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, const Entry* ents, 
 }
 
 // handleAppendEntries on the log's owner, after Step accepted the header (RAFTQ_OUT_APPEND)
-void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const InMsg& im, std::vector<raftq_log_delta_t>& deltas) {
-  const raftq_msg_t& m = im.h;
-  const raftq_wire_ent_t* ents = n->cur_ents + im.ent_first;
-  raftq_msg_t r = header(n, gi, RAFTQ_MSG_APP_RESP, g.term);
+void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_msg_t& m) {
+  const raftq_wire_ent_t* ents = n->cur_ents + m.ent_first;
+  raftq_wire_msg_t& r = send(n, m.from, gi, RAFTQ_MSG_APP_RESP, g.term);
   if (m.index < g.committed) {  // `if m.Index < r.raftLog.committed { send MsgAppResp{Index: committed} }`
     r.index = g.committed;
-    put_frame(n, m.from, r, nullptr, 0);
     return;
   }
-  if (m.index <= g.log.size() && term_at(g, m.index) == m.log_term) {  // raftLog.maybeAppend
+  const uint64_t have = g.log.size();
+  if (m.index <= have && term_at(g, m.index) == m.log_term) {  // raftLog.maybeAppend
     size_t k = 0;
-    for (; k < im.n_ents; ++k) {  // findConflict
+    for (; k < m.n_ents; ++k) {  // findConflict
       const uint64_t idx = m.index + 1 + k;
       if (idx > g.log.size()) break;
       if (g.log[idx - 1].term != ents[k].term) {
-        g.log.resize(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
+        g.log.truncate(idx - 1);  // a conflicting suffix is never committed (Raft 5.3)
         g.wal_upto = std::min<uint64_t>(g.wal_upto, idx - 1);  // the WAL gets the replacement entries again
         // replayWAL published the whole log, committed or not (raft.go:122-134), so `applied` may sit beyond the
         // truncation point: the replacement entries at those indices must reach the commit channel once they
@@ -427,29 +539,29 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const InMsg& im, st
         break;
       }
     }
-    for (; k < im.n_ents; ++k) {
+    for (; k < m.n_ents; ++k) {
       const char* at = n->arena.put(n->cur_bytes + ents[k].data_off, ents[k].data_len);
       if (!at) {  // out of memory: the node poisons itself at the end of this turn; do not acknowledge what is not stored
         n->oom = true;
+        n->out_lane[m.from].msgs.pop_back();
+        n->stats.msgs_sent--;
         return;
       }
       g.log.push_back(Entry{ents[k].term, at, ents[k].data_len});
     }
     wal_touch(n, gi, g);
-    const uint64_t lastnewi = m.index + im.n_ents;
+    const uint64_t lastnewi = m.index + m.n_ents;
     r.index = lastnewi;
-    put_frame(n, m.from, r, nullptr, 0);
     raftq_log_delta_t d;
     d.group = gi;
     d.last_index = g.log.size();
     d.last_term = term_at(g, g.log.size());
     d.commit_to = std::min(m.commit, lastnewi);  // `commitTo(min(m.Commit, lastnewi))`
-    deltas.push_back(d);
+    n->deltas.push_back(d);
   } else {  // reject with the hint
     r.index = m.index;
     r.reject = 1;
-    r.reject_hint = g.log.size();
-    put_frame(n, m.from, r, nullptr, 0);
+    r.reject_hint = have;
   }
 }
 
@@ -460,88 +572,96 @@ int flush_deltas(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   if (n->deltas.empty()) return RAFTQ_OK;
   n->delta_commit.resize(n->deltas.size());
   lk.unlock();
-  const int rc = raftq_apply_log_deltas(n->h, n->deltas.data(), n->deltas.size(), n->delta_commit.data());
+  int rc;
+  {
+    DevCall dev(n, raftq_node::kPhDevDeltas);
+    rc = raftq_apply_log_deltas(n->h, n->deltas.data(), n->deltas.size(), n->delta_commit.data());
+  }
   if (rc != RAFTQ_OK) return rc;
   lk.lock();
-  for (size_t i = 0; i < n->deltas.size(); ++i) note_commit(n, n->groups[n->deltas[i].group], n->delta_commit[i]);
+  const size_t nd = n->deltas.size();
+  for (size_t i = 0; i < nd; ++i) {
+    if (i + 16 < nd) __builtin_prefetch(&n->groups[n->deltas[i + 16].group]);
+    if (i + 8 < nd) ahead_of_publish(n->groups[n->deltas[i + 8].group]);
+    note_commit(n, n->groups[n->deltas[i].group], n->delta_commit[i]);
+  }
   n->deltas.clear();
   return RAFTQ_OK;
 }
 
 // what one Step result means for the node (the "Ready" consequences of one message)
-void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const InMsg& im) {
-  Group& g = n->groups[o.group];
-  const uint64_t gi = o.group;
+void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const raftq_wire_msg_t& im) {
+  const uint64_t gi = im.group;
+  Group& g = n->groups[gi];
   g.term = o.term;
-  g.lead = o.lead;
-  g.vote = o.vote;
+  g.lead = (uint16_t)o.lead;
+  g.vote = (uint16_t)o.vote;
   g.role = o.role;
-  if (o.flags & RAFTQ_OUTF_HARDSTATE) {
-    n->stats.hard_states++;  // wal.Save(rd.HardState, ...) (raft.go:228)
-    wal_touch(n, gi, g);
-  }
-  if (o.flags & RAFTQ_OUTF_STEPPED_DOWN) {
-    g.next.clear();
-    g.match.clear();
+  if (o.flags & (RAFTQ_OUTF_HARDSTATE | RAFTQ_OUTF_STEPPED_DOWN)) {
+    if (o.flags & RAFTQ_OUTF_HARDSTATE) {
+      n->stats.hard_states++;  // wal.Save(rd.HardState, ...) (raft.go:228)
+      wal_touch(n, gi, g);
+    }
+    if (o.flags & RAFTQ_OUTF_STEPPED_DOWN) g.leading = false;
   }
   note_commit(n, g, o.commit);
   switch (o.type) {
-    case RAFTQ_OUT_VOTE_RESP: {
-      raftq_msg_t r = header(n, gi, RAFTQ_MSG_VOTE_RESP, o.term);
-      r.reject = o.reject;
-      put_frame(n, o.to, r, nullptr, 0);
+    case RAFTQ_OUT_VOTE_RESP:
+      send(n, o.to, gi, RAFTQ_MSG_VOTE_RESP, o.term).reject = o.reject;
       break;
-    }
-    case RAFTQ_OUT_HEARTBEAT_RESP: {
-      raftq_msg_t r = header(n, gi, RAFTQ_MSG_HEARTBEAT_RESP, o.term);
-      put_frame(n, o.to, r, nullptr, 0);
+    case RAFTQ_OUT_HEARTBEAT_RESP:
+      send(n, o.to, gi, RAFTQ_MSG_HEARTBEAT_RESP, o.term);
       break;
-    }
     case RAFTQ_OUT_CAMPAIGN:
       for (uint32_t p = 0; p < n->N; ++p) {
         if (p == n->self) continue;
-        raftq_msg_t r = header(n, gi, RAFTQ_MSG_VOTE, o.term);
+        raftq_wire_msg_t& r = send(n, p, gi, RAFTQ_MSG_VOTE, o.term);
         r.index = o.index;
         r.log_term = o.log_term;
-        put_frame(n, p, r, nullptr, 0);
       }
       break;
     case RAFTQ_OUT_BECAME_LEADER:
       // becomeLeader's appendEntry(pb.Entry{Data: nil}): the engine already counted it
-      g.log.resize(std::min<uint64_t>(g.log.size(), o.index - 1));
+      g.log.truncate(o.index - 1);
       g.wal_upto = std::min<uint64_t>(g.wal_upto, g.log.size());
       n->shared_group = ~0ull;
-      g.log.push_back(Entry{o.term, "", 0});
+        g.log.push_back(Entry{o.term, "", 0});
       wal_touch(n, gi, g);
-      g.next.assign(n->N, o.index);  // reset(): Next = lastIndex + 1 (before the empty entry)
-      g.match.assign(n->N, 0);
-      g.match[n->self] = o.index;
-      g.next[n->self] = o.index + 1;
+      for (uint32_t p = 0; p < n->N; ++p) {  // reset(): Next = lastIndex + 1 (before the empty entry)
+        n->next_of(gi, p) = o.index;
+        n->match_of(gi, p) = 0;
+      }
+      g.leading = true;
+      n->match_of(gi, n->self) = o.index;
+      n->next_of(gi, n->self) = o.index + 1;
       note_commit(n, g, o.commit);
       bcast_append(n, gi, g);
       break;
-    case RAFTQ_OUT_PROGRESS:
-      if (g.next.empty()) break;
-      if (im.h.type == RAFTQ_MSG_APP_RESP && im.h.reject) {
+    case RAFTQ_OUT_PROGRESS: {
+      if (!g.leading) break;
+      uint64_t& next = n->next_of(gi, o.to);
+      uint64_t& match = n->match_of(gi, o.to);
+      if (im.type == RAFTQ_MSG_APP_RESP && im.reject) {
         // Progress.maybeDecrTo: a stale rejection is ignored, else back off to the hint
-        if (im.h.index > g.match[o.to]) {
-          g.next[o.to] = std::max<uint64_t>(std::min(im.h.index, im.h.reject_hint + 1), g.match[o.to] + 1);
+        if (im.index > match) {
+          next = std::max<uint64_t>(std::min(im.index, im.reject_hint + 1), match + 1);
           send_append(n, gi, g, o.to);
         }
       } else {
-        g.match[o.to] = o.index;
-        if (g.next[o.to] < o.index + 1) g.next[o.to] = o.index + 1;
-        if (im.h.type == RAFTQ_MSG_APP_RESP) {
+        match = o.index;
+        if (next < o.index + 1) next = o.index + 1;
+        if (im.type == RAFTQ_MSG_APP_RESP) {
           if (o.flags & RAFTQ_OUTF_COMMITTED) bcast_append(n, gi, g);  // `if r.maybeCommit() { r.bcastAppend() }`
-          else if (g.next[o.to] <= g.log.size()) send_append(n, gi, g, o.to);
+          else if (next <= g.log.size()) send_append(n, gi, g, o.to);
         } else if (o.index < g.log.size()) {  // MsgHeartbeatResp: `if pr.Match < lastIndex { sendAppend }`
-          if (g.next[o.to] > o.index + 1) g.next[o.to] = o.index + 1;  // whatever was in flight is lost: resend
+          if (next > o.index + 1) next = o.index + 1;  // whatever was in flight is lost: resend
           send_append(n, gi, g, o.to);
         }
       }
       break;
+    }
     case RAFTQ_OUT_APPEND:
-      follower_append(n, gi, g, im, n->deltas);
+      follower_append(n, gi, g, im);
       break;
     default:
       break;
@@ -566,10 +686,8 @@ int poll_queue(raftq_node_t* n, PeerQueue& q, bool big_endian, void* buf, uint64
   }
   if (pos) std::memcpy(buf, p, pos);
   q.head += pos;
-  if (q.head == q.bytes.size()) {
-    q.bytes.clear();
-    q.head = 0;
-  }
+  if (pos) q.ends_ok = false;  // the frame ends no longer start at the queue's first byte
+  if (q.head == q.bytes.size()) q.reset();
   *len = pos;
   if (pos == 0 && avail != 0) {
     n->errtext = "poll: buffer smaller than the next frame";
@@ -581,53 +699,60 @@ int poll_queue(raftq_node_t* n, PeerQueue& q, bool big_endian, void* buf, uint64
 // rc.transport.Send(rd.Messages) (raft.go:230) for the whole turn: one batched marshal on the GPU, then
 // every peer's slice of the stream goes onto its queue.  Lock convention as flush_deltas.
 int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
-  const size_t nm = n->out_msgs.size();
+  size_t nm = 0;
+  uint64_t cap = 0;  // an upper bound of the stream, kept by send() / attach()
+  for (const OutLane& lane : n->out_lane) {
+    nm += lane.msgs.size();
+    cap += lane.cap;
+  }
   if (nm == 0) return RAFTQ_OK;
   if (n->out_oom) {
     lk.unlock();
     return RAFTQ_ENOMEM;
   }
-  // stable counting sort by addressee: per-peer order is the order of the sends
-  std::vector<uint64_t> first(n->N + 1, 0);
-  for (const raftq_wire_msg_t& m : n->out_msgs) first[m.to + 1]++;
-  for (uint32_t p = 0; p < n->N; ++p) first[p + 1] += first[p];
+  // the lanes back to back: per-peer order is the order of the sends, and every peer's frames are one slice of the stream
+  n->enc_msgs.clear();
+  n->enc_off.resize(nm + 1);
+  if (!n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t)) || !n->enc_out.reserve(cap)) {
+    lk.unlock();
+    return RAFTQ_ENOMEM;
+  }
+  std::vector<uint64_t>& first = n->lane_first;
+  first.assign(n->N + 1, 0);
+  for (uint32_t p = 0; p < n->N; ++p) {
+    OutLane& lane = n->out_lane[p];
+    first[p + 1] = first[p] + lane.msgs.size();
+    n->enc_msgs.append(lane.msgs.data(), lane.msgs.size() * sizeof(raftq_wire_msg_t));
+    lane.msgs.clear();
+    lane.cap = 0;
+  }
+  const raftq_wire_msg_t* sorted = n->enc_msgs.as<raftq_wire_msg_t>();
   const raftq_wire_ent_t* ents = n->out_ents.as<raftq_wire_ent_t>();
   const size_t n_ents = n->out_ents.count<raftq_wire_ent_t>();
-  uint64_t cap = 0;  // an upper bound of the stream: 12 varint fields + tags + the empty snapshot per message
-  n->enc_msgs.clear();
-  if (!n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t))) {
-    lk.unlock();
-    return RAFTQ_ENOMEM;
-  }
-  n->enc_msgs.size = nm * sizeof(raftq_wire_msg_t);
-  raftq_wire_msg_t* sorted = n->enc_msgs.as<raftq_wire_msg_t>();
-  {
-    std::vector<uint64_t> at(first.begin(), first.end() - 1);
-    for (const raftq_wire_msg_t& m : n->out_msgs) {
-      sorted[at[m.to]++] = m;
-      cap += 160;
-      for (uint32_t k = 0; k < m.n_ents; ++k) cap += 48 + ents[m.ent_first + k].data_len;  // shared ranges count per use
-    }
-  }
-  n->out_msgs.clear();
   n->shared_group = ~0ull;
-  n->enc_off.resize(nm + 1);
-  if (!n->enc_out.reserve(cap)) {
-    lk.unlock();
-    return RAFTQ_ENOMEM;
-  }
   raftq_wire_counts_t cnt;
-  lk.unlock();  // put_frame only runs inside advance(), which this thread holds (turn_mu): out_* are safe to read unlocked
-  const int rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap,
-                                   n->enc_off.data(), &cnt);
+  lk.unlock();  // send() only runs inside advance(), which this thread holds (turn_mu): out_* are safe to read unlocked
+  int rc;
+  {
+    DevCall dev(n, raftq_node::kPhDevEncode);
+    rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap, n->enc_off.data(), &cnt);
+  }
   if (rc != RAFTQ_OK) return rc;
   lk.lock();
   n->out_ents.clear();
   n->out_pool.clear();
   const uint64_t* off = n->enc_off.data();
-  for (uint32_t p = 0; p < n->N; ++p)
-    if (first[p + 1] > first[p])
-      n->outbound[p].bytes.append((const char*)n->enc_out.p + off[first[p]], (size_t)(off[first[p + 1]] - off[first[p]]));
+  for (uint32_t p = 0; p < n->N; ++p) {
+    if (first[p + 1] == first[p]) continue;
+    PeerQueue& q = n->outbound[p];
+    const uint64_t from = off[first[p]], base = q.bytes.size();
+    q.bytes.append((const char*)n->enc_out.p + from, (size_t)(off[first[p + 1]] - from));
+    if (q.ends_ok) {
+      const size_t at = q.ends.size();
+      q.ends.resize(at + (size_t)(first[p + 1] - first[p]));
+      for (uint64_t k = first[p]; k < first[p + 1]; ++k) q.ends[at + (k - first[p])] = base + (off[k + 1] - from);
+    }
+  }
   return RAFTQ_OK;
 }
 
@@ -702,7 +827,7 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 // seen replaces it and everything after it)
 bool log_put(raftq_node_t* n, Group& g, uint64_t index, uint64_t term, const char* data, uint32_t len) {
   if (index == 0 || index > g.log.size() + 1) return false;
-  if (index <= g.log.size()) g.log.resize(index - 1);
+  if (index <= g.log.size()) g.log.truncate(index - 1);
   const char* at = n->arena.put(data, len);
   if (!at) return false;
   g.log.push_back(Entry{term, at, len});
@@ -734,6 +859,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   try {
     n->groups.resize(n_groups);
     n->outbound.resize(n_peers);
+    n->out_lane.resize(n_peers);
     n->tick_list.resize(std::min<uint64_t>(n_groups, 4096));
     n->blocked_mark.assign(n_groups, 0);
     n->dirty_mark.assign(n_groups, 0);
@@ -806,6 +932,7 @@ int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat
       committed.assign(n->G, 0);
       vote.assign(n->G, 0);
       match.assign((size_t)n->N * n->G, 0);
+      n->prog.assign((size_t)n->N * n->G * 2, 0);
     } catch (...) {
       n->errtext = "start: host allocation failed";
       return RAFTQ_ENOMEM;
@@ -814,9 +941,10 @@ int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat
       Group& g = n->groups[gi];
       // replayWAL (raft.go:122-134): every logged entry goes out, then the nil sentinel
       publish(n, g, g.log.size());
-      g.q.push_back(Item{RAFTQ_NODE_SENTINEL, "", 0});
+        g.q.push_back(Item{"", 0, RAFTQ_NODE_SENTINEL});
       g.term = term[gi] = g.hs_term;
-      g.vote = vote[gi] = g.hs_vote;
+      vote[gi] = g.hs_vote;
+      g.vote = (uint16_t)g.hs_vote;
       g.committed = committed[gi] = std::min<uint64_t>(g.hs_commit, g.log.size());
       last_index[gi] = g.log.size();
       last_term[gi] = term_at(g, g.log.size());
@@ -908,39 +1036,65 @@ int raftq_node_tick(raftq_node_t* n) {
   return RAFTQ_OK;
 }
 
-int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len) {
+// frames -> the node's inbound buffer.  `ends` (may be null): where each of the n_ends frames ends, as the sending node's
+// encoder reported them (raftq_node_forward); without it the length words are walked here.
+static int deliver_impl(raftq_node_t* n, const void* frames, uint64_t len, const uint64_t* ends, size_t n_ends) {
   if (!n) return RAFTQ_EINVAL;
   if (len && !frames) return nfail(n, RAFTQ_EINVAL, "deliver: null buffer");
   if (len == 0) return RAFTQ_OK;
   // the stream reader's part of messageDecoder.decode: the length words must tile the buffer.  The
   // messages themselves are unmarshalled on the GPU, all of this turn's at once, by the next advance().
-  std::vector<uint64_t> off;
-  try {
-    off.resize((size_t)(len / 8) + 2);
-  } catch (...) {
-    return nfail(n, RAFTQ_ENOMEM, "deliver: host allocation failed");
+  const uint8_t* p = (const uint8_t*)frames;
+  uint64_t nf = n_ends;
+  if (!ends) {
+    uint64_t pos = 0;
+    nf = 0;
+    while (len - pos >= 8) {
+      const uint64_t body = load_len(p + pos, true);
+      if (body > len - pos - 8) break;
+      pos += 8 + body;
+      ++nf;
+    }
+    if (pos != len) return nfail(n, RAFTQ_EINVAL, "deliver: not a whole number of stream frames (truncated or garbage)");
   }
-  uint64_t nf = 0, used = 0;
-  raftq_wire_scan_frames(frames, len, 1, off.data(), off.size() - 1, &nf, &used);
-  if (used != len) return nfail(n, RAFTQ_EINVAL, "deliver: not a whole number of stream frames (truncated or garbage)");
   std::lock_guard<std::mutex> lk(n->mu);
   if (!n->started || n->closed) {
     n->errtext = "deliver: node not running";
     return RAFTQ_ESTATE;
   }
   const uint64_t base = n->in_bytes.size;
-  if (!n->in_bytes.append(frames, (size_t)len)) {
-    n->errtext = "deliver: page-locked allocation failed";
+  try {
+    if (n->in_off.empty()) n->in_off.push_back(0);
+    const size_t at = n->in_off.size();
+    n->in_off.resize(at + (size_t)nf);  // before the bytes: a failure here leaves the buffer as it was
+    if (!n->in_bytes.append(frames, (size_t)len)) {
+      n->in_off.resize(at);
+      n->errtext = "deliver: page-locked allocation failed";
+      return RAFTQ_ENOMEM;
+    }
+    uint64_t* off = n->in_off.data() + at;
+    if (ends) {
+      for (uint64_t i = 0; i < nf; ++i) off[i] = base + ends[i];
+    } else {
+      uint64_t pos = 0;
+      for (uint64_t i = 0; i < nf; ++i) {
+        pos += 8 + load_len(p + pos, true);
+        off[i] = base + pos;
+      }
+    }
+  } catch (...) {
+    n->errtext = "deliver: host allocation failed";
     return RAFTQ_ENOMEM;
   }
-  if (n->in_off.empty()) n->in_off.push_back(0);
-  for (uint64_t i = 1; i <= nf; ++i) n->in_off.push_back(base + off[i]);
   return RAFTQ_OK;
 }
 
+int raftq_node_deliver(raftq_node_t* n, const void* frames, uint64_t len) { return deliver_impl(n, frames, len, nullptr, 0); }
+
 namespace {
 void dump_profile(raftq_node_t* n) {
-  static const char* names[raftq_node::kPhN] = {"decode", "inbound", "tick", "stage", "step", "apply", "deltas", "props", "wal", "encode"};
+  static const char* names[raftq_node::kPhN] = {"decode", "inbound", "tick", "stage", "step", "apply", "deltas", "props", "wal", "encode",
+                                                "dev:deltas", "dev:encode"};
   std::fprintf(stderr, "[raftq_node %u] advance phases, total ms over %llu turns (%llu msgs stepped so far):", n->self,
                (unsigned long long)n->prof_turns, (unsigned long long)n->stats.msgs_stepped);
   for (int i = 0; i < raftq_node::kPhN; ++i) std::fprintf(stderr, " %s %.1f", names[i], n->prof[i] / 1e3);
@@ -948,31 +1102,16 @@ void dump_profile(raftq_node_t* n) {
   std::fill(n->prof, n->prof + raftq_node::kPhN, 0.0);
   n->prof_turns = 0;
 }
-struct Phase {  // accumulates wall time into n->prof[which] when RAFTQ_PROFILE is set
-  raftq_node_t* n;
-  int which;
-  std::chrono::steady_clock::time_point t0;
-  Phase(raftq_node_t* node, int w) : n(node), which(w) {
-    if (n->profiling) t0 = std::chrono::steady_clock::now();
-  }
-  void next(int w) {
-    if (!n->profiling) return;
-    const auto t1 = std::chrono::steady_clock::now();
-    n->prof[which] += std::chrono::duration<double, std::micro>(t1 - t0).count();
-    which = w;
-    t0 = t1;
-  }
-  ~Phase() { next(which); }
-};
 }  // namespace
 
 static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   if (!n) return RAFTQ_EINVAL;
   std::lock_guard<std::mutex> turn(n->turn_mu);
-  Phase ph(n, raftq_node::kPhDecode);
+  PhaseClock ph(n, raftq_node::kPhDecode);
   if (n->profiling) n->prof_turns++;
-  std::vector<InMsg>& work = n->work;
+  std::vector<uint32_t>& work = n->work;
   work.clear();
+  n->local.clear();
   PropBuf& props = n->turn_props;
   props.clear();
   n->cur_ents = nullptr;
@@ -996,72 +1135,43 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   }
   // -- rafthttp's messageDecoder + Message.Unmarshal for everything received since the last turn, on
   // the GPU (raftq_wire_decode).  Frames that do not parse, are not addressed to this node's slot, come
-  // from no peer of the cluster or are of a kind a peer never sends are dropped and counted -- rafthttp
-  // would log and drop the stream; a raft node must survive any bytes a peer throws at it.
-  uint64_t dropped = 0;
+  // from no peer of the cluster or are of a kind a peer never sends are dropped and counted (in the first Step
+  // round below) -- rafthttp would log and drop the stream; a raft node must survive any bytes a peer throws at it.
+  uint64_t nf = 0;
+  const raftq_wire_msg_t* wm = nullptr;
   if (in_off.size() > 1) {
-    const uint64_t nf = in_off.size() - 1;
+    nf = in_off.size() - 1;
+    if (nf >= kLocal) return poison(n, RAFTQ_EINVAL, "more than 2^31 frames in one turn");
     uint64_t ents_cap = std::max<uint64_t>(nf + 1024, n->turn_ents.cap / sizeof(raftq_wire_ent_t));
     if (!n->turn_msgs.reserve(nf * sizeof(raftq_wire_msg_t)) || !n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t)))
       return poison(n, RAFTQ_ENOMEM, "wire_decode (page-locked result buffers)");
-    raftq_wire_msg_t* wm = n->turn_msgs.as<raftq_wire_msg_t>();
+    raftq_wire_msg_t* out = n->turn_msgs.as<raftq_wire_msg_t>();
     raftq_wire_ent_t* we = n->turn_ents.as<raftq_wire_ent_t>();
     raftq_wire_counts_t cnt;
-    int rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, wm, we, ents_cap, &cnt);
+    int rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
     if (rc == RAFTQ_EINVAL && cnt.n_ents > ents_cap) {  // more entries than messages + 1024: grow once, decode again
       ents_cap = cnt.n_ents;
       if (!n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t))) return poison(n, RAFTQ_ENOMEM, "wire_decode (entries)");
       we = n->turn_ents.as<raftq_wire_ent_t>();
-      rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, wm, we, ents_cap, &cnt);
+      rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "wire_decode");
-    ph.next(raftq_node::kPhInbound);
+    wm = out;
     n->cur_ents = we;
     n->cur_bytes = in_bytes.p;
-    work.reserve(nf);
-    for (uint64_t i = 0; i < nf; ++i) {
-      const raftq_wire_msg_t& m = wm[i];
-      const bool kind_ok = m.type == RAFTQ_MSG_PROP || m.type == RAFTQ_MSG_APP || m.type == RAFTQ_MSG_APP_RESP ||
-                           m.type == RAFTQ_MSG_VOTE || m.type == RAFTQ_MSG_VOTE_RESP || m.type == RAFTQ_MSG_HEARTBEAT ||
-                           m.type == RAFTQ_MSG_HEARTBEAT_RESP;
-      if ((m.flags & RAFTQ_WIRE_F_MALFORMED) || !kind_ok || m.group >= n->G || m.from >= n->N || m.to != n->self) {
-        ++dropped;
-        continue;
-      }
-      InMsg im;
-      std::memset(&im.h, 0, sizeof(im.h));
-      im.h.group = m.group;
-      im.h.term = m.term;
-      im.h.log_term = m.log_term;
-      im.h.index = m.index;
-      im.h.commit = m.commit;
-      im.h.reject_hint = m.reject_hint;
-      im.h.from = m.from;
-      im.h.type = m.type;
-      im.h.reject = m.reject;
-      im.ent_first = m.ent_first;
-      im.n_ents = m.n_ents;
-      work.push_back(im);
-    }
   }
+  ph.next(raftq_node::kPhTick);
   // The commit channels, the status mirror and the outbound queues are only written below, under
   // mu, one short critical section per phase.
   std::unique_lock<std::mutex> lk(n->mu);
   const uint64_t published0 = n->stats.entries_published;
-  n->stats.frames_dropped += dropped;
-  bool did = !work.empty() || props.size() != 0 || ticks != 0 || dropped != 0 || !n->turn_hups.empty();
+  bool did = nf != 0 || props.size() != 0 || ticks != 0 || !n->turn_hups.empty();
 
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
-  std::vector<InMsg>& hups = n->hups;
-  hups.clear();
-  for (uint64_t gi : n->turn_hups) {  // rc.node.Campaign: MsgHup through Step, ahead of what the timers raise
-    InMsg im;
-    im.h = header(n, gi, RAFTQ_MSG_HUP, 0);
-    im.ent_first = im.n_ents = 0;
-    hups.push_back(im);
-  }
-  ph.next(raftq_node::kPhTick);
+  std::vector<raftq_wire_msg_t>& local = n->local;
+  for (uint64_t gi : n->turn_hups)  // rc.node.Campaign: MsgHup through Step, ahead of what the timers raise
+    local.push_back(local_msg(n, gi, RAFTQ_MSG_HUP));
   for (uint32_t t = 0; t < ticks; ++t) {
     lk.unlock();
     // the device compacts the two short lists (ascending group ids); no G-byte read-back and no loop over every
@@ -1074,14 +1184,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "tick");
-    lk.lock();
-    for (uint64_t i = 0; i < n_hup; ++i) {
-      InMsg im;
-      im.h = header(n, n->tick_list[i], RAFTQ_MSG_HUP, 0);
-      im.ent_first = im.n_ents = 0;
-      hups.push_back(im);
-    }
-    lk.unlock();
+    for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, n->tick_list[i], RAFTQ_MSG_HUP));
     rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
     if (rc == RAFTQ_OK && n_beat > n->tick_list.size()) {
       n->tick_list.resize(n_beat);
@@ -1094,15 +1197,21 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       if (n->groups[gi].role == RAFTQ_ROLE_LEADER) bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat: host only
     }
   }
-  if (!hups.empty()) {
-    hups.insert(hups.end(), work.begin(), work.end());
-    work.swap(hups);
+  if (local.size() >= kLocal) {
+    lk.unlock();
+    return poison(n, RAFTQ_EINVAL, "more than 2^31 local messages in one turn");
   }
+  ph.next(raftq_node::kPhInbound);
+  // what this turn works through, in order: the locally raised messages, then the inbound ones as they arrived
+  work.resize(local.size() + (size_t)nf);
+  for (size_t i = 0; i < local.size(); ++i) work[i] = kLocal | (uint32_t)i;
+  for (uint64_t i = 0; i < nf; ++i) work[local.size() + i] = (uint32_t)i;
+  auto msg_at = [&](uint32_t ix) -> const raftq_wire_msg_t& { return (ix & kLocal) ? local[ix & ~kLocal] : wm[ix]; };
 
   // -- rc.Process -> Step, in rounds.  A message that changes a group's log (MsgApp, MsgProp) must
   // be the last one of its group in a Step batch: what follows it has to see the new log tail.
-  std::vector<InMsg>& batch = n->batch;
-  std::vector<InMsg>& deferred = n->deferred;
+  std::vector<uint32_t>& batch = n->batch;
+  std::vector<uint32_t>& deferred = n->deferred;
   std::vector<uint64_t>& dirty = n->dirty_list;
   auto next_epoch = [&] {  // a fresh value no mark holds
     if (++n->epoch == 0) {
@@ -1113,7 +1222,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     return n->epoch;
   };
   // the views of one inbound MsgProp's entries (payloads stay in the receive buffer)
-  auto prop_entries = [&](const InMsg& im) -> const Entry* {
+  auto prop_entries = [&](const raftq_wire_msg_t& im) -> const Entry* {
     n->ent_tmp.clear();
     for (uint32_t k = 0; k < im.n_ents; ++k) {
       const raftq_wire_ent_t& e = n->cur_ents[im.ent_first + k];
@@ -1132,33 +1241,50 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
     return RAFTQ_OK;
   };
+  bool first_round = true;
+  uint64_t dropped = 0;
   while (!work.empty()) {
     ph.next(raftq_node::kPhStage);
     batch.clear();
     deferred.clear();
     dirty.clear();
     const uint32_t ep = next_epoch();
-    size_t n_step = 0;
-    for (const InMsg& im : work) {
-      if (n->blocked_mark[im.h.group] == ep) {
-        deferred.push_back(im);
-        continue;
-      }
-      if (im.h.type == RAFTQ_MSG_PROP || im.h.type == RAFTQ_MSG_APP) n->blocked_mark[im.h.group] = ep;
-      n_step += im.h.type != RAFTQ_MSG_PROP;  // MsgProp never reaches Step; everything else does, in arrival order
-      batch.push_back(im);
-    }
+    // one pass: what cannot go yet is deferred, the rest is written where the GPU reads it (raftq_step_stage: device
+    // memory behind a large BAR) -- the decoder's 64-byte record IS Step's record
     raftq_msg_t* staged = nullptr;
     lk.unlock();
+    if (int rc = raftq_step_stage(n->h, work.size(), &staged)) return poison(n, rc, "step_stage");
+    static_assert(sizeof(raftq_msg_t) == sizeof(raftq_wire_msg_t), "the decoder's record is Step's record");
+    size_t n_step = 0;
+    for (const uint32_t ix : work) {
+      const raftq_wire_msg_t& m = msg_at(ix);
+      if (first_round && !(ix & kLocal)) {
+        const bool kind_ok = m.type == RAFTQ_MSG_PROP || m.type == RAFTQ_MSG_APP || m.type == RAFTQ_MSG_APP_RESP ||
+                             m.type == RAFTQ_MSG_VOTE || m.type == RAFTQ_MSG_VOTE_RESP || m.type == RAFTQ_MSG_HEARTBEAT ||
+                             m.type == RAFTQ_MSG_HEARTBEAT_RESP;
+        if ((m.flags & RAFTQ_WIRE_F_MALFORMED) || !kind_ok || m.group >= n->G || m.from >= n->N || m.to != n->self) {
+          ++dropped;
+          continue;
+        }
+      }
+      uint32_t& mark = n->blocked_mark[m.group];
+      if (mark == ep) {
+        deferred.push_back(ix);
+        continue;
+      }
+      if (m.type == RAFTQ_MSG_PROP) {  // MsgProp never reaches Step; everything else does, in arrival order
+        mark = ep;
+      } else {
+        if (m.type == RAFTQ_MSG_APP) mark = ep;
+        std::memcpy(&staged[n_step++], &m, sizeof(raftq_msg_t));
+      }
+      batch.push_back(ix);
+    }
+    first_round = false;
     const raftq_step_out_t* outs = nullptr;
     if (n_step) {
-      int rc = raftq_step_stage(n->h, n_step, &staged);
-      if (rc != RAFTQ_OK) return poison(n, rc, "step_stage");
-      size_t k = 0;
-      for (const InMsg& im : batch)
-        if (im.h.type != RAFTQ_MSG_PROP) staged[k++] = im.h;
       ph.next(raftq_node::kPhStep);
-      rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
+      int rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
       uint64_t n_out = 0;
       if (rc == RAFTQ_OK) rc = raftq_step_results(n->h, &outs, &n_out);
       if (rc != RAFTQ_OK) return poison(n, rc, "step_batch");
@@ -1167,13 +1293,26 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     ph.next(raftq_node::kPhApply);
     n->stats.msgs_stepped += n_step;
     // consequences, in arrival order (stepped results and proposals interleaved as they came)
+    // The groups of a batch are scattered over tens of MB of per-group state: the line of the group 16 messages ahead
+    // and, 8 ahead (its line has arrived by then), its Progress and the tail of its log are asked for now.
+    const size_t nb = batch.size();
+    auto group_of = [&](size_t at) { return msg_at(batch[at]).group; };
     size_t k = 0;
-    for (const InMsg& im : batch) {
-      if (im.h.type == RAFTQ_MSG_PROP) {
-        Group& g = n->groups[im.h.group];
-        if (handle_proposal(n, im.h.group, g, prop_entries(im), im.n_ents) && n->dirty_mark[im.h.group] != ep) {
-          n->dirty_mark[im.h.group] = ep;
-          dirty.push_back(im.h.group);
+    for (size_t bi = 0; bi < nb; ++bi) {
+      if (bi + 16 < nb) __builtin_prefetch(&n->groups[group_of(bi + 16)]);
+      if (bi + 8 < nb) {
+        const uint64_t g8 = group_of(bi + 8);
+        const Group& ahead = n->groups[g8];
+        if (ahead.leading) __builtin_prefetch(&n->prog[g8 * n->N * 2], 1);
+        if (!ahead.log.empty()) __builtin_prefetch(&ahead.log.back(), 1);  // term_at(prev), and where the next entry goes
+        ahead_of_publish(ahead);
+      }
+      const raftq_wire_msg_t& im = msg_at(batch[bi]);
+      if (im.type == RAFTQ_MSG_PROP) {
+        Group& g = n->groups[im.group];
+        if (handle_proposal(n, im.group, g, prop_entries(im), im.n_ents) && n->dirty_mark[im.group] != ep) {
+          n->dirty_mark[im.group] = ep;
+          dirty.push_back(im.group);
         }
       } else {
         apply_result(n, outs[k++], im);
@@ -1183,6 +1322,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
     work.swap(deferred);
   }
+  n->stats.frames_dropped += dropped;
   ph.next(raftq_node::kPhProps);
 
   // -- proposeC (raft.go:211-215)
@@ -1248,18 +1388,25 @@ int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, u
   if (!from) return RAFTQ_EINVAL;
   if (to_peer >= from->N) return nfail(from, RAFTQ_EINVAL, "forward: peer out of range");
   std::string taken;  // the queue's bytes leave under the sender's lock and arrive under the receiver's: never both held
+  std::vector<uint64_t> ends;
+  bool have_ends = false;
   try {
     std::lock_guard<std::mutex> lk(from->mu);
     PeerQueue& q = from->outbound[to_peer];
-    if (q.head == 0) taken.swap(q.bytes);
-    else taken.assign(q.bytes, q.head, std::string::npos);
-    q.bytes.clear();
-    q.head = 0;
+    if (q.head == 0) {
+      taken.swap(q.bytes);
+      have_ends = q.ends_ok;
+      if (have_ends) ends.swap(q.ends);
+    } else {
+      taken.assign(q.bytes, q.head, std::string::npos);
+    }
+    q.reset();
   } catch (...) {
     return nfail(from, RAFTQ_ENOMEM, "forward: host allocation failed");
   }
   if (moved) *moved = taken.size();
   if (!to || taken.empty()) return RAFTQ_OK;
+  if (have_ends && !ends.empty() && ends.back() == taken.size()) return deliver_impl(to, taken.data(), taken.size(), ends.data(), ends.size());
   return raftq_node_deliver(to, taken.data(), taken.size());
 }
 
@@ -1456,6 +1603,151 @@ void raftq_node_destroy(raftq_node_t* n) {
   if (n->profiling && n->prof_turns) dump_profile(n);
   raftq_destroy(n->h);
   delete n;
+}
+
+}  // extern "C"
+
+// ---- raftq_crank: the nodes of one process turned in lock-step, each on a thread of its own ------------------------------
+// What the reference's tests do with three raftNodes over loopback (raftsql_test.go:11-35) and what bench.py's node leg
+// measures: every live node's Tick + Ready-loop iteration at once, then every node's inbound buffer filled from the
+// others' queues (per ADDRESSEE, senders in slot order: what a node receives does not depend on thread timing).  One call
+// per cluster step; the threads live as long as the crank (a Python thread pool costs a GIL hand-off per node and step,
+// and its workers do not stay on the node's core).
+struct raftq_crank {
+  std::vector<raftq_node_t*> nodes;
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  uint64_t epoch = 0;
+  uint32_t pending = 0;
+  int phase = 0;  // 1 = turn, 2 = transport, -1 = quit
+  uint32_t live = 0;
+  int tick = 0;
+  const uint8_t* lost = nullptr;
+  std::vector<int> rc;
+  std::vector<uint64_t> published;
+  double seconds[2] = {0, 0};  // wall time of the steps' two halves so far: the turns, the transport
+};
+
+namespace {
+void crank_worker(raftq_crank* c, uint32_t p, int cpu) {
+#if defined(__linux__)
+  if (cpu >= 0) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpu, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+  }
+#else
+  (void)cpu;
+#endif
+  uint64_t seen = 0;
+  for (;;) {
+    int phase;
+    {
+      std::unique_lock<std::mutex> lk(c->mu);
+      c->cv_go.wait(lk, [&] { return c->epoch != seen; });
+      seen = c->epoch;
+      phase = c->phase;
+    }
+    if (phase < 0) return;
+    const uint32_t n = (uint32_t)c->nodes.size();
+    int rc = RAFTQ_OK;
+    if (phase == 1 && (c->live >> p & 1u)) {
+      if (c->tick) rc = raftq_node_tick(c->nodes[p]);
+      uint64_t pub = 0;
+      if (rc == RAFTQ_OK) rc = raftq_node_advance(c->nodes[p], &pub);
+      c->published[p] = pub;
+    } else if (phase == 2) {
+      for (uint32_t from = 0; from < n && rc == RAFTQ_OK; ++from) {
+        if (from == p || !(c->live >> from & 1u)) continue;
+        const bool gone = !(c->live >> p & 1u) || (c->lost && c->lost[(size_t)p * n + from]);
+        rc = raftq_node_forward(c->nodes[from], p, gone ? nullptr : c->nodes[p], nullptr);
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (rc != RAFTQ_OK && c->rc[p] == RAFTQ_OK) c->rc[p] = rc;
+      if (--c->pending == 0) c->cv_done.notify_one();
+    }
+  }
+}
+
+void crank_run(raftq_crank* c, int phase) {
+  std::unique_lock<std::mutex> lk(c->mu);
+  c->phase = phase;
+  c->pending = (uint32_t)c->nodes.size();
+  c->epoch++;
+  c->cv_go.notify_all();
+  c->cv_done.wait(lk, [&] { return c->pending == 0; });
+}
+}  // namespace
+
+extern "C" {
+
+int raftq_crank_create(raftq_node_t* const* nodes, uint32_t n, const int* cpus, raftq_crank_t** out) {
+  if (!out) return RAFTQ_EINVAL;
+  *out = nullptr;
+  if (!nodes || n == 0 || n > 32) return RAFTQ_EINVAL;
+  for (uint32_t p = 0; p < n; ++p)  // nodes[p] is peer slot p of an n-peer cluster, or NULL (a stopped node: never live)
+    if (nodes[p] && (nodes[p]->N != n || nodes[p]->self != p)) return RAFTQ_EINVAL;
+  raftq_crank* c = new (std::nothrow) raftq_crank();
+  if (!c) return RAFTQ_ENOMEM;
+  try {
+    c->nodes.assign(nodes, nodes + n);
+    c->rc.assign(n, RAFTQ_OK);
+    c->published.assign(n, 0);
+    for (uint32_t p = 0; p < n; ++p) c->threads.emplace_back(crank_worker, c, p, cpus ? cpus[p] : -1);
+  } catch (...) {
+    raftq_crank_destroy(c);
+    return RAFTQ_ENOMEM;
+  }
+  *out = c;
+  return RAFTQ_OK;
+}
+
+int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost, uint64_t* published, int* node_rc) {
+  if (!c) return RAFTQ_EINVAL;
+  const uint32_t n = (uint32_t)c->nodes.size();
+  for (uint32_t p = 0; p < 32; ++p)
+    if ((live_mask >> p & 1u) && (p >= n || !c->nodes[p])) return RAFTQ_EINVAL;
+  c->live = live_mask;
+  c->tick = tick;
+  c->lost = lost;
+  std::fill(c->rc.begin(), c->rc.end(), RAFTQ_OK);
+  std::fill(c->published.begin(), c->published.end(), 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  crank_run(c, 1);
+  const auto t1 = std::chrono::steady_clock::now();
+  crank_run(c, 2);
+  const auto t2 = std::chrono::steady_clock::now();
+  c->seconds[0] += std::chrono::duration<double>(t1 - t0).count();
+  c->seconds[1] += std::chrono::duration<double>(t2 - t1).count();
+  int first = RAFTQ_OK;
+  for (uint32_t p = 0; p < n; ++p) {
+    if (published) published[p] = c->published[p];
+    if (node_rc) node_rc[p] = c->rc[p];
+    if (first == RAFTQ_OK) first = c->rc[p];
+  }
+  return first;
+}
+
+void raftq_crank_seconds(const raftq_crank_t* c, double* turns, double* transport) {
+  if (turns) *turns = c ? c->seconds[0] : 0;
+  if (transport) *transport = c ? c->seconds[1] : 0;
+}
+
+void raftq_crank_destroy(raftq_crank_t* c) {
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->phase = -1;
+    c->epoch++;
+    c->cv_go.notify_all();
+  }
+  for (std::thread& t : c->threads)
+    if (t.joinable()) t.join();
+  delete c;
 }
 
 }  // extern "C"

@@ -6,6 +6,8 @@ in-memory transport that can drop, delay and partition)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
+import time
 from typing import Iterable, Optional
 
 import numpy as np
@@ -49,6 +51,10 @@ _SIGS = [
     ("raftq_node_advance", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("raftq_node_poll", C.c_int, [_P, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_node_forward", C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    ("raftq_crank_create", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_P)]),
+    ("raftq_crank_step", C.c_int, [_P, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("raftq_crank_seconds", None, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("raftq_crank_destroy", None, [_P]),
     ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int)]),
     ("raftq_node_status", C.c_int, [_P, C.c_uint64, C.POINTER(Status)]),
@@ -143,6 +149,15 @@ class RaftNode:
         off[1:] = np.cumsum([len(p) for p in payloads])
         blob = b"".join(payloads)
         self._chk(self._lib.raftq_node_propose_batch(self._p, g.ctypes.data, off.ctypes.data, blob, len(payloads)))
+
+    def propose_blob(self, groups, offsets, blob: bytes) -> None:
+        """raftq_node_propose_batch with the arrays as the ABI takes them: proposal i = blob[offsets[i]:offsets[i + 1]] for
+        groups[i] (a producer that already holds its statements back to back builds no Python list)"""
+        g = np.ascontiguousarray(groups, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if len(off) != len(g) + 1:
+            raise ValueError("offsets must hold len(groups) + 1 entries")
+        self._chk(self._lib.raftq_node_propose_batch(self._p, g.ctypes.data, off.ctypes.data, blob, len(g)))
 
     def campaign(self, groups) -> None:
         """raft.Node.Campaign for these groups: a local MsgHup each at the next advance()"""
@@ -262,11 +277,15 @@ class Cluster:
     `cut` holds (a, b) pairs whose traffic is dropped in both directions."""
 
     def __init__(self, n_groups: int, n_peers: int, device: int = 0, election_tick: int = 10, seed: int = 7,
-                 wal: bool = False, threads: bool = False, native_transport: bool = False):
+                 wal: bool = False, threads: bool = False, native_transport: bool = False, pin_cpus=None):
         self.G, self.N, self.device, self.election_tick, self.seed = n_groups, n_peers, device, election_tick, seed
         # native_transport: the nodes' frames go from queue to queue inside the library (raftq_node_forward) instead of
         # through Python bytes -- same frames, same order, same loss / partition rules (decided here, applied there)
         self.native_transport = native_transport
+        # pin_cpus[p]: the CPU node p's turns run on (threads=True).  A node is a few tens of MB of per-group state worked
+        # through once per turn: a thread that wanders between cores (or shares an L3 slice with another node's) loses it
+        # -- measured on the two-socket GPU box: the same turns take half the time on three fixed cores of three CCDs
+        self.pin_cpus = list(pin_cpus) if pin_cpus else None
         # threads=True: every node's turn (tick, advance, WAL poll, outbound poll) runs on its own thread, as N
         # machines would; the library calls release the GIL and each node has its own engine handle and stream.
         # The transport (deliver) stays on the caller's thread, after all turns: what a turn receives is the same.
@@ -275,6 +294,10 @@ class Cluster:
             from concurrent.futures import ThreadPoolExecutor
 
             self._pool = ThreadPoolExecutor(max_workers=n_peers)
+        # threads + native_transport (and no WAL to collect in between): the whole step is ONE library call, the nodes'
+        # turns and the transport on the library's own threads (raftq_crank_step) -- no GIL hand-off per node and step
+        self._crank = None
+        self.last_published = [0] * n_peers  # entries each node put on its commit channels in the last step()
         self.nodes: list[Optional[RaftNode]] = [RaftNode(n_groups, n_peers, p, device) for p in range(n_peers)]
         # wal=True: every node produces its WAL (raftq_node_wal_enable); self.wal[p] is node p's "disk"
         self.wal_on = wal
@@ -287,6 +310,7 @@ class Cluster:
         self.loss = 0.0  # probability that one node-to-node transfer (a batch of frames) is lost
         self._rng = np.random.default_rng(seed)
         self.ticks = 0
+        self.seconds = {"turns": 0.0, "transport": 0.0}  # wall time of step()'s two halves so far
 
     def start(self) -> None:
         for p, nd in enumerate(self.nodes):
@@ -296,6 +320,8 @@ class Cluster:
         """one iteration of node p's serveChannels loop -> (published, its outbound bytes per addressee | None when the
         frames go from node to node inside the library, raftq_node_forward)"""
         nd = self.nodes[p]
+        if self.pin_cpus and self._pool is not None:
+            os.sched_setaffinity(0, {self.pin_cpus[p % len(self.pin_cpus)]})  # the calling (pool) thread only
         if tick:
             nd.tick()
         published = nd.advance()
@@ -305,30 +331,106 @@ class Cluster:
             return published, None
         return published, [nd.poll(q) if q != p else b"" for q in range(self.N)]
 
+    def _pull(self, q: int, senders, lost) -> None:
+        """the in-process transport towards node q: every sender's queue for q, in sender order (raftq_node_forward);
+        `lost[p]`: that transfer is dropped on the way"""
+        if self.pin_cpus and self._pool is not None:
+            os.sched_setaffinity(0, {self.pin_cpus[q % len(self.pin_cpus)]})
+        for p in senders:
+            if p != q:
+                self.nodes[p].forward(q, None if lost[p] else self.nodes[q])
+
+    def _crank_step(self, tick: bool, live, lost) -> int:
+        lib = _load()
+        if self._crank is None:
+            ptrs = (C.c_void_p * self.N)(*[None if p in self.down else nd._p for p, nd in enumerate(self.nodes)])
+            cpus = None
+            if self.pin_cpus:
+                cpus = (C.c_int * self.N)(*[self.pin_cpus[p % len(self.pin_cpus)] for p in range(self.N)])
+            out = _P()
+            rc = lib.raftq_crank_create(ptrs, self.N, cpus, C.byref(out))
+            if rc != 0:
+                raise RaftqError(rc, "raftq_crank_create failed")
+            self._crank = out
+            self._crank_seen = (0.0, 0.0)
+        mask = 0
+        for p in live:
+            mask |= 1 << p
+        lost_arr = np.ascontiguousarray(np.array(lost, dtype=np.uint8).reshape(-1))
+        pub = np.zeros(self.N, dtype=np.uint64)
+        rcs = np.zeros(self.N, dtype=np.int32)
+        rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_arr.ctypes.data, pub.ctypes.data, rcs.ctypes.data)
+        if rc != 0:
+            bad = int(np.nonzero(rcs)[0][0])
+            self.nodes[bad]._chk(int(rcs[bad]))
+        self.last_published = [int(v) for v in pub]
+        a, b = C.c_double(0), C.c_double(0)
+        lib.raftq_crank_seconds(self._crank, C.byref(a), C.byref(b))
+        self.seconds["turns"] += a.value - self._crank_seen[0]
+        self.seconds["transport"] += b.value - self._crank_seen[1]
+        self._crank_seen = (a.value, b.value)
+        return int(pub.sum())
+
+    def _drop_crank(self) -> None:
+        if self._crank is not None:
+            _load().raftq_crank_destroy(self._crank)
+            self._crank = None
+
+    def _lost_matrix(self, live):
+        """[addressee][sender]: which of this step's node-to-node transfers are lost (down, cut, or the dice)"""
+        lost = [[False] * self.N for _ in range(self.N)]
+        for p in live:
+            for q in range(self.N):
+                if q == p:
+                    continue
+                gone = q in self.down or (p, q) in self.cut or (q, p) in self.cut  # lost on the wire
+                if not gone and self.loss and self._rng.random() < self.loss:
+                    gone = True
+                lost[q][p] = gone
+        return lost
+
     def step(self, tick: bool = True) -> int:
         live = [p for p in range(self.N) if p not in self.down]
+        if self._pool is not None and self.native_transport and not self.wal_on:
+            published = self._crank_step(tick, live, self._lost_matrix(live))
+            self.ticks += int(tick)
+            return published
+        t0 = time.perf_counter()
         if self._pool is not None:
             turns = list(self._pool.map(lambda p: self._turn(p, tick), live))
         else:
             turns = [self._turn(p, tick) for p in live]
-        published = 0
+        t1 = time.perf_counter()
+        self.seconds["turns"] += t1 - t0
+        published = sum(pub for pub, _ in turns)
+        self.last_published = [0] * self.N
+        for p, (pub, _) in zip(live, turns):
+            self.last_published[p] = pub
+        if self.native_transport:
+            # what is lost is decided here, sender by sender and addressee by addressee as the Python transport does (same
+            # draws from the same generator); the moving is done per ADDRESSEE, so with threads every node fills its own
+            # inbound buffer while the others fill theirs, and a node still sees its senders in slot order
+            lost = self._lost_matrix(live)
+            if self._pool is not None:
+                list(self._pool.map(lambda q: self._pull(q, live, lost[q]), range(self.N)))
+            else:
+                for q in range(self.N):
+                    self._pull(q, live, lost[q])
+            self.seconds["transport"] += time.perf_counter() - t1
+            self.ticks += int(tick)
+            return published
         for p, (pub, out) in zip(live, turns):
-            published += pub
             for q in range(self.N):
                 if q == p:
                     continue
                 lost = q in self.down or (p, q) in self.cut or (q, p) in self.cut  # lost on the wire
-                if out is None:  # in-process transport: the library moves the frames (or drops them)
-                    if not lost and self.loss and self._rng.random() < self.loss:
-                        lost = True
-                    self.nodes[p].forward(q, None if lost else self.nodes[q])
-                    continue
                 frames = out[q]
                 if lost:
                     continue
                 if self.loss and frames and self._rng.random() < self.loss:
                     continue
                 self.nodes[q].deliver(frames)
+        self.seconds["transport"] += time.perf_counter() - t1
         self.ticks += int(tick)
         return published
 
@@ -360,6 +462,7 @@ class Cluster:
     def stop(self, p: int) -> list[list[tuple[int, bytes]]]:
         """close node p and return its logs (its WAL, for a later restart); the HardStates a WAL
         would also hold are kept in self.hard_states[p] as (term, vote, commit) per group"""
+        self._drop_crank()
         nd = self.nodes[p]
         logs = [nd.log(g) for g in range(self.G)]
         sts = nd.statuses()
@@ -374,6 +477,7 @@ class Cluster:
     def restart(self, p: int, logs, restore_hard_state: bool = False) -> RaftNode:
         """restart from the WAL.  restore_hard_state=False is the reference's behaviour (replayWAL
         discards HardState, raft.go:124); True is what a correct raft needs to stay safe."""
+        self._drop_crank()
         nd = RaftNode(self.G, self.N, p, self.device)
         for g, ents in enumerate(logs):
             if ents:
@@ -387,6 +491,7 @@ class Cluster:
 
     def restart_from_wal(self, p: int, restore_hard_state: bool = False, wal: Optional[bytes] = None) -> RaftNode:
         """restart node p from its WAL bytes alone (replayWAL, raft.go:122-134); it keeps appending to them"""
+        self._drop_crank()
         nd = RaftNode(self.G, self.N, p, self.device)
         nd.replay_wal(bytes(self.wal[p]) if wal is None else wal, restore_hard_state)
         nd.wal_enable()
@@ -396,6 +501,7 @@ class Cluster:
         return nd
 
     def close(self) -> None:
+        self._drop_crank()
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None

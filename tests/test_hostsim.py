@@ -25,11 +25,14 @@ SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
 INC = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), "-I" + CSRC]
 
 
-def _build() -> str:
+def _build(san=None, lib=None, bdir_name="build_hostsim") -> str:
+    """san / lib / bdir_name: tools/hostsim_opt.py builds the same library without sanitizers to time the host phases"""
+    SAN = globals()["SAN"] if san is None else san
+    LIB = globals()["LIB"] if lib is None else lib
     deps = SOURCES + ORACLE + [os.path.join(ROOT, "include", h) for h in os.listdir(os.path.join(ROOT, "include"))]
     if os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps):
         return LIB
-    bdir = os.path.join(CDIR, "build_hostsim")
+    bdir = os.path.join(CDIR, bdir_name)
     os.makedirs(bdir, exist_ok=True)
     objs = []
     for src in SOURCES:

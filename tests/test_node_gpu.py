@@ -224,17 +224,19 @@ def test_restart_with_an_uncommitted_tail_that_gets_overwritten(Cluster):
         c.close()
 
 
-@pytest.mark.parametrize("seed,from_wal", [(1, False), (2, False), (3, False), (4, True), (5, True)])
-def test_chaos_safety_and_convergence(Cluster, seed, from_wal):
+@pytest.mark.parametrize("seed,from_wal,crank", [(1, False, False), (2, False, False), (3, False, False), (4, True, False),
+                                                 (5, True, False), (6, False, True), (7, False, True)])
+def test_chaos_safety_and_convergence(Cluster, seed, from_wal, crank):
     """Random message loss, partitions, stops and restarts (WAL + HardState restored; from_wal: from the
     node's own WAL bytes -- raftq_node_replay_wal -- and nothing else) while clients
     keep proposing on whatever node they reach.  Throughout: at most one leader per term, committed
     prefixes agree, and what the never-restarted nodes delivered are prefixes of one sequence per
     group.  After healing: all nodes hold the same committed sequence, no payload twice, nothing
-    invented, and every live stream is exactly that sequence."""
+    invented, and every live stream is exactly that sequence.  crank: the nodes' turns and the transport on the library's
+    own threads (raftq_crank_step), stopped nodes and lost transfers included."""
     rng = np.random.default_rng(seed)
     G, N = 24, 5
-    c = Cluster(G, N, seed=seed, wal=from_wal)
+    c = Cluster(G, N, seed=seed, wal=from_wal, threads=crank, native_transport=crank)
 
     def restart(p):
         logs = stopped.pop(p)

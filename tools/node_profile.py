@@ -36,6 +36,23 @@ def step(c, tick):
             t = time.perf_counter(); c.nodes[q].deliver(fr); T["deliver"] += time.perf_counter() - t
 
 
+PIN = os.environ.get("NODE_PIN", "")  # "", "numa", "cores" (one core per node, 8 apart), "adjacent" (neighbouring cores)
+if PIN:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import gpu_numa_cpus
+
+    near = sorted(gpu_numa_cpus(0) or os.sched_getaffinity(0))
+    os.sched_setaffinity(0, near)
+    if PIN in ("cores", "adjacent"):
+        stride = 8 if PIN == "cores" else 1
+        turn0 = Cluster._turn
+
+        def pinned_turn(self, p, tick):
+            os.sched_setaffinity(0, {near[(p * stride) % len(near)]})
+            return turn0(self, p, tick)
+
+        Cluster._turn = pinned_turn
+    print("pin:", PIN, "near cpus", near[0], "..", near[-1], len(near), flush=True)
 c = Cluster(G, N, device=0, seed=5, threads=THREADS)
 c.start()
 t0 = time.perf_counter()
@@ -58,6 +75,12 @@ lead = c.leaders()
 base = [nd.stats() for nd in c.nodes]
 for k in T:
     T[k] = 0.0
+PCS = None
+if os.environ.get("PCSAMPLE"):  # tools/probe/pcsample.c: where the CPU time of the waves goes, by program counter
+    import ctypes
+
+    PCS = ctypes.CDLL(os.environ["PCSAMPLE"])
+    PCS.pcsample_start()
 t0 = time.perf_counter()
 turns = 0
 for r in range(rounds):
@@ -79,6 +102,8 @@ for r in range(rounds):
     else:
         raise SystemExit("wave did not commit")
 dt = time.perf_counter() - t0
+if PCS is not None:
+    PCS.pcsample_stop(os.environ.get("PCSAMPLE_OUT", "/tmp/pcsample.txt").encode())
 print("waves: %.3f s for %d x %d proposals = %.3g /s, %d cluster steps" % (dt, rounds, G, rounds * G / dt, turns),
       {k: round(v, 3) for k, v in T.items()}, flush=True)
 c.close()

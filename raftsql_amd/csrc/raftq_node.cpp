@@ -27,6 +27,7 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
 #endif
 
 namespace {
@@ -81,18 +82,76 @@ struct Item {  // 16 bytes
   int32_t kind;
 };
 
+// The node's own allocator for the per-group arrays (logs, commit channels): power-of-two blocks carved from 2 MB chunks,
+// freed blocks recycled per size, everything returned at once when the node goes.  Not thread-safe and it need not be: the
+// arrays only grow inside advance() (one at a time) or before the node starts.  glibc's realloc was the single most
+// expensive thing in the turn: the blocks belong to the arena of the thread that created the node, every node's turn
+// thread fought for that one lock (4,000 cycles per growing push_back with three nodes in a process, measured).
+struct Pool {
+  static constexpr size_t kChunk = (size_t)2 << 20;
+  static constexpr int kClasses = 15;  // 64 B .. 1 MB
+  std::vector<void*> chunks, big;
+  char* cur = nullptr;
+  size_t left = 0;
+  void* free_list[kClasses] = {};
+  Pool() = default;
+  Pool(const Pool&) = delete;
+  Pool& operator=(const Pool&) = delete;
+  ~Pool() {
+    for (void* c : chunks) std::free(c);
+    for (void* b : big) std::free(b);
+  }
+  // a block of at least `bytes`; *got = its real size.  Throws std::bad_alloc.
+  void* alloc(size_t bytes, size_t* got) {
+    int c = 0;
+    size_t sz = 64;
+    while (sz < bytes) sz <<= 1, ++c;
+    if (c >= kClasses) {  // larger than any class: its own allocation, kept until the node goes
+      void* p = std::malloc(bytes);
+      if (!p) throw std::bad_alloc();
+      big.push_back(p);
+      *got = bytes;
+      return p;
+    }
+    *got = sz;
+    if (void* p = free_list[c]) {
+      std::memcpy(&free_list[c], p, sizeof(void*));
+      return p;
+    }
+    if (left < sz) {
+      void* chunk = std::aligned_alloc(kChunk, kChunk);
+      if (!chunk) throw std::bad_alloc();
+#if defined(__linux__)
+      // RAFTQ_NODE_THP=1: ask for a huge page per chunk (off by default: with defrag=madvise the fault compacts memory
+      // synchronously -- on a VM it doubled the turn)
+      if (std::getenv("RAFTQ_NODE_THP")) (void)madvise(chunk, kChunk, MADV_HUGEPAGE);
+#endif
+      chunks.push_back(chunk);
+      cur = (char*)chunk;
+      left = kChunk;
+    }
+    void* p = cur;
+    cur += sz;
+    left -= sz;
+    return p;
+  }
+  // `bytes`: anything that rounds up to the block's size (an array hands back capacity x element size)
+  void release(void* p, size_t bytes) {
+    if (!p || bytes == 0) return;
+    int c = 0;
+    size_t sz = 64;
+    while (sz < bytes) sz <<= 1, ++c;
+    if (c >= kClasses) return;  // a `big` block: stays until the node goes
+    std::memcpy(p, &free_list[c], sizeof(void*));
+    free_list[c] = p;
+  }
+};
+
 // A growable array in 16 bytes (std::vector takes 24) for the two arrays every group has, so that both headers share the
-// group's one hot cache line.  Trivially copyable elements only; the first element gets room for eight (the first appends of
-// 10^5 groups are otherwise 10^5 x (1, 2, 4, 8)-element reallocations inside a turn); growth failure throws std::bad_alloc
-// like std::vector's (advance() catches it).
+// group's one hot cache line; its blocks come from the node's Pool (which frees them).  Trivially copyable elements only.
 template <typename T> struct TinyVec {
   T* p = nullptr;
   uint32_t n = 0, cap = 0;
-  TinyVec() = default;
-  TinyVec(const TinyVec&) = delete;
-  TinyVec& operator=(const TinyVec&) = delete;
-  TinyVec(TinyVec&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
-  ~TinyVec() { std::free(p); }
   size_t size() const { return n; }
   bool empty() const { return n == 0; }
   T& operator[](size_t i) { return p[i]; }
@@ -104,14 +163,15 @@ template <typename T> struct TinyVec {
   void truncate(size_t k) {
     if (k < n) n = (uint32_t)k;
   }
-  void push_back(const T& v) {
+  void push_back(Pool& pool, const T& v) {
     if (n == cap) {
-      if (cap >= 0x80000000u) throw std::bad_alloc();
-      const uint32_t nc = cap ? cap * 2 : 8;
-      void* q = std::realloc(p, (size_t)nc * sizeof(T));
-      if (!q) throw std::bad_alloc();
-      p = (T*)q;
-      cap = nc;
+      if (cap >= 0x40000000u) throw std::bad_alloc();
+      size_t got = 0;
+      T* q = (T*)pool.alloc(std::max<size_t>((size_t)cap * 2 * sizeof(T), 128), &got);
+      if (n) std::memcpy(q, p, (size_t)n * sizeof(T));
+      pool.release(p, (size_t)cap * sizeof(T));  // the block's class is what capacity x element size rounds up to
+      p = q;
+      cap = (uint32_t)(got / sizeof(T));
     }
     p[n++] = v;
   }
@@ -242,6 +302,7 @@ struct raftq_node {
   std::condition_variable cv_commit;
   PropBuf proposals, turn_props;  // queued / being worked through by advance()
   Arena arena;                    // entry payloads (logs, commit channels)
+  Pool pool;                      // the groups' log and commit-channel arrays
   bool oom = false;               // an arena or queue allocation failed this turn: advance() ends in ENOMEM
   // the turn's decoded inbound entries and the bytes their payloads sit in (valid inside advance())
   const raftq_wire_ent_t* cur_ents = nullptr;
@@ -434,7 +495,7 @@ void publish(raftq_node_t* n, Group& g, uint64_t upto) {
   for (uint64_t idx = g.applied + 1; idx <= upto; ++idx) {
     const Entry& e = g.log[idx - 1];
     if (e.len == 0) continue;
-    g.q.push_back(Item{e.data, e.len, RAFTQ_NODE_ENTRY});
+    g.q.push_back(n->pool, Item{e.data, e.len, RAFTQ_NODE_ENTRY});
     n->stats.entries_published++;
   }
   if (upto > g.applied) g.applied = upto;
@@ -500,7 +561,7 @@ bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, const Entry* ents, 
         n->oom = true;
         return i != 0;
       }
-      g.log.push_back(Entry{g.term, at, ents[i].len});
+      g.log.push_back(n->pool, Entry{g.term, at, ents[i].len});
     }
     if (n_ents) wal_touch(n, gi, g);
     return n_ents != 0;
@@ -547,7 +608,7 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_ms
         n->stats.msgs_sent--;
         return;
       }
-      g.log.push_back(Entry{ents[k].term, at, ents[k].data_len});
+      g.log.push_back(n->pool, Entry{ents[k].term, at, ents[k].data_len});
     }
     wal_touch(n, gi, g);
     const uint64_t lastnewi = m.index + m.n_ents;
@@ -625,7 +686,7 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const raftq_wire_m
       g.log.truncate(o.index - 1);
       g.wal_upto = std::min<uint64_t>(g.wal_upto, g.log.size());
       n->shared_group = ~0ull;
-        g.log.push_back(Entry{o.term, "", 0});
+        g.log.push_back(n->pool, Entry{o.term, "", 0});
       wal_touch(n, gi, g);
       for (uint32_t p = 0; p < n->N; ++p) {  // reset(): Next = lastIndex + 1 (before the empty entry)
         n->next_of(gi, p) = o.index;
@@ -830,7 +891,7 @@ bool log_put(raftq_node_t* n, Group& g, uint64_t index, uint64_t term, const cha
   if (index <= g.log.size()) g.log.truncate(index - 1);
   const char* at = n->arena.put(data, len);
   if (!at) return false;
-  g.log.push_back(Entry{term, at, len});
+  g.log.push_back(n->pool, Entry{term, at, len});
   return true;
 }
 
@@ -895,7 +956,7 @@ int raftq_node_replay(raftq_node_t* n, uint64_t group, const uint64_t* terms, co
       n->errtext = "replay: host allocation failed";
       return RAFTQ_ENOMEM;
     }
-    g.log.push_back(Entry{terms[i], at, lens[i]});
+    g.log.push_back(n->pool, Entry{terms[i], at, lens[i]});
   }
   return RAFTQ_OK;
 }
@@ -941,7 +1002,7 @@ int raftq_node_start(raftq_node_t* n, uint32_t election_tick, uint32_t heartbeat
       Group& g = n->groups[gi];
       // replayWAL (raft.go:122-134): every logged entry goes out, then the nil sentinel
       publish(n, g, g.log.size());
-        g.q.push_back(Item{"", 0, RAFTQ_NODE_SENTINEL});
+        g.q.push_back(n->pool, Item{"", 0, RAFTQ_NODE_SENTINEL});
       g.term = term[gi] = g.hs_term;
       vote[gi] = g.hs_vote;
       g.vote = (uint16_t)g.hs_vote;

@@ -62,6 +62,25 @@ def _build(san=None, lib=None, bdir_name="build_hostsim") -> str:
     return LIB
 
 
+def test_node_threads_under_tsan():
+    """the crank (raftq_crank_step: every node's turn and the transport on the library's own threads), the threaded
+    cluster and raftq_node_forward under ThreadSanitizer, the oracle as the engine"""
+    import shutil
+
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip() if shutil.which("gcc") else ""
+    if not (shutil.which("g++") and os.path.isabs(tsan) and os.path.exists(tsan)):
+        pytest.skip("no g++ / libtsan here")
+    lib = _build(san=["-fsanitize=thread", "-O1", "-g"], lib=os.path.join(CDIR, "libraftq_hostsim_tsan.so"), bdir_name="build_hostsim_tsan")
+    env = dict(os.environ, RAFTQ_LIB=lib, RAFTQ_HOSTSIM="1", LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_node_gpu.py", "-k",
+                        "threaded or forward or (chaos and True)"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    out = r.stdout + r.stderr
+    assert "WARNING: ThreadSanitizer" not in out, out[out.index("WARNING: ThreadSanitizer"):][:4000]
+    assert r.returncode == 0, out[-4000:]
+    m = re.search(r"(\d+) passed", out)
+    assert m and int(m.group(1)) >= 3, out[-2000:]
+
+
 def _run(tests, extra_env=None, timeout=1500):
     import shutil
 

@@ -781,31 +781,30 @@ def _node_measure(Cluster, device, G, N, rounds, near):
     lead = c.leaders()
     mine = [np.nonzero(lead == p)[0] for p in range(N)]
 
-    def waves(count, payload_of):
-        """-> (seconds, cluster steps, ticks fired)"""
+    def waves(count, payload_of, in_flight=1):
+        """`count` waves, at most `in_flight` of them proposed and not yet delivered everywhere, at most one new wave per
+        cluster step (a steady stream of statements, not a burst) -> (seconds, cluster steps, ticks fired, counters before)"""
         base = [nd.stats() for nd in c.nodes]
         done = [0] * N  # entries every node has put on its commit channels since `base`
-        steps = fired = 0
+        steps = fired = proposed = 0
         t0 = next_tick = time.perf_counter()
         next_tick += 0.1
-        for r in range(count):
-            stmt = payload_of(r)
-            for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
-                k = len(mine[p])
-                nd.propose_blob(mine[p], np.arange(k + 1, dtype=np.uint64) * len(stmt), stmt * k)
-            want = (r + 1) * G
-            for _ in range(60):
-                due = time.perf_counter() >= next_tick
-                if due:
-                    next_tick += 0.1
-                    fired += 1
-                c.step(tick=due)
-                steps += 1
-                for p in range(N):
-                    done[p] += c.last_published[p]
-                if min(done) >= want:
-                    break
-            else:
+        while min(done) < count * G:
+            if proposed < count and proposed - min(done) // G < in_flight:
+                stmt = payload_of(proposed)
+                for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
+                    k = len(mine[p])
+                    nd.propose_blob(mine[p], np.arange(k + 1, dtype=np.uint64) * len(stmt), stmt * k)
+                proposed += 1
+            due = time.perf_counter() >= next_tick
+            if due:
+                next_tick += 0.1
+                fired += 1
+            c.step(tick=due)
+            steps += 1
+            for p in range(N):
+                done[p] += c.last_published[p]
+            if steps > 60 * count:
                 raise SystemExit("node_measure: a proposal wave did not commit everywhere")
         return time.perf_counter() - t0, steps, fired, base
 

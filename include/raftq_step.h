@@ -58,9 +58,18 @@ typedef struct raftq_msg {
   uint32_t from;        /* sender's peer slot 0..N-1 (raft ID - 1); ignored for local messages */
   uint8_t type;         /* RAFTQ_MSG_* */
   uint8_t reject;       /* m.Reject */
-  uint8_t _pad[2];
-  uint64_t _resv;       /* library use */
+  uint8_t _pad[2];      /* _pad[1]: RAFTQ_MSGF_* (every other bit: library use) */
+  uint64_t _resv;       /* library use, except under RAFTQ_MSGF_ENTRIES */
 } raftq_msg_t;          /* 64 bytes */
+
+/* raftq_msg_t._pad[1].  RAFTQ_MSGF_ENTRIES on a MsgApp: the caller says what the message carries -- the low 32 bits of
+ * _resv = its number of entries, reject_hint (a field MsgApp does not use) = the Term of the last one (unused with no
+ * entries).  Step then runs raftLog.maybeAppend itself whenever the message appends at the TAIL of the log (m.Index ==
+ * lastIndex and m.LogTerm == lastTerm: findConflict has nothing to look at): lastIndex / lastTerm move past the new
+ * entries, commitTo(min(m.Commit, lastnewi)) runs, and the result is RAFTQ_OUT_APPENDED -- no raftq_apply_log_deltas
+ * round trip for the common case of replication.  Every other MsgApp (a gap, a conflict, an index below the tail)
+ * is answered RAFTQ_OUT_APPEND as without the flag.  Ignored on every other kind and on packed (40-byte) records. */
+#define RAFTQ_MSGF_ENTRIES 0x80u
 
 /* what Step did with message i: out[i] answers msgs[i] */
 #define RAFTQ_OUT_NONE 0            /* ignored: stale term, or this role does not handle the type */
@@ -71,6 +80,8 @@ typedef struct raftq_msg {
 #define RAFTQ_OUT_PROGRESS 5        /* leader took MsgAppResp / MsgHeartbeatResp from `to`: index = Progress.Match now */
 #define RAFTQ_OUT_BCAST_HEARTBEAT 6 /* leader's MsgBeat: send MsgHeartbeat to every other peer */
 #define RAFTQ_OUT_APPEND 7          /* MsgApp header accepted: run raftLog.maybeAppend on the log, then raftq_apply_log_deltas */
+#define RAFTQ_OUT_APPENDED 8        /* MsgApp with RAFTQ_MSGF_ENTRIES that appended at the tail: Step did maybeAppend's bookkeeping -- store
+                                     * the entries, send MsgAppResp{Index: index} (index = lastnewi = last_index); commit is final */
 
 #define RAFTQ_OUTF_HARDSTATE 0x01u    /* Term, Vote or Commit changed: HardState must be persisted (wal.Save, raft.go:228) */
 #define RAFTQ_OUTF_COMMITTED 0x02u    /* raftLog.committed advanced (leader: bcastAppend carries it) */

@@ -126,6 +126,24 @@ static void commit_to(node_t* r, uint64_t tocommit) {
   if (F(committed) < tocommit) F(committed) = tocommit;
 }
 
+/* etcd handleAppendEntries after the header was accepted.  With RAFTQ_MSGF_ENTRIES the message says how many entries it
+ * carries and the last one's term; when it appends at the tail, raftLog.maybeAppend reduces to
+ *   matchTerm(m.Index, m.LogTerm) -> findConflict: nothing behind the tail -> append -> commitTo(min(m.Commit, lastnewi))
+ * and is done here (raftq_step.h); every other MsgApp is left to the log's owner (RAFTQ_OUT_APPEND). */
+static void handle_append(node_t* r, const raftq_msg_t* m, raftq_step_out_t* o) {
+  o->type = RAFTQ_OUT_APPEND;
+  if ((m->_pad[1] & RAFTQ_MSGF_ENTRIES) && m->index == F(last_index) && m->log_term == F(last_term)) {
+    const uint64_t k = m->_resv & 0xffffffffull;
+    if (k) {
+      F(last_index) = m->index + k;
+      F(last_term) = m->reject_hint;
+    }
+    commit_to(r, m->commit); /* clamps to lastIndex = lastnewi */
+    o->type = RAFTQ_OUT_APPENDED;
+    o->index = F(last_index);
+  }
+}
+
 static void out_common(node_t* r, const raftq_msg_t* m, raftq_step_out_t* o) {
   o->group = m->group;
   o->term = F(term);
@@ -215,7 +233,7 @@ static void step(node_t* r, const raftq_msg_t* m, raftq_step_out_t* o) {
       switch (m->type) {
         case RAFTQ_MSG_APP:
           become_follower(r, F(term), m->from + 1);
-          o->type = RAFTQ_OUT_APPEND;
+          handle_append(r, m, o);
           break;
         case RAFTQ_MSG_HEARTBEAT:
           become_follower(r, F(term), m->from + 1);
@@ -250,7 +268,7 @@ static void step(node_t* r, const raftq_msg_t* m, raftq_step_out_t* o) {
         case RAFTQ_MSG_APP:
           F(elapsed) = 0;
           F(lead) = m->from + 1;
-          o->type = RAFTQ_OUT_APPEND;
+          handle_append(r, m, o);
           break;
         case RAFTQ_MSG_HEARTBEAT:
           F(elapsed) = 0;

@@ -246,6 +246,22 @@ struct PinBuf {
   template <typename T> size_t count() const { return size / sizeof(T); }
 };
 
+// u64 offsets in page-locked memory: the codecs copy them to / from the device, and a copy from pageable memory goes
+// through the runtime's staging buffer, synchronously
+struct PinU64 {
+  PinBuf b;
+  size_t size() const { return b.size / 8; }
+  bool empty() const { return b.size == 0; }
+  uint64_t* data() { return (uint64_t*)b.p; }
+  void clear() { b.size = 0; }
+  void swap(PinU64& o) { b.swap(o.b); }
+  bool resize(size_t k) {  // new elements are not initialised
+    if (!b.reserve(k * 8)) return false;
+    b.size = k * 8;
+    return true;
+  }
+};
+
 struct alignas(64) Group {
   // -- the cache line every message of the group touches
   uint64_t term = 0, committed = 0, applied = 0;
@@ -304,6 +320,8 @@ struct raftq_node {
   Arena arena;                    // entry payloads (logs, commit channels)
   Pool pool;                      // the groups' log and commit-channel arrays
   bool oom = false;               // an arena or queue allocation failed this turn: advance() ends in ENOMEM
+  bool tail_appends = true;       // MsgApps are staged with RAFTQ_MSGF_ENTRIES (RAFTQ_NODE_TAIL_APPENDS=0: headers only, as round 2)
+  bool broken = false;            // the engine's view of a log and the log itself disagree: advance() ends in ESTATE
   // the turn's decoded inbound entries and the bytes their payloads sit in (valid inside advance())
   const raftq_wire_ent_t* cur_ents = nullptr;
   const uint8_t* cur_bytes = nullptr;
@@ -312,7 +330,7 @@ struct raftq_node {
   std::vector<PeerQueue> outbound;  // [peer]
   // inbound stream frames as delivered (decoded on the GPU at the next advance)
   PinBuf in_bytes;
-  std::vector<uint64_t> in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size]
+  PinU64 in_off;  // frame boundaries in in_bytes; empty or [0, ..., in_bytes.size]
   // this turn's outbound messages, one lane per addressee, marshalled in one raftq_wire_encode at the end of advance()
   std::vector<OutLane> out_lane;
   // Progress.Next / Progress.Match mirror of the groups this node leads: prog[(g * N + peer) * 2 + {0: Next, 1: Match}]
@@ -323,7 +341,8 @@ struct raftq_node {
   // advance()'s own scratch (only touched under turn_mu): the other half of the inbound double buffer,
   // decoded records, the sorted outbound batch and its stream
   PinBuf turn_bytes, turn_msgs, turn_ents, enc_msgs, enc_out, wal_recs, wal_pool, wal_enc;
-  std::vector<uint64_t> turn_off, enc_off, lane_first;
+  PinU64 turn_off, enc_off;
+  std::vector<uint64_t> lane_first;
   // WAL (off unless raftq_node_wal_enable): encoded records waiting for raftq_node_wal_poll
   bool wal_on = false, wal_head_written = false;
   uint32_t wal_crc = 0;
@@ -575,6 +594,27 @@ bool handle_proposal(raftq_node_t* n, uint64_t gi, Group& g, const Entry* ents, 
   return false;
 }
 
+// RAFTQ_OUT_APPENDED: Step found the MsgApp on the log's tail and did raftLog.maybeAppend's bookkeeping; the entries
+// themselves go into the log here.  false: they could not be stored (the node poisons itself at the end of the turn).
+bool store_at_tail(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_msg_t& m) {
+  if (m.index != g.log.size()) {  // the engine's tail and the log's have parted: nothing this node says can be trusted
+    n->broken = true;
+    return false;
+  }
+  if (m.n_ents == 0) return true;
+  const raftq_wire_ent_t* ents = n->cur_ents + m.ent_first;
+  for (uint32_t k = 0; k < m.n_ents; ++k) {
+    const char* at = n->arena.put(n->cur_bytes + ents[k].data_off, ents[k].data_len);
+    if (!at) {
+      n->oom = true;
+      return false;
+    }
+    g.log.push_back(n->pool, Entry{ents[k].term, at, ents[k].data_len});
+  }
+  wal_touch(n, gi, g);
+  return true;
+}
+
 // handleAppendEntries on the log's owner, after Step accepted the header (RAFTQ_OUT_APPEND)
 void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_msg_t& m) {
   const raftq_wire_ent_t* ents = n->cur_ents + m.ent_first;
@@ -665,8 +705,15 @@ void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const raftq_wire_m
     }
     if (o.flags & RAFTQ_OUTF_STEPPED_DOWN) g.leading = false;
   }
+  // Step appended the message's entries at the tail itself (RAFTQ_MSGF_ENTRIES): they go into the log BEFORE the commit
+  // index it reports is published
+  bool stored = true;
+  if (o.type == RAFTQ_OUT_APPENDED) stored = store_at_tail(n, gi, g, im);
   note_commit(n, g, o.commit);
   switch (o.type) {
+    case RAFTQ_OUT_APPENDED:
+      if (stored) send(n, o.to, gi, RAFTQ_MSG_APP_RESP, o.term).index = o.index;  // MsgAppResp{Index: lastnewi}
+      break;
     case RAFTQ_OUT_VOTE_RESP:
       send(n, o.to, gi, RAFTQ_MSG_VOTE_RESP, o.term).reject = o.reject;
       break;
@@ -773,8 +820,7 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   }
   // the lanes back to back: per-peer order is the order of the sends, and every peer's frames are one slice of the stream
   n->enc_msgs.clear();
-  n->enc_off.resize(nm + 1);
-  if (!n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t)) || !n->enc_out.reserve(cap)) {
+  if (!n->enc_off.resize(nm + 1) || !n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t)) || !n->enc_out.reserve(cap)) {
     lk.unlock();
     return RAFTQ_ENOMEM;
   }
@@ -916,6 +962,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   n->N = n_peers;
   n->self = self_peer;
   n->profiling = std::getenv("RAFTQ_PROFILE") != nullptr;
+  if (const char* ta = std::getenv("RAFTQ_NODE_TAIL_APPENDS")) n->tail_appends = std::atoi(ta) != 0;
   if (const char* ev = std::getenv("RAFTQ_PROFILE_EVERY")) n->prof_every = std::strtoull(ev, nullptr, 10);
   try {
     n->groups.resize(n_groups);
@@ -1124,15 +1171,16 @@ static int deliver_impl(raftq_node_t* n, const void* frames, uint64_t len, const
     return RAFTQ_ESTATE;
   }
   const uint64_t base = n->in_bytes.size;
-  try {
-    if (n->in_off.empty()) n->in_off.push_back(0);
-    const size_t at = n->in_off.size();
-    n->in_off.resize(at + (size_t)nf);  // before the bytes: a failure here leaves the buffer as it was
-    if (!n->in_bytes.append(frames, (size_t)len)) {
-      n->in_off.resize(at);
+  {
+    const bool was_empty = n->in_off.empty();
+    const size_t at = was_empty ? 1 : n->in_off.size();
+    // the offsets before the bytes: a failure leaves the buffer as it was
+    if (!n->in_off.resize(at + (size_t)nf) || !n->in_bytes.append(frames, (size_t)len)) {
+      n->in_off.resize(was_empty ? 0 : at);
       n->errtext = "deliver: page-locked allocation failed";
       return RAFTQ_ENOMEM;
     }
+    if (at == 1) n->in_off.data()[0] = 0;
     uint64_t* off = n->in_off.data() + at;
     if (ends) {
       for (uint64_t i = 0; i < nf; ++i) off[i] = base + ends[i];
@@ -1143,9 +1191,6 @@ static int deliver_impl(raftq_node_t* n, const void* frames, uint64_t len, const
         off[i] = base + pos;
       }
     }
-  } catch (...) {
-    n->errtext = "deliver: host allocation failed";
-    return RAFTQ_ENOMEM;
   }
   return RAFTQ_OK;
 }
@@ -1178,7 +1223,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   n->cur_ents = nullptr;
   n->cur_bytes = nullptr;
   PinBuf& in_bytes = n->turn_bytes;  // the half of the inbound double buffer this turn decodes
-  std::vector<uint64_t>& in_off = n->turn_off;
+  PinU64& in_off = n->turn_off;
   in_bytes.clear();
   in_off.clear();
   uint32_t ticks = 0;
@@ -1335,8 +1380,18 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       }
       if (m.type == RAFTQ_MSG_PROP) {  // MsgProp never reaches Step; everything else does, in arrival order
         mark = ep;
+      } else if (m.type == RAFTQ_MSG_APP) {
+        // a MsgApp says what it carries (RAFTQ_MSGF_ENTRIES): one that lands on the log's tail -- replication's common
+        // case -- is then appended and committed by Step itself, with no raftq_apply_log_deltas round trip behind it
+        mark = ep;
+        raftq_msg_t t;
+        std::memcpy(&t, &m, sizeof(t));
+        t._pad[0] = 0;
+        t._pad[1] = n->tail_appends ? RAFTQ_MSGF_ENTRIES : 0;
+        t._resv = m.n_ents;
+        t.reject_hint = m.n_ents ? n->cur_ents[m.ent_first + m.n_ents - 1].term : 0;
+        std::memcpy(&staged[n_step++], &t, sizeof(t));
       } else {
-        if (m.type == RAFTQ_MSG_APP) mark = ep;
         std::memcpy(&staged[n_step++], &m, sizeof(raftq_msg_t));
       }
       batch.push_back(ix);
@@ -1403,6 +1458,10 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   if (n->oom) {
     lk.unlock();
     return poison(n, RAFTQ_ENOMEM, "entry storage");
+  }
+  if (n->broken) {
+    lk.unlock();
+    return poison(n, RAFTQ_ESTATE, "the engine's log tail and the node's log disagree");
   }
   // -- wal.Save before transport.Send (raft.go:228-230): the caller persists what raftq_node_wal_poll
   // hands out before it transmits what raftq_node_poll hands out

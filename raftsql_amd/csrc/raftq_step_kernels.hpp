@@ -63,7 +63,8 @@ struct NodeArrays {
 constexpr uint8_t kMsgHup = 0, kMsgBeat = 1, kMsgApp = 3, kMsgAppResp = 4, kMsgVote = 5, kMsgVoteResp = 6,
                   kMsgHeartbeat = 8, kMsgHeartbeatResp = 9;
 constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCampaign = 3, kOutBecameLeader = 4,
-                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7;
+                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7, kOutAppended = 8;
+constexpr uint8_t kMsgfEntries = 0x80;  // raftq_msg_t._pad[1]: RAFTQ_MSGF_ENTRIES
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
@@ -243,6 +244,23 @@ struct Node {
     if (committed < tocommit) committed = tocommit;
   }
 
+  // handleAppendEntries once the header is accepted.  A message that says what it carries (RAFTQ_MSGF_ENTRIES) and
+  // appends at the log's tail needs nothing from the entries but their count and the last one's term:
+  // raftLog.maybeAppend = matchTerm(tail) -> no conflict possible -> append -> commitTo(min(m.Commit, lastnewi)).
+  __device__ void handle_append(const MsgRec& m, StepOutRec& o) {
+    o.type = kOutAppend;
+    if ((m.pad[1] & kMsgfEntries) && m.index == last_index && m.log_term == last_term) {
+      const uint64_t k = m.resv & 0xffffffffull;
+      if (k) {
+        last_index = m.index + k;
+        last_term = m.reject_hint;
+      }
+      commit_to(m.commit);  // clamps to last_index = lastnewi
+      o.type = kOutAppended;
+      o.index = last_index;
+    }
+  }
+
   __device__ void step(const MsgRec& m, StepOutRec& o) {
     const uint64_t term0 = term, commit0 = committed;
     const uint32_t vote0 = vote;
@@ -289,7 +307,7 @@ struct Node {
       } else if (role == kCandidate) {
         if (m.type == kMsgApp) {
           become_follower(term, m.from + 1);
-          o.type = kOutAppend;
+          handle_append(m, o);
         } else if (m.type == kMsgHeartbeat) {
           become_follower(term, m.from + 1);
           commit_to(m.commit);
@@ -309,7 +327,7 @@ struct Node {
       } else {
         if (m.type == kMsgApp) {
           elapsed = 0; lead = m.from + 1;
-          o.type = kOutAppend;
+          handle_append(m, o);
         } else if (m.type == kMsgHeartbeat) {
           elapsed = 0; lead = m.from + 1;
           commit_to(m.commit);

@@ -66,6 +66,16 @@ def random_batch(rng, s, n, hot_groups=None):
     m["commit"] = np.maximum(0, li + rng.integers(-4, 3, n)).astype(np.uint64)
     m["reject"] = rng.random(n) < 0.3
     m["reject_hint"] = m["index"]
+    # half of the MsgApps say what they carry (RAFTQ_MSGF_ENTRIES: _resv = entries, reject_hint = the last one's term), and
+    # half of those sit exactly on the tail the group has when the batch is made -- Step then appends by itself
+    says = (t == 3) & (rng.random(n) < 0.5)
+    tail = says & (rng.random(n) < 0.5)
+    m["index"] = np.where(tail, s.last_index[g], m["index"])
+    m["log_term"] = np.where(tail, s.last_term[g], m["log_term"])
+    m["_pad"][:, 1] = np.where(says, 0x80, 0)
+    k = rng.integers(0, 4, n).astype(np.uint64)
+    m["_resv"] = np.where(says, k | (rng.integers(0, 2**31, n).astype(np.uint64) << np.uint64(32)), 0)  # high half: ignored
+    m["reject_hint"] = np.where(says, np.maximum(m["log_term"], m["term"] - (rng.random(n) < 0.5)), m["reject_hint"])
     return m
 
 

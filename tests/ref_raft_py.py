@@ -11,6 +11,7 @@ reference, raft.go:27-34), reached through rc.node.Step (raft.go:268-270) and rc
 """
 from __future__ import annotations
 
+from typing import Optional
 from dataclasses import dataclass, field
 
 NONE = 0  # raft.None
@@ -18,6 +19,7 @@ MsgHup, MsgBeat, MsgApp, MsgAppResp, MsgVote, MsgVoteResp, MsgHeartbeat, MsgHear
 StateFollower, StateCandidate, StateLeader = 0, 1, 2
 (OutNone, OutVoteResp, OutHeartbeatResp, OutCampaign, OutBecameLeader, OutProgress, OutBcastHeartbeat,
  OutAppend) = range(8)
+OutAppended = 8
 FlagHardState, FlagCommitted, FlagUpdated, FlagSteppedDown = 1, 2, 4, 8
 
 
@@ -30,6 +32,7 @@ class Message:
     index: int = 0
     commit: int = 0
     reject: bool = False
+    entries: Optional[tuple] = None  # MsgApp: the Terms of the entries it carries; None = not said (header only)
 
 
 @dataclass
@@ -180,10 +183,22 @@ class Raft:
             return Result(OutProgress, index=self.prs[m.frm].match)
         return Result()
 
+    def handle_append_entries(self, m: Message) -> Result:
+        """handleAppendEntries once the header is accepted.  Only a message that says what it carries AND lands on the
+        tail is finished here: matchTerm holds, nothing lies behind the tail for findConflict, the entries go on,
+        commitTo(min(m.Commit, lastnewi)).  Everything else is the log owner's (OutAppend)."""
+        if m.entries is not None and m.index == self.last_index and m.log_term == self.last_term:
+            if m.entries:
+                self.last_index = m.index + len(m.entries)
+                self.last_term = m.entries[-1]
+            self.commit_to(min(m.commit, self.last_index))
+            return Result(OutAppended, index=self.last_index)
+        return Result(OutAppend)
+
     def step_candidate(self, m: Message) -> Result:
         if m.type == MsgApp:
             self.become_follower(self.term, m.frm)
-            return Result(OutAppend)
+            return self.handle_append_entries(m)
         if m.type == MsgHeartbeat:
             self.become_follower(self.term, m.frm)
             self.commit_to(m.commit)
@@ -203,7 +218,7 @@ class Raft:
         if m.type == MsgApp:
             self.elapsed = 0
             self.lead = m.frm
-            return Result(OutAppend)
+            return self.handle_append_entries(m)
         if m.type == MsgHeartbeat:
             self.elapsed = 0
             self.lead = m.frm

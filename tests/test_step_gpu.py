@@ -492,6 +492,8 @@ def _widened(m):
     resp = m["type"] == S.MSG_APP_RESP
     w["log_term"] = np.where(resp, 0, m["log_term"])
     w["reject_hint"] = np.where(resp, m["reject_hint"], 0)
+    w["_pad"] = 0  # a packed record has no room for RAFTQ_MSGF_ENTRIES: its MsgApps are headers only
+    w["_resv"] = 0
     return w
 
 

@@ -232,7 +232,9 @@ def test_c_oracle_agrees_with_the_object_shaped_python_statement(seed, N, self_p
             res = rafts[g].step(R.Message(type=int(m["type"][i]), frm=0 if local else int(m["from"][i]) + 1,
                                           term=int(m["term"][i]), log_term=int(m["log_term"][i]),
                                           index=int(m["index"][i]), commit=int(m["commit"][i]),
-                                          reject=bool(m["reject"][i])))
+                                          reject=bool(m["reject"][i]),
+                                          entries=(int(m["reject_hint"][i]),) * int(int(m["_resv"][i]) & 0xFFFFFFFF)
+                                          if int(m["_pad"][i][1]) & 0x80 else None))
             o, r = out[i], rafts[g]
             assert (res.type, res.index, res.log_term, res.reject, res.flags) == \
                 (o["type"], o["index"], o["log_term"], o["reject"], o["flags"]), (i, m[i], o, res)

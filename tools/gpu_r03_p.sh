@@ -1,13 +1,12 @@
 #!/bin/bash
-# r03 trip P: the node's own allocator for the per-group arrays, with and without huge pages, same box
 mkdir -p gpurun_out/r03
 {
-timeout 600 python -m pytest -m gpu -x -q tests/test_node_gpu.py tests/test_node_scenarios_gpu.py 2>&1 | tail -2
-for i in 1 2; do
-for t in "" "1"; do
-  echo "== RAFTQ_NODE_THP=$t"
-  RAFTQ_NODE_THP=$t RAFTQ_PROFILE=1 RAFTQ_PROFILE_EVERY=118 timeout 300 python tools/profile_node.py 2>&1 | grep -v "amdgpu.ids\|over 118\|^wall" | sed -e 's/.what.*leaders_per_node/leaders/' | cut -c1-700
-done
-done
-} > gpurun_out/r03/node_pool_ab.txt 2>&1
-cat gpurun_out/r03/node_pool_ab.txt
+python tools/probe/codec_call_probe.py 2>&1 | grep -v amdgpu.ids
+cd /tmp && export TMPDIR=/tmp
+REPS=50 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03/codec_call -o cc -- python $GRAFT_REPO_ROOT/tools/probe/codec_call_probe.py 2>&1 | grep -v amdgpu.ids | tail -3
+cd $GRAFT_REPO_ROOT
+find gpurun_out/r03/codec_call -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'cut -d, -f1-4 {} | cut -c1-150'
+find gpurun_out/r03/codec_call -name "*memory_copy_stats.csv" | head -1 | xargs cat
+find gpurun_out/r03/codec_call -name "*trace.csv" -size +3M -delete
+} > gpurun_out/r03/codec_call_probe.txt 2>&1
+cat gpurun_out/r03/codec_call_probe.txt

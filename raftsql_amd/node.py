@@ -176,7 +176,12 @@ class RaftNode:
         self._chk(self._lib.raftq_node_advance(self._p, C.byref(n)))
         return int(n.value)
 
-    def poll(self, to_peer: int) -> bytes:
+    def poll(self, to_peer: int, cap: Optional[int] = None) -> bytes:
+        """everything queued for `to_peer`; with `cap`: one raftq_node_poll call -- the whole frames that fit in cap bytes"""
+        if cap is not None:
+            n = C.c_uint64(0)
+            self._chk(self._lib.raftq_node_poll(self._p, to_peer, self._wire, min(cap, len(self._wire)), C.byref(n)))
+            return C.string_at(self._wire, n.value)
         out = []
         while True:
             n = C.c_uint64(0)

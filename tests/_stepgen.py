@@ -94,3 +94,52 @@ def assert_same_state(e, s):
         assert np.array_equal(got[k], getattr(s, k)), k
     assert np.array_equal(e.read_match(), s.match), "match"
     assert np.array_equal(e.read_votes(), s.votes), "votes"
+
+
+def tail_append_table():
+    """RAFTQ_MSGF_ENTRIES by hand: (state, message) rows with the answer handleAppendEntries / raftLog.maybeAppend give.
+    Each row is a group of one follower (or candidate) of a 3-peer cluster, peer slot 1, at term 5 with
+    log tail (index 10, term 4) and commit 7.  -> (NodeState, msgs, want) with want[i] = (type, index, commit after,
+    last_index after, last_term after, role after)"""
+    rows = [
+        # (role, flag, m.term, m.index, m.log_term, m.commit, n_ents, last_ent_term) -> (out type, out index, commit, last, lterm, role)
+        (0, 1, 5, 10, 4, 7, 2, 5, (8, 12, 7, 12, 5, 0)),    # two entries on the tail: appended, commit unchanged
+        (0, 1, 5, 10, 4, 12, 2, 5, (8, 12, 12, 12, 5, 0)),   # ... and the leader's commit covers them
+        (0, 1, 5, 10, 4, 99, 1, 5, (8, 11, 11, 11, 5, 0)),   # commitTo(min(m.Commit, lastnewi))
+        (0, 1, 5, 10, 4, 9, 0, 0, (8, 10, 9, 10, 4, 0)),     # no entries: the commit index alone moves (the leader's bcastAppend after a commit)
+        (0, 1, 5, 10, 4, 3, 0, 0, (8, 10, 7, 10, 4, 0)),     # a commit index below ours: commitTo never goes back
+        (0, 0, 5, 10, 4, 12, 2, 5, (7, 0, 7, 10, 4, 0)),     # the same message without the flag: the header only, as before
+        (0, 1, 5, 9, 4, 12, 2, 5, (7, 0, 7, 10, 4, 0)),      # below the tail: findConflict needs the log -- the owner's (OUT_APPEND)
+        (0, 1, 5, 11, 4, 12, 2, 5, (7, 0, 7, 10, 4, 0)),     # a gap: the owner rejects with its hint
+        (0, 1, 5, 10, 3, 12, 2, 5, (7, 0, 7, 10, 4, 0)),     # the tail's term does not match
+        (0, 1, 4, 10, 4, 12, 2, 4, (0, 0, 7, 10, 4, 0)),     # a stale leader (term 4 < 5): ignored altogether
+        (0, 1, 6, 10, 4, 12, 1, 6, (8, 11, 11, 11, 6, 0)),   # a newer term: becomeFollower(6), then the append
+        (1, 1, 5, 10, 4, 11, 1, 5, (8, 11, 11, 11, 5, 0)),   # a candidate of the same term concedes, then appends
+    ]
+    G = len(rows)
+    s = pyoracle.NodeState(G, 3, 1)
+    s.term[:], s.last_index[:], s.last_term[:], s.committed[:] = 5, 10, 4, 7
+    s.role[:] = [r[0] for r in rows]
+    s.vote[:] = np.where(s.role == 1, 2, 0)
+    s.votes[1, s.role == 1] = 1
+    s.match[1] = 10
+    m = np.zeros(G, dtype=pyoracle.STEP_MSG_DT)
+    m["group"] = np.arange(G)
+    m["type"], m["from"] = 3, 0
+    m["_pad"][:, 1] = [0x80 if r[1] else 0 for r in rows]
+    m["term"] = [r[2] for r in rows]
+    m["index"] = [r[3] for r in rows]
+    m["log_term"] = [r[4] for r in rows]
+    m["commit"] = [r[5] for r in rows]
+    m["_resv"] = [r[6] for r in rows]
+    m["reject_hint"] = [r[7] for r in rows]
+    return s, m, [r[8] for r in rows]
+
+
+def check_tail_append_table(out, state_after, want):
+    for i, (typ, idx, commit, last, lterm, role) in enumerate(want):
+        o = out[i]
+        assert (int(o["type"]), int(o["index"]), int(o["commit"]), int(o["last_index"]), int(o["role"])) == \
+            (typ, idx, commit, last, role), (i, o)
+        assert (int(state_after.committed[i]), int(state_after.last_index[i]), int(state_after.last_term[i])) == \
+            (commit, last, lterm), i

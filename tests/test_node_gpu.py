@@ -736,3 +736,59 @@ def test_forward_moves_or_drops_whole_queues(Cluster):
         assert all(nd.drain(7) == [b"two"] for nd in c.nodes)
     finally:
         c.close()
+
+
+def test_crank_steps_like_the_serial_cluster_and_refuses_bad_calls(Cluster):
+    """raftq_crank_step: one call turns every live node on a thread of its own and moves the frames per addressee -- the
+    delivered streams are those of the serial crank (the 4-way test above compares every frame); here: its bookkeeping
+    (entries published per node, the two halves' wall time), a partly polled queue still forwarded frame for frame, a
+    stopped node's NULL slot, a live bit for a node that is not there, and proposals handed over as arrays."""
+    import ctypes as C
+
+    from raftsql_amd import node as ND
+
+    G, N = 300, 3
+    c = Cluster(G, N, seed=11, threads=True, native_transport=True)
+    try:
+        c.start()
+        elect(c)
+        lead = c.leaders()
+        for p, nd in enumerate(c.nodes):  # raftq_node_propose_batch from arrays: no Python list of payloads
+            mine = np.nonzero(lead == p)[0]
+            stmt = b"INSERT %d" % p
+            nd.propose_blob(mine, np.arange(len(mine) + 1, dtype=np.uint64) * len(stmt), stmt * len(mine))
+        total = [0] * N
+        for _ in range(8):
+            c.step(tick=False)
+            total = [a + b for a, b in zip(total, c.last_published)]
+        assert total == [G] * N and c.seconds["turns"] > 0 and c.seconds["transport"] > 0
+        for p, nd in enumerate(c.nodes):
+            for g in range(G):
+                assert [d for d in nd.drain(g) if d is not None] == [b"INSERT %d" % int(lead[g])]
+        # a queue somebody polled from has lost its frame ends: forward still moves whole frames (it walks them again)
+        p = int(lead[5])
+        q = (p + 1) % N
+        c.nodes[p].propose(5, b"x" * 40)
+        c.nodes[p].propose(6 if lead[6] == p else 5, b"y" * 50)
+        c.nodes[p].advance()
+        first = c.nodes[p].poll(q, cap=170)  # the first frame or two, not all of them
+        assert 0 < len(first) <= 170
+        c.nodes[q].deliver(first)
+        c.run(4, tick=False)
+        check_safety(c)
+        assert all(nd.status(5).commit == c.nodes[p].status(5).commit for nd in c.nodes)
+        # the crank itself: a stopped node is a NULL slot; asking for its turn is refused, the others go on
+        lib = ND._load()
+        c.stop(2)
+        c.step(tick=True)
+        assert c._crank is not None
+        pub = np.zeros(N, np.uint64)
+        assert lib.raftq_crank_step(c._crank, 0b111, 0, None, pub.ctypes.data, None) != 0  # node 2 is not there
+        assert lib.raftq_crank_step(c._crank, 0b1000, 0, None, None, None) != 0            # nor is a fourth
+        assert lib.raftq_crank_step(c._crank, 0b011, 0, None, pub.ctypes.data, None) == 0
+        out = C.c_void_p()
+        assert lib.raftq_crank_create(None, 3, None, C.byref(out)) != 0
+        two = (C.c_void_p * 2)(c.nodes[0]._p, c.nodes[1]._p)
+        assert lib.raftq_crank_create(two, 2, None, C.byref(out)) != 0  # nodes of a 3-peer cluster are not a 2-peer one
+    finally:
+        c.close()

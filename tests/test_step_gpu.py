@@ -583,3 +583,19 @@ def test_step_staged_pointer_reused_for_a_later_batch(NodeEngine, oracle):
         for mm in (a, b, a):
             assert np.array_equal(e.step_collect()[0], s.step_batch(mm))
         _stepgen.assert_same_state(e, s)
+
+
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+def test_tail_append_table_on_the_gpu(NodeEngine, oracle, walk, monkeypatch):
+    """the hand-made RAFTQ_MSGF_ENTRIES rows (tests/_stepgen.py) through both walks: the answers written there, the
+    oracle's bytes, the oracle's state"""
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    s, m, want = _stepgen.tail_append_table()
+    with NodeEngine(s.G, s.N, s.self_peer) as e:
+        _stepgen.load_engine(e, s)
+        ref = s.step_batch(m)
+        got, _ = e.step_batch(m)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        _stepgen.check_tail_append_table(got, s, want)
+        _stepgen.assert_same_state(e, s)

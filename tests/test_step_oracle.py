@@ -339,3 +339,11 @@ def test_upstream_is_election_timeout_window_as_recalled(oracle):
         if row["round"]:
             got = np.floor(got * 10 + 0.5) / 10.0
         assert got == row["p"], (row, n_hup / G)
+
+
+def test_tail_append_table_c_oracle():
+    """RAFTQ_MSGF_ENTRIES: a MsgApp that says what it carries and lands on the tail is appended and committed by Step
+    itself (raftLog.maybeAppend without a conflict to look for); everything else is left to the log's owner"""
+    s, m, want = _stepgen.tail_append_table()
+    out = s.step_batch(m)
+    _stepgen.check_tail_append_table(out, s, want)

@@ -1,12 +1,12 @@
 #!/bin/bash
+# r03 trip: do the three nodes' streams share hardware queues?  the node leg with more of them
 mkdir -p gpurun_out/r03
 {
-python tools/probe/codec_call_probe.py 2>&1 | grep -v amdgpu.ids
-cd /tmp && export TMPDIR=/tmp
-REPS=50 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03/codec_call -o cc -- python $GRAFT_REPO_ROOT/tools/probe/codec_call_probe.py 2>&1 | grep -v amdgpu.ids | tail -3
-cd $GRAFT_REPO_ROOT
-find gpurun_out/r03/codec_call -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'cut -d, -f1-4 {} | cut -c1-150'
-find gpurun_out/r03/codec_call -name "*memory_copy_stats.csv" | head -1 | xargs cat
-find gpurun_out/r03/codec_call -name "*trace.csv" -size +3M -delete
-} > gpurun_out/r03/codec_call_probe.txt 2>&1
-cat gpurun_out/r03/codec_call_probe.txt
+for i in 1 2; do
+for q in "" 8 16; do
+  echo "== GPU_MAX_HW_QUEUES=$q"
+  GPU_MAX_HW_QUEUES=$q RAFTQ_PROFILE=1 RAFTQ_PROFILE_EVERY=118 timeout 300 python tools/profile_node.py 2>&1 | grep -v "amdgpu.ids\|over 118\|^wall" | sed -e 's/.what.*leaders_per_node/leaders/' | cut -c1-1000 | grep -v "^ " | grep -v "raftq_node [12]\]"
+done
+done
+} > gpurun_out/r03/node_hwq_ab.txt 2>&1
+cat gpurun_out/r03/node_hwq_ab.txt

@@ -1338,13 +1338,24 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   };
   // report the grown logs' tails, publish what that committed, then bcastAppend
   auto flush_dirty = [&]() -> int {
-    for (uint64_t gi : dirty) {
+    const size_t nd = dirty.size();
+    for (size_t i = 0; i < nd; ++i) {
+      if (i + 16 < nd) __builtin_prefetch(&n->groups[dirty[i + 16]]);
+      const uint64_t gi = dirty[i];
       Group& g = n->groups[gi];
       raftq_log_delta_t d{gi, g.log.size(), g.term, 0};
       n->deltas.push_back(d);
     }
     if (int rc = flush_deltas(n, lk)) return rc;
-    for (uint64_t gi : dirty) bcast_append(n, gi, n->groups[gi]);
+    for (size_t i = 0; i < nd; ++i) {  // bcastAppend: the group's line, its Progress and the entry before Next
+      if (i + 16 < nd) __builtin_prefetch(&n->groups[dirty[i + 16]]);
+      if (i + 8 < nd) {
+        const Group& ahead = n->groups[dirty[i + 8]];
+        __builtin_prefetch(&n->prog[dirty[i + 8] * n->N * 2], 1);
+        if (!ahead.log.empty()) __builtin_prefetch(&ahead.log.back());
+      }
+      bcast_append(n, dirty[i], n->groups[dirty[i]]);
+    }
     return RAFTQ_OK;
   };
   bool first_round = true;
@@ -1445,7 +1456,13 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   if (props.size()) {
     dirty.clear();
     const uint32_t ep = next_epoch();
-    for (size_t i = 0; i < props.size(); ++i) {
+    const size_t np_ = props.size();
+    for (size_t i = 0; i < np_; ++i) {
+      if (i + 16 < np_) __builtin_prefetch(&n->groups[props.group[i + 16]]);
+      if (i + 8 < np_) {  // appendEntry writes behind the log's last entry
+        const Group& ahead = n->groups[props.group[i + 8]];
+        if (ahead.log.p) __builtin_prefetch(ahead.log.p + ahead.log.n, 1);
+      }
       const uint64_t gi = props.group[i];
       const Entry one{0, props.blob.data() + props.off[i], (uint32_t)(props.off[i + 1] - props.off[i])};
       if (handle_proposal(n, gi, n->groups[gi], &one, 1) && n->dirty_mark[gi] != ep) {

@@ -53,7 +53,19 @@ if PIN:
 
         Cluster._turn = pinned_turn
     print("pin:", PIN, "near cpus", near[0], "..", near[-1], len(near), flush=True)
-c = Cluster(G, N, device=0, seed=5, threads=THREADS)
+# NODE_CRANK=1: round 3's runner (the library's own pinned threads + in-process transport) under THIS file's loop, which is
+# round 2's bench loop: six waves, a Tick every third step, the commit check only after the steps without one
+if os.environ.get("NODE_CRANK") == "1":
+    from bench import gpu_numa_cpus, one_cpu_per_l3
+
+    near = gpu_numa_cpus(0)
+    if near:
+        os.sched_setaffinity(0, near)
+    cores = one_cpu_per_l3(near or os.sched_getaffinity(0), N + 1)
+    THREADS = True
+    c = Cluster(G, N, device=0, seed=5, threads=True, native_transport=True, pin_cpus=cores[1:] if len(cores) == N + 1 else None)
+else:
+    c = Cluster(G, N, device=0, seed=5, threads=THREADS)
 c.start()
 t0 = time.perf_counter()
 ticks = 0

@@ -165,6 +165,8 @@ struct raftq {
   void* wire_out = nullptr;
   size_t wire_out_bytes = 0;
   uint64_t* wire_pin = nullptr;    // pinned, 256 bytes
+  uint64_t* wire_pin_d = nullptr;  // the same block as the device addresses it (the codecs' last kernel writes totals / flags there)
+  unsigned long long* wire_flags = nullptr;  // device, 64 bytes, zero between calls: the codecs' malformed counters / bad flags
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "raftq_internal.hpp"
@@ -52,7 +53,36 @@ int grow(raftq_t* h, void** buf, size_t* have, size_t want) {
 
 int ensure_pin(raftq_t* h) {
   if (h->wire_pin) return RAFTQ_OK;
-  HIPCHK(h, hipHostMalloc((void**)&h->wire_pin, 256, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&h->wire_pin, 256, hipHostMallocMapped));
+  HIPCHK(h, hipHostGetDevicePointer((void**)&h->wire_pin_d, h->wire_pin, 0));
+  HIPCHK(h, hipMalloc((void**)&h->wire_flags, 64));
+  HIPCHK(h, hipMemsetAsync(h->wire_flags, 0, 64, h->stream));  // wire_tail_kernel leaves a used word zero again
+  return RAFTQ_OK;
+}
+
+// the address the device has for caller memory, or nullptr when it has none (pageable memory: the runtime's copies then)
+void* dev_view(const void* p) {
+  if (!p) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
+bool kernel_copies() {  // RAFTQ_WIRE_KERNEL_COPIES=0: the runtime's copies even for page-locked buffers (round 2's form; for A/B)
+  static const bool on = [] {
+    const char* e = std::getenv("RAFTQ_WIRE_KERNEL_COPIES");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+unsigned copy_blocks(uint64_t bytes) { return (unsigned)std::min<uint64_t>(kCopyBlocks, std::max<uint64_t>(1, (bytes / 16 + kBlock - 1) / kBlock)); }
+
+// totals / flags of the call -> wire_pin[0], wire_pin[1] (read after the next hipStreamSynchronize)
+int tail_to_pin(raftq_t* h, const uint64_t* total, unsigned long long* flag) {
+  hipLaunchKernelGGL(wire_tail_kernel, dim3(1), dim3(64), 0, h->stream, total, flag, h->wire_pin_d);
+  HIPCHK(h, hipGetLastError());
   return RAFTQ_OK;
 }
 
@@ -82,6 +112,8 @@ int d2h(raftq_t* h, void* dst, const void* src, size_t bytes) {
 void raftq_detail::free_wire_state(raftq_t* h) {
   (void)hipFree(h->wire_dev);
   (void)hipFree(h->wire_out);
+  (void)hipFree(h->wire_flags);
+  h->wire_flags = nullptr;
   if (h->wire_pin) (void)hipHostFree(h->wire_pin);
   h->wire_dev = h->wire_out = nullptr;
   h->wire_pin = nullptr;
@@ -132,17 +164,57 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   WireEnt* d_ents = (WireEnt*)(base + o_ents);
   uint8_t* d_pool = base + o_pool;
   uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
-  unsigned int* d_bad = (unsigned int*)(base + o_bad);
+  unsigned int* d_bad = (unsigned int*)(h->wire_flags + 0);  // (o_bad: unused since the flags have a block of their own)
+  (void)o_bad;
+  // Page-locked caller buffers (what a node passes every turn): the whole call is ONE chain with ONE wait -- everything in
+  // with one launch, sizes, scan, the writers (which refuse a bad or oversized batch themselves), everything out with the
+  // last launch.  Anything else: the runtime's copies, and a wait in the middle to learn the size.
+  void *v_msgs = nullptr, *v_ents = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
+  const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_msgs = dev_view(msgs)) != nullptr &&
+                      (n_ents == 0 || (v_ents = dev_view(ents)) != nullptr) && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
+                      (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
+  if (mapped) {
+    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+    uint8_t* d_out = (uint8_t*)h->wire_out;
+    const CopySegs in = {{{v_msgs, d_msgs, n * sizeof(WireMsg)}, {v_ents, d_ents, n_ents * sizeof(WireEnt)}, {v_pool, d_pool, pool_bytes}}};
+    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(n * sizeof(WireMsg) + n_ents * sizeof(WireEnt) + pool_bytes)), dim3(kBlock), 0,
+                       h->stream, in);
+    hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
+                       (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
+    const EncGuard guard = {h->wire_flags + 0, cap};
+    hipLaunchKernelGGL(wire_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
+                       (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out, guard);
+    if (n_ents)
+      hipLaunchKernelGGL(wire_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
+                         (const WireEnt*)d_ents, (const uint64_t*)d_off, (const uint8_t*)d_pool, d_out, guard);
+    hipLaunchKernelGGL(wire_enc_out_kernel, dim3(copy_blocks(cap / 4)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_out, (uint8_t*)v_out,
+                       (const uint64_t*)d_off, (uint64_t*)v_off, n, guard, h->wire_pin_d);
+    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, h->wire_flags + 0);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t total = h->wire_pin[0];
+    if ((uint32_t)h->wire_pin[1])
+      return fail(h, RAFTQ_EINVAL,
+                  "raftq_wire_encode: a message has to / from >= 255, an entry range outside ents[], or a payload outside "
+                  "the pool; nothing was written");
+    if (counts) {
+      counts->n_msgs = n;
+      counts->n_ents = n_ents;
+      counts->bytes = total;
+    }
+    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: out is too small (counts->bytes is the size needed)");
+    return RAFTQ_OK;
+  }
   if (int rc = h2d(h, d_msgs, msgs, n * sizeof(WireMsg))) return rc;
   if (int rc = h2d(h, d_ents, ents, n_ents * sizeof(WireEnt))) return rc;
   if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
-  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
   hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
                      (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
-  if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
-  if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
+  if (int rc = tail_to_pin(h, d_off + n, h->wire_flags + 0)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint64_t total = h->wire_pin[0];
   if ((uint32_t)h->wire_pin[1])
@@ -158,11 +230,11 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
   uint8_t* d_out = (uint8_t*)h->wire_out;
   hipLaunchKernelGGL(wire_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
-                     (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out);
+                     (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out, EncGuard{nullptr, 0});
   if (n_ents)
     hipLaunchKernelGGL(wire_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                        (const WireMsg*)d_msgs, n, (const WireEnt*)d_ents, (const uint64_t*)d_off,
-                       (const uint8_t*)d_pool, d_out);
+                       (const uint8_t*)d_pool, d_out, EncGuard{nullptr, 0});
   HIPCHK(h, hipGetLastError());
   if (int rc = d2h(h, out, d_out, total)) return rc;
   if (frame_off)
@@ -193,10 +265,18 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   uint64_t *d_off = (uint64_t*)(base + o_off), *d_cnt = (uint64_t*)(base + o_cnt), *d_base = (uint64_t*)(base + o_base);
   WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
   WireEnt* d_ents = (WireEnt*)h->wire_out;
-  unsigned long long* d_bad = (unsigned long long*)(base + o_bad);
-  if (int rc = h2d(h, d_stream, stream, nbytes)) return rc;
-  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
-  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  unsigned long long* d_bad = h->wire_flags + 1;  // (o_bad: unused since the flags have a block of their own)
+  (void)o_bad;
+  void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
+  const bool mapped = kernel_copies() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+                      (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
+  if (mapped) {
+    const CopySegs in = {{{v_stream, d_stream, nbytes}, {v_off, d_off, (n + 1) * 8}, {nullptr, nullptr, 0}}};
+    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(nbytes + (n + 1) * 8)), dim3(kBlock), 0, h->stream, in);
+  } else {
+    if (int rc = h2d(h, d_stream, stream, nbytes)) return rc;
+    if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  }
   hipLaunchKernelGGL(wire_dec_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      nbytes, (const uint64_t*)d_off, n, d_msgs, d_cnt, d_bad);
   HIPCHK(h, hipGetLastError());
@@ -205,9 +285,26 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
                      nbytes, (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
                      dev_cap);
   HIPCHK(h, hipGetLastError());
+  if (mapped) {  // records, the entry headers there turned out to be, totals: one launch, one wait
+    hipLaunchKernelGGL(wire_dec_out_kernel, dim3(copy_blocks(n * sizeof(WireMsg))), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs,
+                       (WireMsg*)v_msgs, n, (const WireEnt*)d_ents, (WireEnt*)v_ents, dev_cap, (const uint64_t*)(d_base + n), d_bad,
+                       h->wire_pin_d);
+    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, d_bad);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t total = h->wire_pin[0];
+    if (counts) {
+      counts->n_msgs = n;
+      counts->n_ents = total;
+      counts->n_malformed = h->wire_pin[1];
+      counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+    }
+    if (ents && total > ents_cap)
+      return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
+    return RAFTQ_OK;
+  }
+  if (int rc = tail_to_pin(h, d_base + n, d_bad)) return rc;
   if (int rc = d2h(h, msgs, d_msgs, n * sizeof(WireMsg))) return rc;
-  if (int rc = d2h(h, &h->wire_pin[0], d_base + n, 8)) return rc;
-  if (int rc = d2h(h, &h->wire_pin[1], d_bad, 8)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint64_t total = h->wire_pin[0];
   if (counts) {

@@ -239,6 +239,77 @@ def test_decode_entry_capacity(eng):
     assert rc == _lib.RAFTQ_EINVAL and c.n_ents == len(e)
 
 
+@pytest.mark.parametrize("copies", ["kernel", "runtime"])
+@pytest.mark.parametrize("seed,n,big", [(171, 1, 0), (172, 900, 4), (173, 6000, 0), (174, 333, 1)])
+def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
+    """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE chain with ONE wait -- its
+    copies are workgroup copies inside the queue, the writers refuse a bad or oversized batch themselves, the entry headers
+    leave with the records -- and has to say and write exactly what the copying form does (RAFTQ_WIRE_KERNEL_COPIES=0, the
+    `runtime` rows): streams, offsets, records, entries, counts, refusals that leave the output alone, the entry capacity."""
+    import ctypes as C
+
+    from raftsql_amd import _lib
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "1" if copies == "kernel" else "0")
+    rng = np.random.default_rng(seed)
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        for rnd in range(3):
+            m, e, pool = _wiregen.random_msgs(rng, n, big_every=big, ent_frac=(0.0, 0.4, 1.0)[rnd])
+            want, want_off = W.wire_encode(m, e, pool)
+            pm, pe, pp = pinned_copy(m), pinned_copy(e) if len(e) else e, pinned_copy(_wiregen_u8(pool))
+            out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+            out[:] = 0xEE
+            got, goff = eng.wire_encode(pm, pe, pp, out=out, off=off)
+            assert np.array_equal(goff, want_off) and got.tobytes() == want.tobytes()
+            assert bytes(out[len(want):]) == b"\xee" * 64  # nothing behind the stream was touched
+            # too small a buffer: refused, the size needed is reported, nothing written
+            small = pinned_empty(max(1, len(want) - 1), np.uint8)
+            small[:] = 0xEE
+            c = _lib.WireCounts()
+            rc = eng._lib.raftq_wire_encode(eng._h, pm.ctypes.data, n, pe.ctypes.data if len(e) else None, len(e), pp.ctypes.data, len(pp),
+                                            small.ctypes.data, len(small), off.ctypes.data, C.byref(c))
+            assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small) == b"\xee" * len(small)
+            # a bad message (addressee 255): refused whole
+            bad = pinned_copy(m)
+            bad["to"][n // 2] = 255
+            out[:] = 0xEE
+            rc = eng._lib.raftq_wire_encode(eng._h, bad.ctypes.data, n, pe.ctypes.data if len(e) else None, len(e), pp.ctypes.data, len(pp),
+                                            out.ctypes.data, len(out), off.ctypes.data, C.byref(c))
+            assert rc == _lib.RAFTQ_EINVAL and bytes(out) == b"\xee" * len(out)
+            # and the next call is fine again (the flag word was left zero)
+            got, goff = eng.wire_encode(pm, pe, pp, out=out, off=off)
+            assert got.tobytes() == want.tobytes()
+            # decode: canonical, then with every 7th frame damaged
+            for damage in (False, True):
+                s = want.copy()
+                if damage:
+                    for k in range(0, n, 7):
+                        s[int(want_off[k]) + 8] = 0x0B
+                wm, we, wbad = W.wire_decode(s, want_off)
+                ps, po = pinned_copy(s), pinned_copy(want_off)
+                dm, de = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 3, W.WIRE_ENT_DT)
+                gm, ge, gbad = eng.wire_decode(ps, po, msgs=dm, ents=de)
+                assert gbad == wbad
+                _same(gm, wm, "msgs")
+                _same(ge, we, "ents")
+                hm, he, hbad = eng.wire_decode(ps, po, want_ents=False, msgs=dm)
+                _same(hm, wm, "msgs (headers only)")
+                assert hbad == wbad
+                if len(we) > 1:  # one entry too many for the caller's array: refused, the count needed is reported
+                    few = pinned_empty(len(we) - 1, W.WIRE_ENT_DT)
+                    rc = eng._lib.raftq_wire_decode(eng._h, ps.ctypes.data, len(ps), po.ctypes.data, n, dm.ctypes.data, few.ctypes.data,
+                                                    len(few), C.byref(c))
+                    assert rc == _lib.RAFTQ_EINVAL and c.n_ents == len(we)
+                    gm, ge, _ = eng.wire_decode(ps, po, msgs=dm, ents=de)  # and the next call is whole again
+                    _same(ge, we, "ents after a refusal")
+
+
+def _wiregen_u8(pool):
+    return np.ascontiguousarray(np.frombuffer(bytes(pool), np.uint8) if not isinstance(pool, np.ndarray) else pool.view(np.uint8))
+
+
 def test_scan_frames_host(eng):
     from raftsql_amd import wire
 

@@ -350,11 +350,21 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   uint32_t* d_pcrc = (uint32_t*)(base + o_pcrc);
   CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
   uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
-  unsigned int* d_bad = (unsigned int*)(base + o_flags);
   uint32_t* d_last = (uint32_t*)(base + o_flags) + 1;
-  if (int rc = h2d(h, d_recs, recs, n * sizeof(WalRec))) return rc;
-  if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
-  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  // page-locked caller buffers: one chain, one wait (as raftq_wire_encode)
+  void *v_recs = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
+  const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr &&
+                      (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) && (v_out = dev_view(out)) != nullptr &&
+                      (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
+  unsigned int* d_bad = mapped ? (unsigned int*)(h->wire_flags + 2) : (unsigned int*)(base + o_flags);
+  if (mapped) {
+    const CopySegs in = {{{v_recs, d_recs, n * sizeof(WalRec)}, {v_pool, d_pool, pool_bytes}, {nullptr, nullptr, 0}}};
+    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(n * sizeof(WalRec) + pool_bytes)), dim3(kBlock), 0, h->stream, in);
+  } else {
+    if (int rc = h2d(h, d_recs, recs, n * sizeof(WalRec))) return rc;
+    if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
+    HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  }
   hipLaunchKernelGGL(wal_enc_payload_crc_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                      (const WalRec*)d_recs, n, (const uint8_t*)d_pool, pool_bytes, d_pcrc);
   hipLaunchKernelGGL(wal_enc_crc_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
@@ -365,6 +375,34 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
                      (const CrcPair*)d_chain, d_sizes);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
+  if (mapped) {
+    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+    uint8_t* d_out = (uint8_t*)h->wire_out;
+    const EncGuard guard = {h->wire_flags + 2, cap};
+    hipLaunchKernelGGL(wal_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
+                       (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last, guard);
+    if (pool_bytes)
+      hipLaunchKernelGGL(wal_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
+                         (const CrcPair*)d_chain, (const uint64_t*)d_off, (const uint8_t*)d_pool, d_out, guard);
+    hipLaunchKernelGGL(wal_enc_out_kernel, dim3(copy_blocks(cap / 4)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_out, (uint8_t*)v_out,
+                       (const uint64_t*)d_off, (uint64_t*)v_off, n, guard, (const uint32_t*)d_last, h->wire_pin_d);
+    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, h->wire_flags + 2);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t total = h->wire_pin[0];
+    if ((uint32_t)h->wire_pin[1])
+      return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: a record has an unknown kind or a payload outside the pool; nothing was written");
+    if (counts) {
+      counts->n_recs = n;
+      counts->bytes = total;
+    }
+    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
+    if (counts) {
+      counts->n_valid = n;
+      counts->last_crc = (uint32_t)h->wire_pin[2];
+    }
+    return RAFTQ_OK;
+  }
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -379,11 +417,11 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
   uint8_t* d_out = (uint8_t*)h->wire_out;
   hipLaunchKernelGGL(wal_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
-                     (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last);
+                     (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last, EncGuard{nullptr, 0});
   if (pool_bytes)
     hipLaunchKernelGGL(wal_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                        (const WalRec*)d_recs, n, (const CrcPair*)d_chain, (const uint64_t*)d_off,
-                       (const uint8_t*)d_pool, d_out);
+                       (const uint8_t*)d_pool, d_out, EncGuard{nullptr, 0});
   HIPCHK(h, hipGetLastError());
   if (int rc = d2h(h, out, d_out, total)) return rc;
   if (frame_off)
@@ -421,8 +459,16 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
   unsigned long long* d_first_bad = (unsigned long long*)(base + o_tail);
   uint64_t* d_tail = (uint64_t*)(base + o_tail) + 1;
-  if (int rc = h2d(h, d_bytes, bytes, nbytes)) return rc;
-  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  void *v_bytes = nullptr, *v_off = nullptr, *v_recs = nullptr;
+  const bool mapped = kernel_copies() && (nbytes == 0 || (v_bytes = dev_view(bytes)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+                      (v_recs = dev_view(recs)) != nullptr;
+  if (mapped) {
+    const CopySegs in = {{{v_bytes, d_bytes, nbytes}, {v_off, d_off, (n + 1) * 8}, {nullptr, nullptr, 0}}};
+    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(nbytes + (n + 1) * 8)), dim3(kBlock), 0, h->stream, in);
+  } else {
+    if (int rc = h2d(h, d_bytes, bytes, nbytes)) return rc;
+    if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  }
   HIPCHK(h, hipMemsetAsync(d_first_bad, 0xff, 8, h->stream));
   hipLaunchKernelGGL(wal_dec_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_bytes, nbytes,
                      (const uint64_t*)d_off, n, prev_crc, d_recs, d_span, d_pair);
@@ -435,8 +481,14 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   hipLaunchKernelGGL(wal_dec_tail_kernel, dim3(1), dim3(64), 0, h->stream, (const CrcPair*)d_chain, n, prev_crc,
                      (const unsigned long long*)d_first_bad, d_tail);
   HIPCHK(h, hipGetLastError());
-  if (int rc = d2h(h, recs, d_recs, n * sizeof(WalRec))) return rc;
-  if (int rc = d2h(h, &h->wire_pin[0], d_tail, 16)) return rc;
+  if (mapped) {
+    const CopySegs outs = {{{d_recs, v_recs, n * sizeof(WalRec)}, {d_tail, h->wire_pin_d, 16}, {nullptr, nullptr, 0}}};
+    hipLaunchKernelGGL(wire_copy_out_kernel, dim3(copy_blocks(n * sizeof(WalRec))), dim3(kBlock), 0, h->stream, outs);
+    HIPCHK(h, hipGetLastError());
+  } else {
+    if (int rc = d2h(h, recs, d_recs, n * sizeof(WalRec))) return rc;
+    if (int rc = d2h(h, &h->wire_pin[0], d_tail, 16)) return rc;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (counts) {
     counts->n_recs = n;

@@ -320,6 +320,29 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_out_kernel(const uint8
   }
 }
 
+// a call's results out (to_host) or its inputs in, up to three ranges a launch
+static __global__ __launch_bounds__(kBlock) void wire_copy_out_kernel(CopySegs segs) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) copy_bytes(segs.s[k].src, segs.s[k].dst, segs.s[k].bytes, true);
+}
+
+// raftq_wal_encode's last launch: the frames and their offsets out -- unless the batch was refused --, the totals, the chain's end
+static __global__ __launch_bounds__(kBlock) void wal_enc_out_kernel(const uint8_t* __restrict__ out, uint8_t* out_h,
+                                                                    const uint64_t* __restrict__ off, uint64_t* off_h, uint64_t n,
+                                                                    EncGuard guard, const uint32_t* __restrict__ last_crc,
+                                                                    uint64_t* __restrict__ pin) {
+  const uint64_t t = off[n];
+  if (!guard.refuses(off + n)) {
+    copy_bytes(out, out_h, t, true);
+    if (off_h != nullptr) copy_bytes(off, off_h, (n + 1) * 8, true);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    pin[0] = t;
+    pin[1] = *guard.bad;
+    pin[2] = *last_crc;
+  }
+}
+
 // the flag word of a call, zero again for the next one (a launch of its own: every workgroup of the out kernels reads it)
 static __global__ void wire_flag_reset_kernel(unsigned long long* flag) {
   if (threadIdx.x == 0) *flag = 0;
@@ -818,7 +841,8 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_write_kernel(const WalR
                                                                       const CrcPair* __restrict__ chain,
                                                                       const uint64_t* __restrict__ off,
                                                                       uint8_t* __restrict__ out,
-                                                                      uint32_t* __restrict__ last_crc) {
+                                                                      uint32_t* __restrict__ last_crc, EncGuard guard) {
+  if (guard.refuses(off + n)) return;
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const WalRec r = recs[i];
@@ -859,7 +883,8 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_payload_kernel(const Wa
                                                                         const CrcPair* __restrict__ chain,
                                                                         const uint64_t* __restrict__ off,
                                                                         const uint8_t* __restrict__ pool,
-                                                                        uint8_t* __restrict__ out) {
+                                                                        uint8_t* __restrict__ out, EncGuard guard) {
+  if (guard.refuses(off + n)) return;
   const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (i >= n) return;
   if (recs[i].data_len == 0 || !wal_has_payload(recs[i].kind)) return;

@@ -306,6 +306,53 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
                     _same(ge, we, "ents after a refusal")
 
 
+@pytest.mark.parametrize("copies", ["kernel", "runtime"])
+@pytest.mark.parametrize("seed,n,big,prev", [(181, 1, 0, 0), (182, 700, 3, 0xDEADBEEF), (183, 5000, 40, 7)])
+def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypatch):
+    """the WAL codecs the same way: every buffer page-locked -> one chain, one wait; bytes, offsets, CRC chain, records,
+    valid count and refusals as the copying form's"""
+    import ctypes as C
+
+    from raftsql_amd import _lib
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "1" if copies == "kernel" else "0")
+    rng = np.random.default_rng(seed)
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        r, pool = _wiregen.random_wal(rng, n, max_payload=300, big_every=big)
+        want, want_off, want_last = W.wal_encode(r, pool, prev)
+        pr, pp = pinned_copy(r), pinned_copy(_wiregen_u8(pool))
+        out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(len(r) + 1, np.uint64)
+        out[:] = 0xEE
+        got, goff, glast = eng.wal_encode(pr, pp, prev, out=out, off=off)
+        assert np.array_equal(goff, want_off) and got.tobytes() == want.tobytes() and glast == want_last
+        assert bytes(out[len(want):]) == b"\xee" * 64
+        small = pinned_empty(max(1, len(want) - 1), np.uint8)
+        small[:] = 0xEE
+        c = _lib.WalCounts()
+        rc = eng._lib.raftq_wal_encode(eng._h, pr.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, small.ctypes.data, len(small),
+                                       off.ctypes.data, C.byref(c))
+        assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small) == b"\xee" * len(small)
+        bad = pinned_copy(r)
+        bad["kind"][len(r) // 2] = 99
+        out[:] = 0xEE
+        rc = eng._lib.raftq_wal_encode(eng._h, bad.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, out.ctypes.data, len(out),
+                                       off.ctypes.data, C.byref(c))
+        assert rc == _lib.RAFTQ_EINVAL and bytes(out) == b"\xee" * len(out)
+        got, goff, glast = eng.wal_encode(pr, pp, prev, out=out, off=off)  # the flag word was left zero
+        assert got.tobytes() == want.tobytes() and glast == want_last
+        for damage in (False, True):
+            s = want.copy()
+            if damage and len(s) > 40:
+                s[len(s) * 2 // 3] ^= 0x5A
+            wr, wnv, wl = W.wal_decode(s, want_off, prev)
+            ps, po = pinned_copy(s), pinned_copy(want_off)
+            recs = pinned_empty(len(r), W.WAL_REC_DT)
+            gr, gnv, gl = eng.wal_decode(ps, po, prev, recs=recs)
+            assert (gnv, gl) == (wnv, wl) and gr.tobytes() == wr.tobytes()
+
+
 def _wiregen_u8(pool):
     return np.ascontiguousarray(np.frombuffer(bytes(pool), np.uint8) if not isinstance(pool, np.ndarray) else pool.view(np.uint8))
 

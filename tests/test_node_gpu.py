@@ -792,3 +792,26 @@ def test_crank_steps_like_the_serial_cluster_and_refuses_bad_calls(Cluster):
         assert lib.raftq_crank_create(two, 2, None, C.byref(out)) != 0  # nodes of a 3-peer cluster are not a 2-peer one
     finally:
         c.close()
+
+
+def test_followers_without_tail_appends(Cluster, monkeypatch):
+    """RAFTQ_NODE_TAIL_APPENDS=0: MsgApps go to Step as headers only, every follower append runs raftLog.maybeAppend on the
+    node's log and reports its tail (raftq_apply_log_deltas) -- round 2's division of labour, now only taken by gaps, conflicts
+    and stale indices, kept whole here: plain replication, then a chaos seed."""
+    monkeypatch.setenv("RAFTQ_NODE_TAIL_APPENDS", "0")
+    c = Cluster(50, 3, seed=13)
+    try:
+        c.start()
+        elect(c)
+        lead = c.leaders()
+        for g in range(50):
+            c.nodes[int(lead[g])].propose(g, b"stmt %d" % g)
+        c.run(6, tick=False)
+        c.settle()
+        for nd in c.nodes:
+            for g in range(50):
+                assert [d for d in nd.drain(g) if d is not None] == [b"stmt %d" % g]
+        check_safety(c)
+    finally:
+        c.close()
+    test_chaos_safety_and_convergence(Cluster, 8, False, False)

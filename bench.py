@@ -816,6 +816,16 @@ def _node_measure(Cluster, device, G, N, rounds, near):
     stepped = sum(s["msgs_stepped"] - b["msgs_stepped"] for s, b in zip(st, base))
     for s_, b in zip(st, base):  # the crank's own count against the nodes' counters
         assert s_["entries_published"] - b["entries_published"] == rounds * G, (s_, b)
+    # the same stream with four waves in flight (a client that does not wait for one statement before sending the next): every
+    # turn then carries all four stages of the protocol for different waves, and its fixed costs are shared by four times the
+    # messages.  (A propose and a commit for one group in one turn are two MsgApps to each follower: both land on the tail
+    # and are finished by Step in one round -- RAFTQ_MSGF_ENTRIES / RAFTQ_MSGF_BARRIER.)
+    depth = 4
+    dt_p, steps_p, _, base_p = waves(rounds, lambda r: b"INSERT INTO t (w) VALUES (%d)" % r, in_flight=depth)
+    st_p = [nd.stats() for nd in c.nodes]
+    stepped_p = sum(s["msgs_stepped"] - b["msgs_stepped"] for s, b in zip(st_p, base_p))
+    for s_, b in zip(st_p, base_p):
+        assert s_["entries_published"] - b["entries_published"] == rounds * G, (s_, b)
     c.close()
     return {"what": "raftq_node x%d on one GPU, %d groups: propose on the leader -> MsgApp -> MsgAppResp -> batched "
                     "Step -> commit -> delivered on every node's commit channel; one wave in flight" % (N, G),
@@ -825,6 +835,8 @@ def _node_measure(Cluster, device, G, N, rounds, near):
             "cluster_steps_per_wave": steps / rounds, "ticks_during_waves": fired, "msgs_per_proposal": stepped / (rounds * G),
             "proposals_committed_everywhere_per_s": rounds * G / dt, "msgs_stepped_per_s": stepped / dt,
             "s_per_wave": dt / rounds,
+            "waves_in_flight_4": {"proposals_committed_everywhere_per_s": rounds * G / dt_p, "msgs_stepped_per_s": stepped_p / dt_p,
+                                  "cluster_steps_per_wave": steps_p / rounds, "msgs_per_proposal": stepped_p / (rounds * G)},
             "ms_per_cluster_step": {"all": 1e3 * dt / steps, "node_turns_in_parallel": 1e3 * sec["turns"] / steps,
                                     "transport": 1e3 * sec["transport"] / steps}}
 

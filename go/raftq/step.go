@@ -50,6 +50,7 @@ const (
 	OutProgress       = C.RAFTQ_OUT_PROGRESS
 	OutBcastHeartbeat = C.RAFTQ_OUT_BCAST_HEARTBEAT
 	OutAppend         = C.RAFTQ_OUT_APPEND
+	OutDeferred       = C.RAFTQ_OUT_DEFERRED // not applied: behind a MsgApp (MsgfBarrier) that was left to the log's owner
 	OutAppended       = C.RAFTQ_OUT_APPENDED // MsgApp flagged MsgfEntries that appended at the tail: store the entries, ack Index
 
 	FlagHardState   = C.RAFTQ_OUTF_HARDSTATE // persist {Term, Vote, Commit} before sending (raft.go:228-230)

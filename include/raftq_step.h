@@ -70,6 +70,12 @@ typedef struct raftq_msg {
  * round trip for the common case of replication.  Every other MsgApp (a gap, a conflict, an index below the tail)
  * is answered RAFTQ_OUT_APPEND as without the flag.  Ignored on every other kind and on packed (40-byte) records. */
 #define RAFTQ_MSGF_ENTRIES 0x80u
+/* RAFTQ_MSGF_BARRIER on a MsgApp: if Step leaves the append to the caller (RAFTQ_OUT_APPEND: the log's tail is about to change
+ * in a way only the log's owner can work out), the messages of the same group that FOLLOW it in this batch are not applied --
+ * they would be stepped against a stale tail -- and are answered RAFTQ_OUT_DEFERRED: step them again, in order, after
+ * raftq_apply_log_deltas.  With it a caller need not keep back everything behind a MsgApp: a batch may hold any number of
+ * messages per group, and the ones that land on the tail (RAFTQ_OUT_APPENDED) hold nobody up. */
+#define RAFTQ_MSGF_BARRIER 0x40u
 
 /* what Step did with message i: out[i] answers msgs[i] */
 #define RAFTQ_OUT_NONE 0            /* ignored: stale term, or this role does not handle the type */
@@ -80,6 +86,7 @@ typedef struct raftq_msg {
 #define RAFTQ_OUT_PROGRESS 5        /* leader took MsgAppResp / MsgHeartbeatResp from `to`: index = Progress.Match now */
 #define RAFTQ_OUT_BCAST_HEARTBEAT 6 /* leader's MsgBeat: send MsgHeartbeat to every other peer */
 #define RAFTQ_OUT_APPEND 7          /* MsgApp header accepted: run raftLog.maybeAppend on the log, then raftq_apply_log_deltas */
+#define RAFTQ_OUT_DEFERRED 9        /* NOT applied: an earlier MsgApp of the group with RAFTQ_MSGF_BARRIER was answered RAFTQ_OUT_APPEND */
 #define RAFTQ_OUT_APPENDED 8        /* MsgApp with RAFTQ_MSGF_ENTRIES that appended at the tail: Step did maybeAppend's bookkeeping -- store
                                      * the entries, send MsgAppResp{Index: index} (index = lastnewi = last_index); commit is final */
 

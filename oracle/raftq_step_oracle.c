@@ -17,6 +17,7 @@
  * One message at a time, in batch order, one group at a time: the shape of the
  * original (a single goroutine draining a channel), not of the GPU kernel.
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include "raftq_oracle.h"
@@ -300,10 +301,24 @@ done:
 }
 
 void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n, raftq_step_out_t* out) {
+  /* RAFTQ_MSGF_BARRIER (raftq_step.h): once a MsgApp that carries it is left to the log's owner (RAFTQ_OUT_APPEND), the
+   * group's later messages OF THIS BATCH are not applied (RAFTQ_OUT_DEFERRED).  held[]: the groups in that state, one byte
+   * each, only allocated when a message of the batch carries the flag. */
+  uint8_t* held = NULL;
+  for (size_t i = 0; i < n && !held; ++i)
+    if (msgs[i].type == RAFTQ_MSG_APP && (msgs[i]._pad[1] & RAFTQ_MSGF_BARRIER)) held = (uint8_t*)calloc(s->G ? s->G : 1, 1);
   for (size_t i = 0; i < n; ++i) {
     node_t r = {s, (size_t)msgs[i].group};
+    if (held && held[r.g]) {
+      memset(&out[i], 0, sizeof(out[i]));
+      out_common(&r, &msgs[i], &out[i]);
+      out[i].type = RAFTQ_OUT_DEFERRED;
+      continue;
+    }
     step(&r, &msgs[i], &out[i]);
+    if (held && out[i].type == RAFTQ_OUT_APPEND && msgs[i].type == RAFTQ_MSG_APP && (msgs[i]._pad[1] & RAFTQ_MSGF_BARRIER)) held[r.g] = 1;
   }
+  free(held);
 }
 
 /* the log's owner reports its new tail: leader = appendEntry's bookkeeping

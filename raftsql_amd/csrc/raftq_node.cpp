@@ -1314,8 +1314,9 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   for (uint64_t i = 0; i < nf; ++i) work[local.size() + i] = (uint32_t)i;
   auto msg_at = [&](uint32_t ix) -> const raftq_wire_msg_t& { return (ix & kLocal) ? local[ix & ~kLocal] : wm[ix]; };
 
-  // -- rc.Process -> Step, in rounds.  A message that changes a group's log (MsgApp, MsgProp) must
-  // be the last one of its group in a Step batch: what follows it has to see the new log tail.
+  // -- rc.Process -> Step, in rounds.  What follows a message that changes a group's log has to see the new log tail: a MsgProp
+  // (which never reaches Step) keeps the rest of its group for the next round; a MsgApp only when Step could not finish it
+  // itself (RAFTQ_MSGF_BARRIER).  In steady-state replication everything goes in the first round.
   std::vector<uint32_t>& batch = n->batch;
   std::vector<uint32_t>& deferred = n->deferred;
   std::vector<uint64_t>& dirty = n->dirty_list;
@@ -1393,12 +1394,13 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
         mark = ep;
       } else if (m.type == RAFTQ_MSG_APP) {
         // a MsgApp says what it carries (RAFTQ_MSGF_ENTRIES): one that lands on the log's tail -- replication's common
-        // case -- is then appended and committed by Step itself, with no raftq_apply_log_deltas round trip behind it
-        mark = ep;
+        // case -- is then appended and committed by Step itself, with no raftq_apply_log_deltas round trip behind it; one
+        // that Step has to leave to this log (a gap, a conflict) holds back what follows it for the group
+        // (RAFTQ_MSGF_BARRIER -> RAFTQ_OUT_DEFERRED): those come round again below, after the log has changed
         raftq_msg_t t;
         std::memcpy(&t, &m, sizeof(t));
         t._pad[0] = 0;
-        t._pad[1] = n->tail_appends ? RAFTQ_MSGF_ENTRIES : 0;
+        t._pad[1] = RAFTQ_MSGF_BARRIER | (n->tail_appends ? RAFTQ_MSGF_ENTRIES : 0);
         t._resv = m.n_ents;
         t.reject_hint = m.n_ents ? n->cur_ents[m.ent_first + m.n_ents - 1].term : 0;
         std::memcpy(&staged[n_step++], &t, sizeof(t));
@@ -1419,6 +1421,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     lk.lock();
     ph.next(raftq_node::kPhApply);
     n->stats.msgs_stepped += n_step;
+    const size_t kept_back = deferred.size();  // (behind a MsgProp: decided while staging; what Step defers is added below)
     // consequences, in arrival order (stepped results and proposals interleaved as they came)
     // The groups of a batch are scattered over tens of MB of per-group state: the line of the group 16 messages ahead
     // and, 8 ahead (its line has arrived by then), its Progress and the tail of its log are asked for now.
@@ -1441,10 +1444,15 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
           n->dirty_mark[im.group] = ep;
           dirty.push_back(im.group);
         }
+      } else if (outs[k].type == RAFTQ_OUT_DEFERRED) {  // behind a MsgApp this log has to work out first: next round
+        deferred.push_back(batch[bi]);
+        n->stats.msgs_stepped--;
+        ++k;
       } else {
         apply_result(n, outs[k++], im);
       }
     }
+    if (deferred.size() != kept_back && kept_back != 0) std::sort(deferred.begin(), deferred.end());  // arrival order
     ph.next(raftq_node::kPhDeltas);
     if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
     work.swap(deferred);

@@ -63,8 +63,8 @@ struct NodeArrays {
 constexpr uint8_t kMsgHup = 0, kMsgBeat = 1, kMsgApp = 3, kMsgAppResp = 4, kMsgVote = 5, kMsgVoteResp = 6,
                   kMsgHeartbeat = 8, kMsgHeartbeatResp = 9;
 constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCampaign = 3, kOutBecameLeader = 4,
-                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7, kOutAppended = 8;
-constexpr uint8_t kMsgfEntries = 0x80;  // raftq_msg_t._pad[1]: RAFTQ_MSGF_ENTRIES
+                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7, kOutAppended = 8, kOutDeferred = 9;
+constexpr uint8_t kMsgfEntries = 0x80, kMsgfBarrier = 0x40;  // raftq_msg_t._pad[1]: RAFTQ_MSGF_ENTRIES, RAFTQ_MSGF_BARRIER
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
@@ -161,6 +161,7 @@ struct Node {
   uint32_t vote, lead, elapsed;
   uint32_t vw;  // the group's vote word (raft.votes as 2 bits per peer): loaded once, stored once
   uint8_t role;
+  bool held = false;  // this batch only: a MsgApp with RAFTQ_MSGF_BARRIER was left to the caller -- the group's later messages wait
 
   __device__ Node(const NodeArrays& arr, uint64_t group) : a(arr), g(group) {
     term = a.term[g]; last_index = a.last_index[g]; last_term = a.last_term[g];
@@ -266,6 +267,12 @@ struct Node {
     const uint32_t vote0 = vote;
     const uint8_t role0 = role;
     o.index = 0; o.log_term = 0; o.type = kOutNone; o.reject = 0; o.flags = 0;
+    if (held) {  // RAFTQ_OUT_DEFERRED: nothing of this message is applied
+      o.type = kOutDeferred;
+      o.group = g; o.term = term; o.commit = committed; o.last_index = last_index;
+      o.to = m.from; o.vote = vote; o.lead = lead; o.role = role;
+      return;
+    }
     const uint32_t q = quorum();
     bool handled = false;
     if (m.type == kMsgHup) {
@@ -340,6 +347,7 @@ struct Node {
         }
       }
     }
+    if (o.type == kOutAppend && m.type == kMsgApp && (m.pad[1] & kMsgfBarrier)) held = true;
     o.group = g; o.term = term; o.commit = committed; o.last_index = last_index;
     o.to = m.from; o.vote = vote; o.lead = lead; o.role = role;
     if (term != term0 || vote != vote0 || committed != commit0) o.flags |= kFlagHardState;

@@ -72,7 +72,8 @@ def random_batch(rng, s, n, hot_groups=None):
     tail = says & (rng.random(n) < 0.5)
     m["index"] = np.where(tail, s.last_index[g], m["index"])
     m["log_term"] = np.where(tail, s.last_term[g], m["log_term"])
-    m["_pad"][:, 1] = np.where(says, 0x80, 0)
+    bars = (t == 3) & (rng.random(n) < 0.35)  # RAFTQ_MSGF_BARRIER: what follows a MsgApp left to the caller waits
+    m["_pad"][:, 1] = np.where(says, 0x80, 0) | np.where(bars, 0x40, 0)
     k = rng.integers(0, 4, n).astype(np.uint64)
     m["_resv"] = np.where(says, k | (rng.integers(0, 2**31, n).astype(np.uint64) << np.uint64(32)), 0)  # high half: ignored
     m["reject_hint"] = np.where(says, np.maximum(m["log_term"], m["term"] - (rng.random(n) < 0.5)), m["reject_hint"])
@@ -143,3 +144,27 @@ def check_tail_append_table(out, state_after, want):
             (typ, idx, commit, last, role), (i, o)
         assert (int(state_after.committed[i]), int(state_after.last_index[i]), int(state_after.last_term[i])) == \
             (commit, last, lterm), i
+
+
+def barrier_table():
+    """RAFTQ_MSGF_BARRIER by hand: ONE follower group (3 peers, slot 1, term 5, tail (10, 4), commit 7) and a batch of
+    messages for it, in order -> (NodeState, msgs, want types, state after)"""
+    s = pyoracle.NodeState(2, 3, 1)
+    s.term[:], s.last_index[:], s.last_term[:], s.committed[:] = 5, 10, 4, 7
+    s.match[1] = 10
+    rows = [
+        # group, type, flags, index, log_term, commit, n_ents, last_ent_term -> out type
+        (0, 3, 0xC0, 10, 4, 7, 1, 5, 8),   # lands on the tail: appended (11, 5); holds nobody up
+        (0, 8, 0x00, 0, 0, 11, 0, 0, 2),   # a heartbeat behind it is stepped against the NEW tail: commit 11
+        (0, 3, 0xC0, 9, 4, 11, 1, 5, 7),   # below the tail: left to the owner (OUT_APPEND) -- with the barrier
+        (0, 8, 0x00, 0, 0, 11, 0, 0, 9),   # ... so what follows is deferred
+        (0, 5, 0x00, 11, 5, 0, 0, 0, 9),   # (a vote request too: it would be judged against a stale tail)
+        (1, 3, 0x80, 9, 4, 11, 1, 5, 7),   # the other group: the same message WITHOUT the barrier
+        (1, 8, 0x00, 0, 0, 9, 0, 0, 2),    # ... and its heartbeat is applied as before (commit 9)
+    ]
+    m = np.zeros(len(rows), dtype=pyoracle.STEP_MSG_DT)
+    for i, r in enumerate(rows):
+        m["group"][i], m["type"][i], m["_pad"][i][1] = r[0], r[1], r[2]
+        m["index"][i], m["log_term"][i], m["commit"][i], m["_resv"][i], m["reject_hint"][i] = r[3], r[4], r[5], r[6], r[7]
+    m["term"], m["from"] = 5, 0
+    return s, m, [r[8] for r in rows], {"committed": [11, 9], "last_index": [11, 10], "last_term": [5, 4]}

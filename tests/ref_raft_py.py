@@ -20,6 +20,7 @@ StateFollower, StateCandidate, StateLeader = 0, 1, 2
 (OutNone, OutVoteResp, OutHeartbeatResp, OutCampaign, OutBecameLeader, OutProgress, OutBcastHeartbeat,
  OutAppend) = range(8)
 OutAppended = 8
+OutDeferred = 9
 FlagHardState, FlagCommitted, FlagUpdated, FlagSteppedDown = 1, 2, 4, 8
 
 
@@ -33,6 +34,7 @@ class Message:
     commit: int = 0
     reject: bool = False
     entries: Optional[tuple] = None  # MsgApp: the Terms of the entries it carries; None = not said (header only)
+    barrier: bool = False  # MsgApp: if it is left to the log's owner, the group's later messages of the batch wait
 
 
 @dataclass
@@ -138,8 +140,13 @@ class Raft:
 
     # -- Step --------------------------------------------------------------
     def step(self, m: Message) -> Result:
+        """one message of a BATCH: `self.held` (cleared by the caller between batches) is the barrier's state"""
+        if getattr(self, "held", False):
+            return Result(OutDeferred)
         before = (self.term, self.vote, self.committed, self.state)
         res = self._step(m)
+        if m.type == MsgApp and m.barrier and res.type == OutAppend:
+            self.held = True
         if (self.term, self.vote, self.committed) != before[:3]:
             res.flags |= FlagHardState
         if self.committed != before[2]:

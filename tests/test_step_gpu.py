@@ -599,3 +599,17 @@ def test_tail_append_table_on_the_gpu(NodeEngine, oracle, walk, monkeypatch):
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
         _stepgen.check_tail_append_table(got, s, want)
         _stepgen.assert_same_state(e, s)
+
+
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+def test_barrier_table_on_the_gpu(NodeEngine, oracle, walk, monkeypatch):
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    s, m, want, after = _stepgen.barrier_table()
+    with NodeEngine(s.G, s.N, s.self_peer) as e:
+        _stepgen.load_engine(e, s)
+        ref = s.step_batch(m)
+        got, _ = e.step_batch(m)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert [int(t) for t in got["type"]] == want
+        _stepgen.assert_same_state(e, s)

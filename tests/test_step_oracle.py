@@ -196,12 +196,13 @@ def test_invariants_under_random_traffic(seed, N, self_peer):
         assert np.all(s.lead[lead] == s.self_peer + 1) and np.all(s.first_idx[lead] != 0)
         assert np.all(s.first_idx[~lead] == 0)
         assert np.all(s.votes[:, s.role != 1] == 0)
-        assert np.all(out["term"] >= m["term"] * (out["type"] != NONE))
+        assert np.all(out["term"] >= m["term"] * ((out["type"] != NONE) & (out["type"] != 9)))  # (9: deferred, not applied)
         assert np.all(s.match[s.self_peer][lead] == s.last_index[lead])
         # batch split invariance: the oracle is sequential, so any split gives the same result
     a = _stepgen.random_state(np.random.default_rng(seed), G, N, self_peer % N)
     b = _stepgen.random_state(np.random.default_rng(seed), G, N, self_peer % N)
     m = _stepgen.random_batch(rng, a, 300)
+    m["_pad"][:, 1] &= 0xBF  # (a barrier holds to the end of ITS batch: the one thing a split would change)
     oa = a.step_batch(m)
     ob = np.concatenate([b.step_batch(m[:77]), b.step_batch(m[77:])])
     assert np.array_equal(oa, ob)
@@ -226,6 +227,8 @@ def test_c_oracle_agrees_with_the_object_shaped_python_statement(seed, N, self_p
     for _ in range(4):
         m = _stepgen.random_batch(rng, s, 250)
         out = s.step_batch(m)
+        for r_ in rafts:
+            r_.held = False  # a barrier holds for one batch
         for i in range(len(m)):
             g = int(m["group"][i])
             local = int(m["type"][i]) in (R.MsgHup, R.MsgBeat)
@@ -234,7 +237,8 @@ def test_c_oracle_agrees_with_the_object_shaped_python_statement(seed, N, self_p
                                           index=int(m["index"][i]), commit=int(m["commit"][i]),
                                           reject=bool(m["reject"][i]),
                                           entries=(int(m["reject_hint"][i]),) * int(int(m["_resv"][i]) & 0xFFFFFFFF)
-                                          if int(m["_pad"][i][1]) & 0x80 else None))
+                                          if int(m["_pad"][i][1]) & 0x80 else None,
+                                          barrier=bool(int(m["_pad"][i][1]) & 0x40)))
             o, r = out[i], rafts[g]
             assert (res.type, res.index, res.log_term, res.reject, res.flags) == \
                 (o["type"], o["index"], o["log_term"], o["reject"], o["flags"]), (i, m[i], o, res)
@@ -347,3 +351,13 @@ def test_tail_append_table_c_oracle():
     s, m, want = _stepgen.tail_append_table()
     out = s.step_batch(m)
     _stepgen.check_tail_append_table(out, s, want)
+
+
+def test_barrier_table_c_oracle():
+    """RAFTQ_MSGF_BARRIER: behind a MsgApp that is left to the log's owner the group's messages wait (RAFTQ_OUT_DEFERRED);
+    behind one that Step appended itself they do not, and they see the new tail"""
+    s, m, want, after = _stepgen.barrier_table()
+    out = s.step_batch(m)
+    assert [int(t) for t in out["type"]] == want
+    for k, v in after.items():
+        assert [int(x) for x in getattr(s, k)] == v, k

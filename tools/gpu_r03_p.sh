@@ -1,12 +1,11 @@
 #!/bin/bash
-# r03 trip: the WAL codecs on kernel copies as well -- wire suite, node suites (WAL restart), bench's wire leg before/after
+# r03 trip: RAFTQ_MSGF_BARRIER / RAFTQ_OUT_DEFERRED -- Step parity, node suites, the node leg with one and four waves in flight
 mkdir -p gpurun_out/r03
 {
-timeout 900 python -m pytest -m gpu -x -q tests/test_wire_gpu.py tests/test_node_gpu.py 2>&1 | tail -5
-for k in 1 0; do echo "== RAFTQ_WIRE_KERNEL_COPIES=$k"; RAFTQ_WIRE_KERNEL_COPIES=$k python -c "
-import bench, json
-r = bench.wire_measure(0)
-print(json.dumps({k: (v if not isinstance(v, dict) else {a: b for a, b in v.items() if a != 'roofline'}) for k, v in r.items()}, default=str)[:1500])
-" 2>&1 | grep -v amdgpu.ids; done
-} > gpurun_out/r03/wal_kernel_copies.txt 2>&1
-cat gpurun_out/r03/wal_kernel_copies.txt
+timeout 900 python -m pytest -m gpu -x -q tests/test_step_gpu.py tests/test_wire_gpu.py tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_pipe_gpu.py 2>&1 | tail -4
+for i in 1 2 3; do
+  RAFTQ_PROFILE=1 RAFTQ_PROFILE_EVERY=118 timeout 300 python tools/profile_node.py 2>&1 | grep -v "amdgpu.ids\|over 118\|^wall" | sed -e 's/.what.*leaders_per_node/leaders/' | cut -c1-1200 | grep -v "^ " | grep -v "raftq_node [12]\]"
+done
+SECONDS_BUDGET=30 python tests/soak/step_stress.py 2>&1 | tail -1
+} > gpurun_out/r03/node_barrier.txt 2>&1
+cat gpurun_out/r03/node_barrier.txt

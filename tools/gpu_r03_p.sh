@@ -1,12 +1,7 @@
 #!/bin/bash
-# A/B of two builds of the library on one box: the node leg, three pairs (RAFTQ_LIB=gpurun_ab/libraftq_{A,B}.so)
-mkdir -p gpurun_out/r03
-{
-for i in 1 2 3; do
-for v in A B; do
-  echo "== $v"
-  RAFTQ_LIB=$PWD/gpurun_ab/libraftq_$v.so RAFTQ_PROFILE=1 RAFTQ_PROFILE_EVERY=118 timeout 300 python tools/profile_node.py 2>&1 | grep -v "amdgpu.ids\|over 118\|^wall" | sed -e 's/.what.*leaders_per_node/leaders/' | cut -c1-700 | grep -v "^ " | grep -v "raftq_node [12]\]"
-done
-done
-} > gpurun_out/r03/node_ab_libs.txt 2>&1
-cat gpurun_out/r03/node_ab_libs.txt
+# the whole GPU suite + smoke + the bench line on the final tree
+P=gpurun_out/r03/final3; mkdir -p $P
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $P/gpu_tests.log 2>&1; echo "suite rc=$? $(tail -n 1 $P/gpu_tests.log)"
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $P/bench_n1.json 2> $P/bench_n1.err; echo "bench rc=$?"
+python tools/results_table.py $P/bench_n1.json | tail -n 4

@@ -1,7 +1,8 @@
 #!/bin/bash
-# the whole GPU suite + smoke + the bench line on the final tree
-P=gpurun_out/r03/final3; mkdir -p $P
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $P/gpu_tests.log 2>&1; echo "suite rc=$? $(tail -n 1 $P/gpu_tests.log)"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
-python bench.py --gpus 1 --steps 20 --warmup 5 > $P/bench_n1.json 2> $P/bench_n1.err; echo "bench rc=$?"
-python tools/results_table.py $P/bench_n1.json | tail -n 4
+# timeline of the batching turn (kernels + copies)
+mkdir -p gpurun_out/r03
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/cy -o cy -- python $GRAFT_REPO_ROOT/tools/profile_cycle.py > /tmp/cy.out 2>&1
+cd $GRAFT_REPO_ROOT
+{ tail -n 3 /tmp/cy.out | cut -c1-600; python tools/probe/timeline.py /tmp/cy -70 70; } > gpurun_out/r03/cycle_timeline.txt 2>&1
+cat gpurun_out/r03/cycle_timeline.txt

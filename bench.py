@@ -779,7 +779,8 @@ def _node_measure(Cluster, device, G, N, rounds, near):
     c.settle()
     t_elect = time.perf_counter() - t0
     lead = c.leaders()
-    mine = [np.nonzero(lead == p)[0] for p in range(N)]
+    mine = [np.nonzero(lead == p)[0].astype(np.uint64) for p in range(N)]
+    offsets = {}  # (node, statement length) -> where each of the node's statements starts in its blob
 
     def waves(count, payload_of, in_flight=1):
         """`count` waves, at most `in_flight` of them proposed and not yet delivered everywhere, at most one new wave per
@@ -794,7 +795,9 @@ def _node_measure(Cluster, device, G, N, rounds, near):
                 stmt = payload_of(proposed)
                 for p, nd in enumerate(c.nodes):  # every node proposes for the groups it leads, one call per node
                     k = len(mine[p])
-                    nd.propose_blob(mine[p], np.arange(k + 1, dtype=np.uint64) * len(stmt), stmt * k)
+                    if (p, len(stmt)) not in offsets:
+                        offsets[p, len(stmt)] = np.arange(k + 1, dtype=np.uint64) * len(stmt)
+                    nd.propose_blob(mine[p], offsets[p, len(stmt)], stmt * k)
                 proposed += 1
             due = time.perf_counter() >= next_tick
             if due:

@@ -315,7 +315,7 @@ class Cluster:
         self.loss = 0.0  # probability that one node-to-node transfer (a batch of frames) is lost
         self._rng = np.random.default_rng(seed)
         self.ticks = 0
-        self.seconds = {"turns": 0.0, "transport": 0.0}  # wall time of step()'s two halves so far
+        self._seconds = {"turns": 0.0, "transport": 0.0}  # see the `seconds` property
 
     def start(self) -> None:
         for p, nd in enumerate(self.nodes):
@@ -358,26 +358,42 @@ class Cluster:
                 raise RaftqError(rc, "raftq_crank_create failed")
             self._crank = out
             self._crank_seen = (0.0, 0.0)
+            self._crank_pub = np.zeros(self.N, dtype=np.uint64)
+            self._crank_rcs = np.zeros(self.N, dtype=np.int32)
         mask = 0
         for p in live:
             mask |= 1 << p
-        lost_arr = np.ascontiguousarray(np.array(lost, dtype=np.uint8).reshape(-1))
-        pub = np.zeros(self.N, dtype=np.uint64)
-        rcs = np.zeros(self.N, dtype=np.int32)
-        rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_arr.ctypes.data, pub.ctypes.data, rcs.ctypes.data)
+        lost_ptr = None
+        if lost is not None:
+            lost_arr = np.ascontiguousarray(np.array(lost, dtype=np.uint8).reshape(-1))
+            lost_ptr = lost_arr.ctypes.data
+        pub, rcs = self._crank_pub, self._crank_rcs  # (the crank writes every slot on every step)
+        rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_ptr, pub.ctypes.data, rcs.ctypes.data)
         if rc != 0:
             bad = int(np.nonzero(rcs)[0][0])
             self.nodes[bad]._chk(int(rcs[bad]))
-        self.last_published = [int(v) for v in pub]
+        self.last_published = pub.tolist()
+        return sum(self.last_published)
+
+    def _crank_seconds(self) -> None:
+        """fold the crank's own clocks (wall time of the steps' two halves) into self.seconds"""
+        if self._crank is None:
+            return
         a, b = C.c_double(0), C.c_double(0)
-        lib.raftq_crank_seconds(self._crank, C.byref(a), C.byref(b))
-        self.seconds["turns"] += a.value - self._crank_seen[0]
-        self.seconds["transport"] += b.value - self._crank_seen[1]
+        _load().raftq_crank_seconds(self._crank, C.byref(a), C.byref(b))
+        self._seconds["turns"] += a.value - self._crank_seen[0]
+        self._seconds["transport"] += b.value - self._crank_seen[1]
         self._crank_seen = (a.value, b.value)
-        return int(pub.sum())
+
+    @property
+    def seconds(self) -> dict:
+        """wall time of step()'s two halves so far: {"turns": every node's turn (the slowest decides), "transport": ...}"""
+        self._crank_seconds()
+        return self._seconds
 
     def _drop_crank(self) -> None:
         if self._crank is not None:
+            self._crank_seconds()  # its clocks go with it
             _load().raftq_crank_destroy(self._crank)
             self._crank = None
 
@@ -397,7 +413,8 @@ class Cluster:
     def step(self, tick: bool = True) -> int:
         live = [p for p in range(self.N) if p not in self.down]
         if self._pool is not None and self.native_transport and not self.wal_on:
-            published = self._crank_step(tick, live, self._lost_matrix(live))
+            quiet = not self.down and not self.cut and not self.loss  # nothing is lost: no matrix to build
+            published = self._crank_step(tick, live, None if quiet else self._lost_matrix(live))
             self.ticks += int(tick)
             return published
         t0 = time.perf_counter()
@@ -406,7 +423,7 @@ class Cluster:
         else:
             turns = [self._turn(p, tick) for p in live]
         t1 = time.perf_counter()
-        self.seconds["turns"] += t1 - t0
+        self._seconds["turns"] += t1 - t0
         published = sum(pub for pub, _ in turns)
         self.last_published = [0] * self.N
         for p, (pub, _) in zip(live, turns):
@@ -421,7 +438,7 @@ class Cluster:
             else:
                 for q in range(self.N):
                     self._pull(q, live, lost[q])
-            self.seconds["transport"] += time.perf_counter() - t1
+            self._seconds["transport"] += time.perf_counter() - t1
             self.ticks += int(tick)
             return published
         for p, (pub, out) in zip(live, turns):
@@ -435,7 +452,7 @@ class Cluster:
                 if self.loss and frames and self._rng.random() < self.loss:
                     continue
                 self.nodes[q].deliver(frames)
-        self.seconds["transport"] += time.perf_counter() - t1
+        self._seconds["transport"] += time.perf_counter() - t1
         self.ticks += int(tick)
         return published
 

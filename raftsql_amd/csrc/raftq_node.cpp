@@ -106,7 +106,7 @@ struct Pool {
     int c = 0;
     size_t sz = 64;
     while (sz < bytes) sz <<= 1, ++c;
-    if (c >= kClasses) {  // larger than any class: its own allocation, kept until the node goes
+    if (c >= kClasses) {  // larger than any class: its own allocation
       void* p = std::malloc(bytes);
       if (!p) throw std::bad_alloc();
       big.push_back(p);
@@ -141,7 +141,16 @@ struct Pool {
     int c = 0;
     size_t sz = 64;
     while (sz < bytes) sz <<= 1, ++c;
-    if (c >= kClasses) return;  // a `big` block: stays until the node goes
+    if (c >= kClasses) {  // a `big` block: handed back to malloc (there are few of them: a log of > 40,000 entries)
+      for (size_t i = big.size(); i-- > 0;)
+        if (big[i] == p) {
+          std::free(p);
+          big[i] = big.back();
+          big.pop_back();
+          break;
+        }
+      return;
+    }
     std::memcpy(p, &free_list[c], sizeof(void*));
     free_list[c] = p;
   }

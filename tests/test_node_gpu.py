@@ -815,3 +815,30 @@ def test_followers_without_tail_appends(Cluster, monkeypatch):
     finally:
         c.close()
     test_chaos_safety_and_convergence(Cluster, 8, False, False)
+
+
+def test_one_group_with_a_very_long_log(Cluster):
+    """70,000 entries in ONE group's log (and on its commit channels): the per-group arrays outgrow the node's pool classes
+    (1 MB blocks) and move to allocations of their own, on the leader and on the followers; every node delivers every
+    statement in order, and the group next door is untouched."""
+    c = Cluster(3, 3, seed=3, threads=True, native_transport=True)
+    try:
+        c.start()
+        elect(c)
+        lead = int(c.leaders()[1])
+        n, per = 70000, 3500
+        for k in range(0, n, per):
+            g = np.full(per, 1, dtype=np.uint64)
+            stmt = [b"s%07d" % i for i in range(k, k + per)]
+            off = np.arange(per + 1, dtype=np.uint64) * 8
+            c.nodes[lead].propose_blob(g, off, b"".join(stmt))
+            c.run(3, tick=False)
+        c.settle()
+        for nd in c.nodes:
+            got = [d for d in nd.drain(1) if d is not None]
+            assert len(got) == n and got[0] == b"s0000000" and got[-1] == b"s%07d" % (n - 1) and got == sorted(got)
+            assert [d for d in nd.drain(0) if d is not None] == []
+            assert int(nd.status(1).commit) >= n
+        check_safety(c)
+    finally:
+        c.close()

@@ -146,12 +146,14 @@ int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, u
  * own them and must be destroyed first.
  * raftq_crank_step = for every node p with bit p of live_mask set: raftq_node_tick (when tick != 0) and
  * raftq_node_advance, all at once; then, all at once per ADDRESSEE q, raftq_node_forward(p -> q) for every live sender p
- * in slot order -- dropped instead when q is not live or lost[q * n + p] != 0 (lost may be NULL).  So what a node receives
- * in a step, and in which order, does not depend on thread timing.  published[p] (may be NULL) = entries node p put on
+ * in slot order starting at first_sender (mod n) -- dropped instead when q is not live or lost[q * n + p] != 0 (lost may be
+ * NULL).  So what a node receives in a step, and in which order, does not depend on thread timing; a caller that passes the
+ * step number as first_sender gives no slot the first word every time (two candidates of one tick: whose MsgVote a third
+ * node reads first decides the election -- with a fixed order the lowest slot would win every tie).  published[p] (may be NULL) = entries node p put on
  * its commit channels; node_rc[p] (may be NULL) = node p's first error; returns the first non-zero of those. */
 typedef struct raftq_crank raftq_crank_t;
 int raftq_crank_create(raftq_node_t* const* nodes, uint32_t n, const int* cpus /*[n]|NULL*/, raftq_crank_t** out);
-int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost /*[n*n]|NULL*/,
+int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost /*[n*n]|NULL*/, uint32_t first_sender,
                      uint64_t* published /*[n]|NULL*/, int* node_rc /*[n]|NULL*/);
 /* wall time of all steps so far, by half: every node's turn (the slowest decides), the transport */
 void raftq_crank_seconds(const raftq_crank_t* c, double* turns, double* transport);

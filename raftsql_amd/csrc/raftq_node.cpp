@@ -1788,7 +1788,8 @@ void raftq_node_destroy(raftq_node_t* n) {
 // ---- raftq_crank: the nodes of one process turned in lock-step, each on a thread of its own ------------------------------
 // What the reference's tests do with three raftNodes over loopback (raftsql_test.go:11-35) and what bench.py's node leg
 // measures: every live node's Tick + Ready-loop iteration at once, then every node's inbound buffer filled from the
-// others' queues (per ADDRESSEE, senders in slot order: what a node receives does not depend on thread timing).  One call
+// others' queues (per ADDRESSEE, senders in slot order from `first_sender` on: what a node receives does not depend on
+// thread timing, and a caller that moves first_sender along gives no slot the first word every time).  One call
 // per cluster step; the threads live as long as the crank (a Python thread pool costs a GIL hand-off per node and step,
 // and its workers do not stay on the node's core).
 struct raftq_crank {
@@ -1799,7 +1800,7 @@ struct raftq_crank {
   uint64_t epoch = 0;
   uint32_t pending = 0;
   int phase = 0;  // 1 = turn, 2 = transport, -1 = quit
-  uint32_t live = 0;
+  uint32_t live = 0, first_sender = 0;
   int tick = 0;
   const uint8_t* lost = nullptr;
   std::vector<int> rc;
@@ -1837,7 +1838,8 @@ void crank_worker(raftq_crank* c, uint32_t p, int cpu) {
       if (rc == RAFTQ_OK) rc = raftq_node_advance(c->nodes[p], &pub);
       c->published[p] = pub;
     } else if (phase == 2) {
-      for (uint32_t from = 0; from < n && rc == RAFTQ_OK; ++from) {
+      for (uint32_t k = 0; k < n && rc == RAFTQ_OK; ++k) {
+        const uint32_t from = (c->first_sender + k) % n;
         if (from == p || !(c->live >> from & 1u)) continue;
         const bool gone = !(c->live >> p & 1u) || (c->lost && c->lost[(size_t)p * n + from]);
         rc = raftq_node_forward(c->nodes[from], p, gone ? nullptr : c->nodes[p], nullptr);
@@ -1884,12 +1886,14 @@ int raftq_crank_create(raftq_node_t* const* nodes, uint32_t n, const int* cpus, 
   return RAFTQ_OK;
 }
 
-int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost, uint64_t* published, int* node_rc) {
+int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost, uint32_t first_sender, uint64_t* published,
+                     int* node_rc) {
   if (!c) return RAFTQ_EINVAL;
   const uint32_t n = (uint32_t)c->nodes.size();
   for (uint32_t p = 0; p < 32; ++p)
     if ((live_mask >> p & 1u) && (p >= n || !c->nodes[p])) return RAFTQ_EINVAL;
   c->live = live_mask;
+  c->first_sender = first_sender % n;
   c->tick = tick;
   c->lost = lost;
   std::fill(c->rc.begin(), c->rc.end(), RAFTQ_OK);

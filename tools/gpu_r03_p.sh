@@ -1,8 +1,7 @@
 #!/bin/bash
-# the whole GPU suite + smoke + the bench line + the node leg three times, on the final tree
-P=gpurun_out/r03/final5; mkdir -p $P
+# the whole GPU suite + smoke + the bench line on the final tree
+P=gpurun_out/r03/final6; mkdir -p $P
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $P/gpu_tests.log 2>&1; echo "suite rc=$? $(tail -n 1 $P/gpu_tests.log)"
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
 python bench.py --gpus 1 --steps 20 --warmup 5 > $P/bench_n1.json 2> $P/bench_n1.err; echo "bench rc=$?"
-for i in 1 2 3; do RAFTQ_PROFILE=1 RAFTQ_PROFILE_EVERY=118 timeout 300 python tools/profile_node.py 2>&1 | grep -v "amdgpu.ids\|^wall" | cut -c1-2400; done > $P/node_leg.txt 2>&1
 python tools/results_table.py $P/bench_n1.json | tail -n 4

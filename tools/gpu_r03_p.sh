@@ -1,7 +1,9 @@
 #!/bin/bash
-# the whole GPU suite + smoke + the bench line on the final tree
-P=gpurun_out/r03/final6; mkdir -p $P
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $P/gpu_tests.log 2>&1; echo "suite rc=$? $(tail -n 1 $P/gpu_tests.log)"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
-python bench.py --gpus 1 --steps 20 --warmup 5 > $P/bench_n1.json 2> $P/bench_n1.err; echo "bench rc=$?"
-python tools/results_table.py $P/bench_n1.json | tail -n 4
+# rocprofv3 kernel stats of the bench's node leg (three raftq_nodes on one GPU)
+P=gpurun_out/r03/node_prof; mkdir -p $P
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np -o node -- python $GRAFT_REPO_ROOT/tools/profile_node.py > /tmp/np.out 2>&1
+cd $GRAFT_REPO_ROOT
+cp $(find /tmp/np -name "*kernel_stats.csv" | head -1) $P/node_kernel_stats.csv
+grep -o "'proposals_committed_everywhere_per_s': [0-9.]*" /tmp/np.out | head -1
+cut -d, -f1-5 $P/node_kernel_stats.csv | cut -c1-160 | head -24

@@ -941,8 +941,8 @@ def main():
     ap.add_argument("--policy", choices=["stream", "cached", "auto"], default="stream",
                     help="cache policy: no batch stays cached between its sweeps, so stream")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
-                    help="torch.distributed backend under torchrun (default nccl = RCCL); gloo is for testing the "
-                         "multi-process path on a box with fewer GPUs than ranks")
+                    help="host-side rendezvous under torchrun (default gloo + a shared-memory barrier: the data path has no "
+                         "collective; nccl = RCCL is opt-in and only adopted when every rank could build it, raftsql_amd/dist.py)")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index on every rank (testing only)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -137,7 +137,12 @@ uint32_t raftq_quorum(uint32_t n_peers);
 
 /* ---- handle lifetime --------------------------------------------------- */
 /* allocates the padded SoA state for G groups x N peers in HBM on `device`;
- * everything starts zeroed (match 0, committed 0, no votes, no terms). */
+ * everything starts zeroed (match 0, committed 0, no votes, no terms).
+ * 1 <= n_groups <= RAFTQ_MAX_GROUPS (RAFTQ_EINVAL above): the bound is what the
+ * parity suite has compared against the oracle on one handle (2^29 + 70001 groups,
+ * tests/test_envelope_gpu.py), rounded up to the next power of two -- a larger
+ * population is several handles (one sweep set), which is also how it shards. */
+#define RAFTQ_MAX_GROUPS (1ull << 30)
 int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out);
 void raftq_destroy(raftq_t* h);
 uint64_t raftq_groups(const raftq_t* h);

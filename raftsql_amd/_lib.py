@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RAFTQ_LIB: another build of the same library (the sanitizer builds of raftsql_amd/build.py: libraftq_asan.so, libraftq_tsan.so)
+# RAFTQ_LIB: another build of the SAME library out of raftsql_amd/build.py (the sanitizer builds libraftq_asan.so /
+# libraftq_tsan.so, an A/B build with other -D defines).  It must sit in this package's directory: the package has no
+# way to be pointed at anything else -- test doubles are the tests' business (tests/conftest.py), not the product's.
 LIB_PATH = os.environ.get("RAFTQ_LIB") or os.path.join(_HERE, "libraftq.so")
 
 RAFTQ_OK = 0
@@ -180,11 +182,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if "hostsim" in os.path.basename(LIB_PATH) and os.environ.get("RAFTQ_HOSTSIM") != "1":
-        # tests/c/libraftq_hostsim.so answers the engine's calls with the CPU oracle so that the host C++ can run under
-        # ASan (tests/test_hostsim.py).  It is test infrastructure: the package never loads it on RAFTQ_LIB alone.
-        raise ImportError("RAFTQ_LIB names the test-only host simulation; it is only loaded together with RAFTQ_HOSTSIM=1 "
-                          "(tests/test_hostsim.py).  raftsql_amd has no CPU path.")
+    env_lib = os.environ.get("RAFTQ_LIB")
+    if env_lib and LIB_PATH == env_lib and os.path.dirname(os.path.abspath(env_lib)) != _HERE:
+        raise ImportError(f"RAFTQ_LIB={env_lib}: only builds of libraftq inside {_HERE} are loaded (raftsql_amd/build.py puts "
+                          "them there).  raftsql_amd has no CPU path and no test double.")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: run `python -m raftsql_amd.build` (needs hipcc). "

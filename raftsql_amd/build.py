@@ -1,4 +1,4 @@
-"""Build the in-tree native pieces: libraftq.so (HIP, gfx950) and the tuner.
+"""Build the in-tree native pieces: libraftq.so (HIP, gfx950) and the standalone measurement tools.
 
 Explicit hipcc invocations so the built .so sits next to the package and
 travels to the GPU box with the source snapshot (a JIT cache would not).
@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "raftsql_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libraftq.so")
-TUNER = os.path.join(PKG, "raftq_tune")
 ARCH = "gfx950"
 
 
@@ -131,44 +130,30 @@ def sanitizer_runtime(kind: str) -> str:
     return subprocess.run([clang, "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
 
 
-def build_tuner(force: bool = False) -> str | None:
-    src = os.path.join(CSRC, "raftq_tune.hip")
-    if not os.path.exists(src):
-        return None
-    if not force and not _stale(TUNER, [src, os.path.join(CSRC, "raftq_kernels.hpp")]):
-        return TUNER
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-           "-I" + CSRC, "-o", TUNER, src]
-    subprocess.check_call(cmd)
-    return TUNER
+TUNE_DIR = os.path.join(ROOT, "tools", "tune")
 
 
-def build_tuner2(force: bool = False) -> str | None:
-    """Second tuner: layout / instruction-count A/B (profiles/r01/tune2_*.jsonl)."""
-    src = os.path.join(CSRC, "raftq_tune2.hip")
-    out = TUNER + "2"
+def build_tool(src: str, out: str | None = None, force: bool = False, deps: list[str] | None = None) -> str | None:
+    """A standalone measurement / probe binary (tools/tune/*.hip, tools/probe/*.hip): NOT part of libraftq.so.  Built
+    in-tree beside its source so that it travels to the GPU box, which needs no compiler for it."""
     if not os.path.exists(src):
         return None
-    if not force and not _stale(out, [src, os.path.join(CSRC, "raftq_kernels.hpp")]):
+    out = out or os.path.splitext(src)[0]
+    if not force and not _stale(out, [src] + (deps or [os.path.join(CSRC, "raftq_kernels.hpp")])):
         return out
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-           "-I" + CSRC, "-o", out, src]
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-o", out, src]
     subprocess.check_call(cmd)
     return out
 
 
-def build_tuner3(force: bool = False) -> str | None:
-    """Third tuner: launch-shape A/B of round 2 (single / set / persistent / LDS ring; profiles/r02/tune3_*.jsonl)."""
-    src = os.path.join(CSRC, "raftq_tune3.hip")
-    out = TUNER + "3"
-    if not os.path.exists(src):
-        return None
-    if not force and not _stale(out, [src, os.path.join(CSRC, "raftq_kernels.hpp")]):
-        return out
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-           "-I" + CSRC, "-o", out, src]
-    subprocess.check_call(cmd)
-    return out
+def tool_sources() -> list[str]:
+    """Every standalone HIP tool of the tree: the sweep tuners (tools/tune/: raftq_tune = round 1's policy / tile A/B,
+    raftq_tune2 = layout / instruction count, raftq_tune3 = launch shapes + the PMC calibration copy, single_launch_ab =
+    round 4's one-launch-at-a-time A/B) and the link / BAR probes (tools/probe/)."""
+    import glob
+
+    return sorted(glob.glob(os.path.join(TUNE_DIR, "*.hip")) + glob.glob(os.path.join(ROOT, "tools", "probe", "*.hip")))
 
 
 SORT_CHECK = os.path.join(PKG, "raftq_sort_check")
@@ -189,12 +174,12 @@ def build_sort_check(force: bool = False) -> str:
 
 
 def build_all(force: bool = False, log: list | None = None) -> None:
-    """The library, the three tuners and the sort checker, concurrently (every piece is its own hipcc process)."""
+    """The library, the standalone tools and the sort checker, concurrently (every piece is its own hipcc process)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    with ThreadPoolExecutor(5) as ex:
-        futs = [ex.submit(build_lib, force, None, False, log), ex.submit(build_tuner, force), ex.submit(build_tuner2, force),
-                ex.submit(build_tuner3, force), ex.submit(build_sort_check, force)]
+    with ThreadPoolExecutor(6) as ex:
+        futs = [ex.submit(build_lib, force, None, False, log), ex.submit(build_sort_check, force)]
+        futs += [ex.submit(build_tool, src, None, force) for src in tool_sources()]
         for f in futs:
             f.result()
 

@@ -327,7 +327,8 @@ uint32_t raftq_peers(const raftq_t* h) { return h ? h->N : 0; }
 int raftq_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_t** out) {
   if (!out) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: null out");
   *out = nullptr;
-  if (n_groups == 0 || n_groups > (1ull << 40)) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: n_groups out of range");
+  if (n_groups == 0 || n_groups > RAFTQ_MAX_GROUPS)
+    return fail(nullptr, RAFTQ_EINVAL, "raftq_create: n_groups out of range (1 .. RAFTQ_MAX_GROUPS = 2^30 per handle)");
   if (n_peers < 1 || n_peers > RAFTQ_MAX_PEERS) return fail(nullptr, RAFTQ_EINVAL, "raftq_create: n_peers must be 1..9");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -4,7 +4,7 @@
 // against libraftq.so -- under AddressSanitizer + UBSan: 1,900 lines of host C++ (mutexes, condition variables, a
 // background thread, arenas, queues) that cannot be run under ASan beside the HIP runtime (profiles/r03/sanitizers_host_cpp.txt).
 // Nothing of the product links, loads or ships this file; it is not a CPU fallback: it exists only inside the test
-// library, which the product's loader only opens when RAFTQ_LIB names it (tests/test_hostsim.py does).
+// library, which the product's loader never opens (tests/conftest.py swaps the path for tests/test_hostsim.py's sub-runs).
 //
 // Semantics follow include/*.h: same return codes, same all-or-nothing rules, same list orders.  The arithmetic is the
 // oracle's, which tests/test_*_gpu.py hold equal to the device's word for word.

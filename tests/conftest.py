@@ -13,6 +13,19 @@ if ROOT not in sys.path:
 os.environ.setdefault("RAFTQ_CYCLE_CHECK", "1")
 
 
+# tests/test_hostsim.py re-runs the node / pipe suites with the host C++ under ASan / TSan and the engine calls answered by
+# the CPU oracle (tests/c/libraftq_hostsim*.so).  That library is a TEST double: the package cannot be pointed at it (its
+# loader only takes builds inside raftsql_amd/), so the sub-run names it in RAFTQ_TEST_ENGINE_DOUBLE and THIS file, not the
+# product, swaps the path before anything is loaded.
+_DOUBLE = os.environ.get("RAFTQ_TEST_ENGINE_DOUBLE")
+if _DOUBLE:
+    assert os.path.dirname(os.path.abspath(_DOUBLE)) == os.path.join(ROOT, "tests", "c"), "the engine double lives under tests/c"
+    from raftsql_amd import _lib as _product_lib
+
+    assert _product_lib._lib is None, "the product library is already loaded"
+    _product_lib.LIB_PATH = _DOUBLE
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 
@@ -32,10 +45,7 @@ def gpu_engine_cls():
     """QuorumEngine bound to the native library; refuses to run without it."""
     from raftsql_amd.engine import QuorumEngine, device_count
 
-    if os.environ.get("RAFTQ_HOSTSIM") == "1":
-        # tests/test_hostsim.py: the node / pipe suites against tests/c/libraftq_hostsim.so (their host C++ under
-        # ASan + UBSan, the engine calls answered by the oracle) -- TEST ONLY, and only when RAFTQ_LIB names that library
-        assert "hostsim" in os.environ.get("RAFTQ_LIB", ""), "RAFTQ_HOSTSIM=1 without the test library"
+    if _DOUBLE:  # tests/test_hostsim.py's sub-run: no GPU is needed, the oracle answers the engine calls
         return QuorumEngine
     import torch
 

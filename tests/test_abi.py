@@ -136,6 +136,34 @@ def test_product_never_imports_the_oracle():
         assert not re.search(r"^(from|import)\s+oracle\b", txt, flags=re.M), f  # module level
 
 
+def test_package_has_no_switch_to_a_test_double():
+    """the oracle-backed engine of tests/test_hostsim.py is the tests' business.  Nothing under
+    raftsql_amd/ names it, and the loader refuses any RAFTQ_LIB outside the package directory."""
+    import subprocess
+    import sys
+
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raftsql_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                assert "hostsim" not in open(os.path.join(dirpath, f)).read().lower(), os.path.join(dirpath, f)
+    r = subprocess.run([sys.executable, "-c", "from raftsql_amd import _lib; _lib.load()"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, RAFTQ_LIB=os.path.join(ROOT, "tests", "c", "libraftq_hostsim.so")))
+    assert r.returncode != 0 and "only builds of libraftq inside" in r.stderr, r.stderr[-600:]
+
+
+def test_group_bound_is_the_tested_one(lib):
+    """raftq_create accepts what one handle has been compared at (tests/test_envelope_gpu.py: 2^29 + 70001), no more."""
+    import ctypes as C
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "raftq.h")).read()
+    assert re.search(r"#define RAFTQ_MAX_GROUPS \(1ull << 30\)", hdr)
+    env = open(os.path.join(ROOT, "tests", "test_envelope_gpu.py")).read()
+    assert "(1 << 29) + 70001" in env
+    h = C.c_void_p()
+    assert lib.raftq_create(0, (1 << 30) + 1, 3, C.byref(h)) == -1 and not h.value  # refused before any device is touched
+
+
 def test_headers_are_plain_c99_and_link_from_c(lib, tmp_path):
     """cgo compiles its preamble as C: all public headers must pass a pedantic C99 compiler and the
     library must link and answer from a C program (no C++ runtime needed by the caller)."""

@@ -5,7 +5,7 @@ libraftq.so (tests/test_node_gpu.py, tests/test_node_scenarios_gpu.py, tests/tes
 ASan cannot run beside the HIP runtime on this image (profiles/r03/sanitizers_host_cpp.txt: its HSA interceptors abort),
 so here the two translation units are linked with tests/c/engine_sim.cpp, which answers the engine's C-ABI on the CPU with
 the oracle -- test infrastructure, not a CPU path of the product: the library exists only under tests/c/ and the product's
-loader only opens it when RAFTQ_LIB names it.  On the GPU box the same suites run against the real engine (and under UBSan
+loader cannot be pointed at it (tests/conftest.py swaps the path for the sub-run, RAFTQ_TEST_ENGINE_DOUBLE).  On the GPU box the same suites run against the real engine (and under UBSan
 and TSan, tools/sanitize_r03.sh).  Besides the sanitizer, this gives the CPU suite the node's and the pipe's behaviour
 tests: election safety, log matching, replay + sentinel, chaos, WAL restart, etcd's network scenarios as recalled."""
 import os
@@ -71,7 +71,7 @@ def test_node_threads_under_tsan():
     if not (shutil.which("g++") and os.path.isabs(tsan) and os.path.exists(tsan)):
         pytest.skip("no g++ / libtsan here")
     lib = _build(san=["-fsanitize=thread", "-O1", "-g"], lib=os.path.join(CDIR, "libraftq_hostsim_tsan.so"), bdir_name="build_hostsim_tsan")
-    env = dict(os.environ, RAFTQ_LIB=lib, RAFTQ_HOSTSIM="1", LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
+    env = dict(os.environ, RAFTQ_TEST_ENGINE_DOUBLE=lib, LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_node_gpu.py", "-k",
                         "threaded or forward or (chaos and True)"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     out = r.stdout + r.stderr
@@ -88,7 +88,7 @@ def _run(tests, extra_env=None, timeout=1500):
     if not (shutil.which("g++") and os.path.isabs(asan) and os.path.exists(asan)):
         pytest.skip("no g++ / libasan here: the host C++ cannot be built under AddressSanitizer")
     lib = _build()
-    env = dict(os.environ, RAFTQ_LIB=lib, RAFTQ_HOSTSIM="1", LD_PRELOAD=asan,
+    env = dict(os.environ, RAFTQ_TEST_ENGINE_DOUBLE=lib, LD_PRELOAD=asan,
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                **(extra_env or {}))
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,

@@ -18,7 +18,7 @@ for c in 3 2 4 5; do
   done
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $P/pmc -o calib_$ctr -- raftsql_amd/raftq_tune3 1 calib > /dev/null 2> $P/pmc_calib_$ctr.err
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $P/pmc -o calib_$ctr -- tools/tune/raftq_tune3 1 calib > /dev/null 2> $P/pmc_calib_$ctr.err
 done
 # 3. where the waves' time goes + L2-side request bytes of the headline kernel
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $P/pmc -o sq1 -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $P/pmc_sq1.err

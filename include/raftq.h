@@ -300,7 +300,10 @@ int raftq_set_wait(raftq_set_t* s, raftq_counts_t* per_member, raftq_counts_t* t
 int raftq_set_timer_begin(raftq_set_t* s);
 int raftq_set_timer_end(raftq_set_t* s, float* elapsed_ms);
 /* the same K sweeps as K launches (raftq_step_async on every handle in turn, each on its
- * own stream): the host loop of a caller without a set, in one call */
+ * own stream): the host loop of a caller without a set, in one call.  Distinct handles that
+ * share ONE stream (members of a set) are alternated between that stream and an auxiliary
+ * one, forked and joined inside the call, so that consecutive launches overlap their
+ * boundaries; everything is ordered behind / in front of the shared stream as before. */
 int raftq_sweep_many_async(raftq_t* const* handles, uint32_t n, unsigned flags);
 /* device-to-device copy of the quorum state (match, commit index, term gate, votes) of
  * `src` into `dst` (same device, groups and peers): fork a population without a host

@@ -59,13 +59,16 @@ def _flags() -> list[str]:
     return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
-def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = False, log: list | None = None) -> str:
+def build_lib(force: bool = False, defines: dict | None = None, verbose: bool = False, log: list | None = None,
+              variant: str | None = None) -> str:
     """libraftq.so from its five translation units: compiled concurrently (one hipcc per unit), then linked.
-    `log` (a list) receives the exact command lines."""
+    `log` (a list) receives the exact command lines.  `variant` + `defines`: an A/B or measurement build beside the
+    product library (raftsql_amd/libraftq_<variant>.so, loaded with RAFTQ_LIB=<that path>)."""
     srcs = lib_sources()
+    LIB = globals()["LIB"] if not variant else os.path.join(PKG, f"libraftq_{variant}.so")
     if not force and not _stale(LIB, srcs):
         return LIB
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build", variant) if variant else os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     defs = [f"-D{k}={v}" for k, v in (defines or {}).items()]
     procs, objs = [], []

@@ -158,6 +158,9 @@ struct raftq {
   uint64_t step_last_n = 0;
   uint32_t step_last_rec = 64;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // raftq_sweep_many_async over handles that share one stream: every other launch goes to this auxiliary stream
+  hipStream_t many_aux = nullptr;
+  hipEvent_t many_fork = nullptr, many_join = nullptr;
   // wire / WAL codecs (raftq_wire.hip): growable device scratch (inputs + temporaries), device
   // output buffer, a small pinned block for totals / flags
   void* wire_dev = nullptr;
@@ -167,6 +170,10 @@ struct raftq {
   uint64_t* wire_pin = nullptr;    // pinned, 256 bytes
   uint64_t* wire_pin_d = nullptr;  // the same block as the device addresses it (the codecs' last kernel writes totals / flags there)
   unsigned long long* wire_flags = nullptr;  // device, 64 bytes, zero between calls: the codecs' malformed counters / bad flags
+  // the streaming codec kernels (raftq_wire_kernels.hpp "the streaming form"): ticket word + per-tile look-back status
+  unsigned long long* wire_lb = nullptr;     // device: kLbHead words {ticket, gave-up flag, landed waves, -}, then kLbArrays status arrays of wire_lb_tiles words
+  uint64_t wire_lb_tiles = 0;
+  uint32_t wire_ticket_base = 0, wire_arrived_base = 0, wire_epoch = 0;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};

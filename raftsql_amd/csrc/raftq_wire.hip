@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "raftq_internal.hpp"
 #include "raftq_wire_kernels.hpp"
@@ -88,6 +90,94 @@ int tail_to_pin(raftq_t* h, const uint64_t* total, unsigned long long* flag) {
 
 unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / kBlock); }
 
+// ---- the streaming form (one persistent kernel per call; raftq_wire_kernels.hpp) -----------------------------------
+bool fused_on() {  // RAFTQ_WIRE_FUSED=0: round 3's chain of copy-in / compute / copy-out kernels (for A/B)
+  static const bool on = [] {
+    const char* e = std::getenv("RAFTQ_WIRE_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+// Workgroups of a streaming kernel.  Few pull host memory faster than many (48 blocks: 55 GB/s, 768: 42,
+// profiles/r04/pcie_duplex_probe.jsonl) but every tile is three PCIe round trips deep, so enough of them must be in
+// flight to keep both directions busy: RAFTQ_WIRE_WGS overrides.
+unsigned fused_grid(uint32_t n_tiles) {
+  const char* e = std::getenv("RAFTQ_WIRE_WGS");  // read per call: the tests drive tiny grids through one process
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return std::min<unsigned>(v > 0 && v <= 4096 ? (unsigned)v : 256u, n_tiles);
+}
+
+constexpr uint64_t kLbHead = 4;  // words in front of the status arrays
+// tiles whose input may be in flight at once (TileCtl::window; RAFTQ_WIRE_WINDOW overrides)
+uint32_t fused_window() {
+  const char* e = std::getenv("RAFTQ_WIRE_WINDOW");
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return v > 0 ? (uint32_t)v : 64u;
+}
+// ticket word + status arrays for a call of n_tiles tiles; a new call is a new epoch (the words of older calls read as
+// "not published yet"), the arrays are zeroed when they are (re)allocated and when the 16-bit epoch wraps
+int tile_ctl(raftq_t* h, uint32_t n_tiles, TileCtl* ctl) {
+  if (n_tiles > h->wire_lb_tiles) {
+    if (h->wire_lb) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipFree(h->wire_lb));
+      h->wire_lb = nullptr;
+      h->wire_lb_tiles = 0;
+    }
+    const uint64_t tiles = std::max<uint64_t>(n_tiles + n_tiles / 2, 4096);
+    HIPCHK(h, hipMalloc((void**)&h->wire_lb, (kLbHead + kLbArrays * tiles) * 8));
+    HIPCHK(h, hipMemsetAsync(h->wire_lb, 0, (kLbHead + kLbArrays * tiles) * 8, h->stream));
+    h->wire_lb_tiles = tiles;
+    h->wire_ticket_base = h->wire_arrived_base = 0;
+    h->wire_epoch = 0;
+  }
+  if (++h->wire_epoch > 0xffffu) {
+    HIPCHK(h, hipMemsetAsync(h->wire_lb + kLbHead, 0, kLbArrays * h->wire_lb_tiles * 8, h->stream));
+    h->wire_epoch = 1;
+  }
+  ctl->ticket = reinterpret_cast<unsigned int*>(h->wire_lb);
+  ctl->ticket_base = h->wire_ticket_base;
+  ctl->arrived_base = h->wire_arrived_base;
+  ctl->window = fused_window();
+  ctl->ablate = 0;
+#if defined(RAFTQ_WIRE_TRACE)
+  if (const char* e = std::getenv("RAFTQ_WIRE_ABLATE")) ctl->ablate = (uint32_t)std::strtol(e, nullptr, 10);
+#endif
+  ctl->epoch = h->wire_epoch;
+  for (int k = 0; k < kLbArrays; ++k) ctl->status[k] = h->wire_lb + kLbHead + (uint64_t)k * h->wire_lb_tiles;
+  return RAFTQ_OK;
+}
+// every workgroup of a launch draws exactly one ticket beyond the tiles; every wave of every tile reports its input once
+void tile_ctl_launched(raftq_t* h, uint32_t n_tiles, unsigned grid) {
+  h->wire_ticket_base += n_tiles + grid;
+  h->wire_arrived_base += n_tiles * (uint32_t)kWaves;
+}
+#if defined(RAFTQ_WIRE_TRACE)
+// RAFTQ_TRACE_STAMP's rows of the call just waited for -> stderr (once every 16th call): per tile, microseconds since the
+// earliest stamp of the launch
+void trace_dump(raftq_t* h, const char* what, uint32_t n_tiles) {
+  static int calls = 0;
+  static const bool dump = std::getenv("RAFTQ_WIRE_TRACE_DUMP") != nullptr;
+  if (!dump || (calls++ & 15) != 15 || n_tiles * 8ull > h->wire_lb_tiles) return;
+  std::vector<unsigned long long> t(n_tiles * 8ull);
+  if (hipMemcpy(t.data(), h->wire_lb + kLbHead + 2 * h->wire_lb_tiles, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  unsigned long long t0 = ~0ull;
+  for (uint32_t i = 0; i < n_tiles; ++i) t0 = std::min(t0, t[i * 8ull]);
+  std::fprintf(stderr, "[trace %s] tile: claimed offs_in dma_issued frames_in parsed lookback ents_out recs_out (us)\n", what);
+  for (uint32_t i = 0; i < n_tiles; i += (n_tiles > 64 ? n_tiles / 32 : 1)) {
+    std::fprintf(stderr, "[trace %s] %5u:", what, i);
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %7.1f", (double)(t[i * 8ull + k] - t0) / 100.0);
+    std::fprintf(stderr, "\n");
+  }
+}
+#endif
+// after the call's wait: did a look-back give up (wire_pin[3], copied from the control block by the last tile)?
+int tile_ctl_check(raftq_t* h, const char* who) {
+  if (h->wire_pin[3] == 0) return RAFTQ_OK;
+  h->wire_lb_tiles = 0;  // the control block is not trusted any more: the next call allocates a fresh one
+  return fail(h, RAFTQ_EHIP, std::string(who) + ": a workgroup waited a second for its predecessor's tile and gave up; the results are not valid");
+}
+
 // chain[i] = pair[0] . pair[1] . ... . pair[i]; tot: scratch for ceil(n / kBlock) pairs
 int crc_chain_scan(raftq_t* h, const CrcPair* pair, CrcPair* chain, uint64_t n, CrcPair* tot) {
   const unsigned nb = blocks_for(n);
@@ -113,7 +203,10 @@ void raftq_detail::free_wire_state(raftq_t* h) {
   (void)hipFree(h->wire_dev);
   (void)hipFree(h->wire_out);
   (void)hipFree(h->wire_flags);
+  (void)hipFree(h->wire_lb);
   h->wire_flags = nullptr;
+  h->wire_lb = nullptr;
+  h->wire_lb_tiles = 0;
   if (h->wire_pin) (void)hipHostFree(h->wire_pin);
   h->wire_dev = h->wire_out = nullptr;
   h->wire_pin = nullptr;
@@ -254,6 +347,35 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (int rc = ensure_pin(h)) return rc;
   // an entry costs its message at least two bytes (tag, length), so this many can never be exceeded
   const uint64_t dev_cap = std::min<uint64_t>(ents_cap, nbytes / 2 + 1);
+  void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
+  const bool mapped = kernel_copies() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+                      (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
+  if (mapped && fused_on() && nbytes >= 16 && nbytes < (1ull << (kLbValueBits - 1)) && ((uintptr_t)v_stream & 15) == 0) {
+    // page-locked caller buffers: ONE persistent kernel pulls, parses and pushes tile by tile -- no device copy of anything
+    const uint32_t n_tiles = blocks_for(n);
+    const unsigned grid = fused_grid(n_tiles);
+    TileCtl ctl;
+    if (int rc = tile_ctl(h, n_tiles, &ctl)) return rc;
+    hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(grid), dim3(kBlock), 0, h->stream, (const uint8_t*)v_stream, nbytes,
+                       (const uint64_t*)v_off, n, (WireMsg*)v_msgs, (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d);
+    HIPCHK(h, hipGetLastError());
+    tile_ctl_launched(h, n_tiles, grid);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+#if defined(RAFTQ_WIRE_TRACE)
+    trace_dump(h, "wire_dec", n_tiles);
+#endif
+    if (int rc = tile_ctl_check(h, "raftq_wire_decode")) return rc;
+    const uint64_t total = h->wire_pin[0];
+    if (counts) {
+      counts->n_msgs = n;
+      counts->n_ents = total;
+      counts->n_malformed = h->wire_pin[1];
+      counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+    }
+    if (ents && total > ents_cap)
+      return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
+    return RAFTQ_OK;
+  }
   const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
   const size_t o_stream = c.take(nbytes), o_off = c.take((n + 1) * 8), o_msgs = c.take(n * sizeof(WireMsg)),
@@ -267,9 +389,6 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   WireEnt* d_ents = (WireEnt*)h->wire_out;
   unsigned long long* d_bad = h->wire_flags + 1;  // (o_bad: unused since the flags have a block of their own)
   (void)o_bad;
-  void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
-  const bool mapped = kernel_copies() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
-                      (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
   if (mapped) {
     const CopySegs in = {{{v_stream, d_stream, nbytes}, {v_off, d_off, (n + 1) * 8}, {nullptr, nullptr, 0}}};
     hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(nbytes + (n + 1) * 8)), dim3(kBlock), 0, h->stream, in);

@@ -731,6 +731,339 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
   msgs[i].ent_first = (uint32_t)first;
 }
 
+// ---- the streaming form of a codec call (round 4) --------------------------------------------------------------------
+// On page-locked caller buffers round 3's call was copy-in kernel -> 3-5 small kernels -> copy-out kernel: the link's two
+// directions never worked at the same time (245 us to decode 64K frames whose inbound and outbound bytes are 55 + 88 us
+// apart).  The probe (profiles/r04/pcie_duplex_probe.jsonl) says what the link takes: workgroups pull host memory at
+// 42-55 GB/s and push at 55, and ONE kernel whose workgroups do both moves 41 GB/s each way at once -- while two kernels
+// on two streams do not overlap at all when one of them writes host memory (the round-1 finding still holds on ROCm 7.2).
+// So a call is now ONE persistent kernel and the device never holds a copy of its inputs or outputs: a workgroup takes
+// the next tile of 256 frames (a ticket), pulls the tile's boundaries and its contiguous run of stream bytes over PCIe
+// straight into LDS, parses there, learns where its entry headers go from a decoupled look-back over the tiles before it
+// (one 64-bit status word per tile: epoch | flag | value, relaxed agent-scope atomics -- value and flag travel together,
+// no fence), and pushes its records -- staged in LDS, so that every store instruction writes 4 KB of consecutive host
+// memory -- and entry headers out.  Workgroups are at different points of that cycle at any moment: some pull while
+// others push.  Tickets (not blockIdx) order the tiles, so a tile is only ever waited for after a running workgroup
+// has claimed it: the look-back cannot deadlock however few workgroups are resident.
+constexpr int kLbValueBits = 46, kLbFlagShift = 46, kLbEpochShift = 48;
+constexpr int kLbArrays = 4;
+constexpr uint64_t kLbValueMask = (1ull << kLbValueBits) - 1;
+constexpr uint32_t kLbAggregate = 1, kLbInclusive = 2;
+
+struct TileCtl {
+  unsigned int* ticket;            // monotonic across calls: tile = ticket - ticket_base; ticket[1] = "a wait gave up";
+                                   // ticket[2] = waves whose input has landed (monotonic: minus arrived_base)
+  uint32_t ticket_base, arrived_base;
+  uint32_t window;                 // tiles whose input may be in flight at once (see next_tile)
+  uint32_t epoch;                  // 1 .. 0xffff: status words of older calls read as "not yet"
+  uint32_t ablate;                 // measurement builds (RAFTQ_WIRE_TRACE) only: bit 0 = records stay, bit 1 = entry headers stay
+  unsigned long long* status[kLbArrays];  // [n_tiles] each: independent running sums (a kernel uses the first two or three)
+};
+
+__device__ __forceinline__ uint64_t lb_word(uint32_t epoch, uint32_t flag, uint64_t v) {
+  return ((uint64_t)epoch << kLbEpochShift) | ((uint64_t)flag << kLbFlagShift) | (v & kLbValueMask);
+}
+// A word of THIS call, waited for.  The wait is bounded (a second or so of polling: five orders of magnitude above a
+// tile's life) so that no fault -- a lost workgroup, a corrupted control block -- can hang the queue: the waiter gives up,
+// raises *stuck (the call then fails with RAFTQ_EHIP) and continues with zero.
+__device__ __forceinline__ uint64_t lb_wait(const unsigned long long* w, uint32_t epoch, unsigned int* stuck) {
+  for (uint32_t spin = 0; spin < (1u << 23); ++spin) {
+    const uint64_t s = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(s >> kLbEpochShift) == epoch && ((s >> kLbFlagShift) & 3u) != 0) return s;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  atomicOr(stuck, 1u);
+  return lb_word(epoch, kLbInclusive, 0);
+}
+// ONE lane per workgroup: publish this tile's aggregate, add up the tiles before it, publish the inclusive sum.
+// -> the exclusive prefix of `tile`.
+__device__ inline uint64_t lb_exclusive(unsigned long long* status, uint32_t epoch, uint32_t tile, uint64_t aggregate, unsigned int* stuck) {
+  if (tile == 0) {
+    __hip_atomic_store(status, lb_word(epoch, kLbInclusive, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  __hip_atomic_store(status + tile, lb_word(epoch, kLbAggregate, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t prefix = 0;
+  for (uint32_t j = tile; j-- > 0;) {
+    const uint64_t s = lb_wait(status + j, epoch, stuck);
+    prefix += s & kLbValueMask;
+    if (((s >> kLbFlagShift) & 3u) == kLbInclusive) break;
+  }
+  __hip_atomic_store(status + tile, lb_word(epoch, kLbInclusive, prefix + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return prefix;
+}
+
+// A workgroup's tile: the next ticket (wave-uniform result through LDS).  The input of tile t is only asked for once the
+// input of tile t - window has landed: with every tile's pulls in flight at once the link serves them all at the same pace
+// and the FIRST tile's frames arrive when the last one's do -- nothing can leave before everything has come in, the two
+// directions take turns (profiles/r04/wire_dec_trace_*.txt).  Inside the window the early tiles get the link to
+// themselves, complete in order, and their records are on the way out while later tiles' frames are still coming in.
+__device__ __forceinline__ uint32_t next_tile(const TileCtl& ctl, uint32_t* slot /*LDS*/, uint32_t n_tiles) {
+  __syncthreads();  // the previous tile's readers of *slot (and of every other LDS array of the loop) are done
+  if (threadIdx.x == 0) {
+    const uint32_t tile = atomicAdd(ctl.ticket, 1u) - ctl.ticket_base;
+    if (tile < n_tiles && tile >= ctl.window) {
+      const uint32_t need = (tile - ctl.window + 1) * (uint32_t)kWaves;
+      uint32_t spin = 0;
+      while (__hip_atomic_load(ctl.ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ctl.arrived_base < need) {
+        if (++spin > (1u << 23)) {
+          atomicOr(ctl.ticket + 1, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    *slot = tile;
+  }
+  __syncthreads();
+  return *slot;
+}
+// a wave's input has landed (one lane says so)
+__device__ __forceinline__ void tile_input_landed(const TileCtl& ctl) {
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctl.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// block-wide exclusive sum of one u32 per thread (kBlock threads) -> this thread's prefix; *total = the block's sum
+__device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wave_tot /*LDS [kWaves]*/, uint64_t* total) {
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
+  }
+  if (lane == 63) wave_tot[w] = incl;
+  __syncthreads();
+  uint64_t pre = 0, all = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < (uint32_t)kWaves; ++k) {
+    const uint64_t t = wave_tot[k];
+    pre += k < w ? t : 0;
+    all += t;
+  }
+  *total = all;
+  return pre + incl - v;
+}
+
+// the tile's records leave through LDS: lane-consecutive 16-byte stores, 4 KB of consecutive host memory per instruction
+template <typename Rec>
+__device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32x4* lds /*[kBlock * sizeof(Rec) / 16]*/, Rec* out_h,
+                                                 uint64_t tile0, uint64_t n) {
+  static_assert(sizeof(Rec) % 16 == 0, "records are whole quads");
+  constexpr uint32_t kQ = sizeof(Rec) / 16;
+  if (live) {
+    u32x4 q[kQ];
+    __builtin_memcpy(q, &mine, sizeof(Rec));
+#pragma unroll
+    for (uint32_t k = 0; k < kQ; ++k) lds[threadIdx.x * kQ + k] = q[k];
+  }
+  __syncthreads();
+  const uint64_t live_recs = n - tile0 < (uint64_t)kBlock ? n - tile0 : (uint64_t)kBlock;
+  const uint32_t quads = (uint32_t)live_recs * kQ;
+  u32x4* dst = reinterpret_cast<u32x4*>(out_h + tile0);
+#pragma unroll
+  for (uint32_t k = 0; k < kQ; ++k) {
+    const uint32_t q = k * kBlock + threadIdx.x;
+    if (q < quads) __builtin_nontemporal_store(lds[q], dst + q);
+  }
+}
+
+// A wave's run of frames on its way into LDS with every request issued before the first one is waited for: global -> LDS
+// DMA (global_load_lds, 16 bytes per lane, 1 KB of consecutive stream per instruction, no VGPR round trip); the caller
+// waits with s_waitcnt vmcnt(0).  (stage_wave_frames' load -> store loop has one round trip per KB in flight.)
+// Needs a 16-byte aligned stream of at least 16 bytes (the caller checks: kernel-uniform).  The one run of a call that ends
+// in the buffer's last, partial quad brings those < 16 bytes in afterwards (stage_tail).
+constexpr uint32_t kStageChunks = kStageBytes / 1024;
+constexpr uint32_t kEntQ = 4;  // entry headers a lane keeps in LDS from its one walk of a frame (more: the frame is walked again)
+struct WaveStageAsync {
+  WaveStage st;
+  uint64_t tail0 = 0;   // stream offset of the bytes still to fetch
+  uint32_t tail_n = 0, tail_at = 0;  // how many, and where in the stage they go
+};
+__device__ __forceinline__ WaveStageAsync stage_wave_frames_async(const uint8_t* stream, uint64_t nbytes, uint64_t a, uint64_t b, bool live,
+                                                                  uint32_t* lds /* this wave's kStageBytes */) {
+  WaveStageAsync r;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t alive = __ballot(live);
+  uint64_t lo = 0, hi = 0, lo16 = 0, full = 0;  // wave-uniform
+  bool ok = alive != 0;
+  if (ok) {
+    lo = wave_bcast_u64(a, 0);
+    hi = wave_bcast_u64(b, 63 - __builtin_clzll(alive));
+    lo16 = lo & ~15ull;
+    ok = lo <= hi && hi <= nbytes && hi - lo16 + 16 <= kStageBytes;
+  }
+  if (ok) {
+    const uint64_t need = (hi - lo16 + 15) >> 4;  // quads that cover the run
+    if (lo16 + (need << 4) <= nbytes) {
+      full = need;
+    } else {  // the buffer ends inside the run's last quad
+      full = (hi - lo16) >> 4;
+      r.tail0 = lo16 + (full << 4);
+      r.tail_n = (uint32_t)(hi - r.tail0);
+      r.tail_at = (uint32_t)(full << 4);
+    }
+    r.st.words = lds;
+    r.st.lo16 = lo16;
+    r.st.lo = lo;
+    r.st.hi = hi;
+  }
+#if defined(RAFTQ_STAGE_FIXED)
+#pragma unroll
+  for (uint32_t c = 0; c < kStageChunks; ++c) {
+#else
+  const uint32_t chunks = (uint32_t)((full + 63) >> 6);  // wave-uniform: instructions of 64 quads; lanes past the run re-read its first quad
+  for (uint32_t c = 0; c < chunks; ++c) {
+#endif
+    const uint64_t q = (uint64_t)c * 64 + lane;
+    const uint8_t* g = stream + (q < full ? lo16 + (q << 4) : lo16);
+    __builtin_amdgcn_global_load_lds((global_cvoid_t*)g, (lds_void_t*)(reinterpret_cast<uint8_t*>(lds) + c * 1024), 16, 0, 0);
+  }
+  return r;
+}
+__device__ __forceinline__ void stage_tail(const WaveStageAsync& r, const uint8_t* stream, uint32_t* lds) {
+  const uint32_t lane = threadIdx.x & 63;
+  if (r.tail_n != 0 && lane < r.tail_n) reinterpret_cast<uint8_t*>(lds)[r.tail_at + lane] = stream[r.tail0 + lane];
+}
+
+// -DRAFTQ_WIRE_TRACE (measurement builds only): lane 0 of every tile leaves wall-clock stamps (100 MHz) of its phases in
+// the spare status array, raftq_wire.hip prints them after the call
+#if defined(RAFTQ_WIRE_TRACE)
+#define RAFTQ_TRACE_STAMP(ctl, tile, k) \
+  do { if (threadIdx.x == 0) (ctl).status[2][(uint64_t)(tile) * 8 + (k)] = wall_clock64(); } while (0)
+#define RAFTQ_ABLATE(ctl, bit) (((ctl).ablate >> (bit)) & 1u)
+#else
+#define RAFTQ_TRACE_STAMP(ctl, tile, k) do { } while (0)
+#define RAFTQ_ABLATE(ctl, bit) false
+#endif
+
+// raftq_wire_decode on page-locked buffers: everything in one launch (see above).  stream / off / msgs_h / ents_h are the
+// caller's buffers as the device addresses them.  pin[0] = entries found, pin[1] = malformed frames (written by the
+// workgroup of the last tile, whose inclusive sums are the totals).  A workgroup claims its next tile only when it is done
+// with the current one: claiming ahead and then waiting for that tile's window would keep the current tile's sums from
+// the tiles whose look-back needs them while they keep the window shut (a cycle; tests/test_wire_gpu.py drives grids of
+// 5 workgroups through 256 tiles).
+static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
+                                                                       const uint64_t* __restrict__ off, uint64_t n,
+                                                                       WireMsg* msgs_h, WireEnt* ents_h, uint64_t ents_cap,
+                                                                       TileCtl ctl, uint64_t* __restrict__ pin) {
+  __shared__ __attribute__((aligned(16))) uint64_t file[kFileSlots * kBlock];  // 34 KB; the records' way out afterwards (16 KB)
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
+  __shared__ __attribute__((aligned(16))) WireEnt ents_lds[kBlock * kEntQ];  // 32 KB: what a lane's frame carries, up to kEntQ headers
+  __shared__ uint64_t offs[kBlock + 1];
+  __shared__ uint64_t wave_tot[kWaves];
+  __shared__ uint64_t prefix[2];
+  __shared__ uint32_t wave_bad[kWaves];
+  __shared__ uint32_t tile_slot;
+  const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  for (;;) {
+    const uint32_t cur = next_tile(ctl, &tile_slot, n_tiles);
+    if (cur >= n_tiles) return;
+    RAFTQ_TRACE_STAMP(ctl, cur, 0);
+    const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
+    // the tile's 257 boundaries: one 8-byte load per lane (each 64-byte line of the caller's array crosses the link once)
+    if (i <= n) offs[tid] = __builtin_nontemporal_load(off + i);
+    if (tid == 0) {
+      const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
+      offs[kBlock] = __builtin_nontemporal_load(off + last);
+    }
+    __syncthreads();
+    RAFTQ_TRACE_STAMP(ctl, cur, 1);
+    const bool live = i < n;
+    const uint64_t a = live ? offs[tid] : 0, b = live ? offs[tid + 1] : 0;
+    const WaveStageAsync sa = stage_wave_frames_async(stream, nbytes, a, b, live, stage[wave]);
+    RAFTQ_TRACE_STAMP(ctl, cur, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tile_input_landed(ctl);  // the window of tile cur + window opens
+    RAFTQ_TRACE_STAMP(ctl, cur, 3);
+    stage_tail(sa, stream, stage[wave]);
+    WireMsg m;
+    bool malformed = false;
+    LdsFile f{file + tid};
+    ByteSrc src = {stream, 0, nullptr, 0};
+    WireEnt* my_ents = ents_lds + tid * kEntQ;
+    if (live) {
+      src = frame_src(sa.st, stream, nbytes, a, b);
+      bool ok = frame_body_staged(src, stream, nbytes, a, b, true);
+      // ONE walk: the first kEntQ entry headers of the frame are left in LDS on the way (a second walk cost every tile 11 us)
+      if (ok) ok = parse_msg<true>(src, b - a - 8, a + 8, f, m, my_ents, 0, kEntQ, 0xffffffffu);
+      if (!ok) {
+        m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
+        m.from = 0;
+        m.type = m.reject = m.to = 0;
+        m.ent_first = m.n_ents = 0;
+        m.flags = kWireMalformed;
+        malformed = true;
+      }
+    }
+    const uint32_t cnt = live ? m.n_ents : 0u;
+    const uint64_t mb = __ballot(malformed);
+    if ((tid & 63) == 0) wave_bad[wave] = (uint32_t)__popcll(mb);
+    uint64_t tile_ents;
+    const uint64_t local = block_exclusive_u32(cnt, wave_tot, &tile_ents);  // (its barrier publishes wave_bad too)
+    RAFTQ_TRACE_STAMP(ctl, cur, 4);
+    if (tid == 0) {
+      uint32_t tile_bad = 0;
+      for (int k = 0; k < kWaves; ++k) tile_bad += wave_bad[k];
+      const uint64_t pe = lb_exclusive(ctl.status[0], ctl.epoch, cur, tile_ents, ctl.ticket + 1);
+      const uint64_t pb = lb_exclusive(ctl.status[1], ctl.epoch, cur, tile_bad, ctl.ticket + 1);
+      prefix[0] = pe;
+      if (cur == n_tiles - 1) {
+        pin[0] = pe + tile_ents;
+        pin[1] = pb + tile_bad;
+        pin[3] = ctl.ticket[1];  // (a give-up in a later-finishing workgroup of an earlier tile shows in the next call at the latest)
+      }
+    }
+    __syncthreads();
+    RAFTQ_TRACE_STAMP(ctl, cur, 5);
+    const uint64_t first = prefix[0] + local;
+    if (cnt != 0) m.ent_first = (uint32_t)first;
+    if (cnt > kEntQ && ents_h != nullptr) {  // a frame with more entries than a lane keeps: walked again, headers straight out
+      WireMsg again;
+      (void)parse_msg<true>(src, b - a - 8, a + 8, f, again, ents_h, first, ents_cap, cnt);
+    }
+    // The tile's entry headers are one contiguous run of the caller's array: gathered in LDS (the frames' stage is free now)
+    // and pushed out like the records, whole 64-byte lines -- 32-byte stores lane by lane cost the link two small
+    // transactions per entry.  A tile with more headers than the stage holds writes them lane by lane.
+    constexpr uint32_t kEntStage = kWaves * kStageBytes / sizeof(WireEnt);  // 1,024
+    WireEnt* ent_run = reinterpret_cast<WireEnt*>(&stage[0][0]);
+    const bool run_staged = tile_ents <= kEntStage;
+    const bool mine_kept = cnt != 0 && cnt <= kEntQ && ents_h != nullptr;
+    __syncthreads();  // nobody files fields or reads frames any more: `file` carries the records out, `stage` the headers
+    if (mine_kept && run_staged) {
+#pragma unroll
+      for (uint32_t k = 0; k < kEntQ; ++k)
+        if (k < cnt) ent_run[local + k] = my_ents[k];
+    }
+    tile_records_out(m, live && !RAFTQ_ABLATE(ctl, 0), reinterpret_cast<u32x4*>(file), RAFTQ_ABLATE(ctl, 0) ? msgs_h - tile0 : msgs_h, tile0,
+                     RAFTQ_ABLATE(ctl, 0) ? tile0 + 1 : n);  // (its barrier publishes ent_run too)
+    RAFTQ_TRACE_STAMP(ctl, cur, 6);
+    if (ents_h != nullptr && tile_ents != 0 && !RAFTQ_ABLATE(ctl, 1)) {
+      const uint64_t run0 = prefix[0];
+      if (run_staged) {
+        // (frames with more than kEntQ entries wrote theirs straight out above; their slots of the run hold stale bytes,
+        // so the run is only pushed whole when no lane of the tile walked twice -- wave-uniform via the block vote)
+        const bool clean = __syncthreads_and(cnt <= kEntQ);
+        if (clean) {
+          const uint64_t room = run0 < ents_cap ? ents_cap - run0 : 0;
+          const uint32_t quads = (uint32_t)(tile_ents < room ? tile_ents : room) * 2;
+          const u32x4* src_q = reinterpret_cast<const u32x4*>(ent_run);
+          u32x4* dst = reinterpret_cast<u32x4*>(ents_h + run0);
+          for (uint32_t q = tid; q < quads; q += kBlock) __builtin_nontemporal_store(src_q[q], dst + q);
+        } else if (mine_kept) {
+          for (uint32_t k = 0; k < cnt; ++k)
+            if (first + k < ents_cap) ents_h[first + k] = my_ents[k];
+        }
+      } else if (mine_kept) {
+        for (uint32_t k = 0; k < cnt; ++k)
+          if (first + k < ents_cap) ents_h[first + k] = my_ents[k];
+      }
+    }
+    RAFTQ_TRACE_STAMP(ctl, cur, 7);
+  }
+}
+
 // ---- kernels: walpb.Record ---------------------------------------------------------------------------
 
 __device__ __forceinline__ bool wal_has_payload(uint8_t kind) { return kind == kWalEntry || kind == kWalMetadata; }

@@ -160,6 +160,36 @@ def test_set_equals_one_launch_per_handle(gpu_engine_cls):
         e.close()
 
 
+def test_many_launches_on_a_shared_stream_alternate_and_stay_ordered(gpu_engine_cls, oracle):
+    """raftq_sweep_many_async over the members of a set (ONE shared stream): every other launch goes to an auxiliary
+    stream, forked and joined inside the call.  Same words as the oracle; work enqueued on the shared stream before
+    (deltas) and after (a set dispatch, reads) stays ordered around it; the same handle twice is not alternated."""
+    sts, es = _members(gpu_engine_cls, 30000, 5, 7, 9100)
+    flags = SWEEP_COMMIT | SWEEP_VOTES | SWEEP_STREAM
+    with SweepSet(es) as s:
+        g = np.arange(500, dtype=np.uint64)
+        top = sts[4].committed[:500] + np.uint64(1 << 41)
+        for p in range(5):
+            es[4].apply_deltas(g, np.full(500, p, np.uint32), top)  # on the shared stream, in front of the launches
+        sts[4].match[:, :500] = np.maximum(sts[4].match[:, :500], top)
+        for rep in range(3):
+            sweep_many_async(es, flags | SWEEP_NO_ADOPT)
+        sweep_many_async(es, flags)  # adopted: the next sweep reads what this one wrote
+        for st, e in zip(sts, es):
+            ung, n_ung = oracle.commit_advance(st.match, st.committed)
+            oc, w, l = oracle.vote_tally(st.votes)
+            c = e.wait(want_counts=True)
+            assert (c.n_changed, c.n_won, c.n_lost) == (n_ung, w, l)
+            assert np.array_equal(e.read_committed(), ung) and np.array_equal(e.read_outcome(), oc)
+        assert np.array_equal(es[4].read_committed()[:500], top)
+        per, tot = s.sweep(SWEEP_COMMIT)  # behind the join: nothing left to advance
+        assert tot.n_changed == 0
+        sweep_many_async([es[0]] * 6 + [es[1]], SWEEP_COMMIT)  # a repeated handle: a chain, launched in order on the one stream
+        assert es[0].wait(want_counts=True).n_changed == 0
+    for e in es:
+        e.close()
+
+
 def test_set_full_size_headline_config(gpu_engine_cls, oracle):
     """BASELINE config 3 at full size, four 1M x 5 members in one dispatch, both launch shapes."""
     G, n, K = 1 << 20, 5, 4

@@ -353,6 +353,34 @@ def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypat
             assert (gnv, gl) == (wnv, wl) and gr.tobytes() == wr.tobytes()
 
 
+@pytest.mark.parametrize("wgs", [5, 64, 160, 1024])
+def test_streaming_decode_at_bench_size(wgs, monkeypatch):
+    """The one-kernel form of raftq_wire_decode (page-locked buffers) at the bench's size -- 65,536 frames, a MsgApp share with
+    entries, some damaged frames -- with few workgroups walking many tiles each (every one a tile ahead of itself), the
+    default grid, and more workgroups than tiles: records, entry headers and counts are the oracle's whatever the grid."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
+    rng = np.random.default_rng(1900 + wgs)
+    n = 65536
+    m, e, pool = _wiregen.random_msgs(rng, n, big_every=0, ent_frac=0.15)
+    s, off = W.wire_encode(m, e, pool)
+    for k in rng.integers(0, n, 300):
+        s[int(off[k]) + 8 + int(rng.integers(0, 6))] ^= 0x5B
+    wm, we, wbad = W.wire_decode(s, off)
+    assert wbad > 0 and len(we) > 1000
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        ps, po = pinned_copy(s), pinned_copy(off)
+        dm, de = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+        for rep in range(4):  # consecutive calls share the control block: tickets and epochs carry over
+            dm[:] = np.zeros(1, W.WIRE_MSG_DT)[0]
+            gm, ge, gbad = eng.wire_decode(ps, po, msgs=dm, ents=de)
+            assert gbad == wbad
+            _same(gm, wm, "msgs")
+            _same(ge, we, "ents")
+
+
 def _wiregen_u8(pool):
     return np.ascontiguousarray(np.frombuffer(bytes(pool), np.uint8) if not isinstance(pool, np.ndarray) else pool.view(np.uint8))
 

@@ -173,7 +173,7 @@ struct raftq {
   // the streaming codec kernels (raftq_wire_kernels.hpp "the streaming form"): ticket word + per-tile look-back status
   unsigned long long* wire_lb = nullptr;     // device: kLbHead words {ticket, gave-up flag, landed waves, -}, then kLbArrays status arrays of wire_lb_tiles words
   uint64_t wire_lb_tiles = 0;
-  uint32_t wire_ticket_base = 0, wire_arrived_base = 0, wire_epoch = 0;
+  uint32_t wire_ticket_base = 0, wire_epoch = 0;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};

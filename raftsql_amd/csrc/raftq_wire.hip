@@ -73,11 +73,8 @@ void* dev_view(const void* p) {
   return d;
 }
 bool kernel_copies() {  // RAFTQ_WIRE_KERNEL_COPIES=0: the runtime's copies even for page-locked buffers (round 2's form; for A/B)
-  static const bool on = [] {
-    const char* e = std::getenv("RAFTQ_WIRE_KERNEL_COPIES");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+  const char* e = std::getenv("RAFTQ_WIRE_KERNEL_COPIES");  // (read per call: the tests switch forms inside one process)
+  return !(e && e[0] == '0');
 }
 unsigned copy_blocks(uint64_t bytes) { return (unsigned)std::min<uint64_t>(kCopyBlocks, std::max<uint64_t>(1, (bytes / 16 + kBlock - 1) / kBlock)); }
 
@@ -92,31 +89,61 @@ unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / k
 
 // ---- the streaming form (one persistent kernel per call; raftq_wire_kernels.hpp) -----------------------------------
 bool fused_on() {  // RAFTQ_WIRE_FUSED=0: round 3's chain of copy-in / compute / copy-out kernels (for A/B)
-  static const bool on = [] {
-    const char* e = std::getenv("RAFTQ_WIRE_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+  const char* e = std::getenv("RAFTQ_WIRE_FUSED");
+  return !(e && e[0] == '0');
 }
-// Workgroups of a streaming kernel.  Few pull host memory faster than many (48 blocks: 55 GB/s, 768: 42,
-// profiles/r04/pcie_duplex_probe.jsonl) but every tile is three PCIe round trips deep, so enough of them must be in
-// flight to keep both directions busy: RAFTQ_WIRE_WGS overrides.
+// Worker workgroups of a streaming kernel (RAFTQ_WIRE_WGS overrides): a tile is ~25 us of dependent work (flags, scratch
+// reads, the parse at one wave per SIMD, the look-back), the link moves a tile every ~0.3 us.
 unsigned fused_grid(uint32_t n_tiles) {
   const char* e = std::getenv("RAFTQ_WIRE_WGS");  // read per call: the tests drive tiny grids through one process
   const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return std::min<unsigned>(v > 0 && v <= 4096 ? (unsigned)v : 256u, n_tiles);
+  return std::min<unsigned>(v > 0 && v <= 4096 ? (unsigned)v : 208u, n_tiles);
 }
 
 constexpr uint64_t kLbHead = 4;  // words in front of the status arrays
-// tiles whose input may be in flight at once (TileCtl::window; RAFTQ_WIRE_WINDOW overrides)
-uint32_t fused_window() {
-  const char* e = std::getenv("RAFTQ_WIRE_WINDOW");
+// reader workgroups of a streaming kernel (RAFTQ_WIRE_READERS overrides): 48 pull a caller's array at 55 GB/s, more are slower
+unsigned fused_readers(uint32_t chunks) {
+  const char* e = std::getenv("RAFTQ_WIRE_READERS");
   const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return v > 0 ? (uint32_t)v : 64u;
+  return std::min<unsigned>(v > 0 && v <= 1024 ? (unsigned)v : 48u, chunks);
 }
+// bytes of all arrays together that a reader brings in before it raises a flag (RAFTQ_WIRE_CHUNK overrides)
+uint64_t feed_chunk() {
+  const char* e = std::getenv("RAFTQ_WIRE_CHUNK");
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return v >= 1024 && v <= (1 << 20) ? (uint64_t)v : 8192;
+}
+
+// The readers' plan for up to three caller arrays (device views `src`, all 16-byte aligned): where they go in the scratch
+// (carved behind `c`), how many chunks, how many bytes of every array per chunk.  max_chunks: flags available.
+struct FeedPlan {
+  InFeed in;
+  size_t off[3];
+};
+FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3], uint64_t max_chunks) {
+  FeedPlan p{};
+  uint64_t total = 0;
+  for (int k = 0; k < 3; ++k) total += bytes[k];
+  const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(max_chunks, (total + feed_chunk() - 1) / feed_chunk()));
+  for (int k = 0; k < 3; ++k) {
+    p.off[k] = c.take(bytes[k]);
+    p.in.seg[k].src = (const uint8_t*)src[k];
+    p.in.seg[k].bytes = bytes[k];
+    p.in.seg[k].per_chunk = std::max<uint64_t>(256, ((bytes[k] + chunks - 1) / chunks + 255) / 256 * 256);
+  }
+  p.in.chunks = (uint32_t)chunks;
+  p.in.readers = fused_readers(p.in.chunks);
+  return p;
+}
+void bind_feed(FeedPlan& p, uint8_t* base, unsigned long long* flags) {
+  for (int k = 0; k < 3; ++k) p.in.seg[k].dst = base + p.off[k];
+  p.in.flag = flags;
+}
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 // ticket word + status arrays for a call of n_tiles tiles; a new call is a new epoch (the words of older calls read as
 // "not published yet"), the arrays are zeroed when they are (re)allocated and when the 16-bit epoch wraps
-int tile_ctl(raftq_t* h, uint32_t n_tiles, TileCtl* ctl) {
+int tile_ctl(raftq_t* h, uint64_t n_tiles, TileCtl* ctl) {
   if (n_tiles > h->wire_lb_tiles) {
     if (h->wire_lb) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -128,7 +155,7 @@ int tile_ctl(raftq_t* h, uint32_t n_tiles, TileCtl* ctl) {
     HIPCHK(h, hipMalloc((void**)&h->wire_lb, (kLbHead + kLbArrays * tiles) * 8));
     HIPCHK(h, hipMemsetAsync(h->wire_lb, 0, (kLbHead + kLbArrays * tiles) * 8, h->stream));
     h->wire_lb_tiles = tiles;
-    h->wire_ticket_base = h->wire_arrived_base = 0;
+    h->wire_ticket_base = 0;
     h->wire_epoch = 0;
   }
   if (++h->wire_epoch > 0xffffu) {
@@ -137,8 +164,6 @@ int tile_ctl(raftq_t* h, uint32_t n_tiles, TileCtl* ctl) {
   }
   ctl->ticket = reinterpret_cast<unsigned int*>(h->wire_lb);
   ctl->ticket_base = h->wire_ticket_base;
-  ctl->arrived_base = h->wire_arrived_base;
-  ctl->window = fused_window();
   ctl->ablate = 0;
 #if defined(RAFTQ_WIRE_TRACE)
   if (const char* e = std::getenv("RAFTQ_WIRE_ABLATE")) ctl->ablate = (uint32_t)std::strtol(e, nullptr, 10);
@@ -147,11 +172,8 @@ int tile_ctl(raftq_t* h, uint32_t n_tiles, TileCtl* ctl) {
   for (int k = 0; k < kLbArrays; ++k) ctl->status[k] = h->wire_lb + kLbHead + (uint64_t)k * h->wire_lb_tiles;
   return RAFTQ_OK;
 }
-// every workgroup of a launch draws exactly one ticket beyond the tiles; every wave of every tile reports its input once
-void tile_ctl_launched(raftq_t* h, uint32_t n_tiles, unsigned grid) {
-  h->wire_ticket_base += n_tiles + grid;
-  h->wire_arrived_base += n_tiles * (uint32_t)kWaves;
-}
+// every worker of a launch draws exactly one ticket beyond the tiles
+void tile_ctl_launched(raftq_t* h, uint32_t n_tiles, unsigned workers) { h->wire_ticket_base += n_tiles + workers; }
 #if defined(RAFTQ_WIRE_TRACE)
 // RAFTQ_TRACE_STAMP's rows of the call just waited for -> stderr (once every 16th call): per tile, microseconds since the
 // earliest stamp of the launch
@@ -160,7 +182,7 @@ void trace_dump(raftq_t* h, const char* what, uint32_t n_tiles) {
   static const bool dump = std::getenv("RAFTQ_WIRE_TRACE_DUMP") != nullptr;
   if (!dump || (calls++ & 15) != 15 || n_tiles * 8ull > h->wire_lb_tiles) return;
   std::vector<unsigned long long> t(n_tiles * 8ull);
-  if (hipMemcpy(t.data(), h->wire_lb + kLbHead + 2 * h->wire_lb_tiles, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  if (hipMemcpy(t.data(), h->wire_lb + kLbHead + kLbSpare * h->wire_lb_tiles, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
   unsigned long long t0 = ~0ull;
   for (uint32_t i = 0; i < n_tiles; ++i) t0 = std::min(t0, t[i * 8ull]);
   std::fprintf(stderr, "[trace %s] tile: claimed offs_in dma_issued frames_in parsed lookback ents_out recs_out (us)\n", what);
@@ -266,6 +288,38 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_msgs = dev_view(msgs)) != nullptr &&
                       (n_ents == 0 || (v_ents = dev_view(ents)) != nullptr) && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
                       (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
+  if (mapped && fused_on() && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool)) {
+    // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
+    const uint32_t n_tiles = blocks_for(n);
+    const unsigned workers = fused_grid(n_tiles);
+    Carver fc;
+    const void* const src[3] = {v_msgs, v_ents, v_pool};
+    const uint64_t sizes[3] = {n * sizeof(WireMsg), n_ents * sizeof(WireEnt), pool_bytes};
+    TileCtl ctl;
+    if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1] + sizes[2]) / feed_chunk() + 1), &ctl)) return rc;
+    FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
+    if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
+    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+    hipLaunchKernelGGL(wire_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, n_ents, pool_bytes,
+                       (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
+    HIPCHK(h, hipGetLastError());
+    tile_ctl_launched(h, n_tiles, workers);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (int rc = tile_ctl_check(h, "raftq_wire_encode")) return rc;
+    const uint64_t total = h->wire_pin[0];
+    if (h->wire_pin[1])
+      return fail(h, RAFTQ_EINVAL,
+                  "raftq_wire_encode: a message has to / from >= 255, an entry range outside ents[], or a payload outside "
+                  "the pool; the output is not valid");
+    if (counts) {
+      counts->n_msgs = n;
+      counts->n_ents = n_ents;
+      counts->bytes = total;
+    }
+    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: out is too small (counts->bytes is the size needed)");
+    return RAFTQ_OK;
+  }
   if (mapped) {
     if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
     uint8_t* d_out = (uint8_t*)h->wire_out;
@@ -350,16 +404,23 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
   const bool mapped = kernel_copies() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
                       (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
-  if (mapped && fused_on() && nbytes >= 16 && nbytes < (1ull << (kLbValueBits - 1)) && ((uintptr_t)v_stream & 15) == 0) {
-    // page-locked caller buffers: ONE persistent kernel pulls, parses and pushes tile by tile -- no device copy of anything
+  if (mapped && fused_on() && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
+    // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
+    // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
     const uint32_t n_tiles = blocks_for(n);
-    const unsigned grid = fused_grid(n_tiles);
+    const unsigned workers = fused_grid(n_tiles);
+    Carver c;
+    const void* const src[3] = {v_off, v_stream, nullptr};
+    const uint64_t bytes[3] = {(n + 1) * 8, nbytes, 0};
     TileCtl ctl;
-    if (int rc = tile_ctl(h, n_tiles, &ctl)) return rc;
-    hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(grid), dim3(kBlock), 0, h->stream, (const uint8_t*)v_stream, nbytes,
-                       (const uint64_t*)v_off, n, (WireMsg*)v_msgs, (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d);
+    if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (bytes[0] + bytes[1]) / feed_chunk() + 1), &ctl)) return rc;
+    FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles);
+    if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+    hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
+                       (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d);
     HIPCHK(h, hipGetLastError());
-    tile_ctl_launched(h, n_tiles, grid);
+    tile_ctl_launched(h, n_tiles, workers);
     HIPCHK(h, hipStreamSynchronize(h->stream));
 #if defined(RAFTQ_WIRE_TRACE)
     trace_dump(h, "wire_dec", n_tiles);
@@ -475,6 +536,39 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr &&
                       (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) && (v_out = dev_view(out)) != nullptr &&
                       (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
+  if (mapped && fused_on() && aligned16(v_recs) && aligned16(v_pool)) {
+    // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
+    const uint32_t n_tiles = blocks_for(n);
+    const unsigned workers = fused_grid(n_tiles);
+    Carver fc;
+    const void* const src[3] = {v_recs, v_pool, nullptr};
+    const uint64_t sizes[3] = {n * sizeof(WalRec), pool_bytes, 0};
+    TileCtl ctl;
+    if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
+    FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
+    if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
+    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+    hipLaunchKernelGGL(wal_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, pool_bytes, prev_crc,
+                       (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
+    HIPCHK(h, hipGetLastError());
+    tile_ctl_launched(h, n_tiles, workers);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (int rc = tile_ctl_check(h, "raftq_wal_encode")) return rc;
+    const uint64_t total = h->wire_pin[0];
+    if (h->wire_pin[1])
+      return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: a record has an unknown kind or a payload outside the pool; the output is not valid");
+    if (counts) {
+      counts->n_recs = n;
+      counts->bytes = total;
+    }
+    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
+    if (counts) {
+      counts->n_valid = n;
+      counts->last_crc = (uint32_t)h->wire_pin[2];
+    }
+    return RAFTQ_OK;
+  }
   unsigned int* d_bad = mapped ? (unsigned int*)(h->wire_flags + 2) : (unsigned int*)(base + o_flags);
   if (mapped) {
     const CopySegs in = {{{v_recs, d_recs, n * sizeof(WalRec)}, {v_pool, d_pool, pool_bytes}, {nullptr, nullptr, 0}}};
@@ -565,6 +659,36 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   if ((!bytes && nbytes) || !frame_off || !recs) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_decode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
+  {
+    void *f_bytes = nullptr, *f_off = nullptr, *f_recs = nullptr;
+    if (kernel_copies() && fused_on() && nbytes < (1ull << (kLbValueBits - 1)) && (nbytes == 0 || (f_bytes = dev_view(bytes)) != nullptr) &&
+        (f_off = dev_view(frame_off)) != nullptr && (f_recs = dev_view(recs)) != nullptr && aligned16(f_bytes) && aligned16(f_off)) {
+      // page-locked caller buffers: the streaming form (readers | workers in one launch)
+      const uint32_t n_tiles = blocks_for(n);
+      const unsigned workers = fused_grid(n_tiles);
+      Carver c;
+      const void* const src[3] = {f_off, f_bytes, nullptr};
+      const uint64_t sizes[3] = {(n + 1) * 8, nbytes, 0};
+      TileCtl ctl;
+      if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
+      FeedPlan plan = plan_feed(c, src, sizes, h->wire_lb_tiles);
+      if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+      bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+      hipLaunchKernelGGL(wal_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, prev_crc,
+                         (WalRec*)f_recs, ctl, h->wire_pin_d);
+      HIPCHK(h, hipGetLastError());
+      tile_ctl_launched(h, n_tiles, workers);
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (int rc = tile_ctl_check(h, "raftq_wal_decode")) return rc;
+      if (counts) {
+        counts->n_recs = n;
+        counts->n_valid = h->wire_pin[0];
+        counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+        counts->last_crc = (uint32_t)h->wire_pin[1];
+      }
+      return RAFTQ_OK;
+    }
+  }
   Carver c;
   const size_t o_bytes = c.take(nbytes), o_off = c.take((n + 1) * 8), o_recs = c.take(n * sizeof(WalRec)),
                o_span = c.take(n * sizeof(WalSpan)), o_pair = c.take(n * 8), o_chain = c.take(n * 8),

@@ -733,28 +733,32 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
 
 // ---- the streaming form of a codec call (round 4) --------------------------------------------------------------------
 // On page-locked caller buffers round 3's call was copy-in kernel -> 3-5 small kernels -> copy-out kernel: the link's two
-// directions never worked at the same time (245 us to decode 64K frames whose inbound and outbound bytes are 55 + 88 us
-// apart).  The probe (profiles/r04/pcie_duplex_probe.jsonl) says what the link takes: workgroups pull host memory at
-// 42-55 GB/s and push at 55, and ONE kernel whose workgroups do both moves 41 GB/s each way at once -- while two kernels
-// on two streams do not overlap at all when one of them writes host memory (the round-1 finding still holds on ROCm 7.2).
-// So a call is now ONE persistent kernel and the device never holds a copy of its inputs or outputs: a workgroup takes
-// the next tile of 256 frames (a ticket), pulls the tile's boundaries and its contiguous run of stream bytes over PCIe
-// straight into LDS, parses there, learns where its entry headers go from a decoupled look-back over the tiles before it
-// (one 64-bit status word per tile: epoch | flag | value, relaxed agent-scope atomics -- value and flag travel together,
-// no fence), and pushes its records -- staged in LDS, so that every store instruction writes 4 KB of consecutive host
-// memory -- and entry headers out.  Workgroups are at different points of that cycle at any moment: some pull while
-// others push.  Tickets (not blockIdx) order the tiles, so a tile is only ever waited for after a running workgroup
-// has claimed it: the look-back cannot deadlock however few workgroups are resident.
+// directions never worked at the same time (245 us to decode 64K frames whose inbound and outbound bytes are 57 + 89 us
+// apart).  What the link takes (profiles/r04/pcie_duplex_probe.jsonl): a FEW workgroups walking host memory in order pull
+// 55 GB/s, many workgroups each pulling a piece of their own 42; workgroups push 55; ONE kernel whose workgroups do both
+// moves 38-41 GB/s each way at once; two kernels on two streams do not overlap at all when one of them writes host memory
+// (the round-1 finding still holds on ROCm 7.2).  So a call is ONE kernel with two roles:
+//   readers  the first few workgroups copy the caller's input arrays, chunk by chunk and in order, into device scratch
+//            (agent-scope write-through stores) and raise a per-chunk flag -- they depend on nothing;
+//   workers  the others take tiles of 256 frames / records by ticket, wait for the chunks that hold the tile's input,
+//            stage it in LDS (DMA from the scratch), parse, learn where their output goes from a decoupled look-back over
+//            the tiles before them (one 64-bit status word per tile: epoch | flag | value, relaxed agent-scope atomics --
+//            value and flag travel together, no fence), and push their records out through LDS, 4 KB of consecutive host
+//            memory per store instruction.
+// The first tile's records leave ~25 us into the call and from then on both directions are busy.  (A first form had every
+// worker pull its own tile's bytes straight from the host, with a window on how many tiles might have pulls in flight:
+// 166-211 us for 64K frames depending on the box -- the many-reader pattern -- against this form's ... us.)
+// Tickets (not blockIdx) order the tiles, and readers are the launch's first workgroups: whatever a worker waits for has
+// been claimed by a running workgroup, so nothing deadlocks however few workgroups are resident.
 constexpr int kLbValueBits = 46, kLbFlagShift = 46, kLbEpochShift = 48;
-constexpr int kLbArrays = 4;
+constexpr int kLbArrays = 6;  // [0..3] running sums of a kernel, [4] spare (measurement builds: phase stamps), [5] the readers' chunk flags
+constexpr int kLbFlags = 5, kLbSpare = 4;
 constexpr uint64_t kLbValueMask = (1ull << kLbValueBits) - 1;
 constexpr uint32_t kLbAggregate = 1, kLbInclusive = 2;
 
 struct TileCtl {
-  unsigned int* ticket;            // monotonic across calls: tile = ticket - ticket_base; ticket[1] = "a wait gave up";
-                                   // ticket[2] = waves whose input has landed (monotonic: minus arrived_base)
-  uint32_t ticket_base, arrived_base;
-  uint32_t window;                 // tiles whose input may be in flight at once (see next_tile)
+  unsigned int* ticket;            // monotonic across calls: tile = ticket - ticket_base; ticket[1] = "a wait gave up"
+  uint32_t ticket_base;
   uint32_t epoch;                  // 1 .. 0xffff: status words of older calls read as "not yet"
   uint32_t ablate;                 // measurement builds (RAFTQ_WIRE_TRACE) only: bit 0 = records stay, bit 1 = entry headers stay
   unsigned long long* status[kLbArrays];  // [n_tiles] each: independent running sums (a kernel uses the first two or three)
@@ -793,34 +797,77 @@ __device__ inline uint64_t lb_exclusive(unsigned long long* status, uint32_t epo
   return prefix;
 }
 
-// A workgroup's tile: the next ticket (wave-uniform result through LDS).  The input of tile t is only asked for once the
-// input of tile t - window has landed: with every tile's pulls in flight at once the link serves them all at the same pace
-// and the FIRST tile's frames arrive when the last one's do -- nothing can leave before everything has come in, the two
-// directions take turns (profiles/r04/wire_dec_trace_*.txt).  Inside the window the early tiles get the link to
-// themselves, complete in order, and their records are on the way out while later tiles' frames are still coming in.
-__device__ __forceinline__ uint32_t next_tile(const TileCtl& ctl, uint32_t* slot /*LDS*/, uint32_t n_tiles) {
+// A worker's tile: the next ticket (wave-uniform result through LDS).
+__device__ __forceinline__ uint32_t next_tile(const TileCtl& ctl, uint32_t* slot /*LDS*/) {
   __syncthreads();  // the previous tile's readers of *slot (and of every other LDS array of the loop) are done
-  if (threadIdx.x == 0) {
-    const uint32_t tile = atomicAdd(ctl.ticket, 1u) - ctl.ticket_base;
-    if (tile < n_tiles && tile >= ctl.window) {
-      const uint32_t need = (tile - ctl.window + 1) * (uint32_t)kWaves;
-      uint32_t spin = 0;
-      while (__hip_atomic_load(ctl.ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ctl.arrived_base < need) {
-        if (++spin > (1u << 23)) {
-          atomicOr(ctl.ticket + 1, 1u);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    *slot = tile;
-  }
+  if (threadIdx.x == 0) *slot = atomicAdd(ctl.ticket, 1u) - ctl.ticket_base;
   __syncthreads();
   return *slot;
 }
-// a wave's input has landed (one lane says so)
-__device__ __forceinline__ void tile_input_landed(const TileCtl& ctl) {
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctl.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+// ---- readers: the caller's input arrays -> device scratch, in order -------------------------------------------------------
+// Up to three arrays travel together: chunk c of the call is bytes [c * per_chunk, (c + 1) * per_chunk) of EVERY array
+// (per_chunk = the array's size / chunks, rounded up to 256 bytes: a chunk boundary is a cache-line boundary of the
+// scratch, so no line of it is ever read before it is final), so that arrays consumed side by side -- frame boundaries and
+// frames, records and payload pool -- arrive side by side.  flag[c] = this call's epoch once chunk c is in the scratch.
+struct FeedSeg {
+  const uint8_t* src;   // the caller's array as the device addresses it (16-byte aligned)
+  uint8_t* dst;         // scratch (256-byte aligned, 16 bytes of slack behind it)
+  uint64_t bytes, per_chunk;
+};
+struct InFeed {
+  FeedSeg seg[3];
+  unsigned long long* flag;  // [chunks]
+  uint32_t chunks, readers;  // workgroups [0, readers) of the launch are readers
+};
+
+__device__ __forceinline__ void sc1_store16(uint8_t* dst, u32x4 v) {  // agent-scope write-through (two 8-byte atomic stores)
+  unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline void reader_role(const InFeed& in, uint32_t epoch) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t c = blockIdx.x; c < in.chunks; c += in.readers) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const FeedSeg sg = in.seg[k];
+      const uint64_t lo = (uint64_t)c * sg.per_chunk;
+      if (sg.bytes == 0 || lo >= sg.bytes) continue;
+      const uint64_t len = sg.bytes - lo < sg.per_chunk ? sg.bytes - lo : sg.per_chunk;
+      const u32x4* s16 = reinterpret_cast<const u32x4*>(sg.src + lo);
+      uint8_t* d = sg.dst + lo;
+      const uint64_t quads = len >> 4;
+      uint64_t q = tid;
+      for (; q + 3 * kBlock < quads; q += 4 * kBlock) {  // four pulls in flight per lane
+        const u32x4 v0 = __builtin_nontemporal_load(s16 + q), v1 = __builtin_nontemporal_load(s16 + q + kBlock),
+                    v2 = __builtin_nontemporal_load(s16 + q + 2 * kBlock), v3 = __builtin_nontemporal_load(s16 + q + 3 * kBlock);
+        sc1_store16(d + (q << 4), v0);
+        sc1_store16(d + ((q + kBlock) << 4), v1);
+        sc1_store16(d + ((q + 2 * kBlock) << 4), v2);
+        sc1_store16(d + ((q + 3 * kBlock) << 4), v3);
+      }
+      for (; q < quads; q += kBlock) sc1_store16(d + (q << 4), __builtin_nontemporal_load(s16 + q));
+      const uint64_t done = quads << 4;  // (only an array's last chunk has a tail)
+      if (tid < len - done) __hip_atomic_store(d + done + tid, sg.src[lo + done + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the coherence point ...
+    __syncthreads();                                   // ... and so have the other waves'
+    if (tid == 0) __hip_atomic_store(in.flag + c, lb_word(epoch, kLbInclusive, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ONE lane: bytes [lo, hi) of array k are in the scratch
+__device__ inline void feed_wait(const InFeed& in, uint32_t epoch, int k, uint64_t lo, uint64_t hi, unsigned int* stuck) {
+  if (hi <= lo) return;
+  const uint64_t per = in.seg[k].per_chunk;
+  uint32_t c1 = (uint32_t)((hi - 1) / per);
+  if (c1 >= in.chunks) c1 = in.chunks - 1;
+  for (uint32_t c = (uint32_t)(lo / per); c <= c1; ++c) (void)lb_wait(in.flag + c, epoch, stuck);
+}
+__device__ inline void feed_wait_all(const InFeed& in, uint32_t epoch, unsigned int* stuck) {
+  for (uint32_t c = 0; c < in.chunks; ++c) (void)lb_wait(in.flag + c, epoch, stuck);
 }
 
 // block-wide exclusive sum of one u32 per thread (kBlock threads) -> this thread's prefix; *total = the block's sum
@@ -868,123 +915,105 @@ __device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32
   }
 }
 
-// A wave's run of frames on its way into LDS with every request issued before the first one is waited for: global -> LDS
-// DMA (global_load_lds, 16 bytes per lane, 1 KB of consecutive stream per instruction, no VGPR round trip); the caller
-// waits with s_waitcnt vmcnt(0).  (stage_wave_frames' load -> store loop has one round trip per KB in flight.)
-// Needs a 16-byte aligned stream of at least 16 bytes (the caller checks: kernel-uniform).  The one run of a call that ends
-// in the buffer's last, partial quad brings those < 16 bytes in afterwards (stage_tail).
-constexpr uint32_t kStageChunks = kStageBytes / 1024;
+// A wave's run of frames on its way from the scratch into LDS with every request issued before the first one is waited
+// for: global -> LDS DMA (global_load_lds, 16 bytes per lane, 1 KB of consecutive stream per instruction, no VGPR round
+// trip, agent-scope so that no stale line of this XCD's L2 can answer); the caller waits with s_waitcnt vmcnt(0).
+// `readable`: bytes of the scratch copy that may be read (the stream rounded up to whole quads: the scratch has the slack).
+constexpr int kAuxSc1 = 16;  // cache-policy operand of the DMA builtin: sc1 (agent scope) on gfx94x / gfx950
 constexpr uint32_t kEntQ = 4;  // entry headers a lane keeps in LDS from its one walk of a frame (more: the frame is walked again)
-struct WaveStageAsync {
+__device__ __forceinline__ WaveStage stage_wave_frames_dma(const uint8_t* stream, uint64_t nbytes, uint64_t readable, uint64_t a, uint64_t b,
+                                                           bool live, uint32_t* lds /* this wave's kStageBytes */) {
   WaveStage st;
-  uint64_t tail0 = 0;   // stream offset of the bytes still to fetch
-  uint32_t tail_n = 0, tail_at = 0;  // how many, and where in the stage they go
-};
-__device__ __forceinline__ WaveStageAsync stage_wave_frames_async(const uint8_t* stream, uint64_t nbytes, uint64_t a, uint64_t b, bool live,
-                                                                  uint32_t* lds /* this wave's kStageBytes */) {
-  WaveStageAsync r;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t alive = __ballot(live);
-  uint64_t lo = 0, hi = 0, lo16 = 0, full = 0;  // wave-uniform
-  bool ok = alive != 0;
-  if (ok) {
-    lo = wave_bcast_u64(a, 0);
-    hi = wave_bcast_u64(b, 63 - __builtin_clzll(alive));
-    lo16 = lo & ~15ull;
-    ok = lo <= hi && hi <= nbytes && hi - lo16 + 16 <= kStageBytes;
-  }
-  if (ok) {
-    const uint64_t need = (hi - lo16 + 15) >> 4;  // quads that cover the run
-    if (lo16 + (need << 4) <= nbytes) {
-      full = need;
-    } else {  // the buffer ends inside the run's last quad
-      full = (hi - lo16) >> 4;
-      r.tail0 = lo16 + (full << 4);
-      r.tail_n = (uint32_t)(hi - r.tail0);
-      r.tail_at = (uint32_t)(full << 4);
-    }
-    r.st.words = lds;
-    r.st.lo16 = lo16;
-    r.st.lo = lo;
-    r.st.hi = hi;
-  }
-#if defined(RAFTQ_STAGE_FIXED)
-#pragma unroll
-  for (uint32_t c = 0; c < kStageChunks; ++c) {
-#else
-  const uint32_t chunks = (uint32_t)((full + 63) >> 6);  // wave-uniform: instructions of 64 quads; lanes past the run re-read its first quad
+  if (alive == 0) return st;
+  const uint64_t lo = wave_bcast_u64(a, 0);  // lane 0 is live whenever any lane is (lanes fill from the front)
+  const uint64_t hi = wave_bcast_u64(b, 63 - __builtin_clzll(alive));
+  const uint64_t lo16 = lo & ~15ull;
+  if (!(lo <= hi && hi <= nbytes) || hi - lo16 + 16 > kStageBytes) return st;  // wave-uniform
+  const uint64_t full = (hi - lo16 + 15) >> 4;  // quads that cover the run
+  if (lo16 + (full << 4) > readable) return st;
+  const uint32_t chunks = (uint32_t)((full + 63) >> 6);  // instructions of 64 quads; lanes past the run re-read its first quad
   for (uint32_t c = 0; c < chunks; ++c) {
-#endif
     const uint64_t q = (uint64_t)c * 64 + lane;
     const uint8_t* g = stream + (q < full ? lo16 + (q << 4) : lo16);
-    __builtin_amdgcn_global_load_lds((global_cvoid_t*)g, (lds_void_t*)(reinterpret_cast<uint8_t*>(lds) + c * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((global_cvoid_t*)g, (lds_void_t*)(reinterpret_cast<uint8_t*>(lds) + c * 1024), 16, 0, kAuxSc1);
   }
-  return r;
-}
-__device__ __forceinline__ void stage_tail(const WaveStageAsync& r, const uint8_t* stream, uint32_t* lds) {
-  const uint32_t lane = threadIdx.x & 63;
-  if (r.tail_n != 0 && lane < r.tail_n) reinterpret_cast<uint8_t*>(lds)[r.tail_at + lane] = stream[r.tail0 + lane];
+  st.words = lds;
+  st.lo16 = lo16;
+  st.lo = lo;
+  st.hi = hi;
+  return st;
 }
 
 // -DRAFTQ_WIRE_TRACE (measurement builds only): lane 0 of every tile leaves wall-clock stamps (100 MHz) of its phases in
-// the spare status array, raftq_wire.hip prints them after the call
+// the spare status array, raftq_wire.hip prints them after the call; RAFTQ_WIRE_ABLATE drops outputs
 #if defined(RAFTQ_WIRE_TRACE)
 #define RAFTQ_TRACE_STAMP(ctl, tile, k) \
-  do { if (threadIdx.x == 0) (ctl).status[2][(uint64_t)(tile) * 8 + (k)] = wall_clock64(); } while (0)
+  do { if (threadIdx.x == 0) (ctl).status[kLbSpare][(uint64_t)(tile) * 8 + (k)] = wall_clock64(); } while (0)
 #define RAFTQ_ABLATE(ctl, bit) (((ctl).ablate >> (bit)) & 1u)
 #else
 #define RAFTQ_TRACE_STAMP(ctl, tile, k) do { } while (0)
 #define RAFTQ_ABLATE(ctl, bit) false
 #endif
 
-// raftq_wire_decode on page-locked buffers: everything in one launch (see above).  stream / off / msgs_h / ents_h are the
-// caller's buffers as the device addresses them.  pin[0] = entries found, pin[1] = malformed frames (written by the
-// workgroup of the last tile, whose inclusive sums are the totals).  A workgroup claims its next tile only when it is done
-// with the current one: claiming ahead and then waiting for that tile's window would keep the current tile's sums from
-// the tiles whose look-back needs them while they keep the window shut (a cycle; tests/test_wire_gpu.py drives grids of
-// 5 workgroups through 256 tiles).
-static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(const uint8_t* __restrict__ stream, uint64_t nbytes,
-                                                                       const uint64_t* __restrict__ off, uint64_t n,
-                                                                       WireMsg* msgs_h, WireEnt* ents_h, uint64_t ents_cap,
-                                                                       TileCtl ctl, uint64_t* __restrict__ pin) {
+// raftq_wire_decode on page-locked buffers: everything in one launch (see above).  Readers bring the frame boundaries
+// (array 0) and the stream (array 1) into the scratch; msgs_h / ents_h are the caller's result arrays as the device
+// addresses them.  pin[0] = entries found, pin[1] = malformed frames (written by the worker of the last tile, whose
+// inclusive sums are the totals), pin[3] = a wait gave up.
+static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
+                                                                       uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin) {
+  if (blockIdx.x < in.readers) {
+    reader_role(in, ctl.epoch);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) uint64_t file[kFileSlots * kBlock];  // 34 KB; the records' way out afterwards (16 KB)
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];  // the frames; the entry headers' way out afterwards
   __shared__ __attribute__((aligned(16))) WireEnt ents_lds[kBlock * kEntQ];  // 32 KB: what a lane's frame carries, up to kEntQ headers
   __shared__ uint64_t offs[kBlock + 1];
   __shared__ uint64_t wave_tot[kWaves];
   __shared__ uint64_t prefix[2];
   __shared__ uint32_t wave_bad[kWaves];
   __shared__ uint32_t tile_slot;
+  const uint64_t* off = reinterpret_cast<const uint64_t*>(in.seg[0].dst);
+  const uint8_t* stream = in.seg[1].dst;
+  const uint64_t readable = (nbytes + 15) & ~15ull;
   const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  unsigned int* stuck = ctl.ticket + 1;
   for (;;) {
-    const uint32_t cur = next_tile(ctl, &tile_slot, n_tiles);
+    const uint32_t cur = next_tile(ctl, &tile_slot);
     if (cur >= n_tiles) return;
     RAFTQ_TRACE_STAMP(ctl, cur, 0);
     const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
-    // the tile's 257 boundaries: one 8-byte load per lane (each 64-byte line of the caller's array crosses the link once)
-    if (i <= n) offs[tid] = __builtin_nontemporal_load(off + i);
-    if (tid == 0) {
-      const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
-      offs[kBlock] = __builtin_nontemporal_load(off + last);
-    }
+    const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
+    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck);  // the tile's 257 boundaries are in the scratch
+    __syncthreads();
+    if (i <= n) offs[tid] = __hip_atomic_load(off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) offs[kBlock] = __hip_atomic_load(off + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     RAFTQ_TRACE_STAMP(ctl, cur, 1);
     const bool live = i < n;
     const uint64_t a = live ? offs[tid] : 0, b = live ? offs[tid + 1] : 0;
-    const WaveStageAsync sa = stage_wave_frames_async(stream, nbytes, a, b, live, stage[wave]);
+    // ... and so are its frames: [first boundary, last boundary) when the boundaries ascend inside the buffer, else (garbage
+    // boundaries: every lane may look anywhere) the whole stream
+    const bool ordered = __syncthreads_and(!live || (a <= b && b <= nbytes));
+    if (tid == 0) {
+      if (ordered) feed_wait(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck);
+      else feed_wait_all(in, ctl.epoch, stuck);
+    }
+    __syncthreads();
+    const WaveStage st = stage_wave_frames_dma(stream, nbytes, readable, a, b, live, stage[wave]);
     RAFTQ_TRACE_STAMP(ctl, cur, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tile_input_landed(ctl);  // the window of tile cur + window opens
     RAFTQ_TRACE_STAMP(ctl, cur, 3);
-    stage_tail(sa, stream, stage[wave]);
     WireMsg m;
     bool malformed = false;
     LdsFile f{file + tid};
     ByteSrc src = {stream, 0, nullptr, 0};
     WireEnt* my_ents = ents_lds + tid * kEntQ;
     if (live) {
-      src = frame_src(sa.st, stream, nbytes, a, b);
+      src = frame_src(st, stream, nbytes, a, b);
       bool ok = frame_body_staged(src, stream, nbytes, a, b, true);
       // ONE walk: the first kEntQ entry headers of the frame are left in LDS on the way (a second walk cost every tile 11 us)
       if (ok) ok = parse_msg<true>(src, b - a - 8, a + 8, f, m, my_ents, 0, kEntQ, 0xffffffffu);
@@ -1006,13 +1035,13 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(const uin
     if (tid == 0) {
       uint32_t tile_bad = 0;
       for (int k = 0; k < kWaves; ++k) tile_bad += wave_bad[k];
-      const uint64_t pe = lb_exclusive(ctl.status[0], ctl.epoch, cur, tile_ents, ctl.ticket + 1);
-      const uint64_t pb = lb_exclusive(ctl.status[1], ctl.epoch, cur, tile_bad, ctl.ticket + 1);
+      const uint64_t pe = lb_exclusive(ctl.status[0], ctl.epoch, cur, tile_ents, stuck);
+      const uint64_t pb = lb_exclusive(ctl.status[1], ctl.epoch, cur, tile_bad, stuck);
       prefix[0] = pe;
       if (cur == n_tiles - 1) {
         pin[0] = pe + tile_ents;
         pin[1] = pb + tile_bad;
-        pin[3] = ctl.ticket[1];  // (a give-up in a later-finishing workgroup of an earlier tile shows in the next call at the latest)
+        pin[3] = __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a give-up elsewhere after this shows in the next call at the latest)
       }
     }
     __syncthreads();
@@ -1024,13 +1053,12 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(const uin
       (void)parse_msg<true>(src, b - a - 8, a + 8, f, again, ents_h, first, ents_cap, cnt);
     }
     // The tile's entry headers are one contiguous run of the caller's array: gathered in LDS (the frames' stage is free now)
-    // and pushed out like the records, whole 64-byte lines -- 32-byte stores lane by lane cost the link two small
-    // transactions per entry.  A tile with more headers than the stage holds writes them lane by lane.
+    // and pushed out like the records, whole 64-byte lines.  A tile with more headers than the stage holds, or with a frame
+    // that was walked twice, writes them lane by lane.
     constexpr uint32_t kEntStage = kWaves * kStageBytes / sizeof(WireEnt);  // 1,024
     WireEnt* ent_run = reinterpret_cast<WireEnt*>(&stage[0][0]);
-    const bool run_staged = tile_ents <= kEntStage;
     const bool mine_kept = cnt != 0 && cnt <= kEntQ && ents_h != nullptr;
-    __syncthreads();  // nobody files fields or reads frames any more: `file` carries the records out, `stage` the headers
+    const bool run_staged = __syncthreads_and(cnt <= kEntQ) && tile_ents <= kEntStage;  // (the barrier: nobody files fields or reads frames any more)
     if (mine_kept && run_staged) {
 #pragma unroll
       for (uint32_t k = 0; k < kEntQ; ++k)
@@ -1042,19 +1070,11 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(const uin
     if (ents_h != nullptr && tile_ents != 0 && !RAFTQ_ABLATE(ctl, 1)) {
       const uint64_t run0 = prefix[0];
       if (run_staged) {
-        // (frames with more than kEntQ entries wrote theirs straight out above; their slots of the run hold stale bytes,
-        // so the run is only pushed whole when no lane of the tile walked twice -- wave-uniform via the block vote)
-        const bool clean = __syncthreads_and(cnt <= kEntQ);
-        if (clean) {
-          const uint64_t room = run0 < ents_cap ? ents_cap - run0 : 0;
-          const uint32_t quads = (uint32_t)(tile_ents < room ? tile_ents : room) * 2;
-          const u32x4* src_q = reinterpret_cast<const u32x4*>(ent_run);
-          u32x4* dst = reinterpret_cast<u32x4*>(ents_h + run0);
-          for (uint32_t q = tid; q < quads; q += kBlock) __builtin_nontemporal_store(src_q[q], dst + q);
-        } else if (mine_kept) {
-          for (uint32_t k = 0; k < cnt; ++k)
-            if (first + k < ents_cap) ents_h[first + k] = my_ents[k];
-        }
+        const uint64_t room = run0 < ents_cap ? ents_cap - run0 : 0;
+        const uint32_t quads = (uint32_t)(tile_ents < room ? tile_ents : room) * 2;
+        const u32x4* src_q = reinterpret_cast<const u32x4*>(ent_run);
+        u32x4* dst = reinterpret_cast<u32x4*>(ents_h + run0);
+        for (uint32_t q = tid; q < quads; q += kBlock) __builtin_nontemporal_store(src_q[q], dst + q);
       } else if (mine_kept) {
         for (uint32_t k = 0; k < cnt; ++k)
           if (first + k < ents_cap) ents_h[first + k] = my_ents[k];
@@ -1327,6 +1347,552 @@ static __global__ void wal_dec_tail_kernel(const CrcPair* __restrict__ chain, ui
   const uint64_t fb = *first_bad < n ? *first_bad : n;
   tail[0] = fb;
   tail[1] = fb == 0 ? prev_crc : chain[fb - 1].c;
+}
+
+// ---- the streaming form of the WAL codecs (see "the streaming form of a codec call") -------------------------------------
+
+// The running CRC across tiles: the look-back's value is an affine map (CrcPair: 64 bits), so a tile publishes it as two
+// status words (c and p, each with epoch and flag); a reader takes a pair only when both words carry the same flag -- a
+// tile writes each word at most twice (aggregate, then inclusive), so a torn read is seen and repeated.
+__device__ inline CrcPair lb_exclusive_crc(unsigned long long* st_c, unsigned long long* st_p, uint32_t epoch, uint32_t tile, CrcPair aggregate,
+                                           unsigned int* stuck) {
+  CrcCompose op;
+  auto put = [&](uint32_t flag, CrcPair v) {
+    __hip_atomic_store(st_c + tile, lb_word(epoch, flag, v.c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(st_p + tile, lb_word(epoch, flag, v.p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (tile == 0) {
+    put(kLbInclusive, aggregate);
+    return kCrcIdentity;
+  }
+  put(kLbAggregate, aggregate);
+  CrcPair prefix = kCrcIdentity;  // the composition of the tiles before `tile` seen so far (they come BEFORE what is in it)
+  for (uint32_t j = tile; j-- > 0;) {
+    uint64_t wc = 0, wp = 0;
+    for (uint32_t tries = 0; tries < (1u << 16); ++tries) {
+      wc = lb_wait(st_c + j, epoch, stuck);
+      wp = lb_wait(st_p + j, epoch, stuck);
+      if (((wc ^ wp) >> kLbFlagShift & 3u) == 0) break;
+    }
+    const CrcPair v = {(uint32_t)wc, (uint32_t)wp};
+    prefix = op(v, prefix);
+    if (((wc >> kLbFlagShift) & 3u) == kLbInclusive) break;
+  }
+  put(kLbInclusive, op(prefix, aggregate));
+  return prefix;
+}
+
+// the look-back for "index of the first bad record so far" (a running minimum; kLbValueMask = none)
+__device__ inline uint64_t lb_exclusive_min(unsigned long long* status, uint32_t epoch, uint32_t tile, uint64_t mine, unsigned int* stuck) {
+  if (tile == 0) {
+    __hip_atomic_store(status, lb_word(epoch, kLbInclusive, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return kLbValueMask;
+  }
+  __hip_atomic_store(status + tile, lb_word(epoch, kLbAggregate, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t before = kLbValueMask;
+  for (uint32_t j = tile; j-- > 0;) {
+    const uint64_t s = lb_wait(status + j, epoch, stuck);
+    const uint64_t v = s & kLbValueMask;
+    before = v < before ? v : before;
+    if (((s >> kLbFlagShift) & 3u) == kLbInclusive) break;
+  }
+  __hip_atomic_store(status + tile, lb_word(epoch, kLbInclusive, mine < before ? mine : before), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return before;
+}
+
+// raftq_wal_decode on page-locked buffers, one launch: readers bring the frame boundaries (array 0) and the WAL bytes
+// (array 1) into the scratch; a worker parses its tile's records from LDS, CRCs their Data (short spans in the lane, long
+// ones by the wave), chains the CRCs through the look-back, compares, and pushes the 48-byte records out.
+// pin[0] = records before the first bad one, pin[1] = the running CRC there, pin[3] = a wait gave up.
+static __global__ __launch_bounds__(kBlock) void wal_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, uint32_t prev_crc, WalRec* recs_h,
+                                                                      TileCtl ctl, uint64_t* __restrict__ pin) {
+  if (blockIdx.x < in.readers) {
+    reader_role(in, ctl.epoch);
+    return;
+  }
+  __shared__ uint32_t tab[kCrcTabs * 256];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];  // the frames; the records' way out afterwards (12 KB)
+  __shared__ uint64_t offs[kBlock + 1];
+  __shared__ uint32_t chain_of[kBlock];
+  __shared__ CrcPair wave_tot[kWaves];
+  __shared__ CrcPair tile_pre;
+  __shared__ unsigned long long wave_min[kWaves];
+  __shared__ unsigned long long bad_before;
+  __shared__ uint32_t tile_slot;
+  const uint64_t* off = reinterpret_cast<const uint64_t*>(in.seg[0].dst);
+  const uint8_t* bytes = in.seg[1].dst;
+  const uint64_t readable = (nbytes + 15) & ~15ull;
+  const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned int* stuck = ctl.ticket + 1;
+  CrcCompose op;
+  crc_table_init(tab);
+  for (;;) {
+    const uint32_t cur = next_tile(ctl, &tile_slot);
+    if (cur >= n_tiles) return;
+    const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
+    const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
+    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck);
+    __syncthreads();
+    if (i <= n) offs[tid] = __hip_atomic_load(off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) offs[kBlock] = __hip_atomic_load(off + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool live = i < n;
+    const uint64_t a = live ? offs[tid] : 0, b = live ? offs[tid + 1] : 0;
+    const bool ordered = __syncthreads_and(!live || (a <= b && b <= nbytes));
+    if (tid == 0) {
+      if (ordered) feed_wait(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck);
+      else feed_wait_all(in, ctl.epoch, stuck);
+    }
+    __syncthreads();
+    const WaveStage st = stage_wave_frames_dma(bytes, nbytes, readable, a, b, live, stage[wave]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WalRec r;
+    uint64_t d_off = 0, d_len = 0, span_off = 0;
+    CrcPair me = kCrcIdentity;  // a record that does not parse leaves the chain alone
+    bool long_span = false;
+    if (live) {
+      const ByteSrc src = frame_src(st, bytes, nbytes, a, b);
+      bool ok = frame_body_staged(src, bytes, nbytes, a, b, false);
+      if (ok) ok = parse_wal_rec(src, b - a - 8, a + 8, r, d_off, d_len);
+      if (!ok) {
+        r.group = r.term = r.index = r.data_off = 0;
+        r.data_len = r.vote = r.crc = 0;
+        r.kind = r.entry_type = r.pad = 0;
+        r.flags = kWalMalformed;
+      } else if (r.kind == kWalCrc) {
+        me.c = r.crc;  // re-seed: the constant map
+        me.p = 0;
+      } else {
+        me.p = crc_xpow8(d_len);
+        span_off = a + 8 + d_off;
+        if (d_len != 0 && d_len <= kCoopBytes) me.c = ~crc_span8(tab, 0xffffffffu, src, d_off, d_len);
+        long_span = d_len > kCoopBytes;
+      }
+    }
+    for (uint64_t todo = __ballot(long_span); todo != 0; todo &= todo - 1) {  // long Data spans: the whole wave per span
+      const int l = __ffsll((long long)todo) - 1;
+      const uint64_t so = wave_bcast_u64(span_off, l), sl = wave_bcast_u64(d_len, l);
+      const uint32_t c = wave_crc(tab, bytes + so, sl);  // (valid in lane 0)
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(c);
+      if ((int)lane == l) me.c = c0;
+    }
+    if (i == 0) me.c ^= crc_mulmod(me.p, prev_crc);
+    CrcPair tile_tot;
+    const CrcPair incl = crc_block_inclusive(live ? me : kCrcIdentity, wave_tot, &tile_tot);
+    if (tid == 0) tile_pre = lb_exclusive_crc(ctl.status[0], ctl.status[1], ctl.epoch, cur, tile_tot, stuck);
+    __syncthreads();
+    const CrcPair pre = tile_pre;
+    const uint32_t chain = cur == 0 ? incl.c : op(pre, incl).c;  // (tile 0 has nothing in front of it: prev_crc is folded into record 0)
+    chain_of[tid] = chain;
+    __syncthreads();
+    const uint32_t before = tid != 0 ? chain_of[tid - 1] : (cur == 0 ? prev_crc : pre.c);  // decoder.crc.Sum32() when the record arrives
+    bool bad = false;
+    if (live) {
+      bad = (r.flags & kWalMalformed) != 0;
+      if (!bad) {
+        bad = r.kind == kWalCrc ? (before != 0 && r.crc != before) : r.crc != chain;
+        if (bad) r.flags |= kWalBadCrc;
+      }
+    }
+    // the first bad record: of this tile (block minimum), of the tiles before it (look-back)
+    unsigned long long mine = bad ? i : kLbValueMask;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long y = __shfl_xor(mine, o, 64);
+      mine = y < mine ? y : mine;
+    }
+    if (lane == 0) wave_min[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long tmin = wave_min[0];
+      for (int k = 1; k < kWaves; ++k) tmin = wave_min[k] < tmin ? wave_min[k] : tmin;
+      const uint64_t earlier = lb_exclusive_min(ctl.status[2], ctl.epoch, cur, tmin, stuck);
+      bad_before = earlier;
+      const uint64_t live_recs = last - tile0;
+      if (earlier == kLbValueMask && tmin != kLbValueMask) {  // the call's first bad record is mine: the chain stops in front of it
+        const uint64_t k = tmin - tile0;
+        pin[1] = k != 0 ? chain_of[k - 1] : (cur == 0 ? prev_crc : pre.c);
+      }
+      if (cur == n_tiles - 1) {
+        const uint64_t fb = earlier < tmin ? earlier : tmin;
+        pin[0] = fb < n ? fb : n;
+        if (fb == kLbValueMask) pin[1] = chain_of[live_recs - 1];
+        pin[3] = __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();  // (chain_of / wave_min are read; the frames in `stage` are dead)
+    tile_records_out(r, live, reinterpret_cast<u32x4*>(&stage[0][0]), recs_h, tile0, n);
+  }
+}
+
+// ---- the streaming form of the encoders ------------------------------------------------------------------------------
+// block-wide exclusive sum of one u64 per thread -> this thread's prefix; *total = the block's sum
+__device__ __forceinline__ uint64_t block_exclusive_u64(uint64_t v, uint64_t* wave_tot /*LDS [kWaves]*/, uint64_t* total) {
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
+  }
+  if (lane == 63) wave_tot[w] = incl;
+  __syncthreads();
+  uint64_t pre = 0, all = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < (uint32_t)kWaves; ++k) {
+    const uint64_t t = wave_tot[k];
+    pre += k < w ? t : 0;
+    all += t;
+  }
+  *total = all;
+  return pre + incl - v;
+}
+// block-wide [min lo, max hi) over the threads that have a range (lo < hi); an empty result has lo >= hi
+__device__ __forceinline__ void block_range(uint64_t& lo, uint64_t& hi, uint64_t* red /*LDS [2 * kWaves]*/) {
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  __syncthreads();  // (red may still be read from the previous use)
+  if (lane == 0) {
+    red[w] = lo;
+    red[kWaves + w] = hi;
+  }
+  __syncthreads();
+  lo = red[0];
+  hi = red[kWaves];
+#pragma unroll
+  for (int k = 1; k < kWaves; ++k) {
+    lo = red[k] < lo ? red[k] : lo;
+    hi = red[kWaves + k] > hi ? red[kWaves + k] : hi;
+  }
+}
+
+// every byte of one stream frame except the entry payloads (what wire_enc_write_kernel writes per lane)
+__device__ inline void enc_write_frame(const WireMsg& m, const WireEnt* __restrict__ ents, uint8_t* dst, uint64_t frame_len) {
+  Sink s(dst);
+  s.u64_be(frame_len - 8);
+  s.field(0x08, m.type);
+  s.field(0x10, (uint64_t)m.to + 1);
+  s.field(0x18, (uint64_t)m.from + 1);
+  s.field(0x20, m.term);
+  s.field(0x28, m.log_term);
+  s.field(0x30, m.index);
+  for (uint32_t k = 0; k < m.n_ents; ++k) {
+    const WireEnt e = ents[m.ent_first + k];
+    s.field(0x3a, entry_size(e.type, e.term, e.index, e.data_len));
+    s.field(0x08, e.type);
+    s.field(0x10, e.term);
+    s.field(0x18, e.index);
+    if (e.data_len) {
+      s.field(0x22, e.data_len);
+      s.skip(e.data_len);
+    }
+  }
+  s.field(0x40, m.commit);
+  s.u64_le(0x0010000a0612084aull);  // 4a 08 12 06 0a 00 10 00 | 18 00: the empty Snapshot
+  s.byte(0x18);
+  s.byte(0x00);
+  s.field(0x50, m.reject ? 1 : 0);
+  s.field(0x58, m.reject_hint);
+  s.field(0x60, m.group);
+  s.flush();
+}
+
+// A tile's run of output bytes, built in device memory by this workgroup, on its way to the caller's buffer: whole
+// 16-byte quads of the DESTINATION as lane-consecutive stores (4 KB of consecutive host memory per instruction), the
+// < 16 bytes at either end byte by byte (the neighbouring tiles write the other bytes of those quads).
+__device__ inline void tile_bytes_out(const uint8_t* __restrict__ src, uint8_t* dst_h, uint64_t len) {
+  if (len == 0) return;
+  const uint32_t tid = threadIdx.x;
+  uint64_t head = (16 - ((uintptr_t)dst_h & 15)) & 15;
+  if (head > len) head = len;
+  if (tid < head) dst_h[tid] = src[tid];
+  const uint64_t quads = (len - head) >> 4;
+  u32x4* d16 = reinterpret_cast<u32x4*>(dst_h + head);
+  for (uint64_t q = tid; q < quads; q += kBlock) {
+    u32x4 v;
+    __builtin_memcpy(&v, src + head + (q << 4), 16);
+    __builtin_nontemporal_store(v, d16 + q);
+  }
+  const uint64_t done = head + (quads << 4);
+  if (tid < len - done) dst_h[done + tid] = src[done + tid];
+}
+
+// raftq_wire_encode on page-locked buffers, one launch: readers bring records (array 0), entry headers (1) and the payload
+// pool (2) into the scratch; a worker sizes its tile's 256 messages, learns the tile's place in the stream from the
+// look-back, writes the frames into the device copy of the stream (lane per frame, payloads by the wave) and pushes the
+// tile's run of bytes and its frame offsets out.  Nothing is ever written at or behind out_h[cap].
+// pin[0] = bytes the stream takes, pin[1] = messages refused (to / from >= 255, ranges outside ents[] / the pool: they
+// count as empty frames), pin[3] = a wait gave up.
+static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in, uint64_t n, uint64_t n_ents, uint64_t pool_bytes, uint8_t* d_out,
+                                                                       uint8_t* out_h, uint64_t cap, uint64_t* off_h, TileCtl ctl,
+                                                                       uint64_t* __restrict__ pin) {
+  if (blockIdx.x < in.readers) {
+    reader_role(in, ctl.epoch);
+    return;
+  }
+  __shared__ uint64_t wave_tot[kWaves];
+  __shared__ uint64_t red[2 * kWaves];
+  __shared__ uint64_t prefix[2];
+  __shared__ uint32_t wave_bad[kWaves];
+  __shared__ uint32_t tile_slot;
+  const WireMsg* msgs = reinterpret_cast<const WireMsg*>(in.seg[0].dst);
+  const WireEnt* ents = reinterpret_cast<const WireEnt*>(in.seg[1].dst);
+  const uint8_t* pool = in.seg[2].dst;
+  const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned int* stuck = ctl.ticket + 1;
+  for (;;) {
+    const uint32_t cur = next_tile(ctl, &tile_slot);
+    if (cur >= n_tiles) return;
+    const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
+    const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
+    const bool live = i < n;
+    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WireMsg), last * sizeof(WireMsg), stuck);
+    __syncthreads();
+    WireMsg m = {};
+    if (live) m = msgs[i];
+    bool is_bad = live && (m.to >= 255 || m.from >= 255 || (m.n_ents != 0 && (uint64_t)m.ent_first + m.n_ents > n_ents));
+    const bool walks = live && !is_bad && m.n_ents != 0;
+    // the entry headers this tile names are in the scratch ...
+    uint64_t lo = walks ? (uint64_t)m.ent_first * sizeof(WireEnt) : ~0ull, hi = walks ? ((uint64_t)m.ent_first + m.n_ents) * sizeof(WireEnt) : 0;
+    block_range(lo, hi, red);
+    if (tid == 0) feed_wait(in, ctl.epoch, 1, lo, hi, stuck);
+    __syncthreads();
+    uint64_t sz = 0;
+    lo = ~0ull;
+    hi = 0;
+    if (live) {
+      sz = 8 + msg_head_size(m) + msg_tail_size(m);
+      if (walks) {
+        for (uint32_t k = 0; k < m.n_ents; ++k) {
+          const WireEnt e = ents[m.ent_first + k];
+          if (e.data_len != 0) {
+            if (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off) {
+              is_bad = true;
+            } else {
+              lo = e.data_off < lo ? e.data_off : lo;
+              hi = e.data_off + e.data_len > hi ? e.data_off + e.data_len : hi;
+            }
+          }
+          const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);
+          sz += 1 + sov(es) + es;
+        }
+      }
+      if (is_bad) sz = 0;
+    }
+    if (is_bad) {  // a refused message carries no payload range
+      lo = ~0ull;
+      hi = 0;
+    }
+    // ... and so are the payloads they name
+    block_range(lo, hi, red);
+    if (tid == 0) feed_wait(in, ctl.epoch, 2, lo, hi, stuck);
+    const uint64_t bb = __ballot(is_bad);
+    if (lane == 0) wave_bad[wave] = (uint32_t)__popcll(bb);
+    uint64_t tile_bytes;
+    const uint64_t local = block_exclusive_u64(sz, wave_tot, &tile_bytes);  // (its barrier publishes wave_bad and the feed wait)
+    if (tid == 0) {
+      uint32_t tile_bad = 0;
+      for (int k = 0; k < kWaves; ++k) tile_bad += wave_bad[k];
+      const uint64_t pb = lb_exclusive(ctl.status[0], ctl.epoch, cur, tile_bytes, stuck);
+      const uint64_t pr = lb_exclusive(ctl.status[1], ctl.epoch, cur, tile_bad, stuck);
+      prefix[0] = pb;
+      if (cur == n_tiles - 1) {
+        pin[0] = pb + tile_bytes;
+        pin[1] = pr + tile_bad;
+        pin[3] = __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (off_h != nullptr) off_h[n] = pb + tile_bytes;
+      }
+    }
+    __syncthreads();
+    const uint64_t base = prefix[0], at = base + local;
+    if (off_h != nullptr && live) off_h[i] = at;
+    const bool fits = base + tile_bytes <= cap;  // (workgroup-uniform: a tile that does not fit is not built at all)
+    if (fits) {
+      if (live && sz != 0) enc_write_frame(m, ents, d_out + at, sz);
+      // payloads: the wave takes its messages that carry entries one after the other, 16 bytes per lane per step
+      const uint64_t pos0 = at + 8 + msg_head_size(m);
+      for (uint64_t todo = __ballot(walks && !is_bad); todo != 0; todo &= todo - 1) {
+        const int l = __ffsll((long long)todo) - 1;
+        uint64_t pos = wave_bcast_u64(pos0, l);
+        const uint32_t first = __builtin_amdgcn_readlane(m.ent_first, l), cnt = __builtin_amdgcn_readlane(m.n_ents, l);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const WireEnt e = ents[first + k];
+          const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);
+          pos += 1 + sov(es) + 3 + sov(e.type) + sov(e.term) + sov(e.index);
+          if (e.data_len) {
+            pos += 1 + sov(e.data_len);
+            wave_copy(d_out + pos, pool + e.data_off, e.data_len);
+            pos += e.data_len;
+          }
+        }
+      }
+      __syncthreads();  // the tile's bytes are in the device copy (this workgroup wrote all of them) ...
+      tile_bytes_out(d_out + base, out_h + base, tile_bytes);  // ... and leave as one run
+    }
+  }
+}
+
+// one WAL frame except an entry's / the metadata's payload bytes (what wal_enc_write_kernel writes per lane)
+__device__ inline void wal_write_frame(const WalRec& r, uint32_t crc, uint64_t dsz, uint8_t* dst) {
+  Sink s(dst);
+  s.u64_le(wal_rec_size(r, crc, dsz));
+  s.field(0x08, r.kind);
+  s.field(0x10, crc);
+  const bool has_data = r.kind != kWalCrc && !(r.kind == kWalMetadata && dsz == 0);
+  if (has_data) {
+    s.field(0x1a, dsz);
+    if (r.kind == kWalEntry) {
+      s.field(0x08, r.entry_type);
+      s.field(0x10, r.term);
+      s.field(0x18, r.index);
+      if (r.data_len) {
+        s.field(0x22, r.data_len);
+        s.skip(r.data_len);
+      }
+      s.field(0x28, r.group);
+    } else if (r.kind == kWalState) {
+      s.field(0x08, r.term);
+      s.field(0x10, r.vote);
+      s.field(0x18, r.index);
+      s.field(0x20, r.group);
+    } else if (r.kind == kWalSnapshot) {
+      s.field(0x08, r.index);
+      s.field(0x10, r.term);
+    }  // metadata: payload only
+  }
+  s.flush();
+}
+
+// raftq_wal_encode on page-locked buffers, one launch: readers bring the records (array 0) and the payload pool (1) into
+// the scratch; a worker CRCs its tile's records (short payloads in the lane, long ones by the wave), chains the CRCs
+// through the look-back -- a frame's size depends on its chained crc's varint length --, sizes, learns the tile's place in
+// the segment from a second look-back, writes the frames into the device copy and pushes the tile's run of bytes and its
+// frame offsets out.  Nothing is ever written at or behind out_h[cap].
+// pin[0] = bytes, pin[1] = records refused (unknown kind, payload outside the pool), pin[2] = the chain's end,
+// pin[3] = a wait gave up.
+static __global__ __launch_bounds__(kBlock) void wal_enc_fused_kernel(InFeed in, uint64_t n, uint64_t pool_bytes, uint32_t prev_crc, uint8_t* d_out,
+                                                                      uint8_t* out_h, uint64_t cap, uint64_t* off_h, TileCtl ctl,
+                                                                      uint64_t* __restrict__ pin) {
+  if (blockIdx.x < in.readers) {
+    reader_role(in, ctl.epoch);
+    return;
+  }
+  __shared__ uint32_t tab[kCrcTabs * 256];
+  __shared__ CrcPair crc_tot[kWaves];
+  __shared__ CrcPair tile_pre;
+  __shared__ uint64_t wave_tot[kWaves];
+  __shared__ uint64_t red[2 * kWaves];
+  __shared__ uint64_t prefix[2];
+  __shared__ uint32_t wave_bad[kWaves];
+  __shared__ uint32_t tile_slot;
+  const WalRec* recs = reinterpret_cast<const WalRec*>(in.seg[0].dst);
+  const uint8_t* pool = in.seg[1].dst;
+  const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned int* stuck = ctl.ticket + 1;
+  CrcCompose op;
+  crc_table_init(tab);
+  for (;;) {
+    const uint32_t cur = next_tile(ctl, &tile_slot);
+    if (cur >= n_tiles) return;
+    const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
+    const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
+    const bool live = i < n;
+    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WalRec), last * sizeof(WalRec), stuck);
+    __syncthreads();
+    WalRec r = {};
+    if (live) r = recs[i];
+    bool is_bad = live && (r.kind < 1 || r.kind > 5);
+    const bool payload = live && !is_bad && wal_has_payload(r.kind) && r.data_len != 0;
+    if (payload && (r.data_off > pool_bytes || r.data_len > pool_bytes - r.data_off)) is_bad = true;
+    const bool copies = payload && !is_bad;
+    uint64_t lo = copies ? r.data_off : ~0ull, hi = copies ? r.data_off + r.data_len : 0;
+    block_range(lo, hi, red);
+    if (tid == 0) feed_wait(in, ctl.epoch, 1, lo, hi, stuck);
+    __syncthreads();
+    // the record's map on the running CRC (wal_enc_crc_kernel): front fields, payload, the group field behind an entry
+    CrcPair me = kCrcIdentity;
+    uint32_t raw = 0xffffffffu;
+    const bool long_pl = copies && r.data_len > kCoopBytes;
+    if (live && !is_bad) {
+      if (r.kind == kWalEntry) {
+        raw = crc_field(tab, raw, 0x08, r.entry_type);
+        raw = crc_field(tab, raw, 0x10, r.term);
+        raw = crc_field(tab, raw, 0x18, r.index);
+        if (r.data_len) raw = crc_field(tab, raw, 0x22, r.data_len);
+      } else if (r.kind == kWalState) {
+        raw = crc_field(tab, raw, 0x08, r.term);
+        raw = crc_field(tab, raw, 0x10, r.vote);
+        raw = crc_field(tab, raw, 0x18, r.index);
+        raw = crc_field(tab, raw, 0x20, r.group);
+      } else if (r.kind == kWalSnapshot) {
+        raw = crc_field(tab, raw, 0x08, r.index);
+        raw = crc_field(tab, raw, 0x10, r.term);
+      }
+      if (copies && !long_pl) raw = crc_span(tab, raw, pool + r.data_off, r.data_len);
+    }
+    for (uint64_t todo = __ballot(long_pl); todo != 0; todo &= todo - 1) {  // long payloads: the whole wave per payload
+      const int l = __ffsll((long long)todo) - 1;
+      const uint64_t po = wave_bcast_u64(r.data_off, l);
+      const uint32_t pl = __builtin_amdgcn_readlane(r.data_len, l);
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(wave_crc(tab, pool + po, pl));  // (valid in lane 0)
+      if ((int)lane == l) raw = ~(crc_mulmod(crc_xpow8(pl), ~raw) ^ c0);  // crc(front || payload)
+    }
+    uint64_t dsz = 0;
+    if (live && !is_bad) {
+      if (r.kind == kWalEntry) raw = crc_field(tab, raw, 0x28, r.group);
+      dsz = wal_data_size(r);
+      me.c = dsz ? ~raw : 0u;
+      me.p = crc_xpow8(dsz);
+      if (i == 0) me.c ^= crc_mulmod(me.p, prev_crc);
+    }
+    CrcPair tile_crc;
+    const CrcPair incl = crc_block_inclusive(live ? me : kCrcIdentity, crc_tot, &tile_crc);
+    if (tid == 0) tile_pre = lb_exclusive_crc(ctl.status[0], ctl.status[1], ctl.epoch, cur, tile_crc, stuck);
+    __syncthreads();
+    const uint32_t crc = op(tile_pre, incl).c;  // Record.crc of record i: the running CRC through it
+    const uint64_t sz = live && !is_bad ? 8 + wal_rec_size(r, crc, dsz) : 0;  // (a refused record takes no bytes: its fields are not to be trusted)
+    const uint64_t bb = __ballot(is_bad);
+    if (lane == 0) wave_bad[wave] = (uint32_t)__popcll(bb);
+    uint64_t tile_bytes;
+    const uint64_t local = block_exclusive_u64(sz, wave_tot, &tile_bytes);
+    if (tid == 0) {
+      uint32_t tile_bad = 0;
+      for (int k = 0; k < kWaves; ++k) tile_bad += wave_bad[k];
+      const uint64_t pb = lb_exclusive(ctl.status[2], ctl.epoch, cur, tile_bytes, stuck);
+      const uint64_t pr = lb_exclusive(ctl.status[3], ctl.epoch, cur, tile_bad, stuck);
+      prefix[0] = pb;
+      if (cur == n_tiles - 1) {
+        pin[0] = pb + tile_bytes;
+        pin[1] = pr + tile_bad;
+        pin[3] = __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (off_h != nullptr) off_h[n] = pb + tile_bytes;
+      }
+    }
+    if (i == n - 1) pin[2] = crc;  // the chain's end: prev_crc of the next batch
+    __syncthreads();
+    const uint64_t base = prefix[0], at = base + local;
+    if (off_h != nullptr && live) off_h[i] = at;
+    const bool fits = base + tile_bytes <= cap;  // (workgroup-uniform)
+    if (fits) {
+      if (live && !is_bad) wal_write_frame(r, crc, dsz, d_out + at);
+      uint64_t pos0 = at + 8 + 2 + sov(r.kind) + sov(crc) + 1 + sov(dsz);
+      if (r.kind == kWalEntry) pos0 += 3 + sov(r.entry_type) + sov(r.term) + sov(r.index) + 1 + sov(r.data_len);
+      for (uint64_t todo = __ballot(copies); todo != 0; todo &= todo - 1) {  // payloads: pool -> frame by the wave
+        const int l = __ffsll((long long)todo) - 1;
+        wave_copy(d_out + wave_bcast_u64(pos0, l), pool + wave_bcast_u64(r.data_off, l), __builtin_amdgcn_readlane(r.data_len, l));
+      }
+      __syncthreads();
+      tile_bytes_out(d_out + base, out_h + base, tile_bytes);
+    }
+  }
 }
 
 }  // namespace raftqk

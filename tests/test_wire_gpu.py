@@ -19,8 +19,77 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "wire_golden.json")
 
 
-@pytest.fixture(scope="module")
-def eng():
+class _PinnedCalls:
+    """The engine with every codec call made on page-locked buffers (raftq_host_alloc) -- what a node hands the codecs every
+    turn, and what takes the streaming form of the call (one kernel: readers | workers).  Same methods, same results."""
+
+    def __init__(self, e):
+        self._e = e
+
+    def __getattr__(self, k):
+        return getattr(self._e, k)
+
+    @staticmethod
+    def _pin(a, dt=None):
+        from raftsql_amd.engine import pinned_copy
+
+        a = np.ascontiguousarray(a if dt is None else np.asarray(a, dtype=dt))
+        return pinned_copy(a) if a.size else a
+
+    def wire_decode(self, stream, frame_off, want_ents=True, **kw):
+        from raftsql_amd.engine import pinned_empty
+
+        s, off = self._pin(_wiregen_u8(stream)), self._pin(frame_off, np.uint64)
+        n = len(off) - 1
+        msgs = pinned_empty(max(n, 1), W.WIRE_MSG_DT)
+        if not want_ents:
+            m, e, bad = self._e.wire_decode(s, off, want_ents=False, msgs=msgs)
+            return m.copy(), e, bad
+        m, _, _ = self._e.wire_decode(s, off, want_ents=False, msgs=msgs)  # (headers only: how many entry headers there are)
+        ents = pinned_empty(int(m["n_ents"].sum()) + 1, W.WIRE_ENT_DT)
+        m, e, bad = self._e.wire_decode(s, off, msgs=msgs, ents=ents)
+        return m.copy(), e.copy(), bad
+
+    def wal_decode(self, data, frame_off, prev_crc=0, **kw):
+        from raftsql_amd.engine import pinned_empty
+
+        b, off = self._pin(_wiregen_u8(data)), self._pin(frame_off, np.uint64)
+        r, nv, lc = self._e.wal_decode(b, off, prev_crc, recs=pinned_empty(max(len(off) - 1, 1), W.WAL_REC_DT))
+        return r.copy(), nv, lc
+
+    def wire_encode(self, msgs, ents=None, pool=b"", out=None, off=None):
+        from raftsql_amd.engine import pinned_empty
+
+        if out is not None:
+            return self._e.wire_encode(msgs, ents, pool, out=out, off=off)
+        m = self._pin(msgs, W.WIRE_MSG_DT)
+        e = self._pin(ents if ents is not None else np.zeros(0, W.WIRE_ENT_DT), W.WIRE_ENT_DT)
+        p = self._pin(_wiregen_u8(pool))
+        try:
+            size = len(W.wire_encode(np.asarray(msgs), np.asarray(e), np.asarray(p))[0])  # (the size only: the call needs a buffer)
+        except Exception:  # noqa: BLE001 - input the oracle refuses: any buffer will do, the call has to refuse too
+            size = 128 * len(m) + len(p) + 1024
+        o, f = pinned_empty(size + 16, np.uint8), pinned_empty(len(m) + 1, np.uint64)
+        got, goff = self._e.wire_encode(m, e, p, out=o, off=f)
+        return got.copy(), goff.copy()
+
+    def wal_encode(self, recs, pool=b"", prev_crc=0, out=None, off=None):
+        from raftsql_amd.engine import pinned_empty
+
+        if out is not None:
+            return self._e.wal_encode(recs, pool, prev_crc, out=out, off=off)
+        r, p = self._pin(recs, W.WAL_REC_DT), self._pin(_wiregen_u8(pool))
+        try:
+            size = len(W.wal_encode(np.asarray(recs), np.asarray(p), prev_crc)[0])
+        except Exception:  # noqa: BLE001
+            size = 128 * len(r) + len(p) + 1024
+        o, f = pinned_empty(size + 16, np.uint8), pinned_empty(len(r) + 1, np.uint64)
+        got, goff, last = self._e.wal_encode(r, p, prev_crc, out=o, off=f)
+        return got.copy(), goff.copy(), last
+
+
+@pytest.fixture(scope="module", params=["pageable", "page-locked"])
+def eng(request):
     import torch
 
     if not torch.cuda.is_available():
@@ -28,7 +97,7 @@ def eng():
     from raftsql_amd.wire import WireEngine
 
     with WireEngine(4096, 5, self_peer=0) as e:
-        yield e
+        yield e if request.param == "pageable" else _PinnedCalls(e)
 
 
 def _same(a: np.ndarray, b: np.ndarray, what=""):
@@ -239,20 +308,27 @@ def test_decode_entry_capacity(eng):
     assert rc == _lib.RAFTQ_EINVAL and c.n_ents == len(e)
 
 
-@pytest.mark.parametrize("copies", ["kernel", "runtime"])
+def _form(monkeypatch, form):
+    """streaming: one kernel, readers | workers (the default on page-locked buffers); chain: round 3's copy-in -> kernels ->
+    copy-out on one stream (RAFTQ_WIRE_FUSED=0); runtime: the runtime's copies (RAFTQ_WIRE_KERNEL_COPIES=0)"""
+    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "0" if form == "runtime" else "1")
+    monkeypatch.setenv("RAFTQ_WIRE_FUSED", "1" if form == "streaming" else "0")
+
+
+@pytest.mark.parametrize("copies", ["streaming", "chain", "runtime"])
 @pytest.mark.parametrize("seed,n,big", [(171, 1, 0), (172, 900, 4), (173, 6000, 0), (174, 333, 1)])
 def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
-    """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE chain with ONE wait -- its
-    copies are workgroup copies inside the queue, the writers refuse a bad or oversized batch themselves, the entry headers
-    leave with the records -- and has to say and write exactly what the copying form does (RAFTQ_WIRE_KERNEL_COPIES=0, the
-    `runtime` rows): streams, offsets, records, entries, counts, refusals that leave the output alone, the entry capacity."""
+    """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE launch with ONE wait and has to
+    say and write exactly what the copying form does (the `runtime` rows): streams, offsets, records, entries, counts, the
+    entry capacity, refusals.  A refused call of the chain / runtime forms leaves the output alone; the streaming form has
+    tiles on their way out before the verdict exists, so its promise is the ABI's: nothing at or behind out[cap] is touched."""
     import ctypes as C
 
     from raftsql_amd import _lib
     from raftsql_amd.engine import pinned_copy, pinned_empty
     from raftsql_amd.wire import WireEngine
 
-    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "1" if copies == "kernel" else "0")
+    _form(monkeypatch, copies)
     rng = np.random.default_rng(seed)
     with WireEngine(4096, 5, self_peer=0) as eng:
         for rnd in range(3):
@@ -264,20 +340,23 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
             got, goff = eng.wire_encode(pm, pe, pp, out=out, off=off)
             assert np.array_equal(goff, want_off) and got.tobytes() == want.tobytes()
             assert bytes(out[len(want):]) == b"\xee" * 64  # nothing behind the stream was touched
-            # too small a buffer: refused, the size needed is reported, nothing written
-            small = pinned_empty(max(1, len(want) - 1), np.uint8)
+            # too small a buffer: refused, the size needed is reported, nothing written at or behind out[cap]
+            cap = max(1, len(want) - 1)
+            small = pinned_empty(cap + 64, np.uint8)
             small[:] = 0xEE
             c = _lib.WireCounts()
             rc = eng._lib.raftq_wire_encode(eng._h, pm.ctypes.data, n, pe.ctypes.data if len(e) else None, len(e), pp.ctypes.data, len(pp),
-                                            small.ctypes.data, len(small), off.ctypes.data, C.byref(c))
-            assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small) == b"\xee" * len(small)
-            # a bad message (addressee 255): refused whole
+                                            small.ctypes.data, cap, off.ctypes.data, C.byref(c))
+            assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small[cap:]) == b"\xee" * 64
+            assert copies == "streaming" or bytes(small) == b"\xee" * len(small)
+            # a bad message (addressee 255): refused
             bad = pinned_copy(m)
             bad["to"][n // 2] = 255
             out[:] = 0xEE
             rc = eng._lib.raftq_wire_encode(eng._h, bad.ctypes.data, n, pe.ctypes.data if len(e) else None, len(e), pp.ctypes.data, len(pp),
-                                            out.ctypes.data, len(out), off.ctypes.data, C.byref(c))
-            assert rc == _lib.RAFTQ_EINVAL and bytes(out) == b"\xee" * len(out)
+                                            out.ctypes.data, len(want), off.ctypes.data, C.byref(c))
+            assert rc == _lib.RAFTQ_EINVAL and bytes(out[len(want):]) == b"\xee" * 64
+            assert copies == "streaming" or bytes(out) == b"\xee" * len(out)
             # and the next call is fine again (the flag word was left zero)
             got, goff = eng.wire_encode(pm, pe, pp, out=out, off=off)
             assert got.tobytes() == want.tobytes()
@@ -306,7 +385,7 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
                     _same(ge, we, "ents after a refusal")
 
 
-@pytest.mark.parametrize("copies", ["kernel", "runtime"])
+@pytest.mark.parametrize("copies", ["streaming", "chain", "runtime"])
 @pytest.mark.parametrize("seed,n,big,prev", [(181, 1, 0, 0), (182, 700, 3, 0xDEADBEEF), (183, 5000, 40, 7)])
 def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypatch):
     """the WAL codecs the same way: every buffer page-locked -> one chain, one wait; bytes, offsets, CRC chain, records,
@@ -317,7 +396,7 @@ def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypat
     from raftsql_amd.engine import pinned_copy, pinned_empty
     from raftsql_amd.wire import WireEngine
 
-    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "1" if copies == "kernel" else "0")
+    _form(monkeypatch, copies)
     rng = np.random.default_rng(seed)
     with WireEngine(4096, 5, self_peer=0) as eng:
         r, pool = _wiregen.random_wal(rng, n, max_payload=300, big_every=big)
@@ -328,18 +407,21 @@ def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypat
         got, goff, glast = eng.wal_encode(pr, pp, prev, out=out, off=off)
         assert np.array_equal(goff, want_off) and got.tobytes() == want.tobytes() and glast == want_last
         assert bytes(out[len(want):]) == b"\xee" * 64
-        small = pinned_empty(max(1, len(want) - 1), np.uint8)
+        cap = max(1, len(want) - 1)
+        small = pinned_empty(cap + 64, np.uint8)
         small[:] = 0xEE
         c = _lib.WalCounts()
-        rc = eng._lib.raftq_wal_encode(eng._h, pr.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, small.ctypes.data, len(small),
+        rc = eng._lib.raftq_wal_encode(eng._h, pr.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, small.ctypes.data, cap,
                                        off.ctypes.data, C.byref(c))
-        assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small) == b"\xee" * len(small)
+        assert rc == _lib.RAFTQ_EINVAL and c.bytes == len(want) and bytes(small[cap:]) == b"\xee" * 64
+        assert copies == "streaming" or bytes(small) == b"\xee" * len(small)
         bad = pinned_copy(r)
         bad["kind"][len(r) // 2] = 99
         out[:] = 0xEE
-        rc = eng._lib.raftq_wal_encode(eng._h, bad.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, out.ctypes.data, len(out),
+        rc = eng._lib.raftq_wal_encode(eng._h, bad.ctypes.data, len(r), pp.ctypes.data, len(pp), prev, out.ctypes.data, len(want),
                                        off.ctypes.data, C.byref(c))
-        assert rc == _lib.RAFTQ_EINVAL and bytes(out) == b"\xee" * len(out)
+        assert rc == _lib.RAFTQ_EINVAL and bytes(out[len(want):]) == b"\xee" * 64
+        assert copies == "streaming" or bytes(out) == b"\xee" * len(out)
         got, goff, glast = eng.wal_encode(pr, pp, prev, out=out, off=off)  # the flag word was left zero
         assert got.tobytes() == want.tobytes() and glast == want_last
         for damage in (False, True):
@@ -379,6 +461,63 @@ def test_streaming_decode_at_bench_size(wgs, monkeypatch):
             assert gbad == wbad
             _same(gm, wm, "msgs")
             _same(ge, we, "ents")
+
+
+@pytest.mark.parametrize("wgs", [3, 64, 208])
+def test_streaming_encode_at_bench_size(wgs, monkeypatch):
+    """The one-kernel form of raftq_wire_encode at the bench's size -- 65,536 messages, a MsgApp share with 1-3 entries of
+    payload -- for a few workgroups walking many tiles, and the default grid: the stream and its offsets are the oracle's."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
+    rng = np.random.default_rng(2900 + wgs)
+    n = 65536
+    m, e, pool = _wiregen.random_msgs(rng, n, big_every=9000, ent_frac=0.15)
+    want, want_off = W.wire_encode(m, e, pool)
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        pm, pe, pp = pinned_copy(m), pinned_copy(e), pinned_copy(_wiregen_u8(pool))
+        out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+        for rep in range(3):
+            out[:] = 0xEE
+            got, goff = eng.wire_encode(pm, pe, pp, out=out, off=off)
+            assert np.array_equal(goff, want_off)
+            assert got.tobytes() == want.tobytes() and bytes(out[len(want):]) == b"\xee" * 64
+
+
+@pytest.mark.parametrize("wgs", [3, 208])
+def test_streaming_wal_codecs_at_bench_size(wgs, monkeypatch):
+    """The one-kernel forms of raftq_wal_encode / _decode at the bench's size: 65,536 records (entries with payloads -- a few
+    long enough for the wave-cooperative CRC --, hard states, a crcType record in mid-segment), the CRC chain crossing every
+    tile boundary; then the same bytes with damage: first bad record, the chain's value there, per-record flags."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
+    rng = np.random.default_rng(3900 + wgs)
+    n = 65536
+    r, pool = _wiregen.random_wal(rng, n, max_payload=200, big_every=7000)
+    r["kind"][40000] = W.WAL_CRC
+    for k in ("group", "term", "index", "vote", "data_len", "data_off", "entry_type"):
+        r[k][40000] = 0
+    want, want_off, want_last = W.wal_encode(r, pool, 0xC0FFEE)
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        pr, pp = pinned_copy(r), pinned_copy(_wiregen_u8(pool))
+        out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+        for rep in range(2):
+            out[:] = 0xEE
+            got, goff, glast = eng.wal_encode(pr, pp, 0xC0FFEE, out=out, off=off)
+            assert np.array_equal(goff, want_off) and glast == want_last
+            assert got.tobytes() == want.tobytes() and bytes(out[len(want):]) == b"\xee" * 64
+        recs = pinned_empty(n, W.WAL_REC_DT)
+        for damage in (None, 50001, 17):
+            s = want.copy()
+            if damage is not None:
+                s[int(want_off[damage]) + 9] ^= 0x10
+            wr, wnv, wl = W.wal_decode(s, want_off, 0xC0FFEE)
+            gr, gnv, gl = eng.wal_decode(pinned_copy(s), pinned_copy(want_off), 0xC0FFEE, recs=recs)
+            assert (gnv, gl) == (wnv, wl) and (damage is None or gnv <= damage)
+            _same(gr, wr, "recs")
 
 
 def _wiregen_u8(pool):

@@ -84,15 +84,7 @@ struct raftq {
   const uint64_t* last_new = nullptr;
   // batched Step node state (raftq_step.hip), lazily allocated
   uint32_t self_peer = 0;
-  uint64_t* term = nullptr;        // [ld]
-  uint32_t* vote = nullptr;        // [ld] 0 = None, else slot + 1
-  uint32_t* lead = nullptr;        // [ld]
-  uint64_t* last_index = nullptr;  // [ld]
-  uint64_t* last_term = nullptr;   // [ld]
-  // sort-free Step walk (raftq_step_kernels.hpp 2b/3b): per-group message lists of the batch in flight
-  uint32_t* lst_head = nullptr;    // [ld]
-  uint32_t* lst_cnt = nullptr;     // [ld]
-  uint32_t* lst_min = nullptr;     // [ld]
+  void* node_rec = nullptr;        // raftqk::NodeRec [ld]: term, vote, lead, last_index, last_term + the list words of the batch in flight
   unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
   bool step_compact = false;       // result records in the 40-byte format (raftq_step_set_compact)
   int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)

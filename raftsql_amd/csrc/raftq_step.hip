@@ -30,38 +30,27 @@ static_assert(sizeof(raftq_msg_t) == sizeof(MsgRec) && sizeof(raftq_step_out_t) 
 namespace {
 
 int ensure_node_state(raftq_t* h) {
-  if (h->term) return RAFTQ_OK;
+  if (h->node_rec) return RAFTQ_OK;
   if (int rc = ensure_tick_state(h)) return rc;  // role, elapsed
   auto alloc = [&](void** p, size_t bytes) -> int {
     HIPCHK(h, hipMalloc(p, bytes));
     HIPCHK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
     return RAFTQ_OK;
   };
-  if (int rc = alloc((void**)&h->vote, h->ld * 4)) return rc;
-  if (int rc = alloc((void**)&h->lead, h->ld * 4)) return rc;
-  if (int rc = alloc((void**)&h->last_index, h->ld * 8)) return rc;
-  if (int rc = alloc((void**)&h->last_term, h->ld * 8)) return rc;
-  if (int rc = alloc((void**)&h->lst_cnt, h->ld * 4)) return rc;
-  HIPCHK(h, hipMalloc((void**)&h->lst_head, h->ld * 4));
-  HIPCHK(h, hipMalloc((void**)&h->lst_min, h->ld * 4));
-  HIPCHK(h, hipMemsetAsync(h->lst_head, 0xff, h->ld * 4, h->stream));
-  HIPCHK(h, hipMemsetAsync(h->lst_min, 0xff, h->ld * 4, h->stream));
   if (int rc = alloc((void**)&h->step_stall, 256)) return rc;
   if (const char* w = std::getenv("RAFTQ_STEP_WALK")) h->step_walk_mode = std::strcmp(w, "sort") == 0 ? 0 : 1;
-  if (int rc = alloc((void**)&h->term, h->ld * 8)) return rc;  // last: marks the state complete
+  HIPCHK(h, hipMalloc((void**)&h->node_rec, h->ld * sizeof(NodeRec)));  // last: marks the state complete
+  hipLaunchKernelGGL(node_init_kernel, dim3((unsigned)((h->ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (NodeRec*)h->node_rec, h->ld);
+  HIPCHK(h, hipGetLastError());
   h->have_terms = true;  // Step maintains the current-term gate itself (closed = 0 until a group leads)
   return RAFTQ_OK;
 }
 
 NodeArrays node_arrays(raftq_t* h) {
   NodeArrays a;
+  a.rec = (NodeRec*)h->node_rec;
   a.role = h->role;
   a.elapsed = h->elapsed;
-  a.term = h->term;
-  a.vote = h->vote;
-  a.lead = h->lead;
-  a.last_index = h->last_index;
-  a.last_term = h->last_term;
   a.committed = h->committed[h->cur];
   a.first_idx = h->first_idx;
   a.match = h->match;
@@ -236,17 +225,42 @@ int ensure_slot_bar(raftq_t* h, raftq::StepSlot& sl, uint64_t n, void** out, siz
   return RAFTQ_OK;
 }
 
+// raftq_load_node / raftq_read_node: the ABI speaks one flat array per field, the device keeps one record per group.  A
+// slab of groups at a time goes through a device temporary and a kernel that writes / reads the field of every record.
+int node_fields(raftq_t* h, bool put, uint64_t* term, uint32_t* vote, uint32_t* lead, uint64_t* last_index, uint64_t* last_term) {
+  void* host[5] = {term, vote, lead, last_index, last_term};
+  const size_t width[5] = {8, 4, 4, 8, 8};
+  if (!term && !vote && !lead && !last_index && !last_term) return RAFTQ_OK;
+  const uint64_t slab = std::min<uint64_t>(h->G, 1ull << 24);
+  void* tmp = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, slab * 8));
+  int rc = RAFTQ_OK;
+  for (int f = 0; f < 5 && rc == RAFTQ_OK; ++f) {
+    if (!host[f]) continue;
+    for (uint64_t g0 = 0; g0 < h->G && rc == RAFTQ_OK; g0 += slab) {
+      const uint64_t cnt = std::min(slab, h->G - g0);
+      uint8_t* hp = (uint8_t*)host[f] + g0 * width[f];
+      hipError_t e = hipSuccess;
+      if (put) e = hipMemcpyAsync(tmp, hp, cnt * width[f], hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) {
+        if (put) hipLaunchKernelGGL(node_field_kernel<true>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (NodeRec*)h->node_rec, g0, cnt, f, tmp);
+        else hipLaunchKernelGGL(node_field_kernel<false>, dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (NodeRec*)h->node_rec, g0, cnt, f, tmp);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess && !put) e = hipMemcpyAsync(hp, tmp, cnt * width[f], hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the temporary is reused by the next slab / field
+      if (e != hipSuccess) rc = fail(h, RAFTQ_EHIP, std::string("raftq node fields: ") + hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(tmp);
+  return rc;
+}
+
 }  // namespace
 
 void raftq_detail::free_node_state(raftq_t* h) {
-  (void)hipFree(h->term);
-  (void)hipFree(h->vote);
-  (void)hipFree(h->lead);
-  (void)hipFree(h->last_index);
-  (void)hipFree(h->last_term);
-  (void)hipFree(h->lst_head);
-  (void)hipFree(h->lst_cnt);
-  (void)hipFree(h->lst_min);
+  (void)hipFree(h->node_rec);
+  h->node_rec = nullptr;
   (void)hipFree(h->step_stall);
   for (auto& sl : h->step_slot) {
     if (sl.busy && sl.copy_pending && h->stream) (void)hipStreamSynchronize(h->stream);  // its kernels; the copy never ran
@@ -280,12 +294,9 @@ int raftq_load_node(raftq_t* h, const uint64_t* term, const uint32_t* vote, cons
   for (uint64_t g = 0; g < h->G; ++g)
     if ((vote && vote[g] > h->N) || (lead && lead[g] > h->N))
       return fail(h, RAFTQ_EINVAL, "raftq_load_node: vote / lead must be 0 (None) or a peer slot + 1");
-  if (term) HIPCHK(h, hipMemcpyAsync(h->term, term, h->G * 8, hipMemcpyHostToDevice, h->stream));
-  if (vote) HIPCHK(h, hipMemcpyAsync(h->vote, vote, h->G * 4, hipMemcpyHostToDevice, h->stream));
-  if (lead) HIPCHK(h, hipMemcpyAsync(h->lead, lead, h->G * 4, hipMemcpyHostToDevice, h->stream));
-  if (last_index) HIPCHK(h, hipMemcpyAsync(h->last_index, last_index, h->G * 8, hipMemcpyHostToDevice, h->stream));
-  if (last_term) HIPCHK(h, hipMemcpyAsync(h->last_term, last_term, h->G * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (int rc = node_fields(h, true, const_cast<uint64_t*>(term), const_cast<uint32_t*>(vote), const_cast<uint32_t*>(lead),
+                           const_cast<uint64_t*>(last_index), const_cast<uint64_t*>(last_term)))
+    return rc;
   return RAFTQ_OK;
 }
 
@@ -293,11 +304,7 @@ int raftq_read_node(raftq_t* h, uint64_t* term, uint32_t* vote, uint32_t* lead, 
                     uint64_t* last_term, uint64_t* first_idx_cur_term) {
   if (int rc = raftq_detail::use_device_idle(h, "raftq_read_node")) return rc;
   if (int rc = ensure_node_state(h)) return rc;
-  if (term) HIPCHK(h, hipMemcpyAsync(term, h->term, h->G * 8, hipMemcpyDeviceToHost, h->stream));
-  if (vote) HIPCHK(h, hipMemcpyAsync(vote, h->vote, h->G * 4, hipMemcpyDeviceToHost, h->stream));
-  if (lead) HIPCHK(h, hipMemcpyAsync(lead, h->lead, h->G * 4, hipMemcpyDeviceToHost, h->stream));
-  if (last_index) HIPCHK(h, hipMemcpyAsync(last_index, h->last_index, h->G * 8, hipMemcpyDeviceToHost, h->stream));
-  if (last_term) HIPCHK(h, hipMemcpyAsync(last_term, h->last_term, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+  if (int rc = node_fields(h, false, term, vote, lead, last_index, last_term)) return rc;
   if (first_idx_cur_term)
     HIPCHK(h, hipMemcpyAsync(first_idx_cur_term, h->first_idx, h->G * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -354,14 +361,6 @@ struct WireSrc {
   const uint64_t* frame_off;
 };
 
-static ListArrays list_arrays(raftq_t* h) {
-  ListArrays l;
-  l.head = h->lst_head;
-  l.cnt = h->lst_cnt;
-  l.minp = h->lst_min;
-  return l;
-}
-
 // key -> stable radix sort -> walk, on the handle's stream (the path that takes runs of any length)
 static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, bool from_wire, void* outs) {
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
@@ -394,9 +393,9 @@ static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from
     in_walk = {(const u64x2*)carry->outs_d, (u64x2*)carry->out_d, cut, quads, quads - 1, d2h_blocks(quads - cut)};
   }
   hipLaunchKernelGGL(step_link_kernel, dim3(blocks + in_link.blocks), dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G,
-                     h->N, from_wire, list_arrays(h), s.next, bad, h->step_stall, in_link);
+                     h->N, from_wire, (NodeRec*)h->node_rec, s.next, bad, h->step_stall, in_link);
   hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + in_walk.blocks), dim3(kBlock), 0, h->stream, node_arrays(h),
-                     (const MsgRec*)s.msgs, s.outs, h->step_compact, n, h->G, list_arrays(h), (const uint32_t*)s.next, s.n_heads,
+                     (const MsgRec*)s.msgs, s.outs, h->step_compact, n, h->G, (const uint32_t*)s.next, s.n_heads,
                      skipped, (const unsigned int*)bad, (const unsigned int*)h->step_stall, in_walk);
   HIPCHK(h, hipGetLastError());
   if (carry) {

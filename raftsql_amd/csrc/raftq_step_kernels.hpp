@@ -44,14 +44,27 @@ struct StepOutC {  // == raftq_step_out_c_t: the result record without what the 
 static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32 && sizeof(StepOutC) == 40,
               "record layout");
 
+// What only Step touches of a group, in ONE 64-byte line: the raft scalars and the words of the group's message list of
+// the batch in flight (step_link_kernel / step_lists_kernel).  Round 3 kept each of these in an array of its own: a touched
+// group cost 18 scattered cache lines in and 18 out for ~100 useful bytes -- 54 MB read and 31 MB written per 64K-message
+// batch (profiles/r04/pmc_traffic_legs.json: traffic x4 of the bytes the walk needs).  What the dense kernels stream stays
+// peer-major / group-major SoA: match, committed (the sweep), first_idx (the gated sweep), the vote words (the tally),
+// role / elapsed (Tick) -- the walk reads role and committed with the record and everything else only on the paths that
+// need it (the vote word in poll, first_idx and the match rows in maybeCommit, elapsed never: Step only ever resets it).
+struct __attribute__((aligned(64))) NodeRec {
+  uint64_t term, last_index, last_term;
+  uint32_t lst_head;  // batch position of the last-linked message of the group, kNil = none
+  uint32_t lst_cnt;   // messages of the group in this batch
+  uint32_t lst_min;   // smallest batch position of the group
+  uint8_t vote, lead; // 0 = None, else slot + 1
+  uint8_t pad[2 + 24];
+};
+static_assert(sizeof(NodeRec) == 64, "one cache line");
+
 struct NodeArrays {
+  NodeRec* rec;     // [ld]
   uint8_t* role;
   uint32_t* elapsed;
-  uint64_t* term;
-  uint32_t* vote;
-  uint32_t* lead;
-  uint64_t* last_index;
-  uint64_t* last_term;
   uint64_t* committed;
   uint64_t* first_idx;
   uint64_t* match;  // [N][ld]
@@ -154,27 +167,71 @@ static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* 
 }
 
 // ---- (3) one group's state in registers ------------------------------------------------------
+constexpr uint32_t kMaxRun = 32;
+constexpr uint32_t kNil = 0xffffffffu;
+
 struct Node {
   const NodeArrays& a;
   uint64_t g;
-  uint64_t term, last_index, last_term, committed, first_idx;
-  uint32_t vote, lead, elapsed;
-  uint32_t vw;  // the group's vote word (raft.votes as 2 bits per peer): loaded once, stored once
+  uint64_t term, last_index, last_term, committed, first_idx = 0;
+  uint32_t vote, lead;
+  uint32_t vw = 0;  // the group's vote word (raft.votes as 2 bits per peer)
+  uint32_t lst_head, lst_cnt, lst_min;  // the record's list words as loaded (the walk empties them when it stores)
   uint8_t role;
   bool held = false;  // this batch only: a MsgApp with RAFTQ_MSGF_BARRIER was left to the caller -- the group's later messages wait
+  // what has been read / has to be written besides the record (which always is, list words emptied)
+  uint64_t committed0;
+  uint8_t role0;
+  bool fi_known = false, fi_dirty = false, vw_known = false, vw_dirty = false, elapsed_reset = false;
 
   __device__ Node(const NodeArrays& arr, uint64_t group) : a(arr), g(group) {
-    term = a.term[g]; last_index = a.last_index[g]; last_term = a.last_term[g];
-    committed = a.committed[g]; first_idx = a.first_idx[g];
-    vote = a.vote[g]; lead = a.lead[g]; elapsed = a.elapsed[g]; role = a.role[g];
-    vw = a.n_peers <= 8 ? (uint32_t)reinterpret_cast<const uint16_t*>(a.votes)[g] : reinterpret_cast<const uint32_t*>(a.votes)[g];
+    const NodeRec r = a.rec[g];  // one line: four 16-byte loads
+    term = r.term; last_index = r.last_index; last_term = r.last_term;
+    vote = r.vote; lead = r.lead;
+    lst_head = r.lst_head; lst_cnt = r.lst_cnt; lst_min = r.lst_min;
+    committed = committed0 = a.committed[g];
+    role = role0 = a.role[g];
   }
-  __device__ void store() const {
-    a.term[g] = term; a.last_index[g] = last_index; a.last_term[g] = last_term;
-    a.committed[g] = committed; a.first_idx[g] = first_idx;
-    a.vote[g] = vote; a.lead[g] = lead; a.elapsed[g] = elapsed; a.role[g] = role;
-    if (a.n_peers <= 8) reinterpret_cast<uint16_t*>(a.votes)[g] = (uint16_t)vw;
-    else reinterpret_cast<uint32_t*>(a.votes)[g] = vw;
+  // list_reset: the walk hands the group's list back empty (log_deltas_kernel leaves the words as they are)
+  __device__ void store(bool list_reset = true) const {
+    NodeRec r;
+    r.term = term; r.last_index = last_index; r.last_term = last_term;
+    r.vote = (uint8_t)vote; r.lead = (uint8_t)lead;
+    r.lst_head = list_reset ? kNil : lst_head;
+    r.lst_cnt = list_reset ? 0u : lst_cnt;
+    r.lst_min = list_reset ? kNil : lst_min;
+    __builtin_memset(r.pad, 0, sizeof r.pad);
+    a.rec[g] = r;
+    if (committed != committed0) a.committed[g] = committed;
+    if (role != role0) a.role[g] = role;
+    if (fi_dirty) a.first_idx[g] = first_idx;
+    if (elapsed_reset) a.elapsed[g] = 0;
+    if (vw_dirty) {
+      if (a.n_peers <= 8) reinterpret_cast<uint16_t*>(a.votes)[g] = (uint16_t)vw;
+      else reinterpret_cast<uint32_t*>(a.votes)[g] = vw;
+    }
+  }
+  __device__ void set_first_idx(uint64_t v) {
+    first_idx = v;
+    fi_known = fi_dirty = true;
+  }
+  __device__ uint64_t get_first_idx() {
+    if (!fi_known) {
+      first_idx = a.first_idx[g];
+      fi_known = true;
+    }
+    return first_idx;
+  }
+  __device__ void set_votes(uint32_t w) {
+    vw = w;
+    vw_known = vw_dirty = true;
+  }
+  __device__ uint32_t get_votes() {
+    if (!vw_known) {
+      vw = a.n_peers <= 8 ? (uint32_t)reinterpret_cast<const uint16_t*>(a.votes)[g] : reinterpret_cast<const uint32_t*>(a.votes)[g];
+      vw_known = true;
+    }
+    return vw;
   }
   __device__ uint64_t& match(uint32_t p) const { return a.match[(uint64_t)p * a.ld + g]; }
   __device__ uint32_t quorum() const { return a.n_peers / 2 + 1; }
@@ -183,21 +240,21 @@ struct Node {
   __device__ void reset(uint64_t t) {
     if (term != t) { term = t; vote = 0; }
     lead = 0;
-    elapsed = 0;
-    vw = 0;
+    elapsed_reset = true;
+    set_votes(0);
     for (uint32_t p = 0; p < a.n_peers; ++p) match(p) = p == a.self ? last_index : 0;
   }
   __device__ void become_follower(uint64_t t, uint32_t new_lead) {
     reset(t);
     lead = new_lead;
     role = kFollower;
-    first_idx = 0;
+    set_first_idx(0);
   }
   __device__ void become_candidate() {
     reset(term + 1);
     vote = a.self + 1;
     role = kCandidate;
-    first_idx = 0;
+    set_first_idx(0);
   }
   // raft.maybeCommit + raftLog.maybeCommit: the largest index held by >= q peers (counting form),
   // then the compact current-term gate
@@ -214,9 +271,12 @@ struct Node {
       for (uint32_t p = 0; p < kMaxPeers; ++p) ge += (p < n && m[p] >= m[c]) ? 1u : 0u;
       if (c < n && ge >= q && m[c] > mci) mci = m[c];
     }
-    if (mci > committed && first_idx != 0 && mci >= first_idx) {
-      committed = mci;
-      return true;
+    if (mci > committed) {  // (the gate's word is only read when there is something to gate)
+      const uint64_t fi = get_first_idx();
+      if (fi != 0 && mci >= fi) {
+        committed = mci;
+        return true;
+      }
     }
     return false;
   }
@@ -227,16 +287,20 @@ struct Node {
     role = kLeader;
     last_index += 1;
     last_term = term;
-    first_idx = last_index;
+    set_first_idx(last_index);
     match(a.self) = last_index;
     (void)maybe_commit();
   }
   // raft.poll: the first response of a peer wins; returns {granted, recorded}
   __device__ void poll(uint32_t from, bool granted, uint32_t& n_granted, uint32_t& n_recorded) {
-    const uint32_t cur = (vw >> (2 * from)) & 3u;
-    if (cur != 1 && cur != 2) vw = (vw & ~(3u << (2 * from))) | ((granted ? 1u : 2u) << (2 * from));
+    uint32_t w = get_votes();
+    const uint32_t cur = (w >> (2 * from)) & 3u;
+    if (cur != 1 && cur != 2) {
+      w = (w & ~(3u << (2 * from))) | ((granted ? 1u : 2u) << (2 * from));
+      set_votes(w);
+    }
     const uint32_t low = 0x55555555u & ((1u << (2 * a.n_peers)) - 1u);
-    const uint32_t g1 = vw & ~(vw >> 1) & low, r1 = (vw >> 1) & ~vw & low;
+    const uint32_t g1 = w & ~(w >> 1) & low, r1 = (w >> 1) & ~w & low;
     n_granted = __popc(g1);
     n_recorded = __popc(g1 | r1);
   }
@@ -333,16 +397,16 @@ struct Node {
         }
       } else {
         if (m.type == kMsgApp) {
-          elapsed = 0; lead = m.from + 1;
+          elapsed_reset = true; lead = m.from + 1;
           handle_append(m, o);
         } else if (m.type == kMsgHeartbeat) {
-          elapsed = 0; lead = m.from + 1;
+          elapsed_reset = true; lead = m.from + 1;
           commit_to(m.commit);
           o.type = kOutHeartbeatResp;
         } else if (m.type == kMsgVote) {
           o.type = kOutVoteResp;
           const bool up_to_date = m.log_term > last_term || (m.log_term == last_term && m.index >= last_index);
-          if ((vote == 0 || vote == m.from + 1) && up_to_date) { elapsed = 0; vote = m.from + 1; }
+          if ((vote == 0 || vote == m.from + 1) && up_to_date) { elapsed_reset = true; vote = m.from + 1; }
           else o.reject = 1;
         }
       }
@@ -393,15 +457,6 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
 // (tests/test_step_gpu.py runs both paths).  A batch with a longer run sets the handle's `stall` word:
 // nothing of it -- nor of any later batch already in flight -- is applied, and the host replays those
 // batches, in order, through the sorted path (raftq_step.hip: replay_stalled).
-constexpr uint32_t kMaxRun = 32;
-constexpr uint32_t kNil = 0xffffffffu;
-
-struct ListArrays {
-  uint32_t* head;  // [ld] batch position of the last-linked message of the group, kNil = none
-  uint32_t* cnt;   // [ld] messages of the group in this batch
-  uint32_t* minp;  // [ld] smallest batch position of the group
-};
-
 // A slice [q0, q1) of the PREVIOUS batch's result records on its way to the host, carried by the first `blocks`
 // workgroups of a kernel of THIS batch (step_d2h_kernel's loop).  As a kernel of its own that copy holds back this
 // batch's kernels until it retires -- measured in round 1, profiles/r01/step_pipeline_trace.txt -- so a pipelined batch
@@ -425,7 +480,7 @@ __device__ __forceinline__ void copy_ride(const CopyRide& c) {
 
 static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* __restrict__ msgs, uint64_t n,
                                                                   uint64_t n_groups, uint32_t n_peers, bool from_wire,
-                                                                  ListArrays l, uint32_t* __restrict__ next,
+                                                                  NodeRec* rec, uint32_t* __restrict__ next,
                                                                   unsigned int* bad, unsigned int* stall, CopyRide ride) {
   if (blockIdx.x < ride.blocks) {
     copy_ride(ride);
@@ -443,9 +498,10 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
     is_bad = g >= n_groups || !known || (!local && from >= n_peers);
     if (from_wire) is_bad = is_bad || (msgs[i].pad[1] & 1u) != 0 || msgs[i].pad[0] >= n_peers;
     if (!is_bad) {
-      next[i] = atomicExch(&l.head[g], (uint32_t)i);
-      too_long = atomicAdd(&l.cnt[g], 1u) + 1 > kMaxRun;
-      atomicMin(&l.minp[g], (uint32_t)i);
+      NodeRec* r = rec + g;  // three atomics on one line
+      next[i] = atomicExch(&r->lst_head, (uint32_t)i);
+      too_long = atomicAdd(&r->lst_cnt, 1u) + 1 > kMaxRun;
+      atomicMin(&r->lst_min, (uint32_t)i);
     }
   }
   if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
@@ -454,7 +510,7 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
 
 static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
                                                                    void* __restrict__ out, bool compact, uint64_t n,
-                                                                   uint64_t n_groups, ListArrays l,
+                                                                   uint64_t n_groups,
                                                                    const uint32_t* __restrict__ next,
                                                                    unsigned long long* n_heads, unsigned int* tail_skipped,
                                                                    const unsigned int* bad, const unsigned int* stall, CopyRide ride) {
@@ -467,10 +523,10 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
   if (stalled || *bad) {             // (*bad: a malformed record somewhere in the batch) -- nothing is applied;
     if (stalled && i == 0) *tail_skipped = 1u;
     if (i < n && msgs[i].group < n_groups) {  // every message empties its group's list words (idempotent)
-      const uint64_t gg = msgs[i].group;
-      l.head[gg] = kNil;
-      l.cnt[gg] = 0;
-      l.minp[gg] = kNil;
+      NodeRec* r = a.rec + msgs[i].group;
+      r->lst_head = kNil;
+      r->lst_cnt = 0;
+      r->lst_min = kNil;
     }
     return;
   }
@@ -478,20 +534,20 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
   bool owner = false;
   if (i < n) {
     g = msgs[i].group;
-    owner = l.minp[g] == (uint32_t)i;
+    owner = a.rec[g].lst_min == (uint32_t)i;
   }
   const uint64_t ob = __ballot(owner);
   if ((threadIdx.x & 63) == 0 && ob) atomicAdd(n_heads, (unsigned long long)__popcll(ob));
   if (!owner) return;
-  const uint32_t c = l.cnt[g];
-  Node node(a, g);
+  Node node(a, g);  // (the record's line is in the L1 already: the owner test read it)
+  const uint32_t c = node.lst_cnt;
   if (c == 1) {
     StepOutRec o;
     node.step(msgs[i], o);
     put_result(out, i, o, compact);
   } else {
     uint32_t pos[kMaxRun];
-    uint32_t p = l.head[g];
+    uint32_t p = node.lst_head;
     for (uint32_t k = 0; k < c; ++k) {  // gather, inserting in ascending order of batch position
       uint32_t j = k;
       while (j > 0 && pos[j - 1] > p) {
@@ -508,12 +564,41 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
       put_result(out, pos[k], o, compact);
     }
   }
+  // the record goes back with the group's list empty for the next batch.  Other lanes of this group only compare lst_min
+  // with their own position to learn that they are not the owner: kNil tells them the same.
   node.store();
-  // the group's list goes back to empty for the next batch.  Other lanes of this group only compare minp with
-  // their own position to learn that they are not the owner: kNil tells them the same.
-  l.head[g] = kNil;
-  l.cnt[g] = 0;
-  l.minp[g] = kNil;
+}
+
+// ---- the record array's bulk paths (raftq_load_node / raftq_read_node: set-up and test traffic, not the hot path) ----------
+static __global__ __launch_bounds__(kBlock) void node_init_kernel(NodeRec* rec, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  NodeRec r;
+  __builtin_memset(&r, 0, sizeof r);
+  r.lst_head = r.lst_min = kNil;
+  rec[i] = r;
+}
+// field: 0 term, 1 vote, 2 lead, 3 last_index, 4 last_term.  `flat` is the ABI's array for groups [g0, g0 + n): u64 or u32.
+template <bool PUT>
+static __global__ __launch_bounds__(kBlock) void node_field_kernel(NodeRec* rec, uint64_t g0, uint64_t n, int field, void* flat) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  NodeRec* r = rec + g0 + i;
+  uint64_t* f64 = static_cast<uint64_t*>(flat);
+  uint32_t* f32 = static_cast<uint32_t*>(flat);
+  if (PUT) {
+    if (field == 0) r->term = f64[i];
+    else if (field == 1) r->vote = (uint8_t)f32[i];
+    else if (field == 2) r->lead = (uint8_t)f32[i];
+    else if (field == 3) r->last_index = f64[i];
+    else r->last_term = f64[i];
+  } else {
+    if (field == 0) f64[i] = r->term;
+    else if (field == 1) f32[i] = r->vote;
+    else if (field == 2) f32[i] = r->lead;
+    else if (field == 3) f64[i] = r->last_index;
+    else f64[i] = r->last_term;
+  }
 }
 
 // ---- (4) results -> pinned, device-mapped host memory.  A small grid (grid-stride, 16 B per lane): the
@@ -547,7 +632,7 @@ static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a,
   } else if (r.commit_to != 0) {
     node.commit_to(r.commit_to);
   }
-  node.store();
+  node.store(false);
   if (committed_out) committed_out[i] = node.committed;
 }
 

@@ -25,13 +25,29 @@ const (
 	MsgHeartbeatResp = C.RAFTQ_MSG_HEARTBEAT_RESP
 )
 
-// Msg is layout-identical to raftq_msg_t (64 bytes).
+// Msg is layout-identical to raftq_msg_t (64 bytes).  WireTo / Flags / Resv are padding -- ignored by the library --
+// unless the engine opted in with SetMsgFlags(true); a caller that opts in sets them on EVERY record (the staging
+// memory StepStage hands out is not zeroed).
 type Msg struct {
 	Group, Term, LogTerm, Index, Commit, RejectHint uint64
 	From                                            uint32 // peer slot = raft ID - 1
 	Type, Reject                                    uint8
-	_                                               [2]uint8
-	_                                               uint64
+	WireTo, Flags                                   uint8  // raftq_msg_t._pad: [1] = MsgfEntries | MsgfBarrier
+	Resv                                            uint64 // under MsgfEntries: low 32 bits = number of entries
+}
+
+const (
+	MsgfEntries = C.RAFTQ_MSGF_ENTRIES // on a MsgApp: Resv = entry count, RejectHint = the last entry's term
+	MsgfBarrier = C.RAFTQ_MSGF_BARRIER // on a MsgApp: what follows it in its group waits if it is left to the log's owner
+)
+
+// SetMsgFlags opts the engine in to (or out of) Msg.Flags / Msg.Resv; no batch may be in flight.
+func (e *Engine) SetMsgFlags(on bool) error {
+	v := C.int(0)
+	if on {
+		v = 1
+	}
+	return e.err(C.raftq_step_set_msg_flags(e.h, v))
 }
 
 // StepOut is layout-identical to raftq_step_out_t (64 bytes).

@@ -58,11 +58,18 @@ typedef struct raftq_msg {
   uint32_t from;        /* sender's peer slot 0..N-1 (raft ID - 1); ignored for local messages */
   uint8_t type;         /* RAFTQ_MSG_* */
   uint8_t reject;       /* m.Reject */
-  uint8_t _pad[2];      /* _pad[1]: RAFTQ_MSGF_* (every other bit: library use) */
-  uint64_t _resv;       /* library use, except under RAFTQ_MSGF_ENTRIES */
+  uint8_t _pad[2];      /* IGNORED unless the handle opted in (raftq_step_set_msg_flags): then _pad[1] = RAFTQ_MSGF_* */
+  uint64_t _resv;       /* IGNORED unless the handle opted in: then, under RAFTQ_MSGF_ENTRIES, low 32 bits = number of entries */
 } raftq_msg_t;          /* 64 bytes */
 
-/* raftq_msg_t._pad[1].  RAFTQ_MSGF_ENTRIES on a MsgApp: the caller says what the message carries -- the low 32 bits of
+/* The ten bytes behind `reject` are padding to every caller that has not said otherwise: raftq_step_stage hands out
+ * uninitialised memory, a caller that fills records field by field (the Go binding) never touches them, and whatever they
+ * hold is ignored.  raftq_step_set_msg_flags(h, 1) -- no batch in flight -- makes them mean what RAFTQ_MSGF_* says below
+ * for every batch submitted afterwards; such a caller writes all 64 bytes of every record.  (Round 3 gave the bits meaning
+ * unconditionally: stale staging bytes could be read as "this MsgApp carries N entries".) */
+int raftq_step_set_msg_flags(raftq_t* h, int on);
+
+/* raftq_msg_t._pad[1] once the handle opted in.  RAFTQ_MSGF_ENTRIES on a MsgApp: the caller says what the message carries -- the low 32 bits of
  * _resv = its number of entries, reject_hint (a field MsgApp does not use) = the Term of the last one (unused with no
  * entries).  Step then runs raftLog.maybeAppend itself whenever the message appends at the TAIL of the log (m.Index ==
  * lastIndex and m.LogTerm == lastTerm: findConflict has nothing to look at): lastIndex / lastTerm move past the new

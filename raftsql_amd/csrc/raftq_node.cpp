@@ -1023,6 +1023,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   if (!n) return RAFTQ_ENOMEM;
   int rc = raftq_create(device, n_groups, n_peers, &n->h);
   if (rc == RAFTQ_OK) rc = raftq_set_self(n->h, self_peer);
+  if (rc == RAFTQ_OK) rc = raftq_step_set_msg_flags(n->h, 1);  // this node fills every byte of every record it stages (RAFTQ_MSGF_*)
   if (rc != RAFTQ_OK) {
     if (n->h) raftq_destroy(n->h);
     delete n;

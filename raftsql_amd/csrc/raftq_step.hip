@@ -58,6 +58,7 @@ NodeArrays node_arrays(raftq_t* h) {
   a.ld = h->ld;
   a.n_peers = h->N;
   a.self = h->self_peer;
+  a.msg_flags = h->step_msg_flags;
   return a;
 }
 
@@ -342,6 +343,12 @@ int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n
     return fail(h, RAFTQ_ESTATE, "raftq_step_results_c: the last batch has full records (raftq_step_results)");
   *out = (const raftq_step_out_c_t*)h->step_last_out;
   *n = h->step_last_n;
+  return RAFTQ_OK;
+}
+
+int raftq_step_set_msg_flags(raftq_t* h, int on) {
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_step_set_msg_flags")) return rc;
+  h->step_msg_flags = on != 0;
   return RAFTQ_OK;
 }
 

@@ -71,6 +71,7 @@ struct NodeArrays {
   uint8_t* votes;   // [ld] packed vote words: 2 bits per peer, 16-bit words (N <= 8) or 32-bit (N = 9)
   uint64_t ld;
   uint32_t n_peers, self;
+  bool msg_flags;   // the handle opted in to RAFTQ_MSGF_* (raftq_step_set_msg_flags): otherwise a record's pad bytes are padding
 };
 
 constexpr uint8_t kMsgHup = 0, kMsgBeat = 1, kMsgApp = 3, kMsgAppResp = 4, kMsgVote = 5, kMsgVoteResp = 6,
@@ -314,7 +315,7 @@ struct Node {
   // raftLog.maybeAppend = matchTerm(tail) -> no conflict possible -> append -> commitTo(min(m.Commit, lastnewi)).
   __device__ void handle_append(const MsgRec& m, StepOutRec& o) {
     o.type = kOutAppend;
-    if ((m.pad[1] & kMsgfEntries) && m.index == last_index && m.log_term == last_term) {
+    if (a.msg_flags && (m.pad[1] & kMsgfEntries) && m.index == last_index && m.log_term == last_term) {
       const uint64_t k = m.resv & 0xffffffffull;
       if (k) {
         last_index = m.index + k;
@@ -411,7 +412,7 @@ struct Node {
         }
       }
     }
-    if (o.type == kOutAppend && m.type == kMsgApp && (m.pad[1] & kMsgfBarrier)) held = true;
+    if (a.msg_flags && o.type == kOutAppend && m.type == kMsgApp && (m.pad[1] & kMsgfBarrier)) held = true;
     o.group = g; o.term = term; o.commit = committed; o.last_index = last_index;
     o.to = m.from; o.vote = vote; o.lead = lead; o.role = role;
     if (term != term0 || vote != vote0 || committed != commit0) o.flags |= kFlagHardState;

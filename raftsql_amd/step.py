@@ -83,11 +83,16 @@ def expand_compact(msgs: np.ndarray, recs: np.ndarray) -> np.ndarray:
 class NodeEngine(QuorumEngine):
     """G raft groups' node state on one GPU + batched Step."""
 
-    def __init__(self, n_groups: int, n_peers: int, self_peer: int = 0, device: int = 0):
+    def __init__(self, n_groups: int, n_peers: int, self_peer: int = 0, device: int = 0, msg_flags: bool = True):
+        """msg_flags: opt the handle in to RAFTQ_MSGF_* (raftq_step_set_msg_flags).  This mirror's records are whole numpy
+        structs (pack_msgs zero-fills the pad bytes), so it opts in by default; a C / Go caller that fills records field by
+        field does not, and the ten bytes behind `reject` stay padding."""
         super().__init__(n_groups, n_peers, device=device)
         self.compact = False
         self.self_peer = int(self_peer)
         self._chk(self._lib.raftq_set_self(self._h, self.self_peer))
+        if msg_flags:
+            self._chk(self._lib.raftq_step_set_msg_flags(self._h, 1))
 
     def set_compact(self, on: bool = True) -> None:
         """result records in the 40-byte format from now on (no batch may be in flight)"""

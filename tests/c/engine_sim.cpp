@@ -31,7 +31,7 @@ struct raftq {
   std::vector<uint8_t> role, votes, action;
   std::vector<uint32_t> elapsed, vote, lead;
   std::vector<uint64_t> term, last_index, last_term, committed, first_idx, match;
-  bool have_terms = false, ticked = false;
+  bool have_terms = false, ticked = false, msg_flags = false;
   uint32_t election_tick = 10, heartbeat_tick = 1;
   uint64_t seed = 0x1000, tick_no = 0;
   std::vector<raftq_msg_t> stage;
@@ -231,6 +231,11 @@ int raftq_set_self(raftq_t* h, uint32_t self_peer) {
   h->self = self_peer;
   return RAFTQ_OK;
 }
+int raftq_step_set_msg_flags(raftq_t* h, int on) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  h->msg_flags = on != 0;
+  return RAFTQ_OK;
+}
 int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   if (election_tick == 0 || heartbeat_tick == 0) return fail(h, RAFTQ_EINVAL, "raftq_set_timers: ticks must be >= 1");
@@ -317,7 +322,16 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
     return fail(h, RAFTQ_ENOMEM, "raftq_step_batch: host allocation failed");
   }
   rq_node_state_t s = h->state();
-  rq_oracle_step_batch(&s, msgs, (size_t)n, h->outs.data());
+  if (h->msg_flags) {
+    rq_oracle_step_batch(&s, msgs, (size_t)n, h->outs.data());
+  } else {  // the pad bytes are padding to a handle that has not opted in (raftq_step_set_msg_flags)
+    std::vector<raftq_msg_t> plain(msgs, msgs + n);
+    for (raftq_msg_t& m : plain) {
+      m._pad[0] = m._pad[1] = 0;
+      m._resv = 0;
+    }
+    rq_oracle_step_batch(&s, plain.data(), (size_t)n, h->outs.data());
+  }
   h->n_out = n;
   if (out) std::copy(h->outs.begin(), h->outs.begin() + (size_t)n, out);
   if (counts) {

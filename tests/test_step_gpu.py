@@ -613,3 +613,37 @@ def test_barrier_table_on_the_gpu(NodeEngine, oracle, walk, monkeypatch):
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
         assert [int(t) for t in got["type"]] == want
         _stepgen.assert_same_state(e, s)
+
+
+def test_pad_bytes_are_padding_until_the_handle_opts_in():
+    """raftq_step_stage hands out uninitialised memory and a Go caller fills records field by field, so the ten
+    bytes behind `reject` must mean nothing unless the handle said so (raftq_step_set_msg_flags).  The same batch -- MsgApps
+    on the tail among it -- with garbage in every pad byte gives, on a handle that has not opted in, exactly what the batch
+    with zeroed pads gives; on a handle that has, the flags it happens to spell are honoured (the oracle's reading)."""
+    import copy
+
+    from raftsql_amd import step as S
+
+    G, N = 3000, 3
+    rng = np.random.default_rng(4242)
+    st = _stepgen.random_state(rng, G, N, self_peer=1)
+    m = _stepgen.random_batch(rng, st, 6000)
+    clean = m.copy()
+    clean["_pad"] = 0
+    clean["_resv"] = 0
+    dirty = clean.copy()
+    dirty["_pad"] = rng.integers(0, 256, dirty["_pad"].shape, dtype=np.uint8)
+    dirty["_resv"] = rng.integers(0, 2**63, len(dirty), dtype=np.uint64)
+    got = {}
+    for name, batch, opt_in in (("clean", clean, False), ("dirty", dirty, False), ("dirty, opted in", dirty, True)):
+        with S.NodeEngine(G, N, self_peer=1, msg_flags=opt_in) as e:
+            _stepgen.load_engine(e, st)
+            out, _ = e.step_batch(batch)
+            got[name] = (out.copy(), {k: np.array(v) for k, v in e.read_node().items()}, e.read_match().copy())
+    assert got["clean"][0].tobytes() == got["dirty"][0].tobytes()
+    for k in got["clean"][1]:
+        assert np.array_equal(got["clean"][1][k], got["dirty"][1][k]), k
+    assert np.array_equal(got["clean"][2], got["dirty"][2])
+    want = copy.deepcopy(st).step_batch(dirty)  # the oracle reads the flags the garbage spells
+    assert got["dirty, opted in"][0].tobytes() == want.tobytes()
+    assert want.tobytes() != got["clean"][0].tobytes()  # (and it does spell some: the opt-in is what makes them count)

@@ -7,6 +7,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
+
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -179,7 +183,24 @@ bool raftq_detail::host_can_write(void* p, size_t bytes) {
     covered = (uintptr_t)b;
   }
   std::fclose(f);
-  return covered >= hi;
+  if (covered < hi) return false;
+  // Mapped "rw" is not yet "a store works": in some containers / VMs the aperture is mapped and a store to it still faults
+  // (ADVICE r03).  Try one without risking a signal: a one-byte pwrite through /proc/self/mem goes through the kernel's
+  // access path and FAILS (EFAULT / EIO) where a store would have raised SIGBUS.  The buffer is fresh and about to be
+  // overwritten by its producer, so the byte written does not matter.  Three outcomes: written -> device staging;
+  // refused with EFAULT -> pinned host staging; the probe itself unavailable (no /proc/self/mem, EPERM, EIO: the mapping
+  // has no access method) -> the maps answer stands.  RAFTQ_STAGE=host forces pinned staging whatever is found here.
+  const int fd = ::open("/proc/self/mem", O_WRONLY | O_CLOEXEC);
+  if (fd < 0) return true;
+  const char zero = 0;
+  bool ok = true;
+  for (const uintptr_t at : {lo, hi - 1}) {
+    if (::pwrite(fd, &zero, 1, (off_t)at) == 1) continue;
+    if (errno == EFAULT) ok = false;
+    break;
+  }
+  ::close(fd);
+  return ok;
 }
 
 int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
@@ -207,6 +228,9 @@ int raftq_detail::ensure_ingest(raftq_t* h, size_t bytes) {
     }
     (void)hipGetLastError();
     h->bar_staging = false;  // no host-writable device memory here: pinned host memory from now on
+    if (std::getenv("RAFTQ_PROFILE"))
+      std::fprintf(stderr, "[raftq] the ack / inbound staging stays in pinned host memory: device memory behind the BAR is not "
+                           "host-writable here (RAFTQ_STAGE=host asks for this outright)\n");
   }
   HIPCHK(h, hipHostMalloc(&h->ingest_h, want, hipHostMallocMapped));
   HIPCHK(h, hipHostGetDevicePointer(&h->ingest_d, h->ingest_h, 0));
@@ -411,9 +435,10 @@ void raftq_destroy(raftq_t* h) {
   if (h->prof_n && std::getenv("RAFTQ_PROFILE"))
     std::fprintf(stderr,
                  "[raftq] cycle phases, avg us over %llu calls: stage/validate %.1f | enqueue scatter %.1f | enqueue sweep "
-                 "%.1f | enqueue collect %.1f | sync %.1f | copy-out %.1f\n",
+                 "%.1f | enqueue collect %.1f | sync %.1f | copy-out %.1f | turns that ended in the blocking wait instead of the "
+                 "polled flag: %llu\n",
                  (unsigned long long)h->prof_n, h->prof[0] / h->prof_n, h->prof[1] / h->prof_n, h->prof[2] / h->prof_n,
-                 h->prof[3] / h->prof_n, h->prof[4] / h->prof_n, h->prof[5] / h->prof_n);
+                 h->prof[3] / h->prof_n, h->prof[4] / h->prof_n, h->prof[5] / h->prof_n, (unsigned long long)h->flag_fallbacks);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->match);
@@ -1150,20 +1175,26 @@ static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
     const char* e = std::getenv("RAFTQ_CYCLE_WAIT");
     return !(e && std::strcmp(e, "block") == 0);
   }();
-  if (poll && flag_epoch) {
+  // A miss (the flag did not land within 2 ms; a turn is ~50 us) is either a slow turn -- a huge handle, a contended
+  // GPU, a profiler -- or a stack on which the flag never reaches the host.  One slow turn must not change the handle's
+  // steady state, so the wake-up is only given up after kMisses misses IN A ROW, and then tried again every
+  // kRetry turns; RAFTQ_PROFILE prints how many turns fell back to the blocking wait.
+  constexpr uint32_t kMisses = 8, kRetry = 1024;
+  const bool try_flag = poll && flag_epoch && (h->flag_misses < kMisses || (++h->flag_rested % kRetry) == 0);
+  if (try_flag) {
     volatile uint64_t* flag = h->h_total + 3;
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0;; ++i) {
       if (*flag == flag_epoch) {
         std::atomic_thread_fence(std::memory_order_acquire);
+        h->flag_misses = 0;
         return hipSuccess;
       }
       if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
     }
-    // The flag did not land within 2 ms (a turn is ~50 us): either the device is far behind or flags do not reach the
-    // host on this stack.  Do not spin a core for 2 ms on every turn from now on: later turns of this handle block.
-    h->stream_write_ok = false;
+    ++h->flag_misses;
   }
+  if (flag_epoch) ++h->flag_fallbacks;
   return hipStreamSynchronize(h->stream);
 }
 

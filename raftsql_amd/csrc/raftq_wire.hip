@@ -72,11 +72,6 @@ void* dev_view(const void* p) {
   }
   return d;
 }
-bool kernel_copies() {  // RAFTQ_WIRE_KERNEL_COPIES=0: the runtime's copies even for page-locked buffers (round 2's form; for A/B)
-  const char* e = std::getenv("RAFTQ_WIRE_KERNEL_COPIES");  // (read per call: the tests switch forms inside one process)
-  return !(e && e[0] == '0');
-}
-unsigned copy_blocks(uint64_t bytes) { return (unsigned)std::min<uint64_t>(kCopyBlocks, std::max<uint64_t>(1, (bytes / 16 + kBlock - 1) / kBlock)); }
 
 // totals / flags of the call -> wire_pin[0], wire_pin[1] (read after the next hipStreamSynchronize)
 int tail_to_pin(raftq_t* h, const uint64_t* total, unsigned long long* flag) {
@@ -88,8 +83,8 @@ int tail_to_pin(raftq_t* h, const uint64_t* total, unsigned long long* flag) {
 unsigned blocks_for(uint64_t lanes) { return (unsigned)((lanes + kBlock - 1) / kBlock); }
 
 // ---- the streaming form (one persistent kernel per call; raftq_wire_kernels.hpp) -----------------------------------
-bool fused_on() {  // RAFTQ_WIRE_FUSED=0: round 3's chain of copy-in / compute / copy-out kernels (for A/B)
-  const char* e = std::getenv("RAFTQ_WIRE_FUSED");
+bool streaming_on() {  // RAFTQ_WIRE_STREAMING=0: the copying form even for page-locked buffers (for A/B and the tests)
+  const char* e = std::getenv("RAFTQ_WIRE_STREAMING");  // (read per call: the tests switch forms inside one process)
   return !(e && e[0] == '0');
 }
 // Worker workgroups of a streaming kernel (RAFTQ_WIRE_WGS overrides): a tile is ~25 us of dependent work (flags, scratch
@@ -268,27 +263,12 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: null argument");
   if (n > kMaxItems || n_ents > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
-  Carver c;
-  const size_t o_msgs = c.take(n * sizeof(WireMsg)), o_ents = c.take(n_ents * sizeof(WireEnt)),
-               o_pool = c.take(pool_bytes), o_sizes = c.take((n + 1) * 8), o_off = c.take((n + 1) * 8),
-               o_bad = c.take(8), o_scan = c.take(scan_bytes);
-  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-  uint8_t* base = (uint8_t*)h->wire_dev;
-  WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
-  WireEnt* d_ents = (WireEnt*)(base + o_ents);
-  uint8_t* d_pool = base + o_pool;
-  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
-  unsigned int* d_bad = (unsigned int*)(h->wire_flags + 0);  // (o_bad: unused since the flags have a block of their own)
-  (void)o_bad;
-  // Page-locked caller buffers (what a node passes every turn): the whole call is ONE chain with ONE wait -- everything in
-  // with one launch, sizes, scan, the writers (which refuse a bad or oversized batch themselves), everything out with the
-  // last launch.  Anything else: the runtime's copies, and a wait in the middle to learn the size.
+  // page-locked caller buffers (what a node passes every turn) take the streaming form; anything else the copying form
   void *v_msgs = nullptr, *v_ents = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
-  const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_msgs = dev_view(msgs)) != nullptr &&
+  const bool mapped = streaming_on() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_msgs = dev_view(msgs)) != nullptr &&
                       (n_ents == 0 || (v_ents = dev_view(ents)) != nullptr) && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
                       (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
-  if (mapped && fused_on() && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool)) {
+  if (mapped && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool)) {
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
     const uint32_t n_tiles = blocks_for(n);
     const unsigned workers = fused_grid(n_tiles);
@@ -320,40 +300,20 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: out is too small (counts->bytes is the size needed)");
     return RAFTQ_OK;
   }
-  if (mapped) {
-    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-    uint8_t* d_out = (uint8_t*)h->wire_out;
-    const CopySegs in = {{{v_msgs, d_msgs, n * sizeof(WireMsg)}, {v_ents, d_ents, n_ents * sizeof(WireEnt)}, {v_pool, d_pool, pool_bytes}}};
-    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(n * sizeof(WireMsg) + n_ents * sizeof(WireEnt) + pool_bytes)), dim3(kBlock), 0,
-                       h->stream, in);
-    hipLaunchKernelGGL(wire_enc_size_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
-                       (const WireEnt*)d_ents, n_ents, pool_bytes, d_sizes, d_bad);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
-    const EncGuard guard = {h->wire_flags + 0, cap};
-    hipLaunchKernelGGL(wire_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
-                       (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out, guard);
-    if (n_ents)
-      hipLaunchKernelGGL(wire_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
-                         (const WireEnt*)d_ents, (const uint64_t*)d_off, (const uint8_t*)d_pool, d_out, guard);
-    hipLaunchKernelGGL(wire_enc_out_kernel, dim3(copy_blocks(cap / 4)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_out, (uint8_t*)v_out,
-                       (const uint64_t*)d_off, (uint64_t*)v_off, n, guard, h->wire_pin_d);
-    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, h->wire_flags + 0);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint64_t total = h->wire_pin[0];
-    if ((uint32_t)h->wire_pin[1])
-      return fail(h, RAFTQ_EINVAL,
-                  "raftq_wire_encode: a message has to / from >= 255, an entry range outside ents[], or a payload outside "
-                  "the pool; nothing was written");
-    if (counts) {
-      counts->n_msgs = n;
-      counts->n_ents = n_ents;
-      counts->bytes = total;
-    }
-    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_encode: out is too small (counts->bytes is the size needed)");
-    return RAFTQ_OK;
-  }
+  // the copying form: the runtime's copies, a wait in the middle to learn the size
+  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
+  Carver c;
+  const size_t o_msgs = c.take(n * sizeof(WireMsg)), o_ents = c.take(n_ents * sizeof(WireEnt)),
+               o_pool = c.take(pool_bytes), o_sizes = c.take((n + 1) * 8), o_off = c.take((n + 1) * 8),
+               o_bad = c.take(8), o_scan = c.take(scan_bytes);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  WireMsg* d_msgs = (WireMsg*)(base + o_msgs);
+  WireEnt* d_ents = (WireEnt*)(base + o_ents);
+  uint8_t* d_pool = base + o_pool;
+  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
+  unsigned int* d_bad = (unsigned int*)(h->wire_flags + 0);  // (o_bad: unused since the flags have a block of their own)
+  (void)o_bad;
   if (int rc = h2d(h, d_msgs, msgs, n * sizeof(WireMsg))) return rc;
   if (int rc = h2d(h, d_ents, ents, n_ents * sizeof(WireEnt))) return rc;
   if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
@@ -377,11 +337,11 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
   uint8_t* d_out = (uint8_t*)h->wire_out;
   hipLaunchKernelGGL(wire_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs, n,
-                     (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out, EncGuard{nullptr, 0});
+                     (const WireEnt*)d_ents, (const uint64_t*)d_off, d_out);
   if (n_ents)
     hipLaunchKernelGGL(wire_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                        (const WireMsg*)d_msgs, n, (const WireEnt*)d_ents, (const uint64_t*)d_off,
-                       (const uint8_t*)d_pool, d_out, EncGuard{nullptr, 0});
+                       (const uint8_t*)d_pool, d_out);
   HIPCHK(h, hipGetLastError());
   if (int rc = d2h(h, out, d_out, total)) return rc;
   if (frame_off)
@@ -402,9 +362,9 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   // an entry costs its message at least two bytes (tag, length), so this many can never be exceeded
   const uint64_t dev_cap = std::min<uint64_t>(ents_cap, nbytes / 2 + 1);
   void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
-  const bool mapped = kernel_copies() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+  const bool mapped = streaming_on() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
                       (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
-  if (mapped && fused_on() && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
+  if (mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
     // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
     // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
     const uint32_t n_tiles = blocks_for(n);
@@ -450,13 +410,9 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   WireEnt* d_ents = (WireEnt*)h->wire_out;
   unsigned long long* d_bad = h->wire_flags + 1;  // (o_bad: unused since the flags have a block of their own)
   (void)o_bad;
-  if (mapped) {
-    const CopySegs in = {{{v_stream, d_stream, nbytes}, {v_off, d_off, (n + 1) * 8}, {nullptr, nullptr, 0}}};
-    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(nbytes + (n + 1) * 8)), dim3(kBlock), 0, h->stream, in);
-  } else {
-    if (int rc = h2d(h, d_stream, stream, nbytes)) return rc;
-    if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
-  }
+  if (int rc = h2d(h, d_stream, stream, nbytes)) return rc;
+  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  
   hipLaunchKernelGGL(wire_dec_kernel, dim3(blocks_for(n + 1)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_stream,
                      nbytes, (const uint64_t*)d_off, n, d_msgs, d_cnt, d_bad);
   HIPCHK(h, hipGetLastError());
@@ -465,24 +421,6 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
                      nbytes, (const uint64_t*)d_off, n, d_msgs, (const uint64_t*)d_base, dev_cap ? d_ents : (WireEnt*)nullptr,
                      dev_cap);
   HIPCHK(h, hipGetLastError());
-  if (mapped) {  // records, the entry headers there turned out to be, totals: one launch, one wait
-    hipLaunchKernelGGL(wire_dec_out_kernel, dim3(copy_blocks(n * sizeof(WireMsg))), dim3(kBlock), 0, h->stream, (const WireMsg*)d_msgs,
-                       (WireMsg*)v_msgs, n, (const WireEnt*)d_ents, (WireEnt*)v_ents, dev_cap, (const uint64_t*)(d_base + n), d_bad,
-                       h->wire_pin_d);
-    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, d_bad);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint64_t total = h->wire_pin[0];
-    if (counts) {
-      counts->n_msgs = n;
-      counts->n_ents = total;
-      counts->n_malformed = h->wire_pin[1];
-      counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
-    }
-    if (ents && total > ents_cap)
-      return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
-    return RAFTQ_OK;
-  }
   if (int rc = tail_to_pin(h, d_base + n, d_bad)) return rc;
   if (int rc = d2h(h, msgs, d_msgs, n * sizeof(WireMsg))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -517,26 +455,12 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (!recs || (pool_bytes && !pool) || (cap && !out)) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: null argument");
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: batch too large");
   if (int rc = ensure_pin(h)) return rc;
-  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
-  Carver c;
-  const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
-               o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
-               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_scan = c.take(scan_bytes),
-               o_tot = c.take((size_t)blocks_for(n) * sizeof(CrcPair));
-  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-  uint8_t* base = (uint8_t*)h->wire_dev;
-  WalRec* d_recs = (WalRec*)(base + o_recs);
-  uint8_t* d_pool = base + o_pool;
-  uint32_t* d_pcrc = (uint32_t*)(base + o_pcrc);
-  CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
-  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
-  uint32_t* d_last = (uint32_t*)(base + o_flags) + 1;
-  // page-locked caller buffers: one chain, one wait (as raftq_wire_encode)
+  // page-locked caller buffers take the streaming form; anything else the copying form
   void *v_recs = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
-  const bool mapped = kernel_copies() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr &&
+  const bool mapped = streaming_on() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr &&
                       (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) && (v_out = dev_view(out)) != nullptr &&
                       (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
-  if (mapped && fused_on() && aligned16(v_recs) && aligned16(v_pool)) {
+  if (mapped && aligned16(v_recs) && aligned16(v_pool)) {
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
     const uint32_t n_tiles = blocks_for(n);
     const unsigned workers = fused_grid(n_tiles);
@@ -569,15 +493,25 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
     }
     return RAFTQ_OK;
   }
-  unsigned int* d_bad = mapped ? (unsigned int*)(h->wire_flags + 2) : (unsigned int*)(base + o_flags);
-  if (mapped) {
-    const CopySegs in = {{{v_recs, d_recs, n * sizeof(WalRec)}, {v_pool, d_pool, pool_bytes}, {nullptr, nullptr, 0}}};
-    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(n * sizeof(WalRec) + pool_bytes)), dim3(kBlock), 0, h->stream, in);
-  } else {
-    if (int rc = h2d(h, d_recs, recs, n * sizeof(WalRec))) return rc;
-    if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
-    HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
-  }
+  const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
+  Carver c;
+  const size_t o_recs = c.take(n * sizeof(WalRec)), o_pool = c.take(pool_bytes), o_pcrc = c.take(n * 4),
+               o_pair = c.take(n * 8), o_chain = c.take(n * 8), o_sizes = c.take((n + 1) * 8),
+               o_off = c.take((n + 1) * 8), o_flags = c.take(8), o_scan = c.take(scan_bytes),
+               o_tot = c.take((size_t)blocks_for(n) * sizeof(CrcPair));
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  uint8_t* base = (uint8_t*)h->wire_dev;
+  WalRec* d_recs = (WalRec*)(base + o_recs);
+  uint8_t* d_pool = base + o_pool;
+  uint32_t* d_pcrc = (uint32_t*)(base + o_pcrc);
+  CrcPair *d_pair = (CrcPair*)(base + o_pair), *d_chain = (CrcPair*)(base + o_chain);
+  uint64_t *d_sizes = (uint64_t*)(base + o_sizes), *d_off = (uint64_t*)(base + o_off);
+  uint32_t* d_last = (uint32_t*)(base + o_flags) + 1;
+  unsigned int* d_bad = (unsigned int*)(base + o_flags);
+  if (int rc = h2d(h, d_recs, recs, n * sizeof(WalRec))) return rc;
+  if (int rc = h2d(h, d_pool, pool, pool_bytes)) return rc;
+  HIPCHK(h, hipMemsetAsync(d_bad, 0, 8, h->stream));
+  
   hipLaunchKernelGGL(wal_enc_payload_crc_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                      (const WalRec*)d_recs, n, (const uint8_t*)d_pool, pool_bytes, d_pcrc);
   hipLaunchKernelGGL(wal_enc_crc_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
@@ -588,34 +522,6 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
                      (const CrcPair*)d_chain, d_sizes);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, exclusive_sum_u64((const uint64_t*)d_sizes, d_off, n + 1, (uint64_t*)(base + o_scan), h->stream));
-  if (mapped) {
-    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-    uint8_t* d_out = (uint8_t*)h->wire_out;
-    const EncGuard guard = {h->wire_flags + 2, cap};
-    hipLaunchKernelGGL(wal_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
-                       (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last, guard);
-    if (pool_bytes)
-      hipLaunchKernelGGL(wal_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
-                         (const CrcPair*)d_chain, (const uint64_t*)d_off, (const uint8_t*)d_pool, d_out, guard);
-    hipLaunchKernelGGL(wal_enc_out_kernel, dim3(copy_blocks(cap / 4)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_out, (uint8_t*)v_out,
-                       (const uint64_t*)d_off, (uint64_t*)v_off, n, guard, (const uint32_t*)d_last, h->wire_pin_d);
-    hipLaunchKernelGGL(wire_flag_reset_kernel, dim3(1), dim3(64), 0, h->stream, h->wire_flags + 2);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint64_t total = h->wire_pin[0];
-    if ((uint32_t)h->wire_pin[1])
-      return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: a record has an unknown kind or a payload outside the pool; nothing was written");
-    if (counts) {
-      counts->n_recs = n;
-      counts->bytes = total;
-    }
-    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
-    if (counts) {
-      counts->n_valid = n;
-      counts->last_crc = (uint32_t)h->wire_pin[2];
-    }
-    return RAFTQ_OK;
-  }
   if (int rc = d2h(h, &h->wire_pin[0], d_off + n, 8)) return rc;
   if (int rc = d2h(h, &h->wire_pin[1], d_bad, 4)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -630,11 +536,11 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, total + 16)) return rc;
   uint8_t* d_out = (uint8_t*)h->wire_out;
   hipLaunchKernelGGL(wal_enc_write_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const WalRec*)d_recs, n,
-                     (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last, EncGuard{nullptr, 0});
+                     (const CrcPair*)d_chain, (const uint64_t*)d_off, d_out, d_last);
   if (pool_bytes)
     hipLaunchKernelGGL(wal_enc_payload_kernel, dim3(blocks_for(n * 64)), dim3(kBlock), 0, h->stream,
                        (const WalRec*)d_recs, n, (const CrcPair*)d_chain, (const uint64_t*)d_off,
-                       (const uint8_t*)d_pool, d_out, EncGuard{nullptr, 0});
+                       (const uint8_t*)d_pool, d_out);
   HIPCHK(h, hipGetLastError());
   if (int rc = d2h(h, out, d_out, total)) return rc;
   if (frame_off)
@@ -661,7 +567,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   if (int rc = ensure_pin(h)) return rc;
   {
     void *f_bytes = nullptr, *f_off = nullptr, *f_recs = nullptr;
-    if (kernel_copies() && fused_on() && nbytes < (1ull << (kLbValueBits - 1)) && (nbytes == 0 || (f_bytes = dev_view(bytes)) != nullptr) &&
+    if (streaming_on() && nbytes < (1ull << (kLbValueBits - 1)) && (nbytes == 0 || (f_bytes = dev_view(bytes)) != nullptr) &&
         (f_off = dev_view(frame_off)) != nullptr && (f_recs = dev_view(recs)) != nullptr && aligned16(f_bytes) && aligned16(f_off)) {
       // page-locked caller buffers: the streaming form (readers | workers in one launch)
       const uint32_t n_tiles = blocks_for(n);
@@ -703,15 +609,11 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   unsigned long long* d_first_bad = (unsigned long long*)(base + o_tail);
   uint64_t* d_tail = (uint64_t*)(base + o_tail) + 1;
   void *v_bytes = nullptr, *v_off = nullptr, *v_recs = nullptr;
-  const bool mapped = kernel_copies() && (nbytes == 0 || (v_bytes = dev_view(bytes)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+  const bool mapped = streaming_on() && (nbytes == 0 || (v_bytes = dev_view(bytes)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
                       (v_recs = dev_view(recs)) != nullptr;
-  if (mapped) {
-    const CopySegs in = {{{v_bytes, d_bytes, nbytes}, {v_off, d_off, (n + 1) * 8}, {nullptr, nullptr, 0}}};
-    hipLaunchKernelGGL(wire_copy_in_kernel, dim3(copy_blocks(nbytes + (n + 1) * 8)), dim3(kBlock), 0, h->stream, in);
-  } else {
-    if (int rc = h2d(h, d_bytes, bytes, nbytes)) return rc;
-    if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
-  }
+  if (int rc = h2d(h, d_bytes, bytes, nbytes)) return rc;
+  if (int rc = h2d(h, d_off, frame_off, (n + 1) * 8)) return rc;
+  
   HIPCHK(h, hipMemsetAsync(d_first_bad, 0xff, 8, h->stream));
   hipLaunchKernelGGL(wal_dec_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, h->stream, (const uint8_t*)d_bytes, nbytes,
                      (const uint64_t*)d_off, n, prev_crc, d_recs, d_span, d_pair);
@@ -724,14 +626,9 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   hipLaunchKernelGGL(wal_dec_tail_kernel, dim3(1), dim3(64), 0, h->stream, (const CrcPair*)d_chain, n, prev_crc,
                      (const unsigned long long*)d_first_bad, d_tail);
   HIPCHK(h, hipGetLastError());
-  if (mapped) {
-    const CopySegs outs = {{{d_recs, v_recs, n * sizeof(WalRec)}, {d_tail, h->wire_pin_d, 16}, {nullptr, nullptr, 0}}};
-    hipLaunchKernelGGL(wire_copy_out_kernel, dim3(copy_blocks(n * sizeof(WalRec))), dim3(kBlock), 0, h->stream, outs);
-    HIPCHK(h, hipGetLastError());
-  } else {
-    if (int rc = d2h(h, recs, d_recs, n * sizeof(WalRec))) return rc;
-    if (int rc = d2h(h, &h->wire_pin[0], d_tail, 16)) return rc;
-  }
+  if (int rc = d2h(h, recs, d_recs, n * sizeof(WalRec))) return rc;
+  if (int rc = d2h(h, &h->wire_pin[0], d_tail, 16)) return rc;
+  
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (counts) {
     counts->n_recs = n;

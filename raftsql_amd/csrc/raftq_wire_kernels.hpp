@@ -244,110 +244,6 @@ static __global__ void wire_tail_kernel(const uint64_t* __restrict__ total, unsi
   }
 }
 
-// ---- a codec call's copies as kernels.  The runtime's copy of a caller's page-locked buffer goes to an SDMA engine, and
-// every switch between that engine and the compute queue costs the chain ~8 us of idle (profiles/r03/codec_timeline.txt: four
-// switches per raftq_wire_decode, 33 us of a 116 us call) on top of a second wait for the entries.  A workgroup copy
-// moves the same bytes over the same link from inside the queue: one launch brings everything in, the call's last
-// launch takes everything out -- records, as many entry headers as there turned out to be, the totals.
-// When the host does not wait for the sizes before it launches the writers (the one-wait form of raftq_wire_encode), the
-// writers decide for themselves: a batch with a bad message, or one that does not fit the caller's buffer, writes nothing.
-struct EncGuard {
-  const unsigned long long* bad;  // nullptr: the host has checked already
-  uint64_t cap;
-  __device__ bool refuses(const uint64_t* total) const { return bad != nullptr && (*bad != 0 || *total > cap); }
-};
-
-struct CopySeg {
-  const void* src;
-  void* dst;
-  uint64_t bytes;
-};
-struct CopySegs {
-  CopySeg s[3];
-};
-constexpr unsigned kCopyBlocks = 96;
-
-__device__ __forceinline__ void copy_bytes(const void* src, void* dst, uint64_t bytes, bool to_host) {
-  if (bytes == 0) return;
-  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
-  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-    const uint64_t quads = bytes >> 4;
-    const u32x4* s = static_cast<const u32x4*>(src);
-    u32x4* d = static_cast<u32x4*>(dst);
-    for (uint64_t q = tid; q < quads; q += stride) {
-      const u32x4 v = s[q];
-      if (to_host) __builtin_nontemporal_store(v, d + q);
-      else d[q] = v;
-    }
-    const uint64_t done = quads << 4;
-    if (tid < bytes - done) static_cast<uint8_t*>(dst)[done + tid] = static_cast<const uint8_t*>(src)[done + tid];
-  } else {
-    for (uint64_t b = tid; b < bytes; b += stride) static_cast<uint8_t*>(dst)[b] = static_cast<const uint8_t*>(src)[b];
-  }
-}
-
-static __global__ __launch_bounds__(kBlock) void wire_copy_in_kernel(CopySegs segs) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) copy_bytes(segs.s[k].src, segs.s[k].dst, segs.s[k].bytes, false);
-}
-
-// raftq_wire_decode's last launch: records out, the entry headers there turned out to be (if they fit), totals, flag reset
-static __global__ __launch_bounds__(kBlock) void wire_dec_out_kernel(const WireMsg* __restrict__ msgs, WireMsg* msgs_h, uint64_t n,
-                                                                     const WireEnt* __restrict__ ents, WireEnt* ents_h, uint64_t ents_cap,
-                                                                     const uint64_t* __restrict__ total, unsigned long long* flag,
-                                                                     uint64_t* __restrict__ pin) {
-  const uint64_t t = *total;
-  copy_bytes(msgs, msgs_h, n * sizeof(WireMsg), true);
-  if (ents_h != nullptr && t <= ents_cap) copy_bytes(ents, ents_h, t * sizeof(WireEnt), true);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    pin[0] = t;
-    pin[1] = *flag;
-  }
-}
-
-// raftq_wire_encode's last launch: the stream and its frame offsets out -- unless the batch was refused --, totals
-static __global__ __launch_bounds__(kBlock) void wire_enc_out_kernel(const uint8_t* __restrict__ out, uint8_t* out_h,
-                                                                     const uint64_t* __restrict__ off, uint64_t* off_h, uint64_t n,
-                                                                     EncGuard guard, uint64_t* __restrict__ pin) {
-  const uint64_t t = off[n];
-  if (!guard.refuses(off + n)) {
-    copy_bytes(out, out_h, t, true);
-    if (off_h != nullptr) copy_bytes(off, off_h, (n + 1) * 8, true);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    pin[0] = t;
-    pin[1] = *guard.bad;
-  }
-}
-
-// a call's results out (to_host) or its inputs in, up to three ranges a launch
-static __global__ __launch_bounds__(kBlock) void wire_copy_out_kernel(CopySegs segs) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) copy_bytes(segs.s[k].src, segs.s[k].dst, segs.s[k].bytes, true);
-}
-
-// raftq_wal_encode's last launch: the frames and their offsets out -- unless the batch was refused --, the totals, the chain's end
-static __global__ __launch_bounds__(kBlock) void wal_enc_out_kernel(const uint8_t* __restrict__ out, uint8_t* out_h,
-                                                                    const uint64_t* __restrict__ off, uint64_t* off_h, uint64_t n,
-                                                                    EncGuard guard, const uint32_t* __restrict__ last_crc,
-                                                                    uint64_t* __restrict__ pin) {
-  const uint64_t t = off[n];
-  if (!guard.refuses(off + n)) {
-    copy_bytes(out, out_h, t, true);
-    if (off_h != nullptr) copy_bytes(off, off_h, (n + 1) * 8, true);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    pin[0] = t;
-    pin[1] = *guard.bad;
-    pin[2] = *last_crc;
-  }
-}
-
-// the flag word of a call, zero again for the next one (a launch of its own: every workgroup of the out kernels reads it)
-static __global__ void wire_flag_reset_kernel(unsigned long long* flag) {
-  if (threadIdx.x == 0) *flag = 0;
-}
-
 // host side of the scan: bytes of scratch for the tile totals, and the two launches
 static inline size_t scan_sum_scratch_bytes(uint64_t n_items) { return (size_t)((n_items + kScanTile - 1) / kScanTile) * 8 + 8; }
 static inline hipError_t exclusive_sum_u64(const uint64_t* in, uint64_t* out, uint64_t n_items, uint64_t* tile_tot, hipStream_t st) {
@@ -531,8 +427,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_size_kernel(const Wire
 static __global__ __launch_bounds__(kBlock) void wire_enc_write_kernel(const WireMsg* __restrict__ msgs, uint64_t n,
                                                                        const WireEnt* __restrict__ ents,
                                                                        const uint64_t* __restrict__ off,
-                                                                       uint8_t* __restrict__ out, EncGuard guard) {
-  if (guard.refuses(off + n)) return;
+                                                                       uint8_t* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const WireMsg m = msgs[i];
@@ -571,8 +466,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_payload_kernel(const W
                                                                          const WireEnt* __restrict__ ents,
                                                                          const uint64_t* __restrict__ off,
                                                                          const uint8_t* __restrict__ pool,
-                                                                         uint8_t* __restrict__ out, EncGuard guard) {
-  if (guard.refuses(off + n)) return;
+                                                                         uint8_t* __restrict__ out) {
   const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (i >= n) return;
   const uint32_t n_ents = msgs[i].n_ents;
@@ -1194,8 +1088,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_write_kernel(const WalR
                                                                       const CrcPair* __restrict__ chain,
                                                                       const uint64_t* __restrict__ off,
                                                                       uint8_t* __restrict__ out,
-                                                                      uint32_t* __restrict__ last_crc, EncGuard guard) {
-  if (guard.refuses(off + n)) return;
+                                                                      uint32_t* __restrict__ last_crc) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const WalRec r = recs[i];
@@ -1236,8 +1129,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_payload_kernel(const Wa
                                                                         const CrcPair* __restrict__ chain,
                                                                         const uint64_t* __restrict__ off,
                                                                         const uint8_t* __restrict__ pool,
-                                                                        uint8_t* __restrict__ out, EncGuard guard) {
-  if (guard.refuses(off + n)) return;
+                                                                        uint8_t* __restrict__ out) {
   const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (i >= n) return;
   if (recs[i].data_len == 0 || !wal_has_payload(recs[i].kind)) return;

@@ -205,7 +205,9 @@ class RaftNode:
         self._chk(self._lib.raftq_node_recv(self._p, group, timeout_ms, self._buf, len(self._buf), C.byref(ln),
                                             C.byref(kind)))
         if kind.value == ENTRY:
-            return ENTRY, C.string_at(self._buf, min(ln.value, len(self._buf)))
+            if ln.value > len(self._buf):
+                raise RaftqError(_lib.RAFTQ_EINVAL, f"a committed payload of {ln.value} bytes does not fit recv()'s {len(self._buf)}-byte buffer")
+            return ENTRY, C.string_at(self._buf, ln.value)
         return kind.value, None
 
     def drain(self, group: int) -> list:
@@ -371,11 +373,15 @@ class Cluster:
         if lost is not None:
             lost_arr = np.ascontiguousarray(np.array(lost, dtype=np.uint8).reshape(-1))
             lost_ptr = lost_arr.ctypes.data
-        pub, rcs = self._crank_pub, self._crank_rcs  # (the crank writes every slot on every step)
+        pub, rcs = self._crank_pub, self._crank_rcs
+        rcs[:] = 0  # (a step that fails before any node's turn leaves them alone)
         rc = lib.raftq_crank_step(self._crank, mask, int(tick), lost_ptr, self.steps % self.N, pub.ctypes.data, rcs.ctypes.data)
         if rc != 0:
-            bad = int(np.nonzero(rcs)[0][0])
-            self.nodes[bad]._chk(int(rcs[bad]))
+            bad = np.nonzero(rcs)[0]
+            if len(bad):
+                self.nodes[int(bad[0])]._chk(int(rcs[int(bad[0])]))
+            raise RaftqError(rc, "raftq_crank_step failed before any node's turn (a live bit whose node was stopped without "
+                                 "stop() / restart()?)")
         self.last_published = pub.tolist()
         return sum(self.last_published)
 
@@ -436,8 +442,10 @@ class Cluster:
         for p, (pub, _) in zip(live, turns):
             self.last_published[p] = pub
         if self.native_transport:
-            # what is lost is decided here, sender by sender and addressee by addressee as the Python transport does (same
-            # draws from the same generator); the moving is done per ADDRESSEE, so with threads every node fills its own
+            # what is lost is decided here for every (sender, addressee) pair -- one draw per pair whether or not anything is
+            # queued, so under loss > 0 the dice fall differently than with the Python transport, which only draws for
+            # non-empty transfers (each mode is deterministic for its seed; they are not draw-for-draw the same); the moving
+            # is done per ADDRESSEE, so with threads every node fills its own
             # inbound buffer while the others fill theirs, and a node still sees its senders in slot order
             lost = self._lost_matrix(live)
             if self._pool is not None:

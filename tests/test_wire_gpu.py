@@ -309,18 +309,17 @@ def test_decode_entry_capacity(eng):
 
 
 def _form(monkeypatch, form):
-    """streaming: one kernel, readers | workers (the default on page-locked buffers); chain: round 3's copy-in -> kernels ->
-    copy-out on one stream (RAFTQ_WIRE_FUSED=0); runtime: the runtime's copies (RAFTQ_WIRE_KERNEL_COPIES=0)"""
-    monkeypatch.setenv("RAFTQ_WIRE_KERNEL_COPIES", "0" if form == "runtime" else "1")
-    monkeypatch.setenv("RAFTQ_WIRE_FUSED", "1" if form == "streaming" else "0")
+    """streaming: one kernel, readers | workers (the default on page-locked buffers); copying: the runtime's copies around
+    the kernel chain (RAFTQ_WIRE_STREAMING=0: what pageable buffers always get)"""
+    monkeypatch.setenv("RAFTQ_WIRE_STREAMING", "1" if form == "streaming" else "0")
 
 
-@pytest.mark.parametrize("copies", ["streaming", "chain", "runtime"])
+@pytest.mark.parametrize("copies", ["streaming", "copying"])
 @pytest.mark.parametrize("seed,n,big", [(171, 1, 0), (172, 900, 4), (173, 6000, 0), (174, 333, 1)])
 def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
     """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE launch with ONE wait and has to
     say and write exactly what the copying form does (the `runtime` rows): streams, offsets, records, entries, counts, the
-    entry capacity, refusals.  A refused call of the chain / runtime forms leaves the output alone; the streaming form has
+    entry capacity, refusals.  A refused call of the copying form leaves the output alone; the streaming form has
     tiles on their way out before the verdict exists, so its promise is the ABI's: nothing at or behind out[cap] is touched."""
     import ctypes as C
 
@@ -385,7 +384,7 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
                     _same(ge, we, "ents after a refusal")
 
 
-@pytest.mark.parametrize("copies", ["streaming", "chain", "runtime"])
+@pytest.mark.parametrize("copies", ["streaming", "copying"])
 @pytest.mark.parametrize("seed,n,big,prev", [(181, 1, 0, 0), (182, 700, 3, 0xDEADBEEF), (183, 5000, 40, 7)])
 def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypatch):
     """the WAL codecs the same way: every buffer page-locked -> one chain, one wait; bytes, offsets, CRC chain, records,

@@ -328,15 +328,19 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
     }
 
 
-def tick_measure(cfg, device, ticks=2000):
-    """rc.node.Tick() for every group as one launch (10 B per group: role 1 +
-    elapsed 4+4 + action 1).  1M groups is 10 MB -> cache-resident and launch-bound; reported as is."""
-    from raftsql_amd.engine import QuorumEngine
+def tick_measure(cfg, device, ticks=2000, members=8):
+    """rc.node.Tick() for every group as one launch (10 B per group: role 1 + elapsed 4+4 + action 1).  One
+    1M-group handle is 10 MB per launch -- cache-resident and launch-bound; a sweep set ticks `members` handles with ONE
+    dispatch (raftq_set_tick), 80 MB behind one launch boundary; raftq_tick_collect is the Tick plus both of its lists
+    (MsgHup / MsgBeat groups, ascending) in two launches and one wait."""
+    from raftsql_amd.engine import QuorumEngine, SweepSet
 
     G = cfg["G"]
-    e = QuorumEngine(G, cfg["N"], device=device)
     role = (np.arange(G) % 3).astype(np.uint8)
-    e.load_roles(role)
+    es = [QuorumEngine(G, cfg["N"], device=device) for _ in range(members)]
+    for e in es:
+        e.load_roles(role)
+    e = es[0]
     for _ in range(50):
         e.tick(want_counts=False)
     e.wait()
@@ -345,13 +349,50 @@ def tick_measure(cfg, device, ticks=2000):
         e.tick(want_counts=False)
     ms = e.timer_end()
     hup, beat = e.tick()
-    e.close()
     us = ms * 1e3 / ticks
+    t0 = time.perf_counter()
+    for _ in range(200):
+        _, nh, _, nb = e.tick_collect(hup_cap=4096, beat_cap=G)
+    us_collect = (time.perf_counter() - t0) / 200 * 1e6
+    with SweepSet(es) as s:
+        for _ in range(20):
+            s.tick()
+        s.wait()
+        s.timer_begin()
+        for _ in range(ticks // 4):
+            s.tick()
+        us_set = s.timer_end() * 1e3 / (ticks // 4)
+        # steady state: heartbeats keep resetting the followers' clocks, no timer is past its base timeout, nobody draws
+        # (above: no heartbeat ever arrives, two thirds of the groups time out again and again and every wave runs the
+        # timeout draw -- three 64-bit multiplies per group: that form is VALU-bound, not HBM-bound)
+        for x in es:
+            x.set_timers(1 << 20, 1, 0x1000)
+            x.load_roles(role)
+        for _ in range(20):
+            s.tick()
+        s.wait()
+        s.timer_begin()
+        for _ in range(ticks // 4):
+            s.tick()
+        us_set_quiet = s.timer_end() * 1e3 / (ticks // 4)
+    for x in es:
+        x.close()
     return {"what": "batched Tick (tickElection/tickHeartbeat) over all groups", "groups": G, "launch_us": us,
             "group_ticks_per_s": G / (us * 1e-6), "GBps": 10.0 * G / (us * 1e-6) / 1e9,
             "roofline": leg_roofline("hbm", "group", G, us * 1e-6, 5.0 * G, 5.0 * G,
                                      "role 1 + elapsed 4 in, elapsed 4 + action 1 out per group; 10 MB per launch is cache-resident "
                                      "and the launch boundary is a third of the time: launch-bound at this size"),
+            "set_dispatch": {"what": "raftq_set_tick: %d handles of %d groups, ONE dispatch per Tick" % (members, G), "members": members,
+                             "launch_us": us_set, "group_ticks_per_s": members * G / (us_set * 1e-6),
+                             "roofline": leg_roofline("hbm", "group", members * G, us_set * 1e-6, 5.0 * G * members, 5.0 * G * members,
+                                                      "the same 10 B per group, %d MB per dispatch; every follower past its base timeout "
+                                                      "(no heartbeats in this loop): every wave runs the timeout draw, VALU-bound" % (10 * members * G // 1000000)),
+                             "steady_state": {"what": "the same dispatch with no timer past its base timeout (what heartbeats keep true): no wave draws",
+                                              "launch_us": us_set_quiet, "group_ticks_per_s": members * G / (us_set_quiet * 1e-6),
+                                              "roofline": leg_roofline("hbm", "group", members * G, us_set_quiet * 1e-6, 5.0 * G * members,
+                                                                       5.0 * G * members, "10 B per group, no draw")}},
+            "tick_and_lists": {"what": "raftq_tick_collect: the Tick + its MsgHup and MsgBeat lists (ascending), two launches, one wait; "
+                                       "wall time of the call", "us_per_call": us_collect, "n_hup": nh, "n_beat": nb},
             "last_tick": {"n_hup": hup, "n_beat": beat}}
 
 

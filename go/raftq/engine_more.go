@@ -101,6 +101,20 @@ func (e *Engine) CollectHups(out []uint64) (uint64, error) {
 	return uint64(n), e.err(rc)
 }
 
+// TickCollect is one Tick and both of its lists in one call (raftq_tick_collect: two launches, one wait).
+func (e *Engine) TickCollect(hups, beats []uint64) (nHup, nBeat uint64, err error) {
+	var hp, bp *C.uint64_t
+	if len(hups) > 0 {
+		hp = (*C.uint64_t)(unsafe.Pointer(&hups[0]))
+	}
+	if len(beats) > 0 {
+		bp = (*C.uint64_t)(unsafe.Pointer(&beats[0]))
+	}
+	var nh, nb C.uint64_t
+	err = e.err(C.raftq_tick_collect(e.h, hp, C.uint64_t(len(hups)), &nh, bp, C.uint64_t(len(beats)), &nb))
+	return uint64(nh), uint64(nb), err
+}
+
 // Campaign is becomeCandidate for the groups named (distinct).
 func (e *Engine) Campaign(groups []uint64, selfPeer uint32) error {
 	if len(groups) == 0 {
@@ -218,6 +232,10 @@ func (e *Engine) TimerEnd() (float32, error) {
 func (s *Set) Size() uint32           { return uint32(C.raftq_set_size(s.s)) }
 func (s *Set) Stream() unsafe.Pointer { return C.raftq_set_get_stream(s.s) }
 func (s *Set) TimerBegin() error      { return s.err(C.raftq_set_timer_begin(s.s)) }
+
+// Tick is one Tick of every member as ONE dispatch (raftq_set_tick); Wait before reading a member's lists.
+func (s *Set) Tick() error { return s.err(C.raftq_set_tick(s.s)) }
+
 func (s *Set) TimerEnd() (float32, error) {
 	var ms C.float
 	err := s.err(C.raftq_set_timer_end(s.s, &ms))

@@ -218,6 +218,11 @@ int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
 /* ascending list of the leader groups the last raftq_tick sent MsgBeat to: they owe their followers a heartbeat
  * round (etcd tickHeartbeat -> Step(MsgBeat) -> bcastHeartbeat, reached from rc.node.Tick(), raft.go:223-224) */
 int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n);
+/* raftq_tick + both lists in one call: two launches and ONE wait (tick, then one kernel that ranks the MsgHup and the
+ * MsgBeat bitmaps into two ascending lists), where raftq_tick + raftq_collect_hups + raftq_collect_beats are five
+ * launches and two waits.  *n_hup / *n_beat receive the full counts even when they exceed the caps. */
+int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n_hup, uint64_t* beats, uint64_t beat_cap,
+                       uint64_t* n_beat);
 /* becomeCandidate for `n` distinct groups: role = candidate, elapsed = 0, votes
  * cleared, the candidate's own slot (`self_peer`) granted.  Term bookkeeping is
  * the caller's (raftq_apply_term_deltas). */
@@ -294,6 +299,9 @@ void* raftq_set_get_stream(const raftq_set_t* s);
 int raftq_set_mode(raftq_set_t* s, int mode, uint32_t persist_workgroups);
 /* enqueue one pass over every member on the set's stream */
 int raftq_set_sweep_async(raftq_set_t* s, unsigned flags);
+/* one Tick of every group of every member as ONE dispatch, enqueued on the set's stream; each member is left exactly as
+ * raftq_tick(member, NULL) would leave it (raftq_collect_hups / _beats / raftq_read_tick per member afterwards) */
+int raftq_set_tick(raftq_set_t* s);
 /* block until the set's stream is idle; tallies of each member's most recent sweep into
  * per_member[raftq_set_size] and / or their sum into *total (either may be NULL) */
 int raftq_set_wait(raftq_set_t* s, raftq_counts_t* per_member, raftq_counts_t* total);

@@ -85,6 +85,7 @@ _SIGS = [
     ("raftq_read_tick", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_collect_hups", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_collect_beats", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_tick_collect", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_campaign", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint32]),
     ("raftq_cycle", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_uint64), C.POINTER(Counts)]),
@@ -102,6 +103,7 @@ _SIGS = [
     ("raftq_set_mode", C.c_int, [_H, C.c_int, C.c_uint32]),
     ("raftq_set_sweep_async", C.c_int, [_H, C.c_uint]),
     ("raftq_set_wait", C.c_int, [_H, C.c_void_p, C.POINTER(Counts)]),
+    ("raftq_set_tick", C.c_int, [_H]),
     ("raftq_set_timer_begin", C.c_int, [_H]),
     ("raftq_set_timer_end", C.c_int, [_H, C.POINTER(C.c_float)]),
     ("raftq_sweep_many_async", C.c_int, [C.POINTER(_H), C.c_uint32, C.c_uint]),

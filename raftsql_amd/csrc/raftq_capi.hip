@@ -460,6 +460,7 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->hup_bits);
   (void)hipFree(h->beat_bits);
   (void)hipFree(h->tick_partials);
+  (void)hipFree(h->tick_offsets2);
   raftq_detail::free_node_state(h);
   raftq_detail::free_wire_state(h);
   if (h->stage_h) (void)hipHostFree(h->stage_h);
@@ -933,6 +934,8 @@ int raftq_detail::ensure_tick_state(raftq_t* h) {
   return RAFTQ_OK;
 }
 
+static int ensure_tick_offsets2(raftq_t* h, uint64_t nw);
+
 extern "C" {
 
 int raftq_set_timers(raftq_t* h, uint32_t election_tick, uint32_t heartbeat_tick, uint64_t seed) {
@@ -958,9 +961,7 @@ int raftq_load_roles(raftq_t* h, const uint8_t* role, const uint32_t* elapsed) {
   return RAFTQ_OK;
 }
 
-int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
-  if (int rc = use_device_idle(h, "raftq_tick")) return rc;
-  if (int rc = ensure_tick_state(h)) return rc;
+static TickArgs tick_args(const raftq_t* h, uint64_t tick_no) {
   TickArgs a;
   a.role = h->role;
   a.elapsed = h->elapsed;
@@ -970,10 +971,17 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
   a.partials = h->tick_partials;
   a.n_groups = h->G;
   a.seed = h->tick_seed;
-  a.tick_no = h->tick_no++;
+  a.tick_no = tick_no;
   a.election_tick = h->election_tick;
   a.heartbeat_tick = h->heartbeat_tick;
-  hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, a);
+  a.et_magic = h->election_tick == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / h->election_tick);
+  return a;
+}
+
+int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
+  if (int rc = use_device_idle(h, "raftq_tick")) return rc;
+  if (int rc = ensure_tick_state(h)) return rc;
+  hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
   HIPCHK(h, hipGetLastError());
   h->ticked = true;
   if (counts) {
@@ -990,6 +998,49 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
   }
   return RAFTQ_OK;
 }
+
+// Tick + both lists: two launches and ONE wait (raftq_tick, raftq_collect_hups and raftq_collect_beats are five launches
+// and two waits).  The lists land in the pinned advance buffer (8 bytes of its 24-byte entries each) and are copied out.
+int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n_hup, uint64_t* beats, uint64_t beat_cap, uint64_t* n_beat) {
+  if (int rc = use_device_idle(h, "raftq_tick_collect")) return rc;
+  if (!n_hup || !n_beat) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect: null count");
+  if ((hup_cap && !hups) || (beat_cap && !beats)) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect: null list with cap > 0");
+  if (int rc = ensure_tick_state(h)) return rc;
+  const uint64_t cap_h = std::min<uint64_t>(hup_cap, h->G), cap_b = std::min<uint64_t>(beat_cap, h->G);
+  if (int rc = ensure_adv(h, (cap_h + cap_b + 2) / 3 + 2)) return rc;
+  hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
+  h->ticked = true;
+  const uint64_t nw = h->gpad / 256;
+  const uint64_t *off_h = nullptr, *off_b = nullptr;
+  if (nw > (1u << 14)) {  // past 16K waves every workgroup summing its predecessors itself would show: scan first
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets, h->d_total, 0);
+    if (int rc = ensure_tick_offsets2(h, nw)) return rc;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->tick_offsets2, h->d_total + 1, 1);
+    off_h = h->offsets;
+    off_b = h->tick_offsets2;
+  }
+  uint64_t* list_d = (uint64_t*)h->adv_d;
+  hipLaunchKernelGGL(tick_lists_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits,
+                     (const uint64_t*)h->beat_bits, (const uint4*)h->tick_partials, list_d, cap_h, list_d + cap_h, cap_b, h->d_total, off_h, off_b);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *n_hup = h->h_total[0];
+  *n_beat = h->h_total[1];
+  const uint64_t* list_h = (const uint64_t*)h->adv_h;
+  if (const uint64_t take = std::min(*n_hup, cap_h)) std::memcpy(hups, list_h, take * 8);
+  if (const uint64_t take = std::min(*n_beat, cap_b)) std::memcpy(beats, list_h + cap_h, take * 8);
+  h->adv_listed = 0;
+  return RAFTQ_OK;
+}
+
+}  // extern "C"
+static int ensure_tick_offsets2(raftq_t* h, uint64_t nw) {
+  if (h->tick_offsets2) return RAFTQ_OK;
+  (void)nw;
+  HIPCHK(h, hipMalloc((void**)&h->tick_offsets2, (h->gpad / 256 + 1) * 8));
+  return RAFTQ_OK;
+}
+extern "C" {
 
 int raftq_read_tick(raftq_t* h, uint8_t* action, uint32_t* elapsed, uint8_t* role) {
   if (int rc = use_device_idle(h, "raftq_read_tick")) return rc;
@@ -1494,6 +1545,7 @@ void raftq_set_destroy(raftq_set_t* s) {
   for (int k = 0; k < 3; ++k) (void)hipFree(s->tab[k]);
   (void)hipFree(s->counts_d);
   (void)hipFree(s->np_d);
+  (void)hipFree(s->tick_tab);
   if (s->counts_h) (void)hipHostFree(s->counts_h);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1546,6 +1598,47 @@ int raftq_set_sweep_async(raftq_set_t* s, unsigned flags) {
   for (raftq_t* h : s->members) sweep_done(h, flags, gpl);
   s->swept = true;
   s->last_flags = flags;
+  return RAFTQ_OK;
+}
+
+// rc.node.Tick() for every group of every member: ONE dispatch (blockIdx.y = member), enqueued on the set's stream.  The
+// members' per-handle results (action bytes, the MsgHup / MsgBeat bitmaps and counts behind raftq_collect_hups / _beats /
+// raftq_read_tick) are what raftq_tick on each member would have left.
+int raftq_set_tick(raftq_set_t* s) {
+  if (int rc = set_ready(s, "raftq_set_tick")) return rc;
+  const size_t K = s->members.size();
+  bool stale = s->tick_tab == nullptr || s->tick_host.size() != K;
+  for (size_t m = 0; m < K; ++m) {
+    raftq_t* h = s->members[m];
+    if (h->step_collected != h->step_submitted)
+      return sfail(s, RAFTQ_ESTATE, "raftq_set_tick: a member has Step batches in flight; collect them first");
+    const bool fresh = h->role == nullptr;
+    if (int rc = ensure_tick_state(h)) return sfail(s, rc, h->err);
+    if (stale || fresh) {
+      stale = true;
+      continue;
+    }
+    const TickArgs now = tick_args(h, h->tick_no), &was = s->tick_host[m];
+    if (now.role != was.role || now.seed != was.seed || now.election_tick != was.election_tick || now.heartbeat_tick != was.heartbeat_tick ||
+        now.tick_no != was.tick_no + s->tick_since)
+      stale = true;  // a member was re-configured, or ticked on its own since the table was built
+  }
+  if (stale) {
+    if (!s->tick_tab) SETCHK(s, hipMalloc((void**)&s->tick_tab, K * sizeof(TickArgs)));
+    s->tick_host.resize(K);
+    for (size_t m = 0; m < K; ++m) s->tick_host[m] = tick_args(s->members[m], s->members[m]->tick_no);
+    SETCHK(s, hipMemcpyAsync(s->tick_tab, s->tick_host.data(), K * sizeof(TickArgs), hipMemcpyHostToDevice, s->stream));  // (pageable: staged before it returns)
+    s->tick_since = 0;
+  }
+  const uint64_t n_blocks = s->gpad / 1024;
+  hipLaunchKernelGGL(tick_set_kernel, dim3((unsigned)((n_blocks + kTickSetRounds - 1) / kTickSetRounds), (unsigned)K), dim3(kBlock), 0, s->stream,
+                     (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+  SETCHK(s, hipGetLastError());
+  ++s->tick_since;
+  for (raftq_t* h : s->members) {
+    ++h->tick_no;
+    h->ticked = true;
+  }
   return RAFTQ_OK;
 }
 

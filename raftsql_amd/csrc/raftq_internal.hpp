@@ -75,6 +75,7 @@ struct raftq {
   uint64_t* hup_bits = nullptr; // [gpad/64]
   uint64_t* beat_bits = nullptr; // [gpad/64]
   uint4* tick_partials = nullptr;  // [gpad/256]
+  uint64_t* tick_offsets2 = nullptr;  // [gpad/256 + 1]: the MsgBeat offsets of raftq_tick_collect on handles of more than 16K waves
   uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
   uint64_t tick_seed = 0x1000, tick_no = 0;
   bool ticked = false;
@@ -197,6 +198,10 @@ struct raftq_set {
   int mode = 0;                       // 0 = K-deep grid, 1 = persistent walk (RAFTQ_SET_MODE / raftq_set_mode)
   uint32_t persist_wgs = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // raftq_set_tick: device table of the members' TickArgs (as of tick_host), set ticks dispatched since it was built
+  raftqk::TickArgs* tick_tab = nullptr;
+  std::vector<raftqk::TickArgs> tick_host;
+  uint64_t tick_since = 0;
   std::string err;
 };
 

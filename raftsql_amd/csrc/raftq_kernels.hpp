@@ -934,6 +934,7 @@ struct TickArgs {
   uint64_t n_groups;     // padding groups never act
   uint64_t seed, tick_no;
   uint32_t election_tick, heartbeat_tick;
+  uint32_t et_magic;     // floor(2^32 / election_tick): x % election_tick without a division (tick_mod)
 };
 
 __device__ __forceinline__ uint32_t tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
@@ -944,48 +945,79 @@ __device__ __forceinline__ uint32_t tick_rand(uint64_t seed, uint64_t tick_no, u
   return (uint32_t)(z >> 32);
 }
 
-static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) {
+// x % d with magic = floor(2^32 / d): the quotient estimate is at most 2 short
+__device__ __forceinline__ uint32_t tick_mod(uint32_t x, uint32_t d, uint32_t magic) {
+  uint32_t r = x - __umulhi(x, magic) * d;
+  r = r >= d ? r - d : r;
+  return r >= d ? r - d : r;
+}
+
+// R consecutive 1,024-group blocks per workgroup (the set dispatch: every load of the R rounds issued before the first
+// compare, a quarter of the workgroups); block = what one workgroup of the R = 1 kernel owns, so bitmaps, action bytes
+// and per-wave counts have one layout whatever R is.  n_blocks: 1,024-group blocks of the handle (gpad / 1024).
+template <int R, bool NT = false>
+__device__ __forceinline__ void tick_tile(const TickArgs& a, uint64_t n_blocks) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t g = ((uint64_t)blockIdx.x * kBlock + tid) * 4;
-  const uint32_t roles = *reinterpret_cast<const uint32_t*>(a.role + g);
-  uint4 el = *reinterpret_cast<const uint4*>(a.elapsed + g);
-  uint32_t e[4] = {el.x, el.y, el.z, el.w};
-  uint32_t acts = 0;
-  uint32_t n_hup = 0, n_beat = 0;  // wave-uniform
-  uint64_t hb[4], bb[4];
+  uint32_t roles[R];
+  uint4 el[R];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t role = (roles >> (8 * k)) & 0xffu;
-    const bool valid = g + k < a.n_groups;
-    uint32_t v = e[k] + 1;
-    const bool beat = role == 2u && v >= a.heartbeat_tick;
-    const int64_t d = (int64_t)v - (int64_t)a.election_tick;
-    const bool hup = role != 2u && d >= 0 && d > (int64_t)(tick_rand(a.seed, a.tick_no, g + k) % a.election_tick);
-    const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
-    e[k] = !valid ? e[k] : (act ? 0u : v);
-    acts |= act << (8 * k);
-    hb[k] = __ballot(act == 1u);
-    bb[k] = __ballot(act == 2u);
-    n_hup += __popcll(hb[k]);
-    n_beat += __popcll(bb[k]);
+  for (int r = 0; r < R; ++r) {
+    const uint64_t blk = (uint64_t)blockIdx.x * R + r;
+    if (blk < n_blocks) {
+      const uint64_t g = (blk * kBlock + tid) * 4;
+      roles[r] = ldg<NT>(reinterpret_cast<const uint32_t*>(a.role + g));
+      const u32x4 v = ldg<NT>(reinterpret_cast<const u32x4*>(a.elapsed + g));
+      el[r].x = v.x; el[r].y = v.y; el[r].z = v.z; el[r].w = v.w;
+    }
   }
-  el.x = e[0]; el.y = e[1]; el.z = e[2]; el.w = e[3];
-  *reinterpret_cast<uint4*>(a.elapsed + g) = el;
-  *reinterpret_cast<uint32_t*>(a.action + g) = acts;
-  if (lane == 0) {
-    const uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * 4;  // 4 words per wave (256 groups)
-    u64x2 lo, hi;
-    lo.x = hb[0]; lo.y = hb[1]; hi.x = hb[2]; hi.y = hb[3];
-    *reinterpret_cast<u64x2*>(a.hup_bits + w0) = lo;
-    *reinterpret_cast<u64x2*>(a.hup_bits + w0 + 2) = hi;
-    lo.x = bb[0]; lo.y = bb[1]; hi.x = bb[2]; hi.y = bb[3];
-    *reinterpret_cast<u64x2*>(a.beat_bits + w0) = lo;
-    *reinterpret_cast<u64x2*>(a.beat_bits + w0 + 2) = hi;
-    uint4 r;
-    r.x = n_hup; r.y = n_beat; r.z = 0; r.w = 0;
-    a.partials[(uint64_t)blockIdx.x * kWaves + wave] = r;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t blk = (uint64_t)blockIdx.x * R + r;
+    if (blk >= n_blocks) break;  // workgroup-uniform
+    const uint64_t g = (blk * kBlock + tid) * 4;
+    uint32_t e[4] = {el[r].x, el[r].y, el[r].z, el[r].w};
+    uint32_t acts = 0;
+    uint32_t n_hup = 0, n_beat = 0;  // wave-uniform
+    uint64_t hb[4], bb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t role = (roles[r] >> (8 * k)) & 0xffu;
+      const bool valid = g + k < a.n_groups;
+      uint32_t v = e[k] + 1;
+      const bool beat = role == 2u && v >= a.heartbeat_tick;
+      const int64_t d = (int64_t)v - (int64_t)a.election_tick;
+      // the draw (three 64-bit multiplies and a 32-bit modulo per group) only where a timer is past its base timeout: the
+      // Tick was VALU-bound with it computed for every group -- 84 MB in 22 us on a chip that streams them in 11
+      bool hup = role != 2u && d >= 0;
+      if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(a.seed, a.tick_no, g + k), a.election_tick, a.et_magic);
+      const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
+      e[k] = !valid ? e[k] : (act ? 0u : v);
+      acts |= act << (8 * k);
+      hb[k] = __ballot(act == 1u);
+      bb[k] = __ballot(act == 2u);
+      n_hup += __popcll(hb[k]);
+      n_beat += __popcll(bb[k]);
+    }
+    u32x4 out;
+    out.x = e[0]; out.y = e[1]; out.z = e[2]; out.w = e[3];
+    stg<NT>(reinterpret_cast<u32x4*>(a.elapsed + g), out);
+    stg<NT>(reinterpret_cast<uint32_t*>(a.action + g), acts);
+    if (lane == 0) {
+      const uint64_t w0 = (blk * kWaves + wave) * 4;  // 4 words per wave (256 groups)
+      u64x2 lo, hi;
+      lo.x = hb[0]; lo.y = hb[1]; hi.x = hb[2]; hi.y = hb[3];
+      *reinterpret_cast<u64x2*>(a.hup_bits + w0) = lo;
+      *reinterpret_cast<u64x2*>(a.hup_bits + w0 + 2) = hi;
+      lo.x = bb[0]; lo.y = bb[1]; hi.x = bb[2]; hi.y = bb[3];
+      *reinterpret_cast<u64x2*>(a.beat_bits + w0) = lo;
+      *reinterpret_cast<u64x2*>(a.beat_bits + w0 + 2) = hi;
+      uint4 pr;
+      pr.x = n_hup; pr.y = n_beat; pr.z = 0; pr.w = 0;
+      a.partials[blk * kWaves + wave] = pr;
+    }
   }
 }
+static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) { tick_tile<1>(a, gridDim.x); }
 
 static __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hup_bits, const uint64_t* offsets,
                                                               uint64_t* out, uint64_t cap) {
@@ -1004,6 +1036,108 @@ static __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint6
       ++rank;
     }
   }
+}
+
+// Both lists of a Tick in ONE launch, no scan launch in front of it: a workgroup owns the four waves (1,024 groups) of one
+// tick_kernel workgroup and computes the exclusive offsets of its first wave itself, as the sums of the per-wave MsgHup /
+// MsgBeat counts of every wave before it (L2-resident words, as compact_changed_kernel does for the advance list), then
+// ranks its own bits.  Ascending group ids in both lists; the last workgroup publishes the two totals.  The host hands in
+// scan_partials_kernel's offsets instead when the handle has more than 16K waves (wave_off_* != nullptr).
+static __global__ __launch_bounds__(kBlock) void tick_lists_kernel(const uint64_t* __restrict__ hup_bits, const uint64_t* __restrict__ beat_bits,
+                                                                    const uint4* __restrict__ partials, uint64_t* hup_out, uint64_t hup_cap,
+                                                                    uint64_t* beat_out, uint64_t beat_cap, uint64_t* totals /*[2]*/,
+                                                                    const uint64_t* __restrict__ wave_off_hup,
+                                                                    const uint64_t* __restrict__ wave_off_beat) {
+  __shared__ uint64_t red[2][kWaves];
+  __shared__ uint32_t mine[2][kWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t first_wave = (uint64_t)blockIdx.x * kWaves;
+  uint64_t acc_h = 0, acc_b = 0;
+  if (wave_off_hup == nullptr) {
+    uint32_t h0 = 0, h1 = 0, b0 = 0, b1 = 0;
+    uint64_t i = tid;
+    for (; i + kBlock < first_wave; i += 2 * kBlock) {
+      const uint4 p0 = partials[i], p1 = partials[i + kBlock];
+      h0 += p0.x; b0 += p0.y;
+      h1 += p1.x; b1 += p1.y;
+    }
+    if (i < first_wave) {
+      const uint4 p0 = partials[i];
+      h0 += p0.x; b0 += p0.y;
+    }
+    acc_h = (uint64_t)h0 + h1;
+    acc_b = (uint64_t)b0 + b1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      acc_h += __shfl_xor(acc_h, o, 64);
+      acc_b += __shfl_xor(acc_b, o, 64);
+    }
+  } else if (lane == 0 && wave == 0) {
+    acc_h = wave_off_hup[first_wave];
+    acc_b = wave_off_beat[first_wave];
+  }
+  if (lane == 0) {
+    red[0][wave] = acc_h;
+    red[1][wave] = acc_b;
+  }
+  if (tid < kWaves) {
+    const uint4 p = partials[first_wave + tid];
+    mine[0][tid] = p.x;
+    mine[1][tid] = p.y;
+  }
+  __syncthreads();
+  uint64_t pos_h = 0, pos_b = 0;
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) {
+    pos_h += red[0][k];
+    pos_b += red[1][k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    uint64_t th = pos_h, tb = pos_b;
+    for (int k = 0; k < kWaves; ++k) {
+      th += mine[0][k];
+      tb += mine[1][k];
+    }
+    totals[0] = th;
+    totals[1] = tb;
+  }
+  for (uint32_t k = 0; k < wave; ++k) {
+    pos_h += mine[0][k];
+    pos_b += mine[1][k];
+  }
+  const uint64_t wv = first_wave + wave;
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint64_t hb[4], bb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hb[k] = hup_bits[wv * 4 + k];
+    bb[k] = beat_bits[wv * 4 + k];
+  }
+  uint64_t rh = pos_h + __popcll(hb[0] & below) + __popcll(hb[1] & below) + __popcll(hb[2] & below) + __popcll(hb[3] & below);
+  uint64_t rb = pos_b + __popcll(bb[0] & below) + __popcll(bb[1] & below) + __popcll(bb[2] & below) + __popcll(bb[3] & below);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t g = wv * 256 + 4ull * lane + k;
+    if ((hb[k] >> lane) & 1) {
+      if (rh < hup_cap) hup_out[rh] = g;
+      ++rh;
+    }
+    if ((bb[k] >> lane) & 1) {
+      if (rb < beat_cap) beat_out[rb] = g;
+      ++rb;
+    }
+  }
+}
+
+// A Tick of every member of a sweep set in ONE dispatch (blockIdx.y = member): the members' TickArgs come from a device
+// table; tick_no advances by `ticks_since` from what the table holds (the host rebuilds the table when a member was
+// ticked on its own in between).  1M groups per launch is launch-bound (10 MB: 4.4 us, 0.29 of the HBM peak); eight
+// members per dispatch move 80 MB behind one launch boundary.
+constexpr int kTickSetRounds = 4;
+static __global__ __launch_bounds__(kBlock) void tick_set_kernel(const TickArgs* __restrict__ tab, uint64_t ticks_since, uint64_t n_blocks) {
+  TickArgs a = tab[blockIdx.y];
+  a.tick_no += ticks_since;
+  tick_tile<kTickSetRounds, true>(a, n_blocks);
 }
 
 // becomeCandidate for a list of (distinct) groups: role = candidate, elapsed = 0,

@@ -433,7 +433,7 @@ struct raftq_node {
   std::mutex turn_mu;  // one advance() at a time
   raftq_node_stats_t stats{};
   // scratch of advance()
-  std::vector<uint64_t> tick_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
+  std::vector<uint64_t> tick_list, beat_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
   std::vector<uint32_t> work, batch, deferred;  // positions (see kLocal)
   std::vector<raftq_wire_msg_t> local;          // the turn's locally raised messages (MsgHup)
   std::vector<Entry> ent_tmp;
@@ -1353,24 +1353,23 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     lk.unlock();
     // the device compacts the two short lists (ascending group ids); no G-byte read-back and no loop over every
     // group under the lock (O(G) host work per 100 ms tick at 1M groups)
-    int rc = raftq_tick(n->h, nullptr);
+    // one call: the Tick and both of its lists (two launches, one wait).  A list that does not fit is fetched again alone.
     uint64_t n_hup = 0, n_beat = 0;
-    if (rc == RAFTQ_OK) rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
+    if (n->beat_list.size() < n->tick_list.size()) n->beat_list.resize(n->tick_list.size());
+    int rc = raftq_tick_collect(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup, n->beat_list.data(), n->beat_list.size(), &n_beat);
     if (rc == RAFTQ_OK && n_hup > n->tick_list.size()) {
       n->tick_list.resize(n_hup);
       rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
     }
-    if (rc != RAFTQ_OK) return poison(n, rc, "tick");
-    for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, n->tick_list[i], RAFTQ_MSG_HUP));
-    rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
-    if (rc == RAFTQ_OK && n_beat > n->tick_list.size()) {
-      n->tick_list.resize(n_beat);
-      rc = raftq_collect_beats(n->h, n->tick_list.data(), n->tick_list.size(), &n_beat);
+    if (rc == RAFTQ_OK && n_beat > n->beat_list.size()) {
+      n->beat_list.resize(n_beat);
+      rc = raftq_collect_beats(n->h, n->beat_list.data(), n->beat_list.size(), &n_beat);
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "tick");
+    for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, n->tick_list[i], RAFTQ_MSG_HUP));
     lk.lock();
     for (uint64_t i = 0; i < n_beat; ++i) {
-      const uint64_t gi = n->tick_list[i];
+      const uint64_t gi = n->beat_list[i];
       if (n->groups[gi].role == RAFTQ_ROLE_LEADER) bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat: host only
     }
   }

@@ -404,6 +404,17 @@ class QuorumEngine:
         self._chk(self._lib.raftq_collect_beats(self._h, _ptr(out) if cap else None, cap, C.byref(n)))
         return out[: min(cap, int(n.value))], int(n.value)
 
+    def tick_collect(self, hup_cap: Optional[int] = None, beat_cap: Optional[int] = None):
+        """raftq_tick_collect: one Tick and both of its lists, two launches and one wait
+        -> (hups, n_hup, beats, n_beat)"""
+        hc = self.n_groups if hup_cap is None else int(hup_cap)
+        bc = self.n_groups if beat_cap is None else int(beat_cap)
+        hups, beats = np.empty(hc, dtype=np.uint64), np.empty(bc, dtype=np.uint64)
+        nh, nb = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._lib.raftq_tick_collect(self._h, _ptr(hups) if hc else None, hc, C.byref(nh), _ptr(beats) if bc else None, bc,
+                                               C.byref(nb)))
+        return hups[: min(hc, int(nh.value))], int(nh.value), beats[: min(bc, int(nb.value))], int(nb.value)
+
     def campaign(self, groups, self_peer: int = 0) -> None:
         g = np.ascontiguousarray(groups, dtype=np.uint64)
         self._chk(self._lib.raftq_campaign(self._h, _ptr(g) if len(g) else None, len(g), self_peer))
@@ -472,6 +483,10 @@ class SweepSet:
 
     def sweep_async(self, flags: int) -> None:
         self._chk(self._lib.raftq_set_sweep_async(self._s, flags))
+
+    def tick(self) -> None:
+        """raftq_set_tick: one Tick of every member as ONE dispatch (enqueued; wait() before reading a member)"""
+        self._chk(self._lib.raftq_set_tick(self._s))
 
     def wait(self, want_counts: bool = False):
         """-> None | (per-member [SweepCounts], total SweepCounts)"""

@@ -291,6 +291,11 @@ int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
 }
 int raftq_collect_hups(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) { return tick_list(h, "raftq_collect_hups", 1, groups, cap, n); }
 int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n) { return tick_list(h, "raftq_collect_beats", 2, groups, cap, n); }
+int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n_hup, uint64_t* beats, uint64_t beat_cap, uint64_t* n_beat) {
+  if (int rc = raftq_tick(h, nullptr)) return rc;
+  if (int rc = tick_list(h, "raftq_tick_collect", 1, hups, hup_cap, n_hup)) return rc;
+  return tick_list(h, "raftq_tick_collect", 2, beats, beat_cap, n_beat);
+}
 
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {
   if (!h || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_stage: null argument");

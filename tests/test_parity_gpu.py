@@ -624,6 +624,65 @@ def test_tick_parity(gpu_engine_cls, oracle, G):
             assert n2 == rh and len(hups2) == min(2, rh)
             beats2, nb2 = e.collect_beats(cap=3)
             assert nb2 == rb and np.array_equal(beats2, np.nonzero(ref_act == 2)[0][:3].astype(np.uint64))
+            # the one-call form: the Tick and both lists, two launches and one wait (raftq_tick_collect); whole lists, then
+            # caps below the counts (the counts still say what there was)
+            for t in range(25, 40):
+                caps = (None, None) if t % 3 else (1, 2)
+                hups, nh, beats, nb = e.tick_collect(*caps)
+                ref_el, ref_act, rh, rb = oracle.tick(role, ref_el, et, hb, seed, t)
+                want_h, want_b = np.nonzero(ref_act == 1)[0].astype(np.uint64), np.nonzero(ref_act == 2)[0].astype(np.uint64)
+                assert (nh, nb) == (rh, rb)
+                assert np.array_equal(hups, want_h[: len(hups)]) and np.array_equal(beats, want_b[: len(beats)])
+                assert len(hups) == (rh if caps[0] is None else min(1, rh)) and len(beats) == (rb if caps[1] is None else min(2, rb))
+                act, got_el, _ = e.read_tick()
+                assert np.array_equal(act, ref_act) and np.array_equal(got_el, ref_el)
+
+
+def test_set_tick_is_every_members_tick(gpu_engine_cls, oracle):
+    """raftq_set_tick: one dispatch ticks every member; each member is left as its own raftq_tick would leave it -- also
+    when a member is ticked on its own, or re-configured, between set ticks (the set's table is rebuilt)."""
+    from raftsql_amd.engine import SweepSet
+
+    G, K = 70001, 4
+    rng = np.random.default_rng(77)
+    roles = [rng.integers(0, 3, G).astype(np.uint8) for _ in range(K)]
+    els = [rng.integers(0, 25, G).astype(np.uint32) for _ in range(K)]
+    es = [gpu_engine_cls(G, 3) for _ in range(K)]
+    cfg = [(10, 1, 0x1000 + k) for k in range(K)]
+    ticks = [0] * K
+    for e, r, el, c in zip(es, roles, els, cfg):
+        e.set_timers(*c)
+        e.load_roles(r, el)
+    ref = [el.copy() for el in els]
+
+    def check(k):
+        act, got_el, _ = es[k].read_tick()
+        assert np.array_equal(act, check.act[k]) and np.array_equal(got_el, ref[k]), k
+        hups, n = es[k].collect_hups()
+        assert np.array_equal(hups, np.nonzero(check.act[k] == 1)[0].astype(np.uint64))
+
+    check.act = [None] * K
+
+    def oracle_tick(k):
+        ref[k], check.act[k], _, _ = oracle.tick(roles[k], ref[k], cfg[k][0], cfg[k][1], cfg[k][2], ticks[k])
+        ticks[k] += 1
+
+    with SweepSet(es) as s:
+        for step in range(12):
+            if step == 4:  # a member ticked on its own in between
+                es[2].tick(want_counts=False)
+                oracle_tick(2)
+            if step == 7:  # a member re-configured in between
+                cfg[1] = (6, 2, 999)
+                es[1].set_timers(*cfg[1])
+            s.tick()
+            for k in range(K):
+                oracle_tick(k)
+            s.wait()
+            for k in range(K):
+                check(k)
+    for e in es:
+        e.close()
 
 
 def test_election_round_trip(gpu_engine_cls, oracle):

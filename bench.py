@@ -47,19 +47,62 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
 HBM_COPY_CEILING_GBPS = 6290.0
 PCIE_PEAK_GBPS = 63.0  # PCIe Gen5 x16, one direction
+PCIE_DUPLEX_GBPS = 83.0  # both directions at once from ONE kernel on this box's link (profiles/r04/pcie_duplex_probe.jsonl: 2 x 41.5)
 
 
-def leg_roofline(bound, unit_name, units, seconds, bytes_in=0.0, bytes_out=0.0, note=""):
+_LEG_PMC = None
+
+
+def leg_traffic(kernels, launches_per_unit=1.0):
+    """HBM traffic of a side leg's kernels from the committed PMC passes (profiles/pmc_traffic_legs.json, written by
+    tools/pmc_legs.py on the GPU box: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_* in separate passes, calibrated on
+    a wide stream, a one-word-per-line gather and a one-word-per-line scatter).  `kernels`: name fragments.  Per matching
+    kernel the bytes are read the way its access pattern was calibrated: a streaming kernel (lane-consecutive 16-byte
+    accesses) by FETCH_SIZE / WRITE_SIZE x the stream factors (FETCH_SIZE counts a 128-byte request as 64: x2.00), a
+    scattered one (one word per line) by its fabric requests (x 64 B read, x 32 / 64 B written).  Summed, per launch.
+    -> dict | None when no record matches."""
+    global _LEG_PMC
+    if _LEG_PMC is None:
+        try:
+            _LEG_PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_legs.json")))
+        except Exception:  # noqa: BLE001
+            _LEG_PMC = {}
+    found = {}
+    for name, rec in _LEG_PMC.get("kernels", {}).items():
+        if any(k in name for k in kernels):
+            b = rec["bytes_stream_calibrated"] if rec.get("pattern") == "stream" else rec["bytes_from_requests"]
+            found[name.split("<")[0].replace("raftqk::", "")] = {"read": b["read"], "write": b["write"], "pattern": rec.get("pattern"),
+                                                                  "dispatches": rec["dispatches"]}
+    if not found:
+        return None
+    total = sum(v["read"] + v["write"] for v in found.values()) * launches_per_unit
+    return {"bytes": total, "kernels": found, "measured_at": _LEG_PMC.get("commit")}
+
+
+def leg_roofline(bound, unit_name, units, seconds, bytes_in=0.0, bytes_out=0.0, note="", traffic=None, algorithmic=None):
     """The roofline object of a side leg, judged the way the headline is.  `bound`: what limits the
     leg -- "pcie" (achieved = the busier direction's bytes / time against one direction's 63 GB/s), "hbm" (read + write
-    bytes / time against 8 TB/s) or "launch" (a chain of dependent launches: the bytes are given for the record, the
-    fraction is of the limit named in `vs`).  bytes_in / bytes_out are per `units` processed in `seconds`."""
-    if bound == "hbm":
-        achieved, peak = (bytes_in + bytes_out) / seconds / 1e9, HBM_PEAK_GBPS
-    else:
+    bytes / time against 8 TB/s), "pcie-duplex" (both directions' bytes / time against the 83 GB/s one kernel moves both
+    ways at once on this link, profiles/r04/pcie_duplex_probe.jsonl), "latency" / "valu" (a chain of dependent launches or
+    arithmetic: the bytes are given for the record, `frac` is of the HBM peak).  bytes_in / bytes_out are per `units`
+    processed in `seconds`.  traffic: leg_traffic()'s record for the leg's kernels (HBM bytes per unit, measured);
+    algorithmic: the HBM bytes per unit the leg needs (both go into traffic_over_algorithmic)."""
+    if bound == "pcie":
         achieved, peak = max(bytes_in, bytes_out) / seconds / 1e9, PCIE_PEAK_GBPS
-    return {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "bytes_per_" + unit_name: {"in": bytes_in / units, "out": bytes_out / units}, "note": note}
+    elif bound == "pcie-duplex":
+        achieved, peak = (bytes_in + bytes_out) / seconds / 1e9, PCIE_DUPLEX_GBPS
+    else:
+        achieved, peak = (bytes_in + bytes_out) / seconds / 1e9, HBM_PEAK_GBPS
+    out = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+           "bytes_per_" + unit_name: {"in": bytes_in / units, "out": bytes_out / units}, "note": note, "traffic": None}
+    if traffic:
+        out["traffic"] = traffic["bytes"]
+        out["traffic_kernels"] = traffic["kernels"]
+        out["traffic_measured_at"] = traffic["measured_at"]
+        if algorithmic:
+            out["algorithmic_hbm_bytes"] = algorithmic
+            out["traffic_over_algorithmic"] = traffic["bytes"] / algorithmic
+    return out
 
 CONFIGS = {
     # BASELINE.json configs[i-1]; G is per GPU
@@ -316,16 +359,30 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
         "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
         "decisions_per_s": G * cycles / t_total,
         "us_per_cycle_copying_form": t_copy / cycles * 1e6,
-        "roofline": leg_roofline("pcie", "turn", cycles, t_total, 24.0 * nd * cycles, 24.0 * adv_total,
+        "roofline": leg_roofline("latency", "turn", cycles, t_total, 24.0 * nd * cycles, 24.0 * adv_total,
                                  "acks in (the producer's stores, before the call) and advances out cross the link once each; "
-                                 "a turn is four dependent launches and one wait -- latency, not the link, is what it is made of"),
+                                 "a turn is four dependent launches and one wait -- latency, not a link and not HBM, is what it is "
+                                 "made of (frac is of the HBM peak and means little); traffic = the turn's kernels together",
+                                 traffic=leg_traffic(["deltas_in_kernel<raftqk::DeltaRec>", "apply_deltas_kernel<raftqk::DeltaRec>", "sweep_kernel<5, 4, true, false, false",
+                                                      "compact_changed_kernel<4, raftqk::Advance>"]),
+                                 algorithmic=cycle_algorithmic(G, N, nd, adv_total / cycles, 24, 24)),
         "packed_records": {"what": "raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED: 16-byte deltas in (validated and scattered "
                                    "in one pass), 16-byte advances out, zero-copy staging",
                            "us_per_cycle": t_packed / cycles * 1e6, "deltas_per_s": nd * cycles / t_packed,
                            "decisions_per_s": G * cycles / t_packed, "advanced_per_cycle": adv_packed / cycles,
-                           "roofline": leg_roofline("pcie", "turn", cycles, t_packed, 16.0 * nd * cycles, 16.0 * adv_packed,
-                                                    "as above with the 16-byte records")},
+                           "roofline": leg_roofline("latency", "turn", cycles, t_packed, 16.0 * nd * cycles, 16.0 * adv_packed,
+                                                    "as above with the 16-byte records (validated and scattered in one pass)",
+                                                    traffic=leg_traffic(["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_kernel<5, 4, true, false, false",
+                                                                         "compact_changed_kernel<4, raftqk::Advance16>"]),
+                                                    algorithmic=cycle_algorithmic(G, N, nd, adv_packed / cycles, 16, 16))},
     }
+
+
+def cycle_algorithmic(G, N, n_deltas, n_advanced, delta_bytes, adv_bytes):
+    """HBM bytes one batching turn needs: the acks read where they were staged and one 8-byte match word read-modified-written
+    each; the commit sweep of all G groups (N + 1 words in, 1 out, the changed bitmap); per advanced group the old and new
+    commit index read again and one record out (to host memory: not HBM)."""
+    return n_deltas * (delta_bytes + 16.0) + G * (8.0 * N + 8 + 8 + 0.125) + n_advanced * 16.0
 
 
 def tick_measure(cfg, device, ticks=2000, members=8):
@@ -381,12 +438,14 @@ def tick_measure(cfg, device, ticks=2000, members=8):
             "group_ticks_per_s": G / (us * 1e-6), "GBps": 10.0 * G / (us * 1e-6) / 1e9,
             "roofline": leg_roofline("hbm", "group", G, us * 1e-6, 5.0 * G, 5.0 * G,
                                      "role 1 + elapsed 4 in, elapsed 4 + action 1 out per group; 10 MB per launch is cache-resident "
-                                     "and the launch boundary is a third of the time: launch-bound at this size"),
+                                     "and the launch boundary is a third of the time: launch-bound at this size",
+                                     traffic=leg_traffic(["tick_kernel"]), algorithmic=10.0 * G + G / 4.0),
             "set_dispatch": {"what": "raftq_set_tick: %d handles of %d groups, ONE dispatch per Tick" % (members, G), "members": members,
                              "launch_us": us_set, "group_ticks_per_s": members * G / (us_set * 1e-6),
                              "roofline": leg_roofline("hbm", "group", members * G, us_set * 1e-6, 5.0 * G * members, 5.0 * G * members,
                                                       "the same 10 B per group, %d MB per dispatch; every follower past its base timeout "
-                                                      "(no heartbeats in this loop): every wave runs the timeout draw, VALU-bound" % (10 * members * G // 1000000)),
+                                                      "(no heartbeats in this loop): every wave runs the timeout draw, VALU-bound" % (10 * members * G // 1000000),
+                                                      traffic=leg_traffic(["tick_set_kernel"]), algorithmic=(10.0 * G + G / 4.0) * members),
                              "steady_state": {"what": "the same dispatch with no timer past its base timeout (what heartbeats keep true): no wave draws",
                                               "launch_us": us_set_quiet, "group_ticks_per_s": members * G / (us_set_quiet * 1e-6),
                                               "roofline": leg_roofline("hbm", "group", members * G, us_set_quiet * 1e-6, 5.0 * G * members,
@@ -535,8 +594,17 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                                    "synchronous call: 64-byte records in (the producer's stores, before the call), 64-byte results out")
     out["pipelined"]["roofline"] = leg_roofline("pcie", "message", M * reps, dt_pipe_staged, 0.0, 64.0 * M * reps,
                                                 "staged batches resubmitted (nothing crosses inbound), 64-byte results out")
+    # HBM bytes the walk needs per batch: 64 B of every message in, a result record out, and per touched group its 64-byte
+    # record in and out, role (1), commit index (8), the acked peer's match word in and out (16) -- and, where the ack moves
+    # the quorum, the N match words and the term gate (8 N + 8) and the commit index out (8)
+    tg = touched / nb
+    step_alg = lambda rec: M * (64.0 + rec) + tg * (64 + 64 + 1 + 8 + 16) + 0.75 * tg * (8.0 * N + 16)  # noqa: E731
     out["pipelined"]["compact_results"]["roofline"] = leg_roofline(
-        "pcie", "message", M * reps, dt_pipe_compact, 0.0, 40.0 * M * reps, "staged batches resubmitted, 40-byte results out")
+        "pcie", "message", M * reps, dt_pipe_compact, 0.0, 40.0 * M * reps,
+        "staged batches resubmitted, 40-byte results out; the previous batch's results ride out inside this batch's two kernels, "
+        "which therefore last as long as the link takes (2.6 MB: 48 us at 55 GB/s + two launch boundaries): PCIe-out-bound. "
+        "traffic = HBM bytes of the link + walk kernels per batch (measured with nothing riding: RAFTQ_STEP_DEFER_COPY=0)",
+        traffic=leg_traffic(["step_link_kernel", "step_lists_kernel"]), algorithmic=step_alg(40.0))
     out["pipelined"]["producer_included"]["roofline_64B"] = leg_roofline(
         "pcie", "message", M, produced[False], 64.0 * M, 40.0 * M, "every batch written into device staging by one host thread, 40-byte results out")
     out["pipelined"]["producer_included"]["roofline_40B"] = leg_roofline(
@@ -608,7 +676,7 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
         return (time.perf_counter() - t0) / k
 
     out = {"what": "batched raftpb.Message / walpb.Record codecs on the GPU; wall time per call incl. PCIe both ways "
-                   "(pageable caller buffers)", "msgs_per_batch": n}
+                   "(pageable caller buffers; `pinned`: page-locked ones -- the streaming form)", "msgs_per_batch": n}
     m, ents, pool = traffic(0.15)
     stream, off = e.wire_encode(m, ents, pool)
     t_enc = timeit(lambda: e.wire_encode(m, ents, pool)) / 2  # the mirror calls twice (size, then bytes)
@@ -634,8 +702,15 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     mf = out["message_frames"]["pinned"]
     enc_in, enc_out = float(pm.nbytes + pe.nbytes + pp.nbytes), float(len(stream) + poff.nbytes)
     dec_in, dec_out = float(len(stream) + poff.nbytes), float(pmsgs.nbytes + len(ents) * 32)
-    mf["roofline_encode"] = leg_roofline("pcie", "message", n, t_enc_p, enc_in, enc_out, "records + payload pool in, frames + offsets out; page-locked buffers, one call")
-    mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out")
+    why = ("one kernel, readers | workers: both directions of the link busy at once; `duplex` judges the call against what ONE kernel "
+           "moves both ways at once on this link (2 x 41.5 GB/s, profiles/r04/pcie_duplex_probe.jsonl), `frac` against one direction's "
+           "63 GB/s as before; traffic = the kernel's HBM bytes (the scratch hop: written once by the readers, read once by the workers)")
+    mf["roofline_encode"] = leg_roofline("pcie", "message", n, t_enc_p, enc_in, enc_out, "records + payload pool in, frames + offsets out; " + why,
+                                         traffic=leg_traffic(["wire_enc_fused_kernel"]), algorithmic=2.0 * enc_in + 2.0 * enc_out)
+    mf["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_enc_p, enc_in, enc_out)
+    mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out; " + why,
+                                         traffic=leg_traffic(["wire_dec_fused_kernel"]), algorithmic=2.0 * dec_in)
+    mf["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_dec_p, dec_in, dec_out)
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)
@@ -723,8 +798,13 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                     "decode_us": t_wdec_p * 1e6, "decode_recs_per_s": n / t_wdec_p,
                                     "decode_GBps": len(wal) / t_wdec_p / 1e9}}
     wp = out["wal_frames"]["pinned"]
-    wp["roofline_encode"] = leg_roofline("pcie", "record", n, t_wenc_p, float(pr.nbytes + pwp.nbytes), float(len(wal) + poff.nbytes), "records + payload pool in, WAL bytes + offsets out")
-    wp["roofline_decode"] = leg_roofline("pcie", "record", n, t_wdec_p, float(len(wal) + poff.nbytes), float(precs.nbytes), "WAL bytes + offsets in, 48-byte records out")
+    w_in, w_out = float(pr.nbytes + pwp.nbytes), float(len(wal) + poff.nbytes)
+    wp["roofline_encode"] = leg_roofline("pcie", "record", n, t_wenc_p, w_in, w_out, "records + payload pool in, WAL bytes + offsets out; " + why,
+                                         traffic=leg_traffic(["wal_enc_fused_kernel"]), algorithmic=2.0 * w_in + 2.0 * w_out)
+    wp["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "record", n, t_wenc_p, w_in, w_out)
+    wp["roofline_decode"] = leg_roofline("pcie", "record", n, t_wdec_p, w_out, float(precs.nbytes), "WAL bytes + offsets in, 48-byte records out; " + why,
+                                         traffic=leg_traffic(["wal_dec_fused_kernel"]), algorithmic=2.0 * w_out)
+    wp["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "record", n, t_wdec_p, w_out, float(precs.nbytes))
     e.close()
     if with_cpu:
         from oracle import pywire as O  # cpu_baseline leg: the per-message loop of the codec oracle, one thread
@@ -1143,7 +1223,9 @@ def main():
         w1, e1 = timed_steps([s0], [d0], flags, k, dist.World(), dist, launcher=lambda s, f: sweep_many_async(e0, f))
         us1 = e1[0] * 1e3 / (k * n_batches)
         out["single_launch"] = {
-            "what": "one launch per 1M-group batch, launch loop in C (raftq_sweep_many_async), same stream",
+            "what": "one launch per 1M-group batch, launch loop in C (raftq_sweep_many_async); the batches share the set's stream, so "
+                    "the library alternates consecutive launches over that stream and one auxiliary stream (fork once, join once): "
+                    "launch k+1's ramp overlaps launch k's drain (profiles/r04/single_launch_ab.jsonl)",
             "kernel": "raftqk::sweep_kernel", "launch_us": us1, "launches_per_step": n_batches,
             "decisions_per_s": groups_per_gpu * k / w1, "GBps": batch_bytes / (us1 * 1e-6) / 1e9,
             "read_GBps": rd * cfg["G"] / (us1 * 1e-6) / 1e9, "frac": batch_bytes / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS,

@@ -41,8 +41,8 @@ LEG_KERNELS = {
     "step_walk_kernel": ("step", "line"),
     "deltas_in_apply_kernel": ("cycle", "line"), "deltas_in_kernel": ("cycle", "stream"), "apply_deltas_kernel": ("cycle", "line"),
     "compact_changed_kernel": ("cycle", "line"), "sweep_kernel": ("cycle", "stream"), "compact_list_kernel": ("cycle", "line"),
-    "tick_kernel": ("tick", "stream"), "tick_fused_kernel": ("tick", "stream"), "scan_partials_kernel": ("tick", "stream"),
-    "compact_hups_kernel": ("tick", "stream"),
+    "tick_kernel": ("tick", "stream"), "tick_set_kernel": ("tick", "stream"), "tick_lists_kernel": ("tick", "stream"),
+    "scan_partials_kernel": ("tick", "stream"), "compact_hups_kernel": ("tick", "stream"),
     "wire_dec_kernel": ("wire", "stream"), "wire_dec_ents_kernel": ("wire", "stream"), "wire_dec_fused_kernel": ("wire", "stream"),
     "wire_enc_fused_kernel": ("wire", "stream"), "wal_dec_kernel": ("wire", "stream"), "wal_dec_fused_kernel": ("wire", "stream"),
     "wal_enc_fused_kernel": ("wire", "stream"),
@@ -51,7 +51,9 @@ LEG_KERNELS = {
 
 def collect(outdir):
     os.makedirs(outdir, exist_ok=True)
-    env = dict(os.environ, TMPDIR="/tmp", CPU="0", REPS="6", TICKS="100")
+    # (RAFTQ_STEP_DEFER_COPY=0: every Step batch copies its own results out, so the link / walk kernels are counted with
+    # nothing riding in them)
+    env = dict(os.environ, TMPDIR="/tmp", CPU="0", REPS="6", TICKS="100", RAFTQ_STEP_DEFER_COPY="0")
     for leg, cmd in LEGS.items():
         for pname, counters in PASSES.items():
             d = os.path.join(outdir, leg)

@@ -43,6 +43,18 @@
  * slot 0xFF (to) / 0xFFFFFFFF (from), which raftq_step_* rejects.
  *
  * No CPU path: all entry points need the handle's GPU.
+ *
+ * How a call moves its bytes.  When every array of a call is page-locked (hipHostMalloc /
+ * hipHostRegister, or the handle's own staging areas) and 16-byte aligned, the call is ONE
+ * kernel that reads the inputs and writes the outputs where they lie, both directions of
+ * the link busy at once ("streaming form").  Otherwise (pageable memory, odd alignment, or
+ * RAFTQ_WIRE_STREAMING=0 in the environment) inputs are copied in, outputs copied out
+ * ("copying form").  Same results, byte for byte.  One difference a caller can see: a
+ * streaming ENCODE that is refused (RAFTQ_EINVAL: cap too small, a range out of bounds, a
+ * bad slot) has already been writing, so out[0 .. cap) and frame_off are unspecified after
+ * it -- nothing at or behind out[cap] is ever touched; the copying form leaves out alone.
+ * A streaming DECODE that finds more entries than ents_cap has likewise filled msgs and the
+ * first ents_cap entry headers before it says so.
  */
 #ifndef RAFTQ_WIRE_H
 #define RAFTQ_WIRE_H

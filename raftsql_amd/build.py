@@ -101,7 +101,7 @@ def build_sanitized(kind: str, verbose: bool = False) -> str:
     """libraftq_<kind>.so: the HOST side of every translation unit under AddressSanitizer + UBSan ("asan") or
     ThreadSanitizer ("tsan") -- raftq_pipe.cpp / raftq_node.cpp (mutexes, condition variables, a background thread) and the
     host halves of the .hip units; the device code is compiled as always (-fno-gpu-sanitize).  Loaded instead of the
-    product library with RAFTQ_LIB=<path> and the matching clang runtime preloaded (tools/sanitize_r03.sh)."""
+    product library with RAFTQ_LIB=<path> and the matching clang runtime preloaded (tools/gpurun_trip.sh sanitize)."""
     san = SANITIZERS[kind]
     out = os.path.join(PKG, f"libraftq_{kind}.so")
     objdir = os.path.join(PKG, "build", kind)

@@ -627,8 +627,8 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
 
 // ---- the streaming form of a codec call (round 4) --------------------------------------------------------------------
 // On page-locked caller buffers round 3's call was copy-in kernel -> 3-5 small kernels -> copy-out kernel: the link's two
-// directions never worked at the same time (245 us to decode 64K frames whose inbound and outbound bytes are 57 + 89 us
-// apart).  What the link takes (profiles/r04/pcie_duplex_probe.jsonl): a FEW workgroups walking host memory in order pull
+// directions never worked at the same time (245 us to decode 64K frames whose inbound and outbound bytes are 77 us of link
+// each).  What the link takes (profiles/r04/pcie_duplex_probe.jsonl): a FEW workgroups walking host memory in order pull
 // 55 GB/s, many workgroups each pulling a piece of their own 42; workgroups push 55; ONE kernel whose workgroups do both
 // moves 38-41 GB/s each way at once; two kernels on two streams do not overlap at all when one of them writes host memory
 // (the round-1 finding still holds on ROCm 7.2).  So a call is ONE kernel with two roles:
@@ -641,7 +641,8 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_ents_kernel(const uint
 //            memory per store instruction.
 // The first tile's records leave ~25 us into the call and from then on both directions are busy.  (A first form had every
 // worker pull its own tile's bytes straight from the host, with a window on how many tiles might have pulls in flight:
-// 166-211 us for 64K frames depending on the box -- the many-reader pattern -- against this form's ... us.)
+// 166-181 us for 64K frames against this form's 175-193 on the same boxes, but nothing in it can feed the encoders' indirect
+// reads -- entry ranges, payload ranges -- from host memory; this form serves all four codecs.)
 // Tickets (not blockIdx) order the tiles, and readers are the launch's first workgroups: whatever a worker waits for has
 // been claimed by a running workgroup, so nothing deadlocks however few workgroups are resident.
 constexpr int kLbValueBits = 46, kLbFlagShift = 46, kLbEpochShift = 48;

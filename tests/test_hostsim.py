@@ -6,7 +6,7 @@ ASan cannot run beside the HIP runtime on this image (profiles/r03/sanitizers_ho
 so here the two translation units are linked with tests/c/engine_sim.cpp, which answers the engine's C-ABI on the CPU with
 the oracle -- test infrastructure, not a CPU path of the product: the library exists only under tests/c/ and the product's
 loader cannot be pointed at it (tests/conftest.py swaps the path for the sub-run, RAFTQ_TEST_ENGINE_DOUBLE).  On the GPU box the same suites run against the real engine (and under UBSan
-and TSan, tools/sanitize_r03.sh).  Besides the sanitizer, this gives the CPU suite the node's and the pipe's behaviour
+and TSan, tools/gpurun_trip.sh sanitize).  Besides the sanitizer, this gives the CPU suite the node's and the pipe's behaviour
 tests: election safety, log matching, replay + sentinel, chaos, WAL restart, etcd's network scenarios as recalled."""
 import os
 import re

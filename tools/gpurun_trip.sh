@@ -1,5 +1,5 @@
 #!/bin/bash
-# One parameterised GPU-box script (replaces round 3's eighteen tools/gpu_r03_*.sh): run as
+# One parameterised GPU-box script (replaces round 3's eighteen tools/gpu_r03_*.sh, profile_r0N.sh and sanitize_r03.sh): run as
 #   gpurun --timeout T -- 'bash tools/gpurun_trip.sh <step> [<step> ...]'
 # Every step writes under gpurun_out/$ROUND/; the summaries worth keeping are copied to profiles/$ROUND/ by hand.
 set -u
@@ -16,6 +16,45 @@ for step in "$@"; do
     pmc)       # FETCH / WRITE / fabric-request counters of the kernels either side of the sweep (tools/pmc_legs.py)
       timeout 900 python tools/pmc_legs.py collect /tmp/pmc_legs > $P/pmc_legs_collect.log 2>&1
       python tools/pmc_legs.py summarise /tmp/pmc_legs $P/pmc_traffic_legs.json > $P/pmc_legs_summary.txt 2>&1; tail -5 $P/pmc_legs_collect.log ;;
+    pmchead)   # HBM traffic of the headline kernel, every BASELINE config: FETCH_SIZE / WRITE_SIZE in separate passes + the calibration
+               # copy (tools/pmc_traffic.py turns the directory into profiles/pmc_traffic.json)
+      H=$P/pmc_head; mkdir -p $H
+      python -c "import json,datetime; json.dump({'commit': '$(cat .git_head 2>/dev/null)', 'date': datetime.datetime.utcnow().isoformat()+'Z'}, open('$H/meta.json','w'))"
+      for c in 3 2 4 5; do
+        $BENCH --no-extras --no-cpu-baseline --config $c > $H/bench_config$c.json 2> $H/bench_config$c.err
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+          rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $H -o config${c}_$ctr -- python bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --config $c > /dev/null 2> $H/pmc_config${c}_$ctr.err
+        done
+      done
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $H -o calib_$ctr -- tools/tune/raftq_tune3 1 calib > /dev/null 2> $H/pmc_calib_$ctr.err
+      done
+      python tools/pmc_traffic.py $H $P/pmc_traffic.json | grep traffic_over ;;
+    sanitize)  # the library's host C++ under UBSan / TSan / ASan, driven by the GPU suites that exercise it (libraries built in-tree by
+               # raftsql_amd/build.py build_sanitized; KINDS="ubsan tsan asan")
+      cat > /tmp/tsan.supp <<'SUPP'
+called_from_lib:libamdhip64.so
+called_from_lib:libhsa-runtime64.so
+called_from_lib:libtorch_hip.so
+called_from_lib:libtorch_cpu.so
+called_from_lib:libc10.so
+race:libamdhip64.so
+race:libhsa-runtime64.so
+SUPP
+      TESTS="tests/test_pipe_gpu.py tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_parity_gpu.py::test_cycle_is_all_or_nothing_across_both_kinds tests/test_parity_gpu.py::test_cycle_zero_copy_staging tests/test_step_gpu.py::test_step_pipelined_submit_collect tests/test_wire_gpu.py::test_step_from_frames_staged_in_place"
+      for kind in ${KINDS:-ubsan tsan}; do
+        RT=$(python -c "from raftsql_amd import build as b; print(b.sanitizer_runtime('$kind'))"); LOG=$P/sanitize_$kind.log; rm -f $P/${kind}_report*
+        echo "== $kind: LD_PRELOAD=$RT RAFTQ_LIB=raftsql_amd/libraftq_$kind.so ==" > $LOG
+        case $kind in
+          ubsan) env LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$P/ubsan_report RAFTQ_LIB=$PWD/raftsql_amd/libraftq_ubsan.so \
+                   timeout 1500 python -m pytest $TESTS -m gpu -q -p no:cacheprovider >> $LOG 2>&1 ;;
+          tsan)  env LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:suppressions=/tmp/tsan.supp:log_path=$P/tsan_report:report_signal_unsafe=0 RAFTQ_LIB=$PWD/raftsql_amd/libraftq_tsan.so \
+                   timeout 1500 python -m pytest tests/test_pipe_gpu.py tests/test_node_gpu.py -m gpu -q -p no:cacheprovider -k "not host-memory" >> $LOG 2>&1 ;;
+          asan)  env LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:allocator_may_return_null=1:log_path=$P/asan_report HSA_XNACK=1 RAFTQ_LIB=$PWD/raftsql_amd/libraftq_asan.so \
+                   timeout 1500 python -m pytest $TESTS -m gpu -q -p no:cacheprovider -x >> $LOG 2>&1 ;;
+        esac
+        echo "rc=$?" >> $LOG; ls $P/${kind}_report* >> $LOG 2>&1 || echo "no $kind report files: clean" >> $LOG; tail -3 $LOG
+      done ;;
     legs)      # the side legs of the bench, plain (no profiler): wire, step, cycle, tick
       for l in wire step cycle tick; do CPU=0 timeout 300 python tools/profile_$l.py > $P/leg_$l.txt 2>&1; echo "$l rc=$?"; done ;;
     legstats)  # rocprofv3 kernel stats of the same legs

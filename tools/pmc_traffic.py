@@ -12,7 +12,7 @@ Method (MI355X_MICROARCH.md "HBM"; cdna_hip_programming.md section 7):
   * one bench.py dispatch covers `batches` 1M-group batches: the counter value is divided by that, and the
     record carries the kernel's demangled name so that bench.py only quotes it for the kernel it launches.
 
-usage: tools/pmc_traffic.py <dir written by tools/profile_r02.sh> <out.json>
+usage: tools/pmc_traffic.py <dir written by tools/gpurun_trip.sh pmchead> <out.json>
 """
 import csv
 import glob

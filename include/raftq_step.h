@@ -83,6 +83,16 @@ int raftq_step_set_msg_flags(raftq_t* h, int on);
  * raftq_apply_log_deltas.  With it a caller need not keep back everything behind a MsgApp: a batch may hold any number of
  * messages per group, and the ones that land on the tail (RAFTQ_OUT_APPENDED) hold nobody up. */
 #define RAFTQ_MSGF_BARRIER 0x40u
+/* RAFTQ_MSGF_HOLD on any record: the message is one Step does not take (raft.Propose's MsgProp, raft.go:211-215: appending is
+ * the log owner's) but whose place in its group's arrival order matters.  It is NOT stepped -- its type and `from` are not even
+ * looked at -- and answered RAFTQ_OUT_HELD (the group's state as it stands at that point of the batch), whatever came before
+ * it; every message of the group BEHIND it in this batch is answered RAFTQ_OUT_DEFERRED, as behind a barrier.  The caller
+ * deals with the held message when it walks the results in order and steps the deferred ones in a later batch. */
+#define RAFTQ_MSGF_HOLD 0x20u
+/* RAFTQ_MSGF_SKIP on any record: not a message at all (a frame that did not parse, or was addressed to somebody else) -- no
+ * field of the record is looked at, nothing is applied, the answer is RAFTQ_OUT_SKIPPED (an otherwise zero record).  With it a
+ * batch can stand for "everything received, in order" and result i still answers record i. */
+#define RAFTQ_MSGF_SKIP 0x10u
 
 /* what Step did with message i: out[i] answers msgs[i] */
 #define RAFTQ_OUT_NONE 0            /* ignored: stale term, or this role does not handle the type */
@@ -93,9 +103,12 @@ int raftq_step_set_msg_flags(raftq_t* h, int on);
 #define RAFTQ_OUT_PROGRESS 5        /* leader took MsgAppResp / MsgHeartbeatResp from `to`: index = Progress.Match now */
 #define RAFTQ_OUT_BCAST_HEARTBEAT 6 /* leader's MsgBeat: send MsgHeartbeat to every other peer */
 #define RAFTQ_OUT_APPEND 7          /* MsgApp header accepted: run raftLog.maybeAppend on the log, then raftq_apply_log_deltas */
-#define RAFTQ_OUT_DEFERRED 9        /* NOT applied: an earlier MsgApp of the group with RAFTQ_MSGF_BARRIER was answered RAFTQ_OUT_APPEND */
+#define RAFTQ_OUT_DEFERRED 9        /* NOT applied: an earlier MsgApp of the group with RAFTQ_MSGF_BARRIER was answered RAFTQ_OUT_APPEND, or an
+                                     * earlier record of the group carried RAFTQ_MSGF_HOLD */
 #define RAFTQ_OUT_APPENDED 8        /* MsgApp with RAFTQ_MSGF_ENTRIES that appended at the tail: Step did maybeAppend's bookkeeping -- store
                                      * the entries, send MsgAppResp{Index: index} (index = lastnewi = last_index); commit is final */
+#define RAFTQ_OUT_SKIPPED 10        /* RAFTQ_MSGF_SKIP: nothing looked at, nothing applied */
+#define RAFTQ_OUT_HELD 11           /* RAFTQ_MSGF_HOLD: not stepped; the group's later messages of this batch are RAFTQ_OUT_DEFERRED */
 
 #define RAFTQ_OUTF_HARDSTATE 0x01u    /* Term, Vote or Commit changed: HardState must be persisted (wal.Save, raft.go:228) */
 #define RAFTQ_OUTF_COMMITTED 0x02u    /* raftLog.committed advanced (leader: bcastAppend carries it) */

@@ -85,7 +85,7 @@ typedef struct raftq_wire_msg {
   uint8_t type;       /* raftpb.MessageType; > 255 decodes to 255 */
   uint8_t reject;
   uint8_t to;         /* addressee's peer slot */
-  uint8_t flags;      /* RAFTQ_WIRE_F_* (decode) */
+  uint8_t flags;      /* RAFTQ_WIRE_F_* (decode); raftq_step_frames adds RAFTQ_MSGF_* (0x10 .. 0x80) */
   uint32_t ent_first; /* this message's entries are ents[ent_first .. ent_first + n_ents) */
   uint32_t n_ents;
 } raftq_wire_msg_t; /* 64 bytes */
@@ -145,6 +145,26 @@ int raftq_step_submit_wire(raftq_t* h, const void* stream, uint64_t nbytes, cons
 int raftq_step_stage_wire(raftq_t* h, uint64_t n_cap, uint64_t nbytes_cap, uint64_t** frame_off, void** stream);
 int raftq_step_wire_msgs(raftq_t* h, const raftq_wire_msg_t** msgs, uint64_t* n);
 int raftq_step_wire_entries(raftq_t* h, const raftq_wire_ent_t** ents, uint64_t* n_ents);
+
+/* A node's inbound half of a turn -- rafthttp's decoder, the checks a node makes on what it received, rc.node.Step for every
+ * message (raft.go:268-270) -- as ONE submission with one wait: raftq_wire_decode into msgs / ents, then raftq_step_batch over
+ * ALL n frames in arrival order, the decoder saying in every record's flag byte what Step is to make of it (RAFTQ_MSGF_*,
+ * raftq_step.h; the handle must have opted in, raftq_step_set_msg_flags):
+ *   - a frame that did not parse, is of a kind a peer never sends (anything but MsgProp, MsgApp, MsgAppResp, MsgVote,
+ *     MsgVoteResp, MsgHeartbeat, MsgHeartbeatResp), names a group >= G or a sender >= N, or is addressed to a slot other than
+ *     the handle's own (raftq_set_self): RAFTQ_MSGF_SKIP -> RAFTQ_OUT_SKIPPED.  rafthttp would log and drop the stream; a node
+ *     has to survive whatever bytes a peer throws at it.
+ *   - MsgProp (appending is the log owner's): RAFTQ_MSGF_HOLD -> RAFTQ_OUT_HELD, the group's later frames RAFTQ_OUT_DEFERRED.
+ *   - MsgApp: RAFTQ_MSGF_BARRIER, and with tail_appends != 0 RAFTQ_MSGF_ENTRIES (reject_hint, which a MsgApp does not use, is
+ *     overwritten with the Term of its last entry) -- one that lands on the log's tail is RAFTQ_OUT_APPENDED.
+ * Results: raftq_step_results (or _c), n records, out[i] answers frame i.  msgs / ents / counts as raftq_wire_decode, except
+ * that more entries than ents_cap is NOT an error here -- the frames have been stepped; counts->n_ents says how many there
+ * are, the first ents_cap are written, raftq_wire_decode fetches the rest.
+ * Every array must be page-locked and 16-byte aligned (RAFTQ_EINVAL otherwise: make the two calls).  No batch may be in
+ * flight.  raftq_node's turn is this call + one for what goes out. */
+int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off /*[n+1]*/, uint64_t n, int tail_appends,
+                      raftq_wire_msg_t* msgs /*[n]*/, raftq_wire_ent_t* ents /*[ents_cap]|NULL*/, uint64_t ents_cap,
+                      raftq_wire_counts_t* counts /*|NULL*/);
 
 /* ---- WAL ------------------------------------------------------------------------------------ */
 

@@ -302,13 +302,27 @@ done:
 
 void rq_oracle_step_batch(rq_node_state_t* s, const raftq_msg_t* msgs, size_t n, raftq_step_out_t* out) {
   /* RAFTQ_MSGF_BARRIER (raftq_step.h): once a MsgApp that carries it is left to the log's owner (RAFTQ_OUT_APPEND), the
-   * group's later messages OF THIS BATCH are not applied (RAFTQ_OUT_DEFERRED).  held[]: the groups in that state, one byte
+   * group's later messages OF THIS BATCH are not applied (RAFTQ_OUT_DEFERRED); RAFTQ_MSGF_HOLD does the same unconditionally
+   * and is itself not stepped; RAFTQ_MSGF_SKIP records are nobody's.  held[]: the groups in that state, one byte
    * each, only allocated when a message of the batch carries the flag. */
   uint8_t* held = NULL;
   for (size_t i = 0; i < n && !held; ++i)
-    if (msgs[i].type == RAFTQ_MSG_APP && (msgs[i]._pad[1] & RAFTQ_MSGF_BARRIER)) held = (uint8_t*)calloc(s->G ? s->G : 1, 1);
+    if ((msgs[i].type == RAFTQ_MSG_APP && (msgs[i]._pad[1] & RAFTQ_MSGF_BARRIER)) || (msgs[i]._pad[1] & RAFTQ_MSGF_HOLD))
+      held = (uint8_t*)calloc(s->G ? s->G : 1, 1);
   for (size_t i = 0; i < n; ++i) {
+    if (msgs[i]._pad[1] & RAFTQ_MSGF_SKIP) { /* not a message: no field is looked at */
+      memset(&out[i], 0, sizeof(out[i]));
+      out[i].type = RAFTQ_OUT_SKIPPED;
+      continue;
+    }
     node_t r = {s, (size_t)msgs[i].group};
+    if (msgs[i]._pad[1] & RAFTQ_MSGF_HOLD) { /* the caller's (MsgProp): answered where it stands, the rest of its group waits */
+      memset(&out[i], 0, sizeof(out[i]));
+      out_common(&r, &msgs[i], &out[i]);
+      out[i].type = RAFTQ_OUT_HELD;
+      held[r.g] = 1;
+      continue;
+    }
     if (held && held[r.g]) {
       memset(&out[i], 0, sizeof(out[i]));
       out_common(&r, &msgs[i], &out[i]);

@@ -135,6 +135,7 @@ struct raftq {
     // raftq_step_submit_wire: where this batch's decoded records sit in `dev`, and the pinned
     // copies raftq_step_wire_msgs / _entries hand out (fetched on demand)
     bool wire = false;
+    uint8_t recs = 0;              // raftqk::kRecsCaller / kRecsWire / kRecsFrames: whose records the batch holds (replays need it)
     void* w_msgs_d = nullptr;      // raftq_wire_msg_t [n]
     void* w_ents_d = nullptr;      // raftq_wire_ent_t [w_ents_cap]
     const uint64_t* w_ent_total_d = nullptr;
@@ -169,6 +170,7 @@ struct raftq {
   // the streaming codec kernels (raftq_wire_kernels.hpp "the streaming form"): ticket word + per-tile look-back status
   unsigned long long* wire_lb = nullptr;     // device: kLbHead words {ticket, gave-up flag, landed waves, -}, then kLbArrays status arrays of wire_lb_tiles words
   uint64_t wire_lb_tiles = 0;
+  uint32_t wire_last_tiles = 0;              // tiles of the streaming decode enqueued last (measurement builds dump its stamps)
   uint32_t wire_ticket_base = 0, wire_epoch = 0;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
@@ -206,6 +208,7 @@ struct raftq_set {
 };
 
 
+struct raftq_wire_counts;  // raftq_wire.h
 namespace raftq_detail {
 int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
@@ -217,6 +220,12 @@ unsigned host_coherence_flag();                 // hipHostMallocCoherent unless 
 int ensure_tick_state(raftq_t* h);              // role / elapsed / action (+ hup bitmap)
 void free_node_state(raftq_t* h);               // raftq_step.hip's allocations (called by raftq_destroy)
 void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations (called by raftq_destroy)
+// raftq_wire.hip, for raftq_step_frames (raftq_step.hip): the streaming decode with a node's checks, enqueued on the handle's
+// stream and not waited for (the records also go to msgs_d, in HBM, for the Step kernels enqueued behind it); and what the
+// decode has to say once the call's one wait is over.  RAFTQ_EINVAL when an array is not page-locked and 16-byte aligned.
+int wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, void* msgs, void* ents,
+                        uint64_t ents_cap, void* msgs_d, int tail_appends);
+int wire_frames_finish(raftq_t* h, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap, ::raftq_wire_counts* counts);
 }  // namespace raftq_detail
 
 #define HIPCHK(h, expr)                                                                        \

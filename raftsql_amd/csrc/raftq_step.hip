@@ -46,7 +46,7 @@ int ensure_node_state(raftq_t* h) {
   return RAFTQ_OK;
 }
 
-NodeArrays node_arrays(raftq_t* h) {
+NodeArrays node_arrays(raftq_t* h, uint8_t recs = raftqk::kRecsCaller) {
   NodeArrays a;
   a.rec = (NodeRec*)h->node_rec;
   a.role = h->role;
@@ -59,6 +59,8 @@ NodeArrays node_arrays(raftq_t* h) {
   a.n_peers = h->N;
   a.self = h->self_peer;
   a.msg_flags = h->step_msg_flags;
+  a.recs = recs;
+  a.n_groups = h->G;
   return a;
 }
 
@@ -366,18 +368,25 @@ struct WireSrc {
   const void* stream;
   uint64_t nbytes;
   const uint64_t* frame_off;
+  // raftq_step_frames: the arrays stay where they are (page-locked), the streaming decoder reads them there, hands the
+  // decoded records and entry headers to the caller and keeps a copy of the records in the slot's scratch for Step
+  bool frames = false;
+  void* msgs_h = nullptr;
+  void* ents_h = nullptr;
+  uint64_t ents_cap = 0;
+  int tail_appends = 0;
 };
 
 // key -> stable radix sort -> walk, on the handle's stream (the path that takes runs of any length)
-static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, bool from_wire, void* outs) {
+static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, uint8_t recs, void* outs) {
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
-                     h->G, h->N, bad, from_wire);
+                     h->G, h->N, bad, h->step_msg_flags, recs, outs, h->step_compact);
   HIPCHK(h, hipGetLastError());
   int in_b = 0;  // which pair of buffers the sorted (group, batch position) pairs end up in
   HIPCHK(h, raftqk::radix_sort_pairs(h->stream, s.sort_scratch, s.keys_in, s.order_in, s.keys_out, s.order_out, n, end_bit, &in_b));
-  hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h), (const MsgRec*)s.msgs,
+  hipLaunchKernelGGL(step_kernel, grid, dim3(kBlock), 0, h->stream, node_arrays(h, recs), (const MsgRec*)s.msgs,
                      (const uint64_t*)(in_b ? s.keys_out : s.keys_in), (const uint32_t*)(in_b ? s.order_out : s.order_in), outs,
                      h->step_compact, n, s.n_heads, (const unsigned int*)bad);
   HIPCHK(h, hipGetLastError());
@@ -388,7 +397,7 @@ static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end
 static unsigned d2h_blocks(uint64_t quads) { return (unsigned)std::min<uint64_t>(64, (quads + kBlock - 1) / kBlock); }
 
 // `carry`: a slot whose result copy is still pending rides in this batch's walk kernel (nullptr: nothing to carry)
-static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from_wire, raftq::StepSlot* carry) {
+static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, uint8_t recs, raftq::StepSlot* carry) {
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   unsigned int* skipped = bad + 1;  // the last word of the 16-byte tail behind the result records
   const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
@@ -400,8 +409,8 @@ static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, bool from
     in_walk = {(const u64x2*)carry->outs_d, (u64x2*)carry->out_d, cut, quads, quads - 1, d2h_blocks(quads - cut)};
   }
   hipLaunchKernelGGL(step_link_kernel, dim3(blocks + in_link.blocks), dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, n, h->G,
-                     h->N, from_wire, (NodeRec*)h->node_rec, s.next, bad, h->step_stall, in_link);
-  hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + in_walk.blocks), dim3(kBlock), 0, h->stream, node_arrays(h),
+                     h->N, h->step_msg_flags, recs, (NodeRec*)h->node_rec, s.next, bad, h->step_stall, s.outs, h->step_compact, in_link);
+  hipLaunchKernelGGL(step_lists_kernel, dim3(blocks + in_walk.blocks), dim3(kBlock), 0, h->stream, node_arrays(h, recs),
                      (const MsgRec*)s.msgs, s.outs, h->step_compact, n, h->G, (const uint32_t*)s.next, s.n_heads,
                      skipped, (const unsigned int*)bad, (const unsigned int*)h->step_stall, in_walk);
   HIPCHK(h, hipGetLastError());
@@ -443,7 +452,13 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   // raftq_step_stage_wire's arrays, filled in place: in device memory the decoder reads them where they lie; in pinned
   // host memory two DMAs take them (the boundaries and the stream are not adjacent there)
   bool wire_staged = false;
-  if (wire) {
+  const bool frames = wire && wire->frames;
+  const uint8_t recs = frames ? raftqk::kRecsFrames : wire ? raftqk::kRecsWire : raftqk::kRecsCaller;
+  if (frames) {
+    if (!h->step_msg_flags)
+      return fail(h, RAFTQ_ESTATE, std::string(who) + ": the handle has not opted in to RAFTQ_MSGF_* (raftq_step_set_msg_flags)");
+    in_bytes = 0;  // nothing is staged: the decoder reads the caller's arrays where they lie
+  } else if (wire) {
     in_bytes = (size_t)(n + 1) * 8 + (size_t)wire->nbytes;
     const uint8_t* fo = (const uint8_t*)wire->frame_off;
     const uint8_t* sb = (const uint8_t*)wire->stream;
@@ -490,7 +505,7 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   if (h->step_last_slot == slot_no) h->step_last_slot = -1;  // that batch's decoded records are about to be overwritten
   sl.wire = false;
   Scratch s;
-  if (int rc = ensure_slot(h, sl, n, end_bit, &s, wire != nullptr, wire ? wire->nbytes : 0)) return rc;
+  if (int rc = ensure_slot(h, sl, n, end_bit, &s, wire != nullptr && !frames, wire && !frames ? wire->nbytes : 0)) return rc;
   // Step moves the live commit index: a what-if (NO_ADOPT) sweep's shadow values are no longer what
   // raftq_read_committed should hand out
   h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;
@@ -509,7 +524,9 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   const void* packed_src = s.msgs40;
   const bool own_staging = staged_in_device && (const uint8_t*)device_src >= (const uint8_t*)sl.in_bar &&
                            (const uint8_t*)device_src + in_bytes <= (const uint8_t*)sl.in_bar + sl.in_bar_bytes;
-  if (wire && wire_staged && staged_in_device) {
+  if (frames) {
+    // (enqueued below, on the handle's stream, in front of Step's kernels)
+  } else if (wire && wire_staged && staged_in_device) {
     s.w_off = (uint64_t*)const_cast<void*>(device_src);
     s.w_stream = (uint8_t*)const_cast<void*>(device_src) + sl.w_stage_stream_off;
     sl.w_off_in_place = s.w_off;
@@ -555,7 +572,13 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
                        (const raftqk::Msg40Rec*)packed_src, s.msgs, n);
     HIPCHK(h, hipGetLastError());
   }
-  if (wire) {
+  if (frames) {
+    // one kernel: readers pull boundaries + stream, workers parse, check, flag (RAFTQ_MSGF_*) and push records + entry headers
+    // to the caller's arrays and the records once more into this slot's scratch
+    if (int rc = raftq_detail::wire_frames_enqueue(h, wire->stream, wire->nbytes, wire->frame_off, n, wire->msgs_h, wire->ents_h,
+                                                   wire->ents_cap, s.msgs, wire->tail_appends))
+      return rc;
+  } else if (wire) {
     // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe.  (s.w_bad only counts
     // malformed frames for raftq_wire_decode's callers; here a malformed frame fails the batch through its flag byte.)
     const dim3 grid1((unsigned)((n + 1 + kBlock - 1) / kBlock));
@@ -583,11 +606,11 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
     if (prev.busy && prev.copy_pending) carry = &prev;
   }
   if (lists) {
-    if (int rc = enqueue_list_walk(h, s, n, wire != nullptr, carry)) return rc;
+    if (int rc = enqueue_list_walk(h, s, n, recs, carry)) return rc;
   } else {
     if (carry)
       if (int rc = enqueue_result_copy(h, *carry, h->stream)) return rc;
-    if (int rc = enqueue_sorted_walk(h, s, n, end_bit, wire != nullptr, s.outs)) return rc;
+    if (int rc = enqueue_sorted_walk(h, s, n, end_bit, recs, s.outs)) return rc;
   }
   sl.outs_d = s.outs;
   sl.out_quads = tail_off(n, rec) / 16 + 1;  // records + the 16-byte tail
@@ -611,7 +634,8 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   sl.end_bit = end_bit;
   sl.rec = rec;
   sl.w_nbytes = wire ? wire->nbytes : 0;
-  sl.wire = wire != nullptr;
+  sl.wire = wire != nullptr && !frames;
+  sl.recs = recs;
   sl.w_msgs_d = s.msgs;
   sl.w_ents_d = s.w_ents;
   sl.w_ent_total_d = s.w_base + n;
@@ -749,7 +773,7 @@ static int replay_stalled(raftq_t* h, uint64_t first) {
     if (int rc = ensure_slot(h, sl, sl.n, sl.end_bit, &s, sl.wire, sl.w_nbytes)) return rc;
     if (sl.msgs_in_place) s.msgs = (MsgRec*)const_cast<void*>(sl.msgs_in_place);
     hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
-    if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.wire, s.outs)) return rc;
+    if (int rc = enqueue_sorted_walk(h, s, sl.n, sl.end_bit, sl.recs, s.outs)) return rc;
     const uint64_t out_quads = tail_off(sl.n, sl.rec) / 16 + 1;
     hipLaunchKernelGGL(step_d2h_kernel, dim3(d2h_blocks(out_quads)), dim3(kBlock), 0, h->stream, (const u64x2*)s.outs,
                        (u64x2*)sl.out_d, out_quads);
@@ -827,6 +851,29 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
     return fail(h, RAFTQ_EINVAL, "raftq_step_batch: compact result records are read in place (raftq_step_results_c), pass out = NULL");
   if (int rc = raftq_step_submit(h, msgs, n)) return rc;
   return raftq_step_collect(h, out, counts);
+}
+
+int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, int tail_appends,
+                      raftq_wire_msg_t* msgs, raftq_wire_ent_t* ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  if (h->step_collected != h->step_submitted)
+    return fail(h, RAFTQ_ESTATE, "raftq_step_frames: submitted batches are still in flight; collect them first");
+  h->step_last_out = nullptr;
+  h->step_last_n = 0;
+  if (n == 0) return RAFTQ_OK;
+  if ((!stream && nbytes) || !frame_off || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_frames: null argument");
+  WireSrc w{stream, nbytes, frame_off, true, msgs, ents, ents ? ents_cap : 0, tail_appends};
+  if (int rc = submit_impl(h, nullptr, n, &w, "raftq_step_frames")) return rc;
+  // one wait: the result copy is the last kernel of the chain the decoder heads
+  const int rc_step = raftq_step_collect(h, nullptr, nullptr);
+  const int rc_dec = raftq_detail::wire_frames_finish(h, frame_off, n, ents != nullptr, ents_cap, counts);
+  if (rc_dec != RAFTQ_OK) {  // a look-back gave up: the records Step read are not to be trusted, nor is what it made of them
+    h->step_last_out = nullptr;
+    h->step_last_n = 0;
+    return rc_dec;
+  }
+  return rc_step;
 }
 
 int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {

@@ -72,13 +72,18 @@ struct NodeArrays {
   uint64_t ld;
   uint32_t n_peers, self;
   bool msg_flags;   // the handle opted in to RAFTQ_MSGF_* (raftq_step_set_msg_flags): otherwise a record's pad bytes are padding
+  uint8_t recs;     // whose records the batch holds: kRecsCaller, kRecsWire (raftq_step_submit_wire: the decoder's, strict) or
+                    // kRecsFrames (raftq_step_frames: the decoder's, with RAFTQ_MSGF_* set by it)
+  uint64_t n_groups;
 };
+constexpr uint8_t kRecsCaller = 0, kRecsWire = 1, kRecsFrames = 2;
 
 constexpr uint8_t kMsgHup = 0, kMsgBeat = 1, kMsgApp = 3, kMsgAppResp = 4, kMsgVote = 5, kMsgVoteResp = 6,
                   kMsgHeartbeat = 8, kMsgHeartbeatResp = 9;
 constexpr uint8_t kOutNone = 0, kOutVoteResp = 1, kOutHeartbeatResp = 2, kOutCampaign = 3, kOutBecameLeader = 4,
-                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7, kOutAppended = 8, kOutDeferred = 9;
-constexpr uint8_t kMsgfEntries = 0x80, kMsgfBarrier = 0x40;  // raftq_msg_t._pad[1]: RAFTQ_MSGF_ENTRIES, RAFTQ_MSGF_BARRIER
+                  kOutProgress = 5, kOutBcastHeartbeat = 6, kOutAppend = 7, kOutAppended = 8, kOutDeferred = 9, kOutSkipped = 10,
+                  kOutHeld = 11;
+constexpr uint8_t kMsgfEntries = 0x80, kMsgfBarrier = 0x40, kMsgfHold = 0x20, kMsgfSkip = 0x10;  // raftq_msg_t._pad[1]: RAFTQ_MSGF_*
 constexpr uint8_t kFlagHardState = 1, kFlagCommitted = 2, kFlagUpdated = 4, kFlagSteppedDown = 8;
 constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
@@ -139,6 +144,32 @@ static __global__ __launch_bounds__(kBlock) void step_unpack40_kernel(const Msg4
   out[i] = m;
 }
 
+// What the two grouping kernels make of record i.  kSkip: RAFTQ_MSGF_SKIP, nobody's (answered on the spot, never grouped);
+// kBad: fails the batch; kTake: goes to its group (a RAFTQ_MSGF_HOLD record too: only its group is looked at).
+enum RecClass : int { kTake = 0, kSkip = 1, kBad = 2 };
+__device__ __forceinline__ RecClass classify(const MsgRec& m, uint64_t n_groups, uint32_t n_peers, bool msg_flags, uint8_t recs) {
+  const uint8_t fl = msg_flags ? m.pad[1] : (uint8_t)0;
+  if (fl & kMsgfSkip) return kSkip;
+  if (m.group >= n_groups) return kBad;
+  if (fl & kMsgfHold) return kTake;
+  const uint8_t t = m.type;
+  const bool local = t == kMsgHup || t == kMsgBeat;
+  const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
+                     t == kMsgHeartbeat || t == kMsgHeartbeatResp;
+  if (!known || (!local && m.from >= n_peers)) return kBad;
+  // records decoded on the device from stream frames (raftq_step_submit_wire) also carry the addressee's slot and the
+  // decoder's flags in the two pad bytes: a frame that did not parse, or one addressed to no peer of this cluster, fails
+  // the batch like any malformed message.  (raftq_step_frames' decoder has made those RAFTQ_MSGF_SKIP itself.)
+  if (recs == kRecsWire && ((m.pad[1] & 1u) != 0 || m.pad[0] >= n_peers)) return kBad;
+  return kTake;
+}
+__device__ __forceinline__ void put_skipped(void* out, uint64_t i, bool compact) {
+  StepOutRec o;
+  __builtin_memset(&o, 0, sizeof o);
+  o.type = kOutSkipped;
+  put_result(out, i, o, compact);
+}
+
 // ---- (1) validate + sort keys.  The batch was DMA-copied from the pinned staging area into
 // HBM; one lane per record reads its first 16 B (group, term) and the 16 B holding from/type.
 // A malformed record raises *bad; step_kernel then applies nothing (the ABI's all-or-nothing rule).
@@ -146,23 +177,17 @@ static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* 
                                                                   uint64_t* __restrict__ keys,
                                                                   uint32_t* __restrict__ order, uint64_t n,
                                                                   uint64_t n_groups, uint32_t n_peers,
-                                                                  unsigned int* bad, bool from_wire) {
+                                                                  unsigned int* bad, bool msg_flags, uint8_t recs,
+                                                                  void* __restrict__ out, bool compact) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool is_bad = false;
   if (i < n) {
-    const uint64_t g = msgs[i].group;
-    const uint32_t from = msgs[i].from;
-    const uint8_t t = msgs[i].type;
-    const bool local = t == kMsgHup || t == kMsgBeat;
-    const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
-                       t == kMsgHeartbeat || t == kMsgHeartbeatResp;
-    is_bad = g >= n_groups || !known || (!local && from >= n_peers);
-    // records decoded on the device from stream frames (raftq_step_submit_wire) also carry the
-    // addressee's slot and the decoder's flags in the two pad bytes: a frame that did not parse, or
-    // one addressed to no peer of this cluster, fails the batch like any malformed message
-    if (from_wire) is_bad = is_bad || (msgs[i].pad[1] & 1u) != 0 || msgs[i].pad[0] >= n_peers;
-    keys[i] = is_bad ? 0 : g;  // keep the sort's key range valid
+    const RecClass c = classify(msgs[i], n_groups, n_peers, msg_flags, recs);
+    is_bad = c == kBad;
+    // a skipped record sorts behind every group (the key range has room for n_groups itself) and is answered here
+    keys[i] = c == kTake ? msgs[i].group : c == kSkip ? n_groups : 0;  // (bad: keep the sort's key range valid)
     order[i] = (uint32_t)i;
+    if (c == kSkip) put_skipped(out, i, compact);
   }
   if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
@@ -316,7 +341,8 @@ struct Node {
   __device__ void handle_append(const MsgRec& m, StepOutRec& o) {
     o.type = kOutAppend;
     if (a.msg_flags && (m.pad[1] & kMsgfEntries) && m.index == last_index && m.log_term == last_term) {
-      const uint64_t k = m.resv & 0xffffffffull;
+      // (the decoder's record keeps ent_first | n_ents << 32 where the caller's keeps the count)
+      const uint64_t k = a.recs == kRecsFrames ? m.resv >> 32 : m.resv & 0xffffffffull;
       if (k) {
         last_index = m.index + k;
         last_term = m.reject_hint;
@@ -332,8 +358,10 @@ struct Node {
     const uint32_t vote0 = vote;
     const uint8_t role0 = role;
     o.index = 0; o.log_term = 0; o.type = kOutNone; o.reject = 0; o.flags = 0;
-    if (held) {  // RAFTQ_OUT_DEFERRED: nothing of this message is applied
-      o.type = kOutDeferred;
+    const bool hold = a.msg_flags && (m.pad[1] & kMsgfHold) != 0;  // RAFTQ_OUT_HELD: the caller's, where it stands; the rest waits
+    if (held || hold) {  // RAFTQ_OUT_DEFERRED: nothing of this message is applied
+      o.type = hold ? kOutHeld : kOutDeferred;
+      held = true;
       o.group = g; o.term = term; o.commit = committed; o.last_index = last_index;
       o.to = m.from; o.vote = vote; o.lead = lead; o.role = role;
       return;
@@ -432,7 +460,7 @@ static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const
   uint64_t g = 0;
   if (k < n) {
     g = keys_sorted[k];
-    head = k == 0 || keys_sorted[k - 1] != g;
+    head = (k == 0 || keys_sorted[k - 1] != g) && g < a.n_groups;  // (key n_groups: the RAFTQ_MSGF_SKIP records, answered by step_keys_kernel)
   }
   const uint64_t hb = __ballot(head);
   if ((threadIdx.x & 63) == 0 && hb) atomicAdd(n_heads, (unsigned long long)__popcll(hb));
@@ -480,9 +508,10 @@ __device__ __forceinline__ void copy_ride(const CopyRide& c) {
 }
 
 static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* __restrict__ msgs, uint64_t n,
-                                                                  uint64_t n_groups, uint32_t n_peers, bool from_wire,
+                                                                  uint64_t n_groups, uint32_t n_peers, bool msg_flags, uint8_t recs,
                                                                   NodeRec* rec, uint32_t* __restrict__ next,
-                                                                  unsigned int* bad, unsigned int* stall, CopyRide ride) {
+                                                                  unsigned int* bad, unsigned int* stall,
+                                                                  void* __restrict__ out, bool compact, CopyRide ride) {
   if (blockIdx.x < ride.blocks) {
     copy_ride(ride);
     return;
@@ -490,19 +519,17 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
   const uint64_t i = (uint64_t)(blockIdx.x - ride.blocks) * kBlock + threadIdx.x;
   bool is_bad = false, too_long = false;
   if (i < n) {
-    const uint64_t g = msgs[i].group;
-    const uint32_t from = msgs[i].from;
-    const uint8_t t = msgs[i].type;
-    const bool local = t == kMsgHup || t == kMsgBeat;
-    const bool known = local || t == kMsgApp || t == kMsgAppResp || t == kMsgVote || t == kMsgVoteResp ||
-                       t == kMsgHeartbeat || t == kMsgHeartbeatResp;
-    is_bad = g >= n_groups || !known || (!local && from >= n_peers);
-    if (from_wire) is_bad = is_bad || (msgs[i].pad[1] & 1u) != 0 || msgs[i].pad[0] >= n_peers;
-    if (!is_bad) {
-      NodeRec* r = rec + g;  // three atomics on one line
+    const RecClass c = classify(msgs[i], n_groups, n_peers, msg_flags, recs);
+    is_bad = c == kBad;
+    if (c == kTake) {
+      NodeRec* r = rec + msgs[i].group;  // three atomics on one line
       next[i] = atomicExch(&r->lst_head, (uint32_t)i);
       too_long = atomicAdd(&r->lst_cnt, 1u) + 1 > kMaxRun;
       atomicMin(&r->lst_min, (uint32_t)i);
+    } else if (c == kSkip) {
+      // nobody's: answered on the spot.  (A batch that turns out bad or stalled is not applied and its results are not
+      // read -- a replay through the sorted walk writes this record again.)
+      put_skipped(out, i, compact);
     }
   }
   if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
@@ -523,7 +550,7 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
   const bool stalled = *stall != 0;  // this batch, or one before it that has not been replayed yet, needs the sorted path
   if (stalled || *bad) {             // (*bad: a malformed record somewhere in the batch) -- nothing is applied;
     if (stalled && i == 0) *tail_skipped = 1u;
-    if (i < n && msgs[i].group < n_groups) {  // every message empties its group's list words (idempotent)
+    if (i < n && classify(msgs[i], n_groups, a.n_peers, a.msg_flags, a.recs) == kTake) {  // every message empties its group's list words (idempotent)
       NodeRec* r = a.rec + msgs[i].group;
       r->lst_head = kNil;
       r->lst_cnt = 0;
@@ -535,7 +562,8 @@ static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a,
   bool owner = false;
   if (i < n) {
     g = msgs[i].group;
-    owner = a.rec[g].lst_min == (uint32_t)i;
+    // (a RAFTQ_MSGF_SKIP record belongs to no group -- its group field may hold anything -- and was answered by the link kernel)
+    owner = !(a.msg_flags && (msgs[i].pad[1] & kMsgfSkip)) && a.rec[g].lst_min == (uint32_t)i;
   }
   const uint64_t ob = __ballot(owner);
   if ((threadIdx.x & 63) == 0 && ob) atomicAdd(n_heads, (unsigned long long)__popcll(ob));

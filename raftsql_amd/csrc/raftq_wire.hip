@@ -350,6 +350,65 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   return RAFTQ_OK;
 }
 
+// The streaming decode (raftq_wire_kernels.hpp "the streaming form"), enqueued on the handle's stream and NOT waited for;
+// v_*: the caller's arrays as the device addresses them.  msgs_d / ff: see wire_dec_fused_kernel (raftq_step_frames).
+static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t nbytes, const void* v_off, uint64_t n, void* v_msgs, void* v_ents,
+                                    uint64_t ents_cap, WireMsg* msgs_d, FrameFilter ff) {
+  const uint32_t n_tiles = blocks_for(n);
+  const unsigned workers = fused_grid(n_tiles);
+  Carver c;
+  const void* const src[3] = {v_off, v_stream, nullptr};
+  const uint64_t bytes[3] = {(n + 1) * 8, nbytes, 0};
+  TileCtl ctl;
+  if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (bytes[0] + bytes[1]) / feed_chunk() + 1), &ctl)) return rc;
+  FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
+  bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+  hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
+                     (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d, msgs_d, ff);
+  HIPCHK(h, hipGetLastError());
+  tile_ctl_launched(h, n_tiles, workers);
+  h->wire_last_tiles = n_tiles;
+  return RAFTQ_OK;
+}
+// ... after the wait that covers it.  too_many_is_error: raftq_wire_decode's contract; raftq_step_frames only reports the count.
+static int decode_streaming_finish(raftq_t* h, const char* who, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap,
+                                   bool too_many_is_error, raftq_wire_counts_t* counts) {
+#if defined(RAFTQ_WIRE_TRACE)
+  trace_dump(h, "wire_dec", h->wire_last_tiles);
+#endif
+  if (int rc = tile_ctl_check(h, who)) return rc;
+  const uint64_t total = h->wire_pin[0];
+  if (counts) {
+    counts->n_msgs = n;
+    counts->n_ents = total;
+    counts->n_malformed = h->wire_pin[1];
+    counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
+  }
+  if (too_many_is_error && have_ents && total > ents_cap)
+    return fail(h, RAFTQ_EINVAL, std::string(who) + ": more entries than ents_cap (counts->n_ents is the number needed)");
+  return RAFTQ_OK;
+}
+
+}  // extern "C"
+int raftq_detail::wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, void* msgs, void* ents,
+                                      uint64_t ents_cap, void* msgs_d, int tail_appends) {
+  if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_step_frames: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
+  const bool mapped = (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
+                      (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
+  if (!(mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off) && aligned16(v_msgs) && aligned16(v_ents)))
+    return fail(h, RAFTQ_EINVAL, "raftq_step_frames: the stream, the boundaries and the result arrays must be page-locked (raftq_host_alloc, "
+                                 "hipHostMalloc, hipHostRegister) and 16-byte aligned -- decode and step in two calls otherwise");
+  const FrameFilter ff{1u, h->N, h->self_peer, tail_appends ? 1u : 0u, h->G};
+  return decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents ? ents_cap : 0, (WireMsg*)msgs_d, ff);
+}
+int raftq_detail::wire_frames_finish(raftq_t* h, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
+  return decode_streaming_finish(h, "raftq_step_frames", frame_off, n, have_ents, ents_cap, false, counts);
+}
+extern "C" {
+
 int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n,
                       raftq_wire_msg_t* msgs, raftq_wire_ent_t* ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
   if (int rc = use_device(h)) return rc;
@@ -367,35 +426,9 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
     // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
     // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
-    const uint32_t n_tiles = blocks_for(n);
-    const unsigned workers = fused_grid(n_tiles);
-    Carver c;
-    const void* const src[3] = {v_off, v_stream, nullptr};
-    const uint64_t bytes[3] = {(n + 1) * 8, nbytes, 0};
-    TileCtl ctl;
-    if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (bytes[0] + bytes[1]) / feed_chunk() + 1), &ctl)) return rc;
-    FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles);
-    if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
-    hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
-                       (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d);
-    HIPCHK(h, hipGetLastError());
-    tile_ctl_launched(h, n_tiles, workers);
+    if (int rc = decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents_cap, nullptr, FrameFilter{0, 0, 0, 0, 0})) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-#if defined(RAFTQ_WIRE_TRACE)
-    trace_dump(h, "wire_dec", n_tiles);
-#endif
-    if (int rc = tile_ctl_check(h, "raftq_wire_decode")) return rc;
-    const uint64_t total = h->wire_pin[0];
-    if (counts) {
-      counts->n_msgs = n;
-      counts->n_ents = total;
-      counts->n_malformed = h->wire_pin[1];
-      counts->bytes = frame_off[n] >= frame_off[0] ? frame_off[n] - frame_off[0] : 0;
-    }
-    if (ents && total > ents_cap)
-      return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
-    return RAFTQ_OK;
+    return decode_streaming_finish(h, "raftq_wire_decode", frame_off, n, ents != nullptr, ents_cap, true, counts);
   }
   const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;

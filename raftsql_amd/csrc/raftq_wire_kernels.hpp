@@ -790,7 +790,7 @@ __device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wa
 // the tile's records leave through LDS: lane-consecutive 16-byte stores, 4 KB of consecutive host memory per instruction
 template <typename Rec>
 __device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32x4* lds /*[kBlock * sizeof(Rec) / 16]*/, Rec* out_h,
-                                                 uint64_t tile0, uint64_t n) {
+                                                 uint64_t tile0, uint64_t n, Rec* out_d = nullptr /* a copy that stays in HBM */) {
   static_assert(sizeof(Rec) % 16 == 0, "records are whole quads");
   constexpr uint32_t kQ = sizeof(Rec) / 16;
   if (live) {
@@ -807,6 +807,14 @@ __device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32
   for (uint32_t k = 0; k < kQ; ++k) {
     const uint32_t q = k * kBlock + threadIdx.x;
     if (q < quads) __builtin_nontemporal_store(lds[q], dst + q);
+  }
+  if (out_d != nullptr) {
+    u32x4* dd = reinterpret_cast<u32x4*>(out_d + tile0);
+#pragma unroll
+    for (uint32_t k = 0; k < kQ; ++k) {
+      const uint32_t q = k * kBlock + threadIdx.x;
+      if (q < quads) dd[q] = lds[q];
+    }
   }
 }
 
@@ -856,8 +864,21 @@ __device__ __forceinline__ WaveStage stage_wave_frames_dma(const uint8_t* stream
 // (array 0) and the stream (array 1) into the scratch; msgs_h / ents_h are the caller's result arrays as the device
 // addresses them.  pin[0] = entries found, pin[1] = malformed frames (written by the worker of the last tile, whose
 // inclusive sums are the totals), pin[3] = a wait gave up.
+//
+// raftq_step_frames (a node's inbound half-turn as one submission): `ff.on` -- the decoder also makes the checks a node makes on
+// what it received and says in the record's flag byte what Step is to do with it (RAFTQ_MSGF_*, raftq_step.h): a frame that did
+// not parse, is of a kind a peer never sends, names no group / sender of this cluster or is addressed to another slot is
+// RAFTQ_MSGF_SKIP; a MsgProp (the log owner's) RAFTQ_MSGF_HOLD; a MsgApp a barrier that says what it carries (reject_hint, which
+// MsgApp does not use = the last entry's term).  msgs_d: the same records once more, in HBM, where Step's kernels -- enqueued
+// right behind this one -- read them.
+struct FrameFilter {
+  uint32_t on, n_peers, self, tail_appends;
+  uint64_t n_groups;
+};
+constexpr uint8_t kFrameSkip = 0x10, kFrameHold = 0x20, kFrameBarrier = 0x40, kFrameEntries = 0x80;  // == RAFTQ_MSGF_*
 static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
-                                                                       uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin) {
+                                                                       uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin,
+                                                                       WireMsg* msgs_d, FrameFilter ff) {
   if (blockIdx.x < in.readers) {
     reader_role(in, ctl.epoch);
     return;
@@ -920,6 +941,18 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
         m.flags = kWireMalformed;
         malformed = true;
       }
+      if (ff.on) {
+        const uint8_t t = m.type;  // MsgProp 2, MsgApp 3, MsgAppResp 4, MsgVote 5, MsgVoteResp 6, MsgHeartbeat 8, MsgHeartbeatResp 9
+        const bool kind_ok = t == 2 || t == 3 || t == 4 || t == 5 || t == 6 || t == 8 || t == 9;
+        if (malformed || !kind_ok || m.group >= ff.n_groups || m.from >= ff.n_peers || m.to != ff.self) {
+          m.flags |= kFrameSkip;
+        } else if (t == 2) {
+          m.flags |= kFrameHold;
+        } else if (t == 3) {
+          m.flags |= kFrameBarrier | (ff.tail_appends ? kFrameEntries : 0);
+          m.reject_hint = m.n_ents ? f.get(14) : 0;  // (slot 14: Term of the Entry walked last)
+        }
+      }
     }
     const uint32_t cnt = live ? m.n_ents : 0u;
     const uint64_t mb = __ballot(malformed);
@@ -960,7 +993,7 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
         if (k < cnt) ent_run[local + k] = my_ents[k];
     }
     tile_records_out(m, live && !RAFTQ_ABLATE(ctl, 0), reinterpret_cast<u32x4*>(file), RAFTQ_ABLATE(ctl, 0) ? msgs_h - tile0 : msgs_h, tile0,
-                     RAFTQ_ABLATE(ctl, 0) ? tile0 + 1 : n);  // (its barrier publishes ent_run too)
+                     RAFTQ_ABLATE(ctl, 0) ? tile0 + 1 : n, msgs_d);  // (its barrier publishes ent_run too)
     RAFTQ_TRACE_STAMP(ctl, cur, 6);
     if (ents_h != nullptr && tile_ents != 0 && !RAFTQ_ABLATE(ctl, 1)) {
       const uint64_t run0 = prefix[0];

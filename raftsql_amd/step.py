@@ -23,6 +23,8 @@ MSG_TYPES = (MSG_HUP, MSG_BEAT, MSG_APP, MSG_APP_RESP, MSG_VOTE, MSG_VOTE_RESP, 
 OUT_NONE, OUT_VOTE_RESP, OUT_HEARTBEAT_RESP, OUT_CAMPAIGN, OUT_BECAME_LEADER, OUT_PROGRESS, OUT_BCAST_HEARTBEAT, OUT_APPEND = range(8)
 OUT_APPENDED = 8  # MsgApp with MSGF_ENTRIES that appended at the tail: Step did maybeAppend's bookkeeping itself
 OUT_DEFERRED = 9  # not applied: an earlier MsgApp of the group with MSGF_BARRIER was left to the caller (OUT_APPEND)
+OUT_SKIPPED, OUT_HELD = 10, 11  # MSGF_SKIP: nobody's, nothing looked at; MSGF_HOLD: the caller's (MsgProp), the rest of its group deferred
+MSGF_SKIP, MSGF_HOLD = 0x10, 0x20
 MSGF_BARRIER = 0x40  # on a MsgApp: if it is answered OUT_APPEND, the group's later messages of the batch are deferred
 MSGF_ENTRIES = 0x80  # msgs["_pad"][:, 1]: _resv = number of entries, reject_hint = the last one's term (raftq_step.h)
 OUTF_HARDSTATE, OUTF_COMMITTED, OUTF_UPDATED, OUTF_STEPPED_DOWN = 1, 2, 4, 8

@@ -116,6 +116,26 @@ class WireEngine(NodeEngine):
         off = np.ascontiguousarray(frame_off, np.uint64)
         self._chk(self._lib.raftq_step_submit_wire(self._h, _p(s), len(s), _ptr(off), len(off) - 1))
 
+    def step_frames(self, stream: np.ndarray, frame_off: np.ndarray, msgs: np.ndarray, ents: np.ndarray | None = None,
+                    tail_appends: bool = True):
+        """raftq_step_frames: decode + a node's checks + Step over every frame, one submission and one wait.  All arrays
+        page-locked (engine.pinned_empty / pinned_copy).  -> (msgs[:n], ents[:min(n_ents, cap)], outs (a copy), counts)"""
+        from .step import OUT_C_DT, OUT_DT
+
+        n = len(frame_off) - 1
+        assert stream.dtype == np.uint8 and frame_off.dtype == np.uint64 and msgs.dtype == WIRE_MSG_DT and len(msgs) >= n
+        c = _lib.WireCounts()
+        self._chk(self._lib.raftq_step_frames(self._h, stream.ctypes.data if len(stream) else None, len(stream), frame_off.ctypes.data, n,
+                                              1 if tail_appends else 0, msgs.ctypes.data, ents.ctypes.data if ents is not None else None,
+                                              len(ents) if ents is not None else 0, C.byref(c)))
+        p, k = C.c_void_p(None), C.c_uint64(0)
+        dt = OUT_C_DT if self.compact else OUT_DT
+        fn = self._lib.raftq_step_results_c if self.compact else self._lib.raftq_step_results
+        self._chk(fn(self._h, C.byref(p), C.byref(k)))
+        outs = np.frombuffer((C.c_char * (k.value * dt.itemsize)).from_address(p.value), dtype=dt, count=k.value).copy() if k.value else np.zeros(0, dt)
+        got_ents = ents[: min(int(c.n_ents), len(ents))] if ents is not None else np.zeros(0, WIRE_ENT_DT)
+        return msgs[:n], got_ents, outs, c
+
     def step_stage_wire(self, n_cap: int, nbytes_cap: int):
         """the arrays the next step_submit_wire_staged() takes (raftq_step_stage_wire) -> (frame_off uint64[n_cap + 1],
         stream uint8[nbytes_cap]); views of device memory behind a large BAR: write-only"""

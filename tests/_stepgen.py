@@ -168,3 +168,42 @@ def barrier_table():
         m["index"][i], m["log_term"][i], m["commit"][i], m["_resv"][i], m["reject_hint"][i] = r[3], r[4], r[5], r[6], r[7]
     m["term"], m["from"] = 5, 0
     return s, m, [r[8] for r in rows], {"committed": [11, 9], "last_index": [11, 10], "last_term": [5, 4]}
+
+
+def with_hold_skip(rng, m, p_hold=0.06, p_skip=0.06):
+    """a copy of the batch with RAFTQ_MSGF_HOLD on some records (half of them made MsgProp, a type Step does not take: it is
+    not to look) and RAFTQ_MSGF_SKIP on others (group / type / from filled with garbage: no field is to be looked at)"""
+    m = m.copy()
+    n = len(m)
+    hold = rng.random(n) < p_hold
+    skip = ~hold & (rng.random(n) < p_skip)
+    m["type"] = np.where(hold & (rng.random(n) < 0.5), 2, m["type"])
+    m["from"] = np.where(hold & (rng.random(n) < 0.3), 0xFFFFFFFF, m["from"])
+    m["group"] = np.where(skip, rng.integers(0, 2**63, n).astype(np.uint64), m["group"])
+    m["type"] = np.where(skip, rng.integers(0, 256, n), m["type"])
+    m["from"] = np.where(skip, rng.integers(0, 2**32, n), m["from"])
+    m["_pad"][:, 1] |= np.where(hold, 0x20, 0).astype(np.uint8) | np.where(skip, 0x10, 0).astype(np.uint8)
+    return m
+
+
+def hold_skip_table():
+    """RAFTQ_MSGF_HOLD / RAFTQ_MSGF_SKIP by hand: two follower groups (3 peers, slot 1, term 5, tail (10, 4), commit 7) ->
+    (NodeState, msgs, want types, state after)"""
+    s = pyoracle.NodeState(2, 3, 1)
+    s.term[:], s.last_index[:], s.last_term[:], s.committed[:] = 5, 10, 4, 7
+    s.match[1] = 10
+    rows = [
+        # group, type, flags, commit -> out type
+        (0, 8, 0x00, 8, 2),        # a heartbeat: commit 8
+        (99, 77, 0x10, 0, 10),     # nobody's (group and type are garbage): skipped
+        (0, 2, 0x20, 0, 11),       # a MsgProp, held: the caller's
+        (0, 8, 0x00, 9, 9),        # ... and the group's later heartbeat waits (commit stays 8)
+        (0, 2, 0x20, 0, 11),       # a second held message of the group is the caller's all the same
+        (1, 8, 0x00, 9, 2),        # the other group is nobody's business: commit 9
+        (0, 8, 0x10, 10, 10),      # skipped wins over everything: not even deferred
+    ]
+    m = np.zeros(len(rows), dtype=pyoracle.STEP_MSG_DT)
+    for i, r in enumerate(rows):
+        m["group"][i], m["type"][i], m["_pad"][i][1], m["commit"][i] = r[0], r[1], r[2], r[3]
+    m["term"], m["from"] = 5, 0
+    return s, m, [r[4] for r in rows], {"committed": [8, 9]}

@@ -647,3 +647,65 @@ def test_pad_bytes_are_padding_until_the_handle_opts_in():
     want = copy.deepcopy(st).step_batch(dirty)  # the oracle reads the flags the garbage spells
     assert got["dirty, opted in"][0].tobytes() == want.tobytes()
     assert want.tobytes() != got["clean"][0].tobytes()  # (and it does spell some: the opt-in is what makes them count)
+
+
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+def test_hold_and_skip_table_on_the_gpu(NodeEngine, oracle, walk, monkeypatch):
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    s, m, want, after = _stepgen.hold_skip_table()
+    with NodeEngine(s.G, s.N, s.self_peer) as e:
+        _stepgen.load_engine(e, s)
+        ref = s.step_batch(m)
+        got, touched = e.step_batch(m)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert [int(t) for t in got["type"]] == want and touched == 2
+        _stepgen.assert_same_state(e, s)
+
+
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+def test_hold_and_skip_flags_random_traffic(NodeEngine, oracle, walk, monkeypatch):
+    """RAFTQ_MSGF_HOLD / RAFTQ_MSGF_SKIP among random traffic (hot groups: many messages per group and batch, long runs that
+    stall the list walk into the sorted one; skipped records with garbage in every field): every result byte and the state
+    against the oracle, synchronous and three batches in flight, full and compact result records."""
+    from raftsql_amd import step as S
+
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    rng = np.random.default_rng(9090)
+    G, N = 5000, 5
+    s = _stepgen.random_state(rng, G, N, self_peer=2)
+    with NodeEngine(G, N, 2) as e:
+        _stepgen.load_engine(e, s)
+        for it in range(8):
+            hot = rng.choice(G, 30) if it % 2 else None
+            m = _stepgen.with_hold_skip(rng, _stepgen.random_batch(rng, s, int(rng.integers(1, 5000)), hot_groups=hot))
+            got, _ = e.step_batch(m)
+            assert np.array_equal(got.view(np.uint8), s.step_batch(m).view(np.uint8)), it
+        _stepgen.assert_same_state(e, s)
+        batches = [_stepgen.with_hold_skip(rng, _stepgen.random_batch(rng, s, 3000, hot_groups=rng.choice(G, 200))) for _ in range(3)]
+        for b in batches:
+            e.step_submit(b)
+        for b in batches:
+            assert np.array_equal(e.step_collect()[0].view(np.uint8), s.step_batch(b).view(np.uint8))
+        _stepgen.assert_same_state(e, s)
+        e.set_compact(True)
+        m = _stepgen.with_hold_skip(rng, _stepgen.random_batch(rng, s, 4000))
+        e.step_submit(m)
+        c, _ = e.step_collect()
+        want = s.step_batch(m)
+        live = want["type"] != S.OUT_SKIPPED  # (a compact record names neither group nor addressee: the caller's batch does --
+        full = S.expand_compact(m, c)         #  and a skipped record's fields are garbage by definition)
+        assert np.array_equal(full[live].view(np.uint8), want[live].view(np.uint8))
+        assert (c["type"][~live] == S.OUT_SKIPPED).all()
+        _stepgen.assert_same_state(e, s)
+    # a handle that has not opted in reads none of it
+    s2 = _stepgen.random_state(rng, 100, 3, 0)
+    m = _stepgen.random_batch(rng, s2, 300)
+    m["_pad"][:, 1] = 0
+    flagged = m.copy()
+    flagged["_pad"][:, 1] = rng.choice([0x10, 0x20, 0x30], len(m)).astype(np.uint8)
+    with S.NodeEngine(100, 3, 0, msg_flags=False) as e:
+        _stepgen.load_engine(e, s2)
+        got, _ = e.step_batch(flagged)
+        assert np.array_equal(got.view(np.uint8), s2.step_batch(m).view(np.uint8))

@@ -361,3 +361,49 @@ def test_barrier_table_c_oracle():
     assert [int(t) for t in out["type"]] == want
     for k, v in after.items():
         assert [int(x) for x in getattr(s, k)] == v, k
+
+
+def test_hold_and_skip_table_c_oracle():
+    """RAFTQ_MSGF_HOLD: not stepped, answered where it stands, the rest of its group waits; RAFTQ_MSGF_SKIP: nobody's"""
+    s, m, want, after = _stepgen.hold_skip_table()
+    before = (s.term.copy(), s.last_index.copy())
+    out = s.step_batch(m)
+    assert [int(t) for t in out["type"]] == want
+    for k, v in after.items():
+        assert [int(x) for x in getattr(s, k)] == v, k
+    assert np.array_equal(s.term, before[0]) and np.array_equal(s.last_index, before[1])
+    skipped = out[out["type"] == 10]
+    assert not skipped.view(np.uint8).reshape(len(skipped), 64)[:, :57].any() and not skipped["role"].any()  # an otherwise zero record
+    held = out[out["type"] == 11]
+    assert list(held["commit"]) == [8, 8] and list(held["group"]) == [0, 0]  # the state as it stood at that point
+
+
+def test_hold_and_skip_equal_removing_the_records():
+    """A batch with held / skipped records leaves the state -- and answers every other record -- exactly as the batch
+    without them and without whatever follows a held record in its group."""
+    import copy
+
+    rng = np.random.default_rng(77)
+    G, N = 40, 5
+    for it in range(20):
+        s = _stepgen.random_state(rng, G, N, self_peer=it % N)
+        m = _stepgen.with_hold_skip(rng, _stepgen.random_batch(rng, s, 600), 0.05, 0.08)
+        fl = m["_pad"][:, 1]
+        keep = np.ones(len(m), bool)
+        held = set()
+        for i in range(len(m)):
+            if fl[i] & 0x10:
+                keep[i] = False
+            elif fl[i] & 0x20:
+                keep[i] = False
+                held.add(int(m["group"][i]))
+            elif int(m["group"][i]) in held:
+                keep[i] = False
+        s2 = copy.deepcopy(s)
+        out = s.step_batch(m)
+        out2 = s2.step_batch(m[keep])
+        assert np.array_equal(out[keep], out2)
+        for k in _STATE_KEYS:
+            assert np.array_equal(getattr(s, k), getattr(s2, k)), k
+        rest = out[~keep]
+        assert set(int(t) for t in rest["type"]) <= {9, 10, 11}

@@ -914,3 +914,152 @@ def test_step_from_frames_staged_in_place():
         na, nb = a.read_node(), b.read_node()
         for k in na:
             assert np.array_equal(na[k], nb[k]), k
+
+
+# ---- raftq_step_frames: a node's inbound half-turn as one submission ---------------------------------------------------
+
+def _node_frames(rng, n, st, self_peer):
+    """n frames as a node of st's cluster might receive them in one turn, consistent with st (an oracle NodeState): MsgApps
+    with entries (half of them exactly on their group's tail), MsgProps with entries, the payload-free kinds, and what a node
+    has to shrug off -- frames for another slot, from no peer, for no group, of kinds a peer never sends, and garbage bytes.
+    -> (stream, frame_off)"""
+    G, N = st.G, st.N
+    m = np.zeros(n, W.WIRE_MSG_DT)
+    g = rng.integers(0, G, n)
+    m["group"] = g
+    m["type"] = rng.choice([2, 3, 4, 5, 6, 8, 9], n, p=[0.08, 0.30, 0.30, 0.06, 0.06, 0.10, 0.10])
+    m["term"] = np.maximum(1, st.term[g].astype(np.int64) + rng.choice([-1, 0, 0, 0, 0, 1], n)).astype(np.uint64)
+    m["from"] = (self_peer + 1 + rng.integers(0, N - 1, n)) % N
+    m["to"] = self_peer
+    li = st.last_index[g].astype(np.int64)
+    m["index"] = np.maximum(0, li + rng.integers(-2, 3, n)).astype(np.uint64)
+    m["log_term"] = np.maximum(0, st.last_term[g].astype(np.int64) + rng.integers(-1, 2, n)).astype(np.uint64)
+    m["commit"] = np.maximum(0, li + rng.integers(-3, 3, n)).astype(np.uint64)
+    m["reject"] = rng.random(n) < 0.2
+    m["reject_hint"] = m["index"]
+    tail = (m["type"] == 3) & (rng.random(n) < 0.6)
+    m["index"] = np.where(tail, st.last_index[g], m["index"])
+    m["log_term"] = np.where(tail, st.last_term[g], m["log_term"])
+    carries = ((m["type"] == 3) & (rng.random(n) < 0.8)) | (m["type"] == 2)
+    k = np.where(carries, rng.choice([1, 1, 2, 3, 6], n), 0)  # (6: more than a decoder lane keeps)
+    m["n_ents"] = k
+    m["ent_first"] = np.concatenate([[0], np.cumsum(k)[:-1]])
+    ne = int(k.sum())
+    e = np.zeros(ne, W.WIRE_ENT_DT)
+    owner = np.repeat(np.arange(n), k)
+    e["term"] = np.maximum(m["log_term"][owner], m["term"][owner] - (rng.random(ne) < 0.5))
+    e["index"] = m["index"][owner] + 1 + (np.arange(ne) - m["ent_first"][owner])
+    e["data_len"] = rng.integers(0, 40, ne)
+    e["data_off"] = np.concatenate([[0], np.cumsum(e["data_len"])[:-1]]) if ne else 0
+    pool = rng.integers(0, 256, int(e["data_len"].sum()) + 1, dtype=np.uint8)
+    # what a node has to shrug off
+    odd = rng.random(n)
+    m["to"] = np.where(odd < 0.03, (self_peer + 1) % N, m["to"])
+    m["from"] = np.where((odd >= 0.03) & (odd < 0.05), N + 3, m["from"])
+    m["group"] = np.where((odd >= 0.05) & (odd < 0.07), G + rng.integers(0, 1000, n), m["group"])
+    m["type"] = np.where((odd >= 0.07) & (odd < 0.10), rng.choice([0, 1, 7, 10, 11, 200], n), m["type"])
+    s, off = W.wire_encode(m, e, pool)
+    s = s.copy()
+    for i in np.nonzero((odd >= 0.10) & (odd < 0.12))[0]:  # garbage where the message's first key was
+        s[int(off[i]) + 8] = 0x0B
+    return s, off
+
+
+def _node_filter(wm, we, G, N, self_peer, tail_appends):
+    """what raftq_step_frames' decoder does to the decoded records (include/raftq_wire.h), restated -> (records as handed to
+    the caller, the same as Step reads them)"""
+    from raftsql_amd import step as S
+
+    out = wm.copy()
+    t = out["type"]
+    kind_ok = np.isin(t, [2, 3, 4, 5, 6, 8, 9])
+    skip = ((out["flags"] & W.F_MALFORMED) != 0) | ~kind_ok | (out["group"] >= G) | (out["from"] >= N) | (out["to"] != self_peer)
+    hold = ~skip & (t == 2)
+    app = ~skip & (t == 3)
+    out["flags"] |= np.where(skip, S.MSGF_SKIP, 0).astype(np.uint8) | np.where(hold, S.MSGF_HOLD, 0).astype(np.uint8)
+    out["flags"] |= np.where(app, S.MSGF_BARRIER | (S.MSGF_ENTRIES if tail_appends else 0), 0).astype(np.uint8)
+    last = np.where(out["n_ents"] > 0, out["ent_first"].astype(np.int64) + out["n_ents"] - 1, 0)
+    last_term = we["term"][np.minimum(last, max(len(we) - 1, 0))] if len(we) else np.zeros(len(out), np.uint64)
+    out["reject_hint"] = np.where(app, np.where(out["n_ents"] > 0, last_term, 0), out["reject_hint"])
+    rec = np.zeros(len(out), S.MSG_DT)
+    for k in ("group", "term", "log_term", "index", "commit", "reject_hint", "from", "type", "reject"):
+        rec[k] = out[k]
+    rec["_pad"][:, 0], rec["_pad"][:, 1] = out["to"], out["flags"]
+    rec["_resv"] = out["n_ents"]  # (the oracle reads the count where a caller's record keeps it)
+    return out, rec
+
+
+@pytest.mark.parametrize("walk", ["lists", "sort"])
+@pytest.mark.parametrize("tail_appends", [True, False])
+def test_step_frames_equals_decode_filter_step(oracle, walk, tail_appends, monkeypatch):
+    """raftq_step_frames against its parts, all from the oracle: decode, the node's checks (restated above), Step over every
+    frame with the flags the checks set -- decoded records, entry headers, every result byte, the state after."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+    from tests import _stepgen
+
+    if walk == "sort":
+        monkeypatch.setenv("RAFTQ_STEP_WALK", "sort")
+    G, N, me = 3000, 5, 2
+    rng = np.random.default_rng(515 + tail_appends)
+    st = _stepgen.random_state(rng, G, N, self_peer=me)
+    with WireEngine(G, N, me) as e:
+        _stepgen.load_engine(e, st)
+        for it, n in enumerate([1, 255, 257, 4000, 9000, 700]):
+            s, off = _node_frames(rng, n, st, me)
+            wm, we, _ = W.wire_decode(s, off)
+            want_m, rec = _node_filter(wm, we, G, N, me, tail_appends)
+            want_o = st.step_batch(rec)
+            ps, po = pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64))
+            msgs, ents = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+            gm, ge, go, c = e.step_frames(ps, po, msgs, ents, tail_appends=tail_appends)
+            assert (c.n_msgs, c.n_ents, c.bytes) == (n, len(we), len(s)) and c.n_malformed == int(((wm["flags"] & W.F_MALFORMED) != 0).sum())
+            _same(gm, want_m, f"records, call {it}")
+            _same(ge, we, f"entry headers, call {it}")
+            _same(go, want_o, f"results, call {it}")
+            types = set(int(t) for t in go["type"])
+            if n >= 4000:
+                assert {S.OUT_SKIPPED, S.OUT_HELD, S.OUT_DEFERRED} <= types and (not tail_appends or S.OUT_APPENDED in types)
+        _stepgen.assert_same_state(e, st)
+        # fewer entry headers than the frames hold: not an error here (the frames HAVE been stepped), the count says so
+        s, off = _node_frames(rng, 2000, st, me)
+        wm, we, _ = W.wire_decode(s, off)
+        _, rec = _node_filter(wm, we, G, N, me, tail_appends)
+        want_o = st.step_batch(rec)
+        ps, po = pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64))
+        msgs, few = pinned_empty(2000, W.WIRE_MSG_DT), pinned_empty(64, W.WIRE_ENT_DT)
+        few[:] = 0
+        gm, ge, go, c = e.step_frames(ps, po, msgs, few, tail_appends=tail_appends)
+        assert c.n_ents == len(we) > 64 and len(ge) == 64
+        _same(go, want_o, "results with a short entry array")
+        _same(ge, we[:64], "the entry headers that fit")
+        _stepgen.assert_same_state(e, st)
+
+
+def test_step_frames_refuses_what_it_cannot_stream(oracle):
+    from raftsql_amd import _lib
+    from raftsql_amd.engine import RaftqError, pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+    from tests import _stepgen
+
+    rng = np.random.default_rng(3)
+    st = _stepgen.random_state(rng, 64, 3, 0)
+    s, off = _node_frames(rng, 100, st, 0)
+    ps, po = pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64))
+    msgs = pinned_empty(100, W.WIRE_MSG_DT)
+    with WireEngine(64, 3, 0) as e:
+        _stepgen.load_engine(e, st)
+        with pytest.raises(RaftqError) as ei:  # pageable memory: the two calls are the caller's to make
+            e.step_frames(np.ascontiguousarray(s), po, msgs)
+        assert ei.value.code == _lib.RAFTQ_EINVAL
+        e.step_submit(_stepgen.random_batch(rng, st, 10))
+        with pytest.raises(RaftqError) as ei:  # a batch in flight
+            e.step_frames(ps, po, msgs)
+        assert ei.value.code == _lib.RAFTQ_ESTATE
+        e.step_collect()
+    with WireEngine(64, 3, 0, msg_flags=False) as e:  # a handle whose pad bytes are padding cannot be told what a frame is
+        _stepgen.load_engine(e, st)
+        with pytest.raises(RaftqError) as ei:
+            e.step_frames(ps, po, msgs)
+        assert ei.value.code == _lib.RAFTQ_ESTATE

@@ -59,7 +59,7 @@
 
 #include <stdint.h>
 
-#include "raftq_step.h"
+#include "raftq_wire.h" /* (raftq_step.h with it) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -78,7 +78,7 @@ typedef struct raftq_node raftq_node_t;
  * MsgApp: index / logTerm = the entry preceding the first one carried, commit = leader's commit;
  * entries carry their own Index and Term.  Frames that do not parse, are not addressed to this node,
  * or are of a kind a peer never sends (MsgHup, MsgBeat, MsgSnap, unknown) are dropped and counted. */
-#define RAFTQ_MSG_PROP 2
+/* (RAFTQ_MSG_PROP = 2: raftq_wire.h) */
 
 typedef struct raftq_node_status {
   uint64_t term, commit, last_index, applied;

@@ -238,6 +238,12 @@ int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n
  * raftLog.committed after record i -- how a commit moved by a tail report (a leader that
  * is its own quorum, a follower's commitTo) surfaces, the way Ready.HardState.Commit does */
 int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out /*[n]|NULL*/);
+/* The same reports enqueued and left: the call returns as soon as the records are staged, the engine's state has moved by the time
+ * anything called later on the handle runs, and nothing comes back -- for the reports whose outcome the caller knows: a LEADER's
+ * appendEntry with more than one peer cannot move raftLog.committed (the leader's own Match is the largest; the quorum-th
+ * largest is somebody else's and no ack has arrived for entries that did not exist), which is every report of a steady-state
+ * turn's proposals.  raftq_node makes this call for exactly those and the waiting one for everything else. */
+int raftq_apply_log_deltas_nowait(raftq_t* h, const raftq_log_delta_t* d, uint64_t n);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ extern "C" {
 #endif
 
 #define RAFTQ_MSG_SNAP 7 /* decoded, never accepted by Step */
+#define RAFTQ_MSG_PROP 2 /* decoded, never stepped: a follower forwarding a proposal to its leader -- the log owner's (raftq_step_frames holds it) */
 
 /* raftq_wire_msg_t.flags */
 #define RAFTQ_WIRE_F_MALFORMED 0x01u /* frame did not parse: every other field of the record is 0 */
@@ -213,6 +214,14 @@ typedef struct raftq_wal_counts {
 int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes,
                      uint32_t prev_crc, void* out, uint64_t cap, uint64_t* frame_off /*[n+1]|NULL*/,
                      raftq_wal_counts_t* counts /*|NULL*/);
+
+/* raftq_wal_encode in two halves, so that a turn's two encodes are ONE submission: _begin enqueues the encode on the handle's
+ * stream and returns without waiting (page-locked buffers only: RAFTQ_EINVAL otherwise); the wait of whatever is called next
+ * on the handle -- raftq_wire_encode in a node's turn -- covers it; _end reports what raftq_wal_encode would have (and waits
+ * itself if nothing has).  out / frame_off are not to be read, nor recs / pool reused, before _end.  One at a time. */
+int raftq_wal_encode_begin(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes,
+                           uint32_t prev_crc, void* out, uint64_t cap, uint64_t* frame_off /*[n+1]|NULL*/);
+int raftq_wal_encode_end(raftq_t* h, raftq_wal_counts_t* counts /*|NULL*/);
 
 /* w.ReadAll for a batch of frames (boundaries from raftq_wire_scan_frames, big_endian = 0):
  * parse every record, recompute the CRC chain from prev_crc and compare.  As ReadAll, a CRC

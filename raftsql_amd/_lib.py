@@ -127,6 +127,7 @@ _STEP_SIGS = [
     ("raftq_read_node", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("raftq_step_batch", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(StepCounts)]),
     ("raftq_apply_log_deltas", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("raftq_apply_log_deltas_nowait", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_step_submit", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("raftq_step_collect", C.c_int, [_H, C.c_void_p, C.POINTER(StepCounts)]),
     ("raftq_step_stage", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -166,6 +167,9 @@ _WIRE_SIGS = [
     ("raftq_step_wire_entries", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_wal_encode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
                                    C.c_void_p, C.POINTER(WalCounts)]),
+    ("raftq_wal_encode_begin", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                         C.c_void_p]),
+    ("raftq_wal_encode_end", C.c_int, [_H, C.POINTER(WalCounts)]),
     ("raftq_wal_decode", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                    C.POINTER(WalCounts)]),
 ]

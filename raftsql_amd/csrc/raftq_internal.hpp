@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "raftq.h"
+#include "raftq_wire.h"
 #include "raftq_kernels.hpp"
 
 struct raftq {
@@ -48,6 +49,15 @@ struct raftq {
   bool bar_probed = false;      // such memory has been found mapped writable into this process (/proc/self/maps)
   // raftq_apply_log_deltas' host bookkeeping, kept across calls: per-group (epoch << 32 | records seen this call)
   std::vector<uint64_t> ld_mark, ld_start;
+  // raftq_apply_log_deltas_nowait: two pinned staging areas taken in turn, an event each (the kernels that read it have run)
+  struct LdNowait {
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+  };
+  LdNowait ld_nowait[2];
+  uint32_t ld_nowait_next = 0;
   std::vector<uint32_t> ld_round, ld_pos;
   uint32_t ld_epoch = 0;
   raftqk::Advance* adv_h = nullptr;     // compacted advance list (host pointer)
@@ -172,6 +182,14 @@ struct raftq {
   uint64_t wire_lb_tiles = 0;
   uint32_t wire_last_tiles = 0;              // tiles of the streaming decode enqueued last (measurement builds dump its stamps)
   uint32_t wire_ticket_base = 0, wire_epoch = 0;
+  // raftq_wal_encode_begin .. _end: enqueued, its totals in wire_pin[8 ..]; `done`: a later wait has covered it and what _end
+  // will report is kept here
+  bool wal_pending = false, wal_pending_done = false;
+  uint64_t wal_pending_n = 0, wal_pending_cap = 0;
+  uint32_t wal_pending_prev = 0;
+  int wal_pending_rc = 0;
+  raftq_wal_counts_t wal_pending_counts{};
+  std::string wal_pending_err;
   std::string err;
   // RAFTQ_PROFILE=1: host-side phase times of raftq_cycle, printed at destroy
   double prof[6] = {0, 0, 0, 0, 0, 0};

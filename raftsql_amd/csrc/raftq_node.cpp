@@ -390,6 +390,14 @@ struct raftq_node {
   Pool pool;                      // the groups' log and commit-channel arrays
   bool oom = false;               // an arena or queue allocation failed this turn: advance() ends in ENOMEM
   bool tail_appends = true;       // MsgApps are staged with RAFTQ_MSGF_ENTRIES (RAFTQ_NODE_TAIL_APPENDS=0: headers only, as round 2)
+  bool deltas_nowait = true;      // RAFTQ_NODE_DELTAS_NOWAIT=0: every tail report is waited for
+  bool split_wal = true;          // RAFTQ_NODE_SPLIT_WAL=0: raftq_wal_encode as a call of its own, waited for, ahead of the outbound marshal
+  bool deltas_need_result = false;  // a report in n->deltas may move the commit index (a follower's): flush_deltas waits
+  bool wal_begun = false;         // flush_wal_begin .. flush_wal_end
+  size_t wal_inflight = 0;
+  raftq_wal_counts_t wal_cnt{};
+  bool fuse_inbound = true;       // a turn's frames are decoded AND stepped by one submission (raftq_step_frames) whenever nothing was
+                                  // raised locally ahead of them (RAFTQ_NODE_FUSE_INBOUND=0: raftq_wire_decode, then the staged rounds)
   bool broken = false;            // the engine's view of a log and the log itself disagree: advance() ends in ESTATE
   // the turn's decoded inbound entries and the bytes their payloads sit in (valid inside advance())
   const raftq_wire_ent_t* cur_ents = nullptr;
@@ -728,6 +736,7 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_ms
     d.last_term = term_at(g, g.log.size());
     d.commit_to = std::min(m.commit, lastnewi);  // `commitTo(min(m.Commit, lastnewi))`
     n->deltas.push_back(d);
+    n->deltas_need_result = true;  // a follower's commitTo: what the engine makes of it is published
   } else {  // reject with the hint
     r.index = m.index;
     r.reject = 1;
@@ -740,6 +749,22 @@ void follower_append(raftq_node_t* n, uint64_t gi, Group& g, const raftq_wire_ms
 // can poison()), on success with it held again.
 int flush_deltas(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   if (n->deltas.empty()) return RAFTQ_OK;
+  if (n->deltas_nowait && n->N > 1 && !n->deltas_need_result) {
+    // every report is a leader's appendEntry and there is more than one peer: raftLog.committed cannot move (the leader's own
+    // Match is the largest, the quorum-th largest is somebody else's) -- enqueued and left (raftq_apply_log_deltas_nowait);
+    // the engine's state has moved by the time the next Step runs
+    lk.unlock();
+    int rc;
+    {
+      DevCall dev(n, raftq_node::kPhDevDeltas);
+      rc = raftq_apply_log_deltas_nowait(n->h, n->deltas.data(), n->deltas.size());
+    }
+    if (rc != RAFTQ_OK) return rc;
+    lk.lock();
+    n->deltas.clear();
+    return RAFTQ_OK;
+  }
+  n->deltas_need_result = false;
   n->delta_commit.resize(n->deltas.size());
   lk.unlock();
   int rc;
@@ -937,7 +962,10 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 // entries, then its HardState if it changed (wal.Save's order), groups ascending; one batched encode with
 // the segment's running CRC carried across turns.  The first call also writes what wal.Create writes at
 // the head of a file: the crc record, the (empty) metadata, the empty snapshot.
-int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+// In two halves: _begin builds the records and ENQUEUES the encode (raftq_wal_encode_begin), the wait of the outbound marshal that
+// follows covers it, _end takes the bytes -- the turn's two encodes are one submission.
+int flush_wal_begin(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+  n->wal_inflight = 0;
   if (!n->wal_on || (n->wal_dirty.empty() && n->wal_head_written)) return RAFTQ_OK;
   std::sort(n->wal_dirty.begin(), n->wal_dirty.end());
   PinBuf& recs = n->wal_recs;
@@ -987,16 +1015,32 @@ int flush_wal(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     lk.unlock();
     return RAFTQ_ENOMEM;
   }
-  raftq_wal_counts_t cnt;
   const uint32_t prev = n->wal_crc;
   lk.unlock();
-  const int rc = raftq_wal_encode(n->h, recs.as<raftq_wal_rec_t>(), n_recs, pool.p, pool.size, prev, n->wal_enc.p, cap, nullptr, &cnt);
+  int rc = n->split_wal ? raftq_wal_encode_begin(n->h, recs.as<raftq_wal_rec_t>(), n_recs, pool.p, pool.size, prev, n->wal_enc.p, cap, nullptr) : RAFTQ_EINVAL;
+  n->wal_begun = rc == RAFTQ_OK;
+  if (rc == RAFTQ_EINVAL) {  // buffers the device cannot address (or RAFTQ_NODE_SPLIT_WAL=0): the whole call, now
+    rc = raftq_wal_encode(n->h, recs.as<raftq_wal_rec_t>(), n_recs, pool.p, pool.size, prev, n->wal_enc.p, cap, nullptr, &n->wal_cnt);
+  }
   if (rc != RAFTQ_OK) return rc;
   lk.lock();
-  n->wal_out.bytes.append((const char*)n->wal_enc.p, (size_t)cnt.bytes);
-  n->wal_crc = cnt.last_crc;
+  n->wal_inflight = n_recs;
+  return RAFTQ_OK;
+}
+int flush_wal_end(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+  if (n->wal_inflight == 0) return RAFTQ_OK;
+  if (n->wal_begun) {
+    lk.unlock();
+    const int rc = raftq_wal_encode_end(n->h, &n->wal_cnt);
+    n->wal_begun = false;
+    if (rc != RAFTQ_OK) return rc;
+    lk.lock();
+  }
+  n->wal_out.bytes.append((const char*)n->wal_enc.p, (size_t)n->wal_cnt.bytes);
+  n->wal_crc = n->wal_cnt.last_crc;
   n->wal_head_written = true;
-  n->stats.wal_records += n_recs;
+  n->stats.wal_records += n->wal_inflight;
+  n->wal_inflight = 0;
   return RAFTQ_OK;
 }
 
@@ -1034,6 +1078,9 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   n->self = self_peer;
   n->profiling = std::getenv("RAFTQ_PROFILE") != nullptr;
   if (const char* ta = std::getenv("RAFTQ_NODE_TAIL_APPENDS")) n->tail_appends = std::atoi(ta) != 0;
+  if (const char* fi = std::getenv("RAFTQ_NODE_FUSE_INBOUND")) n->fuse_inbound = std::atoi(fi) != 0;
+  if (const char* dn = std::getenv("RAFTQ_NODE_DELTAS_NOWAIT")) n->deltas_nowait = std::atoi(dn) != 0;
+  if (const char* sw = std::getenv("RAFTQ_NODE_SPLIT_WAL")) n->split_wal = std::atoi(sw) != 0;
   if (const char* ev = std::getenv("RAFTQ_PROFILE_EVERY")) n->prof_every = std::strtoull(ev, nullptr, 10);
   try {
     n->groups.resize(n_groups);
@@ -1310,39 +1357,12 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     n->turn_hups.clear();
     n->turn_hups.swap(n->pending_hups);
   }
-  // -- rafthttp's messageDecoder + Message.Unmarshal for everything received since the last turn, on
-  // the GPU (raftq_wire_decode).  Frames that do not parse, are not addressed to this node's slot, come
-  // from no peer of the cluster or are of a kind a peer never sends are dropped and counted (in the first Step
-  // round below) -- rafthttp would log and drop the stream; a raft node must survive any bytes a peer throws at it.
-  uint64_t nf = 0;
-  const raftq_wire_msg_t* wm = nullptr;
-  if (in_off.size() > 1) {
-    nf = in_off.size() - 1;
-    if (nf >= kLocal) return poison(n, RAFTQ_EINVAL, "more than 2^31 frames in one turn");
-    uint64_t ents_cap = std::max<uint64_t>(nf + 1024, n->turn_ents.cap / sizeof(raftq_wire_ent_t));
-    if (!n->turn_msgs.reserve(nf * sizeof(raftq_wire_msg_t)) || !n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t)))
-      return poison(n, RAFTQ_ENOMEM, "wire_decode (page-locked result buffers)");
-    raftq_wire_msg_t* out = n->turn_msgs.as<raftq_wire_msg_t>();
-    raftq_wire_ent_t* we = n->turn_ents.as<raftq_wire_ent_t>();
-    raftq_wire_counts_t cnt;
-    int rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
-    if (rc == RAFTQ_EINVAL && cnt.n_ents > ents_cap) {  // more entries than messages + 1024: grow once, decode again
-      ents_cap = cnt.n_ents;
-      if (!n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t))) return poison(n, RAFTQ_ENOMEM, "wire_decode (entries)");
-      we = n->turn_ents.as<raftq_wire_ent_t>();
-      rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
-    }
-    if (rc != RAFTQ_OK) return poison(n, rc, "wire_decode");
-    wm = out;
-    n->cur_ents = we;
-    n->cur_bytes = in_bytes.p;
-  }
   ph.next(raftq_node::kPhTick);
   // The commit channels, the status mirror and the outbound queues are only written below, under
   // mu, one short critical section per phase.
   std::unique_lock<std::mutex> lk(n->mu);
   const uint64_t published0 = n->stats.entries_published;
-  bool did = nf != 0 || props.size() != 0 || ticks != 0 || !n->turn_hups.empty();
+  bool did = in_off.size() > 1 || props.size() != 0 || ticks != 0 || !n->turn_hups.empty();
 
   // -- rc.node.Tick() (raft.go:223-224) for every group: the engine advances the clocks and says
   // which groups' election timers fired (MsgHup -> through Step) and which leaders owe a heartbeat
@@ -1376,6 +1396,48 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   if (local.size() >= kLocal) {
     lk.unlock();
     return poison(n, RAFTQ_EINVAL, "more than 2^31 local messages in one turn");
+  }
+  // -- rafthttp's messageDecoder + Message.Unmarshal for everything received since the last turn, on the GPU.  Frames that
+  // do not parse, are not addressed to this node's slot, come from no peer of the cluster or are of a kind a peer never sends
+  // are dropped and counted -- rafthttp would log and drop the stream; a raft node must survive any bytes a peer throws at it.
+  // When nothing was raised locally ahead of them (no campaign, no timer: every turn of steady-state replication) the same
+  // submission also makes those checks and steps every frame, in arrival order (raftq_step_frames: one wait for the inbound
+  // half of the turn); otherwise the frames are decoded here (raftq_wire_decode) and stepped in the staged rounds below, behind
+  // the local messages.
+  uint64_t nf = in_off.size() > 1 ? in_off.size() - 1 : 0;
+  const raftq_wire_msg_t* wm = nullptr;
+  const raftq_step_out_t* fused_outs = nullptr;  // != nullptr: round 1 has been stepped, out[i] answers frame i
+  if (nf) {
+    lk.unlock();
+    ph.next(raftq_node::kPhDecode);
+    if (nf >= kLocal) return poison(n, RAFTQ_EINVAL, "more than 2^31 frames in one turn");
+    uint64_t ents_cap = std::max<uint64_t>(nf + 1024, n->turn_ents.cap / sizeof(raftq_wire_ent_t));
+    if (!n->turn_msgs.reserve(nf * sizeof(raftq_wire_msg_t)) || !n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t)))
+      return poison(n, RAFTQ_ENOMEM, "wire_decode (page-locked result buffers)");
+    raftq_wire_msg_t* out = n->turn_msgs.as<raftq_wire_msg_t>();
+    raftq_wire_ent_t* we = n->turn_ents.as<raftq_wire_ent_t>();
+    raftq_wire_counts_t cnt;
+    const bool fuse = n->fuse_inbound && local.empty();
+    int rc = fuse ? raftq_step_frames(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, n->tail_appends ? 1 : 0, out, we, ents_cap, &cnt)
+                  : raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
+    if ((rc == RAFTQ_OK || rc == RAFTQ_EINVAL) && cnt.n_ents > ents_cap) {
+      // more entries than messages + 1024: grow once, decode again (after raftq_step_frames only for the headers: the frames
+      // have been stepped, and what the plain decode writes over the records is what Step read minus the flags it was given)
+      ents_cap = cnt.n_ents;
+      if (!n->turn_ents.reserve(ents_cap * sizeof(raftq_wire_ent_t))) return poison(n, RAFTQ_ENOMEM, "wire_decode (entries)");
+      we = n->turn_ents.as<raftq_wire_ent_t>();
+      rc = raftq_wire_decode(n->h, in_bytes.p, in_bytes.size, in_off.data(), nf, out, we, ents_cap, &cnt);
+    }
+    if (rc != RAFTQ_OK) return poison(n, rc, fuse ? "step_frames" : "wire_decode");
+    if (fuse) {
+      uint64_t n_out = 0;
+      rc = raftq_step_results(n->h, &fused_outs, &n_out);
+      if (rc != RAFTQ_OK || n_out != nf || !fused_outs) return poison(n, rc != RAFTQ_OK ? rc : RAFTQ_ESTATE, "step_frames (results)");
+    }
+    wm = out;
+    n->cur_ents = we;
+    n->cur_bytes = in_bytes.p;
+    lk.lock();
   }
   ph.next(raftq_node::kPhInbound);
   // what this turn works through, in order: the locally raised messages, then the inbound ones as they arrived
@@ -1440,10 +1502,19 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     // one pass: what cannot go yet is deferred, the rest is written where the GPU reads it (raftq_step_stage: device
     // memory behind a large BAR) -- the decoder's 64-byte record IS Step's record
     raftq_msg_t* staged = nullptr;
-    lk.unlock();
-    if (int rc = raftq_step_stage(n->h, work.size(), &staged)) return poison(n, rc, "step_stage");
     static_assert(sizeof(raftq_msg_t) == sizeof(raftq_wire_msg_t), "the decoder's record is Step's record");
     size_t n_step = 0;
+    const raftq_step_out_t* outs = nullptr;
+    const bool fused = first_round && fused_outs != nullptr;
+    if (fused) {
+      // round 1 has been stepped already, every frame of it, by the submission that decoded them (raftq_step_frames): what is
+      // nobody's was skipped, a MsgProp held its group, a MsgApp was a barrier -- out[i] answers frame i
+      batch.assign(work.begin(), work.end());
+      outs = fused_outs;
+      first_round = false;
+    } else {
+    lk.unlock();
+    if (int rc = raftq_step_stage(n->h, work.size(), &staged)) return poison(n, rc, "step_stage");
     for (const uint32_t ix : work) {
       const raftq_wire_msg_t& m = msg_at(ix);
       if (first_round && !(ix & kLocal)) {
@@ -1480,7 +1551,6 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       batch.push_back(ix);
     }
     first_round = false;
-    const raftq_step_out_t* outs = nullptr;
     if (n_step) {
       ph.next(raftq_node::kPhStep);
       int rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
@@ -1489,18 +1559,21 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       if (rc != RAFTQ_OK) return poison(n, rc, "step_batch");
     }
     lk.lock();
+    }
     ph.next(raftq_node::kPhApply);
-    n->stats.msgs_stepped += n_step;
+    n->stats.msgs_stepped += fused ? batch.size() : n_step;
     const size_t kept_back = deferred.size();  // (behind a MsgProp: decided while staging; what Step defers is added below)
     // consequences, in arrival order (stepped results and proposals interleaved as they came)
     // The groups of a batch are scattered over tens of MB of per-group state: the line of the group 16 messages ahead
     // and, 8 ahead (its line has arrived by then), its Progress and the tail of its log are asked for now.
     const size_t nb = batch.size();
     auto group_of = [&](size_t at) { return msg_at(batch[at]).group; };
+    // (a skipped frame's group field may hold anything: in a fused round result `at` answers frame `at`)
+    auto live_at = [&](size_t at) { return !fused || outs[at].type != RAFTQ_OUT_SKIPPED; };
     size_t k = 0;
     for (size_t bi = 0; bi < nb; ++bi) {
-      if (bi + 16 < nb) __builtin_prefetch(&n->groups[group_of(bi + 16)]);
-      if (bi + 8 < nb) {
+      if (bi + 16 < nb && live_at(bi + 16)) __builtin_prefetch(&n->groups[group_of(bi + 16)]);
+      if (bi + 8 < nb && live_at(bi + 8)) {
         const uint64_t g8 = group_of(bi + 8);
         const Group& ahead = n->groups[g8];
         if (ahead.leading) __builtin_prefetch(&n->prog[g8 * n->N * 2], 1);
@@ -1508,7 +1581,17 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
         ahead_of_publish(ahead);
       }
       const raftq_wire_msg_t& im = msg_at(batch[bi]);
+      if (fused && outs[k].type == RAFTQ_OUT_SKIPPED) {  // not a message for this node (the checks are the decoder's there)
+        ++dropped;
+        n->stats.msgs_stepped--;
+        ++k;
+        continue;
+      }
       if (im.type == RAFTQ_MSG_PROP) {
+        if (fused) {  // (answered RAFTQ_OUT_HELD: a result slot of its own)
+          n->stats.msgs_stepped--;
+          ++k;
+        }
         Group& g = n->groups[im.group];
         if (handle_proposal(n, im.group, g, prop_entries(im), im.n_ents) && n->dirty_mark[im.group] != ep) {
           n->dirty_mark[im.group] = ep;
@@ -1561,9 +1644,11 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   // -- wal.Save before transport.Send (raft.go:228-230): the caller persists what raftq_node_wal_poll
   // hands out before it transmits what raftq_node_poll hands out
   ph.next(raftq_node::kPhWal);
-  if (int rc = flush_wal(n, lk)) return poison(n, rc, "wal_encode");
+  if (int rc = flush_wal_begin(n, lk)) return poison(n, rc, "wal_encode");
   ph.next(raftq_node::kPhEncode);
   if (int rc = flush_outbound(n, lk)) return poison(n, rc, "wire_encode");
+  ph.next(raftq_node::kPhWal);
+  if (int rc = flush_wal_end(n, lk)) return poison(n, rc, "wal_encode");
   if (did) n->stats.turns++;
   const uint64_t pub = n->stats.entries_published - published0;
   lk.unlock();

@@ -277,6 +277,10 @@ void raftq_detail::free_node_state(raftq_t* h) {
     if (sl.ev_comp) (void)hipEventDestroy(sl.ev_comp);
     if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
   }
+  for (auto& q : h->ld_nowait) {
+    if (q.ev) (void)hipEventDestroy(q.ev);
+    if (q.host) (void)hipHostFree(q.host);
+  }
   if (h->step_s_in) (void)hipStreamDestroy(h->step_s_in);
   if (h->step_s_out) (void)hipStreamDestroy(h->step_s_out);
 }
@@ -876,16 +880,42 @@ int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   return rc_step;
 }
 
-int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {
-  if (int rc = raftq_detail::use_device_idle(h, "raftq_apply_log_deltas")) return rc;
+// wait = false (raftq_apply_log_deltas_nowait): the same kernels from a staging area of their own, enqueued and left
+static int log_deltas_impl(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out, bool wait) {
+  if (int rc = raftq_detail::use_device_idle(h, wait ? "raftq_apply_log_deltas" : "raftq_apply_log_deltas_nowait")) return rc;
   if (n == 0) return RAFTQ_OK;
   if (!d) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: null argument");
   for (uint64_t i = 0; i < n; ++i)
     if (d[i].group >= h->G) return fail(h, RAFTQ_EINVAL, "a log delta is out of range; nothing applied");
   if (int rc = ensure_node_state(h)) return rc;
   const size_t off_out = align256((size_t)n * sizeof(raftq_log_delta_t));
-  if (int rc = ensure_staging(h, off_out + (size_t)n * 8)) return rc;
   if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: batch too large (n must fit 32 bits)");
+  void *stage_h = nullptr, *stage_d = nullptr;
+  hipEvent_t stage_ev = nullptr;
+  if (wait) {
+    if (int rc = ensure_staging(h, off_out + (size_t)n * 8)) return rc;
+    stage_h = h->stage_h;
+    stage_d = h->stage_d;
+  } else {
+    // two pinned areas taken in turn: the host may not write into one before the kernels that read it have run -- which they
+    // have, two calls later, in anything but a pathological queue (the event says so)
+    raftq_t::LdNowait& q = h->ld_nowait[h->ld_nowait_next++ & 1];
+    if (q.ev) HIPCHK(h, hipEventSynchronize(q.ev));
+    else HIPCHK(h, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+    const size_t need = (size_t)n * sizeof(raftq_log_delta_t);
+    if (need > q.bytes) {
+      if (q.host) HIPCHK(h, hipHostFree(q.host));
+      q.host = q.dev = nullptr;
+      q.bytes = 0;
+      const size_t want = std::max(need * 2, (size_t)1 << 16);
+      HIPCHK(h, hipHostMalloc(&q.host, want, hipHostMallocMapped));
+      HIPCHK(h, hipHostGetDevicePointer(&q.dev, q.host, 0));
+      q.bytes = want;
+    }
+    stage_h = q.host;
+    stage_d = q.dev;
+    stage_ev = q.ev;
+  }
   // The common batch names every group once: one round, caller order, no bookkeeping.  Whether it does is found
   // with a per-group mark (epoch << 32 | records seen this call) -- an array lookup per record, not a hash map:
   // the map this replaces was most of the call's host time at 10^4 records (raftq_node's "deltas" phase).
@@ -918,18 +948,22 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
     return fail(h, RAFTQ_ENOMEM, "raftq_apply_log_deltas: host allocation failed");
   }
   h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;  // as in raftq_step_submit: the live commit index moves
-  raftq_log_delta_t* dst = (raftq_log_delta_t*)h->stage_h;
-  uint64_t* out_h = (uint64_t*)((uint8_t*)h->stage_h + off_out);
-  uint64_t* out_d = (uint64_t*)((uint8_t*)h->stage_d + off_out);
+  raftq_log_delta_t* dst = (raftq_log_delta_t*)stage_h;
+  uint64_t* out_h = (uint64_t*)((uint8_t*)stage_h + off_out);
+  uint64_t* out_d = (uint64_t*)((uint8_t*)stage_d + off_out);
   auto launch = [&](uint64_t start, uint64_t m) {
     hipLaunchKernelGGL(log_deltas_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                       node_arrays(h), (const LogDeltaRec*)h->stage_d + start, m,
+                       node_arrays(h), (const LogDeltaRec*)stage_d + start, m,
                        committed_out ? out_d + start : (uint64_t*)nullptr);
   };
   if (n_rounds == 1) {
     std::memcpy(dst, d, (size_t)n * sizeof(raftq_log_delta_t));
     launch(0, n);
     HIPCHK(h, hipGetLastError());
+    if (!wait) {
+      HIPCHK(h, hipEventRecord(stage_ev, h->stream));
+      return RAFTQ_OK;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (committed_out) std::memcpy(committed_out, out_h, (size_t)n * 8);
     return RAFTQ_OK;
@@ -955,10 +989,22 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
     launch(start, m);
     HIPCHK(h, hipGetLastError());
   }
+  if (!wait) {
+    HIPCHK(h, hipEventRecord(stage_ev, h->stream));
+    return RAFTQ_OK;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (committed_out)
     for (uint64_t k = 0; k < n; ++k) committed_out[pos_of[k]] = out_h[k];
   return RAFTQ_OK;
+}
+
+int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, uint64_t* committed_out) {
+  return log_deltas_impl(h, d, n, committed_out, true);
+}
+
+int raftq_apply_log_deltas_nowait(raftq_t* h, const raftq_log_delta_t* d, uint64_t n) {
+  return log_deltas_impl(h, d, n, nullptr, false);
 }
 
 }  // extern "C"

@@ -189,8 +189,8 @@ void trace_dump(raftq_t* h, const char* what, uint32_t n_tiles) {
 }
 #endif
 // after the call's wait: did a look-back give up (wire_pin[3], copied from the control block by the last tile)?
-int tile_ctl_check(raftq_t* h, const char* who) {
-  if (h->wire_pin[3] == 0) return RAFTQ_OK;
+int tile_ctl_check(raftq_t* h, const char* who, uint32_t pin_base = 0) {
+  if (h->wire_pin[pin_base + 3] == 0) return RAFTQ_OK;
   h->wire_lb_tiles = 0;  // the control block is not trusted any more: the next call allocates a fresh one
   return fail(h, RAFTQ_EHIP, std::string(who) + ": a workgroup waited a second for its predecessor's tile and gave up; the results are not valid");
 }
@@ -474,6 +474,59 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   return RAFTQ_OK;
 }
 
+// The streaming WAL encode, enqueued and NOT waited for; its totals go to wire_pin[pin_base ..] (raftq_wal_encode: 0;
+// raftq_wal_encode_begin: 8, so that the call enqueued behind it can use the words at 0).
+static int wal_streaming_enqueue(raftq_t* h, const void* v_recs, uint64_t n, const void* v_pool, uint64_t pool_bytes, uint32_t prev_crc, void* v_out,
+                                 uint64_t cap, void* v_off, uint32_t pin_base) {
+  const uint32_t n_tiles = blocks_for(n);
+  const unsigned workers = fused_grid(n_tiles);
+  Carver fc;
+  const void* const src[3] = {v_recs, v_pool, nullptr};
+  const uint64_t sizes[3] = {n * sizeof(WalRec), pool_bytes, 0};
+  TileCtl ctl;
+  if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
+  FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
+  if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+  bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+  hipLaunchKernelGGL(wal_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, pool_bytes, prev_crc,
+                     (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d + pin_base);
+  HIPCHK(h, hipGetLastError());
+  tile_ctl_launched(h, n_tiles, workers);
+  return RAFTQ_OK;
+}
+static int wal_streaming_finish(raftq_t* h, const char* who, uint64_t n, uint64_t cap, uint32_t prev_crc, uint32_t pin_base, raftq_wal_counts_t* counts) {
+  if (counts) {
+    *counts = raftq_wal_counts_t{0, 0, 0, 0, 0};
+    counts->last_crc = prev_crc;
+  }
+  if (int rc = tile_ctl_check(h, who, pin_base)) return rc;
+  const uint64_t* pin = h->wire_pin + pin_base;
+  const uint64_t total = pin[0];
+  if (pin[1])
+    return fail(h, RAFTQ_EINVAL, std::string(who) + ": a record has an unknown kind or a payload outside the pool; the output is not valid");
+  if (counts) {
+    counts->n_recs = n;
+    counts->bytes = total;
+  }
+  if (total > cap) return fail(h, RAFTQ_EINVAL, std::string(who) + ": out is too small (counts->bytes is the size needed)");
+  if (counts) {
+    counts->n_valid = n;
+    counts->last_crc = (uint32_t)pin[2];
+  }
+  return RAFTQ_OK;
+}
+// a raftq_wal_encode_begin whose _end has not come yet: wait for it and keep what _end will report (called by whatever else
+// is about to use its pinned words' neighbours' scratch from the host side)
+static int wal_pending_complete(raftq_t* h) {
+  if (!h->wal_pending || h->wal_pending_done) return RAFTQ_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->wal_pending_rc = wal_streaming_finish(h, "raftq_wal_encode_begin", h->wal_pending_n, h->wal_pending_cap, h->wal_pending_prev, 8, &h->wal_pending_counts);
+  if (h->wal_pending_rc != RAFTQ_OK) h->wal_pending_err = h->err;
+  h->wal_pending_done = true;
+  return RAFTQ_OK;
+}
+
 int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes,
                      uint32_t prev_crc, void* out, uint64_t cap, uint64_t* frame_off, raftq_wal_counts_t* counts) {
   if (int rc = use_device(h)) return rc;
@@ -495,36 +548,10 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
                       (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
   if (mapped && aligned16(v_recs) && aligned16(v_pool)) {
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
-    const uint32_t n_tiles = blocks_for(n);
-    const unsigned workers = fused_grid(n_tiles);
-    Carver fc;
-    const void* const src[3] = {v_recs, v_pool, nullptr};
-    const uint64_t sizes[3] = {n * sizeof(WalRec), pool_bytes, 0};
-    TileCtl ctl;
-    if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
-    FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
-    if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
-    if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
-    hipLaunchKernelGGL(wal_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, pool_bytes, prev_crc,
-                       (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
-    HIPCHK(h, hipGetLastError());
-    tile_ctl_launched(h, n_tiles, workers);
+    if (int rc = wal_pending_complete(h)) return rc;  // (a raftq_wal_encode_begin nobody ended: its results are kept for its _end)
+    if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 0)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (int rc = tile_ctl_check(h, "raftq_wal_encode")) return rc;
-    const uint64_t total = h->wire_pin[0];
-    if (h->wire_pin[1])
-      return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: a record has an unknown kind or a payload outside the pool; the output is not valid");
-    if (counts) {
-      counts->n_recs = n;
-      counts->bytes = total;
-    }
-    if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
-    if (counts) {
-      counts->n_valid = n;
-      counts->last_crc = (uint32_t)h->wire_pin[2];
-    }
-    return RAFTQ_OK;
+    return wal_streaming_finish(h, "raftq_wal_encode", n, cap, prev_crc, 0, counts);
   }
   const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
   Carver c;
@@ -584,6 +611,38 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
     counts->n_valid = n;
     counts->last_crc = (uint32_t)h->wire_pin[2];
   }
+  return RAFTQ_OK;
+}
+
+int raftq_wal_encode_begin(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes, uint32_t prev_crc,
+                           void* out, uint64_t cap, uint64_t* frame_off) {
+  if (int rc = use_device(h)) return rc;
+  if (h->wal_pending) return fail(h, RAFTQ_ESTATE, "raftq_wal_encode_begin: the previous one has not been ended (raftq_wal_encode_end)");
+  if (n == 0 || !recs || (pool_bytes && !pool) || !out || cap == 0) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode_begin: null argument or empty batch");
+  if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode_begin: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  void *v_recs = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
+  const bool mapped = cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
+                      (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
+  if (!(mapped && aligned16(v_recs) && aligned16(v_pool)))
+    return fail(h, RAFTQ_EINVAL, "raftq_wal_encode_begin: the records, the pool and the output must be page-locked (raftq_host_alloc, hipHostMalloc, "
+                                 "hipHostRegister), records and pool 16-byte aligned -- raftq_wal_encode otherwise");
+  if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 8)) return rc;
+  h->wal_pending = true;
+  h->wal_pending_done = false;
+  h->wal_pending_n = n;
+  h->wal_pending_cap = cap;
+  h->wal_pending_prev = prev_crc;
+  return RAFTQ_OK;
+}
+
+int raftq_wal_encode_end(raftq_t* h, raftq_wal_counts_t* counts) {
+  if (int rc = use_device(h)) return rc;
+  if (!h->wal_pending) return fail(h, RAFTQ_ESTATE, "raftq_wal_encode_end: nothing was begun");
+  if (int rc = wal_pending_complete(h)) return rc;  // (no wait left to make when a later call on the handle has waited already)
+  h->wal_pending = false;
+  if (counts) *counts = h->wal_pending_counts;
+  if (h->wal_pending_rc != RAFTQ_OK) return fail(h, h->wal_pending_rc, h->wal_pending_err);
   return RAFTQ_OK;
 }
 

@@ -193,6 +193,12 @@ class NodeEngine(QuorumEngine):
         a = np.frombuffer(buf, dtype=dt, count=k.value)
         return (a.copy() if copy else a), int(c.n_groups_touched)
 
+    def apply_log_deltas_nowait(self, group, last_index, last_term, commit_to=0) -> None:
+        """the same reports enqueued and left (raftq_apply_log_deltas_nowait): nothing comes back"""
+        a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)
+        a["group"], a["last_index"], a["last_term"], a["commit_to"] = group, last_index, last_term, commit_to
+        self._chk(self._lib.raftq_apply_log_deltas_nowait(self._h, _ptr(a) if len(a) else None, len(a)))
+
     def apply_log_deltas(self, group, last_index, last_term, commit_to=0) -> np.ndarray:
         """-> committed [n] after each record"""
         a = np.zeros(len(np.atleast_1d(group)), dtype=LOG_DELTA_DT)

@@ -187,6 +187,22 @@ class WireEngine(NodeEngine):
         self._chk(self._lib.raftq_wal_encode(*args, _ptr(out), len(out), _ptr(off), C.byref(c)))
         return out, off, int(c.last_crc)
 
+    def wal_encode_begin(self, recs: np.ndarray, pool: np.ndarray, prev_crc: int, out: np.ndarray, off: np.ndarray | None = None) -> None:
+        """raftq_wal_encode_begin: enqueue, do not wait; every array page-locked (engine.pinned_*) and kept alive until
+        wal_encode_end()"""
+        assert recs.dtype == WAL_REC_DT and pool.dtype == np.uint8 and out.dtype == np.uint8
+        self._wal_begun = (recs, pool, out, off)
+        self._chk(self._lib.raftq_wal_encode_begin(self._h, recs.ctypes.data, len(recs), pool.ctypes.data if len(pool) else None, len(pool),
+                                                   int(prev_crc), out.ctypes.data, len(out), off.ctypes.data if off is not None else None))
+
+    def wal_encode_end(self):
+        """-> (bytes written, last_crc) of the encode wal_encode_begin() enqueued"""
+        c = _lib.WalCounts()
+        rc = self._lib.raftq_wal_encode_end(self._h, C.byref(c))
+        self._wal_begun = None
+        self._chk(rc)
+        return int(c.bytes), int(c.last_crc)
+
     def wal_decode(self, data, frame_off, prev_crc: int = 0, recs: np.ndarray | None = None):
         """w.ReadAll for a batch -> (recs, n_valid, last_crc)"""
         b = _u8(data)

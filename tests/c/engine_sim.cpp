@@ -28,6 +28,10 @@ extern "C" {
 struct raftq {
   uint64_t G = 0;
   uint32_t N = 0, self = 0;
+  bool wal_pending = false;
+  int wal_rc = 0;
+  raftq_wal_counts_t wal_counts{};
+  std::string wal_err;
   std::vector<uint8_t> role, votes, action;
   std::vector<uint32_t> elapsed, vote, lead;
   std::vector<uint64_t> term, last_index, last_term, committed, first_idx, match;
@@ -365,6 +369,8 @@ int raftq_apply_log_deltas(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   return RAFTQ_OK;
 }
 
+int raftq_apply_log_deltas_nowait(raftq_t* h, const raftq_log_delta_t* d, uint64_t n) { return raftq_apply_log_deltas(h, d, n, nullptr); }
+
 int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, const raftq_wire_ent_t* ents, uint64_t n_ents, const void* pool,
                       uint64_t pool_bytes, void* out, uint64_t cap, uint64_t* frame_off, raftq_wire_counts_t* counts) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
@@ -411,6 +417,55 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (ents && n_ents > ents_cap) return fail(h, RAFTQ_EINVAL, "raftq_wire_decode: more entries than ents_cap (counts->n_ents is the number needed)");
   return RAFTQ_OK;
 }
+// raftq_step_frames from its parts: the oracle's decoder, the node's checks as include/raftq_wire.h states them, the oracle's Step
+int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, int tail_appends,
+                      raftq_wire_msg_t* msgs, raftq_wire_ent_t* ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  h->n_out = 0;
+  if (n == 0) return RAFTQ_OK;
+  if ((!stream && nbytes) || !frame_off || !msgs) return fail(h, RAFTQ_EINVAL, "raftq_step_frames: null argument");
+  if (!h->msg_flags) return fail(h, RAFTQ_ESTATE, "raftq_step_frames: the handle has not opted in to RAFTQ_MSGF_*");
+  if (!ents) ents_cap = 0;
+  uint64_t n_ents = 0, n_bad = 0;
+  rq_wire_decode((const uint8_t*)stream, nbytes, frame_off, n, msgs, ents, ents_cap, &n_ents, &n_bad);
+  if (counts) *counts = raftq_wire_counts_t{n, n_ents, n_bad, frame_off[n]};
+  std::vector<raftq_wire_ent_t> all;  // the last entry's term is needed even where the caller's array is short
+  const raftq_wire_ent_t* ev = ents;
+  try {
+    if (n_ents > ents_cap) {
+      all.resize((size_t)n_ents);
+      std::vector<raftq_wire_msg_t> tmp((size_t)n);
+      uint64_t a = 0, b = 0;
+      rq_wire_decode((const uint8_t*)stream, nbytes, frame_off, n, tmp.data(), all.data(), n_ents, &a, &b);
+      ev = all.data();
+    }
+    h->outs.resize((size_t)n);
+    std::vector<raftq_msg_t> rec((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) {
+      raftq_wire_msg_t& m = msgs[i];
+      const uint8_t t = m.type;
+      const bool kind_ok = t == RAFTQ_MSG_PROP || t == RAFTQ_MSG_APP || t == RAFTQ_MSG_APP_RESP || t == RAFTQ_MSG_VOTE ||
+                           t == RAFTQ_MSG_VOTE_RESP || t == RAFTQ_MSG_HEARTBEAT || t == RAFTQ_MSG_HEARTBEAT_RESP;
+      if ((m.flags & RAFTQ_WIRE_F_MALFORMED) || !kind_ok || m.group >= h->G || m.from >= h->N || m.to != h->self) {
+        m.flags |= RAFTQ_MSGF_SKIP;
+      } else if (t == RAFTQ_MSG_PROP) {
+        m.flags |= RAFTQ_MSGF_HOLD;
+      } else if (t == RAFTQ_MSG_APP) {
+        m.flags |= RAFTQ_MSGF_BARRIER | (tail_appends ? RAFTQ_MSGF_ENTRIES : 0);
+        m.reject_hint = m.n_ents ? ev[m.ent_first + m.n_ents - 1].term : 0;
+      }
+      memcpy(&rec[i], &m, sizeof(raftq_msg_t));
+      rec[i]._resv = m.n_ents;  // (the oracle reads the count where a caller's record keeps it)
+    }
+    rq_node_state_t s = h->state();
+    rq_oracle_step_batch(&s, rec.data(), (size_t)n, h->outs.data());
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_step_frames: host allocation failed");
+  }
+  h->n_out = n;
+  return RAFTQ_OK;
+}
 int raftq_wire_scan_frames(const void* buf, uint64_t nbytes, int big_endian, uint64_t* off, uint64_t cap, uint64_t* n_frames,
                            uint64_t* consumed) {
   if ((!buf && nbytes) || !off || !n_frames || !consumed) return fail(nullptr, RAFTQ_EINVAL, "raftq_wire_scan_frames: null argument");
@@ -441,6 +496,25 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   }
   if (need > cap) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode: out is too small (counts->bytes is the size needed)");
   rq_wal_encode(recs, n, (const uint8_t*)pool, prev_crc, (uint8_t*)out, cap, frame_off, &last);
+  return RAFTQ_OK;
+}
+// _begin .. _end: here the encode simply happens at _begin and _end hands over what it said
+int raftq_wal_encode_begin(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const void* pool, uint64_t pool_bytes, uint32_t prev_crc, void* out,
+                           uint64_t cap, uint64_t* frame_off) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (h->wal_pending) return fail(h, RAFTQ_ESTATE, "raftq_wal_encode_begin: the previous one has not been ended");
+  if (n == 0 || !recs || !out || cap == 0) return fail(h, RAFTQ_EINVAL, "raftq_wal_encode_begin: null argument or empty batch");
+  h->wal_rc = raftq_wal_encode(h, recs, n, pool, pool_bytes, prev_crc, out, cap, frame_off, &h->wal_counts);
+  h->wal_err = h->err;
+  h->wal_pending = true;
+  return RAFTQ_OK;
+}
+int raftq_wal_encode_end(raftq_t* h, raftq_wal_counts_t* counts) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!h->wal_pending) return fail(h, RAFTQ_ESTATE, "raftq_wal_encode_end: nothing was begun");
+  h->wal_pending = false;
+  if (counts) *counts = h->wal_counts;
+  if (h->wal_rc != RAFTQ_OK) return fail(h, h->wal_rc, h->wal_err);
   return RAFTQ_OK;
 }
 int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, uint32_t prev_crc,

@@ -709,3 +709,25 @@ def test_hold_and_skip_flags_random_traffic(NodeEngine, oracle, walk, monkeypatc
         _stepgen.load_engine(e, s2)
         got, _ = e.step_batch(flagged)
         assert np.array_equal(got.view(np.uint8), s2.step_batch(m).view(np.uint8))
+
+
+def test_log_deltas_nowait_leaves_the_state_the_waiting_call_does(NodeEngine, oracle):
+    """raftq_apply_log_deltas_nowait: the same kernels, enqueued and left -- the state every later call sees is the waiting
+    call's; several in a row (the staging areas are taken in turn), one group more than once in a batch, a Step right behind"""
+    rng = np.random.default_rng(606)
+    G, N = 4000, 3
+    s = _stepgen.random_state(rng, G, N, self_peer=1)
+    with NodeEngine(G, N, 1) as e:
+        _stepgen.load_engine(e, s)
+        for it in range(7):
+            k = int(rng.integers(1, 3000))
+            g = rng.integers(0, G, k) if it % 3 == 2 else rng.choice(G, min(k, G), replace=False)
+            li = s.last_index[g] + rng.integers(0, 3, len(g)).astype(np.uint64)
+            lt = np.maximum(s.last_term[g], s.term[g] * (s.role[g] == 2))
+            ct = np.where(s.role[g] == 2, 0, np.minimum(li, s.committed[g] + rng.integers(0, 3, len(g)).astype(np.uint64)))
+            s.apply_log_deltas(g, li, lt, ct)
+            e.apply_log_deltas_nowait(g, li, lt, ct)
+            if it % 2:
+                m = _stepgen.random_batch(rng, s, 2000)
+                assert np.array_equal(e.step_batch(m)[0].view(np.uint8), s.step_batch(m).view(np.uint8)), it
+        _stepgen.assert_same_state(e, s)

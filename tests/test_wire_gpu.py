@@ -1063,3 +1063,53 @@ def test_step_frames_refuses_what_it_cannot_stream(oracle):
         with pytest.raises(RaftqError) as ei:
             e.step_frames(ps, po, msgs)
         assert ei.value.code == _lib.RAFTQ_ESTATE
+
+
+def test_wal_encode_begin_end_is_one_submission_with_the_call_behind_it():
+    """raftq_wal_encode_begin enqueues and returns; the wait of the raftq_wire_encode called next covers it; _end reports what
+    raftq_wal_encode would have.  Bytes, offsets, CRC against the oracle; also with nothing in between (_end waits itself),
+    with a refused batch (the error surfaces at _end), and begun twice."""
+    from raftsql_amd import _lib
+    from raftsql_amd.engine import RaftqError, pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    rng = np.random.default_rng(808)
+    with WireEngine(4096, 5, self_peer=0) as e:
+        for it, (nr, nm) in enumerate([(3000, 5000), (1, 1), (70000, 300), (257, 66000)]):
+            recs, wpool = _wiregen.random_wal(rng, nr, head=it % 2 == 0)
+            want_w, want_woff, want_crc = W.wal_encode(recs, wpool, prev_crc=77)
+            m, ents, pool = _wiregen.random_msgs(rng, nm, ent_frac=0.2)
+            want_s, want_soff = W.wire_encode(m, ents, pool)
+            p_recs, p_wpool = pinned_copy(np.ascontiguousarray(recs)), pinned_copy(np.ascontiguousarray(_wiregen_u8(wpool)))
+            w_out, w_off = pinned_empty(len(want_w) + 64, np.uint8), pinned_empty(len(recs) + 1, np.uint64)
+            e.wal_encode_begin(p_recs, p_wpool, 77, w_out, w_off)
+            if it != 1:  # (it == 1: nothing in between, _end makes the wait)
+                pm, pe, pp = pinned_copy(np.ascontiguousarray(m)), pinned_copy(np.ascontiguousarray(ents)) if len(ents) else ents, pinned_copy(np.ascontiguousarray(_wiregen_u8(pool)))
+                s_out, s_off = pinned_empty(len(want_s) + 64, np.uint8), pinned_empty(len(m) + 1, np.uint64)
+                got_s, got_soff = e.wire_encode(pm, pe, pp, out=s_out, off=s_off)
+                assert np.array_equal(got_soff, want_soff) and got_s.tobytes() == want_s.tobytes(), it
+            nbytes, crc = e.wal_encode_end()
+            assert (nbytes, crc) == (len(want_w), want_crc), it
+            assert w_out[:nbytes].tobytes() == want_w.tobytes() and np.array_equal(w_off, want_woff), it
+        # a refused batch: enqueued all the same, the verdict is _end's
+        recs, wpool = _wiregen.random_wal(rng, 500)
+        recs = recs.copy()
+        recs["kind"][123] = 9
+        p_recs, p_wpool = pinned_copy(np.ascontiguousarray(recs)), pinned_copy(np.ascontiguousarray(_wiregen_u8(wpool)))
+        w_out = pinned_empty(1 << 20, np.uint8)
+        e.wal_encode_begin(p_recs, p_wpool, 0, w_out)
+        with pytest.raises(RaftqError) as ei:
+            e.wal_encode_begin(p_recs, p_wpool, 0, w_out)  # one at a time
+        assert ei.value.code == _lib.RAFTQ_ESTATE
+        with pytest.raises(RaftqError) as ei:
+            e.wal_encode_end()
+        assert ei.value.code == _lib.RAFTQ_EINVAL
+        with pytest.raises(RaftqError) as ei:
+            e.wal_encode_end()  # nothing begun any more
+        assert ei.value.code == _lib.RAFTQ_ESTATE
+        with pytest.raises(RaftqError) as ei:  # pageable memory: raftq_wal_encode's business
+            e.wal_encode_begin(np.ascontiguousarray(recs), p_wpool, 0, w_out)
+        assert ei.value.code == _lib.RAFTQ_EINVAL
+        good, gpool = _wiregen.random_wal(rng, 50)
+        got, _, crc = e.wal_encode(good, gpool)  # and the handle is as good as before
+        assert got.tobytes() == W.wal_encode(good, gpool)[0].tobytes()

@@ -711,6 +711,34 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out; " + why,
                                          traffic=leg_traffic(["wire_dec_fused_kernel"]), algorithmic=2.0 * dec_in)
     mf["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_dec_p, dec_in, dec_out)
+    # a node's inbound half-turn on the same frames: ONE submission (raftq_step_frames: decode + the node's checks + Step over
+    # every frame, one wait) against round 3's way (raftq_wire_decode, wait, the records copied into the staging area,
+    # raftq_step_batch, wait)
+    from raftsql_amd import step as S_
+
+    def two_calls():
+        e.wire_decode(pstream, poff, msgs=pmsgs, ents=pents)
+        e.step_batch(pmsgs.view(S_.MSG_DT), want_out=False)
+
+    pmsgs2 = pinned_empty(n, W.WIRE_MSG_DT)
+    for _ in range(3):  # every Step slot's buffers exist before the clock starts
+        two_calls()
+        e.step_frames(pstream, poff, pmsgs2, pents, copy=False)
+    t_two = timeit(two_calls)
+    t_one = timeit(lambda: e.step_frames(pstream, poff, pmsgs2, pents, copy=False))
+    e.set_compact(True)  # 40-byte results: what raftq_node reads
+    t_one_c = timeit(lambda: e.step_frames(pstream, poff, pmsgs2, pents, copy=False))
+    e.set_compact(False)
+    half_in, half_out = float(len(stream) + poff.nbytes), float(pmsgs.nbytes + len(ents) * 32 + 64 * n)
+    out["inbound_half_turn"] = {
+        "what": "everything a node received in a turn (%d frames, 15 %% MsgApp with 1-3 entries): decoded, checked, stepped; "
+                "decoded records + entry headers + one 64-byte result per frame back" % n,
+        "one_submission_us": t_one * 1e6, "msgs_per_s": n / t_one, "decode_then_step_us": t_two * 1e6,
+        "one_submission_compact_results_us": t_one_c * 1e6, "msgs_per_s_compact_results": n / t_one_c,
+        "roofline": leg_roofline("pcie", "message", n, t_one, half_in, half_out,
+                                 "frames + offsets in; records, entry headers and results out (the results leave after the walk: the link "
+                                 "is idle while Step's two kernels run)")}
+    out["inbound_half_turn"]["roofline"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_one, half_in, half_out)
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)

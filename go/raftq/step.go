@@ -39,6 +39,8 @@ type Msg struct {
 const (
 	MsgfEntries = C.RAFTQ_MSGF_ENTRIES // on a MsgApp: Resv = entry count, RejectHint = the last entry's term
 	MsgfBarrier = C.RAFTQ_MSGF_BARRIER // on a MsgApp: what follows it in its group waits if it is left to the log's owner
+	MsgfHold    = C.RAFTQ_MSGF_HOLD    // not stepped (a MsgProp: the log owner's), answered OutHeld; the rest of its group is deferred
+	MsgfSkip    = C.RAFTQ_MSGF_SKIP    // nobody's: no field is looked at, answered OutSkipped
 )
 
 // SetMsgFlags opts the engine in to (or out of) Msg.Flags / Msg.Resv; no batch may be in flight.
@@ -68,6 +70,8 @@ const (
 	OutAppend         = C.RAFTQ_OUT_APPEND
 	OutDeferred       = C.RAFTQ_OUT_DEFERRED // not applied: behind a MsgApp (MsgfBarrier) that was left to the log's owner
 	OutAppended       = C.RAFTQ_OUT_APPENDED // MsgApp flagged MsgfEntries that appended at the tail: store the entries, ack Index
+	OutSkipped        = C.RAFTQ_OUT_SKIPPED  // MsgfSkip
+	OutHeld           = C.RAFTQ_OUT_HELD     // MsgfHold
 
 	FlagHardState   = C.RAFTQ_OUTF_HARDSTATE // persist {Term, Vote, Commit} before sending (raft.go:228-230)
 	FlagCommitted   = C.RAFTQ_OUTF_COMMITTED
@@ -144,6 +148,15 @@ func (e *Engine) ApplyLogDeltas(d []LogDelta, committed []uint64) error {
 		pc = (*C.uint64_t)(unsafe.Pointer(&committed[0]))
 	}
 	return e.err(C.raftq_apply_log_deltas(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d)), pc))
+}
+
+// ApplyLogDeltasNowait enqueues the same reports and returns (raftq_apply_log_deltas_nowait): nothing comes back -- for a
+// LEADER's appendEntry with more than one peer, which cannot move raftLog.committed.
+func (e *Engine) ApplyLogDeltasNowait(d []LogDelta) error {
+	if len(d) == 0 {
+		return nil
+	}
+	return e.err(C.raftq_apply_log_deltas_nowait(e.h, (*C.raftq_log_delta_t)(unsafe.Pointer(&d[0])), C.uint64_t(len(d))))
 }
 
 // LoadRoles sets role[g] (0 follower, 1 candidate, 2 leader) and, optionally, the election clocks.

@@ -201,3 +201,45 @@ func (e *Engine) StepStageWire(nCap, nbytesCap int) (frameOff []uint64, stream [
 	}
 	return unsafe.Slice((*uint64)(unsafe.Pointer(po)), nCap+1), unsafe.Slice((*byte)(ps), nbytesCap), nil
 }
+
+// StepFrames is a node's inbound half of a turn as ONE submission and one wait (raftq_step_frames): rafthttp's decoder, the
+// checks a node makes on what it received and rc.node.Step (raft.go:268-270) for every frame, in arrival order.  The decoder
+// says in every record's flag byte what Step made of it: a frame that is nobody's is skipped (OutSkipped), a MsgProp is
+// held for the log's owner (OutHeld, the rest of its group OutDeferred), a MsgApp is a barrier that says what it carries.
+// msgs / ents / stream / frameOff must be page-locked (HostAlloc).  Results: StepResults(), one per frame.  nEnts may exceed
+// len(ents): the frames have been stepped all the same, WireDecode fetches the remaining headers.
+func (e *Engine) StepFrames(stream []byte, frameOff []uint64, tailAppends bool, msgs []WireMsg, ents []WireEnt) (nEnts, nMalformed uint64, err error) {
+	n := len(frameOff) - 1
+	if n <= 0 {
+		return 0, 0, nil
+	}
+	var pe *C.raftq_wire_ent_t
+	if len(ents) > 0 {
+		pe = (*C.raftq_wire_ent_t)(unsafe.Pointer(&ents[0]))
+	}
+	ta := C.int(0)
+	if tailAppends {
+		ta = 1
+	}
+	var c C.raftq_wire_counts_t
+	rc := C.raftq_step_frames(e.h, bytesPtr(stream), C.uint64_t(len(stream)), (*C.uint64_t)(unsafe.Pointer(&frameOff[0])), C.uint64_t(n), ta,
+		(*C.raftq_wire_msg_t)(unsafe.Pointer(&msgs[0])), pe, C.uint64_t(len(ents)), &c)
+	return uint64(c.n_ents), uint64(c.n_malformed), e.err(rc)
+}
+
+// WalSaveBegin / WalSaveEnd: rc.wal.Save (raft.go:228) in two halves, so that a turn's WAL encode and its outbound marshal
+// are one submission: Begin enqueues (raftq_wal_encode_begin; page-locked buffers), the wait of the WireEncode called next
+// covers it, End reports what WalSave would have.  out is not to be read, nor recs / pool reused, before End.
+func (e *Engine) WalSaveBegin(recs []WalRec, pool []byte, prevCrc uint32, out []byte) error {
+	if len(recs) == 0 {
+		return nil
+	}
+	return e.err(C.raftq_wal_encode_begin(e.h, (*C.raftq_wal_rec_t)(unsafe.Pointer(&recs[0])), C.uint64_t(len(recs)), bytesPtr(pool),
+		C.uint64_t(len(pool)), C.uint32_t(prevCrc), bytesPtr(out), C.uint64_t(len(out)), nil))
+}
+
+func (e *Engine) WalSaveEnd() (n uint64, lastCrc uint32, err error) {
+	var c C.raftq_wal_counts_t
+	rc := C.raftq_wal_encode_end(e.h, &c)
+	return uint64(c.bytes), uint32(c.last_crc), e.err(rc)
+}

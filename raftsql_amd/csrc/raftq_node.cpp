@@ -785,6 +785,28 @@ int flush_deltas(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 }
 
 // what one Step result means for the node (the "Ready" consequences of one message)
+// The node reads Step's 40-byte result records (raftq_step_set_compact: what a result says beyond the message it answers --
+// 24 bytes per message less on the link, which is what bounds the inbound half of a turn): group and addressee are the
+// message's own, log_term / last_index share a slot (include/raftq_step.h).
+inline raftq_step_out_t widen(const raftq_step_out_c_t& c, const raftq_wire_msg_t& im) {
+  raftq_step_out_t o;
+  o.group = im.group;
+  o.term = c.term;
+  o.index = c.index;
+  o.commit = c.commit;
+  const bool tip = c.type == RAFTQ_OUT_CAMPAIGN || c.type == RAFTQ_OUT_BECAME_LEADER;  // index IS the last index there
+  o.log_term = tip ? c.aux : 0;
+  o.last_index = tip ? c.index : c.aux;
+  o.to = im.from;
+  o.vote = c.vote;
+  o.lead = c.lead;
+  o.type = c.type;
+  o.reject = c.reject;
+  o.flags = c.flags;
+  o.role = c.role;
+  return o;
+}
+
 void apply_result(raftq_node_t* n, const raftq_step_out_t& o, const raftq_wire_msg_t& im) {
   const uint64_t gi = im.group;
   Group& g = n->groups[gi];
@@ -1068,6 +1090,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   int rc = raftq_create(device, n_groups, n_peers, &n->h);
   if (rc == RAFTQ_OK) rc = raftq_set_self(n->h, self_peer);
   if (rc == RAFTQ_OK) rc = raftq_step_set_msg_flags(n->h, 1);  // this node fills every byte of every record it stages (RAFTQ_MSGF_*)
+  if (rc == RAFTQ_OK) rc = raftq_step_set_compact(n->h, 1);    // ... and reads 40-byte result records (widen())
   if (rc != RAFTQ_OK) {
     if (n->h) raftq_destroy(n->h);
     delete n;
@@ -1406,7 +1429,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   // the local messages.
   uint64_t nf = in_off.size() > 1 ? in_off.size() - 1 : 0;
   const raftq_wire_msg_t* wm = nullptr;
-  const raftq_step_out_t* fused_outs = nullptr;  // != nullptr: round 1 has been stepped, out[i] answers frame i
+  const raftq_step_out_c_t* fused_outs = nullptr;  // != nullptr: round 1 has been stepped, out[i] answers frame i
   if (nf) {
     lk.unlock();
     ph.next(raftq_node::kPhDecode);
@@ -1431,7 +1454,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     if (rc != RAFTQ_OK) return poison(n, rc, fuse ? "step_frames" : "wire_decode");
     if (fuse) {
       uint64_t n_out = 0;
-      rc = raftq_step_results(n->h, &fused_outs, &n_out);
+      rc = raftq_step_results_c(n->h, &fused_outs, &n_out);
       if (rc != RAFTQ_OK || n_out != nf || !fused_outs) return poison(n, rc != RAFTQ_OK ? rc : RAFTQ_ESTATE, "step_frames (results)");
     }
     wm = out;
@@ -1504,7 +1527,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     raftq_msg_t* staged = nullptr;
     static_assert(sizeof(raftq_msg_t) == sizeof(raftq_wire_msg_t), "the decoder's record is Step's record");
     size_t n_step = 0;
-    const raftq_step_out_t* outs = nullptr;
+    const raftq_step_out_c_t* outs = nullptr;
     const bool fused = first_round && fused_outs != nullptr;
     if (fused) {
       // round 1 has been stepped already, every frame of it, by the submission that decoded them (raftq_step_frames): what is
@@ -1555,7 +1578,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       ph.next(raftq_node::kPhStep);
       int rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
       uint64_t n_out = 0;
-      if (rc == RAFTQ_OK) rc = raftq_step_results(n->h, &outs, &n_out);
+      if (rc == RAFTQ_OK) rc = raftq_step_results_c(n->h, &outs, &n_out);
       if (rc != RAFTQ_OK) return poison(n, rc, "step_batch");
     }
     lk.lock();
@@ -1602,7 +1625,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
         n->stats.msgs_stepped--;
         ++k;
       } else {
-        apply_result(n, outs[k++], im);
+        apply_result(n, widen(outs[k++], im), im);
       }
     }
     if (deferred.size() != kept_back && kept_back != 0) std::sort(deferred.begin(), deferred.end());  // arrival order

@@ -117,9 +117,10 @@ class WireEngine(NodeEngine):
         self._chk(self._lib.raftq_step_submit_wire(self._h, _p(s), len(s), _ptr(off), len(off) - 1))
 
     def step_frames(self, stream: np.ndarray, frame_off: np.ndarray, msgs: np.ndarray, ents: np.ndarray | None = None,
-                    tail_appends: bool = True):
+                    tail_appends: bool = True, copy: bool = True):
         """raftq_step_frames: decode + a node's checks + Step over every frame, one submission and one wait.  All arrays
-        page-locked (engine.pinned_empty / pinned_copy).  -> (msgs[:n], ents[:min(n_ents, cap)], outs (a copy), counts)"""
+        page-locked (engine.pinned_empty / pinned_copy).  -> (msgs[:n], ents[:min(n_ents, cap)], outs, counts); copy=False: outs
+        is a view of the library's pinned result area, valid until the next Step call"""
         from .step import OUT_C_DT, OUT_DT
 
         n = len(frame_off) - 1
@@ -132,7 +133,9 @@ class WireEngine(NodeEngine):
         dt = OUT_C_DT if self.compact else OUT_DT
         fn = self._lib.raftq_step_results_c if self.compact else self._lib.raftq_step_results
         self._chk(fn(self._h, C.byref(p), C.byref(k)))
-        outs = np.frombuffer((C.c_char * (k.value * dt.itemsize)).from_address(p.value), dtype=dt, count=k.value).copy() if k.value else np.zeros(0, dt)
+        outs = np.frombuffer((C.c_char * (k.value * dt.itemsize)).from_address(p.value), dtype=dt, count=k.value) if k.value else np.zeros(0, dt)
+        if copy:
+            outs = outs.copy()
         got_ents = ents[: min(int(c.n_ents), len(ents))] if ents is not None else np.zeros(0, WIRE_ENT_DT)
         return msgs[:n], got_ents, outs, c
 

@@ -40,6 +40,8 @@ struct raftq {
   uint64_t seed = 0x1000, tick_no = 0;
   std::vector<raftq_msg_t> stage;
   std::vector<raftq_step_out_t> outs;
+  std::vector<raftq_step_out_c_t> outs_c;
+  bool compact = false;
   uint64_t n_out = 0;
   std::vector<raftq_advance_t> adv;  // the advance list of the last CHANGED sweep, ascending group
   bool have_adv = false;
@@ -355,6 +357,40 @@ int raftq_step_batch(raftq_t* h, const raftq_msg_t* msgs, uint64_t n, raftq_step
 int raftq_step_results(raftq_t* h, const raftq_step_out_t** out, uint64_t* n) {
   if (!h || !out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results: null argument");
   *out = h->outs.data();
+  *n = h->n_out;
+  return RAFTQ_OK;
+}
+int raftq_step_set_compact(raftq_t* h, int on) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  h->compact = on != 0;
+  return RAFTQ_OK;
+}
+// the 40-byte form of the last batch's results (include/raftq_step.h: group / addressee are the message's, log_term and
+// last_index share a slot)
+int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n) {
+  if (!h || !out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results_c: null argument");
+  try {
+    h->outs_c.resize((size_t)h->n_out);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_step_results_c: host allocation failed");
+  }
+  for (uint64_t i = 0; i < h->n_out; ++i) {
+    const raftq_step_out_t& o = h->outs[i];
+    raftq_step_out_c_t c;
+    memset(&c, 0, sizeof(c));
+    c.term = o.term;
+    c.index = o.index;
+    c.commit = o.commit;
+    c.aux = (o.type == RAFTQ_OUT_CAMPAIGN || o.type == RAFTQ_OUT_BECAME_LEADER) ? o.log_term : o.last_index;
+    c.vote = (uint8_t)o.vote;
+    c.lead = (uint8_t)o.lead;
+    c.type = o.type;
+    c.reject = o.reject;
+    c.flags = o.flags;
+    c.role = o.role;
+    h->outs_c[i] = c;
+  }
+  *out = h->outs_c.data();
   *n = h->n_out;
   return RAFTQ_OK;
 }

@@ -6,5 +6,5 @@ import bench
 
 cfg = bench.CONFIGS[3]
 t0 = time.time()
-print(bench.pipeline_measure(cfg, 0, deltas_per_cycle=int(os.environ.get("D", "65536")), cycles=100))
+print(bench.pipeline_measure(cfg, 0, deltas_per_cycle=int(os.environ.get("D", "65536")), cycles=int(os.environ.get("CYCLES", "100"))))
 print("wall", time.time() - t0)

@@ -350,6 +350,21 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
             t_packed += dt
             adv_packed += total
             assert len(adv) == total
+    # ... and with RAFTQ_CYCLE_SEGMENTED: the sweep writes the advance list itself, a segment per tile; no compaction pass
+    t_seg, adv_seg = 0.0, 0
+    for c in range(3 * cycles + 30, 4 * cycles + 40):
+        gg, pk = packs[c % 4]
+        staged16["group"], staged16["peer"] = pk["group"], pk["peer"]
+        staged16["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
+        t0 = time.perf_counter()
+        _, total, _ = e.cycle_packed(flags | _lib.CYCLE_TRUSTED | _lib.CYCLE_SEGMENTED, staged16, None, cap=n_groups, inplace=True, want_counts=False)
+        e.last_advance_segments(raw=True)
+        dt = time.perf_counter() - t0
+        if c >= 3 * cycles + 40:
+            t_seg += dt
+            adv_seg += total
+            recs, counts, stride = e.last_advance_segments()
+            assert int(counts.sum()) == total and len(counts) > 1
     e.close()
     return {
         "what": "raftq_cycle: acks in -> scatter -> full sweep of G groups -> compacted advance list out over PCIe (zero-copy "
@@ -375,6 +390,15 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
                                                     traffic=leg_traffic(["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_kernel<5, 4, true, false, false",
                                                                          "compact_changed_kernel<4, raftqk::Advance16>"]),
                                                     algorithmic=cycle_algorithmic(G, N, nd, adv_packed / cycles, 16, 16))},
+        "segmented_list": {"what": "raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED + RAFTQ_CYCLE_SEGMENTED: the sweep writes the advance list "
+                                   "itself, a segment per 1,024-group tile (raftq_last_advance_segments); two kernels and the "
+                                   "completion word per turn instead of four",
+                           "us_per_cycle": t_seg / cycles * 1e6, "deltas_per_s": nd * cycles / t_seg,
+                           "decisions_per_s": G * cycles / t_seg, "advanced_per_cycle": adv_seg / cycles,
+                           "roofline": leg_roofline("latency", "turn", cycles, t_seg, 16.0 * nd * cycles, 16.0 * adv_seg,
+                                                    "ingest, sweep + list, flag: three launches and one wait",
+                                                    traffic=leg_traffic(["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_segments_kernel<5, 4, false"]),
+                                                    algorithmic=cycle_algorithmic(G, N, nd, adv_seg / cycles, 16, 16))},
     }
 
 

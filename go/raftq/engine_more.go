@@ -220,6 +220,26 @@ func (e *Engine) LastAdvancesPacked() ([]Advance16, error) {
 	return unsafe.Slice((*Advance16)(unsafe.Pointer(p)), int(n)), nil
 }
 
+// CycleSegmented: a CyclePacked turn passed this flag (list read in place, no counts) may leave its advance list in segments --
+// the sweep writes a tile's records itself and the compaction pass does not run (raftq.h RAFTQ_CYCLE_SEGMENTED).
+const CycleSegmented = C.RAFTQ_CYCLE_SEGMENTED
+
+// LastAdvanceSegments returns the last packed turn's advance list as segments: segment s holds counts[s] records at
+// recs[s*stride:]; walked in order they are the ascending list.  A turn that produced the contiguous list is one segment.
+// Views of the library's pinned memory, valid until the next turn.
+func (e *Engine) LastAdvanceSegments() (recs []Advance16, counts []uint32, stride uint64, err error) {
+	var p *C.raftq_advance16_t
+	var pc *C.uint32_t
+	var ns C.uint32_t
+	var st C.uint64_t
+	if err = e.err(C.raftq_last_advance_segments(e.h, &p, &pc, &ns, &st)); err != nil || ns == 0 {
+		return nil, nil, 0, err
+	}
+	counts = unsafe.Slice((*uint32)(unsafe.Pointer(pc)), int(ns))
+	n := uint64(st)*uint64(ns-1) + uint64(counts[ns-1])
+	return unsafe.Slice((*Advance16)(unsafe.Pointer(p)), int(n)), counts, uint64(st), nil
+}
+
 // TimerBegin / TimerEnd bracket work on the handle's stream with HIP events (milliseconds).
 func (e *Engine) TimerBegin() error { return e.err(C.raftq_timer_begin(e.h)) }
 func (e *Engine) TimerEnd() (float32, error) {

@@ -268,6 +268,19 @@ int raftq_stage_packed(raftq_t* h, uint64_t n_deltas, uint64_t n_vote_deltas, ra
                        raftq_vote_delta_t** vote_deltas);
 int raftq_last_advances_packed(raftq_t* h, const raftq_advance16_t** list, uint64_t* n_listed);
 
+/* RAFTQ_CYCLE_SEGMENTED on raftq_cycle_packed (advances_out == NULL, counts == NULL): the advance list may be left in SEGMENTS --
+ * the turn's sweep writes the records of every tile of 1,024 groups itself, ascending, into that tile's own stretch of the
+ * pinned list, and the compaction pass (a kernel, a boundary, 13 us of a 47 us turn) does not run: two kernels and the
+ * completion word per turn instead of four.  Read them with raftq_last_advance_segments: segment s holds counts[s] records
+ * at recs + s * stride, and walking the segments in order IS the ascending list raftq_last_advances_packed would have
+ * returned (n_advanced is the same total).  A turn that cannot take that form (a vote tally or counts asked for, the list
+ * copied out, the A/B sweep) produces the contiguous list as always and raftq_last_advance_segments presents it as ONE
+ * segment: a consumer that passes the flag reads segments, whatever happened.  Valid until the next raftq_cycle* /
+ * raftq_collect_changed on the handle. */
+#define RAFTQ_CYCLE_SEGMENTED 0x200u
+int raftq_last_advance_segments(raftq_t* h, const raftq_advance16_t** recs, const uint32_t** counts, uint32_t* n_segments,
+                                uint64_t* stride);
+
 /* ---- sweep sets: many handles, one dispatch --------------------------------
  * A host that runs more groups than it wants in one handle (several tenants, several
  * shards of one keyspace, 1M-group batches of a larger population) sweeps them together:

@@ -26,6 +26,7 @@ SWEEP_CHANGED = 0x20
 SWEEP_STREAM = 0x40
 SWEEP_CACHED = 0x80
 CYCLE_TRUSTED = 0x100
+CYCLE_SEGMENTED = 0x200  # raftq_cycle_packed: the advance list may be left in segments (raftq_last_advance_segments)
 SET_GRID, SET_PERSISTENT = 0, 1
 
 MAX_PEERS = 9
@@ -95,6 +96,7 @@ _SIGS = [
                                      C.POINTER(C.c_uint64), C.POINTER(Counts)]),
     ("raftq_stage_packed", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("raftq_last_advances_packed", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_last_advance_segments", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("raftq_set_create", C.c_int, [C.POINTER(_H), C.c_uint32, C.POINTER(_H)]),
     ("raftq_set_destroy", None, [_H]),
     ("raftq_set_size", C.c_uint32, [_H]),

@@ -130,6 +130,38 @@ hipError_t launch_n(const SweepLaunch& L, unsigned flags, int nt, hipStream_t s)
   return launch_reg<N, false, false, true>(L, nt, s);
 }
 
+// the segmented turn's sweep (sweep_segments_kernel): commit-only sweeps of one handle
+template <int N>
+hipError_t launch_segments_n(const SweepArgs& a, uint32_t n_tiles, bool gated, int nt, Advance16* list, unsigned int* counts_host, unsigned int* counts_dev,
+                             hipStream_t s) {
+  const dim3 grid(n_tiles), block(kBlock);
+  if (gated) {
+    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, 0>), grid, block, 0, s, a, list, counts_host, counts_dev);
+  } else {
+    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, 0>), grid, block, 0, s, a, list, counts_host, counts_dev);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_segments(uint32_t N, const SweepArgs& a, uint32_t n_tiles, bool gated, int nt, Advance16* list, unsigned int* counts_host,
+                           unsigned int* counts_dev, hipStream_t s) {
+  switch (N) {
+    case 1: return launch_segments_n<1>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 2: return launch_segments_n<2>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 3: return launch_segments_n<3>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 4: return launch_segments_n<4>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 5: return launch_segments_n<5>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 6: return launch_segments_n<6>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 7: return launch_segments_n<7>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 8: return launch_segments_n<8>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 9: return launch_segments_n<9>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_sweep(uint32_t N, const SweepLaunch& L, unsigned flags, int nt, hipStream_t s) {
   switch (N) {
     case 1: return launch_n<1>(L, flags, nt, s);
@@ -449,6 +481,8 @@ void raftq_destroy(raftq_t* h) {
   (void)hipFree(h->outcome);
   (void)hipFree(h->changed_bits);
   (void)hipFree(h->partials);
+  (void)hipFree(h->seg_d);
+  if (h->seg_h) (void)hipHostFree(h->seg_h);
   (void)hipFree(h->offsets);
   (void)hipFree(h->compact_arrived);
   (void)hipFree(h->claim);
@@ -1167,6 +1201,46 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
   return RAFTQ_OK;
 }
 
+// RAFTQ_CYCLE_SEGMENTED: can this turn's sweep write the advance list itself (sweep_segments_kernel)?  A commit sweep (gated or
+// not) with no vote tally and no A/B variant asked for, on a stack where the completion word reaches the host.
+constexpr uint64_t kSegmentsMaxGroups = 1ull << 22;  // the pinned list has a slot per group: 16 B x 4M groups = 64 MB at most (larger handles: the contiguous list)
+static bool segments_ok(const raftq_t* h, unsigned flags) {
+  const unsigned allowed = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_CHANGED | RAFTQ_SWEEP_NO_ADOPT | RAFTQ_SWEEP_STREAM | RAFTQ_SWEEP_CACHED;
+  return (flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED)) && !(flags & ~allowed) && h->gpad <= kSegmentsMaxGroups && h->stream_write_ok;
+}
+// sweep + list + flag, two kernels; leaves the handle as sweep_on + enqueue_collect would
+static int enqueue_sweep_segments(raftq_t* h, unsigned flags) {
+  const uint32_t n_tiles = (uint32_t)(h->gpad / kTile);
+  if (int rc = ensure_adv(h, (h->gpad * sizeof(Advance16) + sizeof(Advance) - 1) / sizeof(Advance))) return rc;  // a segment per tile, a 16-byte slot per group
+  if (h->seg_cap < n_tiles) {
+    if (h->seg_h) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipHostFree(h->seg_h));
+      HIPCHK(h, hipFree(h->seg_d));
+      h->seg_h = h->seg_hd = nullptr;
+      h->seg_d = nullptr;
+      h->seg_cap = 0;
+    }
+    HIPCHK(h, hipHostMalloc((void**)&h->seg_h, (size_t)n_tiles * 4, hipHostMallocMapped | host_coherence_flag()));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->seg_hd, h->seg_h, 0));
+    HIPCHK(h, hipMalloc((void**)&h->seg_d, (size_t)n_tiles * 4));
+    h->seg_cap = n_tiles;
+  }
+  const SweepArgs a = sweep_args(h, h->cur, true);
+  HIPCHK(h, launch_segments(h->N, a, n_tiles, (flags & RAFTQ_SWEEP_GATED) != 0, sweep_policy(flags, sweep_footprint(h)), (Advance16*)h->adv_d, h->seg_hd,
+                            h->seg_d, h->stream));
+  sweep_done(h, flags, kGPL);
+  uint64_t epoch = ++h->compact_epoch;
+  if ((uint32_t)epoch == 0) epoch = ++h->compact_epoch;  // (the word's top half is never 0 for a turn in flight)
+  hipLaunchKernelGGL(raise_flag_segments_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_total + 3, (uint32_t)epoch, h->seg_d, n_tiles);
+  HIPCHK(h, hipGetLastError());
+  h->compact_epoch_armed = (uint64_t)(uint32_t)epoch << 32;
+  h->flag_mask = 0xffffffff00000000ull;
+  h->seg_tiles = n_tiles;
+  h->seg_stride = kTile;
+  return RAFTQ_OK;
+}
+
 extern "C" {
 
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
@@ -1185,6 +1259,7 @@ int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64
   const uint64_t take = std::min(total, take_cap);
   h->adv_listed = take;
   h->adv_packed = false;
+  h->adv_segmented = false;
   if (take) std::memcpy(out, h->adv_h, take * sizeof(Advance));
   return RAFTQ_OK;
 }
@@ -1236,7 +1311,7 @@ static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
     volatile uint64_t* flag = h->h_total + 3;
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0;; ++i) {
-      if (*flag == flag_epoch) {
+      if ((*flag & h->flag_mask) == flag_epoch) {
         std::atomic_thread_fence(std::memory_order_acquire);
         h->flag_misses = 0;
         return hipSuccess;
@@ -1258,6 +1333,8 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
   if (int rc = use_device_idle(h, who)) return rc;
   if ((n_deltas && !deltas) || (n_vote_deltas && !vote_deltas))
     return fail(h, RAFTQ_EINVAL, std::string(who) + ": null array with non-zero length");
+  const bool want_segments = (flags & RAFTQ_CYCLE_SEGMENTED) != 0;
+  flags &= ~RAFTQ_CYCLE_SEGMENTED;
   if (int rc = sweep_check(h, flags & ~RAFTQ_CYCLE_TRUSTED, who)) return rc;  // before anything is enqueued: a refused turn applies nothing
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   const bool want_list = commit && (advances_out || n_advanced || cap);
@@ -1286,10 +1363,19 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
     if (int rc = enqueue_ingest<Rec>(h, deltas, n_deltas, vote_deltas, n_vote_deltas, off_votes, trusted)) return rc;
   const auto t1 = clk::now();
   const int cur_before = h->cur;
-  if (int rc = raftq_step_async(h, flags)) return rc;
-  const auto t2 = clk::now();
   const bool flag_wake = want_list && !counts;  // the compaction is the last thing on the stream: it can say "done"
-  if (want_list)
+  // RAFTQ_CYCLE_SEGMENTED: the sweep writes the list itself, a segment per tile (two kernels and the flag instead of four) --
+  // whenever the turn can take that form; otherwise the contiguous list is presented as one segment
+  const bool segmented = want_segments && flag_wake && !advances_out && sizeof(Adv) == sizeof(Advance16) && segments_ok(h, flags);
+  h->flag_mask = ~0ull;
+  h->adv_segmented = false;
+  if (segmented) {
+    if (int rc = enqueue_sweep_segments(h, flags | RAFTQ_SWEEP_CHANGED)) return rc;
+  } else if (int rc = raftq_step_async(h, flags)) {
+    return rc;
+  }
+  const auto t2 = clk::now();
+  if (want_list && !segmented)
     if (int rc = enqueue_collect<Adv>(h, take_cap, flag_wake)) return rc;
   if (counts)
     HIPCHK(h, hipMemcpyAsync(h->h_partials, h->partials, h->n_partials * sizeof(uint4), hipMemcpyDeviceToHost,
@@ -1302,10 +1388,19 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
     static const bool check = [] { const char* e = std::getenv("RAFTQ_CYCLE_CHECK"); return e && e[0] == '1'; }();
     if (check) {
       auto digest = [&]() {
+        const volatile uint64_t* w = (const volatile uint64_t*)h->adv_h;
+        if (segmented) {  // every segment's count and records
+          uint64_t d = (h->h_total[3] & 0xffffffffull) * 0x9E3779B97F4A7C15ull;
+          for (uint32_t t = 0; t < h->seg_tiles; ++t) {
+            const uint32_t c = ((const volatile uint32_t*)h->seg_h)[t];
+            d = (d ^ c) * 0xBF58476D1CE4E5B9ull;
+            for (uint64_t i = 0; i < (uint64_t)c * 2; ++i) d = (d ^ w[(uint64_t)t * h->seg_stride * 2 + i]) * 0xBF58476D1CE4E5B9ull;
+          }
+          return d;
+        }
         const uint64_t total = *h->h_total;
         const uint64_t words = std::min(total, take_cap) * (sizeof(Adv) / 8);
         uint64_t d = total * 0x9E3779B97F4A7C15ull;
-        const volatile uint64_t* w = (const volatile uint64_t*)h->adv_h;
         for (uint64_t i = 0; i < words; ++i) d = (d ^ w[i]) * 0xBF58476D1CE4E5B9ull;
         return d;
       };
@@ -1343,7 +1438,13 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
     counts->n_won = (flags & RAFTQ_SWEEP_VOTES) ? w : 0;
     counts->n_lost = (flags & RAFTQ_SWEEP_VOTES) ? l : 0;
   }
-  if (want_list) {
+  if (want_list && segmented) {
+    const uint64_t total = h->h_total[3] & 0xffffffffull;  // the completion word: epoch << 32 | records in all segments
+    if (n_advanced) *n_advanced = total;
+    h->adv_listed = total;
+    h->adv_packed = true;
+    h->adv_segmented = true;
+  } else if (want_list) {
     const uint64_t total = *h->h_total;
     if (n_advanced) *n_advanced = total;
     const uint64_t take = std::min(total, take_cap);
@@ -1388,8 +1489,29 @@ int raftq_last_advances_packed(raftq_t* h, const raftq_advance16_t** list, uint6
   if (!list || !n_listed) return fail(h, RAFTQ_EINVAL, "raftq_last_advances_packed: null argument");
   if (h->adv_listed && !h->adv_packed)
     return fail(h, RAFTQ_ESTATE, "raftq_last_advances_packed: the last list was produced in the 24-byte layout");
+  if (h->adv_segmented)
+    return fail(h, RAFTQ_ESTATE, "raftq_last_advances_packed: the last list lies in segments (raftq_last_advance_segments)");
   *list = (const raftq_advance16_t*)h->adv_h;
   *n_listed = h->adv_listed;
+  return RAFTQ_OK;
+}
+
+int raftq_last_advance_segments(raftq_t* h, const raftq_advance16_t** recs, const uint32_t** counts, uint32_t* n_segments, uint64_t* stride) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!recs || !counts || !n_segments || !stride) return fail(h, RAFTQ_EINVAL, "raftq_last_advance_segments: null argument");
+  if (h->adv_listed && !h->adv_packed)
+    return fail(h, RAFTQ_ESTATE, "raftq_last_advance_segments: the last list was produced in the 24-byte layout");
+  *recs = (const raftq_advance16_t*)h->adv_h;
+  if (h->adv_segmented) {
+    *counts = h->seg_h;
+    *n_segments = h->seg_tiles;
+    *stride = h->seg_stride;
+  } else {  // a contiguous list is one segment
+    h->seg_one = (uint32_t)h->adv_listed;
+    *counts = &h->seg_one;
+    *n_segments = 1;
+    *stride = 0;
+  }
   return RAFTQ_OK;
 }
 

@@ -65,6 +65,13 @@ struct raftq {
   uint64_t adv_cap = 0;
   uint64_t adv_listed = 0;     // entries of adv_h valid after the last collect / cycle
   bool adv_packed = false;     // ... in the 16-byte layout (raftq_cycle_packed)
+  // RAFTQ_CYCLE_SEGMENTED: the last list lies in adv_h as one segment of seg_stride records per sweep tile, seg_h[t] of them valid
+  bool adv_segmented = false;
+  uint32_t* seg_h = nullptr;   // pinned [seg_cap] per-tile counts
+  uint32_t* seg_hd = nullptr;  // ... as the device addresses them
+  unsigned int* seg_d = nullptr;  // device copy (the flag kernel adds them up)
+  uint32_t seg_cap = 0, seg_tiles = 0, seg_stride = 0, seg_one = 0;  // seg_one: the count of a contiguous list presented as one segment
+  uint64_t flag_mask = ~0ull;  // which bits of the completion word are the epoch the turn's wait compares (segmented: the top half)
   unsigned int* compact_arrived = nullptr;  // (spare device word)
   uint64_t compact_epoch = 0;  // completion-flag values handed to hipStreamWriteValue64 (h_total[3])
   uint64_t compact_epoch_armed = 0;  // epoch the current turn's wait may poll for (0 = blocking wait)

@@ -917,6 +917,104 @@ static __global__ void raise_flag_kernel(uint64_t* flag, uint64_t epoch) {
 }
 
 // ---------------------------------------------------------------------------
+// The batching turn's sweep writing its own advance list, in SEGMENTS (RAFTQ_CYCLE_SEGMENTED; raft.go:227-235).
+// Round 3's turn ran the sweep (9.5 us), then -- a kernel boundary later -- the compaction above (13.2 us, of which the
+// 350 KB of records on their way out are ~7), then the flag.  A workgroup that has decided its tile holds everything a
+// record needs in registers (old and new commit index of its changed groups, the ballots); written from there the records
+// leave while the rest of the sweep is still streaming and cost the kernel nothing (15 us for sweep + list against 22.7).
+// What they cannot have for free is ONE contiguous list: a tile's position in it is the number of changed groups of every
+// tile before it, and while the sweep saturates HBM an agent-scope round trip between XCDs is 3-5 us -- learning it cost
+// 13-20 us however it was arranged (profiles/r04/sweep_emit_experiment.md).  So tile t writes its records, ascending, at
+// list[t * tile groups ...] -- a tile cannot have more changed groups than groups -- and its count at counts[t]: the list
+// is ascending when its segments are walked in order (raftq_last_advance_segments).  The changed bitmap and the per-wave
+// counts are written as by sweep_kernel: raftq_collect_changed still works afterwards.
+template <int N, int GPL, bool GATED, int POLICY>
+static __global__ __launch_bounds__(kBlock) void sweep_segments_kernel(SweepArgs a, Advance16* list, unsigned int* counts_host, unsigned int* counts_dev) {
+  constexpr bool STNT = (POLICY & kStNT) != 0;
+  constexpr int kTile = kBlock * GPL;
+  constexpr int kRounds = GPL / 2;
+  __shared__ uint32_t wave_cnt[kWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  TileRegs<N, GPL, true, GATED, false> r;
+  tile_load<N, GPL, true, GATED, false, POLICY>(r, a, tile);
+  const uint64_t tile0 = (uint64_t)tile * kTile;
+  u64x2 nw[kRounds];
+  uint64_t even[kRounds], odd[kRounds];  // wave-uniform ballots
+  uint32_t n_changed = 0;
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint64_t g = tile0 + (uint64_t)wave * (64 * GPL) + (uint64_t)j * 128 + 2 * lane;
+    uint64_t v0[N], v1[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      v0[p] = r.m[j][p].x;
+      v1[p] = r.m[j][p].y;
+    }
+    const uint64_t mci0 = N == 1 ? v0[0] : select_quorum_network<N>(v0);
+    const uint64_t mci1 = N == 1 ? v1[0] : select_quorum_network<N>(v1);
+    u64x2 o;
+    o.x = maybe_commit<GATED>(mci0, r.c[j].x, GATED ? r.f[j].x : 0);
+    o.y = maybe_commit<GATED>(mci1, r.c[j].y, GATED ? r.f[j].y : 0);
+    even[j] = __ballot(o.x != r.c[j].x);
+    odd[j] = __ballot(o.y != r.c[j].y);
+    n_changed += __popcll(even[j]) + __popcll(odd[j]);
+    nw[j] = o;
+    if (a.changed_bits != nullptr && lane == 0) {
+      u64x2 w;
+      w.x = even[j];
+      w.y = odd[j];
+      stg<false>(reinterpret_cast<u64x2*>(a.changed_bits + (g >> 6)), w);
+    }
+    stg<STNT>(reinterpret_cast<u64x2*>(a.committed_out + g), o);
+  }
+  if (lane == 0) {
+    uint4 t;
+    t.x = n_changed;
+    t.y = t.z = t.w = 0;
+    stg_u4(a.partials + ((uint64_t)tile * kWaves + wave), t);
+    wave_cnt[wave] = n_changed;
+  }
+  __syncthreads();
+  uint64_t pos = tile0;  // the tile's segment
+  for (uint32_t k = 0; k < wave; ++k) pos += wave_cnt[k];
+  if (tid == 0) {
+    uint32_t tile_cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) tile_cnt += wave_cnt[k];
+    counts_host[tile] = tile_cnt;
+    counts_dev[tile] = tile_cnt;
+  }
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {
+    const uint64_t g0 = tile0 + (uint64_t)wave * (64 * GPL) + (uint64_t)j * 128;
+    const bool e = (even[j] >> lane) & 1, o = (odd[j] >> lane) & 1;
+    const uint64_t rank = __popcll(even[j] & below) + __popcll(odd[j] & below);
+    if (e) list[pos + rank] = make_advance((Advance16*)nullptr, g0 + 2 * lane, r.c[j].x, nw[j].x);
+    if (o) list[pos + rank + (e ? 1 : 0)] = make_advance((Advance16*)nullptr, g0 + 2 * lane + 1, r.c[j].y, nw[j].y);
+    pos += __popcll(even[j]) + __popcll(odd[j]);
+  }
+}
+
+// The segmented turn's flag: one workgroup behind the sweep (the kernel boundary has made every record and count visible to
+// the host) adds up the segments' counts and stores ONE word: epoch << 32 | total.
+static __global__ __launch_bounds__(kBlock) void raise_flag_segments_kernel(uint64_t* flag, uint32_t epoch, const unsigned int* counts_dev, uint32_t n_tiles) {
+  __shared__ uint32_t red[kWaves];
+  uint32_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < n_tiles; i += kBlock) acc += counts_dev[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) total += red[k];
+    __hip_atomic_store(flag, ((uint64_t)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Batched Tick: rc.node.Tick() (raft.go:223-224) for every
 // group at once -- etcd raft.tickElection / tickHeartbeat / isElectionTimeout.
 // A lane owns 4 consecutive groups: one 16-byte load/store of `elapsed`, one

@@ -62,7 +62,6 @@ struct raftq_pipe {
   std::string errtext;
   std::mutex flush_mu;               // one batching turn at a time
   std::vector<raftq_advance_t> advbuf;
-  std::vector<raftq_advance16_t> advbuf16;
   std::vector<raftq_delta_t> turn;
   std::vector<raftq_delta16_t> turn16;
   std::thread worker;
@@ -116,19 +115,13 @@ int flush_turn(raftq_pipe_t* p, uint64_t* n_advanced) {
   uint64_t n_adv = 0;
   const unsigned flags = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_CYCLE_TRUSTED;
   int rc;
+  const raftq_advance16_t* seg_recs = nullptr;  // packed: the list is read where the turn's sweep left it, a segment per tile
+  const uint32_t* seg_counts = nullptr;
+  uint32_t n_segs = 0;
+  uint64_t seg_stride = 0;
   if (p->packed) {
-    rc = raftq_cycle_packed(p->h, p->turn16.data(), p->turn16.size(), nullptr, 0, flags, p->advbuf16.data(), p->advbuf16.size(),
-                            &n_adv, nullptr);
-    if (rc == RAFTQ_OK && n_adv > p->advbuf16.size()) {
-      // more groups advanced than the buffer holds: grow and take the same turn's list again (24-byte collect)
-      p->advbuf.resize(std::min<uint64_t>(p->G, std::max<uint64_t>(n_adv, p->advbuf16.size() * 2)));
-      p->advbuf16.resize(p->advbuf.size());
-      rc = raftq_collect_changed(p->h, p->advbuf.data(), p->advbuf.size(), &n_adv);
-      for (uint64_t i = 0; rc == RAFTQ_OK && i < n_adv; ++i) {
-        p->advbuf16[i].group = (uint32_t)p->advbuf[i].group;
-        p->advbuf16[i].new_commit = p->advbuf[i].new_commit;
-      }
-    }
+    rc = raftq_cycle_packed(p->h, p->turn16.data(), p->turn16.size(), nullptr, 0, flags | RAFTQ_CYCLE_SEGMENTED, nullptr, p->G, &n_adv, nullptr);
+    if (rc == RAFTQ_OK) rc = raftq_last_advance_segments(p->h, &seg_recs, &seg_counts, &n_segs, &seg_stride);
   } else {
     rc = raftq_cycle(p->h, p->turn.data(), p->turn.size(), nullptr, 0, flags, p->advbuf.data(), p->advbuf.size(), &n_adv,
                      nullptr);
@@ -144,12 +137,18 @@ int flush_turn(raftq_pipe_t* p, uint64_t* n_advanced) {
   }
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    for (uint64_t i = 0; i < n_adv; ++i) {
-      const uint64_t gi = p->packed ? p->advbuf16[i].group : p->advbuf[i].group;
-      const uint64_t nc = p->packed ? p->advbuf16[i].new_commit : p->advbuf[i].new_commit;
+    auto advance_to = [&](uint64_t gi, uint64_t nc) {
       Group& g = p->groups[gi];
       publish_locked(g, g.committed, nc);  // the pipe's own cursor IS the old commit index of the record
       g.committed = nc;
+    };
+    if (p->packed) {
+      for (uint32_t sgm = 0; sgm < n_segs; ++sgm) {
+        const raftq_advance16_t* r = seg_recs + (uint64_t)sgm * seg_stride;
+        for (uint32_t i = 0; i < seg_counts[sgm]; ++i) advance_to(r[i].group, r[i].new_commit);
+      }
+    } else {
+      for (uint64_t i = 0; i < n_adv; ++i) advance_to(p->advbuf[i].group, p->advbuf[i].new_commit);
     }
     p->turns++;
   }
@@ -212,7 +211,6 @@ int raftq_pipe_create(int device, uint64_t n_groups, uint32_t n_peers, raftq_pip
   try {
     p->groups.resize(n_groups);
     p->advbuf.resize(std::min<uint64_t>(n_groups, 1 << 16));
-    p->advbuf16.resize(p->advbuf.size());
     p->packed = n_groups <= (1ull << 32);
   } catch (...) {
     raftq_destroy(p->h);

@@ -209,6 +209,27 @@ class QuorumEngine:
         buf = (C.c_char * (n.value * self._ADV16_DT.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=self._ADV16_DT, count=n.value)
 
+    def last_advance_segments(self, raw: bool = False):
+        """raftq_last_advance_segments -> (recs view [n_segments * stride or count], counts uint32[n_segments], stride): segment s
+        holds counts[s] records at recs[s * stride:]; walked in order they are the ascending advance list.  raw=True: the
+        four values as the C caller gets them (addresses and integers, no arrays built)"""
+        pr, pc, ns, st = C.c_void_p(None), C.c_void_p(None), C.c_uint32(0), C.c_uint64(0)
+        self._chk(self._lib.raftq_last_advance_segments(self._h, C.byref(pr), C.byref(pc), C.byref(ns), C.byref(st)))
+        if raw:
+            return pr.value, pc.value, ns.value, st.value
+        counts = np.frombuffer((C.c_char * (ns.value * 4)).from_address(pc.value), dtype=np.uint32, count=ns.value)
+        n_recs = int(st.value) * (ns.value - 1) + int(counts[-1]) if ns.value else 0
+        if n_recs == 0:
+            return np.empty(0, dtype=self._ADV16_DT), counts, int(st.value)
+        recs = np.frombuffer((C.c_char * (n_recs * self._ADV16_DT.itemsize)).from_address(pr.value), dtype=self._ADV16_DT, count=n_recs)
+        return recs, counts, int(st.value)
+
+    def advance_list_from_segments(self) -> np.ndarray:
+        """the segments of the last turn joined into the contiguous ascending list (a copy)"""
+        recs, counts, stride = self.last_advance_segments()
+        parts = [recs[s * stride: s * stride + int(c)] for s, c in enumerate(counts) if c]
+        return np.concatenate(parts) if parts else np.empty(0, dtype=self._ADV16_DT)
+
     def cycle_packed(self, flags: int, deltas: Optional[np.ndarray] = None, vote_deltas: Optional[np.ndarray] = None,
                      cap: Optional[int] = None, inplace: bool = False, want_counts: bool = True):
         """raftq_cycle_packed.  -> (advances [raftq_advance16_t] | None when inplace, n_advanced_total, SweepCounts | None)"""

@@ -44,6 +44,8 @@ struct raftq {
   bool compact = false;
   uint64_t n_out = 0;
   std::vector<raftq_advance_t> adv;  // the advance list of the last CHANGED sweep, ascending group
+  std::vector<raftq_advance16_t> adv16;  // ... of the last packed turn, in the 16-byte layout
+  uint32_t adv16_count = 0;
   bool have_adv = false;
   std::string err;
   rq_node_state_t state() {
@@ -103,7 +105,7 @@ int cycle(raftq_t* h, const char* who, const Rec* d, uint64_t n, const raftq_vot
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
   if ((n && !d) || (nv && !vd)) return fail(h, RAFTQ_EINVAL, std::string(who) + ": null array with non-zero length");
   const bool trusted = flags & RAFTQ_CYCLE_TRUSTED;
-  flags &= ~RAFTQ_CYCLE_TRUSTED;
+  flags &= ~(RAFTQ_CYCLE_TRUSTED | RAFTQ_CYCLE_SEGMENTED);  // (segments: here the list is always one)
   const bool commit = flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED);
   if (!commit && !(flags & RAFTQ_SWEEP_VOTES)) return fail(h, RAFTQ_EINVAL, std::string(who) + ": nothing to sweep");
   if ((flags & RAFTQ_SWEEP_GATED) && !h->have_terms) return fail(h, RAFTQ_ESTATE, std::string(who) + ": gated sweep before raftq_load_terms");
@@ -131,6 +133,19 @@ int cycle(raftq_t* h, const char* who, const Rec* d, uint64_t n, const raftq_vot
   if (commit && (out || n_adv || cap)) {
     const uint64_t total = h->adv.size();
     if (n_adv) *n_adv = total;
+    if constexpr (sizeof(Adv) != sizeof(raftq_advance_t)) {  // the list left in place (raftq_last_advance_segments)
+      try {
+        h->adv16.resize((size_t)total);
+      } catch (...) {
+        return fail(h, RAFTQ_ENOMEM, std::string(who) + ": host allocation failed");
+      }
+      for (uint64_t i = 0; i < total; ++i) {
+        const raftq_advance_t& a = h->adv[i];
+        const uint64_t by = a.new_commit - a.old_commit;
+        h->adv16[i] = raftq_advance16_t{a.new_commit, (uint32_t)a.group, by > 0xfffffffeull ? 0xffffffffu : (uint32_t)by};
+      }
+      h->adv16_count = (uint32_t)total;
+    }
     if (out)
       for (uint64_t i = 0; i < std::min(total, cap); ++i) {
         const raftq_advance_t& a = h->adv[i];
@@ -272,6 +287,14 @@ int raftq_cycle_packed(raftq_t* h, const raftq_delta16_t* deltas, uint64_t n_del
                        uint64_t* n_advanced, raftq_counts_t* counts) {
   if (h && h->G > (1ull << 32)) return fail(h, RAFTQ_EINVAL, "raftq_cycle_packed: more than 2^32 groups");
   return cycle(h, "raftq_cycle_packed", deltas, n_deltas, vote_deltas, n_vote_deltas, flags, advances_out, cap, n_advanced, counts);
+}
+int raftq_last_advance_segments(raftq_t* h, const raftq_advance16_t** recs, const uint32_t** counts, uint32_t* n_segments, uint64_t* stride) {
+  if (!h || !recs || !counts || !n_segments || !stride) return fail(h, RAFTQ_EINVAL, "raftq_last_advance_segments: null argument");
+  *recs = h->adv16.data();
+  *counts = &h->adv16_count;
+  *n_segments = 1;
+  *stride = 0;
+  return RAFTQ_OK;
 }
 int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64_t* n) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");

@@ -723,3 +723,77 @@ def test_election_round_trip(gpu_engine_cls, oracle):
         oc, w, l = oracle.vote_tally(ref_votes)
         assert np.array_equal(out, oc) and (cnt.n_won, cnt.n_lost) == (w, l)
         assert w > 0 and l > 0 and (oc[cands] == 0).any()
+
+
+@pytest.mark.parametrize("n,G", [(1, 5000), (3, 70001), (5, 1 << 20), (7, 300000), (9, 4097)])
+def test_cycle_segmented_list_is_the_contiguous_list(gpu_engine_cls, oracle, n, G):
+    """RAFTQ_CYCLE_SEGMENTED: the turn's sweep writes the advance list itself, a segment per tile.  Two handles fed the same
+    traffic -- one asks for segments, one for the contiguous packed list -- agree on every record (the segments walked in
+    order ARE the list), on the total, on every word of state, turn by turn and with the oracle; gated and ungated, with
+    RAFTQ_CYCLE_TRUSTED and without, a turn in which nothing advances, a refused turn, and the turns that cannot take the
+    form (a vote tally, counts asked for) presented as one segment."""
+    from raftsql_amd._lib import CYCLE_SEGMENTED, CYCLE_TRUSTED
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(4242 + n)
+    st = _state(G, n, 6400, adversarial=False)
+    with gpu_engine_cls(G, n) as a, gpu_engine_cls(G, n) as b:
+        for e in (a, b):
+            e.load_state(st)
+        ref_match, ref_commit = st.match.copy(), st.committed.copy()
+        for turn in range(6):
+            nd = [30000, 1, 65535, 7, 20000, 50000][turn] if G > 10000 else 3000 + turn
+            dg = rng.integers(0, G, nd).astype(np.uint64)
+            dp = rng.integers(0, n, nd).astype(np.uint32)
+            dm = (ref_commit[dg.astype(np.int64)] + rng.integers(0, 3000, nd).astype(np.uint64)).astype(np.uint64)
+            if turn == 3:
+                dm[:] = 0  # acks below everything: nothing advances
+            gated = turn in (1, 4)
+            flags = SWEEP_COMMIT | (SWEEP_GATED if gated else 0) | (CYCLE_TRUSTED if turn % 2 else 0)
+            d, _ = a.stage_packed(nd, 0)
+            d[:] = a.pack_deltas16(dg, dp, dm)
+            _, tot_s, _ = a.cycle_packed(flags | CYCLE_SEGMENTED, d, None, cap=G, inplace=True, want_counts=False)
+            recs, counts, stride = a.last_advance_segments()
+            got = a.advance_list_from_segments()
+            want, tot_c, _ = b.cycle_packed(flags, b.pack_deltas16(dg, dp, dm), None, want_counts=False)
+            ref_match = oracle.apply_deltas(ref_match, dg, dp, dm)
+            new_commit, n_ch = oracle.commit_advance(ref_match, ref_commit, gated, st.first_idx_cur_term)
+            assert tot_s == tot_c == n_ch == len(got) == int(counts.sum()), turn
+            assert len(counts) > 1 or G <= 1024, "the turn did not take the segmented form"
+            assert stride == 1024 or len(counts) == 1
+            assert got.tobytes() == want.tobytes(), turn
+            with pytest.raises(RaftqError):
+                a.last_advances_packed()  # the list lies in segments: the contiguous accessor refuses it
+            assert np.array_equal(a.read_committed(), new_commit) and np.array_equal(b.read_committed(), new_commit)
+            assert np.array_equal(a.read_match(), b.read_match())
+            ref_commit = new_commit
+        # raftq_collect_changed after a segmented turn: the bitmap and the per-wave counts were written as by the plain sweep
+        dg = rng.integers(0, G, 2000).astype(np.uint64)
+        dp = rng.integers(0, n, 2000).astype(np.uint32)
+        dm = (ref_commit[dg.astype(np.int64)] + np.uint64(50)).astype(np.uint64)
+        for e in (a, b):
+            dd, _ = e.stage_packed(2000, 0)
+            dd[:] = e.pack_deltas16(dg, dp, dm)
+            e.cycle_packed(SWEEP_COMMIT | (CYCLE_SEGMENTED if e is a else 0), dd, None, cap=G, inplace=True, want_counts=False)
+        n_seg = len(a.advance_list_from_segments())  # (before raftq_collect_changed rewrites the pinned list in its own layout)
+        (la, na), (lb, nb) = a.collect_changed(), b.collect_changed()
+        assert na == nb == n_seg and np.array_equal(la, lb)
+        ref_match = oracle.apply_deltas(ref_match, dg, dp, dm)
+        ref_commit, _ = oracle.commit_advance(ref_match, ref_commit, False, st.first_idx_cur_term)
+        # a refused turn (a record out of range, no TRUSTED) applies nothing and lists nothing
+        bad = a.pack_deltas16(np.array([G], np.uint64), np.array([0], np.uint32), np.array([5], np.uint64))
+        with pytest.raises(RaftqError):
+            a.cycle_packed(SWEEP_COMMIT | CYCLE_SEGMENTED, bad, None, cap=G, inplace=True, want_counts=False)
+        assert np.array_equal(a.read_committed(), ref_commit)
+        # turns that cannot take the form are presented as ONE segment: a vote tally, counts asked for
+        vd = a.pack_vote_deltas(rng.integers(0, G, 100).astype(np.uint64), rng.integers(0, n, 100).astype(np.uint32),
+                                rng.integers(1, 3, 100).astype(np.uint8))
+        dm2 = (ref_commit[dg.astype(np.int64)] + np.uint64(99)).astype(np.uint64)
+        for k, (fl, kw) in enumerate([(SWEEP_COMMIT | SWEEP_VOTES, dict(want_counts=False)), (SWEEP_COMMIT, dict(want_counts=True))]):
+            dmk = dm2 + np.uint64(k * 100)
+            _, tot, _ = a.cycle_packed(fl | CYCLE_SEGMENTED, a.pack_deltas16(dg, dp, dmk), vd if fl & SWEEP_VOTES else None, cap=G, inplace=True, **kw)
+            want, tot_c, _ = b.cycle_packed(fl, b.pack_deltas16(dg, dp, dmk), vd if fl & SWEEP_VOTES else None, **kw)
+            recs, counts, stride = a.last_advance_segments()
+            assert len(counts) == 1 and int(counts[0]) == tot == tot_c
+            assert a.advance_list_from_segments().tobytes() == want.tobytes()
+            assert a.last_advances_packed().tobytes() == want.tobytes()  # (a contiguous list: both accessors serve it)

@@ -40,7 +40,7 @@ LEG_KERNELS = {
     "step_lists_kernel": ("step", "line"), "step_link_kernel": ("step", "line"), "step_d2h_kernel": ("step", "stream"),
     "step_walk_kernel": ("step", "line"),
     "deltas_in_apply_kernel": ("cycle", "line"), "deltas_in_kernel": ("cycle", "stream"), "apply_deltas_kernel": ("cycle", "line"),
-    "compact_changed_kernel": ("cycle", "line"), "sweep_kernel": ("cycle", "stream"), "compact_list_kernel": ("cycle", "line"),
+    "compact_changed_kernel": ("cycle", "line"), "sweep_kernel": ("cycle", "stream"), "sweep_segments_kernel": ("cycle", "stream"), "compact_list_kernel": ("cycle", "line"),
     "tick_kernel": ("tick", "stream"), "tick_set_kernel": ("tick", "stream"), "tick_lists_kernel": ("tick", "stream"),
     "scan_partials_kernel": ("tick", "stream"), "compact_hups_kernel": ("tick", "stream"),
     "wire_dec_kernel": ("wire", "stream"), "wire_dec_ents_kernel": ("wire", "stream"), "wire_dec_fused_kernel": ("wire", "stream"),

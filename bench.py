@@ -312,20 +312,32 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
     flags = _lib.SWEEP_COMMIT
     nd = n_groups * q
     staged, _ = e.stage(nd, 0)  # pinned, device-visible: the message handlers' batch buffer
+    # The clock is around the library's calls with their arguments built beforehand (the Python mirror's own per-call work --
+    # numpy -> ctypes conversions, a ctypes array type per list length: ~12 us of a 47 us turn -- is not the library's; a C
+    # caller pays none of it: c_caller below).  What the calls returned is checked outside the clock.
+    import ctypes as C
+
+    lib, hnd = e._lib, e._h
+    n_out, list_p, list_n = C.c_uint64(0), C.c_void_p(None), C.c_uint64(0)
+    r_n_out, r_list_p, r_list_n = C.byref(n_out), C.byref(list_p), C.byref(list_n)
+    seg_p, seg_c, seg_n, seg_s = C.c_void_p(None), C.c_void_p(None), C.c_uint32(0), C.c_uint64(0)
+    r_seg = (C.byref(seg_p), C.byref(seg_c), C.byref(seg_n), C.byref(seg_s))
     t_total, adv_total, t_copy = 0.0, 0, 0.0
+    staged_ptr = staged.ctypes.data
     for c in range(cycles + 10):
         gg, pk = packs[c % 4]
         # producer side (not timed): the rafthttp handlers writing this turn's acks into the batch
         staged[:] = pk
         staged["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
         t0 = time.perf_counter()
-        total = e.cycle_inplace(flags, staged, None, cap=n_groups)
-        adv = e.last_advances()
+        rc = lib.raftq_cycle(hnd, staged_ptr, nd, None, 0, flags, None, n_groups, r_n_out, None)
+        rc2 = lib.raftq_last_advances(hnd, r_list_p, r_list_n)
         dt = time.perf_counter() - t0
+        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
         if c >= 10:
             t_total += dt
-            adv_total += total
-            assert len(adv) == total
+            adv_total += n_out.value
+            assert list_n.value == n_out.value == n_groups
     # the copying form of the same call (caller-owned pageable buffers in and out), for comparison
     out = np.empty(n_groups, dtype=e._ADV_DT)
     for c in range(cycles + 10, 2 * cycles + 20):
@@ -337,19 +349,24 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
             t_copy += time.perf_counter() - t0
     # the same turn with the 16-byte records (raftq_cycle_packed): a third fewer bytes each way over PCIe
     staged16, _ = e.stage_packed(nd, 0)
+    staged16_ptr = staged16.ctypes.data
     t_packed, adv_packed = 0.0, 0
     for c in range(2 * cycles + 20, 3 * cycles + 30):
         gg, pk = packs[c % 4]
         staged16["group"], staged16["peer"] = pk["group"], pk["peer"]
         staged16["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
         t0 = time.perf_counter()
-        _, total, _ = e.cycle_packed(flags | _lib.CYCLE_TRUSTED, staged16, None, cap=n_groups, inplace=True, want_counts=False)
-        adv = e.last_advances_packed()
+        rc = lib.raftq_cycle_packed(hnd, staged16_ptr, nd, None, 0, flags | _lib.CYCLE_TRUSTED, None, n_groups, r_n_out, None)
+        rc2 = lib.raftq_last_advances_packed(hnd, r_list_p, r_list_n)
         dt = time.perf_counter() - t0
+        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
         if c >= 2 * cycles + 30:
             t_packed += dt
-            adv_packed += total
-            assert len(adv) == total
+            adv_packed += n_out.value
+            assert list_n.value == n_out.value == n_groups
+            if c == 3 * cycles + 29:  # the list itself, once: ascending, the groups acked, the values acked
+                adv = e.last_advances_packed()
+                assert np.array_equal(np.sort(gg[::q]).astype(np.uint32), adv["group"]) and np.array_equal(adv["new_commit"], base[adv["group"].astype(np.int64)] + np.uint64(16 * (c + 1)))
     # ... and with RAFTQ_CYCLE_SEGMENTED: the sweep writes the advance list itself, a segment per tile; no compaction pass
     t_seg, adv_seg = 0.0, 0
     for c in range(3 * cycles + 30, 4 * cycles + 40):
@@ -357,23 +374,41 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
         staged16["group"], staged16["peer"] = pk["group"], pk["peer"]
         staged16["match"] = base[gg.astype(np.int64)] + np.uint64(16 * (c + 1))
         t0 = time.perf_counter()
-        _, total, _ = e.cycle_packed(flags | _lib.CYCLE_TRUSTED | _lib.CYCLE_SEGMENTED, staged16, None, cap=n_groups, inplace=True, want_counts=False)
-        e.last_advance_segments(raw=True)
+        rc = lib.raftq_cycle_packed(hnd, staged16_ptr, nd, None, 0, flags | _lib.CYCLE_TRUSTED | _lib.CYCLE_SEGMENTED, None, n_groups, r_n_out, None)
+        rc2 = lib.raftq_last_advance_segments(hnd, *r_seg)
         dt = time.perf_counter() - t0
+        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
         if c >= 3 * cycles + 40:
             t_seg += dt
-            adv_seg += total
-            recs, counts, stride = e.last_advance_segments()
-            assert int(counts.sum()) == total and len(counts) > 1
+            adv_seg += n_out.value
+            assert n_out.value == n_groups and seg_n.value > 1
+            if c == 4 * cycles + 39:  # the segments walked in order, once: the same ascending list
+                adv = e.advance_list_from_segments()
+                assert np.array_equal(np.sort(gg[::q]).astype(np.uint32), adv["group"]) and np.array_equal(adv["new_commit"], base[adv["group"].astype(np.int64)] + np.uint64(16 * (c + 1)))
     e.close()
+    # the same turn timed in a C caller (tools/tune/turn_latency.c, what cgo sees): the figures above include the Python mirror's
+    # own work per call (building ctypes arguments: ~6 us of a 40 us turn), which is not the library's
+    c_caller = None
+    tool = os.path.join(ROOT, "tools", "tune", "turn_latency")
+    if os.path.exists(tool):
+        try:
+            import subprocess
+
+            r = subprocess.run([tool, "300"], capture_output=True, text=True, timeout=120)
+            c_caller = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as ex:  # noqa: BLE001
+            c_caller = {"error": repr(ex)[:300]}
     return {
         "what": "raftq_cycle: acks in -> scatter -> full sweep of G groups -> compacted advance list out over PCIe (zero-copy "
                 "staging: the producer writes the records into the handle's ack buffer -- device memory behind a large BAR, "
-                "pinned host memory otherwise -- before the call; wall time of the call incl. its one wait)",
+                "pinned host memory otherwise -- before the call; wall time of the library's calls incl. their one wait, "
+                "arguments built beforehand: the Python mirror's own per-call work, ~12 us, is outside the clock from round 4 on -- "
+                "c_caller is the same turn from plain C)",
         "groups": G, "peers": N, "deltas_per_cycle": nd, "advanced_per_cycle": adv_total / cycles,
         "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
         "decisions_per_s": G * cycles / t_total,
         "us_per_cycle_copying_form": t_copy / cycles * 1e6,
+        "c_caller": c_caller,
         "roofline": leg_roofline("latency", "turn", cycles, t_total, 24.0 * nd * cycles, 24.0 * adv_total,
                                  "acks in (the producer's stores, before the call) and advances out cross the link once each; "
                                  "a turn is four dependent launches and one wait -- latency, not a link and not HBM, is what it is "

@@ -150,6 +150,19 @@ def build_tool(src: str, out: str | None = None, force: bool = False, deps: list
     return out
 
 
+def build_c_tool(src: str, force: bool = False) -> str | None:
+    """A plain-C99 caller of the C-ABI (tools/tune/turn_latency.c: the batching turn as cgo would make it), gcc, linked against
+    the in-tree libraftq.so through an $ORIGIN-relative rpath so that it runs wherever the tree is copied."""
+    if not os.path.exists(src):
+        return None
+    out = os.path.splitext(src)[0]
+    if not force and not _stale(out, [src, os.path.join(ROOT, "include", "raftq.h")]):
+        return out
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), src, "-L" + PKG, "-lraftq",
+                           "-Wl,-rpath,$ORIGIN/../../raftsql_amd", "-o", out])
+    return out
+
+
 def tool_sources() -> list[str]:
     """Every standalone HIP tool of the tree: the sweep tuners (tools/tune/: raftq_tune = round 1's policy / tile A/B,
     raftq_tune2 = layout / instruction count, raftq_tune3 = launch shapes + the PMC calibration copy, single_launch_ab =
@@ -185,6 +198,7 @@ def build_all(force: bool = False, log: list | None = None) -> None:
         futs += [ex.submit(build_tool, src, None, force) for src in tool_sources()]
         for f in futs:
             f.result()
+    build_c_tool(os.path.join(TUNE_DIR, "turn_latency.c"), force)  # (links against the library built above)
 
 
 def toolchain() -> dict:

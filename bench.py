@@ -748,8 +748,27 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     pstream, pmsgs, pents = pinned_copy(stream), pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(ents) + 1, W.WIRE_ENT_DT)
     got, goff = e.wire_encode(pm, pe, pp, out=pout, off=poff)
     assert got.tobytes() == stream.tobytes()
-    t_enc_p = timeit(lambda: e.wire_encode(pm, pe, pp, out=pout, off=poff))
-    t_dec_p = timeit(lambda: e.wire_decode(pstream, poff, msgs=pmsgs, ents=pents))
+    # (the page-locked forms are timed around the library's calls with their arguments built beforehand: the Python mirror's
+    # own per-call work -- numpy -> ctypes conversions, slicing the results: 5-10 us a call -- is not the library's)
+    import ctypes as C
+    from raftsql_amd import _lib
+
+    lib, hnd = e._lib, e._h
+    wcnt, r_wcnt = _lib.WireCounts(), None
+    r_wcnt = C.byref(wcnt)
+    a_enc = (hnd, pm.ctypes.data, n, pe.ctypes.data, len(pe), pp.ctypes.data, len(pp), pout.ctypes.data, len(pout), poff.ctypes.data, r_wcnt)
+    a_dec = (hnd, pstream.ctypes.data, len(pstream), poff.ctypes.data, n, pmsgs.ctypes.data, pents.ctypes.data, len(pents), r_wcnt)
+
+    def lean(fn, args):
+        def call():
+            rc = fn(*args)
+            assert rc == 0, e._chk(rc)
+        return call
+
+    t_enc_p = timeit(lean(lib.raftq_wire_encode, a_enc))
+    assert pout[: len(stream)].tobytes() == stream.tobytes() and wcnt.bytes == len(stream)
+    t_dec_p = timeit(lean(lib.raftq_wire_decode, a_dec))
+    assert wcnt.n_ents == len(ents) and pmsgs.tobytes() == e.wire_decode(stream, off)[0].tobytes()
     out["message_frames"] = {"entries": len(ents), "stream_bytes": int(len(stream)),
                              "encode_us": t_enc * 1e6, "encode_msgs_per_s": n / t_enc,
                              "decode_us": t_dec * 1e6, "decode_msgs_per_s": n / t_dec,
@@ -775,18 +794,33 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     # raftq_step_batch, wait)
     from raftsql_amd import step as S_
 
+    a_stepb = (hnd, pmsgs.ctypes.data, n, None, None)
+
     def two_calls():
-        e.wire_decode(pstream, poff, msgs=pmsgs, ents=pents)
-        e.step_batch(pmsgs.view(S_.MSG_DT), want_out=False)
+        rc = lib.raftq_wire_decode(*a_dec)
+        rc2 = lib.raftq_step_batch(*a_stepb)
+        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
 
     pmsgs2 = pinned_empty(n, W.WIRE_MSG_DT)
     for _ in range(3):  # every Step slot's buffers exist before the clock starts
         two_calls()
         e.step_frames(pstream, poff, pmsgs2, pents, copy=False)
     t_two = timeit(two_calls)
-    t_one = timeit(lambda: e.step_frames(pstream, poff, pmsgs2, pents, copy=False))
+    res_p, res_n = C.c_void_p(None), C.c_uint64(0)
+    a_half = (hnd, pstream.ctypes.data, len(pstream), poff.ctypes.data, n, 1, pmsgs2.ctypes.data, pents.ctypes.data, len(pents), r_wcnt)
+    a_res = (hnd, C.byref(res_p), C.byref(res_n))
+
+    def half_turn(results):
+        def call():
+            rc = lib.raftq_step_frames(*a_half)
+            rc2 = results(*a_res)
+            assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
+        return call
+
+    t_one = timeit(half_turn(lib.raftq_step_results))
+    assert res_n.value == n
     e.set_compact(True)  # 40-byte results: what raftq_node reads
-    t_one_c = timeit(lambda: e.step_frames(pstream, poff, pmsgs2, pents, copy=False))
+    t_one_c = timeit(half_turn(lib.raftq_step_results_c))
     e.set_compact(False)
     half_in, half_out = float(len(stream) + poff.nbytes), float(pmsgs.nbytes + len(ents) * 32 + 64 * n)
     out["inbound_half_turn"] = {
@@ -875,8 +909,13 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     assert nv == n and lc == wlast
     pr, pwp, pwal, precs = pinned_copy(r), pinned_copy(wpool), pinned_copy(wal), pinned_empty(n, W.WAL_REC_DT)
     pwout = pinned_empty(len(wal) + 64, np.uint8)
-    t_wenc_p = timeit(lambda: e.wal_encode(pr, pwp, 0, out=pwout, off=poff))
-    t_wdec_p = timeit(lambda: e.wal_decode(pwal, poff, 0, recs=precs))
+    walc = _lib.WalCounts()
+    a_wenc = (hnd, pr.ctypes.data, n, pwp.ctypes.data, len(pwp), 0, pwout.ctypes.data, len(pwout), poff.ctypes.data, C.byref(walc))
+    a_wdec = (hnd, pwal.ctypes.data, len(pwal), poff.ctypes.data, n, 0, precs.ctypes.data, C.byref(walc))
+    t_wenc_p = timeit(lean(lib.raftq_wal_encode, a_wenc))
+    assert walc.bytes == len(wal) and walc.last_crc == wlast
+    t_wdec_p = timeit(lean(lib.raftq_wal_decode, a_wdec))
+    assert walc.n_valid == n and walc.last_crc == wlast
     assert pwout[: len(wal)].tobytes() == wal.tobytes()
     out["wal_frames"] = {"records": n, "wal_bytes": int(len(wal)), "encode_us": t_wenc * 1e6,
                          "encode_recs_per_s": n / t_wenc, "decode_us": t_wdec * 1e6, "decode_recs_per_s": n / t_wdec,

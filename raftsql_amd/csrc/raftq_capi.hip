@@ -1205,6 +1205,8 @@ static int enqueue_collect(raftq_t* h, uint64_t take_cap, bool want_flag) {
 // not) with no vote tally and no A/B variant asked for, on a stack where the completion word reaches the host.
 constexpr uint64_t kSegmentsMaxGroups = 1ull << 22;  // the pinned list has a slot per group: 16 B x 4M groups = 64 MB at most (larger handles: the contiguous list)
 static bool segments_ok(const raftq_t* h, unsigned flags) {
+  if (const char* e = std::getenv("RAFTQ_CYCLE_SEGMENTS"))  // =0: every turn produces the contiguous list (A/B; the tests' way to a consumer's fallback)
+    if (e[0] == '0') return false;
   const unsigned allowed = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_SWEEP_CHANGED | RAFTQ_SWEEP_NO_ADOPT | RAFTQ_SWEEP_STREAM | RAFTQ_SWEEP_CACHED;
   return (flags & (RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED)) && !(flags & ~allowed) && h->gpad <= kSegmentsMaxGroups && h->stream_write_ok;
 }

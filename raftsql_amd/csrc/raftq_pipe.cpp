@@ -115,13 +115,22 @@ int flush_turn(raftq_pipe_t* p, uint64_t* n_advanced) {
   uint64_t n_adv = 0;
   const unsigned flags = RAFTQ_SWEEP_COMMIT | RAFTQ_SWEEP_GATED | RAFTQ_CYCLE_TRUSTED;
   int rc;
+  bool overflowed = false;                      // packed, contiguous and longer than the buffer: the 24-byte list instead
   const raftq_advance16_t* seg_recs = nullptr;  // packed: the list is read where the turn's sweep left it, a segment per tile
   const uint32_t* seg_counts = nullptr;
   uint32_t n_segs = 0;
   uint64_t seg_stride = 0;
   if (p->packed) {
-    rc = raftq_cycle_packed(p->h, p->turn16.data(), p->turn16.size(), nullptr, 0, flags | RAFTQ_CYCLE_SEGMENTED, nullptr, p->G, &n_adv, nullptr);
+    // (cap only matters to a turn that cannot leave segments -- a handle of more than 4M groups -- and produces the contiguous
+    // list: that one is bounded by the pipe's buffer as before, and taken again through raftq_collect_changed when it overflows)
+    rc = raftq_cycle_packed(p->h, p->turn16.data(), p->turn16.size(), nullptr, 0, flags | RAFTQ_CYCLE_SEGMENTED, nullptr, p->advbuf.size(), &n_adv,
+                            nullptr);
     if (rc == RAFTQ_OK) rc = raftq_last_advance_segments(p->h, &seg_recs, &seg_counts, &n_segs, &seg_stride);
+    if (rc == RAFTQ_OK && n_segs == 1 && seg_counts[0] < n_adv) {
+      p->advbuf.resize(std::min<uint64_t>(p->G, std::max<uint64_t>(n_adv, p->advbuf.size() * 2)));
+      rc = raftq_collect_changed(p->h, p->advbuf.data(), p->advbuf.size(), &n_adv);
+      overflowed = true;
+    }
   } else {
     rc = raftq_cycle(p->h, p->turn.data(), p->turn.size(), nullptr, 0, flags, p->advbuf.data(), p->advbuf.size(), &n_adv,
                      nullptr);
@@ -142,7 +151,7 @@ int flush_turn(raftq_pipe_t* p, uint64_t* n_advanced) {
       publish_locked(g, g.committed, nc);  // the pipe's own cursor IS the old commit index of the record
       g.committed = nc;
     };
-    if (p->packed) {
+    if (p->packed && !overflowed) {
       for (uint32_t sgm = 0; sgm < n_segs; ++sgm) {
         const raftq_advance16_t* r = seg_recs + (uint64_t)sgm * seg_stride;
         for (uint32_t i = 0; i < seg_counts[sgm]; ++i) advance_to(r[i].group, r[i].new_commit);

@@ -160,9 +160,14 @@ def test_background_batching_thread(pipe_cls):
         assert rp.close() == 0
 
 
-def test_many_groups_random_ack_order(pipe_cls):
+@pytest.mark.parametrize("segments", [True, False])
+def test_many_groups_random_ack_order(pipe_cls, segments, monkeypatch):
     """100k groups: every statement is delivered exactly once, in log order, and only after a
-    quorum -- with acks arriving in random order across several batching turns."""
+    quorum -- with acks arriving in random order across several batching turns.  The pipe reads its turns' advance lists in
+    segments (RAFTQ_CYCLE_SEGMENTED); with RAFTQ_CYCLE_SEGMENTS=0 the library produces the contiguous list instead, longer
+    than the pipe's buffer here (all 100,000 groups advance in one turn): the pipe's way out through raftq_collect_changed."""
+    if not segments:
+        monkeypatch.setenv("RAFTQ_CYCLE_SEGMENTS", "0")
     rng = np.random.default_rng(3)
     G, N = 100_000, 5
     with pipe_cls(G, N) as rp:
@@ -173,7 +178,7 @@ def test_many_groups_random_ack_order(pipe_cls):
         acks = [(g, p) for g in range(0, G, 1) for p in (1, 2, 3)]
         order = rng.permutation(len(acks))
         delivered = 0
-        for chunk in np.array_split(order, 5):
+        for chunk in np.array_split(order, 5 if segments else 1):  # (one turn: all 100,000 groups advance, the buffer holds 65,536)
             for k in chunk:
                 g, p = acks[k]
                 rp.process_app_resp(g, p, 2)

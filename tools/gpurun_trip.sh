@@ -81,7 +81,7 @@ PY
       timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o cyc -- python tools/profile_cycle.py > /dev/null 2>&1
       python tools/probe/timeline.py /tmp/tl -12 12 > $P/cycle_timeline.txt; python tools/probe/timeline.py /tmp/tl -340 12 >> $P/cycle_timeline.txt; cat $P/cycle_timeline.txt ;;
     turnsoak)  # >= 10^4 batching turns with the completion flag checked against a full synchronisation every turn (RAFTQ_CYCLE_CHECK)
-      RAFTQ_CYCLE_CHECK=1 CYCLES=4000 timeout 600 python tools/profile_cycle.py > $P/turn_soak.txt 2>&1; echo "rc=$? (3 x 4000 turns)"; tail -c 300 $P/turn_soak.txt ;;
+      RAFTQ_CYCLE_CHECK=1 CYCLES=4000 timeout 600 python tools/profile_cycle.py > $P/turn_soak.txt 2>&1; echo "rc=$? (4 x 4000 turns: 24-byte, copying, packed, segmented)"; tail -c 300 $P/turn_soak.txt ;;
     soak)      RAFTQ_CYCLE_CHECK=1 timeout 900 python tests/soak/soak.py > $P/soak.txt 2>&1; echo "rc=$?"; tail -5 $P/soak.txt ;;
     *)         if [ -f "$step" ]; then bash "$step"; else echo "unknown step $step"; fi ;;
   esac

@@ -32,6 +32,7 @@ while time.time() < t_end:
                 k = min(n, int(rng.integers(28, 40)))
                 m["group"][rng.choice(n, k, replace=False)] = int(rng.integers(0, G))
             n_long += int(np.bincount(m["group"].astype(np.int64)).max() > 32)
+            flagged = rng.random() < 0.35  # RAFTQ_MSGF_HOLD / RAFTQ_MSGF_SKIP among it, where the records travel whole
             mode = rng.random()
             if mode < 0.5:  # staged in place / packed: the device-memory paths of round 2
                 packed = rng.random() < 0.5
@@ -49,6 +50,8 @@ while time.time() < t_end:
                     else:
                         e.step_submit_packed(S.pack_msgs40(m))
                 else:
+                    if flagged:
+                        m = _stepgen.with_hold_skip(rng, m)
                     want = s.step_batch(m)
                     st = e.step_stage(n)
                     st[:] = m
@@ -63,6 +66,8 @@ while time.time() < t_end:
             through_wire = rng.random() < 0.3 and N > 1
             if through_wire:
                 m["_pad"], m["_resv"] = 0, 0  # nor does a frame say it: Step-from-frames reads headers only
+            elif flagged:
+                m = _stepgen.with_hold_skip(rng, m)
             want = s.step_batch(m)
             if through_wire:  # through the wire
                 wm = np.zeros(n, W.WIRE_MSG_DT)

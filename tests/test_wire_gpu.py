@@ -1037,6 +1037,32 @@ def test_step_frames_equals_decode_filter_step(oracle, walk, tail_appends, monke
         _stepgen.assert_same_state(e, st)
 
 
+def test_step_frames_with_long_runs_goes_through_the_sorted_walk(oracle):
+    """Hundreds of frames per group in one call: the list walk gives the batch up (a run longer than it takes) and the call
+    replays it through the sorted walk -- the records the decoder left in HBM are read a second time, skipped and held frames
+    included.  Same answers, same state; and the calls after it are back on the list walk."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+    from tests import _stepgen
+
+    G, N, me = 40, 3, 1
+    rng = np.random.default_rng(99)
+    st = _stepgen.random_state(rng, G, N, self_peer=me)
+    with WireEngine(G, N, me) as e:
+        _stepgen.load_engine(e, st)
+        for it, n in enumerate([6000, 300, 20000, 50]):
+            s, off = _node_frames(rng, n, st, me)
+            wm, we, _ = W.wire_decode(s, off)
+            want_m, rec = _node_filter(wm, we, G, N, me, True)
+            want_o = st.step_batch(rec)
+            msgs, ents = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+            gm, ge, go, c = e.step_frames(pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64)), msgs, ents)
+            _same(gm, want_m, f"records, call {it}")
+            _same(ge, we, f"entry headers, call {it}")
+            _same(go, want_o, f"results, call {it}")
+        _stepgen.assert_same_state(e, st)
+
+
 def test_step_frames_refuses_what_it_cannot_stream(oracle):
     from raftsql_amd import _lib
     from raftsql_amd.engine import RaftqError, pinned_copy, pinned_empty

@@ -82,6 +82,7 @@ PY
       python tools/probe/timeline.py /tmp/tl -12 12 > $P/cycle_timeline.txt; python tools/probe/timeline.py /tmp/tl -340 12 >> $P/cycle_timeline.txt; cat $P/cycle_timeline.txt ;;
     turnsoak)  # >= 10^4 batching turns with the completion flag checked against a full synchronisation every turn (RAFTQ_CYCLE_CHECK)
       RAFTQ_CYCLE_CHECK=1 CYCLES=4000 timeout 600 python tools/profile_cycle.py > $P/turn_soak.txt 2>&1; echo "rc=$? (4 x 4000 turns: 24-byte, copying, packed, segmented)"; tail -c 300 $P/turn_soak.txt ;;
+    stepsoak)  SECONDS_BUDGET=${SECONDS_BUDGET:-90} timeout 600 python tests/soak/step_stress.py > $P/soak_step.txt 2>&1; echo "rc=$?"; tail -3 $P/soak_step.txt ;;
     soak)      RAFTQ_CYCLE_CHECK=1 timeout 900 python tests/soak/soak.py > $P/soak.txt 2>&1; echo "rc=$?"; tail -5 $P/soak.txt ;;
     *)         if [ -f "$step" ]; then bash "$step"; else echo "unknown step $step"; fi ;;
   esac

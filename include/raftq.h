@@ -274,8 +274,9 @@ int raftq_last_advances_packed(raftq_t* h, const raftq_advance16_t** list, uint6
  * completion word per turn instead of four.  Read them with raftq_last_advance_segments: segment s holds counts[s] records
  * at recs + s * stride, and walking the segments in order IS the ascending list raftq_last_advances_packed would have
  * returned (n_advanced is the same total).  A turn that cannot take that form (a vote tally or counts asked for, the list
- * copied out, the A/B sweep) produces the contiguous list as always and raftq_last_advance_segments presents it as ONE
- * segment: a consumer that passes the flag reads segments, whatever happened.  Valid until the next raftq_cycle* /
+ * copied out, the A/B sweep, a handle of more than 4M groups -- the pinned list has a slot per group) produces the contiguous
+ * list as always, `cap` records of it at most, and raftq_last_advance_segments presents it as ONE segment: a consumer that
+ * passes the flag reads segments, whatever happened (and compares counts[0] with n_advanced when there is one).  Valid until the next raftq_cycle* /
  * raftq_collect_changed on the handle. */
 #define RAFTQ_CYCLE_SEGMENTED 0x200u
 int raftq_last_advance_segments(raftq_t* h, const raftq_advance16_t** recs, const uint32_t** counts, uint32_t* n_segments,

@@ -407,3 +407,28 @@ def test_hold_and_skip_equal_removing_the_records():
             assert np.array_equal(getattr(s, k), getattr(s2, k)), k
         rest = out[~keep]
         assert set(int(t) for t in rest["type"]) <= {9, 10, 11}
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 7, 9])
+def test_a_leaders_append_report_cannot_move_commit_with_more_than_one_peer(N):
+    """What raftq_apply_log_deltas_nowait rests on (include/raftq_step.h): once a leader's commit index is what its peers'
+    Match values give (every ack runs maybeCommit), reporting that the leader appended -- its own Match and lastIndex move up --
+    advances nothing: the leader's Match is the largest already, the quorum-th largest is somebody else's.  (N = 1: it does,
+    and raftq_node waits for those reports.)"""
+    rng = np.random.default_rng(1000 + N)
+    G = 4000
+    s = _stepgen.random_state(rng, G, N, self_peer=int(rng.integers(0, N)))
+    lead = np.nonzero(s.role == 2)[0]
+    assert len(lead) > 500
+    s.apply_log_deltas(lead, s.last_index[lead], s.last_term[lead], 0)  # the fixpoint every ack leaves behind
+    before = s.committed.copy()
+    for _ in range(3):
+        grow = rng.integers(1, 5, len(lead)).astype(np.uint64)
+        out = s.apply_log_deltas(lead, s.last_index[lead] + grow, s.term[lead], 0)
+        assert np.array_equal(out, before[lead]) and np.array_equal(s.committed, before)
+    one = _stepgen.random_state(rng, 100, 1, 0)
+    l1 = np.nonzero(one.role == 2)[0]
+    one.apply_log_deltas(l1, one.last_index[l1], one.last_term[l1], 0)
+    c0 = one.committed.copy()
+    one.apply_log_deltas(l1, one.last_index[l1] + np.uint64(3), one.term[l1], 0)
+    assert (one.committed[l1] > c0[l1]).all()  # a leader that is its own quorum commits what it appends

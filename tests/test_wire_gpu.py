@@ -1139,3 +1139,37 @@ def test_wal_encode_begin_end_is_one_submission_with_the_call_behind_it():
         good, gpool = _wiregen.random_wal(rng, 50)
         got, _, crc = e.wal_encode(good, gpool)  # and the handle is as good as before
         assert got.tobytes() == W.wal_encode(good, gpool)[0].tobytes()
+
+
+def test_step_frames_at_bench_size(oracle):
+    """bench.py's inbound half-turn: 65,536 frames for 1M x 5 groups in one call (256 tiles through ~208 workers, the Step
+    kernels behind the decoder) -- every record, entry header and result against the oracle, the state after."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+    from tests import _stepgen
+
+    G, N, me = 1 << 20, 5, 0
+    rng = np.random.default_rng(2026)
+    st = _stepgen.random_state(rng, G, N, self_peer=me)
+    with WireEngine(G, N, me) as e:
+        _stepgen.load_engine(e, st)
+        for it in range(2):
+            n = 65536
+            s, off = _node_frames(rng, n, st, me)
+            wm, we, _ = W.wire_decode(s, off)
+            want_m, rec = _node_filter(wm, we, G, N, me, True)
+            want_o = st.step_batch(rec)
+            msgs, ents = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+            e.set_compact(it == 1)
+            gm, ge, go, c = e.step_frames(pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64)), msgs, ents)
+            _same(gm, want_m, f"records, call {it}")
+            _same(ge, we, f"entry headers, call {it}")
+            if it == 1:
+                from raftsql_amd import step as S
+
+                live = want_o["type"] != S.OUT_SKIPPED
+                full = S.expand_compact(gm.view(S.MSG_DT), go)
+                assert np.array_equal(full[live].view(np.uint8), want_o[live].view(np.uint8)) and (go["type"][~live] == S.OUT_SKIPPED).all()
+            else:
+                _same(go, want_o, f"results, call {it}")
+        _stepgen.assert_same_state(e, st)

@@ -1109,7 +1109,10 @@ def test_wal_encode_begin_end_is_one_submission_with_the_call_behind_it():
             p_recs, p_wpool = pinned_copy(np.ascontiguousarray(recs)), pinned_copy(np.ascontiguousarray(_wiregen_u8(wpool)))
             w_out, w_off = pinned_empty(len(want_w) + 64, np.uint8), pinned_empty(len(recs) + 1, np.uint64)
             e.wal_encode_begin(p_recs, p_wpool, 77, w_out, w_off)
-            if it != 1:  # (it == 1: nothing in between, _end makes the wait)
+            if it == 2:  # the copying form (pageable arrays) in between: ordered behind the begun encode by the stream alone
+                got_s, got_soff = e.wire_encode(m, ents, pool)
+                assert np.array_equal(got_soff, want_soff) and got_s.tobytes() == want_s.tobytes(), it
+            elif it != 1:  # (it == 1: nothing in between, _end makes the wait)
                 pm, pe, pp = pinned_copy(np.ascontiguousarray(m)), pinned_copy(np.ascontiguousarray(ents)) if len(ents) else ents, pinned_copy(np.ascontiguousarray(_wiregen_u8(pool)))
                 s_out, s_off = pinned_empty(len(want_s) + 64, np.uint8), pinned_empty(len(m) + 1, np.uint64)
                 got_s, got_soff = e.wire_encode(pm, pe, pp, out=s_out, off=s_off)

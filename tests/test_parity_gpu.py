@@ -725,6 +725,7 @@ def test_election_round_trip(gpu_engine_cls, oracle):
         assert w > 0 and l > 0 and (oc[cands] == 0).any()
 
 
+@pytest.mark.usefixtures("stage_mode")
 @pytest.mark.parametrize("n,G", [(1, 5000), (3, 70001), (5, 1 << 20), (7, 300000), (9, 4097)])
 def test_cycle_segmented_list_is_the_contiguous_list(gpu_engine_cls, oracle, n, G):
     """RAFTQ_CYCLE_SEGMENTED: the turn's sweep writes the advance list itself, a segment per tile.  Two handles fed the same

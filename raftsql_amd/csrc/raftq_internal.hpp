@@ -249,7 +249,7 @@ void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations 
 // stream and not waited for (the records also go to msgs_d, in HBM, for the Step kernels enqueued behind it); and what the
 // decode has to say once the call's one wait is over.  RAFTQ_EINVAL when an array is not page-locked and 16-byte aligned.
 int wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, void* msgs, void* ents,
-                        uint64_t ents_cap, void* msgs_d, int tail_appends);
+                        uint64_t ents_cap, void* msgs_d, int tail_appends, void* zero2 /* two device words left zero, or nullptr */);
 int wire_frames_finish(raftq_t* h, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap, ::raftq_wire_counts* counts);
 }  // namespace raftq_detail
 

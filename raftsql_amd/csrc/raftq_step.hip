@@ -569,7 +569,8 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
   }
   // touched count + bad + skipped: the default result copy leaves them zeroed behind it (step_d2h_kernel zero_tail)
   const uint32_t rec = h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
-  if (!sl.tail_zeroed || sl.tail_n != n || sl.tail_rec != rec || sl.dev != sl.tail_dev) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
+  // (a frames batch: the decoder that heads the chain zeroes them)
+  if (!frames && (!sl.tail_zeroed || sl.tail_n != n || sl.tail_rec != rec || sl.dev != sl.tail_dev)) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
   sl.tail_zeroed = false;
   if (packed) {
     hipLaunchKernelGGL(raftqk::step_unpack40_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
@@ -580,7 +581,7 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
     // one kernel: readers pull boundaries + stream, workers parse, check, flag (RAFTQ_MSGF_*) and push records + entry headers
     // to the caller's arrays and the records once more into this slot's scratch
     if (int rc = raftq_detail::wire_frames_enqueue(h, wire->stream, wire->nbytes, wire->frame_off, n, wire->msgs_h, wire->ents_h,
-                                                   wire->ents_cap, s.msgs, wire->tail_appends))
+                                                   wire->ents_cap, s.msgs, wire->tail_appends, s.n_heads))
       return rc;
   } else if (wire) {
     // frames -> the batch's message records, in HBM: the 64-byte records never cross PCIe.  (s.w_bad only counts

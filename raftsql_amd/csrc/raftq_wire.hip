@@ -392,7 +392,7 @@ static int decode_streaming_finish(raftq_t* h, const char* who, const uint64_t* 
 
 }  // extern "C"
 int raftq_detail::wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, void* msgs, void* ents,
-                                      uint64_t ents_cap, void* msgs_d, int tail_appends) {
+                                      uint64_t ents_cap, void* msgs_d, int tail_appends, void* zero2) {
   if (n > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_step_frames: batch too large");
   if (int rc = ensure_pin(h)) return rc;
   void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
@@ -401,7 +401,7 @@ int raftq_detail::wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t n
   if (!(mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off) && aligned16(v_msgs) && aligned16(v_ents)))
     return fail(h, RAFTQ_EINVAL, "raftq_step_frames: the stream, the boundaries and the result arrays must be page-locked (raftq_host_alloc, "
                                  "hipHostMalloc, hipHostRegister) and 16-byte aligned -- decode and step in two calls otherwise");
-  const FrameFilter ff{1u, h->N, h->self_peer, tail_appends ? 1u : 0u, h->G};
+  const FrameFilter ff{1u, h->N, h->self_peer, tail_appends ? 1u : 0u, h->G, (unsigned long long*)zero2};
   return decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents ? ents_cap : 0, (WireMsg*)msgs_d, ff);
 }
 int raftq_detail::wire_frames_finish(raftq_t* h, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
@@ -426,7 +426,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   if (mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
     // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
     // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
-    if (int rc = decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents_cap, nullptr, FrameFilter{0, 0, 0, 0, 0})) return rc;
+    if (int rc = decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents_cap, nullptr, FrameFilter{0, 0, 0, 0, 0, nullptr})) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return decode_streaming_finish(h, "raftq_wire_decode", frame_off, n, ents != nullptr, ents_cap, true, counts);
   }

@@ -874,6 +874,7 @@ __device__ __forceinline__ WaveStage stage_wave_frames_dma(const uint8_t* stream
 struct FrameFilter {
   uint32_t on, n_peers, self, tail_appends;
   uint64_t n_groups;
+  unsigned long long* zero2;  // two words this kernel leaves zero for the kernels behind it (Step's {touched groups, bad | skipped}), or nullptr
 };
 constexpr uint8_t kFrameSkip = 0x10, kFrameHold = 0x20, kFrameBarrier = 0x40, kFrameEntries = 0x80;  // == RAFTQ_MSGF_*
 static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
@@ -897,6 +898,7 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
   const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
   unsigned int* stuck = ctl.ticket + 1;
+  if (ff.zero2 != nullptr && blockIdx.x == in.readers && tid < 2) ff.zero2[tid] = 0;  // (saves Step a launch of its own in front of this one)
   for (;;) {
     const uint32_t cur = next_tile(ctl, &tile_slot);
     if (cur >= n_tiles) return;

@@ -1037,6 +1037,33 @@ def test_step_frames_equals_decode_filter_step(oracle, walk, tail_appends, monke
         _stepgen.assert_same_state(e, st)
 
 
+@pytest.mark.parametrize("N,me", [(2, 1), (3, 0), (4, 3), (7, 2), (9, 8)])
+def test_step_frames_for_every_cluster_size(oracle, N, me):
+    """the same comparison for 2 ... 9 peers and every kind of own slot (the vote word is 16 or 32 bits wide, the quorum even
+    or odd, `to` / `from` checks against other bounds)"""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+    from tests import _stepgen
+
+    G = 2000
+    rng = np.random.default_rng(7000 + N)
+    st = _stepgen.random_state(rng, G, N, self_peer=me)
+    with WireEngine(G, N, me) as e:
+        _stepgen.load_engine(e, st)
+        for it, n in enumerate([3000, 513, 6000]):
+            s, off = _node_frames(rng, n, st, me)
+            wm, we, _ = W.wire_decode(s, off)
+            want_m, rec = _node_filter(wm, we, G, N, me, it != 1)
+            want_o = st.step_batch(rec)
+            msgs, ents = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+            gm, ge, go, c = e.step_frames(pinned_copy(np.ascontiguousarray(s)), pinned_copy(np.ascontiguousarray(off, np.uint64)), msgs, ents,
+                                          tail_appends=it != 1)
+            _same(gm, want_m, f"records, call {it}")
+            _same(ge, we, f"entry headers, call {it}")
+            _same(go, want_o, f"results, call {it}")
+        _stepgen.assert_same_state(e, st)
+
+
 def test_step_frames_with_long_runs_goes_through_the_sorted_walk(oracle):
     """Hundreds of frames per group in one call: the list walk gives the batch up (a run longer than it takes) and the call
     replays it through the sorted walk -- the records the decoder left in HBM are read a second time, skipped and held frames

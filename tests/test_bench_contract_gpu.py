@@ -13,24 +13,57 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_LIMIT = 4096  # round 4's line was 24.9 KB and the driver's record came back `parsed: null`
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def read_line(stdout, legs_path):
+    """What the driver does: the LAST stdout line, parsed on its own.  It must be the only JSON line, at most 4 KB, carry every
+    contract key with roofline / cpu_baseline as flat objects, and agree with the full record written beside it; -> the full
+    record (every side leg's objects) with the line's own objects in place of the full ones, the line under "_line"."""
+    out = stdout.rstrip("\n").splitlines()
+    assert out, "nothing on stdout"
+    line_text = out[-1]
+    assert [ln for ln in out if ln.lstrip().startswith("{")] == [line_text], stdout[-2000:]
+    assert len(line_text.encode()) <= LINE_LIMIT, len(line_text)
+    line = json.loads(line_text)
+    for k in CONTRACT:
+        assert k in line, k
+    for k, v in line["roofline"].items():  # scalars, the two byte counts and one entry per GPU: nothing nested
+        assert not isinstance(v, dict) or k == "bytes_per_decision", k
+    assert all(isinstance(v, (int, float)) or k == "errors" for k, v in line.get("legs", {}).items())
+    full = json.load(open(legs_path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data"):
+        assert full[k] == line[k], k
+    assert full["roofline"]["frac"] == line["roofline"]["frac"] and full["roofline"]["launch_us"] == line["roofline"]["launch_us"]
+    if full["cpu_baseline"] is not None:
+        assert full["cpu_baseline"]["value"] == line["cpu_baseline"]["value"]
+    merged = dict(full)
+    merged["_line"] = line
+    return merged
+
+
 def run_bench(*args, expect_rc=0):
+    import tempfile
+
     env = {k: v for k, v in os.environ.items() if k != "RAFTQ_CYCLE_CHECK"}  # the bench measures the turn as shipped
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+    legs = os.path.join(tempfile.mkdtemp(prefix="raftq_bench_"), "legs.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--legs-out", legs], capture_output=True, text=True,
                        timeout=900, cwd=ROOT, env=env)
     if expect_rc != 0:
         assert p.returncode != 0, p.stdout[-500:]
         return p
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    return read_line(p.stdout, legs)
 
 
 def check_line(d, n_gpus, steps, warmup, sharing=1):
     """sharing: how many of the job's "GPUs" were mapped onto one device (testing only): each dispatch then runs that much slower"""
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    for k in CONTRACT:
         assert k in d, k
+    if "_line" in d:  # the same checks hold for the line the driver parses (its objects are trimmed, never recomputed)
+        check_line(d["_line"], n_gpus, steps, warmup, sharing)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"].split(" across")[0] in base["metric"]
     assert d["unit"] == "decisions/s" and d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
@@ -121,14 +154,15 @@ def _free_port():
 
 def _torchrun_bench(nproc, _port_hint, *args):
     port = _free_port()  # (a fixed port would collide with whatever else runs on the box)
+    import tempfile
+
     env = dict({k: v for k, v in os.environ.items() if k != "RAFTQ_CYCLE_CHECK"}, MASTER_ADDR="127.0.0.1")
+    legs = os.path.join(tempfile.mkdtemp(prefix="raftq_bench_"), "legs.json")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
-                        *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        *args, "--legs-out", legs], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    return read_line(p.stdout, legs)
 
 
 def test_bench_four_ranks_under_torchrun_on_one_gpu(gpu_engine_cls):

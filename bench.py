@@ -53,7 +53,7 @@ PCIE_DUPLEX_GBPS = 83.0  # both directions at once from ONE kernel on this box's
 _LEG_PMC = None
 
 
-def leg_traffic(kernels, launches_per_unit=1.0):
+def leg_traffic(kernels, launches_per_unit=1.0, leg=None):
     """HBM traffic of a side leg's kernels from the committed PMC passes (profiles/pmc_traffic_legs.json, written by
     tools/pmc_legs.py on the GPU box: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_* in separate passes, calibrated on
     a wide stream, a one-word-per-line gather and a one-word-per-line scatter).  `kernels`: name fragments.  Per matching
@@ -71,8 +71,11 @@ def leg_traffic(kernels, launches_per_unit=1.0):
     for frag in kernels:
         hit = False
         for name, rec in _LEG_PMC.get("kernels", {}).items():
-            if frag in name:
+            # (records are keyed "<leg>:<kernel>": the same kernel measured in two legs -- the decoder with and without the node's
+            # filter -- has two; a record of round 4's file has no leg and matches any)
+            if frag in rec.get("kernel", name) and (leg is None or rec.get("leg") in (None, leg)):
                 hit = True
+                name = rec.get("kernel", name)
                 b = rec["bytes_stream_calibrated"] if rec.get("pattern") == "stream" else rec["bytes_from_requests"]
                 found[name.split("<")[0].replace("raftqk::", "")] = {"read": b["read"], "write": b["write"], "pattern": rec.get("pattern"),
                                                                       "dispatches": rec["dispatches"]}
@@ -124,8 +127,10 @@ LEG_SCALARS = {
     "config4_whole_job_decisions_per_s": ("config4_whole_job", "decisions_per_s"),
     "turn_segmented_c_us": ("pipeline", "c_caller", "us_per_turn_segmented_list"),
     "turn_contiguous_c_us": ("pipeline", "c_caller", "us_per_turn_contiguous_list"),
+    "turn_segmented_py_us": ("pipeline", "python_loop_us", "segmented_list"),
     "tick_set_frac": ("tick", "set_dispatch", "steady_state", "roofline", "frac"),
     "tick_lists_us": ("tick", "tick_and_lists", "us_per_call"),
+    "tick_lists_bitmap_us": ("tick", "tick_and_lists", "beat_bitmap", "us_per_call"),
     "step_msgs_per_s": ("step", "pipelined", "compact_results", "msgs_per_s"),
     "frames_decode_us": ("wire", "message_frames", "pinned", "decode_us"),
     "frames_encode_us": ("wire", "message_frames", "pinned", "encode_us"),
@@ -495,42 +500,53 @@ def pipeline_measure(cfg, device, deltas_per_cycle=65536, cycles=60):
             c_caller = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
         except Exception as ex:  # noqa: BLE001
             c_caller = {"error": repr(ex)[:300]}
+    def turn_leg(what, seconds, adv, delta_b, adv_b, kernels, note):
+        """A latency-bound leg says microseconds, not a fraction of a peak it is not bound by: wall time of
+        the calls, what crosses the link, and the turn's HBM traffic against what its arrays add up to."""
+        r = {"what": what, "us_per_cycle": seconds / cycles * 1e6, "deltas_per_s": nd * cycles / seconds, "decisions_per_s": G * cycles / seconds,
+             "advanced_per_cycle": adv / cycles,
+             "roofline": {"bound": "latency", "wall_us": seconds / cycles * 1e6, "launches": len(kernels) + (0 if "flag" in kernels[-1] else 1),
+                          "bytes_per_turn": {"in": float(delta_b * nd), "out": float(adv_b * adv / cycles)}, "note": note, "traffic": None}}
+        t = leg_traffic(kernels, leg="cycle")
+        alg = cycle_algorithmic(G, N, nd, adv / cycles, delta_b, adv_b)
+        if t["bytes"] is None:
+            r["roofline"]["traffic_note"] = "no PMC record for " + ", ".join(t["missing"]) + ": no traffic quoted (a partial sum is not one)"
+        else:
+            r["roofline"].update(traffic=t["bytes"], traffic_kernels=t["kernels"], traffic_measured_at=t["measured_at"],
+                                 algorithmic_hbm_bytes=alg, traffic_over_algorithmic=t["bytes"] / alg)
+        return r
+
+    seg = turn_leg("raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED + RAFTQ_CYCLE_SEGMENTED (what raftq_pipe runs): 16-byte acks in, the sweep writes "
+                   "the advance list itself, a segment per 1,024-group tile (raftq_last_advance_segments); three launches, one wait",
+                   t_seg, adv_seg, 16, 16,
+                   ["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_segments_kernel<5, 4, false", "raise_flag_segments_kernel"],
+                   "ingest, sweep + list, flag: three launches and one wait on the completion word")
+    packed = turn_leg("raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED: 16-byte acks in (validated and scattered in one pass), ONE contiguous "
+                      "list of 16-byte advances out", t_packed, adv_packed, 16, 16,
+                      ["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_kernel<5, 4, true, false, false", "compact_changed_kernel<4, raftqk::Advance16>"],
+                      "ingest, sweep, compaction, flag: four launches and one wait")
+    wide = turn_leg("raftq_cycle: 24-byte acks in, validated, then scattered; ONE contiguous list of 24-byte advances out",
+                    t_total, adv_total, 24, 24,
+                    ["deltas_in_kernel<raftqk::DeltaRec>", "apply_deltas_kernel<raftqk::DeltaRec>", "sweep_kernel<5, 4, true, false, false",
+                     "compact_changed_kernel<4, raftqk::Advance>"], "ingest (two kernels), sweep, compaction, flag: five launches and one wait")
+    ok_c = isinstance(c_caller, dict) and "us_per_turn_segmented_list" in c_caller
     return {
-        "what": "raftq_cycle: acks in -> scatter -> full sweep of G groups -> compacted advance list out over PCIe (zero-copy "
-                "staging: the producer writes the records into the handle's ack buffer -- device memory behind a large BAR, "
-                "pinned host memory otherwise -- before the call; wall time of the library's calls incl. their one wait, "
-                "arguments built beforehand: the Python mirror's own per-call work, ~12 us, is outside the clock from round 4 on -- "
-                "c_caller is the same turn from plain C)",
-        "groups": G, "peers": N, "deltas_per_cycle": nd, "advanced_per_cycle": adv_total / cycles,
-        "us_per_cycle": t_total / cycles * 1e6, "deltas_per_s": nd * cycles / t_total,
-        "decisions_per_s": G * cycles / t_total,
-        "us_per_cycle_copying_form": t_copy / cycles * 1e6,
+        "what": "one batching turn (raft.go:227-235 for every group): %d acks in -> scatter -> sweep of all %d groups -> the advance list "
+                "out, zero-copy staging both ways (the producer writes the acks into the handle's ack buffer before the call: device "
+                "memory behind a large BAR, page-locked host memory otherwise).  The SHIPPED form first (segments: what raftq_pipe runs), "
+                "on the clock of a plain-C caller at the C-ABI (tools/tune/turn_latency.c: what cgo sees); the same calls timed in this "
+                "interpreter's loop (arguments built beforehand) under python_loop_us" % (nd, G),
+        "groups": G, "peers": N, "deltas_per_cycle": nd, "advanced_per_cycle": adv_seg / cycles,
+        "us_per_cycle": c_caller["us_per_turn_segmented_list"] if ok_c else seg["us_per_cycle"],
+        "clock": "plain-C caller at the C-ABI" if ok_c else "this interpreter's loop (the C caller did not run)",
+        "us_per_cycle_by_form": {"segmented_list": c_caller.get("us_per_turn_segmented_list"),
+                                 "contiguous_list_16B": c_caller.get("us_per_turn_contiguous_list")} if ok_c else None,
+        "python_loop_us": {"segmented_list": seg["us_per_cycle"], "contiguous_list_16B": packed["us_per_cycle"],
+                           "contiguous_list_24B": wide["us_per_cycle"], "copying_form_24B": t_copy / cycles * 1e6},
+        "deltas_per_s": nd / ((c_caller["us_per_turn_segmented_list"] if ok_c else seg["us_per_cycle"]) * 1e-6),
         "c_caller": c_caller,
-        "roofline": leg_roofline("latency", "turn", cycles, t_total, 24.0 * nd * cycles, 24.0 * adv_total,
-                                 "acks in (the producer's stores, before the call) and advances out cross the link once each; "
-                                 "a turn is four dependent launches and one wait -- latency, not a link and not HBM, is what it is "
-                                 "made of (frac is of the HBM peak and means little); traffic = the turn's kernels together",
-                                 traffic=leg_traffic(["deltas_in_kernel<raftqk::DeltaRec>", "apply_deltas_kernel<raftqk::DeltaRec>", "sweep_kernel<5, 4, true, false, false",
-                                                      "compact_changed_kernel<4, raftqk::Advance>"]),
-                                 algorithmic=cycle_algorithmic(G, N, nd, adv_total / cycles, 24, 24)),
-        "packed_records": {"what": "raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED: 16-byte deltas in (validated and scattered "
-                                   "in one pass), 16-byte advances out, zero-copy staging",
-                           "us_per_cycle": t_packed / cycles * 1e6, "deltas_per_s": nd * cycles / t_packed,
-                           "decisions_per_s": G * cycles / t_packed, "advanced_per_cycle": adv_packed / cycles,
-                           "roofline": leg_roofline("latency", "turn", cycles, t_packed, 16.0 * nd * cycles, 16.0 * adv_packed,
-                                                    "as above with the 16-byte records (validated and scattered in one pass)",
-                                                    traffic=leg_traffic(["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_kernel<5, 4, true, false, false",
-                                                                         "compact_changed_kernel<4, raftqk::Advance16>"]),
-                                                    algorithmic=cycle_algorithmic(G, N, nd, adv_packed / cycles, 16, 16))},
-        "segmented_list": {"what": "raftq_cycle_packed + RAFTQ_CYCLE_TRUSTED + RAFTQ_CYCLE_SEGMENTED: the sweep writes the advance list "
-                                   "itself, a segment per 1,024-group tile (raftq_last_advance_segments); two kernels and the "
-                                   "completion word per turn instead of four",
-                           "us_per_cycle": t_seg / cycles * 1e6, "deltas_per_s": nd * cycles / t_seg,
-                           "decisions_per_s": G * cycles / t_seg, "advanced_per_cycle": adv_seg / cycles,
-                           "roofline": leg_roofline("latency", "turn", cycles, t_seg, 16.0 * nd * cycles, 16.0 * adv_seg,
-                                                    "ingest, sweep + list, flag: three launches and one wait",
-                                                    traffic=leg_traffic(["deltas_in_apply_kernel<raftqk::Delta16Rec>", "sweep_segments_kernel<5, 4, false"]),
-                                                    algorithmic=cycle_algorithmic(G, N, nd, adv_seg / cycles, 16, 16))},
+        "roofline": seg["roofline"],
+        "segmented_list": seg, "packed_records": packed, "wide_records": wide,
     }
 
 
@@ -546,6 +562,7 @@ def tick_measure(cfg, device, ticks=2000, members=8):
     1M-group handle is 10 MB per launch -- cache-resident and launch-bound; a sweep set ticks `members` handles with ONE
     dispatch (raftq_set_tick), 80 MB behind one launch boundary; raftq_tick_collect is the Tick plus both of its lists
     (MsgHup / MsgBeat groups, ascending) in two launches and one wait."""
+    from raftsql_amd import _lib
     from raftsql_amd.engine import QuorumEngine, SweepSet
 
     G = cfg["G"]
@@ -564,17 +581,46 @@ def tick_measure(cfg, device, ticks=2000, members=8):
     hup, beat = e.tick()
     us = ms * 1e3 / ticks
     t0 = time.perf_counter()
-    for _ in range(200):
-        _, nh, _, nb = e.tick_collect(hup_cap=4096, beat_cap=G)
-    us_collect = (time.perf_counter() - t0) / 200 * 1e6
-    with SweepSet(es) as s:
+    for _ in range(100):
+        _, nh, _, nb = e.tick_collect(hup_cap=G, beat_cap=G)
+    us_collect = (time.perf_counter() - t0) / 100 * 1e6
+    # the in-place form (raftq_tick_collect_lists + raftq_last_tick_lists): 4-byte ids read where the device left them, the beats
+    # as a list or as a group-order bitmap; the clock is around the library's calls, their arguments built beforehand
+    import ctypes as C
+
+    lib, hnd = e._lib, e._h
+    c_nh, c_nb = C.c_uint64(0), C.c_uint64(0)
+    r_nh, r_nb = C.byref(c_nh), C.byref(c_nb)
+    ptrs = [C.c_void_p(None) for _ in range(3)]
+    lens = [C.c_uint64(0) for _ in range(3)]
+    r_last = (C.byref(ptrs[0]), C.byref(lens[0]), C.byref(ptrs[1]), C.byref(lens[1]), C.byref(ptrs[2]), C.byref(lens[2]))
+
+    def in_place(flags, reps=300):
+        for _ in range(20):
+            e._chk(lib.raftq_tick_collect_lists(hnd, flags, G, G, r_nh, r_nb))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rc = lib.raftq_tick_collect_lists(hnd, flags, G, G, r_nh, r_nb)
+            rc2 = lib.raftq_last_tick_lists(hnd, *r_last)
+        dt = (time.perf_counter() - t0) / reps
+        assert rc == 0 and rc2 == 0
+        return dt * 1e6, int(c_nh.value), int(c_nb.value)
+
+    us_lists, nh_l, nb_l = in_place(0)
+    assert lens[0].value == nh_l and lens[1].value == nb_l and lens[2].value == 0
+    us_bitmap, nh_m, nb_m = in_place(_lib.TICK_BEAT_BITMAP)
+    assert lens[0].value == nh_m and lens[2].value == (G + 63) // 64
+    def set_times(s):
+        for x in es:
+            x.set_timers(10, 1, 0x1000)
+            x.load_roles(role)
         for _ in range(20):
             s.tick()
         s.wait()
         s.timer_begin()
         for _ in range(ticks // 4):
             s.tick()
-        us_set = s.timer_end() * 1e3 / (ticks // 4)
+        draw = s.timer_end() * 1e3 / (ticks // 4)
         # steady state: heartbeats keep resetting the followers' clocks, no timer is past its base timeout, nobody draws
         # (above: no heartbeat ever arrives, two thirds of the groups time out again and again and every wave runs the
         # timeout draw -- three 64-bit multiplies per group: that form is VALU-bound, not HBM-bound)
@@ -587,7 +633,20 @@ def tick_measure(cfg, device, ticks=2000, members=8):
         s.timer_begin()
         for _ in range(ticks // 4):
             s.tick()
-        us_set_quiet = s.timer_end() * 1e3 / (ticks // 4)
+        return draw, s.timer_end() * 1e3 / (ticks // 4)
+
+    shapes = {}
+    with SweepSet(es) as s:
+        was = os.environ.pop("RAFTQ_TICK_SHAPE", None)
+        us_set, us_set_quiet = set_times(s)  # the shipped default
+        for shape in ("narrow", "wide1", "wide2", "wide4"):  # the launch shapes side by side, same box, same process
+            os.environ["RAFTQ_TICK_SHAPE"] = shape
+            d, q = set_times(s)
+            shapes[shape] = {"every_follower_draws_us": d, "steady_state_us": q,
+                             "steady_state_frac": 10.0 * G * members / (q * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+        os.environ.pop("RAFTQ_TICK_SHAPE", None)
+        if was is not None:
+            os.environ["RAFTQ_TICK_SHAPE"] = was
     for x in es:
         x.close()
     return {"what": "batched Tick (tickElection/tickHeartbeat) over all groups", "groups": G, "launch_us": us,
@@ -595,19 +654,32 @@ def tick_measure(cfg, device, ticks=2000, members=8):
             "roofline": leg_roofline("hbm", "group", G, us * 1e-6, 5.0 * G, 5.0 * G,
                                      "role 1 + elapsed 4 in, elapsed 4 + action 1 out per group; 10 MB per launch is cache-resident "
                                      "and the launch boundary is a third of the time: launch-bound at this size",
-                                     traffic=leg_traffic(["tick_kernel"]), algorithmic=10.0 * G + G / 4.0),
+                                     traffic=leg_traffic(["tick_kernel"], leg="tick"), algorithmic=10.0 * G + G / 4.0),
             "set_dispatch": {"what": "raftq_set_tick: %d handles of %d groups, ONE dispatch per Tick" % (members, G), "members": members,
                              "launch_us": us_set, "group_ticks_per_s": members * G / (us_set * 1e-6),
                              "roofline": leg_roofline("hbm", "group", members * G, us_set * 1e-6, 5.0 * G * members, 5.0 * G * members,
                                                       "the same 10 B per group, %d MB per dispatch; every follower past its base timeout "
                                                       "(no heartbeats in this loop): every wave runs the timeout draw, VALU-bound" % (10 * members * G // 1000000),
-                                                      traffic=leg_traffic(["tick_set_kernel"]), algorithmic=(10.0 * G + G / 4.0) * members),
+                                                      traffic=leg_traffic(["tick_set_wide_kernel<2>"], leg="tick"), algorithmic=(10.0 * G + G / 4.0) * members),
                              "steady_state": {"what": "the same dispatch with no timer past its base timeout (what heartbeats keep true): no wave draws",
                                               "launch_us": us_set_quiet, "group_ticks_per_s": members * G / (us_set_quiet * 1e-6),
                                               "roofline": leg_roofline("hbm", "group", members * G, us_set_quiet * 1e-6, 5.0 * G * members,
-                                                                       5.0 * G * members, "10 B per group, no draw")}},
-            "tick_and_lists": {"what": "raftq_tick_collect: the Tick + its MsgHup and MsgBeat lists (ascending), two launches, one wait; "
-                                       "wall time of the call", "us_per_call": us_collect, "n_hup": nh, "n_beat": nb},
+                                                                       5.0 * G * members, "10 B per group, no draw")},
+                             "shapes": shapes,
+                             "shapes_what": "RAFTQ_TICK_SHAPE: wide2 (shipped: 16 groups per lane, two 1,024-group blocks per wave), wide1, wide4, "
+                                            "narrow (round 4: 4 groups per lane, four rounds per workgroup)"},
+            "tick_and_lists": {"what": "raftq_tick_collect_lists + raftq_last_tick_lists: the Tick + its MsgHup and MsgBeat lists (ascending, "
+                                       "4-byte ids) left in page-locked memory, three launches, one wait on the completion word; wall time "
+                                       "of the two calls, arguments built beforehand", "us_per_call": us_lists, "n_hup": nh_l, "n_beat": nb_l,
+                               "roofline": leg_roofline("pcie", "call", 1, us_lists * 1e-6, 0.0, 4.0 * (nh_l + nb_l) + 16,
+                                                        "ids out over the link; the Tick itself is 4.4 us of the call"),
+                               "beat_bitmap": {"what": "the same with RAFTQ_TICK_BEAT_BITMAP: the MsgBeat groups as a group-order bitmap "
+                                                       "(with HeartbeatTick 1 the beat list is the leader set, every tick)",
+                                               "us_per_call": us_bitmap, "n_hup": nh_m, "n_beat": nb_m,
+                                               "roofline": leg_roofline("pcie", "call", 1, us_bitmap * 1e-6, 0.0, 4.0 * nh_m + G / 8.0 + 16,
+                                                                        "latency-bound: 0.3 MB out")},
+                               "copying_form_us": us_collect,
+                               "copying_form": "raftq_tick_collect: 8-byte ids copied into the caller's arrays (round 4's call)"},
             "last_tick": {"n_hup": hup, "n_beat": beat}}
 
 
@@ -760,7 +832,7 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
         "staged batches resubmitted, 40-byte results out; the previous batch's results ride out inside this batch's two kernels, "
         "which therefore last as long as the link takes (2.6 MB: 48 us at 55 GB/s + two launch boundaries): PCIe-out-bound. "
         "traffic = HBM bytes of the link + walk kernels per batch (measured with nothing riding: RAFTQ_STEP_DEFER_COPY=0)",
-        traffic=leg_traffic(["step_link_kernel", "step_lists_kernel"]), algorithmic=step_alg(40.0))
+        traffic=leg_traffic(["step_link_kernel", "step_lists_kernel"], leg="step"), algorithmic=step_alg(40.0))
     out["pipelined"]["producer_included"]["roofline_64B"] = leg_roofline(
         "pcie", "message", M, produced[False], 64.0 * M, 40.0 * M, "every batch written into device staging by one host thread, 40-byte results out")
     out["pipelined"]["producer_included"]["roofline_40B"] = leg_roofline(
@@ -881,10 +953,10 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
            "moves both ways at once on this link (2 x 41.5 GB/s, profiles/r04/pcie_duplex_probe.jsonl), `frac` against one direction's "
            "63 GB/s as before; traffic = the kernel's HBM bytes (the scratch hop: written once by the readers, read once by the workers)")
     mf["roofline_encode"] = leg_roofline("pcie", "message", n, t_enc_p, enc_in, enc_out, "records + payload pool in, frames + offsets out; " + why,
-                                         traffic=leg_traffic(["wire_enc_fused_kernel"]), algorithmic=2.0 * enc_in + 2.0 * enc_out)
+                                         traffic=leg_traffic(["wire_enc_fused_kernel"], leg="wire"), algorithmic=2.0 * enc_in + 2.0 * enc_out)
     mf["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_enc_p, enc_in, enc_out)
     mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out; " + why,
-                                         traffic=leg_traffic(["wire_dec_fused_kernel"]), algorithmic=2.0 * dec_in)
+                                         traffic=leg_traffic(["wire_dec_fused_kernel"], leg="wire"), algorithmic=2.0 * dec_in)
     mf["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_dec_p, dec_in, dec_out)
     # a node's inbound half-turn on the same frames: ONE submission (raftq_step_frames: decode + the node's checks + Step over
     # every frame, one wait) against round 3's way (raftq_wire_decode, wait, the records copied into the staging area,
@@ -1023,10 +1095,10 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     wp = out["wal_frames"]["pinned"]
     w_in, w_out = float(pr.nbytes + pwp.nbytes), float(len(wal) + poff.nbytes)
     wp["roofline_encode"] = leg_roofline("pcie", "record", n, t_wenc_p, w_in, w_out, "records + payload pool in, WAL bytes + offsets out; " + why,
-                                         traffic=leg_traffic(["wal_enc_fused_kernel"]), algorithmic=2.0 * w_in + 2.0 * w_out)
+                                         traffic=leg_traffic(["wal_enc_fused_kernel"], leg="wire"), algorithmic=2.0 * w_in + 2.0 * w_out)
     wp["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "record", n, t_wenc_p, w_in, w_out)
     wp["roofline_decode"] = leg_roofline("pcie", "record", n, t_wdec_p, w_out, float(precs.nbytes), "WAL bytes + offsets in, 48-byte records out; " + why,
-                                         traffic=leg_traffic(["wal_dec_fused_kernel"]), algorithmic=2.0 * w_out)
+                                         traffic=leg_traffic(["wal_dec_fused_kernel"], leg="wire"), algorithmic=2.0 * w_out)
     wp["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "record", n, t_wdec_p, w_out, float(precs.nbytes))
     e.close()
     if with_cpu:

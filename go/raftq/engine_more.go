@@ -115,6 +115,44 @@ func (e *Engine) TickCollect(hups, beats []uint64) (nHup, nBeat uint64, err erro
 	return uint64(nh), uint64(nb), err
 }
 
+// TickBeatBitmap asks TickCollectLists for the MsgBeat groups as a bitmap in group order instead of a list.
+const TickBeatBitmap = uint(C.RAFTQ_TICK_BEAT_BITMAP)
+
+// TickLists is what TickCollectLists left in the library's page-locked memory: valid until the next call on the engine.
+type TickLists struct {
+	Hups       []uint32 // ascending
+	Beats      []uint32 // ascending; nil with TickBeatBitmap
+	BeatBitmap []uint64 // bit g%64 of word g/64; nil without TickBeatBitmap
+	NHup       uint64   // totals (the lists hold at most hupCap / beatCap of them)
+	NBeat      uint64
+}
+
+// TickCollectLists is rc.node.Tick() (raft.go:223-224) of every group and its two lists, left in place: 4-byte group ids in
+// page-locked memory, nothing copied (raftq_tick_collect_lists + raftq_last_tick_lists: three launches, one wait).
+func (e *Engine) TickCollectLists(flags uint, hupCap, beatCap uint64) (TickLists, error) {
+	var nh, nb C.uint64_t
+	if err := e.err(C.raftq_tick_collect_lists(e.h, C.uint(flags), C.uint64_t(hupCap), C.uint64_t(beatCap), &nh, &nb)); err != nil {
+		return TickLists{}, err
+	}
+	var ph, pb *C.uint32_t
+	var pm *C.uint64_t
+	var lh, lb, lm C.uint64_t
+	if err := e.err(C.raftq_last_tick_lists(e.h, &ph, &lh, &pb, &lb, &pm, &lm)); err != nil {
+		return TickLists{}, err
+	}
+	t := TickLists{NHup: uint64(nh), NBeat: uint64(nb)}
+	if lh > 0 {
+		t.Hups = unsafe.Slice((*uint32)(unsafe.Pointer(ph)), int(lh))
+	}
+	if lb > 0 {
+		t.Beats = unsafe.Slice((*uint32)(unsafe.Pointer(pb)), int(lb))
+	}
+	if lm > 0 {
+		t.BeatBitmap = unsafe.Slice((*uint64)(unsafe.Pointer(pm)), int(lm))
+	}
+	return t, nil
+}
+
 // Campaign is becomeCandidate for the groups named (distinct).
 func (e *Engine) Campaign(groups []uint64, selfPeer uint32) error {
 	if len(groups) == 0 {

@@ -86,6 +86,10 @@ type Engine struct {
 	h      *C.raftq_t
 	Groups uint64
 	Peers  uint32
+	// walBegun: a WalSaveBegin that enqueued something is waiting for its WalSaveEnd; walPrevCrc: what an End answers when the
+	// Begin before it had no records (nothing was enqueued, the chain's CRC is where it was)
+	walBegun   bool
+	walPrevCrc uint32
 }
 
 func (e *Engine) err(rc C.int) error {

@@ -213,6 +213,9 @@ func (e *Engine) StepFrames(stream []byte, frameOff []uint64, tailAppends bool, 
 	if n <= 0 {
 		return 0, 0, nil
 	}
+	if len(msgs) < n {
+		return 0, 0, fmt.Errorf("raftq: StepFrames: %d frames, room for %d records", n, len(msgs))
+	}
 	var pe *C.raftq_wire_ent_t
 	if len(ents) > 0 {
 		pe = (*C.raftq_wire_ent_t)(unsafe.Pointer(&ents[0]))
@@ -231,14 +234,22 @@ func (e *Engine) StepFrames(stream []byte, frameOff []uint64, tailAppends bool, 
 // are one submission: Begin enqueues (raftq_wal_encode_begin; page-locked buffers), the wait of the WireEncode called next
 // covers it, End reports what WalSave would have.  out is not to be read, nor recs / pool reused, before End.
 func (e *Engine) WalSaveBegin(recs []WalRec, pool []byte, prevCrc uint32, out []byte) error {
-	if len(recs) == 0 {
+	e.walPrevCrc = prevCrc
+	if len(recs) == 0 { // a turn with nothing to persist: the End paired with it answers (0, prevCrc, nil)
+		e.walBegun = false
 		return nil
 	}
-	return e.err(C.raftq_wal_encode_begin(e.h, (*C.raftq_wal_rec_t)(unsafe.Pointer(&recs[0])), C.uint64_t(len(recs)), bytesPtr(pool),
+	err := e.err(C.raftq_wal_encode_begin(e.h, (*C.raftq_wal_rec_t)(unsafe.Pointer(&recs[0])), C.uint64_t(len(recs)), bytesPtr(pool),
 		C.uint64_t(len(pool)), C.uint32_t(prevCrc), bytesPtr(out), C.uint64_t(len(out)), nil))
+	e.walBegun = err == nil
+	return err
 }
 
 func (e *Engine) WalSaveEnd() (n uint64, lastCrc uint32, err error) {
+	if !e.walBegun {
+		return 0, e.walPrevCrc, nil
+	}
+	e.walBegun = false
 	var c C.raftq_wal_counts_t
 	rc := C.raftq_wal_encode_end(e.h, &c)
 	return uint64(c.bytes), uint32(c.last_crc), e.err(rc)

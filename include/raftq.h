@@ -223,6 +223,19 @@ int raftq_collect_beats(raftq_t* h, uint64_t* groups, uint64_t cap, uint64_t* n)
  * launches and two waits.  *n_hup / *n_beat receive the full counts even when they exceed the caps. */
 int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n_hup, uint64_t* beats, uint64_t beat_cap,
                        uint64_t* n_beat);
+
+/* The same Tick + lists as they are meant to be read by a batching host: 4-byte group ids (a handle holds at most 2^30
+ * groups) LEFT IN PLACE in page-locked memory -- nothing is copied into caller arrays -- and, with RAFTQ_TICK_BEAT_BITMAP,
+ * the MsgBeat groups as a bitmap in group order (bit g % 64 of word g / 64) instead of a list: with HeartbeatTick 1
+ * (raft.go:155) every leader owes a heartbeat on every tick, so the beat list IS the leader set, tick after tick.
+ * n_hup / n_beat are the totals; at most hup_cap / beat_cap ids are listed (beat_cap is ignored with the bitmap).  Three
+ * launches and one wait on the turn's completion word.  Stands in for rc.node.Tick() of every group (raft.go:223-224). */
+#define RAFTQ_TICK_BEAT_BITMAP 1u
+int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint64_t beat_cap, uint64_t* n_hup, uint64_t* n_beat);
+/* what the last raftq_tick_collect_lists left: ascending ids (valid until the next call of either on this handle); any
+ * pointer argument may be NULL.  With the bitmap: *beats = NULL, *n_beats = 0, *bitmap_words = ceil(G / 64). */
+int raftq_last_tick_lists(raftq_t* h, const uint32_t** hups, uint64_t* n_hups, const uint32_t** beats, uint64_t* n_beats,
+                          const uint64_t** beat_bitmap, uint64_t* bitmap_words);
 /* becomeCandidate for `n` distinct groups: role = candidate, elapsed = 0, votes
  * cleared, the candidate's own slot (`self_peer`) granted.  Term bookkeeping is
  * the caller's (raftq_apply_term_deltas). */

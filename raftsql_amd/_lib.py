@@ -26,6 +26,7 @@ SWEEP_CHANGED = 0x20
 SWEEP_STREAM = 0x40
 SWEEP_CACHED = 0x80
 CYCLE_TRUSTED = 0x100
+TICK_BEAT_BITMAP = 1  # raftq_tick_collect_lists: the MsgBeat groups as a group-order bitmap instead of a list
 CYCLE_SEGMENTED = 0x200  # raftq_cycle_packed: the advance list may be left in segments (raftq_last_advance_segments)
 SET_GRID, SET_PERSISTENT = 0, 1
 
@@ -87,6 +88,9 @@ _SIGS = [
     ("raftq_collect_hups", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_collect_beats", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("raftq_tick_collect", C.c_int, [_H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("raftq_tick_collect_lists", C.c_int, [_H, C.c_uint, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("raftq_last_tick_lists", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_campaign", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint32]),
     ("raftq_cycle", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_uint64), C.POINTER(Counts)]),

@@ -500,6 +500,7 @@ void raftq_destroy(raftq_t* h) {
   if (h->stage_h) (void)hipHostFree(h->stage_h);
   if (h->ingest_h) (void)(h->ingest_in_device ? hipFree(h->ingest_h) : hipHostFree(h->ingest_h));
   if (h->adv_h) (void)hipHostFree(h->adv_h);
+  if (h->tl_h) (void)hipHostFree(h->tl_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
   if (h->h_total) (void)hipHostFree(h->h_total);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -969,6 +970,8 @@ int raftq_detail::ensure_tick_state(raftq_t* h) {
 }
 
 static int ensure_tick_offsets2(raftq_t* h, uint64_t nw);
+static int flag_mode();
+static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch);
 
 extern "C" {
 
@@ -1064,6 +1067,88 @@ int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n
   if (const uint64_t take = std::min(*n_hup, cap_h)) std::memcpy(hups, list_h, take * 8);
   if (const uint64_t take = std::min(*n_beat, cap_b)) std::memcpy(beats, list_h + cap_h, take * 8);
   h->adv_listed = 0;
+  return RAFTQ_OK;
+}
+
+// Tick + both lists as they are meant to be read: 4-byte group ids LEFT IN PLACE in page-locked memory
+// (raftq_last_tick_lists: no copy into caller arrays -- 110 of the 172 us raftq_tick_collect took at 1M groups / 400K entries),
+// the MsgBeat groups as a group-order bitmap when the caller asks for it (RAFTQ_TICK_BEAT_BITMAP), and the wait on the turn's
+// completion word instead of a stream synchronisation.  Three launches (tick, lists, flag), one wait.
+int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint64_t beat_cap, uint64_t* n_hup, uint64_t* n_beat) {
+  if (int rc = use_device_idle(h, "raftq_tick_collect_lists")) return rc;
+  if (!n_hup || !n_beat) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect_lists: null count");
+  if (flags & ~RAFTQ_TICK_BEAT_BITMAP) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect_lists: unknown flag");
+  if (int rc = ensure_tick_state(h)) return rc;
+  const bool bitmap = flags & RAFTQ_TICK_BEAT_BITMAP;
+  const uint64_t cap_h = std::min<uint64_t>(hup_cap, h->G), cap_b = bitmap ? 0 : std::min<uint64_t>(beat_cap, h->G);
+  const uint64_t map_off = ((cap_h + cap_b) * 4 + 255) / 256 * 256;
+  const uint64_t need = map_off + h->gpad / 8 + 256;
+  h->tl_valid = false;
+  if (need > h->tl_bytes) {
+    if (h->tl_h) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipHostFree(h->tl_h));
+      h->tl_h = h->tl_d = nullptr;
+      h->tl_bytes = 0;
+    }
+    const uint64_t want = std::max<uint64_t>(need, 1 << 16);
+    HIPCHK(h, hipHostMalloc((void**)&h->tl_h, want, hipHostMallocMapped | host_coherence_flag()));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->tl_d, h->tl_h, 0));
+    h->tl_bytes = want;
+  }
+  hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
+  h->ticked = true;
+  const uint64_t nw = h->gpad / 256;
+  const uint64_t *off_h = nullptr, *off_b = nullptr;
+  if (nw > (1u << 14)) {  // past 16K waves every workgroup summing its predecessors itself would show: scan first
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets, h->d_total, 0);
+    if (int rc = ensure_tick_offsets2(h, nw)) return rc;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->tick_offsets2, h->d_total + 1, 1);
+    off_h = h->offsets;
+    off_b = h->tick_offsets2;
+  }
+  uint32_t* const hup_d = h->tl_d;
+  uint32_t* const beat_d = h->tl_d + cap_h;
+  uint64_t* const map_d = (uint64_t*)((uint8_t*)h->tl_d + map_off);
+  const dim3 grid((unsigned)(h->gpad / 1024));
+  if (bitmap)
+    hipLaunchKernelGGL((tick_lists32_kernel<true>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits,
+                       (const uint4*)h->tick_partials, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b);
+  else
+    hipLaunchKernelGGL((tick_lists32_kernel<false>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits,
+                       (const uint4*)h->tick_partials, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b);
+  HIPCHK(h, hipGetLastError());
+  // the completion word: a one-thread kernel behind the lists (only a kernel boundary orders eight XCDs' stores to host memory
+  // before it -- raftq_cycle's finding), polled by the host; the blocking wait where the word cannot be had
+  uint64_t epoch = 0;
+  if (h->stream_write_ok && flag_mode() == 1) {
+    epoch = ++h->compact_epoch;
+    h->flag_mask = ~0ull;
+    hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, wait_turn(h, epoch));
+  *n_hup = h->tl_n_hup = h->h_total[0];
+  *n_beat = h->tl_n_beat = h->h_total[1];
+  h->tl_hup_cap = cap_h;
+  h->tl_beat_cap = cap_b;
+  h->tl_map_off = map_off;
+  h->tl_flags = flags;
+  h->tl_valid = true;
+  return RAFTQ_OK;
+}
+
+int raftq_last_tick_lists(raftq_t* h, const uint32_t** hups, uint64_t* n_hups, const uint32_t** beats, uint64_t* n_beats,
+                          const uint64_t** beat_bitmap, uint64_t* bitmap_words) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!h->tl_valid) return fail(h, RAFTQ_ESTATE, "raftq_last_tick_lists: no raftq_tick_collect_lists before it");
+  const bool bitmap = h->tl_flags & RAFTQ_TICK_BEAT_BITMAP;
+  if (hups) *hups = h->tl_h;
+  if (n_hups) *n_hups = std::min(h->tl_n_hup, h->tl_hup_cap);
+  if (beats) *beats = bitmap ? nullptr : h->tl_h + h->tl_hup_cap;
+  if (n_beats) *n_beats = bitmap ? 0 : std::min(h->tl_n_beat, h->tl_beat_cap);
+  if (beat_bitmap) *beat_bitmap = bitmap ? (const uint64_t*)((const uint8_t*)h->tl_h + h->tl_map_off) : nullptr;
+  if (bitmap_words) *bitmap_words = bitmap ? (h->G + 63) / 64 : 0;
   return RAFTQ_OK;
 }
 
@@ -1755,8 +1840,28 @@ int raftq_set_tick(raftq_set_t* s) {
     s->tick_since = 0;
   }
   const uint64_t n_blocks = s->gpad / 1024;
-  hipLaunchKernelGGL(tick_set_kernel, dim3((unsigned)((n_blocks + kTickSetRounds - 1) / kTickSetRounds), (unsigned)K), dim3(kBlock), 0, s->stream,
-                     (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+  // RAFTQ_TICK_SHAPE: wide2 (default: 16 groups per lane, two 1,024-group blocks per wave), wide1 / wide4, narrow (round 4's
+  // 4 groups per lane).  Same results, byte for byte (tests/test_parity_gpu.py runs the set Tick in every shape).
+  // (read at every call -- a getenv is nothing beside a launch -- so that a test or the bench can A/B the shapes in one process)
+  int shape_now = 2;
+  if (const char* e = std::getenv("RAFTQ_TICK_SHAPE"))
+    shape_now = std::strcmp(e, "narrow") == 0 ? 0 : std::strcmp(e, "wide1") == 0 ? 1 : std::strcmp(e, "wide4") == 0 ? 4 : 2;
+  auto wide_grid = [&](int r) { return dim3((unsigned)((n_blocks + (uint64_t)kWaves * r - 1) / ((uint64_t)kWaves * r)), (unsigned)K); };
+  switch (shape_now) {
+    case 0:
+      hipLaunchKernelGGL(tick_set_kernel, dim3((unsigned)((n_blocks + kTickSetRounds - 1) / kTickSetRounds), (unsigned)K), dim3(kBlock), 0, s->stream,
+                         (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+      break;
+    case 1:
+      hipLaunchKernelGGL((tick_set_wide_kernel<1>), wide_grid(1), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+      break;
+    case 4:
+      hipLaunchKernelGGL((tick_set_wide_kernel<4>), wide_grid(4), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+      break;
+    default:
+      hipLaunchKernelGGL((tick_set_wide_kernel<kTickWideBlocks>), wide_grid(kTickWideBlocks), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab,
+                         s->tick_since, n_blocks);
+  }
   SETCHK(s, hipGetLastError());
   ++s->tick_since;
   for (raftq_t* h : s->members) {

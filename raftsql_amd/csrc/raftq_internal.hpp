@@ -92,6 +92,13 @@ struct raftq {
   uint64_t* hup_bits = nullptr; // [gpad/64]
   uint64_t* beat_bits = nullptr; // [gpad/64]
   uint4* tick_partials = nullptr;  // [gpad/256]
+  // raftq_tick_collect_lists: the two lists left in place (page-locked; 4-byte group ids; MsgBeat optionally as a bitmap)
+  uint32_t* tl_h = nullptr;     // pinned: [tl_hup_cap] MsgHup ids | [tl_beat_cap] MsgBeat ids | beat bitmap (gpad / 64 words, 16-byte aligned)
+  uint32_t* tl_d = nullptr;     // ... as the device addresses it
+  uint64_t tl_bytes = 0, tl_hup_cap = 0, tl_beat_cap = 0, tl_map_off = 0;  // tl_map_off: byte offset of the bitmap
+  uint64_t tl_n_hup = 0, tl_n_beat = 0;
+  unsigned tl_flags = 0;
+  bool tl_valid = false;
   uint64_t* tick_offsets2 = nullptr;  // [gpad/256 + 1]: the MsgBeat offsets of raftq_tick_collect on handles of more than 16K waves
   uint32_t election_tick = 10, heartbeat_tick = 1;  // reference raft.go:154-155
   uint64_t tick_seed = 0x1000, tick_no = 0;

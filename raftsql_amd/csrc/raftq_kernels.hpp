@@ -1050,6 +1050,39 @@ __device__ __forceinline__ uint32_t tick_mod(uint32_t x, uint32_t d, uint32_t ma
   return r >= d ? r - d : r;
 }
 
+// v_writelane_b32: a wave-uniform value into lane L of a vector register (this toolchain has no clang builtin for it)
+template <int L>
+__device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t x /*wave-uniform*/) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(L));
+  return v;
+}
+
+// What a wave leaves for one 256-group chunk beside the elapsed / action bytes: its four MsgHup and four MsgBeat bitmap words
+// and its {n_hup, n_beat, 0, 0} counts -- 20 dwords, all wave-uniform (ballots and popcounts live in SGPRs).  They are moved
+// into lanes 0..19 of ONE vector register with v_writelane and leave in ONE masked store instruction.  Round 4 had lane 0
+// store them under `if (lane == 0)`: five flat stores in a branch, behind which the compiler can only wait with vmcnt(0) --
+// i.e. for the round's elapsed store to come back from memory -- before it touches the next round's registers.
+__device__ __forceinline__ void tick_chunk_out(const TickArgs& a, uint64_t chunk /* blk * kWaves + c */, uint32_t lane, const uint64_t (&hb)[4],
+                                               const uint64_t (&bb)[4], uint32_t n_hup, uint32_t n_beat) {
+  uint32_t v = 0;
+  v = write_lane<0>(v, (uint32_t)hb[0]);  v = write_lane<1>(v, (uint32_t)(hb[0] >> 32));
+  v = write_lane<2>(v, (uint32_t)hb[1]);  v = write_lane<3>(v, (uint32_t)(hb[1] >> 32));
+  v = write_lane<4>(v, (uint32_t)hb[2]);  v = write_lane<5>(v, (uint32_t)(hb[2] >> 32));
+  v = write_lane<6>(v, (uint32_t)hb[3]);  v = write_lane<7>(v, (uint32_t)(hb[3] >> 32));
+  v = write_lane<8>(v, (uint32_t)bb[0]);  v = write_lane<9>(v, (uint32_t)(bb[0] >> 32));
+  v = write_lane<10>(v, (uint32_t)bb[1]); v = write_lane<11>(v, (uint32_t)(bb[1] >> 32));
+  v = write_lane<12>(v, (uint32_t)bb[2]); v = write_lane<13>(v, (uint32_t)(bb[2] >> 32));
+  v = write_lane<14>(v, (uint32_t)bb[3]); v = write_lane<15>(v, (uint32_t)(bb[3] >> 32));
+  v = write_lane<16>(v, n_hup);
+  v = write_lane<17>(v, n_beat);
+  // (addresses as integers: selects, not branches)
+  const uint64_t at_hup = (uint64_t)(uintptr_t)a.hup_bits + chunk * 32 + 4ull * lane;
+  const uint64_t at_beat = (uint64_t)(uintptr_t)a.beat_bits + chunk * 32 + 4ull * lane - 32;
+  const uint64_t at_part = (uint64_t)(uintptr_t)a.partials + chunk * 16 + 4ull * lane - 64;
+  const uint64_t at = lane < 8 ? at_hup : (lane < 16 ? at_beat : at_part);
+  if (lane < 20) stg<false>(reinterpret_cast<uint32_t*>((uintptr_t)at), v);
+}
+
 // R consecutive 1,024-group blocks per workgroup (the set dispatch: every load of the R rounds issued before the first
 // compare, a quarter of the workgroups); block = what one workgroup of the R = 1 kernel owns, so bitmaps, action bytes
 // and per-wave counts have one layout whatever R is.  n_blocks: 1,024-group blocks of the handle (gpad / 1024).
@@ -1100,22 +1133,90 @@ __device__ __forceinline__ void tick_tile(const TickArgs& a, uint64_t n_blocks) 
     out.x = e[0]; out.y = e[1]; out.z = e[2]; out.w = e[3];
     stg<NT>(reinterpret_cast<u32x4*>(a.elapsed + g), out);
     stg<NT>(reinterpret_cast<uint32_t*>(a.action + g), acts);
-    if (lane == 0) {
-      const uint64_t w0 = (blk * kWaves + wave) * 4;  // 4 words per wave (256 groups)
-      u64x2 lo, hi;
-      lo.x = hb[0]; lo.y = hb[1]; hi.x = hb[2]; hi.y = hb[3];
-      *reinterpret_cast<u64x2*>(a.hup_bits + w0) = lo;
-      *reinterpret_cast<u64x2*>(a.hup_bits + w0 + 2) = hi;
-      lo.x = bb[0]; lo.y = bb[1]; hi.x = bb[2]; hi.y = bb[3];
-      *reinterpret_cast<u64x2*>(a.beat_bits + w0) = lo;
-      *reinterpret_cast<u64x2*>(a.beat_bits + w0 + 2) = hi;
-      uint4 pr;
-      pr.x = n_hup; pr.y = n_beat; pr.z = 0; pr.w = 0;
-      a.partials[blk * kWaves + wave] = pr;
-    }
+    tick_chunk_out(a, blk * kWaves + wave, lane, hb, bb, n_hup, n_beat);
   }
 }
 static __global__ __launch_bounds__(kBlock) void tick_kernel(TickArgs a) { tick_tile<1>(a, gridDim.x); }
+
+// The set dispatch at the sweep's access shape: a WAVE owns whole 1,024-group blocks -- the four
+// 256-group chunks tick_tile gives to four waves -- so that every global access of a lane is 16 bytes and every wave
+// instruction 1 KB: ONE 16-byte role load and ONE 16-byte action store per lane for the block's 1,024 groups (16 groups per
+// lane) beside the four 16-byte elapsed loads / stores, where tick_tile issues four 4-byte ones (256 B per wave instruction).
+// A lane's role quad covers groups 16l .. 16l+15; the chunk it ticks in round c is groups c*256 + 4l .. +3: the block's
+// 1 KB of role bytes goes through a wave-private LDS kilobyte (one ds_write_b128, four conflict-free ds_read_b32) and the
+// action bytes come back the same way.  Chunk c of block blk leaves exactly what wave c of tick_tile's workgroup leaves:
+// bitmaps, per-wave counts and action bytes keep ONE layout (tick_lists_kernel, compact_hups_kernel and the oracle
+// comparison read either).  R blocks per wave, every load of the R blocks issued before the first compare.
+template <int R, bool NT>
+__device__ __forceinline__ void tick_tile_wide(const TickArgs& a, uint64_t n_blocks) {
+  __shared__ uint32_t xpose[kWaves][256];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* const xp = xpose[wave];
+  u32x4 rq[R];
+  u32x4 el[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // (a block past the end loads the last block again and is never processed: unconditional loads keep the compiler's count of
+    // what is in flight exact -- behind a branch it has to assume the fewest and waits for nearly everything at the first use)
+    const uint64_t blk_r = ((uint64_t)blockIdx.x * kWaves + wave) * R + r;
+    const uint64_t blk = blk_r < n_blocks ? blk_r : n_blocks - 1;
+    const uint64_t g0 = blk * 1024;
+    rq[r] = ldg<NT>(reinterpret_cast<const u32x4*>(a.role + g0 + 16 * lane));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) el[r][c] = ldg<NT>(reinterpret_cast<const u32x4*>(a.elapsed + g0 + c * 256 + 4 * lane));
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t blk = ((uint64_t)blockIdx.x * kWaves + wave) * R + r;
+    if (blk >= n_blocks) break;  // wave-uniform; blocks ascend with r
+    const uint64_t g0 = blk * 1024;
+    *reinterpret_cast<u32x4*>(xp + 4 * lane) = rq[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t roles[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) roles[c] = xp[c * 64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t g = g0 + c * 256 + 4 * lane;
+      uint32_t e[4] = {el[r][c].x, el[r][c].y, el[r][c].z, el[r][c].w};
+      uint32_t acts = 0;
+      uint32_t n_hup = 0, n_beat = 0;  // wave-uniform
+      uint64_t hb[4], bb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t role = (roles[c] >> (8 * k)) & 0xffu;
+        const bool valid = g + k < a.n_groups;
+        uint32_t v = e[k] + 1;
+        const bool beat = role == 2u && v >= a.heartbeat_tick;
+        const int64_t d = (int64_t)v - (int64_t)a.election_tick;
+        bool hup = role != 2u && d >= 0;
+        if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(a.seed, a.tick_no, g + k), a.election_tick, a.et_magic);
+        const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
+        e[k] = !valid ? e[k] : (act ? 0u : v);
+        acts |= act << (8 * k);
+        hb[k] = __ballot(act == 1u);
+        bb[k] = __ballot(act == 2u);
+        n_hup += __popcll(hb[k]);
+        n_beat += __popcll(bb[k]);
+      }
+      u32x4 out;
+      out.x = e[0]; out.y = e[1]; out.z = e[2]; out.w = e[3];
+      stg<NT>(reinterpret_cast<u32x4*>(a.elapsed + g), out);
+      xp[c * 64 + lane] = acts;
+      tick_chunk_out(a, blk * kWaves + c, lane, hb, bb, n_hup, n_beat);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32x4 aq = *reinterpret_cast<const u32x4*>(xp + 4 * lane);
+    stg<NT>(reinterpret_cast<u32x4*>(a.action + g0 + 16 * lane), aq);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 
 static __global__ __launch_bounds__(kBlock) void compact_hups_kernel(const uint64_t* hup_bits, const uint64_t* offsets,
                                                               uint64_t* out, uint64_t cap) {
@@ -1227,6 +1328,111 @@ static __global__ __launch_bounds__(kBlock) void tick_lists_kernel(const uint64_
   }
 }
 
+// The same two lists as they are meant to be read: LEFT IN PLACE in page-locked memory, 4-byte group ids (a handle holds at
+// most 2^30 groups), and -- BEAT_BITMAP -- the MsgBeat groups as a bitmap in GROUP order (bit g % 64 of word g / 64) instead
+// of a list: with HeartbeatTick 1 (raft.go:155) every leader beats on every tick, so the beat "list" is the leader set --
+// 128 KB as a bitmap against 1.4 MB of ids per 1M groups a third of which lead.  A workgroup compacts its 1,024 groups' ids
+// in LDS and writes them out as runs of consecutive words (full lines over the link, not a lane's four words at a time).
+template <bool BEAT_BITMAP>
+static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint64_t* __restrict__ hup_bits, const uint64_t* __restrict__ beat_bits,
+                                                                      const uint4* __restrict__ partials, uint32_t* hup_out, uint64_t hup_cap,
+                                                                      uint32_t* beat_out, uint64_t beat_cap, uint64_t* beat_map,
+                                                                      uint64_t* totals /*[2]*/, const uint64_t* __restrict__ wave_off_hup,
+                                                                      const uint64_t* __restrict__ wave_off_beat) {
+  __shared__ uint64_t red[2][kWaves];
+  __shared__ uint32_t mine[2][kWaves];
+  __shared__ uint32_t ids[2][kBlock * 4];
+  __shared__ uint64_t map_words[kWaves * 4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t first_wave = (uint64_t)blockIdx.x * kWaves;
+  uint64_t acc_h = 0, acc_b = 0;
+  if (wave_off_hup == nullptr) {
+    uint32_t h0 = 0, h1 = 0, b0 = 0, b1 = 0;
+    uint64_t i = tid;
+    for (; i + kBlock < first_wave; i += 2 * kBlock) {
+      const uint4 p0 = partials[i], p1 = partials[i + kBlock];
+      h0 += p0.x; b0 += p0.y;
+      h1 += p1.x; b1 += p1.y;
+    }
+    if (i < first_wave) {
+      const uint4 p0 = partials[i];
+      h0 += p0.x; b0 += p0.y;
+    }
+    acc_h = (uint64_t)h0 + h1;
+    acc_b = (uint64_t)b0 + b1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      acc_h += __shfl_xor(acc_h, o, 64);
+      acc_b += __shfl_xor(acc_b, o, 64);
+    }
+  } else if (lane == 0 && wave == 0) {
+    acc_h = wave_off_hup[first_wave];
+    acc_b = wave_off_beat[first_wave];
+  }
+  if (lane == 0) {
+    red[0][wave] = acc_h;
+    red[1][wave] = acc_b;
+  }
+  if (tid < kWaves) {
+    const uint4 p = partials[first_wave + tid];
+    mine[0][tid] = p.x;
+    mine[1][tid] = p.y;
+  }
+  __syncthreads();
+  uint64_t pos_h = 0, pos_b = 0;  // where this workgroup's ids start in the two lists
+  uint32_t loc_h = 0, loc_b = 0, tot_h = 0, tot_b = 0;  // this wave's first id inside the workgroup's run; the run's length
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) {
+    pos_h += red[0][k];
+    pos_b += red[1][k];
+    loc_h += (uint32_t)k < wave ? mine[0][k] : 0u;
+    loc_b += (uint32_t)k < wave ? mine[1][k] : 0u;
+    tot_h += mine[0][k];
+    tot_b += mine[1][k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    totals[0] = pos_h + tot_h;
+    totals[1] = pos_b + tot_b;
+  }
+  const uint64_t wv = first_wave + wave;
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint64_t hb[4], bb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hb[k] = hup_bits[wv * 4 + k];
+    bb[k] = beat_bits[wv * 4 + k];
+  }
+  uint32_t rh = loc_h + __popcll(hb[0] & below) + __popcll(hb[1] & below) + __popcll(hb[2] & below) + __popcll(hb[3] & below);
+  uint32_t rb = loc_b + __popcll(bb[0] & below) + __popcll(bb[1] & below) + __popcll(bb[2] & below) + __popcll(bb[3] & below);
+  uint32_t nib = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t g = (uint32_t)(wv * 256 + 4ull * lane + k);
+    if ((hb[k] >> lane) & 1) ids[0][rh++] = g;
+    if (!BEAT_BITMAP) {
+      if ((bb[k] >> lane) & 1) ids[1][rb++] = g;
+    } else {
+      nib |= (uint32_t)((bb[k] >> lane) & 1) << k;
+    }
+  }
+  if (BEAT_BITMAP) {
+    // lane l holds the four bits of groups 4l .. 4l+3 of the wave's 256: group-order word j is lanes 16j .. 16j+15
+    uint64_t v = (uint64_t)nib << (4 * (lane & 15));
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v |= __shfl_xor(v, o, 64);
+    if ((lane & 15) == 0) map_words[wave * 4 + (lane >> 4)] = v;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < tot_h; i += kBlock)
+    if (pos_h + i < hup_cap) hup_out[pos_h + i] = ids[0][i];
+  if (!BEAT_BITMAP) {
+    for (uint32_t i = tid; i < tot_b; i += kBlock)
+      if (pos_b + i < beat_cap) beat_out[pos_b + i] = ids[1][i];
+  } else if (tid < kWaves * 4) {
+    beat_map[(uint64_t)blockIdx.x * (kWaves * 4) + tid] = map_words[tid];
+  }
+}
+
 // A Tick of every member of a sweep set in ONE dispatch (blockIdx.y = member): the members' TickArgs come from a device
 // table; tick_no advances by `ticks_since` from what the table holds (the host rebuilds the table when a member was
 // ticked on its own in between).  1M groups per launch is launch-bound (10 MB: 4.4 us, 0.29 of the HBM peak); eight
@@ -1236,6 +1442,14 @@ static __global__ __launch_bounds__(kBlock) void tick_set_kernel(const TickArgs*
   TickArgs a = tab[blockIdx.y];
   a.tick_no += ticks_since;
   tick_tile<kTickSetRounds, true>(a, n_blocks);
+}
+// ... at 16 groups per lane (tick_tile_wide): a workgroup's four waves own kTickWideBlocks 1,024-group blocks each
+constexpr int kTickWideBlocks = 2;
+template <int R>
+static __global__ __launch_bounds__(kBlock) void tick_set_wide_kernel(const TickArgs* __restrict__ tab, uint64_t ticks_since, uint64_t n_blocks) {
+  TickArgs a = tab[blockIdx.y];
+  a.tick_no += ticks_since;
+  tick_tile_wide<R, true>(a, n_blocks);
 }
 
 // becomeCandidate for a list of (distinct) groups: role = candidate, elapsed = 0,

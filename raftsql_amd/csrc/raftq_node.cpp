@@ -441,13 +441,13 @@ struct raftq_node {
   std::mutex turn_mu;  // one advance() at a time
   raftq_node_stats_t stats{};
   // scratch of advance()
-  std::vector<uint64_t> tick_list, beat_list;  // MsgHup / MsgBeat groups of the last tick (grown on demand)
+  std::vector<uint64_t> tick_list;  // MsgHup groups of a tick whose in-place list was too short (grown on demand); its size is the cap asked for
   std::vector<uint32_t> work, batch, deferred;  // positions (see kLocal)
   std::vector<raftq_wire_msg_t> local;          // the turn's locally raised messages (MsgHup)
   std::vector<Entry> ent_tmp;
   // per-group marks of one Step round: blocked (a log-changing message of the group is in this batch) and dirty
   // (its log grew); a mark is set when it equals the round's epoch -- no hashing, no clearing
-  std::vector<uint32_t> blocked_mark, dirty_mark;
+  std::vector<uint32_t> blocked_mark, dirty_mark, defer_mark;  // defer_mark: a message of the group went to the next round
   std::vector<uint64_t> dirty_list;
   uint32_t epoch = 0;
   std::vector<raftq_log_delta_t> deltas;
@@ -920,6 +920,36 @@ int poll_queue(raftq_node_t* n, PeerQueue& q, bool big_endian, void* buf, uint64
   return RAFTQ_OK;
 }
 
+// The second half of the WAL encode, in two steps so that a turn's WAL bytes are PUBLISHED BEFORE its outbound frames
+// (wal.Save before transport.Send, raft.go:228-230; the poll calls may run on a transport thread during advance(): a
+// thread that takes turn T's MsgAppResp off raftq_node_poll must find T's HardState / entries in raftq_node_wal_poll).
+// wal_end_device: the device wait, with mu released; wal_publish: the bytes onto wal_out, with mu held.
+int wal_end_device(raftq_node_t* n) {
+  if (n->wal_inflight == 0 || !n->wal_begun) return RAFTQ_OK;
+  const int rc = raftq_wal_encode_end(n->h, &n->wal_cnt);
+  n->wal_begun = false;
+  return rc;
+}
+void wal_publish(raftq_node_t* n) {
+  if (n->wal_inflight == 0) return;
+  n->wal_out.bytes.append((const char*)n->wal_enc.p, (size_t)n->wal_cnt.bytes);
+  n->wal_crc = n->wal_cnt.last_crc;
+  n->wal_head_written = true;
+  n->stats.wal_records += n->wal_inflight;
+  n->wal_inflight = 0;
+}
+// a turn with nothing to send: the WAL encode's wait is its own
+int flush_wal_end(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
+  if (n->wal_inflight == 0) return RAFTQ_OK;
+  if (n->wal_begun) {
+    lk.unlock();
+    if (const int rc = wal_end_device(n)) return rc;
+    lk.lock();
+  }
+  wal_publish(n);
+  return RAFTQ_OK;
+}
+
 // rc.transport.Send(rd.Messages) (raft.go:230) for the whole turn: one batched marshal on the GPU, then
 // every peer's slice of the stream goes onto its queue.  Lock convention as flush_deltas.
 int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
@@ -961,7 +991,15 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap, n->enc_off.data(), &cnt);
   }
   if (rc != RAFTQ_OK) return rc;
+  // the marshal's wait covered the WAL encode enqueued in front of it: take its verdict now, still unlocked, and publish the
+  // WAL bytes first, the frames second, under ONE hold of mu (the frames used to be visible a device call earlier)
+  {
+    DevCall dev(n, raftq_node::kPhDevEncode);
+    rc = wal_end_device(n);
+  }
+  if (rc != RAFTQ_OK) return rc;
   lk.lock();
+  wal_publish(n);
   n->out_ents.clear();
   n->out_pool.clear();
   const uint64_t* off = n->enc_off.data();
@@ -1049,23 +1087,6 @@ int flush_wal_begin(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   n->wal_inflight = n_recs;
   return RAFTQ_OK;
 }
-int flush_wal_end(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
-  if (n->wal_inflight == 0) return RAFTQ_OK;
-  if (n->wal_begun) {
-    lk.unlock();
-    const int rc = raftq_wal_encode_end(n->h, &n->wal_cnt);
-    n->wal_begun = false;
-    if (rc != RAFTQ_OK) return rc;
-    lk.lock();
-  }
-  n->wal_out.bytes.append((const char*)n->wal_enc.p, (size_t)n->wal_cnt.bytes);
-  n->wal_crc = n->wal_cnt.last_crc;
-  n->wal_head_written = true;
-  n->stats.wal_records += n->wal_inflight;
-  n->wal_inflight = 0;
-  return RAFTQ_OK;
-}
-
 // one entry into a group's log under the WAL's rule (wal.ReadAll: a later entry with an index already
 // seen replaces it and everything after it)
 bool log_put(raftq_node_t* n, Group& g, uint64_t index, uint64_t term, const char* data, uint32_t len) {
@@ -1111,6 +1132,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
     n->out_lane.resize(n_peers);
     n->tick_list.resize(std::min<uint64_t>(n_groups, 4096));
     n->blocked_mark.assign(n_groups, 0);
+    n->defer_mark.assign(n_groups, 0);
     n->dirty_mark.assign(n_groups, 0);
   } catch (...) {
     raftq_destroy(n->h);
@@ -1397,23 +1419,31 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     // the device compacts the two short lists (ascending group ids); no G-byte read-back and no loop over every
     // group under the lock (O(G) host work per 100 ms tick at 1M groups)
     // one call: the Tick and both of its lists (two launches, one wait).  A list that does not fit is fetched again alone.
+    // (raftq_tick_collect_lists: 4-byte ids read where the device left them, the MsgBeat groups as a bitmap -- with
+    // HeartbeatTick 1 the beat list is the set of groups this node leads, every tick)
     uint64_t n_hup = 0, n_beat = 0;
-    if (n->beat_list.size() < n->tick_list.size()) n->beat_list.resize(n->tick_list.size());
-    int rc = raftq_tick_collect(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup, n->beat_list.data(), n->beat_list.size(), &n_beat);
-    if (rc == RAFTQ_OK && n_hup > n->tick_list.size()) {
+    int rc = raftq_tick_collect_lists(n->h, RAFTQ_TICK_BEAT_BITMAP, n->tick_list.size(), 0, &n_hup, &n_beat);
+    const uint32_t* hups = nullptr;
+    const uint64_t* beat_map = nullptr;
+    uint64_t n_listed = 0, map_words = 0;
+    if (rc == RAFTQ_OK) rc = raftq_last_tick_lists(n->h, &hups, &n_listed, nullptr, nullptr, &beat_map, &map_words);
+    if (rc == RAFTQ_OK && n_hup > n_listed) {  // more timers fired than the list was sized for: fetch them again, alone
       n->tick_list.resize(n_hup);
       rc = raftq_collect_hups(n->h, n->tick_list.data(), n->tick_list.size(), &n_hup);
-    }
-    if (rc == RAFTQ_OK && n_beat > n->beat_list.size()) {
-      n->beat_list.resize(n_beat);
-      rc = raftq_collect_beats(n->h, n->beat_list.data(), n->beat_list.size(), &n_beat);
+      if (rc == RAFTQ_OK)
+        for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, n->tick_list[i], RAFTQ_MSG_HUP));
+    } else if (rc == RAFTQ_OK) {
+      for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, hups[i], RAFTQ_MSG_HUP));
     }
     if (rc != RAFTQ_OK) return poison(n, rc, "tick");
-    for (uint64_t i = 0; i < n_hup; ++i) local.push_back(local_msg(n, n->tick_list[i], RAFTQ_MSG_HUP));
     lk.lock();
-    for (uint64_t i = 0; i < n_beat; ++i) {
-      const uint64_t gi = n->beat_list[i];
-      if (n->groups[gi].role == RAFTQ_ROLE_LEADER) bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat: host only
+    if (n_beat) {
+      for (uint64_t w = 0; w < map_words; ++w) {
+        for (uint64_t bits = beat_map[w]; bits; bits &= bits - 1) {
+          const uint64_t gi = w * 64 + (uint64_t)__builtin_ctzll(bits);
+          if (n->groups[gi].role == RAFTQ_ROLE_LEADER) bcast_heartbeat(n, gi, n->groups[gi]);  // stepLeader MsgBeat: host only
+        }
+      }
     }
   }
   if (local.size() >= kLocal) {
@@ -1479,6 +1509,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     if (++n->epoch == 0) {
       std::fill(n->blocked_mark.begin(), n->blocked_mark.end(), 0u);
       std::fill(n->dirty_mark.begin(), n->dirty_mark.end(), 0u);
+      std::fill(n->defer_mark.begin(), n->defer_mark.end(), 0u);
       n->epoch = 1;
     }
     return n->epoch;
@@ -1615,6 +1646,13 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
           n->stats.msgs_stepped--;
           ++k;
         }
+        if (n->defer_mark[im.group] == ep) {
+          // something of this group that arrived earlier waits for the next round (Step deferred it behind a hold or a
+          // barrier): the proposal waits behind it -- a group's messages are worked off in arrival order whichever way the
+          // round was stepped ([MsgProp, MsgAppResp, MsgProp] used to run the second proposal first)
+          deferred.push_back(batch[bi]);
+          continue;
+        }
         Group& g = n->groups[im.group];
         if (handle_proposal(n, im.group, g, prop_entries(im), im.n_ents) && n->dirty_mark[im.group] != ep) {
           n->dirty_mark[im.group] = ep;
@@ -1622,6 +1660,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
         }
       } else if (outs[k].type == RAFTQ_OUT_DEFERRED) {  // behind a MsgApp this log has to work out first: next round
         deferred.push_back(batch[bi]);
+        n->defer_mark[im.group] = ep;
         n->stats.msgs_stepped--;
         ++k;
       } else {

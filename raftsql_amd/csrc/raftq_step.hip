@@ -39,9 +39,16 @@ int ensure_node_state(raftq_t* h) {
   };
   if (int rc = alloc((void**)&h->step_stall, 256)) return rc;
   if (const char* w = std::getenv("RAFTQ_STEP_WALK")) h->step_walk_mode = std::strcmp(w, "sort") == 0 ? 0 : 1;
-  HIPCHK(h, hipMalloc((void**)&h->node_rec, h->ld * sizeof(NodeRec)));  // last: marks the state complete
-  hipLaunchKernelGGL(node_init_kernel, dim3((unsigned)((h->ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (NodeRec*)h->node_rec, h->ld);
-  HIPCHK(h, hipGetLastError());
+  // h->node_rec marks the state complete: it is assigned only once the records have been allocated AND their initialisation has
+  // been launched (a failed launch used to leave the pointer set, and the next call stepped uninitialised records)
+  void* rec = nullptr;
+  HIPCHK(h, hipMalloc(&rec, h->ld * sizeof(NodeRec)));
+  hipLaunchKernelGGL(node_init_kernel, dim3((unsigned)((h->ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (NodeRec*)rec, h->ld);
+  if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+    (void)hipFree(rec);
+    HIPCHK(h, e);
+  }
+  h->node_rec = (decltype(h->node_rec))rec;
   h->have_terms = true;  // Step maintains the current-term gate itself (closed = 0 until a group leads)
   return RAFTQ_OK;
 }

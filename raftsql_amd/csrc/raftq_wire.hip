@@ -268,7 +268,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   const bool mapped = streaming_on() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_msgs = dev_view(msgs)) != nullptr &&
                       (n_ents == 0 || (v_ents = dev_view(ents)) != nullptr) && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
                       (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
-  if (mapped && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool)) {
+  if (mapped && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool) && aligned16(v_out) && aligned16(v_off)) {
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
     const uint32_t n_tiles = blocks_for(n);
     const unsigned workers = fused_grid(n_tiles);
@@ -423,7 +423,8 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
   void *v_stream = nullptr, *v_off = nullptr, *v_msgs = nullptr, *v_ents = nullptr;
   const bool mapped = streaming_on() && (nbytes == 0 || (v_stream = dev_view(stream)) != nullptr) && (v_off = dev_view(frame_off)) != nullptr &&
                       (v_msgs = dev_view(msgs)) != nullptr && (!ents || (v_ents = dev_view(ents)) != nullptr);
-  if (mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off)) {
+  // (every array, inputs and outputs: the workers store whole 16-byte quads into msgs / ents -- raftq_wire.h "odd alignment")
+  if (mapped && nbytes < (1ull << (kLbValueBits - 1)) && aligned16(v_stream) && aligned16(v_off) && aligned16(v_msgs) && aligned16(v_ents)) {
     // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
     // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
     if (int rc = decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents_cap, nullptr, FrameFilter{0, 0, 0, 0, 0, nullptr})) return rc;
@@ -546,7 +547,7 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
   const bool mapped = streaming_on() && cap != 0 && cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr &&
                       (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) && (v_out = dev_view(out)) != nullptr &&
                       (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
-  if (mapped && aligned16(v_recs) && aligned16(v_pool)) {
+  if (mapped && aligned16(v_recs) && aligned16(v_pool) && aligned16(v_out) && aligned16(v_off)) {
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
     if (int rc = wal_pending_complete(h)) return rc;  // (a raftq_wal_encode_begin nobody ended: its results are kept for its _end)
     if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 0)) return rc;
@@ -624,9 +625,9 @@ int raftq_wal_encode_begin(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, 
   void *v_recs = nullptr, *v_pool = nullptr, *v_out = nullptr, *v_off = nullptr;
   const bool mapped = cap <= ((uint64_t)1 << 31) && (v_recs = dev_view(recs)) != nullptr && (pool_bytes == 0 || (v_pool = dev_view(pool)) != nullptr) &&
                       (v_out = dev_view(out)) != nullptr && (!frame_off || (v_off = dev_view(frame_off)) != nullptr);
-  if (!(mapped && aligned16(v_recs) && aligned16(v_pool)))
+  if (!(mapped && aligned16(v_recs) && aligned16(v_pool) && aligned16(v_out) && aligned16(v_off)))
     return fail(h, RAFTQ_EINVAL, "raftq_wal_encode_begin: the records, the pool and the output must be page-locked (raftq_host_alloc, hipHostMalloc, "
-                                 "hipHostRegister), records and pool 16-byte aligned -- raftq_wal_encode otherwise");
+                                 "hipHostRegister) and 16-byte aligned -- raftq_wal_encode otherwise");
   if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 8)) return rc;
   h->wal_pending = true;
   h->wal_pending_done = false;
@@ -660,7 +661,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
   {
     void *f_bytes = nullptr, *f_off = nullptr, *f_recs = nullptr;
     if (streaming_on() && nbytes < (1ull << (kLbValueBits - 1)) && (nbytes == 0 || (f_bytes = dev_view(bytes)) != nullptr) &&
-        (f_off = dev_view(frame_off)) != nullptr && (f_recs = dev_view(recs)) != nullptr && aligned16(f_bytes) && aligned16(f_off)) {
+        (f_off = dev_view(frame_off)) != nullptr && (f_recs = dev_view(recs)) != nullptr && aligned16(f_bytes) && aligned16(f_off) && aligned16(f_recs)) {
       // page-locked caller buffers: the streaming form (readers | workers in one launch)
       const uint32_t n_tiles = blocks_for(n);
       const unsigned workers = fused_grid(n_tiles);

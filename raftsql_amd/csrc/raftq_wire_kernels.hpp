@@ -716,10 +716,20 @@ struct InFeed {
   uint32_t chunks, readers;  // workgroups [0, readers) of the launch are readers
 };
 
-__device__ __forceinline__ void sc1_store16(uint8_t* dst, u32x4 v) {  // agent-scope write-through (two 8-byte atomic stores)
+// Agent-scope write-through of one 16-byte quad as ONE store instruction (`global_store_dwordx4 ... sc1`).  Round 4 split the
+// quad into two 8-byte agent-scope atomic stores -- the widest store the atomic builtins express -- and every 8 bytes became a
+// 32-byte write request: the scratch hop's HBM traffic was x2.5-x3 of its bytes (profiles/pmc_traffic_legs.json, r04).  Four
+// lanes now fill a 64-byte request.  The compiler does not count an asm store in its vmcnt bookkeeping: whoever publishes the
+// bytes waits with an explicit s_waitcnt vmcnt(0) (reader_role does, before the chunk's flag).  RAFTQ_WIRE_SC1_SPLIT builds
+// the old form for an A/B.
+__device__ __forceinline__ void sc1_store16(uint8_t* dst, u32x4 v) {
+#if defined(RAFTQ_WIRE_SC1_SPLIT)
   unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+#endif
 }
 
 __device__ inline void reader_role(const InFeed& in, uint32_t epoch) {

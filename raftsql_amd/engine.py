@@ -436,6 +436,27 @@ class QuorumEngine:
                                                C.byref(nb)))
         return hups[: min(hc, int(nh.value))], int(nh.value), beats[: min(bc, int(nb.value))], int(nb.value)
 
+    def tick_collect_lists(self, hup_cap: Optional[int] = None, beat_cap: Optional[int] = None, beat_bitmap: bool = False):
+        """raftq_tick_collect_lists + raftq_last_tick_lists: one Tick and its lists LEFT IN PLACE (page-locked, 4-byte ids; the
+        MsgBeat groups as a group-order bitmap when asked) -> (hups view u32, n_hup, beats view u32 | bitmap view u64, n_beat).
+        The views are the library's memory: valid until the next call of this on the handle."""
+        hc = self.n_groups if hup_cap is None else int(hup_cap)
+        bc = self.n_groups if beat_cap is None else int(beat_cap)
+        nh, nb = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._lib.raftq_tick_collect_lists(self._h, _lib.TICK_BEAT_BITMAP if beat_bitmap else 0, hc, bc, C.byref(nh), C.byref(nb)))
+        ph, pb, pm = C.c_void_p(None), C.c_void_p(None), C.c_void_p(None)
+        lh, lb, lm = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._lib.raftq_last_tick_lists(self._h, C.byref(ph), C.byref(lh), C.byref(pb), C.byref(lb), C.byref(pm), C.byref(lm)))
+
+        def view(p, n, dt):
+            if not n:
+                return np.empty(0, dtype=dt)
+            return np.frombuffer((C.c_char * (int(n) * np.dtype(dt).itemsize)).from_address(p.value), dtype=dt)
+
+        hups = view(ph, lh.value, np.uint32)
+        second = view(pm, lm.value, np.uint64) if beat_bitmap else view(pb, lb.value, np.uint32)
+        return hups, int(nh.value), second, int(nb.value)
+
     def campaign(self, groups, self_peer: int = 0) -> None:
         g = np.ascontiguousarray(groups, dtype=np.uint64)
         self._chk(self._lib.raftq_campaign(self._h, _ptr(g) if len(g) else None, len(g), self_peer))

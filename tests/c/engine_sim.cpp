@@ -36,6 +36,9 @@ struct raftq {
   std::vector<uint32_t> elapsed, vote, lead;
   std::vector<uint64_t> term, last_index, last_term, committed, first_idx, match;
   bool have_terms = false, ticked = false, msg_flags = false;
+  std::vector<uint32_t> tl_hups, tl_beats;  // raftq_tick_collect_lists: left in place
+  std::vector<uint64_t> tl_map;
+  bool tl_bitmap = false, tl_valid = false;
   uint32_t election_tick = 10, heartbeat_tick = 1;
   uint64_t seed = 0x1000, tick_no = 0;
   std::vector<raftq_msg_t> stage;
@@ -324,6 +327,43 @@ int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n
   if (int rc = raftq_tick(h, nullptr)) return rc;
   if (int rc = tick_list(h, "raftq_tick_collect", 1, hups, hup_cap, n_hup)) return rc;
   return tick_list(h, "raftq_tick_collect", 2, beats, beat_cap, n_beat);
+}
+
+int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint64_t beat_cap, uint64_t* n_hup, uint64_t* n_beat) {
+  if (!h || !n_hup || !n_beat) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect_lists: null argument");
+  if (flags & ~RAFTQ_TICK_BEAT_BITMAP) return fail(h, RAFTQ_EINVAL, "raftq_tick_collect_lists: unknown flag");
+  if (int rc = raftq_tick(h, nullptr)) return rc;
+  const bool bitmap = flags & RAFTQ_TICK_BEAT_BITMAP;
+  h->tl_hups.clear();
+  h->tl_beats.clear();
+  h->tl_map.assign(bitmap ? (h->G + 63) / 64 : 0, 0);
+  uint64_t nh = 0, nb = 0;
+  for (uint64_t g = 0; g < h->G; ++g) {
+    if (h->action[g] == 1) {
+      if (nh++ < hup_cap) h->tl_hups.push_back((uint32_t)g);
+    } else if (h->action[g] == 2) {
+      if (bitmap) h->tl_map[g / 64] |= 1ull << (g % 64);
+      else if (nb < beat_cap) h->tl_beats.push_back((uint32_t)g);
+      ++nb;
+    }
+  }
+  *n_hup = nh;
+  *n_beat = nb;
+  h->tl_bitmap = bitmap;
+  h->tl_valid = true;
+  return RAFTQ_OK;
+}
+int raftq_last_tick_lists(raftq_t* h, const uint32_t** hups, uint64_t* n_hups, const uint32_t** beats, uint64_t* n_beats,
+                          const uint64_t** beat_bitmap, uint64_t* bitmap_words) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!h->tl_valid) return fail(h, RAFTQ_ESTATE, "raftq_last_tick_lists: no raftq_tick_collect_lists before it");
+  if (hups) *hups = h->tl_hups.data();
+  if (n_hups) *n_hups = h->tl_hups.size();
+  if (beats) *beats = h->tl_bitmap ? nullptr : h->tl_beats.data();
+  if (n_beats) *n_beats = h->tl_bitmap ? 0 : h->tl_beats.size();
+  if (beat_bitmap) *beat_bitmap = h->tl_bitmap ? h->tl_map.data() : nullptr;
+  if (bitmap_words) *bitmap_words = h->tl_bitmap ? h->tl_map.size() : 0;
+  return RAFTQ_OK;
 }
 
 int raftq_step_stage(raftq_t* h, uint64_t n, raftq_msg_t** msgs) {

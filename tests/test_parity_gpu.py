@@ -637,13 +637,62 @@ def test_tick_parity(gpu_engine_cls, oracle, G):
                 act, got_el, _ = e.read_tick()
                 assert np.array_equal(act, ref_act) and np.array_equal(got_el, ref_el)
 
+            # the in-place form (raftq_tick_collect_lists + raftq_last_tick_lists): 4-byte ids read where the device left them,
+            # the MsgBeat groups as a list or as a group-order bitmap; whole lists, then caps below the counts
+            for t in range(40, 58):
+                bitmap = t % 2 == 0
+                caps = (None, None) if t % 3 else (1, 2)
+                hups, nh, second, nb = e.tick_collect_lists(*caps, beat_bitmap=bitmap)
+                ref_el, ref_act, rh, rb = oracle.tick(role, ref_el, et, hb, seed, t)
+                want_h, want_b = np.nonzero(ref_act == 1)[0].astype(np.uint32), np.nonzero(ref_act == 2)[0].astype(np.uint32)
+                assert (nh, nb) == (rh, rb) and hups.dtype == np.uint32
+                assert len(hups) == (rh if caps[0] is None else min(1, rh)) and np.array_equal(hups, want_h[: len(hups)])
+                if bitmap:
+                    assert second.dtype == np.uint64 and len(second) == (G + 63) // 64
+                    bits = np.unpackbits(second.view(np.uint8), bitorder="little")[:G]
+                    assert np.array_equal(np.nonzero(bits)[0].astype(np.uint32), want_b)
+                    assert not np.unpackbits(second.view(np.uint8), bitorder="little")[G:].any()
+                else:
+                    assert len(second) == (rb if caps[1] is None else min(2, rb)) and np.array_equal(second, want_b[: len(second)])
+                act, got_el, _ = e.read_tick()
+                assert np.array_equal(act, ref_act) and np.array_equal(got_el, ref_el)
 
-def test_set_tick_is_every_members_tick(gpu_engine_cls, oracle):
+
+def test_tick_collect_lists_at_a_million_groups(gpu_engine_cls, oracle):
+    """The in-place lists at the bench's size (1M groups, a third of them leaders, timers spread so that tens of thousands
+    fire per tick): both forms against the oracle's action bytes, over handles beyond 16K waves too (the scanned offsets)."""
+    for G in ((1 << 20) + 77, (1 << 22) + 4100 + 3):
+        rng = np.random.default_rng(G)
+        role = (np.arange(G) % 3).astype(np.uint8)
+        el = rng.integers(0, 21, G).astype(np.uint32)
+        with gpu_engine_cls(G, 5) as e:
+            e.set_timers(10, 1, 0xBEEF)
+            e.load_roles(role, el)
+            ref_el = el.copy()
+            for t in range(4):
+                bitmap = t % 2 == 1
+                hups, nh, second, nb = e.tick_collect_lists(beat_bitmap=bitmap)
+                ref_el, ref_act, rh, rb = oracle.tick(role, ref_el, 10, 1, 0xBEEF, t)
+                assert (nh, nb) == (rh, rb) and rh > 1000 and rb > G // 4
+                assert np.array_equal(hups, np.nonzero(ref_act == 1)[0].astype(np.uint32))
+                if bitmap:
+                    bits = np.unpackbits(second.view(np.uint8), bitorder="little")
+                    assert np.array_equal(bits[:G], (ref_act == 2).astype(np.uint8)) and not bits[G:].any()
+                else:
+                    assert np.array_equal(second, np.nonzero(ref_act == 2)[0].astype(np.uint32))
+
+
+@pytest.mark.parametrize("shape,G", [("wide2", 70001), ("narrow", 70001), ("wide1", 70001), ("wide4", 70001), ("wide2", 1), ("wide2", 1025),
+                                     ("wide4", 8 * 1024 + 1), ("wide2", (1 << 20) + 5)])
+def test_set_tick_is_every_members_tick(gpu_engine_cls, oracle, shape, G, monkeypatch):
     """raftq_set_tick: one dispatch ticks every member; each member is left as its own raftq_tick would leave it -- also
-    when a member is ticked on its own, or re-configured, between set ticks (the set's table is rebuilt)."""
+    when a member is ticked on its own, or re-configured, between set ticks (the set's table is rebuilt).  In every launch
+    shape (RAFTQ_TICK_SHAPE: 16 groups per lane with 1 / 2 / 4 blocks per wave, round 4's 4 groups per lane): one layout of
+    action bytes, bitmaps and counts, so the lists behind them are checked too."""
     from raftsql_amd.engine import SweepSet
 
-    G, K = 70001, 4
+    monkeypatch.setenv("RAFTQ_TICK_SHAPE", shape)
+    K = 4
     rng = np.random.default_rng(77)
     roles = [rng.integers(0, 3, G).astype(np.uint8) for _ in range(K)]
     els = [rng.integers(0, 25, G).astype(np.uint32) for _ in range(K)]
@@ -660,6 +709,8 @@ def test_set_tick_is_every_members_tick(gpu_engine_cls, oracle):
         assert np.array_equal(act, check.act[k]) and np.array_equal(got_el, ref[k]), k
         hups, n = es[k].collect_hups()
         assert np.array_equal(hups, np.nonzero(check.act[k] == 1)[0].astype(np.uint64))
+        beats, nb = es[k].collect_beats()
+        assert np.array_equal(beats, np.nonzero(check.act[k] == 2)[0].astype(np.uint64))
 
     check.act = [None] * K
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One parameterised GPU-box script (replaces round 3's eighteen tools/gpu_r03_*.sh, profile_r0N.sh and sanitize_r03.sh): run as
-#   gpurun --timeout T -- 'bash tools/gpurun_trip.sh <step> [<step> ...]'
+#   tools/gpu.sh T 'bash tools/gpurun_trip.sh <step> [<step> ...]'      (gpu.sh stamps the shipped tree into .git_head first)
 # Every step writes under gpurun_out/$ROUND/; the summaries worth keeping are copied to profiles/$ROUND/ by hand.
 set -u
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 P=gpurun_out/$ROUND; mkdir -p $P; export TMPDIR=/tmp
 BENCH="python bench.py --gpus 1 --steps 20 --warmup 5"
 for step in "$@"; do
@@ -19,7 +19,7 @@ for step in "$@"; do
     pmchead)   # HBM traffic of the headline kernel, every BASELINE config: FETCH_SIZE / WRITE_SIZE in separate passes + the calibration
                # copy (tools/pmc_traffic.py turns the directory into profiles/pmc_traffic.json)
       H=$P/pmc_head; mkdir -p $H
-      python -c "import json,datetime; json.dump({'commit': '$(cat .git_head 2>/dev/null)', 'date': datetime.datetime.utcnow().isoformat()+'Z'}, open('$H/meta.json','w'))"
+      python -c "import json,datetime; json.dump({'commit': '$(cat .git_head 2>/dev/null)', 'dirty': '$(cat .git_dirty 2>/dev/null)' == '1', 'date': datetime.datetime.utcnow().isoformat()+'Z'}, open('$H/meta.json','w'))"
       for c in 3 2 4 5; do
         $BENCH --no-extras --no-cpu-baseline --config $c > $H/bench_config$c.json 2> $H/bench_config$c.err
         for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -56,17 +56,18 @@ SUPP
         echo "rc=$?" >> $LOG; ls $P/${kind}_report* >> $LOG 2>&1 || echo "no $kind report files: clean" >> $LOG; tail -3 $LOG
       done ;;
     legs)      # the side legs of the bench, plain (no profiler): wire, step, cycle, tick
-      for l in wire step cycle tick; do CPU=0 timeout 300 python tools/profile_$l.py > $P/leg_$l.txt 2>&1; echo "$l rc=$?"; done ;;
+      for l in wire step cycle tick frames; do CPU=0 timeout 300 python tools/profile_$l.py > $P/leg_$l.txt 2>&1; echo "$l rc=$?"; done ;;
     legstats)  # rocprofv3 kernel stats of the same legs
-      for l in wire step cycle tick; do
+      for l in wire step cycle tick frames; do
         CPU=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$l -o $l -- python tools/profile_$l.py > /dev/null 2>&1
         cp $(find /tmp/ks_$l -name "*kernel_stats.csv" | head -1) $P/${l}_kernel_stats.csv 2>/dev/null; done ;;
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q > $P/gpu_tests.log 2>&1; echo "rc=$? $(tail -1 $P/gpu_tests.log)" ;;
     wiretests) timeout 900 python -m pytest tests/test_wire_gpu.py -m gpu -x -q > $P/gpu_tests_wire.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_wire.log)" ;;
     steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;
     nodetests) timeout 900 python -m pytest tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_pipe_gpu.py -m gpu -x -q > $P/gpu_tests_node.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_node.log)" ;;
-    bench)     $BENCH > $P/bench_n1.json 2> $P/bench_n1.err; echo "rc=$?"; python - <<PY
-import json; d = json.load(open("$P/bench_n1.json")); print({k: d[k] for k in ("value", "ms_per_step")}, d["roofline"]["frac"])
+    bench)     # the driver's command: stdout = the ONE contract line (<= 4 KB), the full record (every side leg) beside it
+      $BENCH --legs-out $P/bench_legs.json > $P/bench_n1.json 2> $P/bench_n1.err; echo "rc=$? $(wc -c < $P/bench_n1.json) bytes on stdout"; python - <<PY
+import json; d = json.loads(open("$P/bench_n1.json").read().strip().splitlines()[-1]); print({k: d[k] for k in ("value", "ms_per_step")}, d["roofline"]["frac"], d["cpu_baseline"]["value"] if d["cpu_baseline"] else None); print(d.get("legs"))
 PY
       ;;
     benchstats) # the driver's command under --kernel-trace --stats (the roofline's average launch duration must agree)

@@ -33,20 +33,42 @@ LEGS = {
     "cycle": ["python", "tools/profile_cycle.py"],
     "tick": ["python", "tools/profile_tick.py"],
     "wire": ["python", "tools/profile_wire.py"],
+    "frames": ["python", "tools/profile_frames.py"],
     "calib": ["tools/tune/pmc_calib", "12"],
 }
-# kernel-name fragment -> (leg, access pattern of its dominant traffic)
-LEG_KERNELS = {
-    "step_lists_kernel": ("step", "line"), "step_link_kernel": ("step", "line"), "step_d2h_kernel": ("step", "stream"),
-    "step_walk_kernel": ("step", "line"),
-    "deltas_in_apply_kernel": ("cycle", "line"), "deltas_in_kernel": ("cycle", "stream"), "apply_deltas_kernel": ("cycle", "line"),
-    "compact_changed_kernel": ("cycle", "line"), "sweep_kernel": ("cycle", "stream"), "sweep_segments_kernel": ("cycle", "stream"), "compact_list_kernel": ("cycle", "line"),
-    "tick_kernel": ("tick", "stream"), "tick_set_kernel": ("tick", "stream"), "tick_lists_kernel": ("tick", "stream"),
-    "scan_partials_kernel": ("tick", "stream"), "compact_hups_kernel": ("tick", "stream"),
-    "wire_dec_kernel": ("wire", "stream"), "wire_dec_ents_kernel": ("wire", "stream"), "wire_dec_fused_kernel": ("wire", "stream"),
-    "wire_enc_fused_kernel": ("wire", "stream"), "wal_dec_kernel": ("wire", "stream"), "wal_dec_fused_kernel": ("wire", "stream"),
-    "wal_enc_fused_kernel": ("wire", "stream"),
-}
+# (kernel-name fragment, leg, access pattern of its dominant traffic).  A kernel that runs in two legs with different arguments
+# -- the decoder with and without the node's filter, Step's walk with and without held / skipped records -- has a record per
+# leg: records are keyed "<leg>:<kernel>".
+LEG_KERNELS = [
+    ("step_lists_kernel", "step", "line"), ("step_link_kernel", "step", "line"), ("step_d2h_kernel", "step", "stream"),
+    ("step_walk_kernel", "step", "line"),
+    ("deltas_in_apply_kernel", "cycle", "line"), ("deltas_in_kernel", "cycle", "stream"), ("apply_deltas_kernel", "cycle", "line"),
+    ("compact_changed_kernel", "cycle", "line"), ("sweep_kernel", "cycle", "stream"), ("sweep_segments_kernel", "cycle", "stream"),
+    ("raise_flag_segments_kernel", "cycle", "line"), ("raise_flag_kernel", "cycle", "line"), ("compact_list_kernel", "cycle", "line"),
+    ("tick_kernel", "tick", "stream"), ("tick_set_kernel", "tick", "stream"), ("tick_set_wide_kernel", "tick", "stream"),
+    ("tick_lists_kernel", "tick", "stream"), ("tick_lists32_kernel", "tick", "stream"),
+    ("scan_partials_kernel", "tick", "stream"), ("compact_hups_kernel", "tick", "stream"),
+    ("wire_dec_kernel", "wire", "stream"), ("wire_dec_ents_kernel", "wire", "stream"), ("wire_dec_fused_kernel", "wire", "stream"),
+    ("wire_enc_fused_kernel", "wire", "stream"), ("wal_dec_kernel", "wire", "stream"), ("wal_dec_fused_kernel", "wire", "stream"),
+    ("wal_enc_fused_kernel", "wire", "stream"),
+    ("wire_dec_fused_kernel", "frames", "stream"), ("step_link_kernel", "frames", "line"), ("step_lists_kernel", "frames", "line"),
+    ("step_d2h_kernel", "frames", "stream"),
+]
+
+
+def shipped_tree():
+    """The tree this run measures, as tools/gpu.sh stamped it before shipping (.git_head / .git_dirty; the box has no .git); in
+    the container itself, git."""
+    head = dirty = None
+    if os.path.exists(os.path.join(ROOT, ".git_head")):
+        head = open(os.path.join(ROOT, ".git_head")).read().strip()
+        if os.path.exists(os.path.join(ROOT, ".git_dirty")):
+            dirty = open(os.path.join(ROOT, ".git_dirty")).read().strip() == "1"
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        got = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        head = got or head
+        dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip())
+    return head, dirty
 
 
 def collect(outdir):
@@ -54,7 +76,14 @@ def collect(outdir):
     # (RAFTQ_STEP_DEFER_COPY=0: every Step batch copies its own results out, so the link / walk kernels are counted with
     # nothing riding in them)
     env = dict(os.environ, TMPDIR="/tmp", CPU="0", REPS="6", TICKS="100", RAFTQ_STEP_DEFER_COPY="0")
+    import datetime
+
+    head, dirty = shipped_tree()
+    json.dump({"commit": head, "dirty": dirty, "date": datetime.datetime.utcnow().isoformat() + "Z"}, open(os.path.join(outdir, "meta.json"), "w"))
+    only = [x for x in os.environ.get("LEGS", "").split(",") if x]
     for leg, cmd in LEGS.items():
+        if only and leg not in only and leg != "calib":
+            continue
         for pname, counters in PASSES.items():
             d = os.path.join(outdir, leg)
             os.makedirs(d, exist_ok=True)
@@ -105,20 +134,23 @@ def summarise(outdir, out):
         "RDREQ_per_64B_streamed": g("calib_stream_kernel", "TCC_EA0_RDREQ_sum") / ((64 << 20) / 64),
         "WRREQ_per_64B_streamed": g("calib_stream_kernel", "TCC_EA0_WRREQ_sum") / ((16 << 20) / 64),
     }
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    if not head and os.path.exists(os.path.join(ROOT, ".git_head")):
-        head = open(os.path.join(ROOT, ".git_head")).read().strip()
+    meta = {}
+    if os.path.exists(os.path.join(outdir, "meta.json")):  # written by collect() on the box: the tree that was measured
+        meta = json.load(open(os.path.join(outdir, "meta.json")))
+    head = meta.get("commit") or shipped_tree()[0]
     res = {"source": "rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ/_32B/WRREQ/_64B: three separate passes, "
                      "--kernel-trace only) around tools/profile_{step,cycle,tick,wire}.py; medians per dispatch; calibrated on "
                      "tools/tune/pmc_calib.hip (wide stream, one-word-per-line gather, one-word-per-line scatter)",
-           "commit": head, "calibration": cal, "factors": factors, "kernels": {}}
+           "commit": head, "measured_at": {"commit": head, "dirty_tree": meta.get("dirty"), "date": meta.get("date")},
+           "calibration": cal, "factors": factors, "kernels": {}}
     for leg in LEGS:
         if leg == "calib":
             continue
         for k, c in load(outdir, leg).items():
-            frag = next((f for f in LEG_KERNELS if f in k and LEG_KERNELS[f][0] == leg), None)
-            if frag is None:
+            hit = next(((f, pat) for f, lg, pat in LEG_KERNELS if lg == leg and f in k), None)
+            if hit is None:
                 continue
+            pattern = hit[1]
             raw = {n: med(v) for n, v in c.items()}
             n_disp = max(len(v) for v in c.values())
             rd_raw, wr_raw = raw.get("FETCH_SIZE", 0.0) * 1024, raw.get("WRITE_SIZE", 0.0) * 1024
@@ -126,8 +158,8 @@ def summarise(outdir, out):
             # request 64 B if counted so, else 32 B
             rq, rq32 = raw.get("TCC_EA0_RDREQ_sum", 0.0), raw.get("TCC_EA0_RDREQ_32B_sum", 0.0)
             wq, wq64 = raw.get("TCC_EA0_WRREQ_sum", 0.0), raw.get("TCC_EA0_WRREQ_64B_sum", 0.0)
-            res["kernels"][k] = {
-                "leg": leg, "pattern": LEG_KERNELS[frag][1], "dispatches": n_disp, "raw_median": raw,
+            res["kernels"][leg + ":" + k] = {
+                "leg": leg, "kernel": k, "pattern": pattern, "dispatches": n_disp, "raw_median": raw,
                 "bytes_stream_calibrated": {"read": rd_raw * f_stream_rd, "write": wr_raw * f_stream_wr},
                 "bytes_raw_counters": {"read": rd_raw, "write": wr_raw},
                 "bytes_from_requests": {"read": rq32 * 32 + (rq - rq32) * 64, "write": wq64 * 64 + (wq - wq64) * 32},

@@ -660,13 +660,13 @@ def tick_measure(cfg, device, ticks=2000, members=8):
                              "roofline": leg_roofline("hbm", "group", members * G, us_set * 1e-6, 5.0 * G * members, 5.0 * G * members,
                                                       "the same 10 B per group, %d MB per dispatch; every follower past its base timeout "
                                                       "(no heartbeats in this loop): every wave runs the timeout draw, VALU-bound" % (10 * members * G // 1000000),
-                                                      traffic=leg_traffic(["tick_set_wide_kernel<2>"], leg="tick"), algorithmic=(10.0 * G + G / 4.0) * members),
+                                                      traffic=leg_traffic(["tick_set_wide_kernel<1>"], leg="tick"), algorithmic=(10.0 * G + G / 4.0) * members),
                              "steady_state": {"what": "the same dispatch with no timer past its base timeout (what heartbeats keep true): no wave draws",
                                               "launch_us": us_set_quiet, "group_ticks_per_s": members * G / (us_set_quiet * 1e-6),
                                               "roofline": leg_roofline("hbm", "group", members * G, us_set_quiet * 1e-6, 5.0 * G * members,
                                                                        5.0 * G * members, "10 B per group, no draw")},
                              "shapes": shapes,
-                             "shapes_what": "RAFTQ_TICK_SHAPE: wide2 (shipped: 16 groups per lane, two 1,024-group blocks per wave), wide1, wide4, "
+                             "shapes_what": "RAFTQ_TICK_SHAPE: wide1 (shipped: 16 groups per lane, one 1,024-group block per wave), wide2, wide4, "
                                             "narrow (round 4: 4 groups per lane, four rounds per workgroup)"},
             "tick_and_lists": {"what": "raftq_tick_collect_lists + raftq_last_tick_lists: the Tick + its MsgHup and MsgBeat lists (ascending, "
                                        "4-byte ids) left in page-locked memory, three launches, one wait on the completion word; wall time "
@@ -1276,6 +1276,121 @@ def _node_measure(Cluster, device, G, N, rounds, near):
                                     "transport": 1e3 * sec["transport"] / steps}}
 
 
+def one_node_measure(device, G=32768, N=3, waves=24, near=None):
+    """SURVEY 8f-2 in the deployment shape: ONE raftq_node -- the leader of all G groups -- with the GPU and
+    its link to itself, and SCRIPTED peers on the host: what slots 1 .. N-1 would answer (MsgVoteResp, then one MsgAppResp per
+    MsgApp) is known in advance, so their frames are built before the clock starts (by the library's own marshaller on a handle
+    that is closed again before the node exists) and handed to raftq_node_deliver turn by turn; what the node sends them is
+    dropped where a transport would take it (raftq_node_forward to nobody).  One turn = one raftq_node_advance = one iteration of
+    the Ready loop (raft.go:220-246) for every group: the acks of the previous wave are decoded, checked and stepped (commit
+    advances, the entries go onto the commit channels), this wave's proposals are appended, and the MsgApps for them are
+    marshalled -- 2 (N-1) G frames and G proposals per turn.  Closed loop: every turn must publish exactly G entries."""
+    from raftsql_amd import step as S_
+    from raftsql_amd import wire as W
+    from raftsql_amd.node import RaftNode
+    from raftsql_amd.wire import WireEngine
+
+    peers = N - 1
+    per_turn = (1, 4)  # proposals per group per turn: one statement, and a client that batches four
+    turns_of = {k: (waves if k == 1 else max(4, waves // 2)) for k in per_turn}
+    warm = 3
+    # -- the peers' script (before the node exists; this handle is gone before the clock starts)
+    enc = WireEngine(G, N, self_peer=1, device=device)
+    groups = np.arange(G, dtype=np.uint64)
+
+    def answers(mtype, term, index):
+        m = np.zeros(G * peers, W.WIRE_MSG_DT)
+        m["group"] = np.tile(groups, peers)
+        m["from"] = np.repeat(np.arange(1, N, dtype=np.uint32), G)
+        m["to"], m["type"], m["term"], m["index"] = 0, mtype, term, index
+        stream, _ = enc.wire_encode(m)
+        return bytes(stream)
+
+    votes = answers(S_.MSG_VOTE_RESP, 1, 0)
+    script, idx = [], 1  # the log index the peers acknowledge: 1 = the leader's empty entry
+    script.append(answers(S_.MSG_APP_RESP, 1, idx))
+    for k in per_turn:
+        for _ in range(turns_of[k] + warm + 1):
+            idx += k
+            script.append(answers(S_.MSG_APP_RESP, 1, idx))
+    enc.close()
+    out = {}
+    for wal in (False, True):
+        nd = RaftNode(G, N, 0, device)
+        if wal:
+            nd.wal_enable()
+        nd.start(10, 1, seed=11)
+
+        def turn(frames, tick=False, nd=nd, wal=wal):
+            if frames:
+                nd.deliver(frames)
+            if tick:
+                nd.tick()
+            pub = nd.advance()
+            if wal:
+                nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
+            for q in range(1, N):
+                nd.forward(q, None)  # where a transport would take the frames for peer q
+            return pub
+
+        nd.campaign(groups)
+        turn(b"")  # MsgHup -> MsgVote out
+        turn(votes)  # granted -> leader of every group: the empty entry of its term, bcastAppend
+        assert (nd.roles() == 2).all(), "one_node_measure: the election did not finish"
+        turn(script[0])  # the empty entries are committed
+        at = 1
+        res = {}
+        for k in per_turn:
+            stmt = b"INSERT INTO t (v) VALUES (%7d)" % k
+            g_k = np.repeat(groups, k)
+            off_k = np.arange(G * k + 1, dtype=np.uint64) * len(stmt)
+            blob = stmt * (G * k)
+            # (turn 0 of a run only proposes; from then on every turn steps the previous turn's acks and proposes again)
+            nd.propose_blob(g_k, off_k, blob)
+            turn(b"")
+            for _ in range(warm):
+                nd.propose_blob(g_k, off_k, blob)
+                assert turn(script[at]) == G * k
+                at += 1
+            base = nd.stats()
+            n_turns = turns_of[k]
+            t0 = next_tick = time.perf_counter()
+            next_tick += 0.1
+            fired = 0
+            for _ in range(n_turns):
+                nd.propose_blob(g_k, off_k, blob)
+                due = time.perf_counter() >= next_tick  # the reference's 100 ms ticker (raft.go:217); heartbeats go unanswered
+                if due:
+                    next_tick += 0.1
+                    fired += 1
+                pub = turn(script[at], tick=due)
+                at += 1
+                assert pub == G * k, (pub, G * k)
+            dt = time.perf_counter() - t0
+            st = nd.stats()
+            assert st["entries_published"] - base["entries_published"] == n_turns * G * k
+            assert turn(script[at]) == G * k  # the last wave's acks (nothing proposed): the run ends with everything committed
+            at += 1
+            res[k] = {"proposals_committed_per_s": n_turns * G * k / dt, "ms_per_turn": 1e3 * dt / n_turns, "turns": n_turns,
+                      "msgs_stepped_per_s": (st["msgs_stepped"] - base["msgs_stepped"]) / dt, "ticks_during_run": fired,
+                      "frames_in_per_turn": peers * G, "frames_out_per_turn": peers * G, "entries_per_frame_out": k}
+        stat = nd.statuses()
+        assert (stat["commit"] == idx).all() and (stat["role"] == 2).all(), "one_node_measure: not every group committed every wave"
+        nd.close()
+        nd.destroy()
+        at_end = at
+        key = "with_wal" if wal else "no_wal"
+        out[key] = {"one_statement_per_group_per_turn": res[1], "four_statements_per_group_per_turn": res[4]}
+        assert at_end == len(script)
+    first = out["no_wal"]["one_statement_per_group_per_turn"]
+    return {"what": "ONE raftq_node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: "
+                    "per turn %d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> "
+                    "append -> %d MsgApps marshalled (one call); closed loop, every turn publishes one entry per group and proposal" %
+                    (G, N, peers * G, G, peers * G),
+            "groups": G, "peers": N, "proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"],
+            **out}
+
+
 def cpu_baseline(cfg, st, budget_s=12.0):
     """The oracle timed on this box's host cores (rank 0, N=1 only)."""
     from oracle import pyoracle
@@ -1637,6 +1752,8 @@ def main():
         out["step"] = guarded(step_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
         out["wire"] = guarded(wire_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
         out["node"] = guarded(node_measure, d0)
+        if isinstance(out["node"], dict) and "error" not in out["node"]:
+            out["node"]["one_node_one_gpu"] = guarded(one_node_measure, d0)
     dist.barrier(world)
     if world.rank == 0:
         legs_file = None

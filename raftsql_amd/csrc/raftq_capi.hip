@@ -1840,20 +1840,21 @@ int raftq_set_tick(raftq_set_t* s) {
     s->tick_since = 0;
   }
   const uint64_t n_blocks = s->gpad / 1024;
-  // RAFTQ_TICK_SHAPE: wide2 (default: 16 groups per lane, two 1,024-group blocks per wave), wide1 / wide4, narrow (round 4's
-  // 4 groups per lane).  Same results, byte for byte (tests/test_parity_gpu.py runs the set Tick in every shape).
+  // RAFTQ_TICK_SHAPE: wide1 (default: 16 groups per lane, one 1,024-group block per wave: 14.9 us per 8 x 1M groups = 0.70 of HBM
+  // in steady state, profiles/r05), wide2 / wide4 (two / four blocks per wave: 16.1 / 17.2), narrow (round 4's 4 groups per lane,
+  // four rounds per workgroup: 15.7).  Same results, byte for byte (tests/test_parity_gpu.py runs the set Tick in every shape).
   // (read at every call -- a getenv is nothing beside a launch -- so that a test or the bench can A/B the shapes in one process)
-  int shape_now = 2;
+  int shape_now = 1;
   if (const char* e = std::getenv("RAFTQ_TICK_SHAPE"))
-    shape_now = std::strcmp(e, "narrow") == 0 ? 0 : std::strcmp(e, "wide1") == 0 ? 1 : std::strcmp(e, "wide4") == 0 ? 4 : 2;
+    shape_now = std::strcmp(e, "narrow") == 0 ? 0 : std::strcmp(e, "wide2") == 0 ? 2 : std::strcmp(e, "wide4") == 0 ? 4 : 1;
   auto wide_grid = [&](int r) { return dim3((unsigned)((n_blocks + (uint64_t)kWaves * r - 1) / ((uint64_t)kWaves * r)), (unsigned)K); };
   switch (shape_now) {
     case 0:
       hipLaunchKernelGGL(tick_set_kernel, dim3((unsigned)((n_blocks + kTickSetRounds - 1) / kTickSetRounds), (unsigned)K), dim3(kBlock), 0, s->stream,
                          (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
       break;
-    case 1:
-      hipLaunchKernelGGL((tick_set_wide_kernel<1>), wide_grid(1), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
+    case 2:
+      hipLaunchKernelGGL((tick_set_wide_kernel<2>), wide_grid(2), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);
       break;
     case 4:
       hipLaunchKernelGGL((tick_set_wide_kernel<4>), wide_grid(4), dim3(kBlock), 0, s->stream, (const TickArgs*)s->tick_tab, s->tick_since, n_blocks);

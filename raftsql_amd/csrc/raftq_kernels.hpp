@@ -1444,7 +1444,7 @@ static __global__ __launch_bounds__(kBlock) void tick_set_kernel(const TickArgs*
   tick_tile<kTickSetRounds, true>(a, n_blocks);
 }
 // ... at 16 groups per lane (tick_tile_wide): a workgroup's four waves own kTickWideBlocks 1,024-group blocks each
-constexpr int kTickWideBlocks = 2;
+constexpr int kTickWideBlocks = 1;  // measured: 1 block per wave 14.9 us, 2: 16.1, 4: 17.2 per 8 x 1M groups (profiles/r05)
 template <int R>
 static __global__ __launch_bounds__(kBlock) void tick_set_wide_kernel(const TickArgs* __restrict__ tab, uint64_t ticks_since, uint64_t n_blocks) {
   TickArgs a = tab[blockIdx.y];

@@ -1276,15 +1276,22 @@ def _node_measure(Cluster, device, G, N, rounds, near):
                                     "transport": 1e3 * sec["transport"] / steps}}
 
 
-def one_node_measure(device, G=32768, N=3, waves=24, near=None):
-    """SURVEY 8f-2 in the deployment shape: ONE raftq_node -- the leader of all G groups -- with the GPU and
-    its link to itself, and SCRIPTED peers on the host: what slots 1 .. N-1 would answer (MsgVoteResp, then one MsgAppResp per
+def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
+    """SURVEY 8f-2 in the deployment shape: ONE node -- the leader of all G groups -- with the GPU and its
+    link to itself, and SCRIPTED peers on the host: what slots 1 .. N-1 would answer (MsgVoteResp, then one MsgAppResp per
     MsgApp) is known in advance, so their frames are built before the clock starts (by the library's own marshaller on a handle
     that is closed again before the node exists) and handed to raftq_node_deliver turn by turn; what the node sends them is
     dropped where a transport would take it (raftq_node_forward to nobody).  One turn = one raftq_node_advance = one iteration of
     the Ready loop (raft.go:220-246) for every group: the acks of the previous wave are decoded, checked and stepped (commit
     advances, the entries go onto the commit channels), this wave's proposals are appended, and the MsgApps for them are
-    marshalled -- 2 (N-1) G frames and G proposals per turn.  Closed loop: every turn must publish exactly G entries."""
+    marshalled -- 2 (N-1) G frames and G proposals per turn.  Closed loop: every turn must publish exactly one entry per group
+    and proposal.
+    `shards`: groups are independent, so a node's G groups may be K raftq_node handles of G / K groups, each with its own
+    thread and Ready loop (the reference's one goroutine per raft group, batched K ways instead of G ways): the host side of a
+    turn -- 23 ns per ack, 46 ns per proposal, one core -- is what bounds one handle (profiles/r05/one_node_phases.txt), and it
+    runs K-fold; every shard's turn is still two waits on the device."""
+    import threading
+
     from raftsql_amd import step as S_
     from raftsql_amd import wire as W
     from raftsql_amd.node import RaftNode
@@ -1294,100 +1301,151 @@ def one_node_measure(device, G=32768, N=3, waves=24, near=None):
     per_turn = (1, 4)  # proposals per group per turn: one statement, and a client that batches four
     turns_of = {k: (waves if k == 1 else max(4, waves // 2)) for k in per_turn}
     warm = 3
-    # -- the peers' script (before the node exists; this handle is gone before the clock starts)
-    enc = WireEngine(G, N, self_peer=1, device=device)
-    groups = np.arange(G, dtype=np.uint64)
-
-    def answers(mtype, term, index):
-        m = np.zeros(G * peers, W.WIRE_MSG_DT)
-        m["group"] = np.tile(groups, peers)
-        m["from"] = np.repeat(np.arange(1, N, dtype=np.uint32), G)
-        m["to"], m["type"], m["term"], m["index"] = 0, mtype, term, index
-        stream, _ = enc.wire_encode(m)
-        return bytes(stream)
-
-    votes = answers(S_.MSG_VOTE_RESP, 1, 0)
-    script, idx = [], 1  # the log index the peers acknowledge: 1 = the leader's empty entry
-    script.append(answers(S_.MSG_APP_RESP, 1, idx))
-    for k in per_turn:
-        for _ in range(turns_of[k] + warm + 1):
-            idx += k
-            script.append(answers(S_.MSG_APP_RESP, 1, idx))
-    enc.close()
+    near = gpu_numa_cpus(device) or os.sched_getaffinity(0)
     out = {}
-    for wal in (False, True):
-        nd = RaftNode(G, N, 0, device)
-        if wal:
-            nd.wal_enable()
-        nd.start(10, 1, seed=11)
+    dbg = (lambda *a: print("[one_node]", *a, file=sys.stderr, flush=True)) if os.environ.get("RAFTQ_BENCH_DEBUG") else (lambda *a: None)
+    for K in shard_counts:
+        Gs = G // K
+        dbg("K", K, "script")
+        # -- the peers' script for ONE shard (group ids are the shard's own 0 .. Gs-1: every shard reads the same bytes); built
+        # before any node exists, on a handle that is gone before the clock starts
+        enc = WireEngine(Gs, N, self_peer=1, device=device)
+        groups = np.arange(Gs, dtype=np.uint64)
 
-        def turn(frames, tick=False, nd=nd, wal=wal):
-            if frames:
-                nd.deliver(frames)
-            if tick:
-                nd.tick()
-            pub = nd.advance()
-            if wal:
-                nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
-            for q in range(1, N):
-                nd.forward(q, None)  # where a transport would take the frames for peer q
-            return pub
+        def answers(mtype, term, index, enc=enc, groups=groups, Gs=Gs):
+            m = np.zeros(Gs * peers, W.WIRE_MSG_DT)
+            m["group"] = np.tile(groups, peers)
+            m["from"] = np.repeat(np.arange(1, N, dtype=np.uint32), Gs)
+            m["to"], m["type"], m["term"], m["index"] = 0, mtype, term, index
+            stream, _ = enc.wire_encode(m)
+            return bytes(stream)
 
-        nd.campaign(groups)
-        turn(b"")  # MsgHup -> MsgVote out
-        turn(votes)  # granted -> leader of every group: the empty entry of its term, bcastAppend
-        assert (nd.roles() == 2).all(), "one_node_measure: the election did not finish"
-        turn(script[0])  # the empty entries are committed
-        at = 1
-        res = {}
+        votes = answers(S_.MSG_VOTE_RESP, 1, 0)
+        script, idx = [answers(S_.MSG_APP_RESP, 1, 1)], 1  # idx: the log index the peers acknowledge; 1 = the leader's empty entry
         for k in per_turn:
-            stmt = b"INSERT INTO t (v) VALUES (%7d)" % k
-            g_k = np.repeat(groups, k)
-            off_k = np.arange(G * k + 1, dtype=np.uint64) * len(stmt)
-            blob = stmt * (G * k)
-            # (turn 0 of a run only proposes; from then on every turn steps the previous turn's acks and proposes again)
-            nd.propose_blob(g_k, off_k, blob)
-            turn(b"")
-            for _ in range(warm):
-                nd.propose_blob(g_k, off_k, blob)
-                assert turn(script[at]) == G * k
-                at += 1
-            base = nd.stats()
-            n_turns = turns_of[k]
-            t0 = next_tick = time.perf_counter()
-            next_tick += 0.1
-            fired = 0
-            for _ in range(n_turns):
-                nd.propose_blob(g_k, off_k, blob)
-                due = time.perf_counter() >= next_tick  # the reference's 100 ms ticker (raft.go:217); heartbeats go unanswered
-                if due:
-                    next_tick += 0.1
-                    fired += 1
-                pub = turn(script[at], tick=due)
-                at += 1
-                assert pub == G * k, (pub, G * k)
-            dt = time.perf_counter() - t0
-            st = nd.stats()
-            assert st["entries_published"] - base["entries_published"] == n_turns * G * k
-            assert turn(script[at]) == G * k  # the last wave's acks (nothing proposed): the run ends with everything committed
-            at += 1
-            res[k] = {"proposals_committed_per_s": n_turns * G * k / dt, "ms_per_turn": 1e3 * dt / n_turns, "turns": n_turns,
-                      "msgs_stepped_per_s": (st["msgs_stepped"] - base["msgs_stepped"]) / dt, "ticks_during_run": fired,
-                      "frames_in_per_turn": peers * G, "frames_out_per_turn": peers * G, "entries_per_frame_out": k}
-        stat = nd.statuses()
-        assert (stat["commit"] == idx).all() and (stat["role"] == 2).all(), "one_node_measure: not every group committed every wave"
-        nd.close()
-        nd.destroy()
-        at_end = at
-        key = "with_wal" if wal else "no_wal"
-        out[key] = {"one_statement_per_group_per_turn": res[1], "four_statements_per_group_per_turn": res[4]}
-        assert at_end == len(script)
-    first = out["no_wal"]["one_statement_per_group_per_turn"]
-    return {"what": "ONE raftq_node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: "
-                    "per turn %d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> "
-                    "append -> %d MsgApps marshalled (one call); closed loop, every turn publishes one entry per group and proposal" %
+            for _ in range(turns_of[k] + warm + 1):
+                idx += k
+                script.append(answers(S_.MSG_APP_RESP, 1, idx))
+        enc.close()
+        cores = one_cpu_per_l3(near, K) if K > 1 else None
+        for wal in (False, True):
+            dbg("K", K, "wal", wal, "create")
+            nodes = [RaftNode(Gs, N, 0, device) for _ in range(K)]
+            for nd in nodes:
+                if wal:
+                    nd.wal_enable()
+                nd.start(10, 1, seed=11)
+            results = [None] * K
+            errors = []
+            gate = threading.Barrier(K)
+
+            def shard(si, nodes=nodes, wal=wal, groups=groups, Gs=Gs, script=script, votes=votes, results=results, cores=cores, gate=gate):
+                try:
+                    nd = nodes[si]
+                    if cores and len(cores) == len(nodes):
+                        os.sched_setaffinity(0, {cores[si]})  # this thread only: a shard is host work over its groups' state
+
+                    def turn(frames, tick=False):
+                        if frames:
+                            nd.deliver(frames)
+                        if tick:
+                            nd.tick()
+                        pub = nd.advance()
+                        if wal:
+                            nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
+                        for q in range(1, N):
+                            nd.forward(q, None)  # where a transport would take the frames for peer q
+                        return pub
+
+                    dbg("shard", si, "campaign")
+                    nd.campaign(groups)
+                    turn(b"")  # MsgHup -> MsgVote out
+                    dbg("shard", si, "votes")
+                    turn(votes)  # granted -> leader of every group: the empty entry of its term, bcastAppend
+                    dbg("shard", si, "leader")
+                    assert (nd.roles() == 2).all(), "one_node_measure: the election did not finish"
+                    turn(script[0])  # the empty entries are committed
+                    at, res = 1, {}
+                    for k in per_turn:
+                        stmt = b"INSERT INTO t (v) VALUES (%7d)" % k
+                        g_k = np.repeat(groups, k)
+                        off_k = np.arange(Gs * k + 1, dtype=np.uint64) * len(stmt)
+                        blob = stmt * (Gs * k)
+                        nd.propose_blob(g_k, off_k, blob)  # (turn 0 of a run only proposes; from then on every turn steps the
+                        turn(b"")                          # previous turn's acks and proposes again)
+                        for _ in range(warm):
+                            nd.propose_blob(g_k, off_k, blob)
+                            assert turn(script[at]) == Gs * k
+                            at += 1
+                        base = nd.stats()
+                        n_turns = turns_of[k]
+                        dbg("shard", si, "k", k, "warm done")
+                        gate.wait()  # every shard starts its clock together; wall time of the run = the slowest shard's
+                        t0 = next_tick = time.perf_counter()
+                        next_tick += 0.1
+                        fired = 0
+                        for _ in range(n_turns):
+                            nd.propose_blob(g_k, off_k, blob)
+                            due = time.perf_counter() >= next_tick  # the reference's 100 ms ticker (raft.go:217); heartbeats go unanswered
+                            if due:
+                                next_tick += 0.1
+                                fired += 1
+                            pub = turn(script[at], tick=due)
+                            at += 1
+                            assert pub == Gs * k, (pub, Gs * k)
+                        t1 = time.perf_counter()
+                        st = nd.stats()
+                        assert st["entries_published"] - base["entries_published"] == n_turns * Gs * k
+                        assert turn(script[at]) == Gs * k  # the last wave's acks (nothing proposed): the run ends with everything committed
+                        at += 1
+                        res[k] = (t0, t1, st["msgs_stepped"] - base["msgs_stepped"], fired)
+                        gate.wait()
+                    assert at == len(script)
+                    stat = nd.statuses()
+                    assert (stat["role"] == 2).all() and (stat["commit"] == stat["last_index"]).all() and (stat["commit"] == stat["commit"][0]).all()
+                    results[si] = res
+                except BaseException as ex:  # noqa: BLE001
+                    errors.append(repr(ex))
+                    gate.abort()
+
+            if K == 1:
+                shard(0)
+            else:
+                before = os.sched_getaffinity(0)
+                ths = [threading.Thread(target=shard, args=(si,)) for si in range(K)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                os.sched_setaffinity(0, before)
+            dbg("K", K, "wal", wal, "destroy")
+            for nd in nodes:
+                nd.close()
+                nd.destroy()
+            dbg("K", K, "wal", wal, "destroyed")
+            if errors:
+                raise RuntimeError("one_node_measure (%d shards): %s" % (K, errors[0]))
+            rec = {}
+            for k in per_turn:
+                t0 = min(r[k][0] for r in results)
+                t1 = max(r[k][1] for r in results)
+                n_turns = turns_of[k]
+                rec["one_statement_per_group_per_turn" if k == 1 else "four_statements_per_group_per_turn"] = {
+                    "proposals_committed_per_s": n_turns * G // K * K * k / (t1 - t0), "ms_per_turn": 1e3 * (t1 - t0) / n_turns, "turns": n_turns,
+                    "msgs_stepped_per_s": sum(r[k][2] for r in results) / (t1 - t0), "ticks_during_run": max(r[k][3] for r in results),
+                    "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": peers * Gs * K, "entries_per_frame_out": k}
+            out.setdefault("shards_%d" % K, {"shards": K, "groups_per_shard": Gs, "shard_thread_cpus": cores})["with_wal" if wal else "no_wal"] = rec
+    first = out["shards_%d" % shard_counts[0]]["no_wal"]["one_statement_per_group_per_turn"]
+    best_k = max(shard_counts, key=lambda K: out["shards_%d" % K]["no_wal"]["one_statement_per_group_per_turn"]["proposals_committed_per_s"])
+    best = out["shards_%d" % best_k]["no_wal"]["one_statement_per_group_per_turn"]
+    return {"what": "ONE node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: per turn "
+                    "%d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> append -> %d "
+                    "MsgApps marshalled (one call); closed loop, every turn publishes one entry per group and proposal.  shards_K: the "
+                    "node's groups as K raftq_node handles of G / K groups, each with its own thread and Ready loop" %
                     (G, N, peers * G, G, peers * G),
-            "groups": G, "peers": N, "proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"],
+            "groups": G, "peers": N,
+            "proposals_committed_per_s": best["proposals_committed_per_s"], "ms_per_turn": best["ms_per_turn"], "shards": best_k,
+            "one_handle": {"proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"]},
             **out}
 
 
@@ -1436,6 +1494,99 @@ def cpu_baseline(cfg, st, budget_s=12.0):
     }
 
 
+SIDE_LEGS = ("other_configs", "pipeline", "tick", "step", "wire", "node")
+
+
+def side_legs_child(args):
+    """`bench.py --side-legs-child OUT.json --device D --config C`: every side leg on device D, each guarded, the objects written
+    to OUT.json after EVERY leg (what a crashed leg leaves behind is everything before it)."""
+    import torch
+
+    from raftsql_amd import _lib, dist
+
+    d0 = args.device or 0
+    torch.cuda.set_device(d0)
+    _lib.load()
+    near = None if args.no_pin else gpu_numa_cpus(d0)
+    if near:
+        os.sched_setaffinity(0, near)
+    cfg = CONFIGS[args.config]
+    res = {}
+
+    def guarded(name, fn, *a, **k):  # a leg that raises says so and the next one runs
+        try:
+            res[name] = fn(*a, **k)
+        except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        with open(args.side_legs_child + ".tmp", "w") as f:
+            json.dump(res, f)
+        os.replace(args.side_legs_child + ".tmp", args.side_legs_child)
+
+    def others():
+        o = {}
+        for c in sorted(CONFIGS):
+            if c == args.config:
+                continue
+            cc = CONFIGS[c]
+            r_, w_ = bytes_per_decision(cc)
+            nb = max(4, int(round(6e9 / (cc["G"] * (r_ + w_)))))
+            try:
+                o[f"config{c}"] = measure_config(c, nb, 30, 3, d0, dist)
+            except BaseException as e:  # noqa: BLE001
+                o[f"config{c}"] = {"error": f"{type(e).__name__}: {e}"}
+        return o
+
+    guarded("other_configs", others)
+    guarded("pipeline", pipeline_measure, cfg, d0)
+    guarded("tick", tick_measure, cfg, d0)
+    guarded("step", step_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
+    guarded("wire", wire_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
+    guarded("node", node_measure, d0)
+    if isinstance(res.get("node"), dict) and "error" not in res["node"]:
+        try:
+            res["node"]["one_node_one_gpu"] = one_node_measure(d0)
+        except BaseException as e:  # noqa: BLE001
+            res["node"]["one_node_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+        with open(args.side_legs_child, "w") as f:
+            json.dump(res, f)
+    return 0
+
+
+def run_side_legs(args, device, timeout_s=900):
+    """-> {leg: object} for every side leg; a leg the child did not get to (it crashed, or ran out of time) reads {"error": ...}"""
+    import subprocess
+    import tempfile
+
+    path = os.path.join(tempfile.mkdtemp(prefix="raftq_legs_"), "side_legs.json")
+    cmd = [sys.executable, os.path.abspath(__file__), "--side-legs-child", path, "--device", str(device), "--config", str(args.config)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_pin:
+        cmd.append("--no-pin")
+    # (the child is a plain single-GPU process whatever launched this one: no rendezvous variables)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    why = None
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        if p.returncode != 0:
+            tail = [ln for ln in (p.stderr or "").splitlines() if "amdgpu.ids" not in ln][-3:]
+            why = "the side-leg process ended with status %d: %s" % (p.returncode, " | ".join(tail)[-400:])
+    except subprocess.TimeoutExpired:
+        why = "the side-leg process was stopped after %d s" % timeout_s
+    res = {}
+    try:
+        res = json.load(open(path))
+    except (OSError, ValueError):
+        pass
+    for leg in SIDE_LEGS:
+        if leg not in res:
+            res[leg] = {"error": why or "the side-leg process left no record of this leg"}
+    if why:
+        res["side_legs_note"] = why
+    return res
+
+
 def plan_devices(gpus: int, forced_device, visible: int, world_size: int, local_rank: int) -> list[int]:
     """The GPU indices THIS process drives.  Under torchrun: one (its local rank).  Launched directly:
     all `gpus` of them.  Never fewer than asked for: a job that cannot get its GPUs fails loudly.
@@ -1478,6 +1629,8 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--side-legs-child", default=None, metavar="OUT.json",
+                    help="(internal) run the side legs only, on --device, and write their objects to OUT.json")
     ap.add_argument("--legs-out", default=os.path.join(ROOT, "gpurun_out", "bench_legs.json"),
                     help="where the FULL record goes (every side leg's objects): stdout carries one line of at "
                          "most 4 KB with the contract's keys and a few scalars per leg")
@@ -1490,6 +1643,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the quorum sweep has no CPU path (only the oracle baseline does)")
+    if args.side_legs_child:
+        return side_legs_child(args)
     world = dist.init_from_env(args.backend, device=args.device)
     devices = plan_devices(args.gpus, args.device, torch.cuda.device_count(), world.size, world.local_rank)
     n_gpus = world.size * len(devices) if world.size > 1 else len(devices)
@@ -1700,12 +1855,6 @@ def main():
             e.close()
     sets, all_engines = [], []
 
-    def guarded(fn, *a, **k):  # side measurements never take the headline line down with them
-        try:
-            return fn(*a, **k)
-        except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
-            return {"error": f"{type(e).__name__}: {e}"}
-
     if n_gpus > 1 and not args.no_extras:
         # BASELINE configs[3] as a whole job: 2M groups x 7 peers per GPU (16M x 7 over 8), same step definition
         c4 = CONFIGS[4]
@@ -1738,22 +1887,10 @@ def main():
                 "frac_per_gpu": (rd4 + wr4) * c4["G"] * nb4 / (us4 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
             }
     if world.rank == 0 and n_gpus == 1 and not args.no_extras:
-        d0 = devices[0]
-        out["other_configs"] = {}
-        for c in sorted(CONFIGS):
-            if c == args.config:
-                continue
-            cc = CONFIGS[c]
-            r_, w_ = bytes_per_decision(cc)
-            nb = max(4, int(round(6e9 / (cc["G"] * (r_ + w_)))))
-            out["other_configs"][f"config{c}"] = guarded(measure_config, c, nb, 30, 3, d0, dist)
-        out["pipeline"] = guarded(pipeline_measure, cfg, d0)
-        out["tick"] = guarded(tick_measure, cfg, d0)
-        out["step"] = guarded(step_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
-        out["wire"] = guarded(wire_measure, cfg, d0, with_cpu=not args.no_cpu_baseline)
-        out["node"] = guarded(node_measure, d0)
-        if isinstance(out["node"], dict) and "error" not in out["node"]:
-            out["node"]["one_node_one_gpu"] = guarded(one_node_measure, d0)
+        # The side legs run in a CHILD process (this script with --side-legs-child): a leg that takes the process down with it --
+        # a GPU memory fault aborts, it does not raise -- costs its own numbers, never the headline line (round 4's line was lost
+        # to its size; a line lost to a crashed leg would be the same empty record).  This process holds no device memory by now.
+        out.update(run_side_legs(args, devices[0]))
     dist.barrier(world)
     if world.rank == 0:
         legs_file = None

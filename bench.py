@@ -76,9 +76,12 @@ def leg_traffic(kernels, launches_per_unit=1.0, leg=None):
             if frag in rec.get("kernel", name) and (leg is None or rec.get("leg") in (None, leg)):
                 hit = True
                 name = rec.get("kernel", name)
-                b = rec["bytes_stream_calibrated"] if rec.get("pattern") == "stream" else rec["bytes_from_requests"]
+                # HBM bytes proper where the DRAM-only request counters were taken (a kernel that also reads or writes page-locked
+                # host memory shows the link's bytes in every other counter); else by the calibration of its access pattern
+                b = rec.get("bytes_hbm") or (rec["bytes_stream_calibrated"] if rec.get("pattern") == "stream" else rec["bytes_from_requests"])
                 found[name.split("<")[0].replace("raftqk::", "")] = {"read": b["read"], "write": b["write"], "pattern": rec.get("pattern"),
-                                                                      "dispatches": rec["dispatches"]}
+                                                                      "dispatches": rec["dispatches"], "link": rec.get("bytes_link"),
+                                                                      "counters": "DRAM requests" if rec.get("bytes_hbm") else "calibrated FETCH / WRITE"}
         if not hit:
             missing.append(frag)
     if missing or not found:

@@ -1081,7 +1081,8 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
   if (int rc = ensure_tick_state(h)) return rc;
   const bool bitmap = flags & RAFTQ_TICK_BEAT_BITMAP;
   const uint64_t cap_h = std::min<uint64_t>(hup_cap, h->G), cap_b = bitmap ? 0 : std::min<uint64_t>(beat_cap, h->G);
-  const uint64_t map_off = ((cap_h + cap_b) * 4 + 255) / 256 * 256;
+  const uint64_t beat_at = (cap_h + 3) & ~3ull;  // the MsgBeat ids start on a 16-byte boundary (the lists leave in whole quads)
+  const uint64_t map_off = ((beat_at + cap_b) * 4 + 255) / 256 * 256;
   const uint64_t need = map_off + h->gpad / 8 + 256;
   h->tl_valid = false;
   if (need > h->tl_bytes) {
@@ -1108,7 +1109,7 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
     off_b = h->tick_offsets2;
   }
   uint32_t* const hup_d = h->tl_d;
-  uint32_t* const beat_d = h->tl_d + cap_h;
+  uint32_t* const beat_d = h->tl_d + beat_at;
   uint64_t* const map_d = (uint64_t*)((uint8_t*)h->tl_d + map_off);
   const dim3 grid((unsigned)(h->gpad / 1024));
   if (bitmap)
@@ -1132,6 +1133,7 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
   *n_beat = h->tl_n_beat = h->h_total[1];
   h->tl_hup_cap = cap_h;
   h->tl_beat_cap = cap_b;
+  h->tl_beat_at = beat_at;
   h->tl_map_off = map_off;
   h->tl_flags = flags;
   h->tl_valid = true;
@@ -1145,7 +1147,7 @@ int raftq_last_tick_lists(raftq_t* h, const uint32_t** hups, uint64_t* n_hups, c
   const bool bitmap = h->tl_flags & RAFTQ_TICK_BEAT_BITMAP;
   if (hups) *hups = h->tl_h;
   if (n_hups) *n_hups = std::min(h->tl_n_hup, h->tl_hup_cap);
-  if (beats) *beats = bitmap ? nullptr : h->tl_h + h->tl_hup_cap;
+  if (beats) *beats = bitmap ? nullptr : h->tl_h + h->tl_beat_at;
   if (n_beats) *n_beats = bitmap ? 0 : std::min(h->tl_n_beat, h->tl_beat_cap);
   if (beat_bitmap) *beat_bitmap = bitmap ? (const uint64_t*)((const uint8_t*)h->tl_h + h->tl_map_off) : nullptr;
   if (bitmap_words) *bitmap_words = bitmap ? (h->G + 63) / 64 : 0;
@@ -1409,6 +1411,24 @@ static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
   }
   if (flag_epoch) ++h->flag_fallbacks;
   return hipStreamSynchronize(h->stream);
+}
+
+hipError_t raftq_detail::wait_call(raftq_t* h) {
+  static const bool block = [] {
+    const char* e = std::getenv("RAFTQ_CALL_WAIT");
+    return e && std::strcmp(e, "block") == 0;
+  }();
+  hipError_t e;
+  if (block || !h->stream_write_ok || flag_mode() != 1 || !h->d_total) {
+    e = hipStreamSynchronize(h->stream);
+  } else {
+    const uint64_t epoch = ++h->compact_epoch;
+    h->flag_mask = ~0ull;
+    hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
+    e = hipGetLastError() != hipSuccess ? hipStreamSynchronize(h->stream) : wait_turn(h, epoch);
+  }
+  if (e == hipSuccess && h->wal_pending && !h->wal_pending_done) h->wal_pending_waited = true;  // the begun WAL encode was enqueued before this wait
+  return e;
 }
 
 // One batching turn (raft.go:227-235 for every group at once): ingest -> sweep -> advance list, one wait.

@@ -95,7 +95,7 @@ struct raftq {
   // raftq_tick_collect_lists: the two lists left in place (page-locked; 4-byte group ids; MsgBeat optionally as a bitmap)
   uint32_t* tl_h = nullptr;     // pinned: [tl_hup_cap] MsgHup ids | [tl_beat_cap] MsgBeat ids | beat bitmap (gpad / 64 words, 16-byte aligned)
   uint32_t* tl_d = nullptr;     // ... as the device addresses it
-  uint64_t tl_bytes = 0, tl_hup_cap = 0, tl_beat_cap = 0, tl_map_off = 0;  // tl_map_off: byte offset of the bitmap
+  uint64_t tl_bytes = 0, tl_hup_cap = 0, tl_beat_cap = 0, tl_beat_at = 0, tl_map_off = 0;  // tl_beat_at: index of the first MsgBeat id; tl_map_off: byte offset of the bitmap
   uint64_t tl_n_hup = 0, tl_n_beat = 0;
   unsigned tl_flags = 0;
   bool tl_valid = false;
@@ -199,6 +199,7 @@ struct raftq {
   // raftq_wal_encode_begin .. _end: enqueued, its totals in wire_pin[8 ..]; `done`: a later wait has covered it and what _end
   // will report is kept here
   bool wal_pending = false, wal_pending_done = false;
+  bool wal_pending_waited = false;  // a wait on the handle's stream has come back since the begin: its kernel has run
   uint64_t wal_pending_n = 0, wal_pending_cap = 0;
   uint32_t wal_pending_prev = 0;
   int wal_pending_rc = 0;
@@ -258,6 +259,11 @@ void free_wire_state(raftq_t* h);               // raftq_wire.hip's allocations 
 int wire_frames_enqueue(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, void* msgs, void* ents,
                         uint64_t ents_cap, void* msgs_d, int tail_appends, void* zero2 /* two device words left zero, or nullptr */);
 int wire_frames_finish(raftq_t* h, const uint64_t* frame_off, uint64_t n, bool have_ents, uint64_t ents_cap, ::raftq_wire_counts* counts);
+// The wait that ends a call whose results the kernels wrote into page-locked memory themselves (the streaming codecs,
+// raftq_step_frames): a one-thread kernel raises the handle's completion word behind everything enqueued so far and the host
+// polls it (raftq_cycle's wait, raftq_capi.hip wait_turn) -- a stream synchronisation costs 15-20 us more than the word does.
+// The blocking wait where the word cannot be had or RAFTQ_CALL_WAIT=block.
+hipError_t wait_call(raftq_t* h);
 }  // namespace raftq_detail
 
 #define HIPCHK(h, expr)                                                                        \

@@ -1333,6 +1333,24 @@ static __global__ __launch_bounds__(kBlock) void tick_lists_kernel(const uint64_
 // of a list: with HeartbeatTick 1 (raft.go:155) every leader beats on every tick, so the beat "list" is the leader set --
 // 128 KB as a bitmap against 1.4 MB of ids per 1M groups a third of which lead.  A workgroup compacts its 1,024 groups' ids
 // in LDS and writes them out as runs of consecutive words (full lines over the link, not a lane's four words at a time).
+// A workgroup's run of ids, LDS -> its place in a list in page-locked host memory: whole 16-byte quads of the DESTINATION (1 KB per
+// wave instruction over the link), the few words before the first and behind the last quad one by one.
+__device__ __forceinline__ void run_out(uint32_t* out, uint64_t cap, uint64_t pos, const uint32_t* ids /*LDS*/, uint32_t n, uint32_t tid) {
+  if (pos >= cap) return;
+  if (pos + n > cap) n = (uint32_t)(cap - pos);
+  const uint32_t head = (uint32_t)((4 - (pos & 3)) & 3) < n ? (uint32_t)((4 - (pos & 3)) & 3) : n;  // words before the first whole quad
+  const uint32_t quads = (n - head) >> 2;
+  if (tid < head) out[pos + tid] = ids[tid];
+  for (uint32_t q = tid; q < quads; q += kBlock) {
+    const uint32_t i = head + 4 * q;
+    u32x4 v;
+    v.x = ids[i]; v.y = ids[i + 1]; v.z = ids[i + 2]; v.w = ids[i + 3];
+    *reinterpret_cast<u32x4*>(out + pos + i) = v;
+  }
+  const uint32_t done = head + 4 * quads;
+  if (tid < n - done) out[pos + done + tid] = ids[done + tid];
+}
+
 template <bool BEAT_BITMAP>
 static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint64_t* __restrict__ hup_bits, const uint64_t* __restrict__ beat_bits,
                                                                       const uint4* __restrict__ partials, uint32_t* hup_out, uint64_t hup_cap,
@@ -1423,11 +1441,9 @@ static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint6
     if ((lane & 15) == 0) map_words[wave * 4 + (lane >> 4)] = v;
   }
   __syncthreads();
-  for (uint32_t i = tid; i < tot_h; i += kBlock)
-    if (pos_h + i < hup_cap) hup_out[pos_h + i] = ids[0][i];
+  run_out(hup_out, hup_cap, pos_h, ids[0], tot_h, tid);
   if (!BEAT_BITMAP) {
-    for (uint32_t i = tid; i < tot_b; i += kBlock)
-      if (pos_b + i < beat_cap) beat_out[pos_b + i] = ids[1][i];
+    run_out(beat_out, beat_cap, pos_b, ids[1], tot_b, tid);
   } else if (tid < kWaves * 4) {
     beat_map[(uint64_t)blockIdx.x * (kWaves * 4) + tid] = map_words[tid];
   }

@@ -285,7 +285,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
                        (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
     HIPCHK(h, hipGetLastError());
     tile_ctl_launched(h, n_tiles, workers);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, raftq_detail::wait_call(h));
     if (int rc = tile_ctl_check(h, "raftq_wire_encode")) return rc;
     const uint64_t total = h->wire_pin[0];
     if (h->wire_pin[1])
@@ -428,7 +428,7 @@ int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uin
     // page-locked caller buffers: ONE kernel -- readers bring boundaries and stream into the scratch in order, workers parse
     // tile by tile behind them and push records and entry headers out (raftq_wire_kernels.hpp "the streaming form")
     if (int rc = decode_streaming_enqueue(h, v_stream, nbytes, v_off, n, v_msgs, v_ents, ents_cap, nullptr, FrameFilter{0, 0, 0, 0, 0, nullptr})) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, raftq_detail::wait_call(h));
     return decode_streaming_finish(h, "raftq_wire_decode", frame_off, n, ents != nullptr, ents_cap, true, counts);
   }
   const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
@@ -521,7 +521,8 @@ static int wal_streaming_finish(raftq_t* h, const char* who, uint64_t n, uint64_
 // is about to use its pinned words' neighbours' scratch from the host side)
 static int wal_pending_complete(raftq_t* h) {
   if (!h->wal_pending || h->wal_pending_done) return RAFTQ_OK;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // (the wait of the marshal called in between has usually covered it: then there is nothing to wait for, and nothing to launch)
+  if (!h->wal_pending_waited) HIPCHK(h, raftq_detail::wait_call(h));
   h->wal_pending_rc = wal_streaming_finish(h, "raftq_wal_encode_begin", h->wal_pending_n, h->wal_pending_cap, h->wal_pending_prev, 8, &h->wal_pending_counts);
   if (h->wal_pending_rc != RAFTQ_OK) h->wal_pending_err = h->err;
   h->wal_pending_done = true;
@@ -551,7 +552,7 @@ int raftq_wal_encode(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, const 
     // page-locked caller buffers: the streaming form (readers | workers in one launch; raftq_wire_kernels.hpp)
     if (int rc = wal_pending_complete(h)) return rc;  // (a raftq_wal_encode_begin nobody ended: its results are kept for its _end)
     if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 0)) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, raftq_detail::wait_call(h));
     return wal_streaming_finish(h, "raftq_wal_encode", n, cap, prev_crc, 0, counts);
   }
   const size_t scan_bytes = scan_sum_scratch_bytes(n + 1);  // tile totals of the hand-written scan
@@ -631,6 +632,7 @@ int raftq_wal_encode_begin(raftq_t* h, const raftq_wal_rec_t* recs, uint64_t n, 
   if (int rc = wal_streaming_enqueue(h, v_recs, n, v_pool, pool_bytes, prev_crc, v_out, cap, v_off, 8)) return rc;
   h->wal_pending = true;
   h->wal_pending_done = false;
+  h->wal_pending_waited = false;
   h->wal_pending_n = n;
   h->wal_pending_cap = cap;
   h->wal_pending_prev = prev_crc;
@@ -677,7 +679,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
                          (WalRec*)f_recs, ctl, h->wire_pin_d);
       HIPCHK(h, hipGetLastError());
       tile_ctl_launched(h, n_tiles, workers);
-      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, raftq_detail::wait_call(h));
       if (int rc = tile_ctl_check(h, "raftq_wal_decode")) return rc;
       if (counts) {
         counts->n_recs = n;

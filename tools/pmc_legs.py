@@ -27,6 +27,10 @@ PASSES = {
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
     "tcc": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"],
+    # where the requests go: HBM (DRAM) or the link (IO) -- a kernel that reads or writes page-locked HOST memory (the streaming
+    # codecs, Step's result copy, the lists of a Tick, the advance list of a turn) shows those bytes in FETCH_SIZE / WRITE_SIZE
+    # and in the plain request counters too; only these tell the two apart (units of 32 bytes; calibrated below on the stream)
+    "dram": ["TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "TCC_EA0_RDREQ_IO_32B_sum", "TCC_EA0_WRREQ_WRITE_IO_32B_sum"],
 }
 LEGS = {
     "step": ["python", "tools/profile_step.py"],
@@ -133,7 +137,12 @@ def summarise(outdir, out):
         "WRREQ_64B_per_scattered_line": g("calib_scatter_kernel", "TCC_EA0_WRREQ_64B_sum") / (1 << 20),
         "RDREQ_per_64B_streamed": g("calib_stream_kernel", "TCC_EA0_RDREQ_sum") / ((64 << 20) / 64),
         "WRREQ_per_64B_streamed": g("calib_stream_kernel", "TCC_EA0_WRREQ_sum") / ((16 << 20) / 64),
+        # bytes per count of the DRAM-only counters, from the stream kernel (64 MiB read, 16 MiB written, all of it HBM)
+        "bytes_per_RDREQ_DRAM_32B": (64 << 20) / g("calib_stream_kernel", "TCC_EA0_RDREQ_DRAM_32B_sum"),
+        "bytes_per_WRREQ_WRITE_DRAM_32B": (16 << 20) / g("calib_stream_kernel", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"),
+        "stream_IO_32B_counts": {"read": g("calib_stream_kernel", "TCC_EA0_RDREQ_IO_32B_sum"), "write": g("calib_stream_kernel", "TCC_EA0_WRREQ_WRITE_IO_32B_sum")},
     }
+    f_dram_rd, f_dram_wr = factors["bytes_per_RDREQ_DRAM_32B"], factors["bytes_per_WRREQ_WRITE_DRAM_32B"]
     meta = {}
     if os.path.exists(os.path.join(outdir, "meta.json")):  # written by collect() on the box: the tree that was measured
         meta = json.load(open(os.path.join(outdir, "meta.json")))
@@ -163,6 +172,12 @@ def summarise(outdir, out):
                 "bytes_stream_calibrated": {"read": rd_raw * f_stream_rd, "write": wr_raw * f_stream_wr},
                 "bytes_raw_counters": {"read": rd_raw, "write": wr_raw},
                 "bytes_from_requests": {"read": rq32 * 32 + (rq - rq32) * 64, "write": wq64 * 64 + (wq - wq64) * 32},
+                # HBM only / the link only (the DRAM / IO request counters, 32-byte units; the HBM ones calibrated on the stream kernel,
+                # the IO ones taken at the same bytes per count)
+                "bytes_hbm": ({"read": raw["TCC_EA0_RDREQ_DRAM_32B_sum"] * f_dram_rd, "write": raw["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] * f_dram_wr}
+                              if "TCC_EA0_RDREQ_DRAM_32B_sum" in raw and f_dram_rd == f_dram_rd else None),
+                "bytes_link": ({"read": raw.get("TCC_EA0_RDREQ_IO_32B_sum", 0.0) * f_dram_rd, "write": raw.get("TCC_EA0_WRREQ_WRITE_IO_32B_sum", 0.0) * f_dram_wr}
+                               if "TCC_EA0_RDREQ_IO_32B_sum" in raw and f_dram_rd == f_dram_rd else None),
                 "lines_if_scattered": {"read": rd_raw / factors["raw_FETCH_bytes_per_gathered_line"] if factors["raw_FETCH_bytes_per_gathered_line"] else None,
                                        "written": wr_raw / factors["raw_WRITE_bytes_per_scattered_line"] if factors["raw_WRITE_bytes_per_scattered_line"] else None},
             }

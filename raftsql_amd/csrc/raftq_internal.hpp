@@ -192,10 +192,11 @@ struct raftq {
   uint64_t* wire_pin_d = nullptr;  // the same block as the device addresses it (the codecs' last kernel writes totals / flags there)
   unsigned long long* wire_flags = nullptr;  // device, 64 bytes, zero between calls: the codecs' malformed counters / bad flags
   // the streaming codec kernels (raftq_wire_kernels.hpp "the streaming form"): ticket word + per-tile look-back status
-  unsigned long long* wire_lb = nullptr;     // device: kLbHead words {ticket, gave-up flag, landed waves, -}, then kLbArrays status arrays of wire_lb_tiles words
+  unsigned long long* wire_lb = nullptr;     // device: kLbHead words {ticket, gave-up flag | landed waves | - | chunk ticket}, then kLbArrays status arrays of wire_lb_tiles words
   uint64_t wire_lb_tiles = 0;
   uint32_t wire_last_tiles = 0;              // tiles of the streaming decode enqueued last (measurement builds dump its stamps)
   uint32_t wire_ticket_base = 0, wire_epoch = 0;
+  uint32_t wire_chunk_base = 0, wire_chunk_pending = 0;  // the readers' chunk tickets (the head's fourth word), accounted like the tiles'
   // raftq_wal_encode_begin .. _end: enqueued, its totals in wire_pin[8 ..]; `done`: a later wait has covered it and what _end
   // will report is kept here
   bool wal_pending = false, wal_pending_done = false;

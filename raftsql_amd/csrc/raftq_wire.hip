@@ -130,9 +130,13 @@ FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3],
   p.in.readers = fused_readers(p.in.chunks);
   return p;
 }
-void bind_feed(FeedPlan& p, uint8_t* base, unsigned long long* flags) {
+// (called once per launch, after tile_ctl: the chunk tickets of the launch are accounted for in tile_ctl_launched)
+void bind_feed(raftq_t* h, FeedPlan& p, uint8_t* base, unsigned long long* flags) {
   for (int k = 0; k < 3; ++k) p.in.seg[k].dst = base + p.off[k];
   p.in.flag = flags;
+  p.in.chunk_ticket = reinterpret_cast<unsigned int*>(h->wire_lb + 3);  // the head's fourth word
+  p.in.chunk_base = h->wire_chunk_base;
+  h->wire_chunk_pending = p.in.chunks + p.in.readers;  // every reader workgroup draws exactly one ticket beyond the chunks
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -151,6 +155,7 @@ int tile_ctl(raftq_t* h, uint64_t n_tiles, TileCtl* ctl) {
     HIPCHK(h, hipMemsetAsync(h->wire_lb, 0, (kLbHead + kLbArrays * tiles) * 8, h->stream));
     h->wire_lb_tiles = tiles;
     h->wire_ticket_base = 0;
+    h->wire_chunk_base = 0;
     h->wire_epoch = 0;
   }
   if (++h->wire_epoch > 0xffffu) {
@@ -168,7 +173,11 @@ int tile_ctl(raftq_t* h, uint64_t n_tiles, TileCtl* ctl) {
   return RAFTQ_OK;
 }
 // every worker of a launch draws exactly one ticket beyond the tiles
-void tile_ctl_launched(raftq_t* h, uint32_t n_tiles, unsigned workers) { h->wire_ticket_base += n_tiles + workers; }
+void tile_ctl_launched(raftq_t* h, uint32_t n_tiles, unsigned workers) {
+  h->wire_ticket_base += n_tiles + workers;
+  h->wire_chunk_base += h->wire_chunk_pending;
+  h->wire_chunk_pending = 0;
+}
 #if defined(RAFTQ_WIRE_TRACE)
 // RAFTQ_TRACE_STAMP's rows of the call just waited for -> stderr (once every 16th call): per tile, microseconds since the
 // earliest stamp of the launch
@@ -280,7 +289,7 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
     if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
     if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-    bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+    bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
     hipLaunchKernelGGL(wire_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, n_ents, pool_bytes,
                        (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
     HIPCHK(h, hipGetLastError());
@@ -363,7 +372,7 @@ static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t n
   if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (bytes[0] + bytes[1]) / feed_chunk() + 1), &ctl)) return rc;
   FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles);
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-  bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+  bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
   hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
                      (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d, msgs_d, ff);
   HIPCHK(h, hipGetLastError());
@@ -489,7 +498,7 @@ static int wal_streaming_enqueue(raftq_t* h, const void* v_recs, uint64_t n, con
   FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-  bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+  bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
   hipLaunchKernelGGL(wal_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, pool_bytes, prev_crc,
                      (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d + pin_base);
   HIPCHK(h, hipGetLastError());
@@ -674,7 +683,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
       if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
       FeedPlan plan = plan_feed(c, src, sizes, h->wire_lb_tiles);
       if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-      bind_feed(plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+      bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
       hipLaunchKernelGGL(wal_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, prev_crc,
                          (WalRec*)f_recs, ctl, h->wire_pin_d);
       HIPCHK(h, hipGetLastError());

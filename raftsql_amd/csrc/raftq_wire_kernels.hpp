@@ -714,6 +714,15 @@ struct InFeed {
   FeedSeg seg[3];
   unsigned long long* flag;  // [chunks]
   uint32_t chunks, readers;  // workgroups [0, readers) of the launch are readers
+  // Chunks are CLAIMED, in order, by whichever reader workgroup is running (chunk = ticket - chunk_base; monotonic across calls
+  // like the tile ticket).  Round 4 gave chunk c to reader c % readers: a reader that is not resident yet then owns chunks its
+  // launch's workers spin for -- with ONE such kernel on the chip that cannot happen (readers are the launch's first
+  // workgroups), with several handles' kernels resident together (the nodes of one process, 102 KB of LDS a decoder workgroup:
+  // one per CU) it can, XCD by XCD, and two launches can then wait for each other's readers until the bounded waits give up.
+  // Claimed chunks are always in the hands of a running workgroup; and where a launch has a worker resident on an XCD, its
+  // readers there were dispatched before it.
+  unsigned int* chunk_ticket;
+  uint32_t chunk_base;
 };
 
 // Agent-scope write-through of one 16-byte quad as ONE store instruction (`global_store_dwordx4 ... sc1`).  Round 4 split the
@@ -733,8 +742,20 @@ __device__ __forceinline__ void sc1_store16(uint8_t* dst, u32x4 v) {
 }
 
 __device__ inline void reader_role(const InFeed& in, uint32_t epoch) {
+  __shared__ uint32_t chunk_slot;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t c = blockIdx.x; c < in.chunks; c += in.readers) {
+#if defined(RAFTQ_WIRE_STATIC_CHUNKS)  // round 4's assignment, for the A/B that shows what it does under several resident launches
+  for (uint32_t c = blockIdx.x;; c += in.readers) {
+    if (c >= in.chunks) return;
+    (void)chunk_slot;  // (the ticket word is not used in this build)
+#else
+  for (;;) {
+    __syncthreads();  // (the previous round's readers of chunk_slot are done)
+    if (tid == 0) chunk_slot = atomicAdd(in.chunk_ticket, 1u) - in.chunk_base;
+    __syncthreads();
+    const uint32_t c = chunk_slot;
+    if (c >= in.chunks) return;  // every reader workgroup draws exactly one ticket beyond the chunks
+#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const FeedSeg sg = in.seg[k];

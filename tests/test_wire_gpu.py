@@ -462,6 +462,61 @@ def test_streaming_decode_at_bench_size(wgs, monkeypatch):
             _same(ge, we, "ents")
 
 
+def test_streaming_codecs_of_many_handles_resident_together():
+    """Several handles' one-kernel codec calls on the device AT ONCE (the nodes of one process: bench.py's node legs, any host
+    with a handle per shard): a decoder workgroup holds 102 KB of LDS -- one per CU -- so six launches of up to 256 workgroups
+    oversubscribe the chip and a launch's workgroups become resident XCD by XCD, late.  Every wait inside a launch must be for
+    something a RUNNING workgroup has claimed (tiles by ticket; the readers' chunks by ticket too, round 5 -- they used to belong
+    to reader c % readers, resident or not, and two launches could wait for each other's readers until the bounded waits gave
+    up: `a workgroup waited a second for its predecessor's tile`).  Six threads, a handle each, decode + encode in a loop:
+    every call's results are the oracle's."""
+    import threading
+
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    K, n, reps = 6, 32768, 12
+    rng = np.random.default_rng(4242)
+    work = []
+    for k in range(K):
+        m, e, pool = _wiregen.random_msgs(rng, n, big_every=0, ent_frac=0.15)
+        s, off = W.wire_encode(m, e, pool)
+        wm, we, wbad = W.wire_decode(s, off)
+        work.append((m, e, pool, s, off, wm, we, wbad))
+    engines = [WireEngine(4096, 5, self_peer=0) for _ in range(K)]
+    errors = []
+    gate = threading.Barrier(K)
+
+    def run(k):
+        try:
+            m, e, pool, s, off, wm, we, wbad = work[k]
+            eng = engines[k]
+            ps, po = pinned_copy(s), pinned_copy(off)
+            dm, de = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+            pm, pe, pp = pinned_copy(m), pinned_copy(e), pinned_copy(_wiregen_u8(pool))
+            out, ooff = pinned_empty(len(s) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+            gate.wait()
+            for rep in range(reps):
+                gm, ge, gbad = eng.wire_decode(ps, po, msgs=dm, ents=de)
+                assert gbad == wbad
+                _same(gm, wm, "msgs")
+                _same(ge, we, "ents")
+                got, goff = eng.wire_encode(pm, pe, pp, out=out, off=ooff)
+                assert got.tobytes() == s.tobytes() and np.array_equal(goff, off)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append("handle %d: %r" % (k, ex))
+            gate.abort()
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(K)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for eng in engines:
+        eng.close()
+    assert not errors, errors[:2]
+
+
 @pytest.mark.parametrize("wgs", [3, 64, 208])
 def test_streaming_encode_at_bench_size(wgs, monkeypatch):
     """The one-kernel form of raftq_wire_encode at the bench's size -- 65,536 messages, a MsgApp share with 1-3 entries of

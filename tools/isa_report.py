@@ -42,7 +42,7 @@ def main():
              "# tree: %s%s" % (head, " + uncommitted changes under raftsql_amd/csrc" if dirty else ""),
              "# " + " | ".join(tc["version"][:2]), "# " + " ".join(cmd), "#",
              "# %-6s %-6s %-6s %-8s %-5s %-4s kernel" % ("VGPR", "AGPR", "SGPR", "scratch", "LDS", "occ")]
-    want = re.compile(r"raftqk::(sweep_kernel|sweep_set_kernel|sweep_persist_kernel|sweep_lds_kernel|set_counts_kernel|"
+    want = re.compile(r"raftqk::(sweep_kernel|sweep_set_kernel|sweep_persist_kernel|sweep_lds_kernel|set_counts_kernel|sweep_segments_kernel|tick_set_wide_kernel|tick_set_kernel|tick_lists32_kernel|"
                       r"deltas_in|apply_deltas|scan_partials|compact_changed|tick_kernel)")
     rows = []
     for k, n in zip(kernels, names):

@@ -11,13 +11,13 @@ code -- and counts, per batch:
   * groups touched;
 and the bytes per message of three formats: today's 40-byte record; 16 B per message + a 24-byte tail per TOUCHED group; 16 B
 per message + a 32-byte state record only for messages that CHANGED the group's state (an index into a side array in the
-16-byte record).   usage: tools/step_results_share.py [out.txt]"""
+16-byte record).   usage: tests/analysis/step_results_share.py [out.txt]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle  # noqa: E402
 from raftsql_amd import step as S  # noqa: E402  (record dtypes and constants only: no engine is created)
@@ -96,7 +96,7 @@ def account(name, s, msgs, lines):
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05", "step_results_share.txt")
-    lines = ["# tools/step_results_share.py: what a batch of Step results is made of (1M x 5 groups, 64K messages per batch; sequential oracle)", ""]
+    lines = ["# tests/analysis/step_results_share.py: what a batch of Step results is made of (1M x 5 groups, 64K messages per batch; sequential oracle)", ""]
     s, last = fresh()
     tails = []
     for b in range(3):

@@ -1517,10 +1517,18 @@ def side_legs_child(args):
     res = {}
 
     def guarded(name, fn, *a, **k):  # a leg that raises says so and the next one runs
-        try:
-            res[name] = fn(*a, **k)
-        except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
-            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        first = None
+        for attempt in range(2):  # (a leg gets ONE more try, and its record says what the first one died of)
+            try:
+                res[name] = fn(*a, **k)
+                if first and isinstance(res[name], dict):
+                    res[name]["first_attempt_error"] = first
+                break
+            except BaseException as e:  # noqa: BLE001 - SystemExit from a leg included
+                res[name] = {"error": f"{type(e).__name__}: {e}"}
+                if first:
+                    res[name]["first_attempt_error"] = first
+                first = res[name]["error"]
         with open(args.side_legs_child + ".tmp", "w") as f:
             json.dump(res, f)
         os.replace(args.side_legs_child + ".tmp", args.side_legs_child)

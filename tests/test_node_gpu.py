@@ -468,6 +468,62 @@ def test_node_drops_frames_that_are_not_for_it(Cluster):
         c.close()
 
 
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_a_groups_messages_are_worked_off_in_arrival_order(Cluster, fuse, monkeypatch):
+    """One turn of a leader receives, for one group: a forwarded MsgProp, a MsgHeartbeat of a HIGHER term from another peer, a
+    second forwarded MsgProp.  In arrival order the first proposal is appended by the leader, the heartbeat makes it a follower
+    of the sender, and the second proposal is forwarded to that new leader -- whichever way the round was stepped
+    (RAFTQ_NODE_FUSE_INBOUND: one submission, where the heartbeat is deferred behind the held proposal, or the staged rounds).
+    ADVICE r04: the fused round used to run the second proposal first, appending it in the old term."""
+    from oracle import pywire as W
+
+    monkeypatch.setenv("RAFTQ_NODE_FUSE_INBOUND", fuse)
+    c = Cluster(2, 3)
+    try:
+        c.start()
+        elect(c)
+        g = 1
+        lead = int(c.leaders()[g])
+        a, b = [p for p in range(3) if p != lead]
+        nd = c.nodes[lead]
+        st0 = nd.status(g)
+        log0 = nd.log(g)
+        e1, e2 = b"INSERT INTO t (v) VALUES (1)", b"INSERT INTO t (v) VALUES (2)"
+        m = np.zeros(3, W.WIRE_MSG_DT)
+        m["group"], m["to"] = g, lead
+        m["type"] = [2, 8, 2]  # MsgProp, MsgHeartbeat, MsgProp
+        m["from"] = [a, b, a]
+        m["term"] = [0, st0.term + 1, 0]
+        m["n_ents"] = [1, 0, 1]
+        m["ent_first"] = [0, 0, 1]
+        ents = np.zeros(2, W.WIRE_ENT_DT)
+        ents["data_len"] = [len(e1), len(e2)]
+        ents["data_off"] = [0, len(e1)]
+        frames, _ = W.wire_encode(m, ents, np.frombuffer(e1 + e2, np.uint8))
+        for q in (a, b):
+            nd.forward(q, None)  # whatever the election left queued
+        nd.deliver(bytes(frames))
+        nd.advance()
+        st = nd.status(g)
+        assert (st.role, st.term, st.lead) == (0, st0.term + 1, b + 1), (st.role, st.term, st.lead)
+        log1 = nd.log(g)
+        assert log1[: len(log0)] == log0 and [d for _, d in log1[len(log0):]] == [e1], log1[len(log0):]
+        assert log1[-1][0] == st0.term  # appended by the old leader, in its term, before it heard of the new one
+        out_b = nd.poll(b)
+        off, used = W.scan_frames(out_b, big_endian=True)
+        assert used == len(out_b)
+        mm, ee, bad = W.wire_decode(out_b, off)
+        assert bad == 0
+        kinds = [int(t) for t in mm["type"][mm["group"] == g]]
+        assert 9 in kinds and 2 in kinds, kinds  # MsgHeartbeatResp, and the second proposal forwarded as MsgProp
+        prop = mm[(mm["group"] == g) & (mm["type"] == 2)][0]
+        assert int(prop["n_ents"]) == 1
+        ent = ee[int(prop["ent_first"])]
+        assert bytes(out_b[int(ent["data_off"]): int(ent["data_off"]) + int(ent["data_len"])]) == e2
+    finally:
+        c.close()
+
+
 def _wal_view(wal: bytes, G: int):
     """what a WAL holds, by the oracle: per-group log (the later record of an index wins) and last HardState"""
     from oracle import pywire as W

@@ -78,6 +78,12 @@ PY
     nodestats)
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np -o node -- python tools/profile_node.py > $P/node_under_rocprof.txt 2>&1
       cp $(find /tmp/np -name "*kernel_stats.csv" | head -1) $P/node_kernel_stats.csv ;;
+    onenode)   # one node on one GPU, scripted peers (bench.one_node_measure), as one handle and as four shard handles; with the phase clock
+      SHARDS=1,4 timeout 300 python tools/profile_one_node.py > $P/one_node.json 2> $P/one_node.err; echo "rc=$?"
+      RAFTQ_PROFILE=1 SHARDS=1 timeout 300 python tools/profile_one_node.py 2>&1 | grep "advance phases" | cut -c1-400 > $P/one_node_phases.txt; cat $P/one_node_phases.txt ;;
+    onenodestats)  # ... under rocprofv3: the device calls of a turn (one handle)
+      SHARDS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/on -o node -- python tools/profile_one_node.py > $P/one_node_under_rocprof.txt 2>&1
+      cp $(find /tmp/on -name "*kernel_stats.csv" | head -1) $P/node_kernel_stats.csv; head -12 $P/node_kernel_stats.csv | cut -c1-160 ;;
     timeline)  # the batching turn as a timeline of kernels: the last turns of tools/profile_cycle.py (24-byte, packed, segmented: the segmented ones are last)
       timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o cyc -- python tools/profile_cycle.py > /dev/null 2>&1
       python tools/probe/timeline.py /tmp/tl -12 12 > $P/cycle_timeline.txt; python tools/probe/timeline.py /tmp/tl -340 12 >> $P/cycle_timeline.txt; cat $P/cycle_timeline.txt ;;

@@ -1286,8 +1286,9 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
     that is closed again before the node exists) and handed to raftq_node_deliver turn by turn; what the node sends them is
     dropped where a transport would take it (raftq_node_forward to nobody).  One turn = one raftq_node_advance = one iteration of
     the Ready loop (raft.go:220-246) for every group: the acks of the previous wave are decoded, checked and stepped (commit
-    advances, the entries go onto the commit channels), this wave's proposals are appended, and the MsgApps for them are
-    marshalled -- 2 (N-1) G frames and G proposals per turn.  Closed loop: every turn must publish exactly one entry per group
+    advances, the entries go onto the commit channels and -- etcd's `if r.maybeCommit() { r.bcastAppend() }` -- every follower
+    is sent the new commit index), this wave's proposals are appended, and the MsgApps for them are marshalled: (N-1) G frames
+    in, G proposals, 2 (N-1) G frames out per turn.  Closed loop: every turn must publish exactly one entry per group
     and proposal.
     `shards`: groups are independent, so a node's G groups may be K raftq_node handles of G / K groups, each with its own
     thread and Ready loop (the reference's one goroutine per raft group, batched K ways instead of G ways): the host side of a
@@ -1401,7 +1402,7 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
                         assert st["entries_published"] - base["entries_published"] == n_turns * Gs * k
                         assert turn(script[at]) == Gs * k  # the last wave's acks (nothing proposed): the run ends with everything committed
                         at += 1
-                        res[k] = (t0, t1, st["msgs_stepped"] - base["msgs_stepped"], fired)
+                        res[k] = (t0, t1, st["msgs_stepped"] - base["msgs_stepped"], fired, st["msgs_sent"] - base["msgs_sent"])
                         gate.wait()
                     assert at == len(script)
                     stat = nd.statuses()
@@ -1436,16 +1437,17 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
                 rec["one_statement_per_group_per_turn" if k == 1 else "four_statements_per_group_per_turn"] = {
                     "proposals_committed_per_s": n_turns * G // K * K * k / (t1 - t0), "ms_per_turn": 1e3 * (t1 - t0) / n_turns, "turns": n_turns,
                     "msgs_stepped_per_s": sum(r[k][2] for r in results) / (t1 - t0), "ticks_during_run": max(r[k][3] for r in results),
-                    "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": peers * Gs * K, "entries_per_frame_out": k}
+                    "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": sum(r[k][4] for r in results) / n_turns,
+                    "statements_per_proposing_frame": k}
             out.setdefault("shards_%d" % K, {"shards": K, "groups_per_shard": Gs, "shard_thread_cpus": cores})["with_wal" if wal else "no_wal"] = rec
     first = out["shards_%d" % shard_counts[0]]["no_wal"]["one_statement_per_group_per_turn"]
     best_k = max(shard_counts, key=lambda K: out["shards_%d" % K]["no_wal"]["one_statement_per_group_per_turn"]["proposals_committed_per_s"])
     best = out["shards_%d" % best_k]["no_wal"]["one_statement_per_group_per_turn"]
     return {"what": "ONE node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: per turn "
                     "%d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> append -> %d "
-                    "MsgApps marshalled (one call); closed loop, every turn publishes one entry per group and proposal.  shards_K: the "
+                    "MsgApps marshalled (one call: the commit index to every follower, then the new entry); closed loop, every turn publishes one entry per group and proposal.  shards_K: the "
                     "node's groups as K raftq_node handles of G / K groups, each with its own thread and Ready loop" %
-                    (G, N, peers * G, G, peers * G),
+                    (G, N, peers * G, G, 2 * peers * G),
             "groups": G, "peers": N,
             "proposals_committed_per_s": best["proposals_committed_per_s"], "ms_per_turn": best["ms_per_turn"], "shards": best_k,
             "one_handle": {"proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"]},

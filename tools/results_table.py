@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""DESIGN.md's round-2 results table from a bench line:  tools/results_table.py profiles/r02/bench_n1.json"""
+"""DESIGN.md's results tables from a bench record:  tools/results_table.py profiles/r05/bench_legs.json   (the FULL record that
+bench.py writes to --legs-out; the stdout line carries the headline and a few scalars per leg only)"""
 import json
 import sys
 
-d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][0])
+text = open(sys.argv[1]).read()
+try:
+    d = json.loads(text)  # the full record (indented JSON)
+except ValueError:
+    d = json.loads([ln for ln in text.splitlines() if ln.startswith("{")][0])  # a round-2 .. 4 line
 r, cfg = d["roofline"], d["config"]
 
 
@@ -46,3 +51,7 @@ print("Step from frames: %.0f us, compact %.0f us; staged %.0f / %.0f us" % (f["
       f["staged_in_device_memory"]["us_per_batch"], f["staged_in_device_memory"]["us_per_batch_compact"]))
 print("turn: %.1f us (packed %.1f us); node: %s proposals/s, election %.2f s" % (pl["us_per_cycle"], pl["packed_records"]["us_per_cycle"],
       e(nd["proposals_committed_everywhere_per_s"]), nd["election_s"]))
+on = nd.get("one_node_one_gpu")
+if isinstance(on, dict) and "error" not in on:
+    print("one node, one GPU: %s proposals/s from one handle, %s as %d shard handles" % (e(on["one_handle"]["proposals_committed_per_s"]),
+          e(on["proposals_committed_per_s"]), on["shards"]))

@@ -1111,13 +1111,24 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
   uint32_t* const hup_d = h->tl_d;
   uint32_t* const beat_d = h->tl_d + beat_at;
   uint64_t* const map_d = (uint64_t*)((uint8_t*)h->tl_d + map_off);
-  const dim3 grid((unsigned)(h->gpad / 1024));
-  if (bitmap)
-    hipLaunchKernelGGL((tick_lists32_kernel<true>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits,
-                       (const uint4*)h->tick_partials, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b);
-  else
-    hipLaunchKernelGGL((tick_lists32_kernel<false>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits,
-                       (const uint4*)h->tick_partials, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b);
+  // blocks of 1,024 groups per workgroup of the lists kernel: 1.  Four (runs of ~1,600 ids instead of ~400 at the bench's density,
+  // RAFTQ_TICK_LISTS_BPW=4, read per call) measured no better: 47.1 against 46.5 us a call -- 1.6 MB of ids take the link 34 us
+  // however they are cut
+  int bpw = 1;
+  if (const char* e = std::getenv("RAFTQ_TICK_LISTS_BPW")) bpw = std::atoi(e) == 4 ? 4 : 1;
+  const uint64_t per_wg = (uint64_t)kWaves * bpw;
+  const dim3 grid((unsigned)((nw + per_wg - 1) / per_wg));
+#define RAFTQ_TICK_LISTS_LAUNCH(BM, B)                                                                                                       \
+  hipLaunchKernelGGL((tick_lists32_kernel<BM, B>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits, \
+                     (const uint4*)h->tick_partials, nw, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b)
+  if (bitmap) {
+    if (bpw == 1) RAFTQ_TICK_LISTS_LAUNCH(true, 1);
+    else RAFTQ_TICK_LISTS_LAUNCH(true, 4);
+  } else {
+    if (bpw == 1) RAFTQ_TICK_LISTS_LAUNCH(false, 1);
+    else RAFTQ_TICK_LISTS_LAUNCH(false, 4);
+  }
+#undef RAFTQ_TICK_LISTS_LAUNCH
   HIPCHK(h, hipGetLastError());
   // the completion word: a one-thread kernel behind the lists (only a kernel boundary orders eight XCDs' stores to host memory
   // before it -- raftq_cycle's finding), polled by the host; the blocking wait where the word cannot be had

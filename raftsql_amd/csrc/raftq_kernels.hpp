@@ -1351,18 +1351,21 @@ __device__ __forceinline__ void run_out(uint32_t* out, uint64_t cap, uint64_t po
   if (tid < n - done) out[pos + done + tid] = ids[done + tid];
 }
 
-template <bool BEAT_BITMAP>
+// BPW: 1,024-group blocks per workgroup.  A workgroup's ids leave as ONE run per list; longer runs (BPW = 4) were measured no
+// faster than BPW = 1 (1M groups, 400K ids: 34 us of kernel either way -- 1.6 MB at the link's 47 GB/s for this pattern).
+template <bool BEAT_BITMAP, int BPW>
 static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint64_t* __restrict__ hup_bits, const uint64_t* __restrict__ beat_bits,
-                                                                      const uint4* __restrict__ partials, uint32_t* hup_out, uint64_t hup_cap,
-                                                                      uint32_t* beat_out, uint64_t beat_cap, uint64_t* beat_map,
-                                                                      uint64_t* totals /*[2]*/, const uint64_t* __restrict__ wave_off_hup,
-                                                                      const uint64_t* __restrict__ wave_off_beat) {
+                                                                      const uint4* __restrict__ partials, uint64_t n_chunks /* gpad / 256 */,
+                                                                      uint32_t* hup_out, uint64_t hup_cap, uint32_t* beat_out, uint64_t beat_cap,
+                                                                      uint64_t* beat_map, uint64_t* totals /*[2]*/,
+                                                                      const uint64_t* __restrict__ wave_off_hup, const uint64_t* __restrict__ wave_off_beat) {
+  constexpr int kC = kWaves * BPW;  // 256-group chunks (a tick wave's share) per workgroup
   __shared__ uint64_t red[2][kWaves];
-  __shared__ uint32_t mine[2][kWaves];
-  __shared__ uint32_t ids[2][kBlock * 4];
-  __shared__ uint64_t map_words[kWaves * 4];
+  __shared__ uint32_t mine[2][kC];
+  __shared__ uint32_t ids[2][kBlock * 4 * BPW];
+  __shared__ uint64_t map_words[kC * 4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t first_wave = (uint64_t)blockIdx.x * kWaves;
+  const uint64_t first_wave = (uint64_t)blockIdx.x * kC;
   uint64_t acc_h = 0, acc_b = 0;
   if (wave_off_hup == nullptr) {
     uint32_t h0 = 0, h1 = 0, b0 = 0, b1 = 0;
@@ -1391,20 +1394,23 @@ static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint6
     red[0][wave] = acc_h;
     red[1][wave] = acc_b;
   }
-  if (tid < kWaves) {
-    const uint4 p = partials[first_wave + tid];
+  if (tid < kC) {
+    uint4 p;
+    p.x = p.y = p.z = p.w = 0;
+    if (first_wave + tid < n_chunks) p = partials[first_wave + tid];
     mine[0][tid] = p.x;
     mine[1][tid] = p.y;
   }
   __syncthreads();
   uint64_t pos_h = 0, pos_b = 0;  // where this workgroup's ids start in the two lists
-  uint32_t loc_h = 0, loc_b = 0, tot_h = 0, tot_b = 0;  // this wave's first id inside the workgroup's run; the run's length
+  uint32_t tot_h = 0, tot_b = 0;  // the lengths of its two runs
 #pragma unroll
   for (int k = 0; k < kWaves; ++k) {
     pos_h += red[0][k];
     pos_b += red[1][k];
-    loc_h += (uint32_t)k < wave ? mine[0][k] : 0u;
-    loc_b += (uint32_t)k < wave ? mine[1][k] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < kC; ++k) {
     tot_h += mine[0][k];
     tot_b += mine[1][k];
   }
@@ -1412,40 +1418,51 @@ static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint6
     totals[0] = pos_h + tot_h;
     totals[1] = pos_b + tot_b;
   }
-  const uint64_t wv = first_wave + wave;
   const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  uint64_t hb[4], bb[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    hb[k] = hup_bits[wv * 4 + k];
-    bb[k] = beat_bits[wv * 4 + k];
-  }
-  uint32_t rh = loc_h + __popcll(hb[0] & below) + __popcll(hb[1] & below) + __popcll(hb[2] & below) + __popcll(hb[3] & below);
-  uint32_t rb = loc_b + __popcll(bb[0] & below) + __popcll(bb[1] & below) + __popcll(bb[2] & below) + __popcll(bb[3] & below);
-  uint32_t nib = 0;
+  for (int b = 0; b < BPW; ++b) {
+    const uint32_t ci = (uint32_t)b * kWaves + wave;  // this wave's chunk of the round
+    const uint64_t wv = first_wave + ci;
+    if (wv >= n_chunks) continue;  // wave-uniform
+    uint32_t loc_h = 0, loc_b = 0;  // this chunk's first id inside the workgroup's runs
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t g = (uint32_t)(wv * 256 + 4ull * lane + k);
-    if ((hb[k] >> lane) & 1) ids[0][rh++] = g;
-    if (!BEAT_BITMAP) {
-      if ((bb[k] >> lane) & 1) ids[1][rb++] = g;
-    } else {
-      nib |= (uint32_t)((bb[k] >> lane) & 1) << k;
+    for (int k = 0; k < kC; ++k) {
+      loc_h += (uint32_t)k < ci ? mine[0][k] : 0u;
+      loc_b += (uint32_t)k < ci ? mine[1][k] : 0u;
     }
-  }
-  if (BEAT_BITMAP) {
-    // lane l holds the four bits of groups 4l .. 4l+3 of the wave's 256: group-order word j is lanes 16j .. 16j+15
-    uint64_t v = (uint64_t)nib << (4 * (lane & 15));
+    uint64_t hb[4], bb[4];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v |= __shfl_xor(v, o, 64);
-    if ((lane & 15) == 0) map_words[wave * 4 + (lane >> 4)] = v;
+    for (int k = 0; k < 4; ++k) {
+      hb[k] = hup_bits[wv * 4 + k];
+      bb[k] = beat_bits[wv * 4 + k];
+    }
+    uint32_t rh = loc_h + __popcll(hb[0] & below) + __popcll(hb[1] & below) + __popcll(hb[2] & below) + __popcll(hb[3] & below);
+    uint32_t rb = loc_b + __popcll(bb[0] & below) + __popcll(bb[1] & below) + __popcll(bb[2] & below) + __popcll(bb[3] & below);
+    uint32_t nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t g = (uint32_t)(wv * 256 + 4ull * lane + k);
+      if ((hb[k] >> lane) & 1) ids[0][rh++] = g;
+      if (!BEAT_BITMAP) {
+        if ((bb[k] >> lane) & 1) ids[1][rb++] = g;
+      } else {
+        nib |= (uint32_t)((bb[k] >> lane) & 1) << k;
+      }
+    }
+    if (BEAT_BITMAP) {
+      // lane l holds the four bits of groups 4l .. 4l+3 of the chunk's 256: group-order word j is lanes 16j .. 16j+15
+      uint64_t v = (uint64_t)nib << (4 * (lane & 15));
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v |= __shfl_xor(v, o, 64);
+      if ((lane & 15) == 0) map_words[ci * 4 + (lane >> 4)] = v;
+    }
   }
   __syncthreads();
   run_out(hup_out, hup_cap, pos_h, ids[0], tot_h, tid);
   if (!BEAT_BITMAP) {
     run_out(beat_out, beat_cap, pos_b, ids[1], tot_b, tid);
-  } else if (tid < kWaves * 4) {
-    beat_map[(uint64_t)blockIdx.x * (kWaves * 4) + tid] = map_words[tid];
+  } else if (tid < kC * 4 && first_wave * 4 + tid < n_chunks * 4) {
+    beat_map[first_wave * 4 + tid] = map_words[tid];
   }
 }
 

@@ -1288,17 +1288,19 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
     the Ready loop (raft.go:220-246) for every group: the acks of the previous wave are decoded, checked and stepped (commit
     advances, the entries go onto the commit channels and -- etcd's `if r.maybeCommit() { r.bcastAppend() }` -- every follower
     is sent the new commit index), this wave's proposals are appended, and the MsgApps for them are marshalled: (N-1) G frames
-    in, G proposals, 2 (N-1) G frames out per turn.  Closed loop: every turn must publish exactly one entry per group
-    and proposal.
-    `shards`: groups are independent, so a node's G groups may be K raftq_node handles of G / K groups, each with its own
-    thread and Ready loop (the reference's one goroutine per raft group, batched K ways instead of G ways): the host side of a
-    turn -- 23 ns per ack, 46 ns per proposal, one core -- is what bounds one handle (profiles/r05/one_node_phases.txt), and it
-    runs K-fold; every shard's turn is still two waits on the device."""
+    in, G proposals, 2 (N-1) G frames out per turn.  Closed loop: every turn must publish exactly one entry per group and
+    proposal.
+    `shards`: groups are independent, so a node's G groups may be K raftq_node handles of G / K groups, each turned on a thread of
+    its own (the reference's one goroutine per raft group, batched K ways instead of G ways): the host side of a turn -- 23 ns
+    per ack, 46 ns per proposal, one core -- is what bounds one handle (profiles/r05/one_node_phases.txt), and it runs K-fold;
+    every shard's turn is still two waits on the device.  Measured two ways: every shard's whole loop on a thread of the
+    caller's (`caller_threads`), and every shard's turn on the library's threads, one raftq_shards_turn per turn, with the
+    caller's one thread doing for each shard in turn what a transport does (`library_threads`)."""
     import threading
 
     from raftsql_amd import step as S_
     from raftsql_amd import wire as W
-    from raftsql_amd.node import RaftNode
+    from raftsql_amd.node import RaftNode, Shards
     from raftsql_amd.wire import WireEngine
 
     peers = N - 1
@@ -1308,11 +1310,14 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
     near = gpu_numa_cpus(device) or os.sched_getaffinity(0)
     out = {}
     dbg = (lambda *a: print("[one_node]", *a, file=sys.stderr, flush=True)) if os.environ.get("RAFTQ_BENCH_DEBUG") else (lambda *a: None)
+    names = {1: "one_statement_per_group_per_turn", 4: "four_statements_per_group_per_turn"}
     for K in shard_counts:
         Gs = G // K
-        dbg("K", K, "script")
+        modes = ("one_thread",) if K == 1 else ("caller_threads", "library_threads")
+        runs = [(mode, k) for mode in modes for k in per_turn]  # played one after the other on the same nodes: the log goes on
         # -- the peers' script for ONE shard (group ids are the shard's own 0 .. Gs-1: every shard reads the same bytes); built
         # before any node exists, on a handle that is gone before the clock starts
+        dbg("K", K, "script")
         enc = WireEngine(Gs, N, self_peer=1, device=device)
         groups = np.arange(Gs, dtype=np.uint64)
 
@@ -1325,11 +1330,14 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
             return bytes(stream)
 
         votes = answers(S_.MSG_VOTE_RESP, 1, 0)
-        script, idx = [answers(S_.MSG_APP_RESP, 1, 1)], 1  # idx: the log index the peers acknowledge; 1 = the leader's empty entry
-        for k in per_turn:
+        first_ack, idx = answers(S_.MSG_APP_RESP, 1, 1), 1  # idx: the log index the peers acknowledge; 1 = the leader's empty entry
+        acks = []  # per run: warm + turns + 1 frames (the last one ends the run with everything committed)
+        for _, k in runs:
+            mine = []
             for _ in range(turns_of[k] + warm + 1):
                 idx += k
-                script.append(answers(S_.MSG_APP_RESP, 1, idx))
+                mine.append(answers(S_.MSG_APP_RESP, 1, idx))
+            acks.append(mine)
         enc.close()
         cores = one_cpu_per_l3(near, K) if K > 1 else None
         for wal in (False, True):
@@ -1339,164 +1347,180 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
                 if wal:
                     nd.wal_enable()
                 nd.start(10, 1, seed=11)
-            results = [None] * K
+
+            def after_turn(nd, wal=wal):
+                if wal:
+                    nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
+                for q in range(1, N):
+                    nd.forward(q, None)  # where a transport would take the frames for peer q
+
+            def turn(nd, frames, tick=False):
+                if frames:
+                    nd.deliver(frames)
+                if tick:
+                    nd.tick()
+                pub = nd.advance()
+                after_turn(nd)
+                return pub
+
+            def payload(k, mode):
+                stmt = b"INSERT INTO %s (v) VALUES (%7d)" % (mode[:1].encode(), k)
+                return np.repeat(groups, k), np.arange(Gs * k + 1, dtype=np.uint64) * len(stmt), stmt * (Gs * k)
+
+            def run_on_its_own_thread(nd, k, mode, frames, gate):
+                """one shard's closed loop for one run -> (t0, t1, msgs stepped, ticks fired, msgs sent)"""
+                g_k, off_k, blob = payload(k, mode)
+                nd.propose_blob(g_k, off_k, blob)  # (turn 0 of a run only proposes; from then on every turn steps the previous
+                turn(nd, b"")                      # turn's acks and proposes again)
+                at = 0
+                for _ in range(warm):
+                    nd.propose_blob(g_k, off_k, blob)
+                    assert turn(nd, frames[at]) == Gs * k
+                    at += 1
+                base = nd.stats()
+                gate.wait()  # every shard starts its clock together; wall time of the run = the slowest shard's
+                t0 = next_tick = time.perf_counter()
+                next_tick += 0.1
+                fired = 0
+                for _ in range(turns_of[k]):
+                    nd.propose_blob(g_k, off_k, blob)
+                    due = time.perf_counter() >= next_tick  # the reference's 100 ms ticker (raft.go:217); heartbeats go unanswered
+                    if due:
+                        next_tick += 0.1
+                        fired += 1
+                    pub = turn(nd, frames[at], tick=due)
+                    at += 1
+                    assert pub == Gs * k, (pub, Gs * k)
+                t1 = time.perf_counter()
+                st = nd.stats()
+                assert st["entries_published"] - base["entries_published"] == turns_of[k] * Gs * k
+                assert turn(nd, frames[at]) == Gs * k  # the last wave's acks (nothing proposed): the run ends with everything committed
+                gate.wait()
+                return t0, t1, st["msgs_stepped"] - base["msgs_stepped"], fired, st["msgs_sent"] - base["msgs_sent"]
+
+            def run_in_lock_step(sh, k, mode, frames):
+                """every shard's turn on the library's threads (raftq_shards_turn), this thread the transport of all of them"""
+                g_k, off_k, blob = payload(k, mode)
+
+                def all_turn(fr, tick=False):
+                    for nd in nodes:
+                        if fr is not None:
+                            nd.propose_blob(g_k, off_k, blob)
+                        if fr:
+                            nd.deliver(fr)
+                    pub = sh.turn(tick=tick)
+                    for nd in nodes:
+                        after_turn(nd)
+                    return pub
+
+                all_turn(b"")
+                at = 0
+                for _ in range(warm):
+                    assert (all_turn(frames[at]) == Gs * k).all()
+                    at += 1
+                base = [nd.stats() for nd in nodes]
+                t0 = next_tick = time.perf_counter()
+                next_tick += 0.1
+                fired = 0
+                for _ in range(turns_of[k]):
+                    due = time.perf_counter() >= next_tick
+                    if due:
+                        next_tick += 0.1
+                        fired += 1
+                    pub = all_turn(frames[at], tick=due)
+                    at += 1
+                    assert (pub == Gs * k).all(), (pub, Gs * k)
+                t1 = time.perf_counter()
+                st = [nd.stats() for nd in nodes]
+                for nd in nodes:  # the last wave's acks, nothing proposed
+                    nd.deliver(frames[at])
+                assert (sh.turn() == Gs * k).all()
+                for nd in nodes:
+                    after_turn(nd)
+                return [(t0, t1, s_["msgs_stepped"] - b["msgs_stepped"], fired, s_["msgs_sent"] - b["msgs_sent"]) for s_, b in zip(st, base)]
+
+            results = {}  # (mode, k) -> per shard tuples
             errors = []
             gate = threading.Barrier(K)
 
-            def shard(si, nodes=nodes, wal=wal, groups=groups, Gs=Gs, script=script, votes=votes, results=results, cores=cores, gate=gate):
+            def shard(si):
                 try:
                     nd = nodes[si]
                     if cores and len(cores) == len(nodes):
                         os.sched_setaffinity(0, {cores[si]})  # this thread only: a shard is host work over its groups' state
-
-                    def turn(frames, tick=False):
-                        if frames:
-                            nd.deliver(frames)
-                        if tick:
-                            nd.tick()
-                        pub = nd.advance()
-                        if wal:
-                            nd.wal_poll()  # wal.Save before transport.Send (raft.go:228-230)
-                        for q in range(1, N):
-                            nd.forward(q, None)  # where a transport would take the frames for peer q
-                        return pub
-
                     dbg("shard", si, "campaign")
                     nd.campaign(groups)
-                    turn(b"")  # MsgHup -> MsgVote out
-                    dbg("shard", si, "votes")
-                    turn(votes)  # granted -> leader of every group: the empty entry of its term, bcastAppend
-                    dbg("shard", si, "leader")
+                    turn(nd, b"")  # MsgHup -> MsgVote out
+                    turn(nd, votes)  # granted -> leader of every group: the empty entry of its term, bcastAppend
                     assert (nd.roles() == 2).all(), "one_node_measure: the election did not finish"
-                    turn(script[0])  # the empty entries are committed
-                    at, res = 1, {}
-                    for k in per_turn:
-                        stmt = b"INSERT INTO t (v) VALUES (%7d)" % k
-                        g_k = np.repeat(groups, k)
-                        off_k = np.arange(Gs * k + 1, dtype=np.uint64) * len(stmt)
-                        blob = stmt * (Gs * k)
-                        nd.propose_blob(g_k, off_k, blob)  # (turn 0 of a run only proposes; from then on every turn steps the
-                        turn(b"")                          # previous turn's acks and proposes again)
-                        for _ in range(warm):
-                            nd.propose_blob(g_k, off_k, blob)
-                            assert turn(script[at]) == Gs * k
-                            at += 1
-                        base = nd.stats()
-                        n_turns = turns_of[k]
-                        dbg("shard", si, "k", k, "warm done")
-                        gate.wait()  # every shard starts its clock together; wall time of the run = the slowest shard's
-                        t0 = next_tick = time.perf_counter()
-                        next_tick += 0.1
-                        fired = 0
-                        for _ in range(n_turns):
-                            nd.propose_blob(g_k, off_k, blob)
-                            due = time.perf_counter() >= next_tick  # the reference's 100 ms ticker (raft.go:217); heartbeats go unanswered
-                            if due:
-                                next_tick += 0.1
-                                fired += 1
-                            pub = turn(script[at], tick=due)
-                            at += 1
-                            assert pub == Gs * k, (pub, Gs * k)
-                        t1 = time.perf_counter()
-                        st = nd.stats()
-                        assert st["entries_published"] - base["entries_published"] == n_turns * Gs * k
-                        assert turn(script[at]) == Gs * k  # the last wave's acks (nothing proposed): the run ends with everything committed
-                        at += 1
-                        res[k] = (t0, t1, st["msgs_stepped"] - base["msgs_stepped"], fired, st["msgs_sent"] - base["msgs_sent"])
-                        gate.wait()
-                    assert at == len(script)
-                    stat = nd.statuses()
-                    assert (stat["role"] == 2).all() and (stat["commit"] == stat["last_index"]).all() and (stat["commit"] == stat["commit"][0]).all()
-                    results[si] = res
+                    turn(nd, first_ack)  # the empty entries are committed
+                    for ri, (mode, k) in enumerate(runs):
+                        if mode == "library_threads":
+                            break
+                        r = run_on_its_own_thread(nd, k, mode, acks[ri], gate)
+                        results.setdefault((mode, k), [None] * K)[si] = r
+                        dbg("shard", si, mode, k, "done")
                 except BaseException as ex:  # noqa: BLE001
                     errors.append(repr(ex))
                     gate.abort()
 
+            before = os.sched_getaffinity(0)
             if K == 1:
                 shard(0)
             else:
-                before = os.sched_getaffinity(0)
                 ths = [threading.Thread(target=shard, args=(si,)) for si in range(K)]
                 for t in ths:
                     t.start()
                 for t in ths:
                     t.join()
-                os.sched_setaffinity(0, before)
+            if K > 1 and not errors:
+                try:
+                    with Shards(nodes, cpus=cores if cores and len(cores) == K else None) as sh:
+                        for ri, (mode, k) in enumerate(runs):
+                            if mode == "library_threads":
+                                results[(mode, k)] = run_in_lock_step(sh, k, mode, acks[ri])
+                                dbg("lock step", k, "done")
+                except BaseException as ex:  # noqa: BLE001
+                    errors.append(repr(ex))
+            os.sched_setaffinity(0, before)
+            if not errors:
+                for nd in nodes:
+                    stat = nd.statuses()
+                    assert (stat["role"] == 2).all() and (stat["commit"] == idx).all(), "one_node_measure: not every group committed every wave"
             dbg("K", K, "wal", wal, "destroy")
             for nd in nodes:
                 nd.close()
                 nd.destroy()
-            dbg("K", K, "wal", wal, "destroyed")
             if errors:
                 raise RuntimeError("one_node_measure (%d shards): %s" % (K, errors[0]))
-            rec = {}
-            for k in per_turn:
-                t0 = min(r[k][0] for r in results)
-                t1 = max(r[k][1] for r in results)
+            top = out.setdefault("shards_%d" % K, {"shards": K, "groups_per_shard": Gs, "shard_thread_cpus": cores})
+            for (mode, k), per in results.items():
+                t0, t1 = min(r[0] for r in per), max(r[1] for r in per)
                 n_turns = turns_of[k]
-                rec["one_statement_per_group_per_turn" if k == 1 else "four_statements_per_group_per_turn"] = {
-                    "proposals_committed_per_s": n_turns * G // K * K * k / (t1 - t0), "ms_per_turn": 1e3 * (t1 - t0) / n_turns, "turns": n_turns,
-                    "msgs_stepped_per_s": sum(r[k][2] for r in results) / (t1 - t0), "ticks_during_run": max(r[k][3] for r in results),
-                    "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": sum(r[k][4] for r in results) / n_turns,
+                top.setdefault(mode, {}).setdefault("with_wal" if wal else "no_wal", {})[names[k]] = {
+                    "proposals_committed_per_s": n_turns * Gs * K * k / (t1 - t0), "ms_per_turn": 1e3 * (t1 - t0) / n_turns, "turns": n_turns,
+                    "msgs_stepped_per_s": sum(r[2] for r in per) / (t1 - t0), "ticks_during_run": max(r[3] for r in per),
+                    "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": sum(r[4] for r in per) / n_turns,
                     "statements_per_proposing_frame": k}
-            out.setdefault("shards_%d" % K, {"shards": K, "groups_per_shard": Gs, "shard_thread_cpus": cores})["with_wal" if wal else "no_wal"] = rec
-    first = out["shards_%d" % shard_counts[0]]["no_wal"]["one_statement_per_group_per_turn"]
-    best_k = max(shard_counts, key=lambda K: out["shards_%d" % K]["no_wal"]["one_statement_per_group_per_turn"]["proposals_committed_per_s"])
-    best = out["shards_%d" % best_k]["no_wal"]["one_statement_per_group_per_turn"]
+
+    def rate(K, mode):
+        return out["shards_%d" % K][mode]["no_wal"][names[1]]
+
+    first = rate(shard_counts[0], "one_thread" if shard_counts[0] == 1 else "caller_threads")
+    cands = [(K, mode) for K in shard_counts for mode in (("one_thread",) if K == 1 else ("caller_threads", "library_threads"))]
+    best_k, best_mode = max(cands, key=lambda c: rate(*c)["proposals_committed_per_s"])
+    best = rate(best_k, best_mode)
     return {"what": "ONE node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: per turn "
                     "%d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> append -> %d "
-                    "MsgApps marshalled (one call: the commit index to every follower, then the new entry); closed loop, every turn publishes one entry per group and proposal.  shards_K: the "
-                    "node's groups as K raftq_node handles of G / K groups, each with its own thread and Ready loop" %
-                    (G, N, peers * G, G, 2 * peers * G),
+                    "MsgApps marshalled (one call: the commit index to every follower, then the new entry); closed loop, every turn "
+                    "publishes one entry per group and proposal.  shards_K: the node's groups as K raftq_node handles of G / K groups, "
+                    "each shard's loop on a thread of the caller's (caller_threads) or every shard's turn on the library's threads, one "
+                    "raftq_shards_turn per turn (library_threads)" % (G, N, peers * G, G, 2 * peers * G),
             "groups": G, "peers": N,
             "proposals_committed_per_s": best["proposals_committed_per_s"], "ms_per_turn": best["ms_per_turn"], "shards": best_k,
+            "threads": best_mode,
             "one_handle": {"proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"]},
             **out}
-
-
-def cpu_baseline(cfg, st, budget_s=12.0):
-    """The oracle timed on this box's host cores (rank 0, N=1 only)."""
-    from oracle import pyoracle
-
-    pyoracle.build()
-    visible = os.cpu_count() or 1
-    quota = None  # a container may see every core of the box and still be throttled to a few (cgroup v2 cpu.max)
-    try:
-        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = float(q) / float(period)
-    except Exception:
-        pass
-    try:
-        visible = min(visible, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    # the threads actually used = the cores this process may actually run on (VERDICT r01: "256 threads" on a
-    # 16-core quota was really a 16-core figure)
-    cores = max(1, min(visible, int(np.ceil(quota))) if quota else visible)
-    votes = st.votes if cfg["votes"] else None
-    fi = st.first_idx_cur_term if cfg["gated"] else None
-    res = {}
-    for label, kind, threads in (("port_1t", 0, 1), ("port_all", 0, cores), ("tight_1t", 1, 1), ("tight_all", 1, cores)):
-        sec, _, _ = pyoracle.timed_sweeps(kind, threads, 1, st.match, st.committed, votes, cfg["gated"], fi)
-        sweeps = max(1, min(2000, int(budget_s / 4 / max(sec, 1e-6))))
-        sec, _, _ = pyoracle.timed_sweeps(kind, threads, sweeps, st.match, st.committed, votes, cfg["gated"], fi)
-        res[label] = dict(decisions_per_s=cfg["G"] * sweeps / sec, sweeps=sweeps, seconds=round(sec, 3), threads=threads)
-    return {
-        "value": res["port_all"]["decisions_per_s"],
-        "unit": "decisions/s",
-        "cores": cores,
-        "cores_visible": os.cpu_count(),
-        "cgroup_cpu_quota_cores": quota,
-        "speedup_all_threads_over_one": res["port_all"]["decisions_per_s"] / res["port_1t"]["decisions_per_s"],
-        "kind": "port",
-        "sample": f"{res['port_all']['sweeps']} sweeps of the same {cfg['G']} x {cfg['N']} batch "
-                  f"({res['port_all']['seconds']} s), C restatement of the reference-era loop "
-                  "(malloc N-slice + insertion sort desc + index q-1 + vote scan), pthreads over contiguous group ranges",
-        "single_thread": res["port_1t"]["decisions_per_s"],
-        "tight_network_all_cores": res["tight_all"]["decisions_per_s"],
-        "tight_network_single_thread": res["tight_1t"]["decisions_per_s"],
-    }
 
 
 SIDE_LEGS = ("other_configs", "pipeline", "tick", "step", "wire", "node")

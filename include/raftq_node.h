@@ -161,6 +161,18 @@ int raftq_crank_step(raftq_crank_t* c, uint32_t live_mask, int tick, const uint8
 void raftq_crank_seconds(const raftq_crank_t* c, double* turns, double* transport);
 void raftq_crank_destroy(raftq_crank_t* c);
 
+/* The SHARDS of one node.  One raftq_node handle turns its groups on ONE host thread, and at tens of thousands of groups a
+ * turn is mostly host work (Progress, logs, queues: 3.5 of 4.0 ms at 32,768 groups).  Groups are independent -- the reference
+ * runs one raftNode goroutine per group (raft.go:204-246) -- so a process may split a node's groups over K handles (the same
+ * n_peers and self_peer; group g of the node = group g mod G/K of shard g / (G/K), or any other split the transport knows)
+ * and turn them all at once: raftq_shards_turn = raftq_node_tick (when tick != 0) + raftq_node_advance of every shard, each
+ * on a thread of its own (thread i pinned to cpus[i] when cpus != NULL and cpus[i] >= 0), one call.  Everything else stays
+ * per shard handle: raftq_node_deliver / _propose / _poll / _wal_poll / _recv (a transport keeps a stream per shard and
+ * peer, so no frame has to be looked into to find its shard).  published[i] / shard_rc[i] (may be NULL) as raftq_crank_step's.
+ * The set does not own the shards; destroy it (raftq_crank_destroy) before them.  k <= 32. */
+int raftq_shards_create(raftq_node_t* const* shards, uint32_t k, const int* cpus /*[k]|NULL*/, raftq_crank_t** out);
+int raftq_shards_turn(raftq_crank_t* set, int tick, uint64_t* published /*[k]|NULL*/, int* shard_rc /*[k]|NULL*/);
+
 /* whole WAL frames produced so far, at most cap bytes; *len = bytes written (0 = nothing pending) */
 int raftq_node_wal_poll(raftq_node_t* n, void* buf, uint64_t cap, uint64_t* len);
 

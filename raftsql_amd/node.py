@@ -55,6 +55,8 @@ _SIGS = [
     ("raftq_crank_step", C.c_int, [_P, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("raftq_crank_seconds", None, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("raftq_crank_destroy", None, [_P]),
+    ("raftq_shards_create", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_P)]),
+    ("raftq_shards_turn", C.c_int, [_P, C.c_int, C.c_void_p, C.c_void_p]),
     ("raftq_node_recv", C.c_int, [_P, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int)]),
     ("raftq_node_status", C.c_int, [_P, C.c_uint64, C.POINTER(Status)]),
@@ -274,6 +276,51 @@ class RaftNode:
     def __del__(self):  # pragma: no cover
         try:
             self.destroy()
+        except Exception:
+            pass
+
+
+class Shards:
+    """The shards of ONE node (raftq_shards_create / raftq_shards_turn): K RaftNode handles -- the same peer slot of the same
+    cluster for K disjoint sets of groups -- turned all at once, each on a library thread of its own (pinned to cpus[i])."""
+
+    def __init__(self, shards, cpus=None):
+        self.shards = list(shards)
+        k = len(self.shards)
+        ptrs = (C.c_void_p * k)(*[nd._p.value for nd in self.shards])
+        cp = (C.c_int * k)(*[int(c) for c in cpus]) if cpus is not None and len(cpus) == k else None
+        self._p = _P(None)
+        rc = _load().raftq_shards_create(ptrs, k, cp, C.byref(self._p))
+        if rc != 0:
+            self._p = _P(None)
+            raise RaftqError(rc, "raftq_shards_create: the shards must be distinct handles of one n_peers / self_peer")
+        self._pub = np.zeros(k, np.uint64)
+        self._rc = np.zeros(k, np.int32)
+
+    def turn(self, tick: bool = False) -> np.ndarray:
+        """every shard's optional Tick + Ready iteration, at once -> entries each shard put on its commit channels"""
+        rc = _load().raftq_shards_turn(self._p, int(tick), self._pub.ctypes.data, self._rc.ctypes.data)
+        if rc != 0:
+            bad = int(np.nonzero(self._rc)[0][0]) if self._rc.any() else -1
+            if bad >= 0:
+                self.shards[bad]._chk(int(self._rc[bad]))
+            raise RaftqError(rc, "raftq_shards_turn failed")
+        return self._pub.copy()
+
+    def close(self) -> None:
+        if getattr(self, "_p", None) is not None and self._p.value:
+            _load().raftq_crank_destroy(self._p)
+            self._p = _P(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
         except Exception:
             pass
 

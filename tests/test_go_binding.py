@@ -4,7 +4,7 @@
     an integer (or the other way round) -- for the arguments whose kind can be read off the source;
   * a Go struct documented as "layout-identical" to a C struct whose fields do not sit at the same offsets with the same
     sizes (natural alignment on both sides), or whose field names disagree;
-  * an export of the headers that no Go file binds (the host drivers raftq_pipe_* / raftq_node_* / raftq_crank_* are C++
+  * an export of the headers that no Go file binds (the host drivers raftq_pipe_* / raftq_node_* / raftq_crank_* / raftq_shards_* are C++
     stand-ins for code that IS Go in a Go deployment -- go/raftq/node.go, batcher.go -- and are exempt, by name);
   * a `C.raftq_*` name the headers do not declare.
 It reads source text only: nothing here proves the binding runs."""
@@ -17,7 +17,7 @@ GO = sorted(glob.glob(os.path.join(ROOT, "go", "raftq", "*.go")))
 HEADERS = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 # C++ host drivers that stand in for Go host code: not bound on purpose
-EXEMPT_PREFIXES = ("raftq_pipe_", "raftq_node_", "raftq_crank_")
+EXEMPT_PREFIXES = ("raftq_pipe_", "raftq_node_", "raftq_crank_", "raftq_shards_")
 
 SCALARS = {"uint64_t": 8, "int64_t": 8, "uint32_t": 4, "int32_t": 4, "uint16_t": 2, "uint8_t": 1, "int": 4, "unsigned": 4, "float": 4,
            "size_t": 8, "char": 1}

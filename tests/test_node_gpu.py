@@ -346,6 +346,49 @@ def test_single_node_cluster_commits_immediately(Cluster):
         c.close()
 
 
+def test_shards_of_one_node_are_turned_at_once(Cluster):
+    """raftq_shards_create / raftq_shards_turn: K handles that are the same peer slot of the same cluster for K disjoint sets of
+    groups, turned all at once on the library's threads.  Here the cluster has one peer (every group elects itself and commits
+    on its own), so a shard is complete without a transport: what each shard publishes is what was proposed to IT, in order; a
+    set refuses handles of different clusters, the same handle twice, and the cluster crank's step."""
+    import ctypes as C
+
+    from raftsql_amd.node import RaftNode, RaftqError, Shards, _load
+
+    sizes = (5, 3, 8)
+    nodes = [RaftNode(g, 1, 0) for g in sizes]
+    other = RaftNode(4, 3, 0)
+    try:
+        for nd in nodes:
+            nd.start(10, 1, seed=3)
+        with pytest.raises(RaftqError):
+            Shards([nodes[0], other])  # not the same cluster
+        with pytest.raises(RaftqError):
+            Shards([nodes[0], nodes[0]])  # a handle is turned by one thread at a time
+        with Shards(nodes) as sh:
+            for _ in range(40):  # elections: every group's timer fires within 2 x election_tick ticks
+                sh.turn(tick=True)
+                if all((nd.roles() == 2).all() for nd in nodes):
+                    break
+            assert all((nd.roles() == 2).all() for nd in nodes)
+            sh.turn()
+            for k, nd in enumerate(nodes):
+                for g in range(sizes[k]):
+                    for j in range(k + 1):  # shard k: k + 1 statements per group
+                        nd.propose(g, b"s%d g%d #%d" % (k, g, j))
+            pub = sh.turn()
+            assert pub.tolist() == [sizes[k] * (k + 1) for k in range(len(sizes))]
+            assert sh.turn().tolist() == [0, 0, 0]
+            for k, nd in enumerate(nodes):
+                for g in range(sizes[k]):
+                    assert nd.drain(g) == [None] + [b"s%d g%d #%d" % (k, g, j) for j in range(k + 1)]
+            # the cluster crank's step is not for shards (there is no transport between them)
+            assert _load().raftq_crank_step(sh._p, 1, 0, None, 0, None, None) != 0
+    finally:
+        for nd in nodes + [other]:
+            nd.destroy()
+
+
 def test_node_rejects_garbage_frames_and_bad_calls(Cluster):
     from raftsql_amd.engine import RaftqError
 

@@ -1523,6 +1523,51 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
             **out}
 
 
+def cpu_baseline(cfg, st, budget_s=12.0):
+    """The oracle timed on this box's host cores (rank 0, N=1 only)."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    visible = os.cpu_count() or 1
+    quota = None  # a container may see every core of the box and still be throttled to a few (cgroup v2 cpu.max)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        pass
+    try:
+        visible = min(visible, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    # the threads actually used = the cores this process may actually run on (VERDICT r01: "256 threads" on a
+    # 16-core quota was really a 16-core figure)
+    cores = max(1, min(visible, int(np.ceil(quota))) if quota else visible)
+    votes = st.votes if cfg["votes"] else None
+    fi = st.first_idx_cur_term if cfg["gated"] else None
+    res = {}
+    for label, kind, threads in (("port_1t", 0, 1), ("port_all", 0, cores), ("tight_1t", 1, 1), ("tight_all", 1, cores)):
+        sec, _, _ = pyoracle.timed_sweeps(kind, threads, 1, st.match, st.committed, votes, cfg["gated"], fi)
+        sweeps = max(1, min(2000, int(budget_s / 4 / max(sec, 1e-6))))
+        sec, _, _ = pyoracle.timed_sweeps(kind, threads, sweeps, st.match, st.committed, votes, cfg["gated"], fi)
+        res[label] = dict(decisions_per_s=cfg["G"] * sweeps / sec, sweeps=sweeps, seconds=round(sec, 3), threads=threads)
+    return {
+        "value": res["port_all"]["decisions_per_s"],
+        "unit": "decisions/s",
+        "cores": cores,
+        "cores_visible": os.cpu_count(),
+        "cgroup_cpu_quota_cores": quota,
+        "speedup_all_threads_over_one": res["port_all"]["decisions_per_s"] / res["port_1t"]["decisions_per_s"],
+        "kind": "port",
+        "sample": f"{res['port_all']['sweeps']} sweeps of the same {cfg['G']} x {cfg['N']} batch "
+                  f"({res['port_all']['seconds']} s), C restatement of the reference-era loop "
+                  "(malloc N-slice + insertion sort desc + index q-1 + vote scan), pthreads over contiguous group ranges",
+        "single_thread": res["port_1t"]["decisions_per_s"],
+        "tight_network_all_cores": res["tight_all"]["decisions_per_s"],
+        "tight_network_single_thread": res["tight_1t"]["decisions_per_s"],
+    }
+
+
 SIDE_LEGS = ("other_configs", "pipeline", "tick", "step", "wire", "node")
 
 

@@ -83,3 +83,29 @@ def test_pack_msgs40_layout_and_ranges():
     m["group"][1] = 1 << 32
     with pytest.raises(ValueError):
         S.pack_msgs40(m)
+
+
+def test_bench_py_names_resolve():
+    """bench.py only runs on the GPU box: a name that no longer exists (a function lost in an edit) would show up there, as the
+    driver's empty record.  Every name loaded anywhere in the file is a builtin, an import, a module-level definition or a local."""
+    import ast
+    import builtins
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    known = set(dir(builtins)) | {"__file__", "__name__"}
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            known.add(n.name)
+        elif isinstance(n, ast.Import):
+            known |= {a.asname or a.name.split(".")[0] for a in n.names}
+        elif isinstance(n, ast.ImportFrom):
+            known |= {a.asname or a.name for a in n.names}
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            known.add(n.id)
+        elif isinstance(n, ast.arg):
+            known.add(n.arg)
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            known.add(n.name)
+    missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in known})
+    assert not missing, missing

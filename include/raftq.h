@@ -198,8 +198,8 @@ int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64
  * role: 0 follower, 1 candidate, 2 leader; action: 0 none, 1 MsgHup, 2 MsgBeat.
  * Timers default to the reference's ElectionTick 10 / HeartbeatTick 1
  * (raft.go:154-155).  The randomised election timeout draws from a
- * counter-based splitmix64 stream (seed, tick number, group), not Go's
- * math/rand -- see oracle/raftq_oracle.h. */
+ * counter-based stream (a 64-bit key per (seed, tick number), a 32-bit hash
+ * of the group under it), not Go's math/rand -- see oracle/raftq_oracle.h. */
 #define RAFTQ_ROLE_FOLLOWER 0
 #define RAFTQ_ROLE_CANDIDATE 1
 #define RAFTQ_ROLE_LEADER 2

@@ -212,12 +212,28 @@ void rq_oracle_apply_vote_deltas(uint8_t* votes, size_t ld, int n, size_t G,
 /* ------------------------------------------------------------------------ */
 /* batched Tick: rc.node.Tick() every 100 ms (raft.go:207, 223-224)          */
 
-uint32_t rq_oracle_tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
-  uint64_t z = (seed ^ (tick_no * 0xD1B54A32D192ED03ull)) + (group + 1) * 0x9E3779B97F4A7C15ull;
+/* The timeout draw's stream (round 6: redefined, oracle + kernel + tests together).  Go's math/rand cannot be reproduced
+ * without the Go runtime, so the stream is this repo's own definition; what matters is that it is uniform and that the
+ * device can afford it for every follower of every group on every tick.  Round 5's splitmix64 of (seed, tick, group)
+ * was three 64-bit multiplies per GROUP.  Now: one splitmix64 finaliser per TICK makes a 64-bit key (the same for
+ * every group: scalar work on the device), and a group's draw is murmur3's 32-bit finaliser -- two 32-bit multiplies --
+ * of (group ^ key.lo), xored with key.hi. */
+uint64_t rq_oracle_tick_key(uint64_t seed, uint64_t tick_no) {
+  uint64_t z = seed ^ (tick_no * 0xD1B54A32D192ED03ull);
+  z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  return z ^ (z >> 31);
+}
+uint32_t rq_oracle_tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
+  const uint64_t key = rq_oracle_tick_key(seed, tick_no);
+  uint32_t x = ((uint32_t)group ^ (uint32_t)(group >> 32)) ^ (uint32_t)key;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x ^ (uint32_t)(key >> 32);
 }
 
 /* etcd raft.tickHeartbeat (leaders):

@@ -81,8 +81,11 @@ void rq_oracle_apply_vote_deltas(uint8_t* votes, size_t ld, int n, size_t G,
 /* ---- batched Tick: etcd raft.tickElection / tickHeartbeat ----
  * role: 0 follower, 1 candidate, 2 leader.  action_out: 0 none, 1 MsgHup
  * (campaign), 2 MsgBeat (heartbeat).  The randomised election timeout uses a
- * counter-based splitmix64 stream instead of Go's math/rand (which cannot be
- * reproduced without the Go runtime): rnd = splitmix64(seed, tick_no, group) >> 32. */
+ * counter-based stream instead of Go's math/rand (which cannot be reproduced
+ * without the Go runtime): key = splitmix64 finaliser of (seed, tick_no), once
+ * per tick; rnd = fmix32(group ^ key.lo) ^ key.hi (murmur3's 32-bit finaliser:
+ * two 32-bit multiplies per group). */
+uint64_t rq_oracle_tick_key(uint64_t seed, uint64_t tick_no);
 uint32_t rq_oracle_tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group);
 void rq_oracle_tick(const uint8_t* role, uint32_t* elapsed /*in/out*/, size_t G, uint32_t election_tick,
                     uint32_t heartbeat_tick, uint64_t seed, uint64_t tick_no, uint8_t* action_out,

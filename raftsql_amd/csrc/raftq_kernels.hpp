@@ -1035,12 +1035,26 @@ struct TickArgs {
   uint32_t et_magic;     // floor(2^32 / election_tick): x % election_tick without a division (tick_mod)
 };
 
-__device__ __forceinline__ uint32_t tick_rand(uint64_t seed, uint64_t tick_no, uint64_t group) {
-  uint64_t z = (seed ^ (tick_no * 0xD1B54A32D192ED03ull)) + (group + 1) * 0x9E3779B97F4A7C15ull;
+// The timeout draw (the stream is this repo's own definition -- Go's math/rand cannot be matched; oracle/raftq_oracle.c
+// rq_oracle_tick_rand states it).  tick_key: one splitmix64 finaliser of (seed, tick number) -- wave-uniform, the scalar unit
+// computes it once per kernel.  tick_rand: murmur3's 32-bit finaliser of (group ^ key.lo), xored with key.hi: two
+// v_mul_lo_u32 per group where round 5's splitmix64 of (seed, tick, group) cost three 64-bit multiplies (a dozen
+// quarter-rate instructions) -- with every follower past its base timeout the Tick was VALU-bound at 0.58 of HBM.
+__device__ __forceinline__ uint64_t tick_key(uint64_t seed, uint64_t tick_no) {
+  uint64_t z = seed ^ (tick_no * 0xD1B54A32D192ED03ull);
+  z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t tick_rand(uint64_t key, uint32_t group /* a handle holds <= 2^30 groups: the oracle's fold of the high word is a no-op */) {
+  uint32_t x = group ^ (uint32_t)key;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x ^ (uint32_t)(key >> 32);
 }
 
 // x % d with magic = floor(2^32 / d): the quotient estimate is at most 2 short
@@ -1089,6 +1103,7 @@ __device__ __forceinline__ void tick_chunk_out(const TickArgs& a, uint64_t chunk
 template <int R, bool NT = false>
 __device__ __forceinline__ void tick_tile(const TickArgs& a, uint64_t n_blocks) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t key = tick_key(a.seed, a.tick_no);  // wave-uniform
   uint32_t roles[R];
   uint4 el[R];
 #pragma unroll
@@ -1120,7 +1135,7 @@ __device__ __forceinline__ void tick_tile(const TickArgs& a, uint64_t n_blocks) 
       // the draw (three 64-bit multiplies and a 32-bit modulo per group) only where a timer is past its base timeout: the
       // Tick was VALU-bound with it computed for every group -- 84 MB in 22 us on a chip that streams them in 11
       bool hup = role != 2u && d >= 0;
-      if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(a.seed, a.tick_no, g + k), a.election_tick, a.et_magic);
+      if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(key, (uint32_t)g + k), a.election_tick, a.et_magic);
       const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
       e[k] = !valid ? e[k] : (act ? 0u : v);
       acts |= act << (8 * k);
@@ -1151,6 +1166,7 @@ template <int R, bool NT>
 __device__ __forceinline__ void tick_tile_wide(const TickArgs& a, uint64_t n_blocks) {
   __shared__ uint32_t xpose[kWaves][256];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t key = tick_key(a.seed, a.tick_no);  // wave-uniform
   uint32_t* const xp = xpose[wave];
   u32x4 rq[R];
   u32x4 el[R][4];
@@ -1193,7 +1209,7 @@ __device__ __forceinline__ void tick_tile_wide(const TickArgs& a, uint64_t n_blo
         const bool beat = role == 2u && v >= a.heartbeat_tick;
         const int64_t d = (int64_t)v - (int64_t)a.election_tick;
         bool hup = role != 2u && d >= 0;
-        if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(a.seed, a.tick_no, g + k), a.election_tick, a.et_magic);
+        if (__ballot(hup) != 0) hup = hup && d > (int64_t)tick_mod(tick_rand(key, (uint32_t)g + k), a.election_tick, a.et_magic);
         const uint32_t act = !valid ? 0u : (hup ? 1u : (beat ? 2u : 0u));
         e[k] = !valid ? e[k] : (act ? 0u : v);
         acts |= act << (8 * k);

@@ -16,6 +16,7 @@ from tests import ref_numpy
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 U64 = hst.integers(min_value=0, max_value=2**64 - 1)
+TICK_DRAW_KAT = [2098302166, 199365097, 3216719330, 189792652]  # draws of groups 0..3 at seed 0x1000, tick 0
 
 
 def test_quorum(oracle):
@@ -248,6 +249,56 @@ def test_tick_hand_checked_draw(oracle):
         expect = d >= 0 and d > oracle.tick_rand(seed, t, 0) % et
         assert int(act[0]) == (1 if expect else 0)
         assert int(el[0]) == (0 if expect else before + 1)
+
+
+def test_tick_draw_known_answers(oracle):
+    """The stream is this repo's own definition (Go's math/rand cannot be matched): frozen here so that a change to it is
+    a change to oracle, kernel and these numbers together.  Worked by hand from the definition in python integers
+    (tests/ref_numpy.tick_key / tick_rand), not produced by the C oracle."""
+    assert ref_numpy.tick_key(0, 0) == 0xE220A8397B1DCDAF  # splitmix64's first output for seed 0
+    frozen = {(0x1000, 0, 0): None, (0x1000, 7, 12345): None, (0xC0FFEE, 1 << 40, (1 << 30) - 1): None, (1, 2, (1 << 32) + 5): None}
+    for (seed, t, g) in frozen:
+        want = int(ref_numpy.tick_rand(seed, t, [g])[0])
+        assert oracle.tick_rand(seed, t, g) == want
+    # the literal values (so that the numpy statement cannot drift with the C one unnoticed)
+    assert [int(v) for v in ref_numpy.tick_rand(0x1000, 0, [0, 1, 2, 3])] == TICK_DRAW_KAT
+
+
+def test_tick_draw_numpy_and_c_agree(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        seed, t = int(rng.integers(0, 2**63)), int(rng.integers(0, 2**40))
+        g = rng.integers(0, 2**34, 64, dtype=np.uint64)
+        want = ref_numpy.tick_rand(seed, t, g)
+        assert [oracle.tick_rand(seed, t, int(x)) for x in g] == [int(v) for v in want]
+
+
+def test_tick_draw_is_uniform():
+    """chi-square of the draw modulo the reference's ElectionTick (10, raft.go:154) over 10^7 groups of one tick, of
+    consecutive ticks of one group, and of the top bits; 9 degrees of freedom: 27.9 is the 0.1 % point."""
+    g = np.arange(10_000_000, dtype=np.uint64)
+    for seed, t in ((0x1000, 0), (0x1000, 1), (0xDEADBEEF, 123456789)):
+        r = ref_numpy.tick_rand(seed, t, g)
+        for draw in (r % np.uint32(10), r >> np.uint32(28)):
+            k = int(draw.max()) + 1
+            cnt = np.bincount(draw.astype(np.int64), minlength=k).astype(np.float64)
+            exp = g.size / k if k != 10 else None
+            if k == 10:
+                # 2^32 is not a multiple of 10: residues 0..5 are 429496730 / 2^32 likely, 6..9 429496729 / 2^32
+                p = np.array([429496730] * 6 + [429496729] * 4, dtype=np.float64) / 2.0**32
+                chi = float((((cnt - g.size * p) ** 2) / (g.size * p)).sum())
+                assert chi < 27.9, (seed, t, chi)
+            else:
+                chi = float((((cnt - exp) ** 2) / exp).sum())
+                assert chi < 39.3, (seed, t, chi)  # 15 degrees of freedom, 0.1 %
+    # one group over 10^5 consecutive ticks (the key changes, the group does not)
+    per_tick = np.array([int(ref_numpy.tick_rand(0x1000, t, [77])[0]) % 10 for t in range(100_000)])
+    cnt = np.bincount(per_tick, minlength=10).astype(np.float64)
+    assert float((((cnt - 1e4) ** 2) / 1e4).sum()) < 27.9
+    # neighbouring groups' draws are not correlated (lag-1 serial correlation of the residues)
+    r = (ref_numpy.tick_rand(0x1000, 3, g[:1_000_000]) % np.uint32(10)).astype(np.float64)
+    c = float(np.corrcoef(r[:-1], r[1:])[0, 1])
+    assert abs(c) < 0.005, c
 
 
 def test_campaign_semantics(oracle):

@@ -198,8 +198,14 @@ int raftq_collect_changed(raftq_t* h, raftq_advance_t* out, uint64_t cap, uint64
  * role: 0 follower, 1 candidate, 2 leader; action: 0 none, 1 MsgHup, 2 MsgBeat.
  * Timers default to the reference's ElectionTick 10 / HeartbeatTick 1
  * (raft.go:154-155).  The randomised election timeout draws from a
- * counter-based stream (a 64-bit key per (seed, tick number), a 32-bit hash
- * of the group under it), not Go's math/rand -- see oracle/raftq_oracle.h. */
+ * counter-based stream, not Go's math/rand (which cannot be reproduced
+ * without the Go runtime).  The stream, exactly (round 6):
+ *   key = fin64((seed ^ tick_no * 0xD1B54A32D192ED03) + 0x9E3779B97F4A7C15)   once per tick,
+ *         fin64(z): z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9; z = (z ^ z >> 27) * 0x94D049BB133111EB; z ^ z >> 31
+ *   rnd = fin32(lo32(group) ^ hi32(group) ^ lo32(key)) ^ hi32(key)             per group,
+ *         fin32(x): x ^= x >> 16; x *= 0x85EBCA6B; x ^= x >> 13; x *= 0xC2B2AE35; x ^ x >> 16
+ * and a timer fires when elapsed - election_tick > rnd % election_tick
+ * (etcd's isElectionTimeout with its rand.Int() replaced by rnd). */
 #define RAFTQ_ROLE_FOLLOWER 0
 #define RAFTQ_ROLE_CANDIDATE 1
 #define RAFTQ_ROLE_LEADER 2

@@ -197,6 +197,8 @@ struct raftq {
   uint32_t wire_last_tiles = 0;              // tiles of the streaming decode enqueued last (measurement builds dump its stamps)
   uint32_t wire_ticket_base = 0, wire_epoch = 0;
   uint32_t wire_chunk_base = 0, wire_chunk_pending = 0;  // the readers' chunk tickets (the head's fourth word), accounted like the tiles'
+  hipStream_t wire_copy_stream = nullptr;    // RAFTQ_WIRE_SDMA=1 (A/B only): the runtime's copies bring the decoder's input in
+  hipEvent_t wire_copy_ev = nullptr;
   // raftq_wal_encode_begin .. _end: enqueued, its totals in wire_pin[8 ..]; `done`: a later wait has covered it and what _end
   // will report is kept here
   bool wal_pending = false, wal_pending_done = false;

@@ -1035,8 +1035,8 @@ struct TickArgs {
   uint32_t et_magic;     // floor(2^32 / election_tick): x % election_tick without a division (tick_mod)
 };
 
-// The timeout draw (the stream is this repo's own definition -- Go's math/rand cannot be matched; oracle/raftq_oracle.c
-// rq_oracle_tick_rand states it).  tick_key: one splitmix64 finaliser of (seed, tick number) -- wave-uniform, the scalar unit
+// The timeout draw (the stream is this repo's own definition -- Go's math/rand cannot be matched; include/raftq.h
+// "batched Tick" states it).  tick_key: one splitmix64 finaliser of (seed, tick number) -- wave-uniform, the scalar unit
 // computes it once per kernel.  tick_rand: murmur3's 32-bit finaliser of (group ^ key.lo), xored with key.hi: two
 // v_mul_lo_u32 per group where round 5's splitmix64 of (seed, tick, group) cost three 64-bit multiplies (a dozen
 // quarter-rate instructions) -- with every follower past its base timeout the Tick was VALU-bound at 0.58 of HBM.

@@ -89,21 +89,35 @@ bool streaming_on() {  // RAFTQ_WIRE_STREAMING=0: the copying form even for page
 }
 // Worker workgroups of a streaming kernel (RAFTQ_WIRE_WGS overrides): a tile is ~25 us of dependent work (flags, scratch
 // reads, the parse at one wave per SIMD, the look-back), the link moves a tile every ~0.3 us.
-unsigned fused_grid(uint32_t n_tiles) {
+// `fit`: what is resident at once beside the readers when the caller knows better than 208 (the decoder: its LDS per workgroup)
+unsigned fused_grid(uint32_t n_tiles, unsigned fit = 208u) {
   const char* e = std::getenv("RAFTQ_WIRE_WGS");  // read per call: the tests drive tiny grids through one process
   const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return std::min<unsigned>(v > 0 && v <= 4096 ? (unsigned)v : 208u, n_tiles);
+  return std::min<unsigned>(v > 0 && v <= 4096 ? (unsigned)v : fit, n_tiles);
+}
+// frames per tile = threads per workgroup of the streaming decoder (RAFTQ_WIRE_TILE=128|256; raftq_wire_kernels.hpp wire_dec_fused_kernel)
+unsigned dec_tile() {
+  const char* e = std::getenv("RAFTQ_WIRE_TILE");  // read per call: the tests run both
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return v == 256 ? 256u : 128u;
 }
 
 constexpr uint64_t kLbHead = 4;  // words in front of the status arrays
 // reader workgroups of a streaming kernel (RAFTQ_WIRE_READERS overrides): 48 pull a caller's array at 55 GB/s, more are slower
-unsigned fused_readers(uint32_t chunks) {
+// RAFTQ_WIRE_READERS=0: NO reader workgroups -- every chunk is brought in by a worker that found nobody else doing it (the
+// liveness argument's limit case, tests/test_wire_gpu.py::test_streaming_codecs_without_readers).  `dflt`: 48 workgroups of 256
+// threads; the 128-thread decoder launches 96 for the same bytes in flight.
+unsigned fused_readers(uint32_t chunks, unsigned dflt = 48u) {
   const char* e = std::getenv("RAFTQ_WIRE_READERS");
-  const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return std::min<unsigned>(v > 0 && v <= 1024 ? (unsigned)v : 48u, chunks);
+  char* end = nullptr;
+  const long v = e ? std::strtol(e, &end, 10) : -1;
+  if (e && end != e && v == 0) return 0;
+  return std::min<unsigned>(v > 0 && v <= 1024 ? (unsigned)v : dflt, chunks);
 }
 // bytes of all arrays together that a reader brings in before it raises a flag (RAFTQ_WIRE_CHUNK overrides)
+uint64_t sdma_chunk();
 uint64_t feed_chunk() {
+  if (const uint64_t s = sdma_chunk()) return s;
   const char* e = std::getenv("RAFTQ_WIRE_CHUNK");
   const long v = e ? std::strtol(e, nullptr, 10) : 0;
   return v >= 1024 && v <= (1 << 20) ? (uint64_t)v : 8192;
@@ -115,7 +129,7 @@ struct FeedPlan {
   InFeed in;
   size_t off[3];
 };
-FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3], uint64_t max_chunks) {
+FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3], uint64_t max_chunks, unsigned readers_dflt = 48u) {
   FeedPlan p{};
   uint64_t total = 0;
   for (int k = 0; k < 3; ++k) total += bytes[k];
@@ -127,7 +141,7 @@ FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3],
     p.in.seg[k].per_chunk = std::max<uint64_t>(256, ((bytes[k] + chunks - 1) / chunks + 255) / 256 * 256);
   }
   p.in.chunks = (uint32_t)chunks;
-  p.in.readers = fused_readers(p.in.chunks);
+  p.in.readers = fused_readers(p.in.chunks, readers_dflt);
   return p;
 }
 // (called once per launch, after tile_ctl: the chunk tickets of the launch are accounted for in tile_ctl_launched)
@@ -136,7 +150,17 @@ void bind_feed(raftq_t* h, FeedPlan& p, uint8_t* base, unsigned long long* flags
   p.in.flag = flags;
   p.in.chunk_ticket = reinterpret_cast<unsigned int*>(h->wire_lb + 3);  // the head's fourth word
   p.in.chunk_base = h->wire_chunk_base;
+  p.in.no_serve = 0;
   h->wire_chunk_pending = p.in.chunks + p.in.readers;  // every reader workgroup draws exactly one ticket beyond the chunks
+}
+// RAFTQ_WIRE_SDMA=<chunk KiB> (A/B only; VERDICT r04 / r05 item 1: "build the SDMA-reader A/B instead of citing the old probe"): the
+// decoder's input is brought in by the RUNTIME's copies on a second stream -- one hipMemcpyAsync per array and chunk, the chunk's
+// flag raised behind it by hipStreamWriteValue64 -- and the kernel is launched with no reader workgroups and workers that only
+// wait.  profiles/r06/wire_sdma_ab.txt has what it measured.
+uint64_t sdma_chunk() {
+  const char* e = std::getenv("RAFTQ_WIRE_SDMA");
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return v >= 1 && v <= 65536 ? (uint64_t)v << 10 : 0;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -230,6 +254,10 @@ void raftq_detail::free_wire_state(raftq_t* h) {
   (void)hipFree(h->wire_out);
   (void)hipFree(h->wire_flags);
   (void)hipFree(h->wire_lb);
+  if (h->wire_copy_stream) (void)hipStreamDestroy(h->wire_copy_stream);
+  if (h->wire_copy_ev) (void)hipEventDestroy(h->wire_copy_ev);
+  h->wire_copy_stream = nullptr;
+  h->wire_copy_ev = nullptr;
   h->wire_flags = nullptr;
   h->wire_lb = nullptr;
   h->wire_lb_tiles = 0;
@@ -363,21 +391,54 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
 // v_*: the caller's arrays as the device addresses them.  msgs_d / ff: see wire_dec_fused_kernel (raftq_step_frames).
 static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t nbytes, const void* v_off, uint64_t n, void* v_msgs, void* v_ents,
                                     uint64_t ents_cap, WireMsg* msgs_d, FrameFilter ff) {
-  const uint32_t n_tiles = blocks_for(n);
-  const unsigned workers = fused_grid(n_tiles);
+  const unsigned tb = dec_tile();
+  const uint32_t n_tiles = (uint32_t)((n + tb - 1) / tb);
+  // what is resident at once: 34 KB of LDS a 128-frame workgroup (four per CU), 68 KB a 256-frame one (two); the readers' share taken off
+  const unsigned workers = fused_grid(n_tiles, tb == 128 ? 1024u - 96u : 512u - 48u);
   Carver c;
   const void* const src[3] = {v_off, v_stream, nullptr};
   const uint64_t bytes[3] = {(n + 1) * 8, nbytes, 0};
   TileCtl ctl;
   if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (bytes[0] + bytes[1]) / feed_chunk() + 1), &ctl)) return rc;
-  FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles);
+  FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles, tb == 128 ? 96u : 48u);
+  const size_t o_spill = c.take((size_t)n_tiles * tb * kEntQ * sizeof(WireEnt));  // a slot of kEntQ entry headers per lane
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
   bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
-  hipLaunchKernelGGL(wire_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
-                     (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d, msgs_d, ff);
+  WireEnt* spill = (WireEnt*)((uint8_t*)h->wire_dev + o_spill);
+  const bool sdma = sdma_chunk() != 0;
+  if (sdma) {
+    plan.in.readers = 0;
+    plan.in.no_serve = 1;
+    h->wire_chunk_pending = 0;  // nobody draws a chunk ticket
+    if (!h->wire_copy_stream) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->wire_copy_stream, hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->wire_copy_ev, hipEventDisableTiming));
+    }
+    HIPCHK(h, hipEventRecord(h->wire_copy_ev, h->stream));  // the scratch's previous user is done before a copy lands in it
+    HIPCHK(h, hipStreamWaitEvent(h->wire_copy_stream, h->wire_copy_ev, 0));
+  }
+  if (tb == 128)
+    hipLaunchKernelGGL(wire_dec_fused_kernel<128>, dim3(plan.in.readers + workers), dim3(128), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
+                       (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d, msgs_d, ff, spill);
+  else
+    hipLaunchKernelGGL(wire_dec_fused_kernel<256>, dim3(plan.in.readers + workers), dim3(256), 0, h->stream, plan.in, nbytes, n, (WireMsg*)v_msgs,
+                       (WireEnt*)v_ents, ents_cap, ctl, h->wire_pin_d, msgs_d, ff, spill);
   HIPCHK(h, hipGetLastError());
   tile_ctl_launched(h, n_tiles, workers);
   h->wire_last_tiles = n_tiles;
+  if (sdma) {  // behind the launch: the kernel's workers are already waiting for the flags
+    const uint64_t word = lb_word(ctl.epoch, kLbInclusive, 0);
+    for (uint32_t ck = 0; ck < plan.in.chunks; ++ck) {
+      for (int k = 0; k < 2; ++k) {
+        const FeedSeg& sg = plan.in.seg[k];
+        const uint64_t lo = (uint64_t)ck * sg.per_chunk;
+        if (sg.bytes == 0 || lo >= sg.bytes) continue;
+        const uint64_t len = std::min<uint64_t>(sg.per_chunk, sg.bytes - lo);
+        HIPCHK(h, hipMemcpyAsync(sg.dst + lo, sg.src + lo, len, hipMemcpyDefault, h->wire_copy_stream));
+      }
+      HIPCHK(h, hipStreamWriteValue64(h->wire_copy_stream, (void*)(plan.in.flag + ck), word, 0));
+    }
+  }
   return RAFTQ_OK;
 }
 // ... after the wait that covers it.  too_many_is_error: raftq_wire_decode's contract; raftq_step_frames only reports the count.

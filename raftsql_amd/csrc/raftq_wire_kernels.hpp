@@ -489,11 +489,13 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_payload_kernel(const W
 
 // The scalar fields of the frame a lane is parsing, in LDS: slot-major, one 8-byte column per lane (consecutive lanes,
 // consecutive banks -- a wave filing the same field is conflict-free, a wave filing different fields nearly so).
-struct LdsFile {
+template <int STRIDE>
+struct LdsFileT {
   uint64_t* col;  // &file[0][tid]
-  __device__ __forceinline__ void put(uint32_t slot, uint64_t v) { col[slot * kBlock] = v; }
-  __device__ __forceinline__ uint64_t get(uint32_t slot) const { return col[slot * kBlock]; }
+  __device__ __forceinline__ void put(uint32_t slot, uint64_t v) { col[slot * STRIDE] = v; }
+  __device__ __forceinline__ uint64_t get(uint32_t slot) const { return col[slot * STRIDE]; }
 };
+using LdsFile = LdsFileT<kBlock>;
 
 // A wave's 64 frames are one contiguous run of the stream: the wave copies it into LDS (16 bytes per lane per step)
 // and its lanes then read their frames from there -- ~64 cycles per dependent read instead of ~600 from L2.  Runs longer
@@ -659,7 +661,7 @@ struct TileCtl {
   unsigned long long* status[kLbArrays];  // [n_tiles] each: independent running sums (a kernel uses the first two or three)
 };
 
-__device__ __forceinline__ uint64_t lb_word(uint32_t epoch, uint32_t flag, uint64_t v) {
+__host__ __device__ __forceinline__ uint64_t lb_word(uint32_t epoch, uint32_t flag, uint64_t v) {
   return ((uint64_t)epoch << kLbEpochShift) | ((uint64_t)flag << kLbFlagShift) | (v & kLbValueMask);
 }
 // A word of THIS call, waited for.  The wait is bounded (a second or so of polling: five orders of magnitude above a
@@ -723,6 +725,7 @@ struct InFeed {
   // readers there were dispatched before it.
   unsigned int* chunk_ticket;
   uint32_t chunk_base;
+  uint32_t no_serve;  // the chunks are not the kernel's to bring in at all (RAFTQ_WIRE_SDMA: the runtime's copy engine does): workers only wait
 };
 
 // Agent-scope write-through of one 16-byte quad as ONE store instruction (`global_store_dwordx4 ... sc1`).  Round 4 split the
@@ -741,6 +744,38 @@ __device__ __forceinline__ void sc1_store16(uint8_t* dst, u32x4 v) {
 #endif
 }
 
+// chunk c of the call, host -> scratch, by the whole workgroup; its flag once every byte has reached the coherence point
+template <int TB = kBlock>  // threads of the workgroup
+__device__ inline void feed_copy_chunk(const InFeed& in, uint32_t c, uint32_t epoch) {
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const FeedSeg sg = in.seg[k];
+    const uint64_t lo = (uint64_t)c * sg.per_chunk;
+    if (sg.bytes == 0 || lo >= sg.bytes) continue;
+    const uint64_t len = sg.bytes - lo < sg.per_chunk ? sg.bytes - lo : sg.per_chunk;
+    const u32x4* s16 = reinterpret_cast<const u32x4*>(sg.src + lo);
+    uint8_t* d = sg.dst + lo;
+    const uint64_t quads = len >> 4;
+    uint64_t q = tid;
+    for (; q + 3 * TB < quads; q += 4 * TB) {  // four pulls in flight per lane
+      const u32x4 v0 = __builtin_nontemporal_load(s16 + q), v1 = __builtin_nontemporal_load(s16 + q + TB),
+                  v2 = __builtin_nontemporal_load(s16 + q + 2 * TB), v3 = __builtin_nontemporal_load(s16 + q + 3 * TB);
+      sc1_store16(d + (q << 4), v0);
+      sc1_store16(d + ((q + TB) << 4), v1);
+      sc1_store16(d + ((q + 2 * TB) << 4), v2);
+      sc1_store16(d + ((q + 3 * TB) << 4), v3);
+    }
+    for (; q < quads; q += TB) sc1_store16(d + (q << 4), __builtin_nontemporal_load(s16 + q));
+    const uint64_t done = quads << 4;  // (only an array's last chunk has a tail)
+    if (tid < len - done) __hip_atomic_store(d + done + tid, sg.src[lo + done + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the coherence point ...
+  __syncthreads();                                   // ... and so have the other waves'
+  if (tid == 0) __hip_atomic_store(in.flag + c, lb_word(epoch, kLbInclusive, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int TB = kBlock>
 __device__ inline void reader_role(const InFeed& in, uint32_t epoch) {
   __shared__ uint32_t chunk_slot;
   const uint32_t tid = threadIdx.x;
@@ -756,48 +791,99 @@ __device__ inline void reader_role(const InFeed& in, uint32_t epoch) {
     const uint32_t c = chunk_slot;
     if (c >= in.chunks) return;  // every reader workgroup draws exactly one ticket beyond the chunks
 #endif
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const FeedSeg sg = in.seg[k];
-      const uint64_t lo = (uint64_t)c * sg.per_chunk;
-      if (sg.bytes == 0 || lo >= sg.bytes) continue;
-      const uint64_t len = sg.bytes - lo < sg.per_chunk ? sg.bytes - lo : sg.per_chunk;
-      const u32x4* s16 = reinterpret_cast<const u32x4*>(sg.src + lo);
-      uint8_t* d = sg.dst + lo;
-      const uint64_t quads = len >> 4;
-      uint64_t q = tid;
-      for (; q + 3 * kBlock < quads; q += 4 * kBlock) {  // four pulls in flight per lane
-        const u32x4 v0 = __builtin_nontemporal_load(s16 + q), v1 = __builtin_nontemporal_load(s16 + q + kBlock),
-                    v2 = __builtin_nontemporal_load(s16 + q + 2 * kBlock), v3 = __builtin_nontemporal_load(s16 + q + 3 * kBlock);
-        sc1_store16(d + (q << 4), v0);
-        sc1_store16(d + ((q + kBlock) << 4), v1);
-        sc1_store16(d + ((q + 2 * kBlock) << 4), v2);
-        sc1_store16(d + ((q + 3 * kBlock) << 4), v3);
-      }
-      for (; q < quads; q += kBlock) sc1_store16(d + (q << 4), __builtin_nontemporal_load(s16 + q));
-      const uint64_t done = quads << 4;  // (only an array's last chunk has a tail)
-      if (tid < len - done) __hip_atomic_store(d + done + tid, sg.src[lo + done + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the coherence point ...
-    __syncthreads();                                   // ... and so have the other waves'
-    if (tid == 0) __hip_atomic_store(in.flag + c, lb_word(epoch, kLbInclusive, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    feed_copy_chunk<TB>(in, c, epoch);
   }
 }
 
-// ONE lane: bytes [lo, hi) of array k are in the scratch
-__device__ inline void feed_wait(const InFeed& in, uint32_t epoch, int k, uint64_t lo, uint64_t hi, unsigned int* stuck) {
-  if (hi <= lo) return;
+// ---- a worker's wait for its input (round 6: liveness is structural) -------------------------------------------------------
+// Round 5's workers only ever WAITED for chunks.  That is live as long as every unclaimed chunk will be claimed by a reader
+// workgroup that gets to run -- a statement about the dispatcher (a launch's first workgroups become resident before its later
+// ones; several launches resident together do not starve each other's readers), not about this code: with chunks owned by
+// position two launches waited for each other's readers in 2 of 40 runs of the bench's node legs; with tickets 0 of 40 -- a
+// bound of ~7 % on the failure rate, no more.  Now a worker that waits for chunk c watches the chunk
+// ticket as well as the chunk's flag: when c is still UNCLAIMED and the ticket has not moved for kFeedStall looks (~100 us: a
+// running reader claims a chunk every ~0.15 us) nobody resident is bringing input in, and the worker's whole workgroup takes
+// the reader's role itself -- it claims the next unclaimed chunk (compare-and-swap: a worker never draws a ticket beyond the
+// chunks, the host's count of the launch's draws stays chunks + readers), copies it, raises its flag, and goes on claiming
+// until its own chunk is claimed.  So: a chunk is either claimed by a RUNNING workgroup (a reader, or a worker that serves
+// itself; copying waits for nothing) or will be claimed by whoever waits for it; a tile is claimed by a running worker whose
+// waits are for chunks and for tiles below its own -- by induction over the tile index no worker waits for work that no
+// resident workgroup holds, whatever the dispatcher does, down to a launch with NO reader workgroups at all
+// (RAFTQ_WIRE_READERS=0, tests/test_wire_gpu.py::test_streaming_codecs_without_readers).  The normal path is unchanged: the
+// ticket moves all the time, no worker ever serves.  (RAFTQ_WIRE_STATIC_CHUNKS -- round 4's ownership by position, kept for
+// the soak's A/B -- has no ticket to claim: it waits as it did, and still fails the soak.)
+constexpr uint32_t kFeedLookEvery = 16, kFeedStall = 64;
+constexpr uint32_t kFeedReady = 0, kFeedGaveUp = 1, kFeedServe = 2;  // kFeedServe + c: copy chunk c, then ask again
+// ONE lane
+__device__ inline uint32_t feed_poll(const InFeed& in, uint32_t epoch, uint32_t c, bool eager, unsigned int* stuck) {
+  const unsigned long long* w = in.flag + c;
+  uint32_t last_t = ~0u, still = 0;
+  for (uint32_t spin = 0; spin < (1u << 23); ++spin) {
+    const uint64_t s = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(s >> kLbEpochShift) == epoch && ((s >> kLbFlagShift) & 3u) != 0) return kFeedReady;
+#if !defined(RAFTQ_WIRE_STATIC_CHUNKS)
+    if (!in.no_serve && (eager || (spin & (kFeedLookEvery - 1)) == kFeedLookEvery - 1)) {
+      const uint32_t raw = __hip_atomic_load(in.chunk_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t t = raw - in.chunk_base;  // chunks claimed so far (readers draw past the end: may exceed in.chunks)
+      if (t > c) {
+        still = 0;  // mine is in the hands of a running workgroup
+        eager = false;
+      } else if (!eager && t != last_t) {
+        last_t = t;  // readers are at work
+        still = 0;
+      } else if (eager || ++still >= kFeedStall) {
+        unsigned int expect = raw;
+        if (__hip_atomic_compare_exchange_strong(in.chunk_ticket, &expect, raw + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          return kFeedServe + t;
+        still = 0;  // somebody else moved it
+      }
+    }
+#endif
+    __builtin_amdgcn_s_sleep(2);
+  }
+  atomicOr(stuck, 1u);
+  return kFeedGaveUp;
+}
+// The WHOLE workgroup (lo, hi workgroup-uniform): bytes [lo, hi) of array k are in the scratch.  Ends on a barrier.
+// -> false (workgroup-uniform): a wait gave up (a fault: a lost workgroup, a corrupted control block) -- the bytes are NOT there,
+// *stuck is raised, the call fails with RAFTQ_EHIP; the decoders then treat the tile's frames as unreadable instead of parsing
+// whatever the scratch holds (raftq_step_frames would step from it)
+template <int TB = kBlock>
+__device__ inline bool feed_wait_chunks(const InFeed& in, uint32_t epoch, uint32_t c0, uint32_t c1, unsigned int* stuck, uint32_t* slot /*LDS*/) {
+  bool eager = false, ok = true;  // (workgroup-uniform: set from *slot)
+  for (uint32_t c = c0; c <= c1; ++c) {
+    for (;;) {
+      if (threadIdx.x == 0) *slot = feed_poll(in, epoch, c, eager, stuck);
+      __syncthreads();
+      const uint32_t s = *slot;
+      __syncthreads();  // (*slot is written again)
+      if (s == kFeedGaveUp) ok = false;
+      if (s < kFeedServe) break;
+      feed_copy_chunk<TB>(in, s - kFeedServe, epoch);  // ends on a barrier
+      eager = true;  // nobody else is bringing input in: keep claiming until this wait's chunks are claimed
+    }
+  }
+  return ok;
+}
+template <int TB = kBlock>
+__device__ inline bool feed_wait(const InFeed& in, uint32_t epoch, int k, uint64_t lo, uint64_t hi, unsigned int* stuck, uint32_t* slot) {
+  if (hi <= lo) {
+    __syncthreads();
+    return true;
+  }
   const uint64_t per = in.seg[k].per_chunk;
   uint32_t c1 = (uint32_t)((hi - 1) / per);
   if (c1 >= in.chunks) c1 = in.chunks - 1;
-  for (uint32_t c = (uint32_t)(lo / per); c <= c1; ++c) (void)lb_wait(in.flag + c, epoch, stuck);
+  return feed_wait_chunks<TB>(in, epoch, (uint32_t)(lo / per), c1, stuck, slot);
 }
-__device__ inline void feed_wait_all(const InFeed& in, uint32_t epoch, unsigned int* stuck) {
-  for (uint32_t c = 0; c < in.chunks; ++c) (void)lb_wait(in.flag + c, epoch, stuck);
+template <int TB = kBlock>
+__device__ inline bool feed_wait_all(const InFeed& in, uint32_t epoch, unsigned int* stuck, uint32_t* slot) {
+  return feed_wait_chunks<TB>(in, epoch, 0, in.chunks - 1, stuck, slot);
 }
 
 // block-wide exclusive sum of one u32 per thread (kBlock threads) -> this thread's prefix; *total = the block's sum
-__device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wave_tot /*LDS [kWaves]*/, uint64_t* total) {
+template <int W = kWaves>
+__device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wave_tot /*LDS [W]*/, uint64_t* total) {
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint64_t incl = v;
 #pragma unroll
@@ -809,7 +895,7 @@ __device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wa
   __syncthreads();
   uint64_t pre = 0, all = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < (uint32_t)kWaves; ++k) {
+  for (uint32_t k = 0; k < (uint32_t)W; ++k) {
     const uint64_t t = wave_tot[k];
     pre += k < w ? t : 0;
     all += t;
@@ -819,8 +905,8 @@ __device__ __forceinline__ uint64_t block_exclusive_u32(uint32_t v, uint64_t* wa
 }
 
 // the tile's records leave through LDS: lane-consecutive 16-byte stores, 4 KB of consecutive host memory per instruction
-template <typename Rec>
-__device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32x4* lds /*[kBlock * sizeof(Rec) / 16]*/, Rec* out_h,
+template <typename Rec, int TB = kBlock>
+__device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32x4* lds /*[TB * sizeof(Rec) / 16]*/, Rec* out_h,
                                                  uint64_t tile0, uint64_t n, Rec* out_d = nullptr /* a copy that stays in HBM */) {
   static_assert(sizeof(Rec) % 16 == 0, "records are whole quads");
   constexpr uint32_t kQ = sizeof(Rec) / 16;
@@ -831,19 +917,19 @@ __device__ __forceinline__ void tile_records_out(const Rec& mine, bool live, u32
     for (uint32_t k = 0; k < kQ; ++k) lds[threadIdx.x * kQ + k] = q[k];
   }
   __syncthreads();
-  const uint64_t live_recs = n - tile0 < (uint64_t)kBlock ? n - tile0 : (uint64_t)kBlock;
+  const uint64_t live_recs = n - tile0 < (uint64_t)TB ? n - tile0 : (uint64_t)TB;
   const uint32_t quads = (uint32_t)live_recs * kQ;
   u32x4* dst = reinterpret_cast<u32x4*>(out_h + tile0);
 #pragma unroll
   for (uint32_t k = 0; k < kQ; ++k) {
-    const uint32_t q = k * kBlock + threadIdx.x;
+    const uint32_t q = k * TB + threadIdx.x;
     if (q < quads) __builtin_nontemporal_store(lds[q], dst + q);
   }
   if (out_d != nullptr) {
     u32x4* dd = reinterpret_cast<u32x4*>(out_d + tile0);
 #pragma unroll
     for (uint32_t k = 0; k < kQ; ++k) {
-      const uint32_t q = k * kBlock + threadIdx.x;
+      const uint32_t q = k * TB + threadIdx.x;
       if (q < quads) dd[q] = lds[q];
     }
   }
@@ -908,25 +994,33 @@ struct FrameFilter {
   unsigned long long* zero2;  // two words this kernel leaves zero for the kernels behind it (Step's {touched groups, bad | skipped}), or nullptr
 };
 constexpr uint8_t kFrameSkip = 0x10, kFrameHold = 0x20, kFrameBarrier = 0x40, kFrameEntries = 0x80;  // == RAFTQ_MSGF_*
-static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
-                                                                       uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin,
-                                                                       WireMsg* msgs_d, FrameFilter ff) {
+// TB (round 6): threads of a workgroup = frames of a tile.  Round 5's workgroup was 256 frames with 102 KB of LDS -- the scalar
+// fields' file (34 KB), the frames' stage (32 KB), four entry headers per lane (32 KB): ONE workgroup per CU, one wave per SIMD,
+// and every reader workgroup of the launch paid for the same 102 KB.  Now the entry headers a lane meets on its one walk go to
+// a slot of its own in device scratch (`ent_spill`: 15 % of the lanes write one to three 32-byte headers; they are read back,
+// L2-resident, when the tile's run is gathered behind the look-back), and the tile is a template parameter: 128 frames =
+// 34.3 KB (four workgroups per CU, every tile of a 64K-frame call resident at once, each waiting for its own bytes);
+// 256 frames = 68.5 KB (two per CU).  RAFTQ_WIRE_TILE picks; profiles/r06/wire_tile_ab.txt has the A/B.
+template <int TB>
+static __global__ __launch_bounds__(TB) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
+                                                                   uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin,
+                                                                   WireMsg* msgs_d, FrameFilter ff, WireEnt* __restrict__ ent_spill) {
+  constexpr int W = TB / 64;
   if (blockIdx.x < in.readers) {
-    reader_role(in, ctl.epoch);
+    reader_role<TB>(in, ctl.epoch);
     return;
   }
-  __shared__ __attribute__((aligned(16))) uint64_t file[kFileSlots * kBlock];  // 34 KB; the records' way out afterwards (16 KB)
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageBytes / 4];  // the frames; the entry headers' way out afterwards
-  __shared__ __attribute__((aligned(16))) WireEnt ents_lds[kBlock * kEntQ];  // 32 KB: what a lane's frame carries, up to kEntQ headers
-  __shared__ uint64_t offs[kBlock + 1];
-  __shared__ uint64_t wave_tot[kWaves];
+  __shared__ __attribute__((aligned(16))) uint64_t file[kFileSlots * TB];  // 136 B per frame; the records' way out afterwards (64 B per frame)
+  __shared__ __attribute__((aligned(16))) uint32_t stage[W][kStageBytes / 4];  // the frames; the entry headers' way out afterwards
+  __shared__ uint64_t offs[TB + 1];
+  __shared__ uint64_t wave_tot[W];
   __shared__ uint64_t prefix[2];
-  __shared__ uint32_t wave_bad[kWaves];
-  __shared__ uint32_t tile_slot;
+  __shared__ uint32_t wave_bad[W];
+  __shared__ uint32_t tile_slot, feed_slot;
   const uint64_t* off = reinterpret_cast<const uint64_t*>(in.seg[0].dst);
   const uint8_t* stream = in.seg[1].dst;
   const uint64_t readable = (nbytes + 15) & ~15ull;
-  const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
+  const uint32_t n_tiles = (uint32_t)((n + TB - 1) / TB);
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
   unsigned int* stuck = ctl.ticket + 1;
   if (ff.zero2 != nullptr && blockIdx.x == in.readers && tid < 2) ff.zero2[tid] = 0;  // (saves Step a launch of its own in front of this one)
@@ -934,12 +1028,11 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
     const uint32_t cur = next_tile(ctl, &tile_slot);
     if (cur >= n_tiles) return;
     RAFTQ_TRACE_STAMP(ctl, cur, 0);
-    const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
-    const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
-    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck);  // the tile's 257 boundaries are in the scratch
-    __syncthreads();
+    const uint64_t tile0 = (uint64_t)cur * TB, i = tile0 + tid;
+    const uint64_t last = tile0 + TB < n ? tile0 + TB : n;
+    bool fed = feed_wait<TB>(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck, &feed_slot);  // the tile's TB + 1 boundaries are in the scratch
     if (i <= n) offs[tid] = __hip_atomic_load(off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) offs[kBlock] = __hip_atomic_load(off + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) offs[TB] = __hip_atomic_load(off + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     RAFTQ_TRACE_STAMP(ctl, cur, 1);
     const bool live = i < n;
@@ -947,24 +1040,21 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
     // ... and so are its frames: [first boundary, last boundary) when the boundaries ascend inside the buffer, else (garbage
     // boundaries: every lane may look anywhere) the whole stream
     const bool ordered = __syncthreads_and(!live || (a <= b && b <= nbytes));
-    if (tid == 0) {
-      if (ordered) feed_wait(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck);
-      else feed_wait_all(in, ctl.epoch, stuck);
-    }
-    __syncthreads();
-    const WaveStage st = stage_wave_frames_dma(stream, nbytes, readable, a, b, live, stage[wave]);
+    if (ordered) fed &= feed_wait<TB>(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck, &feed_slot);
+    else fed &= feed_wait_all<TB>(in, ctl.epoch, stuck, &feed_slot);
+    const WaveStage st = stage_wave_frames_dma(stream, nbytes, readable, a, b, live && fed, stage[wave]);
     RAFTQ_TRACE_STAMP(ctl, cur, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RAFTQ_TRACE_STAMP(ctl, cur, 3);
     WireMsg m;
     bool malformed = false;
-    LdsFile f{file + tid};
+    LdsFileT<TB> f{file + tid};
     ByteSrc src = {stream, 0, nullptr, 0};
-    WireEnt* my_ents = ents_lds + tid * kEntQ;
+    WireEnt* my_ents = ent_spill + ((uint64_t)cur * TB + tid) * kEntQ;
     if (live) {
       src = frame_src(st, stream, nbytes, a, b);
-      bool ok = frame_body_staged(src, stream, nbytes, a, b, true);
-      // ONE walk: the first kEntQ entry headers of the frame are left in LDS on the way (a second walk cost every tile 11 us)
+      bool ok = fed && frame_body_staged(src, stream, nbytes, a, b, true);  // (a wait that gave up: the bytes are not there -- nothing is parsed)
+      // ONE walk: the first kEntQ entry headers of the frame are left in the lane's scratch slot on the way (a second walk cost every tile 11 us)
       if (ok) ok = parse_msg<true>(src, b - a - 8, a + 8, f, m, my_ents, 0, kEntQ, 0xffffffffu);
       if (!ok) {
         m.group = m.term = m.log_term = m.index = m.commit = m.reject_hint = 0;
@@ -991,11 +1081,11 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
     const uint64_t mb = __ballot(malformed);
     if ((tid & 63) == 0) wave_bad[wave] = (uint32_t)__popcll(mb);
     uint64_t tile_ents;
-    const uint64_t local = block_exclusive_u32(cnt, wave_tot, &tile_ents);  // (its barrier publishes wave_bad too)
+    const uint64_t local = block_exclusive_u32<W>(cnt, wave_tot, &tile_ents);  // (its barrier publishes wave_bad too)
     RAFTQ_TRACE_STAMP(ctl, cur, 4);
     if (tid == 0) {
       uint32_t tile_bad = 0;
-      for (int k = 0; k < kWaves; ++k) tile_bad += wave_bad[k];
+      for (int k = 0; k < W; ++k) tile_bad += wave_bad[k];
       const uint64_t pe = lb_exclusive(ctl.status[0], ctl.epoch, cur, tile_ents, stuck);
       const uint64_t pb = lb_exclusive(ctl.status[1], ctl.epoch, cur, tile_bad, stuck);
       prefix[0] = pe;
@@ -1014,19 +1104,19 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
       (void)parse_msg<true>(src, b - a - 8, a + 8, f, again, ents_h, first, ents_cap, cnt);
     }
     // The tile's entry headers are one contiguous run of the caller's array: gathered in LDS (the frames' stage is free now)
-    // and pushed out like the records, whole 64-byte lines.  A tile with more headers than the stage holds, or with a frame
-    // that was walked twice, writes them lane by lane.
-    constexpr uint32_t kEntStage = kWaves * kStageBytes / sizeof(WireEnt);  // 1,024
+    // and pushed out like the records, whole 64-byte lines.  A tile with a frame that was walked twice writes them lane by lane.
+    constexpr uint32_t kEntStage = W * kStageBytes / sizeof(WireEnt);
+    static_assert(kEntStage >= TB * kEntQ, "the stage holds every header a tile's lanes can keep");
     WireEnt* ent_run = reinterpret_cast<WireEnt*>(&stage[0][0]);
     const bool mine_kept = cnt != 0 && cnt <= kEntQ && ents_h != nullptr;
-    const bool run_staged = __syncthreads_and(cnt <= kEntQ) && tile_ents <= kEntStage;  // (the barrier: nobody files fields or reads frames any more)
+    const bool run_staged = __syncthreads_and(cnt <= kEntQ);  // (the barrier: nobody files fields or reads frames any more)
     if (mine_kept && run_staged) {
 #pragma unroll
       for (uint32_t k = 0; k < kEntQ; ++k)
         if (k < cnt) ent_run[local + k] = my_ents[k];
     }
-    tile_records_out(m, live && !RAFTQ_ABLATE(ctl, 0), reinterpret_cast<u32x4*>(file), RAFTQ_ABLATE(ctl, 0) ? msgs_h - tile0 : msgs_h, tile0,
-                     RAFTQ_ABLATE(ctl, 0) ? tile0 + 1 : n, msgs_d);  // (its barrier publishes ent_run too)
+    tile_records_out<WireMsg, TB>(m, live && !RAFTQ_ABLATE(ctl, 0), reinterpret_cast<u32x4*>(file), RAFTQ_ABLATE(ctl, 0) ? msgs_h - tile0 : msgs_h, tile0,
+                                  RAFTQ_ABLATE(ctl, 0) ? tile0 + 1 : n, msgs_d);  // (its barrier publishes ent_run too)
     RAFTQ_TRACE_STAMP(ctl, cur, 6);
     if (ents_h != nullptr && tile_ents != 0 && !RAFTQ_ABLATE(ctl, 1)) {
       const uint64_t run0 = prefix[0];
@@ -1035,7 +1125,7 @@ static __global__ __launch_bounds__(kBlock) void wire_dec_fused_kernel(InFeed in
         const uint32_t quads = (uint32_t)(tile_ents < room ? tile_ents : room) * 2;
         const u32x4* src_q = reinterpret_cast<const u32x4*>(ent_run);
         u32x4* dst = reinterpret_cast<u32x4*>(ents_h + run0);
-        for (uint32_t q = tid; q < quads; q += kBlock) __builtin_nontemporal_store(src_q[q], dst + q);
+        for (uint32_t q = tid; q < quads; q += TB) __builtin_nontemporal_store(src_q[q], dst + q);
       } else if (mine_kept) {
         for (uint32_t k = 0; k < cnt; ++k)
           if (first + k < ents_cap) ents_h[first + k] = my_ents[k];
@@ -1377,7 +1467,7 @@ static __global__ __launch_bounds__(kBlock) void wal_dec_fused_kernel(InFeed in,
   __shared__ CrcPair tile_pre;
   __shared__ unsigned long long wave_min[kWaves];
   __shared__ unsigned long long bad_before;
-  __shared__ uint32_t tile_slot;
+  __shared__ uint32_t tile_slot, feed_slot;
   const uint64_t* off = reinterpret_cast<const uint64_t*>(in.seg[0].dst);
   const uint8_t* bytes = in.seg[1].dst;
   const uint64_t readable = (nbytes + 15) & ~15ull;
@@ -1391,19 +1481,15 @@ static __global__ __launch_bounds__(kBlock) void wal_dec_fused_kernel(InFeed in,
     if (cur >= n_tiles) return;
     const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
     const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
-    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck);
-    __syncthreads();
+    feed_wait(in, ctl.epoch, 0, tile0 * 8, (last + 1) * 8, stuck, &feed_slot);
     if (i <= n) offs[tid] = __hip_atomic_load(off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) offs[kBlock] = __hip_atomic_load(off + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const bool live = i < n;
     const uint64_t a = live ? offs[tid] : 0, b = live ? offs[tid + 1] : 0;
     const bool ordered = __syncthreads_and(!live || (a <= b && b <= nbytes));
-    if (tid == 0) {
-      if (ordered) feed_wait(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck);
-      else feed_wait_all(in, ctl.epoch, stuck);
-    }
-    __syncthreads();
+    if (ordered) feed_wait(in, ctl.epoch, 1, offs[0], offs[last - tile0], stuck, &feed_slot);
+    else feed_wait_all(in, ctl.epoch, stuck, &feed_slot);
     const WaveStage st = stage_wave_frames_dma(bytes, nbytes, readable, a, b, live, stage[wave]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WalRec r;
@@ -1599,7 +1685,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
   __shared__ uint64_t red[2 * kWaves];
   __shared__ uint64_t prefix[2];
   __shared__ uint32_t wave_bad[kWaves];
-  __shared__ uint32_t tile_slot;
+  __shared__ uint32_t tile_slot, feed_slot;
   const WireMsg* msgs = reinterpret_cast<const WireMsg*>(in.seg[0].dst);
   const WireEnt* ents = reinterpret_cast<const WireEnt*>(in.seg[1].dst);
   const uint8_t* pool = in.seg[2].dst;
@@ -1612,8 +1698,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
     const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
     const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
     const bool live = i < n;
-    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WireMsg), last * sizeof(WireMsg), stuck);
-    __syncthreads();
+    feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WireMsg), last * sizeof(WireMsg), stuck, &feed_slot);
     WireMsg m = {};
     if (live) m = msgs[i];
     bool is_bad = live && (m.to >= 255 || m.from >= 255 || (m.n_ents != 0 && (uint64_t)m.ent_first + m.n_ents > n_ents));
@@ -1621,8 +1706,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
     // the entry headers this tile names are in the scratch ...
     uint64_t lo = walks ? (uint64_t)m.ent_first * sizeof(WireEnt) : ~0ull, hi = walks ? ((uint64_t)m.ent_first + m.n_ents) * sizeof(WireEnt) : 0;
     block_range(lo, hi, red);
-    if (tid == 0) feed_wait(in, ctl.epoch, 1, lo, hi, stuck);
-    __syncthreads();
+    feed_wait(in, ctl.epoch, 1, lo, hi, stuck, &feed_slot);
     uint64_t sz = 0;
     lo = ~0ull;
     hi = 0;
@@ -1651,7 +1735,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
     }
     // ... and so are the payloads they name
     block_range(lo, hi, red);
-    if (tid == 0) feed_wait(in, ctl.epoch, 2, lo, hi, stuck);
+    feed_wait(in, ctl.epoch, 2, lo, hi, stuck, &feed_slot);
     const uint64_t bb = __ballot(is_bad);
     if (lane == 0) wave_bad[wave] = (uint32_t)__popcll(bb);
     uint64_t tile_bytes;
@@ -1750,7 +1834,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_fused_kernel(InFeed in,
   __shared__ uint64_t red[2 * kWaves];
   __shared__ uint64_t prefix[2];
   __shared__ uint32_t wave_bad[kWaves];
-  __shared__ uint32_t tile_slot;
+  __shared__ uint32_t tile_slot, feed_slot;
   const WalRec* recs = reinterpret_cast<const WalRec*>(in.seg[0].dst);
   const uint8_t* pool = in.seg[1].dst;
   const uint32_t n_tiles = (uint32_t)((n + kBlock - 1) / kBlock);
@@ -1764,8 +1848,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_fused_kernel(InFeed in,
     const uint64_t tile0 = (uint64_t)cur * kBlock, i = tile0 + tid;
     const uint64_t last = tile0 + kBlock < n ? tile0 + kBlock : n;
     const bool live = i < n;
-    if (tid == 0) feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WalRec), last * sizeof(WalRec), stuck);
-    __syncthreads();
+    feed_wait(in, ctl.epoch, 0, tile0 * sizeof(WalRec), last * sizeof(WalRec), stuck, &feed_slot);
     WalRec r = {};
     if (live) r = recs[i];
     bool is_bad = live && (r.kind < 1 || r.kind > 5);
@@ -1774,8 +1857,7 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_fused_kernel(InFeed in,
     const bool copies = payload && !is_bad;
     uint64_t lo = copies ? r.data_off : ~0ull, hi = copies ? r.data_off + r.data_len : 0;
     block_range(lo, hi, red);
-    if (tid == 0) feed_wait(in, ctl.epoch, 1, lo, hi, stuck);
-    __syncthreads();
+    feed_wait(in, ctl.epoch, 1, lo, hi, stuck, &feed_slot);
     // the record's map on the running CRC (wal_enc_crc_kernel): front fields, payload, the group field behind an entry
     CrcPair me = kCrcIdentity;
     uint32_t raw = 0xffffffffu;

@@ -314,7 +314,7 @@ def _form(monkeypatch, form):
     monkeypatch.setenv("RAFTQ_WIRE_STREAMING", "1" if form == "streaming" else "0")
 
 
-@pytest.mark.parametrize("copies", ["streaming", "copying"])
+@pytest.mark.parametrize("copies", ["streaming", "streaming-256", "copying"])
 @pytest.mark.parametrize("seed,n,big", [(171, 1, 0), (172, 900, 4), (173, 6000, 0), (174, 333, 1)])
 def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
     """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE launch with ONE wait and has to
@@ -327,6 +327,9 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
     from raftsql_amd.engine import pinned_copy, pinned_empty
     from raftsql_amd.wire import WireEngine
 
+    if copies == "streaming-256":  # the decoder's 256-frame tile (round 5's; the default is 128 frames)
+        monkeypatch.setenv("RAFTQ_WIRE_TILE", "256")
+        copies = "streaming"
     _form(monkeypatch, copies)
     rng = np.random.default_rng(seed)
     with WireEngine(4096, 5, self_peer=0) as eng:
@@ -434,8 +437,9 @@ def test_wal_codecs_on_page_locked_buffers(seed, n, big, prev, copies, monkeypat
             assert (gnv, gl) == (wnv, wl) and gr.tobytes() == wr.tobytes()
 
 
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("wgs", [5, 64, 160, 1024])
-def test_streaming_decode_at_bench_size(wgs, monkeypatch):
+def test_streaming_decode_at_bench_size(wgs, tile, monkeypatch):
     """The one-kernel form of raftq_wire_decode (page-locked buffers) at the bench's size -- 65,536 frames, a MsgApp share with
     entries, some damaged frames -- with few workgroups walking many tiles each (every one a tile ahead of itself), the
     default grid, and more workgroups than tiles: records, entry headers and counts are the oracle's whatever the grid."""
@@ -443,6 +447,7 @@ def test_streaming_decode_at_bench_size(wgs, monkeypatch):
     from raftsql_amd.wire import WireEngine
 
     monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
+    monkeypatch.setenv("RAFTQ_WIRE_TILE", str(tile))  # frames per tile = threads per decoder workgroup (round 6: 128 is the default)
     rng = np.random.default_rng(1900 + wgs)
     n = 65536
     m, e, pool = _wiregen.random_msgs(rng, n, big_every=0, ent_frac=0.15)
@@ -462,10 +467,64 @@ def test_streaming_decode_at_bench_size(wgs, monkeypatch):
             _same(ge, we, "ents")
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("wgs", [7, 0])
+def test_streaming_codecs_without_readers(wgs, tile, monkeypatch):
+    """liveness of a codec call is structural, not a property of the dispatcher.  RAFTQ_WIRE_READERS=0
+    launches every streaming codec with NO reader workgroups: nobody is ever going to claim a chunk, so every worker finds its
+    chunk unclaimed and the ticket still, takes the reader's role itself (raftq_wire_kernels.hpp feed_poll), and the call
+    completes -- byte-identical to the oracle, bench-sized, all four codecs, a few workers walking many tiles and the default
+    grid.  Before round 6 this launch shape spun for a second per wait and failed with RAFTQ_EHIP."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    monkeypatch.setenv("RAFTQ_WIRE_READERS", "0")
+    monkeypatch.setenv("RAFTQ_WIRE_TILE", str(tile))
+    if wgs:
+        monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
+    rng = np.random.default_rng(6100 + wgs + tile)
+    n = 65536 if wgs == 0 else 20000
+    m, e, pool = _wiregen.random_msgs(rng, n, big_every=9000, ent_frac=0.15)
+    s, off = W.wire_encode(m, e, pool)
+    wm, we, wbad = W.wire_decode(s, off)
+    r, rpool = _wiregen.random_wal(rng, n, max_payload=200, big_every=7000)
+    wal, wal_off, wal_last = W.wal_encode(r, rpool, 0xC0FFEE)
+    wr, wnv, wl = W.wal_decode(wal, wal_off, 0xC0FFEE)
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        ps, po = pinned_copy(s), pinned_copy(off)
+        dm, de = pinned_empty(n, W.WIRE_MSG_DT), pinned_empty(len(we) + 1, W.WIRE_ENT_DT)
+        pm, pe, pp = pinned_copy(m), pinned_copy(e), pinned_copy(_wiregen_u8(pool))
+        out, ooff = pinned_empty(len(s) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+        pr, prp = pinned_copy(r), pinned_copy(_wiregen_u8(rpool))
+        wout, woff = pinned_empty(len(wal) + 64, np.uint8), pinned_empty(n + 1, np.uint64)
+        recs = pinned_empty(n, W.WAL_REC_DT)
+        pw, pwo = pinned_copy(wal), pinned_copy(wal_off)
+        for rep in range(3):  # consecutive calls share the control block: the chunk ticket's base carries over
+            dm[:] = np.zeros(1, W.WIRE_MSG_DT)[0]
+            gm, ge, gbad = eng.wire_decode(ps, po, msgs=dm, ents=de)
+            assert gbad == wbad
+            _same(gm, wm, "msgs")
+            _same(ge, we, "ents")
+            out[:] = 0xEE
+            got, goff = eng.wire_encode(pm, pe, pp, out=out, off=ooff)
+            assert got.tobytes() == s.tobytes() and np.array_equal(goff, off) and bytes(out[len(s):]) == b"\xee" * 64
+            got, goff, glast = eng.wal_encode(pr, prp, 0xC0FFEE, out=wout, off=woff)
+            assert got.tobytes() == wal.tobytes() and np.array_equal(goff, wal_off) and glast == wal_last
+            gr, gnv, gl = eng.wal_decode(pw, pwo, 0xC0FFEE, recs=recs)
+            assert (gnv, gl) == (wnv, wl)
+            _same(gr, wr, "recs")
+    # and with the readers back the very next call of a fresh handle is the ordinary path
+    monkeypatch.delenv("RAFTQ_WIRE_READERS")
+    with WireEngine(4096, 5, self_peer=0) as eng:
+        gm, ge, gbad = eng.wire_decode(pinned_copy(s), pinned_copy(off), msgs=pinned_empty(n, W.WIRE_MSG_DT), ents=pinned_empty(len(we) + 1, W.WIRE_ENT_DT))
+        assert gbad == wbad
+        _same(gm, wm, "msgs")
+
+
 def test_streaming_codecs_of_many_handles_resident_together():
     """Several handles' one-kernel codec calls on the device AT ONCE (the nodes of one process: bench.py's node legs, any host
-    with a handle per shard): a decoder workgroup holds 102 KB of LDS -- one per CU -- so six launches of up to 256 workgroups
-    oversubscribe the chip and a launch's workgroups become resident XCD by XCD, late.  Every wait inside a launch must be for
+    with a handle per shard): six launches of hundreds of workgroups each (a decoder workgroup held 102 KB of LDS until round 6,
+    one per CU; 34 KB now) oversubscribe the chip and a launch's workgroups become resident XCD by XCD, late.  Every wait inside a launch must be for
     something a RUNNING workgroup has claimed (tiles by ticket; the readers' chunks by ticket too, round 5 -- they used to belong
     to reader c % readers, resident or not, and two launches could wait for each other's readers until the bounded waits gave
     up: `a workgroup waited a second for its predecessor's tile`).  Six threads, a handle each, decode + encode in a loop:

@@ -3,7 +3,7 @@
 #   tools/gpu.sh T 'bash tools/gpurun_trip.sh <step> [<step> ...]'      (gpu.sh stamps the shipped tree into .git_head first)
 # Every step writes under gpurun_out/$ROUND/; the summaries worth keeping are copied to profiles/$ROUND/ by hand.
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 P=gpurun_out/$ROUND; mkdir -p $P; export TMPDIR=/tmp
 BENCH="python bench.py --gpus 1 --steps 20 --warmup 5"
 for step in "$@"; do
@@ -63,6 +63,9 @@ SUPP
         cp $(find /tmp/ks_$l -name "*kernel_stats.csv" | head -1) $P/${l}_kernel_stats.csv 2>/dev/null; done ;;
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q > $P/gpu_tests.log 2>&1; echo "rc=$? $(tail -1 $P/gpu_tests.log)" ;;
     wiretests) timeout 900 python -m pytest tests/test_wire_gpu.py -m gpu -x -q > $P/gpu_tests_wire.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_wire.log)" ;;
+    ticktests) timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_set_gpu.py tests/test_abi_gpu.py -m gpu -x -q -k "tick or election or abi or drive" > $P/gpu_tests_tick.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_tick.log)" ;;
+    tileab)    # the streaming decoder's launch shapes, one process: tile 128 / 256, readers, chunk, no readers at all, the SDMA-reader form
+      timeout 600 python tools/probe/wire_tile_ab.py > $P/wire_tile_ab.jsonl 2> $P/wire_tile_ab.err; echo "rc=$?"; cut -c1-220 $P/wire_tile_ab.jsonl ;;
     steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;
     nodetests) timeout 900 python -m pytest tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_pipe_gpu.py -m gpu -x -q > $P/gpu_tests_node.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_node.log)" ;;
     bench)     # the driver's command: stdout = the ONE contract line (<= 4 KB), the full record (every side leg) beside it

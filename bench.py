@@ -1512,13 +1512,19 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
                     "frames_in_per_turn": peers * Gs * K, "frames_out_per_turn": sum(r[4] for r in per) / n_turns,
                     "statements_per_proposing_frame": k}
 
-    def rate(K, mode):
-        return out["shards_%d" % K][mode]["no_wal"][names[1]]
+    # The headline is the WITH-WAL rate: the reference persists before it sends (wal.Save, then transport.Send:
+    # raft.go:228-230), so a turn that produces and drains no WAL is not the reference-equivalent path; the no-WAL rate is
+    # reported beside it (`no_wal`), never as the headline.  Both say which thread mode produced them: the best figures come from
+    # the CALLER's threads (one per shard handle); raftq_shards_turn -- the library's lock-step threads -- reaches about half.
+    def rate(K, mode, wal="with_wal"):
+        return out["shards_%d" % K][mode][wal][names[1]]
 
     first = rate(shard_counts[0], "one_thread" if shard_counts[0] == 1 else "caller_threads")
+    first_nw = rate(shard_counts[0], "one_thread" if shard_counts[0] == 1 else "caller_threads", "no_wal")
     cands = [(K, mode) for K in shard_counts for mode in (("one_thread",) if K == 1 else ("caller_threads", "library_threads"))]
     best_k, best_mode = max(cands, key=lambda c: rate(*c)["proposals_committed_per_s"])
     best = rate(best_k, best_mode)
+    best_nw = rate(best_k, best_mode, "no_wal")
     return {"what": "ONE node (leader of all %d groups, %d-peer groups) with the GPU to itself, scripted peers on the host: per turn "
                     "%d acks in -> decode + checks + Step (one submission) -> commit -> commit channels; %d proposals -> append -> %d "
                     "MsgApps marshalled (one call: the commit index to every follower, then the new entry); closed loop, every turn "
@@ -1527,8 +1533,10 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
                     "raftq_shards_turn per turn (library_threads)" % (G, N, peers * G, G, 2 * peers * G),
             "groups": G, "peers": N,
             "proposals_committed_per_s": best["proposals_committed_per_s"], "ms_per_turn": best["ms_per_turn"], "shards": best_k,
-            "threads": best_mode,
-            "one_handle": {"proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"]},
+            "threads": best_mode, "wal": "produced and drained every turn (raft.go:228: wal.Save before transport.Send)",
+            "no_wal": {"proposals_committed_per_s": best_nw["proposals_committed_per_s"], "ms_per_turn": best_nw["ms_per_turn"]},
+            "one_handle": {"proposals_committed_per_s": first["proposals_committed_per_s"], "ms_per_turn": first["ms_per_turn"],
+                           "no_wal": {"proposals_committed_per_s": first_nw["proposals_committed_per_s"], "ms_per_turn": first_nw["ms_per_turn"]}},
             **out}
 
 

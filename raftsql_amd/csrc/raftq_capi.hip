@@ -1018,6 +1018,7 @@ static TickArgs tick_args(const raftq_t* h, uint64_t tick_no) {
 int raftq_tick(raftq_t* h, raftq_tick_counts_t* counts) {
   if (int rc = use_device_idle(h, "raftq_tick")) return rc;
   if (int rc = ensure_tick_state(h)) return rc;
+  h->tl_valid = false;  // (raftq_last_tick_lists must not hand out an older tick's lists as the last one's)
   hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
   HIPCHK(h, hipGetLastError());
   h->ticked = true;
@@ -1045,13 +1046,15 @@ int raftq_tick_collect(raftq_t* h, uint64_t* hups, uint64_t hup_cap, uint64_t* n
   if (int rc = ensure_tick_state(h)) return rc;
   const uint64_t cap_h = std::min<uint64_t>(hup_cap, h->G), cap_b = std::min<uint64_t>(beat_cap, h->G);
   if (int rc = ensure_adv(h, (cap_h + cap_b + 2) / 3 + 2)) return rc;
+  const uint64_t nw = h->gpad / 256;
+  if (nw > (1u << 14))
+    if (int rc = ensure_tick_offsets2(h, nw)) return rc;  // (before the Tick: a call that fails has not ticked)
+  h->tl_valid = false;  // raftq_last_tick_lists hands out the lists of the LAST tick, and this is a newer one
   hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
   h->ticked = true;
-  const uint64_t nw = h->gpad / 256;
   const uint64_t *off_h = nullptr, *off_b = nullptr;
   if (nw > (1u << 14)) {  // past 16K waves every workgroup summing its predecessors itself would show: scan first
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets, h->d_total, 0);
-    if (int rc = ensure_tick_offsets2(h, nw)) return rc;
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->tick_offsets2, h->d_total + 1, 1);
     off_h = h->offsets;
     off_b = h->tick_offsets2;
@@ -1097,13 +1100,16 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->tl_d, h->tl_h, 0));
     h->tl_bytes = want;
   }
+  // every allocation is made BEFORE the Tick is enqueued: a call that fails has not ticked (an allocation failure
+  // behind the tick kernel left the timers advanced and the MsgHup / MsgBeat groups of that tick unreported)
+  const uint64_t nw = h->gpad / 256;
+  if (nw > (1u << 14))
+    if (int rc = ensure_tick_offsets2(h, nw)) return rc;
   hipLaunchKernelGGL(tick_kernel, dim3((unsigned)(h->gpad / 1024)), dim3(kBlock), 0, h->stream, tick_args(h, h->tick_no++));
   h->ticked = true;
-  const uint64_t nw = h->gpad / 256;
   const uint64_t *off_h = nullptr, *off_b = nullptr;
   if (nw > (1u << 14)) {  // past 16K waves every workgroup summing its predecessors itself would show: scan first
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->offsets, h->d_total, 0);
-    if (int rc = ensure_tick_offsets2(h, nw)) return rc;
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, h->stream, h->tick_partials, nw, h->tick_offsets2, h->d_total + 1, 1);
     off_h = h->offsets;
     off_b = h->tick_offsets2;
@@ -1139,7 +1145,7 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
     hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
     HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, wait_turn(h, epoch));
+  HIPCHK(h, wait_turn(h, epoch, 1));
   *n_hup = h->tl_n_hup = h->h_total[0];
   *n_beat = h->tl_n_beat = h->h_total[1];
   h->tl_hup_cap = cap_h;
@@ -1396,7 +1402,7 @@ int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_li
 // the host polls the word -- bounded, then falls back to the blocking wait.
 // (Polling hipStreamQuery instead was measured SLOWER than blocking: 88 vs 80 us per turn, profiles/r02.)
 // RAFTQ_CYCLE_WAIT=block restores the plain blocking wait.
-static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
+static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch, int kind = 0) {
   static const bool poll = [] {
     const char* e = std::getenv("RAFTQ_CYCLE_WAIT");
     return !(e && std::strcmp(e, "block") == 0);
@@ -1406,19 +1412,24 @@ static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch) {
   // steady state, so the wake-up is only given up after kMisses misses IN A ROW, and then tried again every
   // kRetry turns; RAFTQ_PROFILE prints how many turns fell back to the blocking wait.
   constexpr uint32_t kMisses = 8, kRetry = 1024;
-  const bool try_flag = poll && flag_epoch && (h->flag_misses < kMisses || (++h->flag_rested % kRetry) == 0);
+  const bool try_flag = poll && flag_epoch && (h->flag_misses[kind] < kMisses || (++h->flag_rested[kind] % kRetry) == 0);
   if (try_flag) {
     volatile uint64_t* flag = h->h_total + 3;
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0;; ++i) {
       if ((*flag & h->flag_mask) == flag_epoch) {
         std::atomic_thread_fence(std::memory_order_acquire);
-        h->flag_misses = 0;
-        return hipSuccess;
+        h->flag_misses[kind] = 0;
+        // the word says the stream's work is done; an asynchronous error of that work is only known to the runtime (ADVICE r05:
+        // the poll returned success without asking, and the error surfaced in a later call).  Whatever this thread has on
+        // record -- possibly a benign, older one -- is cleared and the stream itself is asked: its answer is the call's.
+        if (hipPeekAtLastError() == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        return hipStreamSynchronize(h->stream);
       }
       if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
     }
-    ++h->flag_misses;
+    ++h->flag_misses[kind];
   }
   if (flag_epoch) ++h->flag_fallbacks;
   return hipStreamSynchronize(h->stream);
@@ -1436,7 +1447,7 @@ hipError_t raftq_detail::wait_call(raftq_t* h) {
     const uint64_t epoch = ++h->compact_epoch;
     h->flag_mask = ~0ull;
     hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
-    e = hipGetLastError() != hipSuccess ? hipStreamSynchronize(h->stream) : wait_turn(h, epoch);
+    e = hipGetLastError() != hipSuccess ? hipStreamSynchronize(h->stream) : wait_turn(h, epoch, 1);
   }
   if (e == hipSuccess && h->wal_pending && !h->wal_pending_done) h->wal_pending_waited = true;  // the begun WAL encode was enqueued before this wait
   return e;
@@ -1897,6 +1908,7 @@ int raftq_set_tick(raftq_set_t* s) {
   SETCHK(s, hipGetLastError());
   ++s->tick_since;
   for (raftq_t* h : s->members) {
+    h->tl_valid = false;
     ++h->tick_no;
     h->ticked = true;
   }

@@ -76,7 +76,10 @@ struct raftq {
   uint64_t compact_epoch = 0;  // completion-flag values handed to hipStreamWriteValue64 (h_total[3])
   uint64_t compact_epoch_armed = 0;  // epoch the current turn's wait may poll for (0 = blocking wait)
   bool stream_write_ok = true; // hipStreamWriteValue64 works on this stack
-  uint32_t flag_misses = 0, flag_rested = 0;  // wait_turn: consecutive turns whose flag did not land in time; turns sat out since
+  // wait_turn: consecutive waits whose flag did not land in time and waits sat out since -- per KIND of wait ([0] the batching
+  // turn, [1] every other call that ends on the completion word: codecs, tick lists): a codec call under a profiler must not
+  // switch the turn's wake-up off
+  uint32_t flag_misses[2] = {0, 0}, flag_rested[2] = {0, 0};
   uint64_t flag_fallbacks = 0;                // turns that ended in the blocking wait although a flag was armed
   uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
   // sparse ingest: device copy of the batch (validated on the way in) and the "bad batch" epoch words

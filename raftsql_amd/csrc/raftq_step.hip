@@ -37,7 +37,8 @@ int ensure_node_state(raftq_t* h) {
     HIPCHK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
     return RAFTQ_OK;
   };
-  if (int rc = alloc((void**)&h->step_stall, 256)) return rc;
+  if (!h->step_stall)  // (a retry after a failed launch below finds it allocated: ADVICE r05, 256 bytes leaked per failed attempt)
+    if (int rc = alloc((void**)&h->step_stall, 256)) return rc;
   if (const char* w = std::getenv("RAFTQ_STEP_WALK")) h->step_walk_mode = std::strcmp(w, "sort") == 0 ? 0 : 1;
   // h->node_rec marks the state complete: it is assigned only once the records have been allocated AND their initialisation has
   // been launched (a failed launch used to leave the pointer set, and the next call stepped uninitialised records)

@@ -31,7 +31,7 @@ for step in "$@"; do
       done
       python tools/pmc_traffic.py $H $P/pmc_traffic.json | grep traffic_over ;;
     sanitize)  # the library's host C++ under UBSan / TSan / ASan, driven by the GPU suites that exercise it (libraries built in-tree by
-               # raftsql_amd/build.py build_sanitized; KINDS="ubsan tsan asan")
+               # raftsql_amd/build.py build_sanitized; KINDS="ubsan tsan"; the GPU pool refuses AddressSanitizer runs: ASan runs on the CPU build, tests/test_hostsim.py)
       cat > /tmp/tsan.supp <<'SUPP'
 called_from_lib:libamdhip64.so
 called_from_lib:libhsa-runtime64.so
@@ -50,8 +50,6 @@ SUPP
                    timeout 1500 python -m pytest $TESTS -m gpu -q -p no:cacheprovider >> $LOG 2>&1 ;;
           tsan)  env LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:suppressions=/tmp/tsan.supp:log_path=$P/tsan_report:report_signal_unsafe=0 RAFTQ_LIB=$PWD/raftsql_amd/libraftq_tsan.so \
                    timeout 1500 python -m pytest tests/test_pipe_gpu.py tests/test_node_gpu.py -m gpu -q -p no:cacheprovider -k "not host-memory" >> $LOG 2>&1 ;;
-          asan)  env LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:allocator_may_return_null=1:log_path=$P/asan_report HSA_XNACK=1 RAFTQ_LIB=$PWD/raftsql_amd/libraftq_asan.so \
-                   timeout 1500 python -m pytest $TESTS -m gpu -q -p no:cacheprovider -x >> $LOG 2>&1 ;;
         esac
         echo "rc=$?" >> $LOG; ls $P/${kind}_report* >> $LOG 2>&1 || echo "no $kind report files: clean" >> $LOG; tail -3 $LOG
       done ;;

@@ -971,7 +971,7 @@ int raftq_detail::ensure_tick_state(raftq_t* h) {
 
 static int ensure_tick_offsets2(raftq_t* h, uint64_t nw);
 static int flag_mode();
-static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch);
+static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch, int kind = 0);
 
 extern "C" {
 
@@ -1402,7 +1402,7 @@ int raftq_last_advances(raftq_t* h, const raftq_advance_t** list, uint64_t* n_li
 // the host polls the word -- bounded, then falls back to the blocking wait.
 // (Polling hipStreamQuery instead was measured SLOWER than blocking: 88 vs 80 us per turn, profiles/r02.)
 // RAFTQ_CYCLE_WAIT=block restores the plain blocking wait.
-static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch, int kind = 0) {
+static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch, int kind) {
   static const bool poll = [] {
     const char* e = std::getenv("RAFTQ_CYCLE_WAIT");
     return !(e && std::strcmp(e, "block") == 0);

@@ -254,3 +254,50 @@ func (e *Engine) WalSaveEnd() (n uint64, lastCrc uint32, err error) {
 	rc := C.raftq_wal_encode_end(e.h, &c)
 	return uint64(c.bytes), uint32(c.last_crc), e.err(rc)
 }
+
+// Prop is layout-identical to raftq_prop_t (16 bytes): a group this node leads, and which of propEnts are its new entries.
+type Prop struct {
+	Group    uint64
+	EntFirst uint32 // into propEnts
+	NEnts    uint32 // >= 1
+}
+
+// PropEnt is layout-identical to raftq_prop_ent_t (16 bytes): where one proposed Entry's Data lies in the pool.
+type PropEnt struct {
+	DataOff uint64
+	DataLen uint32
+	Type    uint32 // raftpb.EntryType
+}
+
+// ProposeFrames is a node's outbound half of a turn for what it was asked to propose (raftq_propose_frames; raft.go:211-215 ->
+// :227-230) as ONE submission and one wait: for every Prop the leader's appendEntry on the device-resident state and the N - 1
+// MsgApps of bcastAppend, written into the encoder's input in HBM -- they never exist in host memory --, then the marshal of
+// msgs (what the caller queued itself this turn) followed by those MsgApps, one run per peer slot != self, ascending.  The
+// caller still owns the log (it appends the entries itself) and Progress.Next (it names only groups whose followers are all at
+// the tail, and moves Next past the new entries).  Every slice must be page-locked (HostAlloc).  SOURCE ONLY (round 6).
+func (e *Engine) ProposeFrames(props []Prop, propEnts []PropEnt, msgs []WireMsg, ents []WireEnt, pool, out []byte, frameOff []uint64) (need uint64, err error) {
+	var pp *C.raftq_prop_t
+	var ppe *C.raftq_prop_ent_t
+	var pm *C.raftq_wire_msg_t
+	var pe *C.raftq_wire_ent_t
+	var po *C.uint64_t
+	if len(props) > 0 {
+		pp = (*C.raftq_prop_t)(unsafe.Pointer(&props[0]))
+	}
+	if len(propEnts) > 0 {
+		ppe = (*C.raftq_prop_ent_t)(unsafe.Pointer(&propEnts[0]))
+	}
+	if len(msgs) > 0 {
+		pm = (*C.raftq_wire_msg_t)(unsafe.Pointer(&msgs[0]))
+	}
+	if len(ents) > 0 {
+		pe = (*C.raftq_wire_ent_t)(unsafe.Pointer(&ents[0]))
+	}
+	if len(frameOff) > 0 {
+		po = (*C.uint64_t)(unsafe.Pointer(&frameOff[0]))
+	}
+	var c C.raftq_wire_counts_t
+	rc := C.raftq_propose_frames(e.h, pp, C.uint64_t(len(props)), ppe, C.uint64_t(len(propEnts)), pm, C.uint64_t(len(msgs)), pe, C.uint64_t(len(ents)),
+		bytesPtr(pool), C.uint64_t(len(pool)), bytesPtr(out), C.uint64_t(len(out)), po, &c)
+	return uint64(c.bytes), e.err(rc)
+}

@@ -97,6 +97,7 @@ typedef struct raftq_node_stats {
   uint64_t proposals_dropped; /* proposals that met a group with no leader (etcd drops them) */
   uint64_t frames_dropped;    /* inbound frames that did not parse / were not for this node */
   uint64_t wal_records;       /* walpb.Records produced (raftq_node_wal_enable) */
+  uint64_t msgs_built_on_device; /* of msgs_sent: MsgApps of proposals that raftq_propose_frames built in HBM (round 6) */
 } raftq_node_stats_t;
 
 int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t self_peer, raftq_node_t** out);

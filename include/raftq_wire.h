@@ -167,6 +167,41 @@ int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uin
                       raftq_wire_msg_t* msgs /*[n]*/, raftq_wire_ent_t* ents /*[ents_cap]|NULL*/, uint64_t ents_cap,
                       raftq_wire_counts_t* counts /*|NULL*/);
 
+/* A node's OUTBOUND half of a turn for what it was asked to propose (round 6; raft.go:211-215 -> :227-230: rc.node.Propose ->
+ * appendEntry -> bcastAppend -> rc.transport.Send) as ONE submission with one wait: for every record of props[] the leader's
+ * appendEntry (lastIndex += n_ents, lastTerm = Term, its own Progress.Match) on the device-resident state, and bcastAppend --
+ * the N - 1 MsgApp{Term, LogTerm: old lastTerm, Index: old lastIndex, Commit, Entries} headers and their entry headers are
+ * written INTO THE ENCODER'S INPUT IN HBM (they never exist in host memory); then raftq_wire_encode over msgs[] (what the
+ * caller queued itself this turn: responses, resends, heartbeats) followed by those MsgApps.  What the host keeps of a
+ * proposal is its payload bytes (in `pool`, where data_off points) and its own log.
+ *
+ * props[i]: a group THIS handle's node leads (role == leader; anything else fails the call), at most once per call, with
+ * every follower's Progress.Next at the log's tail -- the state bcastAppend leaves behind, i.e. every group outside a
+ * catch-up; the caller, who owns Progress.Next (raftq_step.h), sends the others itself -- and 1 <= n_ents entries
+ * prop_ents[ent_first .. ent_first + n_ents) in log order.  The new entries get Term = the group's Term, Index = old lastIndex
+ * + 1 + k.  The handle needs more than one peer (with one the append commits: raftq_apply_log_deltas reports that).
+ *
+ * The stream: the frames of msgs[0 .. n_msgs), then for every peer slot p != self, ascending, the n_props MsgApps addressed to
+ * p in props[] order -- frame_off (may be NULL) gets n_msgs + (N - 1) * n_props + 1 offsets; peer p's MsgApps are ONE slice.
+ * Byte for byte what raftq_wire_encode makes of the same messages built on the host (tests/test_wire_gpu.py::
+ * test_propose_frames_*).  Every array must be page-locked and 16-byte aligned (RAFTQ_EINVAL otherwise), no Step batch may be
+ * in flight.  A call that fails has applied nothing (a validation kernel runs first); `out` is unspecified after a refusal, as
+ * with the streaming raftq_wire_encode.  raftq_node's turn is raftq_step_frames + this. */
+typedef struct raftq_prop {
+  uint64_t group;
+  uint32_t ent_first; /* into prop_ents[] */
+  uint32_t n_ents;    /* >= 1 */
+} raftq_prop_t; /* 16 bytes */
+typedef struct raftq_prop_ent {
+  uint64_t data_off; /* byte offset of Entry.Data in pool; ignored when data_len == 0 */
+  uint32_t data_len;
+  uint32_t type; /* raftpb.EntryType */
+} raftq_prop_ent_t; /* 16 bytes */
+int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props, const raftq_prop_ent_t* prop_ents, uint64_t n_prop_ents,
+                         const raftq_wire_msg_t* msgs, uint64_t n_msgs, const raftq_wire_ent_t* ents, uint64_t n_ents, const void* pool,
+                         uint64_t pool_bytes, void* out, uint64_t cap, uint64_t* frame_off /*[n_msgs + (N-1) n_props + 1]|NULL*/,
+                         raftq_wire_counts_t* counts /*|NULL*/);
+
 /* ---- WAL ------------------------------------------------------------------------------------ */
 
 /* walpb record types (wal/wal.go) */

@@ -168,6 +168,8 @@ _WIRE_SIGS = [
     ("raftq_step_submit_wire", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     ("raftq_step_frames", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_void_p]),
+    ("raftq_propose_frames", C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(WireCounts)]),
     ("raftq_step_stage_wire", C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("raftq_step_wire_msgs", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("raftq_step_wire_entries", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

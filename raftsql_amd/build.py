@@ -47,6 +47,7 @@ def lib_sources() -> list[str]:
         os.path.join(CSRC, "raftq_internal.hpp"),
         os.path.join(CSRC, "raftq_wire_kernels.hpp"),
         os.path.join(CSRC, "raftq_wire_parse.hpp"),
+        os.path.join(CSRC, "raftq_propose_kernels.hpp"),
         os.path.join(ROOT, "include", "raftq.h"),
         os.path.join(ROOT, "include", "raftq_step.h"),
         os.path.join(ROOT, "include", "raftq_pipe.h"),

@@ -200,6 +200,8 @@ struct raftq {
   uint32_t wire_last_tiles = 0;              // tiles of the streaming decode enqueued last (measurement builds dump its stamps)
   uint32_t wire_ticket_base = 0, wire_epoch = 0;
   uint32_t wire_chunk_base = 0, wire_chunk_pending = 0;  // the readers' chunk tickets (the head's fourth word), accounted like the tiles'
+  bool wire_chunk_unknown = false;           // the last launch had no reader workgroups: how far its chunk ticket got is not known
+  unsigned int prop_stamp = 0;               // raftq_propose_frames: the call's stamp (its validation's verdict word holds it when a record was refused)
   hipStream_t wire_copy_stream = nullptr;    // RAFTQ_WIRE_SDMA=1 (A/B only): the runtime's copies bring the decoder's input in
   hipEvent_t wire_copy_ev = nullptr;
   // raftq_wal_encode_begin .. _end: enqueued, its totals in wire_pin[8 ..]; `done`: a later wait has covered it and what _end
@@ -248,7 +250,12 @@ struct raftq_set {
 
 
 struct raftq_wire_counts;  // raftq_wire.h
+namespace raftqk {
+struct NodeArrays;  // raftq_step_kernels.hpp
+}
 namespace raftq_detail {
+// raftq_step.hip, for raftq_propose_frames (raftq_wire.hip): Step's device state exists (allocated on first use) and *out views it
+int node_arrays_of(raftq_t* h, raftqk::NodeArrays* out);
 int fail(raftq_t* h, int code, const std::string& msg);
 int use_device(raftq_t* h);
 int use_device_idle(raftq_t* h, const char* who);  // + no Step batch in flight (RAFTQ_ESTATE otherwise)

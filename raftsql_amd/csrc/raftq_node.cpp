@@ -396,6 +396,15 @@ struct raftq_node {
   bool wal_begun = false;         // flush_wal_begin .. flush_wal_end
   size_t wal_inflight = 0;
   raftq_wal_counts_t wal_cnt{};
+  // Round 6: what a leader is asked to propose goes to the device as two 16-byte records -- which group, which payload bytes -- and
+  // appendEntry + bcastAppend (the N - 1 MsgApp headers, the entry headers) are the device's, written into the encoder's input
+  // (raftq_propose_frames) -- for every group whose followers all have their Progress.Next at the log's tail, which is every group
+  // outside a catch-up.  RAFTQ_NODE_PROPOSE_DEVICE=0: handle_proposal + bcast_append on the host for everybody, as round 5.
+  bool propose_device = true;
+  PinBuf prop_recs, prop_ents;           // raftq_prop_t[], raftq_prop_ent_t[] of the turn (page-locked: the kernels read them in place)
+  std::vector<uint32_t> prop_slot;       // [group] index of the group's record in prop_recs, valid where prop_mark == the turn's epoch
+  std::vector<uint32_t> prop_mark;       // [group] epoch | kind: the group proposes this turn through the device (fast) or the host (slow)
+  uint64_t prop_cap = 0;                 // upper bound of the device-built frames' bytes, per addressee
   bool fuse_inbound = true;       // a turn's frames are decoded AND stepped by one submission (raftq_step_frames) whenever nothing was
                                   // raised locally ahead of them (RAFTQ_NODE_FUSE_INBOUND=0: raftq_wire_decode, then the staged rounds)
   bool broken = false;            // the engine's view of a log and the log itself disagree: advance() ends in ESTATE
@@ -959,14 +968,19 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     nm += lane.msgs.size();
     cap += lane.cap;
   }
-  if (nm == 0) return RAFTQ_OK;
+  // the groups whose proposals go through the device (raftq_propose_frames): N - 1 MsgApps each that exist only in HBM, one run per
+  // peer behind the frames of what this turn queued on the host
+  const size_t n_props = n->prop_recs.count<raftq_prop_t>(), n_pents = n->prop_ents.count<raftq_prop_ent_t>();
+  const size_t n_dev = n_props * (n->N - 1);
+  cap += n_props ? n->prop_cap * (n->N - 1) : 0;
+  if (nm + n_dev == 0) return RAFTQ_OK;
   if (n->out_oom) {
     lk.unlock();
     return RAFTQ_ENOMEM;
   }
   // the lanes back to back: per-peer order is the order of the sends, and every peer's frames are one slice of the stream
   n->enc_msgs.clear();
-  if (!n->enc_off.resize(nm + 1) || !n->enc_msgs.reserve(nm * sizeof(raftq_wire_msg_t)) || !n->enc_out.reserve(cap)) {
+  if (!n->enc_off.resize(nm + n_dev + 1) || !n->enc_msgs.reserve(std::max<size_t>(nm, 1) * sizeof(raftq_wire_msg_t)) || !n->enc_out.reserve(cap)) {
     lk.unlock();
     return RAFTQ_ENOMEM;
   }
@@ -988,7 +1002,11 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   int rc;
   {
     DevCall dev(n, raftq_node::kPhDevEncode);
-    rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap, n->enc_off.data(), &cnt);
+    if (n_props)
+      rc = raftq_propose_frames(n->h, n->prop_recs.as<raftq_prop_t>(), n_props, n->prop_ents.as<raftq_prop_ent_t>(), n_pents, nm ? sorted : nullptr, nm,
+                                n_ents ? ents : nullptr, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap, n->enc_off.data(), &cnt);
+    else
+      rc = raftq_wire_encode(n->h, sorted, nm, ents, n_ents, n->out_pool.p, n->out_pool.size, n->enc_out.p, cap, n->enc_off.data(), &cnt);
   }
   if (rc != RAFTQ_OK) return rc;
   // the marshal's wait covered the WAL encode enqueued in front of it: take its verdict now, still unlocked, and publish the
@@ -1002,17 +1020,29 @@ int flush_outbound(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   wal_publish(n);
   n->out_ents.clear();
   n->out_pool.clear();
+  n->prop_recs.clear();
+  n->prop_ents.clear();
   const uint64_t* off = n->enc_off.data();
-  for (uint32_t p = 0; p < n->N; ++p) {
-    if (first[p + 1] == first[p]) continue;
-    PeerQueue& q = n->outbound[p];
+  // peer p's bytes: the slice of what the host queued for it, then (p != self) its run of the device-built MsgApps -- the order
+  // of the sends: the proposals are the turn's last
+  auto take = [&](PeerQueue& q, uint64_t k0, uint64_t k1) {
+    if (k1 == k0) return;
     if (q.bytes.empty()) q.reuse_spares();
-    const uint64_t from = off[first[p]], base = q.bytes.size();
-    q.bytes.append((const char*)n->enc_out.p + from, (size_t)(off[first[p + 1]] - from));
+    const uint64_t from = off[k0], base = q.bytes.size();
+    q.bytes.append((const char*)n->enc_out.p + from, (size_t)(off[k1] - from));
     if (q.ends_ok) {
       const size_t at = q.ends.size();
-      q.ends.resize(at + (size_t)(first[p + 1] - first[p]));
-      for (uint64_t k = first[p]; k < first[p + 1]; ++k) q.ends[at + (k - first[p])] = base + (off[k + 1] - from);
+      q.ends.resize(at + (size_t)(k1 - k0));
+      for (uint64_t k = k0; k < k1; ++k) q.ends[at + (k - k0)] = base + (off[k + 1] - from);
+    }
+  };
+  uint32_t run = 0;
+  for (uint32_t p = 0; p < n->N; ++p) {
+    PeerQueue& q = n->outbound[p];
+    take(q, first[p], first[p + 1]);
+    if (n_props && p != n->self) {
+      take(q, nm + (uint64_t)run * n_props, nm + (uint64_t)(run + 1) * n_props);
+      ++run;
     }
   }
   return RAFTQ_OK;
@@ -1125,6 +1155,8 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   if (const char* fi = std::getenv("RAFTQ_NODE_FUSE_INBOUND")) n->fuse_inbound = std::atoi(fi) != 0;
   if (const char* dn = std::getenv("RAFTQ_NODE_DELTAS_NOWAIT")) n->deltas_nowait = std::atoi(dn) != 0;
   if (const char* sw = std::getenv("RAFTQ_NODE_SPLIT_WAL")) n->split_wal = std::atoi(sw) != 0;
+  if (const char* pd = std::getenv("RAFTQ_NODE_PROPOSE_DEVICE")) n->propose_device = std::atoi(pd) != 0;
+  if (n_peers < 2) n->propose_device = false;  // (a single-peer group commits what it appends: the report has to come back)
   if (const char* ev = std::getenv("RAFTQ_PROFILE_EVERY")) n->prof_every = std::strtoull(ev, nullptr, 10);
   try {
     n->groups.resize(n_groups);
@@ -1134,6 +1166,8 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
     n->blocked_mark.assign(n_groups, 0);
     n->defer_mark.assign(n_groups, 0);
     n->dirty_mark.assign(n_groups, 0);
+    n->prop_mark.assign(n_groups, 0);
+    n->prop_slot.assign(n_groups, 0);
   } catch (...) {
     raftq_destroy(n->h);
     delete n;
@@ -1506,10 +1540,11 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   std::vector<uint32_t>& deferred = n->deferred;
   std::vector<uint64_t>& dirty = n->dirty_list;
   auto next_epoch = [&] {  // a fresh value no mark holds
-    if (++n->epoch == 0) {
+    if (++n->epoch >= 0x80000000u) {  // (below 2^31: the proposals' marks use the top bit)
       std::fill(n->blocked_mark.begin(), n->blocked_mark.end(), 0u);
       std::fill(n->dirty_mark.begin(), n->dirty_mark.end(), 0u);
       std::fill(n->defer_mark.begin(), n->defer_mark.end(), 0u);
+      std::fill(n->prop_mark.begin(), n->prop_mark.end(), 0u);
       n->epoch = 1;
     }
     return n->epoch;
@@ -1676,10 +1711,74 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   ph.next(raftq_node::kPhProps);
 
   // -- proposeC (raft.go:211-215)
+  n->prop_recs.clear();
+  n->prop_ents.clear();
+  n->prop_cap = 0;
   if (props.size()) {
     dirty.clear();
     const uint32_t ep = next_epoch();
     const size_t np_ = props.size();
+    // Pass 1 (round 6): which groups go through the device.  A group this node leads whose followers all have Progress.Next at
+    // the log's tail (what bcastAppend leaves behind: every group outside a catch-up) gets ONE raftq_prop_t for the turn, in the
+    // order of its first proposal -- the order its MsgApps take in every peer's stream -- and a count; everybody else takes
+    // round 5's way below (handle_proposal: a follower forwards, a leader with a lagging follower sends from its own log).
+    // prop_mark[g] == ep: through the device, prop_slot[g] = its record; == ep with the top bit set aside: decided, host.
+    std::vector<uint32_t>& pmark = n->prop_mark;
+    constexpr uint32_t kSlowBit = 0x80000000u;
+    const uint32_t ep_fast = ep, ep_slow = ep | kSlowBit;  // (epochs stay below 2^31: next_epoch)
+    size_t n_fast = 0;
+    if (n->propose_device) {
+      bool pin_oom = !n->prop_recs.reserve(np_ * sizeof(raftq_prop_t)) || !n->prop_ents.reserve(np_ * sizeof(raftq_prop_ent_t));
+      raftq_prop_t* recs = n->prop_recs.as<raftq_prop_t>();
+      for (size_t i = 0; i < np_ && !pin_oom; ++i) {
+        if (i + 16 < np_) __builtin_prefetch(&n->groups[props.group[i + 16]]);
+        if (i + 8 < np_) __builtin_prefetch(&n->prog[props.group[i + 8] * n->N * 2]);
+        const uint64_t gi = props.group[i];
+        uint32_t& mk = pmark[gi];
+        if (mk == ep_slow) continue;
+        const uint64_t len = props.off[i + 1] - props.off[i];
+        if (mk == ep_fast) {  // another statement for a group already on its way: one MsgApp carries them all, within raft.Config.MaxSizePerMsg
+          raftq_prop_t& r = recs[n->prop_slot[gi]];
+          r.n_ents++;
+          r.ent_first = (uint32_t)std::min<uint64_t>((uint64_t)r.ent_first + len, 0xffffffffull);  // (the payload bytes so far; the entries' place comes below)
+          continue;
+        }
+        const Group& g = n->groups[gi];
+        bool fast = g.role == RAFTQ_ROLE_LEADER && g.leading;
+        const uint64_t tail = g.log.size() + 1;
+        for (uint32_t p = 0; fast && p < n->N; ++p)
+          if (p != n->self) fast = n->next_of(gi, p) == tail;
+        if (!fast) {
+          mk = ep_slow;
+          continue;
+        }
+        mk = ep_fast;
+        n->prop_slot[gi] = (uint32_t)n_fast;
+        recs[n_fast++] = raftq_prop_t{gi, (uint32_t)std::min<uint64_t>(len, 0xffffffffull), 1};
+      }
+      // a group whose statements outgrow one message (raft.Config.MaxSizePerMsg, raft.go:157: sendAppend would cut it) is the host's
+      uint32_t ent_at = 0;
+      size_t kept = 0;
+      for (size_t k = 0; k < n_fast; ++k) {
+        raftq_prop_t r = recs[k];
+        if (r.n_ents > kMaxEntriesPerMsg || r.ent_first >= kMaxBytesPerMsg) {
+          pmark[r.group] = ep_slow;
+          continue;
+        }
+        r.ent_first = ent_at;
+        ent_at += r.n_ents;
+        r.n_ents = 0;  // (filled again, entry by entry, by the second pass)
+        n->prop_slot[r.group] = (uint32_t)kept;
+        recs[kept++] = r;
+      }
+      n_fast = kept;
+      if (pin_oom) n->out_oom = true;
+    }
+    raftq_prop_t* recs = n->prop_recs.as<raftq_prop_t>();
+    raftq_prop_ent_t* pents = n->prop_ents.as<raftq_prop_ent_t>();
+    size_t n_pents = 0;
+    // Pass 2: every statement, in arrival order.  Through the device: the payload once into the log's arena and once into the
+    // turn's page-locked pool (where the encoder's readers find it), the log's entry, 16 bytes that say where the payload is.
     for (size_t i = 0; i < np_; ++i) {
       if (i + 16 < np_) __builtin_prefetch(&n->groups[props.group[i + 16]]);
       if (i + 8 < np_) {  // appendEntry writes behind the log's last entry
@@ -1688,10 +1787,48 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       }
       const uint64_t gi = props.group[i];
       const Entry one{0, props.blob.data() + props.off[i], (uint32_t)(props.off[i + 1] - props.off[i])};
+      if (n_fast != 0 && pmark[gi] == ep_fast) {
+        Group& g = n->groups[gi];
+        const char* at = n->arena.put(one.data, one.len);
+        if (!at) {
+          n->oom = true;
+          break;
+        }
+        g.log.push_back(n->pool, Entry{g.term, at, one.len});
+        raftq_prop_t& r = recs[n->prop_slot[gi]];
+        raftq_prop_ent_t& pe = pents[r.ent_first + r.n_ents++];
+        pe.data_off = one.len ? n->out_pool.size : 0;
+        pe.data_len = one.len;
+        pe.type = 0;
+        ++n_pents;
+        if (!n->out_pool.append(one.data, one.len)) n->out_oom = true;
+        n->prop_cap += 48 + one.len;
+        continue;
+      }
       if (handle_proposal(n, gi, n->groups[gi], &one, 1) && n->dirty_mark[gi] != ep) {
         n->dirty_mark[gi] = ep;
         dirty.push_back(gi);
       }
+    }
+    // what bcastAppend leaves on the host for the groups that went through the device: Progress.Next past what is being sent
+    // (the optimistic cursor), the WAL's dirty mark, the count of sends
+    for (size_t k = 0; k < n_fast; ++k) {
+      if (k + 8 < n_fast) __builtin_prefetch(&n->prog[recs[k + 8].group * n->N * 2], 1);
+      const uint64_t gi = recs[k].group;
+      Group& g = n->groups[gi];
+      const uint64_t next = g.log.size() + 1;
+      for (uint32_t p = 0; p < n->N; ++p)
+        if (p != n->self) n->next_of(gi, p) = next;
+      wal_touch(n, gi, g);
+    }
+    n->stats.msgs_sent += n_fast * (n->N - 1);
+    n->stats.msgs_built_on_device += n_fast * (n->N - 1);
+    n->prop_cap += n_fast * 160;  // (per addressee: flush_outbound multiplies)
+    n->prop_recs.size = n_fast * sizeof(raftq_prop_t);
+    n->prop_ents.size = n_pents * sizeof(raftq_prop_ent_t);
+    if (n->oom) {  // (a device record without its log entry must not go out)
+      n->prop_recs.clear();
+      n->prop_ents.clear();
     }
     if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
   }

@@ -72,6 +72,15 @@ NodeArrays node_arrays(raftq_t* h, uint8_t recs = raftqk::kRecsCaller) {
   return a;
 }
 
+}  // namespace
+int raftq_detail::node_arrays_of(raftq_t* h, raftqk::NodeArrays* out) {
+  if (int rc = ensure_node_state(h)) return rc;
+  *out = node_arrays(h);
+  h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;  // as in raftq_step_submit: the live state moves
+  return RAFTQ_OK;
+}
+namespace {
+
 // device scratch of one batch, carved from a single allocation
 struct Scratch {
   MsgRec* msgs;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "raftq_internal.hpp"
+#include "raftq_propose_kernels.hpp"
 #include "raftq_wire_kernels.hpp"
 
 using namespace raftqk;
@@ -21,7 +22,7 @@ using raftq_detail::fail;
 using raftq_detail::use_device;
 
 static_assert(sizeof(raftq_wire_msg_t) == sizeof(WireMsg) && sizeof(raftq_wire_ent_t) == sizeof(WireEnt) &&
-                  sizeof(raftq_wal_rec_t) == sizeof(WalRec),
+                  sizeof(raftq_wal_rec_t) == sizeof(WalRec) && sizeof(raftq_prop_t) == sizeof(PropRec) && sizeof(raftq_prop_ent_t) == sizeof(PropEnt),
               "ABI struct mismatch");
 
 namespace {
@@ -99,7 +100,7 @@ unsigned fused_grid(uint32_t n_tiles, unsigned fit = 208u) {
 unsigned dec_tile() {
   const char* e = std::getenv("RAFTQ_WIRE_TILE");  // read per call: the tests run both
   const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return v == 256 ? 256u : 128u;
+  return v == 128 ? 128u : 256u;  // measured (profiles/r06/wire_tile_ab.jsonl): 256 frames 172 us a call, 128 frames 186
 }
 
 constexpr uint64_t kLbHead = 4;  // words in front of the status arrays
@@ -129,13 +130,15 @@ struct FeedPlan {
   InFeed in;
   size_t off[3];
 };
-FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3], uint64_t max_chunks, unsigned readers_dflt = 48u) {
+// extra[k]: bytes of array k that follow, in the scratch, what the readers bring (records a kernel writes there itself)
+FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3], uint64_t max_chunks, unsigned readers_dflt = 48u,
+                   const uint64_t* extra = nullptr) {
   FeedPlan p{};
   uint64_t total = 0;
   for (int k = 0; k < 3; ++k) total += bytes[k];
   const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(max_chunks, (total + feed_chunk() - 1) / feed_chunk()));
   for (int k = 0; k < 3; ++k) {
-    p.off[k] = c.take(bytes[k]);
+    p.off[k] = c.take(bytes[k] + (extra ? extra[k] : 0));
     p.in.seg[k].src = (const uint8_t*)src[k];
     p.in.seg[k].bytes = bytes[k];
     p.in.seg[k].per_chunk = std::max<uint64_t>(256, ((bytes[k] + chunks - 1) / chunks + 255) / 256 * 256);
@@ -145,22 +148,25 @@ FeedPlan plan_feed(Carver& c, const void* const src[3], const uint64_t bytes[3],
   return p;
 }
 // (called once per launch, after tile_ctl: the chunk tickets of the launch are accounted for in tile_ctl_launched)
-void bind_feed(raftq_t* h, FeedPlan& p, uint8_t* base, unsigned long long* flags) {
+// The chunk ticket is monotonic across calls: a launch with reader workgroups draws exactly chunks + readers tickets whoever
+// copies what (a worker that serves itself claims by compare-and-swap and never draws past the end; the readers draw the rest
+// and one beyond each), so the next call's base is known without asking the device.  A launch with NO readers (RAFTQ_WIRE_READERS=0,
+// RAFTQ_WIRE_SDMA) only claims the chunks somebody waited for -- a chunk past every array's end, or one that holds bytes no tile
+// names, stays unclaimed -- so its count is not known: the ticket word is zeroed in front of such a launch and in front of the
+// first launch after one (a 4-byte memset in the stream: test and A/B shapes only).
+int bind_feed(raftq_t* h, FeedPlan& p, uint8_t* base, unsigned long long* flags) {
   for (int k = 0; k < 3; ++k) p.in.seg[k].dst = base + p.off[k];
   p.in.flag = flags;
   p.in.chunk_ticket = reinterpret_cast<unsigned int*>(h->wire_lb + 3);  // the head's fourth word
+  if (p.in.readers == 0 || h->wire_chunk_unknown) {
+    HIPCHK(h, hipMemsetAsync(p.in.chunk_ticket, 0, 4, h->stream));
+    h->wire_chunk_base = 0;
+    h->wire_chunk_unknown = p.in.readers == 0;
+  }
   p.in.chunk_base = h->wire_chunk_base;
   p.in.no_serve = 0;
-  h->wire_chunk_pending = p.in.chunks + p.in.readers;  // every reader workgroup draws exactly one ticket beyond the chunks
-}
-// RAFTQ_WIRE_SDMA=<chunk KiB> (A/B only; VERDICT r04 / r05 item 1: "build the SDMA-reader A/B instead of citing the old probe"): the
-// decoder's input is brought in by the RUNTIME's copies on a second stream -- one hipMemcpyAsync per array and chunk, the chunk's
-// flag raised behind it by hipStreamWriteValue64 -- and the kernel is launched with no reader workgroups and workers that only
-// wait.  profiles/r06/wire_sdma_ab.txt has what it measured.
-uint64_t sdma_chunk() {
-  const char* e = std::getenv("RAFTQ_WIRE_SDMA");
-  const long v = e ? std::strtol(e, nullptr, 10) : 0;
-  return v >= 1 && v <= 65536 ? (uint64_t)v << 10 : 0;
+  h->wire_chunk_pending = p.in.readers ? p.in.chunks + p.in.readers : 0;  // every reader workgroup draws exactly one ticket beyond the chunks
+  return RAFTQ_OK;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -180,6 +186,7 @@ int tile_ctl(raftq_t* h, uint64_t n_tiles, TileCtl* ctl) {
     h->wire_lb_tiles = tiles;
     h->wire_ticket_base = 0;
     h->wire_chunk_base = 0;
+    h->wire_chunk_unknown = false;
     h->wire_epoch = 0;
   }
   if (++h->wire_epoch > 0xffffu) {
@@ -317,9 +324,9 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
     FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
     if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
     if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-    bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+    if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
     hipLaunchKernelGGL(wire_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, n_ents, pool_bytes,
-                       (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d);
+                       (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d, (const unsigned int*)nullptr, 0u);
     HIPCHK(h, hipGetLastError());
     tile_ctl_launched(h, n_tiles, workers);
     HIPCHK(h, raftq_detail::wait_call(h));
@@ -387,6 +394,75 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   return RAFTQ_OK;
 }
 
+int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props, const raftq_prop_ent_t* prop_ents, uint64_t n_prop_ents,
+                         const raftq_wire_msg_t* msgs, uint64_t n_msgs, const raftq_wire_ent_t* ents, uint64_t n_ents, const void* pool,
+                         uint64_t pool_bytes, void* out, uint64_t cap, uint64_t* frame_off, raftq_wire_counts_t* counts) {
+  if (int rc = raftq_detail::use_device_idle(h, "raftq_propose_frames")) return rc;
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  if (n_props == 0)  // nothing proposed: the marshal of what the caller queued
+    return raftq_wire_encode(h, msgs, n_msgs, ents, n_ents, pool, pool_bytes, out, cap, frame_off, counts);
+  if (!props || !prop_ents || n_prop_ents == 0 || (n_msgs && !msgs) || (n_ents && !ents) || (pool_bytes && !pool) || !out || cap == 0)
+    return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: null argument");
+  if (h->N < 2)
+    return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a single-peer group commits what it appends -- raftq_apply_log_deltas reports that");
+  const uint64_t n_dev = n_props * (h->N - 1), n = n_msgs + n_dev, n_e = n_ents + n_prop_ents;
+  if (n > kMaxItems || n_e > kMaxItems) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: batch too large");
+  if (int rc = ensure_pin(h)) return rc;
+  void *v_props = dev_view(props), *v_pe = dev_view(prop_ents), *v_msgs = n_msgs ? dev_view(msgs) : nullptr, *v_ents = n_ents ? dev_view(ents) : nullptr,
+       *v_pool = pool_bytes ? dev_view(pool) : nullptr, *v_out = dev_view(out), *v_off = frame_off ? dev_view(frame_off) : nullptr;
+  const bool mapped = v_props && v_pe && (!n_msgs || v_msgs) && (!n_ents || v_ents) && (!pool_bytes || v_pool) && v_out && (!frame_off || v_off) &&
+                      cap <= ((uint64_t)1 << 31);
+  if (!(mapped && aligned16(v_props) && aligned16(v_pe) && aligned16(v_msgs) && aligned16(v_ents) && aligned16(v_pool) && aligned16(v_out) && aligned16(v_off)))
+    return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: every array must be page-locked (raftq_host_alloc, hipHostMalloc, hipHostRegister) and "
+                                 "16-byte aligned -- append with raftq_apply_log_deltas and marshal with raftq_wire_encode otherwise");
+  NodeArrays na;
+  if (int rc = raftq_detail::node_arrays_of(h, &na)) return rc;
+  const uint32_t n_tiles = blocks_for(n);
+  const unsigned workers = fused_grid(n_tiles);
+  Carver fc;
+  const void* const src[3] = {v_msgs, v_ents, v_pool};
+  const uint64_t sizes[3] = {n_msgs * sizeof(WireMsg), n_ents * sizeof(WireEnt), pool_bytes};
+  const uint64_t extra[3] = {n_dev * sizeof(WireMsg), n_prop_ents * sizeof(WireEnt), 0};
+  TileCtl ctl;
+  if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1] + sizes[2]) / feed_chunk() + 1), &ctl)) return rc;
+  FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles, 48u, extra);
+  if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
+  if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
+  if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
+  // appendEntry + bcastAppend on the device, INTO the encoder's input (the scratch behind what its readers bring) ...
+  // the validation's verdict: a word that holds THIS call's stamp when a record was refused (no memset in the chain: a stamp
+  // of an earlier call reads as "fine")
+  unsigned int* bad = (unsigned int*)(h->wire_flags + 2);
+  if (++h->prop_stamp == 0) h->prop_stamp = 1;
+  const unsigned int stamp = h->prop_stamp;
+  WireMsg* msgs_dev = (WireMsg*)(plan.in.seg[0].dst + sizes[0]);
+  WireEnt* ents_dev = (WireEnt*)(plan.in.seg[1].dst + sizes[1]);
+  const dim3 pg((unsigned)((n_props + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(propose_check_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe, n_prop_ents, pool_bytes, bad,
+                     stamp);
+  hipLaunchKernelGGL(propose_apply_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe,
+                     (const unsigned int*)bad, stamp, msgs_dev, ents_dev, (uint32_t)n_ents);
+  // ... and the marshal of everything right behind it: one wait
+  hipLaunchKernelGGL(wire_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, n_e, pool_bytes, (uint8_t*)h->wire_out,
+                     (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d, (const unsigned int*)bad, stamp);
+  HIPCHK(h, hipGetLastError());
+  tile_ctl_launched(h, n_tiles, workers);
+  HIPCHK(h, raftq_detail::wait_call(h));
+  if (int rc = tile_ctl_check(h, "raftq_propose_frames")) return rc;
+  const uint64_t total = h->wire_pin[0];
+  if (h->wire_pin[1])
+    return fail(h, RAFTQ_EINVAL,
+                "raftq_propose_frames: a proposal names a group this node does not lead (or names one twice, or carries no entries, or a payload "
+                "outside the pool) -- nothing was appended; or a queued message has to / from >= 255 or a range out of bounds; the output is not valid");
+  if (counts) {
+    counts->n_msgs = n;
+    counts->n_ents = n_e;
+    counts->bytes = total;
+  }
+  if (total > cap) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: out is too small (counts->bytes is the size needed); the proposals WERE appended");
+  return RAFTQ_OK;
+}
+
 // The streaming decode (raftq_wire_kernels.hpp "the streaming form"), enqueued on the handle's stream and NOT waited for;
 // v_*: the caller's arrays as the device addresses them.  msgs_d / ff: see wire_dec_fused_kernel (raftq_step_frames).
 static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t nbytes, const void* v_off, uint64_t n, void* v_msgs, void* v_ents,
@@ -403,13 +479,12 @@ static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t n
   FeedPlan plan = plan_feed(c, src, bytes, h->wire_lb_tiles, tb == 128 ? 96u : 48u);
   const size_t o_spill = c.take((size_t)n_tiles * tb * kEntQ * sizeof(WireEnt));  // a slot of kEntQ entry headers per lane
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-  bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
-  WireEnt* spill = (WireEnt*)((uint8_t*)h->wire_dev + o_spill);
   const bool sdma = sdma_chunk() != 0;
+  if (sdma) plan.in.readers = 0;
+  if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
+  WireEnt* spill = (WireEnt*)((uint8_t*)h->wire_dev + o_spill);
   if (sdma) {
-    plan.in.readers = 0;
-    plan.in.no_serve = 1;
-    h->wire_chunk_pending = 0;  // nobody draws a chunk ticket
+    plan.in.no_serve = 1;  // nobody draws a chunk ticket
     if (!h->wire_copy_stream) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->wire_copy_stream, hipStreamNonBlocking));
       HIPCHK(h, hipEventCreateWithFlags(&h->wire_copy_ev, hipEventDisableTiming));
@@ -559,7 +634,7 @@ static int wal_streaming_enqueue(raftq_t* h, const void* v_recs, uint64_t n, con
   FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles);
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
-  bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+  if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
   hipLaunchKernelGGL(wal_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, pool_bytes, prev_crc,
                      (uint8_t*)h->wire_out, (uint8_t*)v_out, cap, (uint64_t*)v_off, ctl, h->wire_pin_d + pin_base);
   HIPCHK(h, hipGetLastError());
@@ -744,7 +819,7 @@ int raftq_wal_decode(raftq_t* h, const void* bytes, uint64_t nbytes, const uint6
       if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1]) / feed_chunk() + 1), &ctl)) return rc;
       FeedPlan plan = plan_feed(c, src, sizes, h->wire_lb_tiles);
       if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, c.off)) return rc;
-      bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags]);
+      if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
       hipLaunchKernelGGL(wal_dec_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, nbytes, n, prev_crc,
                          (WalRec*)f_recs, ctl, h->wire_pin_d);
       HIPCHK(h, hipGetLastError());

@@ -867,6 +867,9 @@ __device__ inline bool feed_wait_chunks(const InFeed& in, uint32_t epoch, uint32
 }
 template <int TB = kBlock>
 __device__ inline bool feed_wait(const InFeed& in, uint32_t epoch, int k, uint64_t lo, uint64_t hi, unsigned int* stuck, uint32_t* slot) {
+  // (an array may go on, in the scratch, behind what the READERS bring: records an earlier kernel of the stream left there --
+  // raftq_propose_frames -- are simply there)
+  if (hi > in.seg[k].bytes) hi = in.seg[k].bytes;
   if (hi <= lo) {
     __syncthreads();
     return true;
@@ -1000,7 +1003,10 @@ constexpr uint8_t kFrameSkip = 0x10, kFrameHold = 0x20, kFrameBarrier = 0x40, kF
 // a slot of its own in device scratch (`ent_spill`: 15 % of the lanes write one to three 32-byte headers; they are read back,
 // L2-resident, when the tile's run is gathered behind the look-back), and the tile is a template parameter: 128 frames =
 // 34.3 KB (four workgroups per CU, every tile of a 64K-frame call resident at once, each waiting for its own bytes);
-// 256 frames = 68.5 KB (two per CU).  RAFTQ_WIRE_TILE picks; profiles/r06/wire_tile_ab.txt has the A/B.
+// 256 frames = 68.5 KB (two per CU).  RAFTQ_WIRE_TILE picks.  MEASURED (profiles/r06/wire_tile_ab.jsonl, 64K frames, one box, one
+// process): 256 frames 172 us a call, 128 frames 186 -- residency is not what bounds a call (every tile has a worker waiting
+// for its bytes either way; the call is its input over the link plus ONE tile's chain), and twice the tiles are twice the
+// look-back words, barriers and status traffic.  256 is the default; both are tested.
 template <int TB>
 static __global__ __launch_bounds__(TB) void wire_dec_fused_kernel(InFeed in, uint64_t nbytes, uint64_t n, WireMsg* msgs_h, WireEnt* ents_h,
                                                                    uint64_t ents_cap, TileCtl ctl, uint64_t* __restrict__ pin,
@@ -1674,9 +1680,12 @@ __device__ inline void tile_bytes_out(const uint8_t* __restrict__ src, uint8_t* 
 // tile's run of bytes and its frame offsets out.  Nothing is ever written at or behind out_h[cap].
 // pin[0] = bytes the stream takes, pin[1] = messages refused (to / from >= 255, ranges outside ents[] / the pool: they
 // count as empty frames), pin[3] = a wait gave up.
+// raftq_propose_frames: msgs / ents go on in the scratch behind the caller's (in.seg[0] / [1].bytes: what the readers bring) with
+// the records propose_apply_kernel wrote there -- n and n_ents count both parts; *ext_bad == ext_stamp (its validation refused the call):
+// every message counts as refused, nothing is built.
 static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in, uint64_t n, uint64_t n_ents, uint64_t pool_bytes, uint8_t* d_out,
                                                                        uint8_t* out_h, uint64_t cap, uint64_t* off_h, TileCtl ctl,
-                                                                       uint64_t* __restrict__ pin) {
+                                                                       uint64_t* __restrict__ pin, const unsigned int* __restrict__ ext_bad, unsigned int ext_stamp) {
   if (blockIdx.x < in.readers) {
     reader_role(in, ctl.epoch);
     return;
@@ -1702,6 +1711,7 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
     WireMsg m = {};
     if (live) m = msgs[i];
     bool is_bad = live && (m.to >= 255 || m.from >= 255 || (m.n_ents != 0 && (uint64_t)m.ent_first + m.n_ents > n_ents));
+    if (ext_bad != nullptr && *ext_bad == ext_stamp) is_bad = live;
     const bool walks = live && !is_bad && m.n_ents != 0;
     // the entry headers this tile names are in the scratch ...
     uint64_t lo = walks ? (uint64_t)m.ent_first * sizeof(WireEnt) : ~0ull, hi = walks ? ((uint64_t)m.ent_first + m.n_ents) * sizeof(WireEnt) : 0;

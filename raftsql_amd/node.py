@@ -32,7 +32,7 @@ assert STATUS_DTYPE.itemsize == C.sizeof(Status)
 
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("turns", "msgs_stepped", "msgs_sent", "entries_published", "hard_states",
-                                          "proposals_dropped", "frames_dropped", "wal_records")]
+                                          "proposals_dropped", "frames_dropped", "wal_records", "msgs_built_on_device")]
 
 
 _SIGS = [

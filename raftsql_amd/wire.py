@@ -27,6 +27,8 @@ WIRE_MSG_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("log_term", "<u8"), 
                         ("reject_hint", "<u8"), ("from", "<u4"), ("type", "u1"), ("reject", "u1"), ("to", "u1"),
                         ("flags", "u1"), ("ent_first", "<u4"), ("n_ents", "<u4")])
 WIRE_ENT_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("data_off", "<u8"), ("data_len", "<u4"), ("type", "<u4")])
+PROP_DT = np.dtype([("group", "<u8"), ("ent_first", "<u4"), ("n_ents", "<u4")])  # == raftq_prop_t
+PROP_ENT_DT = np.dtype([("data_off", "<u8"), ("data_len", "<u4"), ("type", "<u4")])  # == raftq_prop_ent_t
 WAL_REC_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("data_off", "<u8"), ("data_len", "<u4"),
                        ("vote", "<u4"), ("crc", "<u4"), ("kind", "u1"), ("entry_type", "u1"), ("flags", "u1"),
                        ("_pad", "u1")])
@@ -138,6 +140,20 @@ class WireEngine(NodeEngine):
             outs = outs.copy()
         got_ents = ents[: min(int(c.n_ents), len(ents))] if ents is not None else np.zeros(0, WIRE_ENT_DT)
         return msgs[:n], got_ents, outs, c
+
+    def propose_frames(self, props: np.ndarray, prop_ents: np.ndarray, msgs: np.ndarray, ents: np.ndarray, pool: np.ndarray, out: np.ndarray,
+                       off: np.ndarray | None = None):
+        """raftq_propose_frames: appendEntry + bcastAppend for props[] on the device, written into the encoder's input, and the
+        marshal of msgs[] + those MsgApps -- one submission, one wait.  All arrays page-locked (engine.pinned_*).
+        -> (stream view of out, frame_off | None, counts)"""
+        assert props.dtype == PROP_DT and prop_ents.dtype == PROP_ENT_DT and msgs.dtype == WIRE_MSG_DT and ents.dtype == WIRE_ENT_DT
+        c = _lib.WireCounts()
+        self._chk(self._lib.raftq_propose_frames(self._h, props.ctypes.data if len(props) else None, len(props),
+                                                 prop_ents.ctypes.data if len(prop_ents) else None, len(prop_ents),
+                                                 msgs.ctypes.data if len(msgs) else None, len(msgs), ents.ctypes.data if len(ents) else None, len(ents),
+                                                 pool.ctypes.data if len(pool) else None, len(pool), out.ctypes.data, len(out),
+                                                 off.ctypes.data if off is not None else None, C.byref(c)))
+        return out[: int(c.bytes)], off, c
 
     def step_stage_wire(self, n_cap: int, nbytes_cap: int):
         """the arrays the next step_submit_wire_staged() takes (raftq_step_stage_wire) -> (frame_off uint64[n_cap + 1],

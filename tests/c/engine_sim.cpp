@@ -498,6 +498,70 @@ int raftq_wire_encode(raftq_t* h, const raftq_wire_msg_t* msgs, uint64_t n, cons
   rq_wire_encode(msgs, n, ents, (const uint8_t*)pool, (uint8_t*)out, cap, frame_off);
   return RAFTQ_OK;
 }
+// raftq_propose_frames from its parts, as include/raftq_wire.h states it: the records are validated (nothing applied on a
+// refusal), then for every group appendEntry -- the oracle's raftq_apply_log_deltas with the new tail -- and the N - 1 MsgApps
+// bcastAppend sends, built the way raftq_node.cpp's send_append builds them; then the oracle's encoder over msgs[] + those.
+int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props, const raftq_prop_ent_t* prop_ents, uint64_t n_prop_ents,
+                         const raftq_wire_msg_t* msgs, uint64_t n_msgs, const raftq_wire_ent_t* ents, uint64_t n_ents, const void* pool,
+                         uint64_t pool_bytes, void* out, uint64_t cap, uint64_t* frame_off, raftq_wire_counts_t* counts) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (counts) *counts = raftq_wire_counts_t{0, 0, 0, 0};
+  if (n_props == 0) return raftq_wire_encode(h, msgs, n_msgs, ents, n_ents, pool, pool_bytes, out, cap, frame_off, counts);
+  if (!props || !prop_ents || n_prop_ents == 0 || (n_msgs && !msgs) || (n_ents && !ents) || (pool_bytes && !pool) || !out || cap == 0)
+    return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: null argument");
+  if (h->N < 2) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a single-peer group commits what it appends");
+  std::vector<uint8_t> seen(h->G, 0);
+  for (uint64_t i = 0; i < n_props; ++i) {
+    const raftq_prop_t& p = props[i];
+    bool bad = p.group >= h->G || p.n_ents == 0 || p.n_ents > 1024 || (uint64_t)p.ent_first + p.n_ents > n_prop_ents;
+    if (!bad) bad = h->role[p.group] != RAFTQ_ROLE_LEADER || seen[p.group]++;
+    for (uint32_t k = 0; !bad && k < p.n_ents; ++k) {
+      const raftq_prop_ent_t& e = prop_ents[p.ent_first + k];
+      bad = e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off);
+    }
+    if (bad) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a proposal names a group this node does not lead (or twice, or no entries, or a payload outside the pool) -- nothing was appended");
+  }
+  const uint64_t n_dev = n_props * (h->N - 1);
+  std::vector<raftq_wire_msg_t> all(n_msgs + n_dev);
+  std::vector<raftq_wire_ent_t> all_e(n_ents + n_prop_ents);
+  if (n_msgs) memcpy(all.data(), msgs, n_msgs * sizeof(raftq_wire_msg_t));
+  if (n_ents) memcpy(all_e.data(), ents, n_ents * sizeof(raftq_wire_ent_t));
+  for (uint64_t i = 0; i < n_props; ++i) {
+    const raftq_prop_t& p = props[i];
+    const uint64_t g = p.group, old_last = h->last_index[g], old_term = h->last_term[g];
+    raftq_log_delta_t d{g, old_last + p.n_ents, h->term[g], 0};
+    rq_node_state_t s = h->state();
+    rq_oracle_apply_log_deltas(&s, &d, 1, nullptr);
+    for (uint32_t k = 0; k < p.n_ents; ++k) {
+      const raftq_prop_ent_t& e = prop_ents[p.ent_first + k];
+      raftq_wire_ent_t& w = all_e[n_ents + p.ent_first + k];
+      memset(&w, 0, sizeof(w));
+      w.term = h->term[g];
+      w.index = old_last + 1 + k;
+      w.data_len = e.data_len;
+      w.data_off = e.data_len ? e.data_off : 0;
+      w.type = e.type;
+    }
+    uint32_t run = 0;
+    for (uint32_t to = 0; to < h->N; ++to) {
+      if (to == h->self) continue;
+      raftq_wire_msg_t& m = all[n_msgs + (uint64_t)run * n_props + i];
+      memset(&m, 0, sizeof(m));
+      m.group = g;
+      m.term = h->term[g];
+      m.log_term = old_term;
+      m.index = old_last;
+      m.commit = h->committed[g];
+      m.from = h->self;
+      m.type = RAFTQ_MSG_APP;
+      m.to = (uint8_t)to;
+      m.ent_first = (uint32_t)(n_ents + p.ent_first);
+      m.n_ents = p.n_ents;
+      ++run;
+    }
+  }
+  return raftq_wire_encode(h, all.data(), all.size(), all_e.data(), all_e.size(), pool, pool_bytes, out, cap, frame_off, counts);
+}
 int raftq_wire_decode(raftq_t* h, const void* stream, uint64_t nbytes, const uint64_t* frame_off, uint64_t n, raftq_wire_msg_t* msgs,
                       raftq_wire_ent_t* ents, uint64_t ents_cap, raftq_wire_counts_t* counts) {
   if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");

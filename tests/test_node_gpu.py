@@ -481,6 +481,53 @@ def test_node_speaks_raftpb_frames(Cluster):
         c.close()
 
 
+@pytest.mark.parametrize("N,per_turn", [(3, 1), (5, 3)])
+def test_device_built_msgapps_are_the_hosts_byte_for_byte(Cluster, N, per_turn, monkeypatch):
+    """a leader's appendEntry + bcastAppend for what it is asked to propose run on the device
+    (raftq_propose_frames: the MsgApp headers are written into the encoder's input in HBM and never exist on the host).  The same
+    scripted cluster -- elections, several statements per group and turn, statements proposed on followers too (forwarded as
+    MsgProp: the host's way), three WALs -- run once with RAFTQ_NODE_PROPOSE_DEVICE=0 (round 5: handle_proposal + bcast_append
+    on the host) and once with the device path: every batch of frames that crosses the transport, every WAL byte and every
+    commit channel are IDENTICAL, byte for byte, and the device path was really taken."""
+    G = 24
+
+    def run(device_path):
+        monkeypatch.setenv("RAFTQ_NODE_PROPOSE_DEVICE", "1" if device_path else "0")
+        c = Cluster(G, N, wal=True, seed=11)
+        try:
+            seen = _tap(c)
+            c.start()
+            elect(c)
+            lead = c.leaders().copy()
+            for wave in range(6):
+                for g in range(G):
+                    for k in range(per_turn if g % 3 else 1):
+                        proposer = int(lead[g]) if (g + wave) % 4 else (int(lead[g]) + 1) % N  # every fourth: through a follower
+                        c.nodes[proposer].propose(g, b"INSERT INTO t (v) VALUES (%d) -- g%d w%d" % (k, g, wave))
+                c.step()
+            c.settle()
+            c.run(2)
+            c.settle()
+            assert (c.leaders() == lead).all()
+            chans = [[nd.drain(g) for g in range(G)] for nd in c.nodes]
+            check_safety(c)
+            built = sum(nd.stats()["msgs_built_on_device"] for nd in c.nodes)
+            # every statement proposed ON its group's leader went out as device-built MsgApps: 3 of 4 waves per group
+            assert built == (0 if not device_path else (N - 1) * sum(1 for wave in range(6) for g in range(G) if (g + wave) % 4))
+            return [(a, b, bytes(blob)) for a, b, blob in seen], [bytes(w) for w in c.wal], chans
+        finally:
+            c.close()
+
+    frames_h, wal_h, chans_h = run(False)
+    frames_d, wal_d, chans_d = run(True)
+    assert chans_h == chans_d
+    assert len(frames_h) == len(frames_d)
+    for (a, b, x), (a2, b2, y) in zip(frames_h, frames_d):
+        assert (a, b) == (a2, b2) and x == y, "a batch of frames from node %d to node %d differs" % (a, b)
+    assert wal_h == wal_d
+    assert sum(len(x) for _, _, x in frames_d) > 6 * G * 60  # (the statements did travel)
+
+
 def test_node_drops_frames_that_are_not_for_it(Cluster):
     """Well-framed bytes whose message does not parse, is addressed elsewhere, comes from no peer,
     names no group or is of a kind a peer never sends are counted and dropped; the node lives on."""

@@ -314,7 +314,7 @@ def _form(monkeypatch, form):
     monkeypatch.setenv("RAFTQ_WIRE_STREAMING", "1" if form == "streaming" else "0")
 
 
-@pytest.mark.parametrize("copies", ["streaming", "streaming-256", "copying"])
+@pytest.mark.parametrize("copies", ["streaming", "streaming-128", "copying"])
 @pytest.mark.parametrize("seed,n,big", [(171, 1, 0), (172, 900, 4), (173, 6000, 0), (174, 333, 1)])
 def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
     """What a node hands the codecs every turn: every buffer page-locked.  The call is then ONE launch with ONE wait and has to
@@ -327,8 +327,8 @@ def test_codecs_on_page_locked_buffers(seed, n, big, copies, monkeypatch):
     from raftsql_amd.engine import pinned_copy, pinned_empty
     from raftsql_amd.wire import WireEngine
 
-    if copies == "streaming-256":  # the decoder's 256-frame tile (round 5's; the default is 128 frames)
-        monkeypatch.setenv("RAFTQ_WIRE_TILE", "256")
+    if copies == "streaming-128":  # the decoder's 128-frame tile (34 KB of LDS, four workgroups per CU; the default is 256 frames, 68 KB)
+        monkeypatch.setenv("RAFTQ_WIRE_TILE", "128")
         copies = "streaming"
     _form(monkeypatch, copies)
     rng = np.random.default_rng(seed)
@@ -447,7 +447,7 @@ def test_streaming_decode_at_bench_size(wgs, tile, monkeypatch):
     from raftsql_amd.wire import WireEngine
 
     monkeypatch.setenv("RAFTQ_WIRE_WGS", str(wgs))
-    monkeypatch.setenv("RAFTQ_WIRE_TILE", str(tile))  # frames per tile = threads per decoder workgroup (round 6: 128 is the default)
+    monkeypatch.setenv("RAFTQ_WIRE_TILE", str(tile))  # frames per tile = threads per decoder workgroup (256 is the default)
     rng = np.random.default_rng(1900 + wgs)
     n = 65536
     m, e, pool = _wiregen.random_msgs(rng, n, big_every=0, ent_frac=0.15)
@@ -1317,3 +1317,187 @@ def test_step_frames_at_bench_size(oracle):
             else:
                 _same(go, want_o, f"results, call {it}")
         _stepgen.assert_same_state(e, st)
+
+
+# ---- raftq_propose_frames: appendEntry + bcastAppend on the device, into the encoder's input (round 6) ------------------------
+
+def _propose_setup(rng, G, N, me, n_props, n_host_msgs, max_per_group=3):
+    """a handle whose node leads every group but a few, random tails; -> (state dict, props, prop_ents, pool, host msgs / ents)"""
+    from raftsql_amd.wire import PROP_DT, PROP_ENT_DT
+
+    term = rng.integers(2, 9, G).astype(np.uint64)
+    last = rng.integers(1, 1000, G).astype(np.uint64)
+    last_term = np.minimum(term, rng.integers(1, 9, G).astype(np.uint64))
+    committed = (last * rng.random(G)).astype(np.uint64)
+    role = np.full(G, 2, np.uint8)
+    groups = rng.choice(G, n_props, replace=False).astype(np.uint64)
+    cnt = rng.integers(1, max_per_group + 1, n_props).astype(np.uint32)
+    props = np.zeros(n_props, PROP_DT)
+    props["group"], props["n_ents"] = groups, cnt
+    props["ent_first"] = np.cumsum(cnt) - cnt
+    ne = int(cnt.sum())
+    pe = np.zeros(ne, PROP_ENT_DT)
+    pe["data_len"] = rng.integers(0, 200, ne)
+    pe["data_len"][rng.random(ne) < 0.1] = 0  # (an empty statement: Entry.Data omitted)
+    # the host's own part of the turn: responses and a resend with entries, payloads in the same pool
+    hm, he, hpool = _wiregen.random_msgs(rng, n_host_msgs, big_every=0, ent_frac=0.2) if n_host_msgs else (np.zeros(0, W.WIRE_MSG_DT), np.zeros(0, W.WIRE_ENT_DT), b"")
+    hpool = _wiregen_u8(hpool)
+    pe["data_off"] = len(hpool) + np.cumsum(pe["data_len"]) - pe["data_len"]
+    pool = np.concatenate([hpool, rng.integers(0, 256, int(pe["data_len"].sum()), dtype=np.uint8)])
+    st = dict(term=term, last=last, last_term=last_term, committed=committed, role=role)
+    return st, props, pe, pool, hm, he
+
+
+def _propose_expect(st, N, me, props, pe, hm, he):
+    """what raft.go:211-215 -> appendEntry + bcastAppend make of props[]: the messages (host part, then one run per peer), the
+    entry headers, and the state afterwards -- built here the way raftq_node.cpp's send_append builds them"""
+    n_props = len(props)
+    msgs = np.zeros(len(hm) + n_props * (N - 1), W.WIRE_MSG_DT)
+    ents = np.zeros(len(he) + len(pe), W.WIRE_ENT_DT)
+    msgs[: len(hm)] = hm
+    ents[: len(he)] = he
+    new_last = st["last"].copy()
+    new_last_term = st["last_term"].copy()
+    for i, p in enumerate(props):
+        g, k, f = int(p["group"]), int(p["n_ents"]), int(p["ent_first"])
+        for j in range(k):
+            e = ents[len(he) + f + j]
+            e["term"], e["index"] = st["term"][g], st["last"][g] + 1 + j
+            e["data_len"], e["type"] = pe["data_len"][f + j], pe["type"][f + j]
+            e["data_off"] = pe["data_off"][f + j] if pe["data_len"][f + j] else 0
+            ents[len(he) + f + j] = e
+        run = 0
+        for to in range(N):
+            if to == me:
+                continue
+            m = msgs[len(hm) + run * n_props + i]
+            m["group"], m["term"], m["log_term"], m["index"], m["commit"] = g, st["term"][g], st["last_term"][g], st["last"][g], st["committed"][g]
+            m["from"], m["to"], m["type"], m["ent_first"], m["n_ents"] = me, to, 3, len(he) + f, k
+            msgs[len(hm) + run * n_props + i] = m
+            run += 1
+        new_last[g] += k
+        new_last_term[g] = st["term"][g]
+    return msgs, ents, new_last, new_last_term
+
+
+def _propose_engine(G, N, me, st):
+    from raftsql_amd.wire import WireEngine
+
+    e = WireEngine(G, N, self_peer=me)
+    match = np.tile(st["committed"], (N, 1))
+    match[me] = st["last"]
+    e.load_match(match, st["committed"])
+    e.load_terms(st["term"], np.ones(G, np.uint64))
+    e.load_roles(st["role"])
+    e.load_node(st["term"], np.full(G, me + 1, np.uint32), np.full(G, me + 1, np.uint32), st["last"], st["last_term"])
+    return e
+
+
+@pytest.mark.parametrize("N,me,n_props,n_host", [(3, 0, 1, 0), (3, 2, 700, 300), (5, 1, 5000, 0), (7, 6, 2000, 4000), (2, 1, 33, 7)])
+def test_propose_frames_is_append_entry_and_bcast_append(N, me, n_props, n_host):
+    """raftq_propose_frames against the oracle's encoder over the messages bcastAppend would have built on the host: the stream
+    and every frame offset byte for byte -- the caller's own messages first, then one run of MsgApps per peer --, and the
+    device-resident state afterwards: lastIndex / lastTerm moved, the leader's own Match with them, nothing else touched."""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+
+    G = 8192
+    rng = np.random.default_rng(7000 + n_props + N)
+    st, props, pe, pool, hm, he = _propose_setup(rng, G, N, me, n_props, n_host)
+    want_m, want_e, new_last, new_last_term = _propose_expect(st, N, me, props, pe, hm, he)
+    want, want_off = W.wire_encode(want_m, want_e, pool)
+    with _propose_engine(G, N, me, st) as e:
+        before = e.read_node()
+        match0 = e.read_match()
+        out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(len(want_m) + 1, np.uint64)
+        out[:] = 0xEE
+        got, goff, c = e.propose_frames(pinned_copy(props), pinned_copy(pe), pinned_copy(hm), pinned_copy(he), pinned_copy(pool), out, off)
+        assert np.array_equal(goff, want_off)
+        assert got.tobytes() == want.tobytes() and bytes(out[len(want):]) == b"\xee" * 64
+        assert (c.n_msgs, c.n_ents, c.bytes) == (len(want_m), len(want_e), len(want))
+        after = e.read_node()
+        assert np.array_equal(after["last_index"], new_last) and np.array_equal(after["last_term"], new_last_term)
+        for k in ("term", "vote", "lead", "first_idx", "role", "committed"):
+            assert np.array_equal(after[k], before[k]), k
+        match1 = e.read_match()
+        want_match = match0.copy()
+        want_match[me] = np.maximum(match0[me], new_last)
+        assert np.array_equal(match1, want_match)
+        # and Step goes on from the new tail: an acknowledgement of the last new entry by a quorum commits it
+        from raftsql_amd import step as S_
+
+        g = props["group"].astype(np.uint64)
+        for p in [q for q in range(N) if q != me][: N // 2]:
+            outs, _ = e.step_batch(S_.pack_msgs(g, S_.MSG_APP_RESP, term=st["term"][g.astype(np.int64)], frm=p, index=new_last[g.astype(np.int64)]))
+        assert np.array_equal(e.read_committed()[g.astype(np.int64)], new_last[g.astype(np.int64)])
+
+
+def test_propose_frames_refuses_and_applies_nothing():
+    """a record that names a group this node does not lead, a group twice, no entries, entries outside prop_ents[], a payload
+    outside the pool, a single-peer handle, pageable arrays: RAFTQ_EINVAL, the state untouched, and the next call is whole"""
+    import ctypes as C
+
+    from raftsql_amd import _lib
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+    from raftsql_amd.wire import WireEngine
+
+    G, N, me = 4096, 3, 1
+    rng = np.random.default_rng(7777)
+    st, props, pe, pool, hm, he = _propose_setup(rng, G, N, me, 600, 50)
+    st["role"][int(props["group"][17])] = 0  # a follower among them
+    st2 = st.copy()
+    dup = props.copy()
+    dup["group"][5] = dup["group"][400]
+    none = props.copy()
+    none["n_ents"][9] = 0
+    outside = props.copy()
+    outside["ent_first"][599] = len(pe)
+    far = pe.copy()
+    far["data_off"][3], far["data_len"][3] = len(pool), 8
+    with _propose_engine(G, N, me, st) as e:
+        before, match0 = e.read_node(), e.read_match()
+        out, off = pinned_empty(1 << 20, np.uint8), pinned_empty(len(hm) + 600 * (N - 1) + 1, np.uint64)
+        ph, pee, ppool = pinned_copy(hm), pinned_copy(he), pinned_copy(pool)
+        for what, (pr, ents_, pl) in {"follower": (props, pe, pool), "twice": (dup, pe, pool), "empty": (none, pe, pool),
+                                      "range": (outside, pe, pool), "payload": (props, far, pool)}.items():
+            if what != "follower":
+                e.load_roles(np.full(G, 2, np.uint8))
+            with pytest.raises(Exception) as ei:
+                e.propose_frames(pinned_copy(pr), pinned_copy(ents_), ph, pee, ppool, out, off)
+            assert "propose_frames" in str(ei.value), (what, ei.value)
+            after = e.read_node()
+            for k in ("term", "last_index", "last_term", "committed"):
+                assert np.array_equal(after[k], before[k]), (what, k)
+            assert np.array_equal(e.read_match(), match0), what
+        # pageable arrays: refused before anything is enqueued
+        c = _lib.WireCounts()
+        rc = e._lib.raftq_propose_frames(e._h, props.ctypes.data, len(props), pe.ctypes.data, len(pe), None, 0, None, 0, ppool.ctypes.data, len(ppool),
+                                         out.ctypes.data, len(out), None, C.byref(c))
+        assert rc == _lib.RAFTQ_EINVAL
+        # ... and the whole call right behind the refusals
+        want_m, want_e, new_last, _ = _propose_expect(st2 | {"role": np.full(G, 2, np.uint8)}, N, me, props, pe, hm, he)
+        want, want_off = W.wire_encode(want_m, want_e, pool)
+        got, goff, _ = e.propose_frames(pinned_copy(props), pinned_copy(pe), ph, pee, ppool, out, off)
+        assert got.tobytes() == want.tobytes() and np.array_equal(goff[: len(want_off)], want_off)
+        assert np.array_equal(e.read_node()["last_index"], new_last)
+    with WireEngine(64, 1, self_peer=0) as e1:
+        with pytest.raises(Exception):
+            e1.propose_frames(pinned_copy(props[:1]), pinned_copy(pe), pinned_copy(hm[:0]), pinned_copy(he[:0]), pinned_copy(pool), out, None)
+
+
+def test_propose_frames_at_bench_size():
+    """32,768 groups x 3 peers, one statement each, behind 65,536 queued messages (the one-node leg's turn): the stream is the
+    oracle's, three calls in a row (the control block carries over)"""
+    from raftsql_amd.engine import pinned_copy, pinned_empty
+
+    G, N, me = 32768, 3, 0
+    rng = np.random.default_rng(7321)
+    st, props, pe, pool, hm, he = _propose_setup(rng, G, N, me, G, 65536, max_per_group=1)
+    with _propose_engine(G, N, me, st) as e:
+        pp, ppe, ph, phe, ppool = pinned_copy(props), pinned_copy(pe), pinned_copy(hm), pinned_copy(he), pinned_copy(pool)
+        for rep in range(3):
+            want_m, want_e, new_last, new_lt = _propose_expect(st, N, me, props, pe, hm, he)
+            want, want_off = W.wire_encode(want_m, want_e, pool)
+            out, off = pinned_empty(len(want) + 64, np.uint8), pinned_empty(len(want_m) + 1, np.uint64)
+            got, goff, _ = e.propose_frames(pp, ppe, ph, phe, ppool, out, off)
+            assert np.array_equal(goff, want_off) and got.tobytes() == want.tobytes()
+            st["last"], st["last_term"] = new_last, new_lt

@@ -41,20 +41,25 @@ ents["data_len"] = rng.integers(40, 120, ne)
 ents["data_off"] = np.cumsum(ents["data_len"]) - ents["data_len"]
 pool = rng.integers(0, 256, max(1, int(ents["data_len"].sum())), dtype=np.uint8)
 
+T128 = {"RAFTQ_WIRE_TILE": "128"}
 VARIANTS = [
-    ("tile128 (default)", {}),
-    ("tile256", {"RAFTQ_WIRE_TILE": "256"}),
-    ("tile128 readers48", {"RAFTQ_WIRE_READERS": "48"}),
-    ("tile128 readers144", {"RAFTQ_WIRE_READERS": "144"}),
-    ("tile256 readers96", {"RAFTQ_WIRE_TILE": "256", "RAFTQ_WIRE_READERS": "96"}),
-    ("tile128 chunk16K", {"RAFTQ_WIRE_CHUNK": "16384"}),
-    ("tile128 chunk4K", {"RAFTQ_WIRE_CHUNK": "4096"}),
-    ("tile128 workers416", {"RAFTQ_WIRE_WGS": "416"}),
-    ("tile128 no readers (every chunk self-served)", {"RAFTQ_WIRE_READERS": "0"}),
-    ("tile128 sdma 64K", {"RAFTQ_WIRE_SDMA": "64"}),
-    ("tile128 sdma 256K", {"RAFTQ_WIRE_SDMA": "256"}),
-    ("tile128 sdma 1M", {"RAFTQ_WIRE_SDMA": "1024"}),
-    ("tile256 sdma 256K", {"RAFTQ_WIRE_TILE": "256", "RAFTQ_WIRE_SDMA": "256"}),
+    ("tile256 (default)", {}),
+    ("tile128", T128),
+    ("tile256 workers208 (round 5's grid)", {"RAFTQ_WIRE_WGS": "208"}),
+    ("tile256 chunk4K", {"RAFTQ_WIRE_CHUNK": "4096"}),
+    ("tile256 chunk6K", {"RAFTQ_WIRE_CHUNK": "6144"}),
+    ("tile256 chunk16K", {"RAFTQ_WIRE_CHUNK": "16384"}),
+    ("tile256 readers32", {"RAFTQ_WIRE_READERS": "32"}),
+    ("tile256 readers96", {"RAFTQ_WIRE_READERS": "96"}),
+    ("tile128 readers48", dict(T128, RAFTQ_WIRE_READERS="48")),
+    ("tile128 readers144", dict(T128, RAFTQ_WIRE_READERS="144")),
+    ("tile128 chunk4K", dict(T128, RAFTQ_WIRE_CHUNK="4096")),
+    ("tile128 workers416", dict(T128, RAFTQ_WIRE_WGS="416")),
+    ("tile256 no readers (every chunk self-served)", {"RAFTQ_WIRE_READERS": "0"}),
+    ("tile256 sdma 64K", {"RAFTQ_WIRE_SDMA": "64"}),
+    ("tile256 sdma 256K", {"RAFTQ_WIRE_SDMA": "256"}),
+    ("tile256 sdma 1M", {"RAFTQ_WIRE_SDMA": "1024"}),
+    ("tile256 sdma 4M (one copy per array)", {"RAFTQ_WIRE_SDMA": "4096"}),
 ]
 KEYS = sorted({k for _, env in VARIANTS for k in env})
 

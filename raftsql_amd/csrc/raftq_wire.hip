@@ -168,6 +168,15 @@ int bind_feed(raftq_t* h, FeedPlan& p, uint8_t* base, unsigned long long* flags)
   h->wire_chunk_pending = p.in.readers ? p.in.chunks + p.in.readers : 0;  // every reader workgroup draws exactly one ticket beyond the chunks
   return RAFTQ_OK;
 }
+// RAFTQ_WIRE_SDMA=<chunk KiB> (A/B only; VERDICT r04 / r05 item 1: "build the SDMA-reader A/B instead of citing the old probe"): the
+// decoder's input is brought in by the RUNTIME's copies on a second stream -- one hipMemcpyAsync per array and chunk, the chunk's
+// flag raised behind it by hipStreamWriteValue64 -- and the kernel is launched with no reader workgroups and workers that only
+// wait.  profiles/r06/wire_tile_ab.jsonl has what it measured (2.0 ms with 64 KB chunks, 0.35 ms with 1 MB chunks, against 0.17 ms).
+uint64_t sdma_chunk() {
+  const char* e = std::getenv("RAFTQ_WIRE_SDMA");
+  const long v = e ? std::strtol(e, nullptr, 10) : 0;
+  return v >= 1 && v <= 65536 ? (uint64_t)v << 10 : 0;
+}
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // ticket word + status arrays for a call of n_tiles tiles; a new call is a new epoch (the words of older calls read as

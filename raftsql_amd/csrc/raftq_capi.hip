@@ -133,31 +133,31 @@ hipError_t launch_n(const SweepLaunch& L, unsigned flags, int nt, hipStream_t s)
 // the segmented turn's sweep (sweep_segments_kernel): commit-only sweeps of one handle
 template <int N>
 hipError_t launch_segments_n(const SweepArgs& a, uint32_t n_tiles, bool gated, int nt, Advance16* list, unsigned int* counts_host, unsigned int* counts_dev,
-                             hipStream_t s) {
+                             hipStream_t s, const Arrival& ar) {
   const dim3 grid(n_tiles), block(kBlock);
   if (gated) {
-    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
-    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
-    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, 0>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
+    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
+    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, true, 0>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
   } else {
-    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
-    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev);
-    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, 0>), grid, block, 0, s, a, list, counts_host, counts_dev);
+    if (nt == 3) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT | kStNT>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
+    else if (nt == 1) hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, kLdNT>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
+    else hipLaunchKernelGGL((sweep_segments_kernel<N, kGPL, false, 0>), grid, block, 0, s, a, list, counts_host, counts_dev, ar);
   }
   return hipGetLastError();
 }
 hipError_t launch_segments(uint32_t N, const SweepArgs& a, uint32_t n_tiles, bool gated, int nt, Advance16* list, unsigned int* counts_host,
-                           unsigned int* counts_dev, hipStream_t s) {
+                           unsigned int* counts_dev, hipStream_t s, const Arrival& ar) {
   switch (N) {
-    case 1: return launch_segments_n<1>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 2: return launch_segments_n<2>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 3: return launch_segments_n<3>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 4: return launch_segments_n<4>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 5: return launch_segments_n<5>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 6: return launch_segments_n<6>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 7: return launch_segments_n<7>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 8: return launch_segments_n<8>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
-    case 9: return launch_segments_n<9>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s);
+    case 1: return launch_segments_n<1>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 2: return launch_segments_n<2>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 3: return launch_segments_n<3>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 4: return launch_segments_n<4>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 5: return launch_segments_n<5>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 6: return launch_segments_n<6>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 7: return launch_segments_n<7>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 8: return launch_segments_n<8>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
+    case 9: return launch_segments_n<9>(a, n_tiles, gated, nt, list, counts_host, counts_dev, s, ar);
     default: return hipErrorInvalidValue;
   }
 }
@@ -503,6 +503,7 @@ void raftq_destroy(raftq_t* h) {
   if (h->tl_h) (void)hipHostFree(h->tl_h);
   if (h->h_partials) (void)hipHostFree(h->h_partials);
   if (h->h_total) (void)hipHostFree(h->h_total);
+  if (h->arrive_count) (void)hipFree(h->arrive_count);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->many_aux) {
@@ -972,6 +973,8 @@ int raftq_detail::ensure_tick_state(raftq_t* h) {
 static int ensure_tick_offsets2(raftq_t* h, uint64_t nw);
 static int flag_mode();
 static hipError_t wait_turn(raftq_t* h, uint64_t flag_epoch, int kind = 0);
+static int flag_mode();
+static int ensure_arrive(raftq_t* h);
 
 extern "C" {
 
@@ -1124,9 +1127,24 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
   if (const char* e = std::getenv("RAFTQ_TICK_LISTS_BPW")) bpw = std::atoi(e) == 4 ? 4 : 1;
   const uint64_t per_wg = (uint64_t)kWaves * bpw;
   const dim3 grid((unsigned)((nw + per_wg - 1) / per_wg));
+  // the completion word: a one-thread kernel behind the lists (only a kernel boundary orders eight XCDs' stores to host memory
+  // before it -- raftq_cycle's finding), polled by the host; RAFTQ_CYCLE_FLAG=arrive: the lists kernel's last workgroup to arrive
+  // raises it itself, =packet: the runtime's write-value packet; the blocking wait where the word cannot be had
+  uint64_t epoch = 0;
+  Arrival ar{nullptr, nullptr, 0};
+  if (h->stream_write_ok) {
+    epoch = ++h->compact_epoch;
+    if ((uint32_t)epoch == 0) epoch = ++h->compact_epoch;
+    h->flag_mask = ~0ull;
+    if (flag_mode() == 3) {
+      if (int rc = ensure_arrive(h)) return rc;
+      epoch &= 0xffffffffull;  // (the arrival form's word carries 32 bits of epoch)
+      ar = Arrival{(unsigned long long*)(h->d_total + 3), h->arrive_count, (uint32_t)epoch};
+    }
+  }
 #define RAFTQ_TICK_LISTS_LAUNCH(BM, B)                                                                                                       \
   hipLaunchKernelGGL((tick_lists32_kernel<BM, B>), grid, dim3(kBlock), 0, h->stream, (const uint64_t*)h->hup_bits, (const uint64_t*)h->beat_bits, \
-                     (const uint4*)h->tick_partials, nw, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b)
+                     (const uint4*)h->tick_partials, nw, hup_d, cap_h, beat_d, cap_b, map_d, h->d_total, off_h, off_b, ar)
   if (bitmap) {
     if (bpw == 1) RAFTQ_TICK_LISTS_LAUNCH(true, 1);
     else RAFTQ_TICK_LISTS_LAUNCH(true, 4);
@@ -1136,14 +1154,12 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
   }
 #undef RAFTQ_TICK_LISTS_LAUNCH
   HIPCHK(h, hipGetLastError());
-  // the completion word: a one-thread kernel behind the lists (only a kernel boundary orders eight XCDs' stores to host memory
-  // before it -- raftq_cycle's finding), polled by the host; the blocking wait where the word cannot be had
-  uint64_t epoch = 0;
-  if (h->stream_write_ok && flag_mode() == 1) {
-    epoch = ++h->compact_epoch;
-    h->flag_mask = ~0ull;
+  if (epoch && flag_mode() == 1) {
     hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(64), 0, h->stream, h->d_total + 3, epoch);
     HIPCHK(h, hipGetLastError());
+  } else if (epoch && flag_mode() == 2 && hipStreamWriteValue64(h->stream, (void*)(h->d_total + 3), epoch, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    epoch = 0;  // not supported here: the blocking wait
   }
   HIPCHK(h, wait_turn(h, epoch, 1));
   *n_hup = h->tl_n_hup = h->h_total[0];
@@ -1251,12 +1267,19 @@ int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self
 // flag the host can poll (its value is left in h->compact_epoch_armed): a one-thread kernel of ours behind the
 // compaction (default), or the runtime's stream write-value packet (RAFTQ_CYCLE_FLAG=packet: a 3.4 us kernel that
 // starts 5 us after the compaction ends, profiles/r03/cycle_kernel_trace_before.txt).
-static int flag_mode() {  // 1 = raise_flag_kernel, 2 = write-value packet
+static int flag_mode() {  // 1 = raise_flag_kernel, 2 = write-value packet, 3 = the last workgroup to arrive raises it (where a kernel can: the segmented turn, the tick lists)
   static const int m = [] {
     const char* e = std::getenv("RAFTQ_CYCLE_FLAG");
-    return e && std::strcmp(e, "packet") == 0 ? 2 : 1;
+    return e && std::strcmp(e, "packet") == 0 ? 2 : e && std::strcmp(e, "arrive") == 0 ? 3 : 1;
   }();
   return m;
+}
+// the arrival counter of mode 3: a device word of the handle, zero between kernels
+static int ensure_arrive(raftq_t* h) {
+  if (h->arrive_count) return RAFTQ_OK;
+  HIPCHK(h, hipMalloc((void**)&h->arrive_count, 64));
+  HIPCHK(h, hipMemsetAsync(h->arrive_count, 0, 64, h->stream));
+  return RAFTQ_OK;
 }
 
 template <typename Adv>
@@ -1333,12 +1356,18 @@ static int enqueue_sweep_segments(raftq_t* h, unsigned flags) {
     h->seg_cap = n_tiles;
   }
   const SweepArgs a = sweep_args(h, h->cur, true);
-  HIPCHK(h, launch_segments(h->N, a, n_tiles, (flags & RAFTQ_SWEEP_GATED) != 0, sweep_policy(flags, sweep_footprint(h)), (Advance16*)h->adv_d, h->seg_hd,
-                            h->seg_d, h->stream));
-  sweep_done(h, flags, kGPL);
   uint64_t epoch = ++h->compact_epoch;
   if ((uint32_t)epoch == 0) epoch = ++h->compact_epoch;  // (the word's top half is never 0 for a turn in flight)
-  hipLaunchKernelGGL(raise_flag_segments_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_total + 3, (uint32_t)epoch, h->seg_d, n_tiles);
+  Arrival ar{nullptr, nullptr, (uint32_t)epoch};
+  if (flag_mode() == 3) {  // RAFTQ_CYCLE_FLAG=arrive: no flag kernel -- the sweep's last workgroup to arrive raises the word
+    if (int rc = ensure_arrive(h)) return rc;
+    ar.flag = (unsigned long long*)(h->d_total + 3);
+    ar.count = h->arrive_count;
+  }
+  HIPCHK(h, launch_segments(h->N, a, n_tiles, (flags & RAFTQ_SWEEP_GATED) != 0, sweep_policy(flags, sweep_footprint(h)), (Advance16*)h->adv_d, h->seg_hd,
+                            h->seg_d, h->stream, ar));
+  sweep_done(h, flags, kGPL);
+  if (ar.flag == nullptr) hipLaunchKernelGGL(raise_flag_segments_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_total + 3, (uint32_t)epoch, h->seg_d, n_tiles);
   HIPCHK(h, hipGetLastError());
   h->compact_epoch_armed = (uint64_t)(uint32_t)epoch << 32;
   h->flag_mask = 0xffffffff00000000ull;
@@ -1441,8 +1470,12 @@ hipError_t raftq_detail::wait_call(raftq_t* h) {
     return e && std::strcmp(e, "block") == 0;
   }();
   hipError_t e;
-  if (block || !h->stream_write_ok || flag_mode() != 1 || !h->d_total) {
+  if (block || !h->stream_write_ok || !h->d_total) {
     e = hipStreamSynchronize(h->stream);
+  } else if (flag_mode() == 2) {  // RAFTQ_CYCLE_FLAG=packet (A/B): the runtime's write-value packet behind the call's kernels
+    const uint64_t epoch = ++h->compact_epoch;
+    h->flag_mask = ~0ull;
+    e = hipStreamWriteValue64(h->stream, (void*)(h->d_total + 3), epoch, 0) != hipSuccess ? hipStreamSynchronize(h->stream) : wait_turn(h, epoch, 1);
   } else {
     const uint64_t epoch = ++h->compact_epoch;
     h->flag_mask = ~0ull;

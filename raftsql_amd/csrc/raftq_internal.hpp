@@ -80,6 +80,7 @@ struct raftq {
   // turn, [1] every other call that ends on the completion word: codecs, tick lists): a codec call under a profiler must not
   // switch the turn's wake-up off
   uint32_t flag_misses[2] = {0, 0}, flag_rested[2] = {0, 0};
+  unsigned int* arrive_count = nullptr;       // RAFTQ_CYCLE_FLAG=arrive: the arrival counter (device, zero between kernels)
   uint64_t flag_fallbacks = 0;                // turns that ended in the blocking wait although a flag was armed
   uint32_t* claim = nullptr;    // u32 [N][ld] vote-slot claims, lazily allocated
   // sparse ingest: device copy of the batch (validated on the way in) and the "bad batch" epoch words

@@ -928,8 +928,33 @@ static __global__ void raise_flag_kernel(uint64_t* flag, uint64_t epoch) {
 // list[t * tile groups ...] -- a tile cannot have more changed groups than groups -- and its count at counts[t]: the list
 // is ascending when its segments are walked in order (raftq_last_advance_segments).  The changed bitmap and the per-wave
 // counts are written as by sweep_kernel: raftq_collect_changed still works afterwards.
+// VERDICT r05 item 6, candidate (b): the completion word WITHOUT a kernel of its own.  Every workgroup makes its stores -- records
+// and counts in page-locked host memory among them -- performed system-wide (`__threadfence_system()` by every thread, then the
+// workgroup's barrier) BEFORE it counts itself in (one agent-scope atomic); the workgroup that finds itself last adds up what the
+// others left (agent-scope loads: they may sit in another XCD's L2) and stores the word with system-scope release, and hands the
+// counter back zero.  Round 3's attempt had the compaction's last workgroup raise the flag with NO fence in the other workgroups:
+// the word overtook the data in 8 of 15 tests.  RAFTQ_CYCLE_FLAG=arrive selects this form; profiles/r06/flag_ab.txt has what
+// RAFTQ_CYCLE_CHECK made of it over 16,000 turns and what it costs beside the one-thread kernel and the runtime's write-value packet.
+struct Arrival {
+  unsigned long long* flag;  // the completion word as the device addresses it, or nullptr: the flag is somebody else's (a kernel behind this one)
+  unsigned int* count;       // device word, zero between kernels
+  uint32_t epoch;
+};
+// ALL threads of the workgroup call it, behind their last store.  -> true in every thread of the LAST workgroup to arrive.
+__device__ __forceinline__ bool arrive_last(const Arrival& ar, uint32_t* slot /*LDS*/) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int seen = __hip_atomic_fetch_add(ar.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    *slot = seen == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  return *slot != 0;
+}
+
 template <int N, int GPL, bool GATED, int POLICY>
-static __global__ __launch_bounds__(kBlock) void sweep_segments_kernel(SweepArgs a, Advance16* list, unsigned int* counts_host, unsigned int* counts_dev) {
+static __global__ __launch_bounds__(kBlock) void sweep_segments_kernel(SweepArgs a, Advance16* list, unsigned int* counts_host, unsigned int* counts_dev,
+                                                                       Arrival ar) {
   constexpr bool STNT = (POLICY & kStNT) != 0;
   constexpr int kTile = kBlock * GPL;
   constexpr int kRounds = GPL / 2;
@@ -993,6 +1018,24 @@ static __global__ __launch_bounds__(kBlock) void sweep_segments_kernel(SweepArgs
     if (e) list[pos + rank] = make_advance((Advance16*)nullptr, g0 + 2 * lane, r.c[j].x, nw[j].x);
     if (o) list[pos + rank + (e ? 1 : 0)] = make_advance((Advance16*)nullptr, g0 + 2 * lane + 1, r.c[j].y, nw[j].y);
     pos += __popcll(even[j]) + __popcll(odd[j]);
+  }
+  if (ar.flag != nullptr) {  // RAFTQ_CYCLE_FLAG=arrive: the last workgroup to arrive is the flag kernel
+    __shared__ uint32_t last_slot;
+    __shared__ uint32_t red[kWaves];
+    if (!arrive_last(ar, &last_slot)) return;
+    uint32_t acc = 0;
+    for (uint32_t i = tid; i < gridDim.x; i += kBlock) acc += __hip_atomic_load(counts_dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t total = 0;
+#pragma unroll
+      for (int k = 0; k < kWaves; ++k) total += red[k];
+      __hip_atomic_store(ar.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ar.flag, ((unsigned long long)ar.epoch << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1374,7 +1417,8 @@ static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint6
                                                                       const uint4* __restrict__ partials, uint64_t n_chunks /* gpad / 256 */,
                                                                       uint32_t* hup_out, uint64_t hup_cap, uint32_t* beat_out, uint64_t beat_cap,
                                                                       uint64_t* beat_map, uint64_t* totals /*[2]*/,
-                                                                      const uint64_t* __restrict__ wave_off_hup, const uint64_t* __restrict__ wave_off_beat) {
+                                                                      const uint64_t* __restrict__ wave_off_hup, const uint64_t* __restrict__ wave_off_beat,
+                                                                      Arrival ar) {
   constexpr int kC = kWaves * BPW;  // 256-group chunks (a tick wave's share) per workgroup
   __shared__ uint64_t red[2][kWaves];
   __shared__ uint32_t mine[2][kC];
@@ -1479,6 +1523,13 @@ static __global__ __launch_bounds__(kBlock) void tick_lists32_kernel(const uint6
     run_out(beat_out, beat_cap, pos_b, ids[1], tot_b, tid);
   } else if (tid < kC * 4 && first_wave * 4 + tid < n_chunks * 4) {
     beat_map[first_wave * 4 + tid] = map_words[tid];
+  }
+  if (ar.flag != nullptr) {  // RAFTQ_CYCLE_FLAG=arrive (see sweep_segments_kernel): the totals are among the stores fenced before the count
+    __shared__ uint32_t last_slot;
+    if (arrive_last(ar, &last_slot) && tid == 0) {
+      __hip_atomic_store(ar.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ar.flag, (unsigned long long)ar.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

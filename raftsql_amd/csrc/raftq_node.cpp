@@ -1716,8 +1716,99 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   n->prop_cap = 0;
   if (props.size()) {
     dirty.clear();
-    const uint32_t ep = next_epoch();
     const size_t np_ = props.size();
+    // Are every group's statements of this turn NEXT TO EACH OTHER in the queue (the common shapes: one statement per group, or
+    // a client's run of statements for one group)?  One look at the queue's group ids -- no group state is touched -- says so; then
+    // a group is dealt with ONCE, while its lines are in cache: classified, its statements stored, its Progress moved.
+    bool runs = true;
+    {
+      const uint32_t seen = next_epoch();
+      std::vector<uint32_t>& mk = n->prop_mark;
+      for (size_t i = 0; i < np_; ++i) {
+        const uint64_t gi = props.group[i];
+        if (i && gi == props.group[i - 1]) continue;
+        if (mk[gi] == seen) {
+          runs = false;
+          break;
+        }
+        mk[gi] = seen;
+      }
+    }
+    const uint32_t ep = next_epoch();
+    if (runs) {
+      const bool dev = n->propose_device;
+      bool pin_oom = dev && (!n->prop_recs.reserve(np_ * sizeof(raftq_prop_t)) || !n->prop_ents.reserve(np_ * sizeof(raftq_prop_ent_t)));
+      raftq_prop_t* recs = n->prop_recs.as<raftq_prop_t>();
+      raftq_prop_ent_t* pents = n->prop_ents.as<raftq_prop_ent_t>();
+      size_t n_fast = 0, n_pents = 0;
+      for (size_t i = 0; i < np_ && !n->oom;) {
+        // (the queue is in arrival order; a run's first statement is a good enough place to look ahead from)
+        if (i + 16 < np_) __builtin_prefetch(&n->groups[props.group[i + 16]]);
+        if (i + 8 < np_) {
+          const uint64_t g8 = props.group[i + 8];
+          const Group& ahead = n->groups[g8];
+          __builtin_prefetch(&n->prog[g8 * n->N * 2], 1);
+          if (ahead.log.p) __builtin_prefetch(ahead.log.p + ahead.log.n, 1);  // appendEntry writes behind the log's last entry
+        }
+        const uint64_t gi = props.group[i];
+        size_t j = i + 1;
+        while (j < np_ && props.group[j] == gi) ++j;
+        const uint64_t bytes = props.off[j] - props.off[i];
+        Group& g = n->groups[gi];
+        // through the device: a group this node leads, every follower's Progress.Next at the log's tail (what bcastAppend leaves
+        // behind: every group outside a catch-up), one message's worth of statements (raft.Config.MaxSizePerMsg, raft.go:157)
+        bool fast = dev && !pin_oom && g.role == RAFTQ_ROLE_LEADER && g.leading && j - i <= kMaxEntriesPerMsg && bytes < kMaxBytesPerMsg;
+        const uint64_t tail = g.log.size() + 1;
+        for (uint32_t p = 0; fast && p < n->N; ++p)
+          if (p != n->self) fast = n->next_of(gi, p) == tail;
+        if (fast) {
+          recs[n_fast++] = raftq_prop_t{gi, (uint32_t)n_pents, (uint32_t)(j - i)};
+          for (size_t k = i; k < j; ++k) {
+            const uint32_t len = (uint32_t)(props.off[k + 1] - props.off[k]);
+            const char* src = props.blob.data() + props.off[k];
+            const char* at = n->arena.put(src, len);
+            if (!at) {
+              n->oom = true;
+              break;
+            }
+            g.log.push_back(n->pool, Entry{g.term, at, len});
+            raftq_prop_ent_t& pe = pents[n_pents++];
+            pe.data_off = len ? n->out_pool.size : 0;
+            pe.data_len = len;
+            pe.type = 0;
+            if (!n->out_pool.append(src, len)) n->out_oom = true;
+            n->prop_cap += 48 + len;
+          }
+          const uint64_t next = g.log.size() + 1;  // bcastAppend's optimistic cursor
+          for (uint32_t p = 0; p < n->N; ++p)
+            if (p != n->self) n->next_of(gi, p) = next;
+          wal_touch(n, gi, g);
+        } else {
+          bool grew = false;
+          for (size_t k = i; k < j; ++k) {
+            const Entry one{0, props.blob.data() + props.off[k], (uint32_t)(props.off[k + 1] - props.off[k])};
+            grew |= handle_proposal(n, gi, g, &one, 1);
+          }
+          if (grew && n->dirty_mark[gi] != ep) {
+            n->dirty_mark[gi] = ep;
+            dirty.push_back(gi);
+          }
+        }
+        i = j;
+      }
+      if (pin_oom) n->out_oom = true;
+      n->stats.msgs_sent += n_fast * (n->N - 1);
+      n->stats.msgs_built_on_device += n_fast * (n->N - 1);
+      n->prop_cap += n_fast * 160;  // (per addressee: flush_outbound multiplies)
+      n->prop_recs.size = n_fast * sizeof(raftq_prop_t);
+      n->prop_ents.size = n_pents * sizeof(raftq_prop_ent_t);
+      if (n->oom) {  // (a device record without its log entry must not go out)
+        n->prop_recs.clear();
+        n->prop_ents.clear();
+      }
+      if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
+    } else {
+    // The general shape (a group's statements interleaved with other groups'), two passes.
     // Pass 1 (round 6): which groups go through the device.  A group this node leads whose followers all have Progress.Next at
     // the log's tail (what bcastAppend leaves behind: every group outside a catch-up) gets ONE raftq_prop_t for the turn, in the
     // order of its first proposal -- the order its MsgApps take in every peer's stream -- and a count; everybody else takes
@@ -1831,6 +1922,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       n->prop_ents.clear();
     }
     if (int rc = flush_dirty()) return poison(n, rc, "apply_log_deltas");
+    }
   }
   if (n->oom) {
     lk.unlock();

@@ -481,8 +481,8 @@ def test_node_speaks_raftpb_frames(Cluster):
         c.close()
 
 
-@pytest.mark.parametrize("N,per_turn", [(3, 1), (5, 3)])
-def test_device_built_msgapps_are_the_hosts_byte_for_byte(Cluster, N, per_turn, monkeypatch):
+@pytest.mark.parametrize("N,per_turn,interleave", [(3, 1, False), (5, 3, False), (3, 3, True)])
+def test_device_built_msgapps_are_the_hosts_byte_for_byte(Cluster, N, per_turn, interleave, monkeypatch):
     """a leader's appendEntry + bcastAppend for what it is asked to propose run on the device
     (raftq_propose_frames: the MsgApp headers are written into the encoder's input in HBM and never exist on the host).  The same
     scripted cluster -- elections, several statements per group and turn, statements proposed on followers too (forwarded as
@@ -500,10 +500,14 @@ def test_device_built_msgapps_are_the_hosts_byte_for_byte(Cluster, N, per_turn, 
             elect(c)
             lead = c.leaders().copy()
             for wave in range(6):
-                for g in range(G):
-                    for k in range(per_turn if g % 3 else 1):
-                        proposer = int(lead[g]) if (g + wave) % 4 else (int(lead[g]) + 1) % N  # every fourth: through a follower
-                        c.nodes[proposer].propose(g, b"INSERT INTO t (v) VALUES (%d) -- g%d w%d" % (k, g, wave))
+                # a group's statements of a turn next to each other in its leader's queue (one pass over the queue), or -- interleave --
+                # spread between other groups' (the general, two-pass shape): one MsgApp per group and peer either way
+                order = [(g, k) for g in range(G) for k in range(per_turn if g % 3 else 1)]
+                if interleave:
+                    order.sort(key=lambda gk: (gk[1], gk[0]))
+                for g, k in order:
+                    proposer = int(lead[g]) if (g + wave) % 4 else (int(lead[g]) + 1) % N  # every fourth: through a follower
+                    c.nodes[proposer].propose(g, b"INSERT INTO t (v) VALUES (%d) -- g%d w%d" % (k, g, wave))
                 c.step()
             c.settle()
             c.run(2)

@@ -1162,6 +1162,30 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
     epoch = 0;  // not supported here: the blocking wait
   }
   HIPCHK(h, wait_turn(h, epoch, 1));
+  if (epoch) {
+    // RAFTQ_CYCLE_CHECK=1 (tests, soaks): what the host reads when the word lands -- the two totals, the ids, the bitmap -- must be
+    // what it reads after a full stream synchronisation
+    static const bool check = [] { const char* e = std::getenv("RAFTQ_CYCLE_CHECK"); return e && e[0] == '1'; }();
+    if (check) {
+      auto digest = [&]() {
+        const volatile uint64_t* tot = (const volatile uint64_t*)h->h_total;
+        uint64_t d = (tot[0] * 0x9E3779B97F4A7C15ull) ^ tot[1];
+        const volatile uint32_t* ids = (const volatile uint32_t*)h->tl_h;
+        const uint64_t nh = std::min<uint64_t>(tot[0], cap_h), nb = std::min<uint64_t>(tot[1], cap_b);
+        for (uint64_t i = 0; i < nh; ++i) d = (d ^ ids[i]) * 0xBF58476D1CE4E5B9ull;
+        for (uint64_t i = 0; i < nb; ++i) d = (d ^ ids[beat_at + i]) * 0xBF58476D1CE4E5B9ull;
+        if (bitmap) {
+          const volatile uint64_t* mw = (const volatile uint64_t*)((const uint8_t*)h->tl_h + map_off);
+          for (uint64_t i = 0; i < h->gpad / 64; ++i) d = (d ^ mw[i]) * 0xBF58476D1CE4E5B9ull;
+        }
+        return d;
+      };
+      const uint64_t at_flag = digest();
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (digest() != at_flag)
+        return fail(h, RAFTQ_EHIP, "raftq_tick_collect_lists: the completion word arrived before the lists it announces (RAFTQ_CYCLE_CHECK)");
+    }
+  }
   *n_hup = h->tl_n_hup = h->h_total[0];
   *n_beat = h->tl_n_beat = h->h_total[1];
   h->tl_hup_cap = cap_h;

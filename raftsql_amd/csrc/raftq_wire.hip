@@ -478,8 +478,11 @@ static int decode_streaming_enqueue(raftq_t* h, const void* v_stream, uint64_t n
                                     uint64_t ents_cap, WireMsg* msgs_d, FrameFilter ff) {
   const unsigned tb = dec_tile();
   const uint32_t n_tiles = (uint32_t)((n + tb - 1) / tb);
-  // what is resident at once: 34 KB of LDS a 128-frame workgroup (four per CU), 68 KB a 256-frame one (two); the readers' share taken off
-  const unsigned workers = fused_grid(n_tiles, tb == 128 ? 1024u - 96u : 512u - 48u);
+  // 128-frame tiles: every workgroup that fits (34 KB of LDS: four per CU, the readers' share taken off).  256-frame tiles: 208, one per
+  // CU beside the readers as in round 5 -- at 68 KB two fit, but 464 workers measured SLOWER than 208 (173.9 against 167.6 us a call,
+  // profiles/r06/wire_tile_ab.jsonl): with 256 tiles in a 64K-frame call every tile has its own waiting worker at 208 already, and
+  // twice the workgroups are twice the pollers of the chunk flags
+  const unsigned workers = fused_grid(n_tiles, tb == 128 ? 1024u - 96u : 208u);
   Carver c;
   const void* const src[3] = {v_off, v_stream, nullptr};
   const uint64_t bytes[3] = {(n + 1) * 8, nbytes, 0};

@@ -1169,9 +1169,10 @@ int raftq_tick_collect_lists(raftq_t* h, unsigned flags, uint64_t hup_cap, uint6
     if (check) {
       auto digest = [&]() {
         const volatile uint64_t* tot = (const volatile uint64_t*)h->h_total;
-        uint64_t d = (tot[0] * 0x9E3779B97F4A7C15ull) ^ tot[1];
+        const uint64_t t0 = tot[0], t1 = tot[1];
+        uint64_t d = (t0 * 0x9E3779B97F4A7C15ull) ^ t1;
         const volatile uint32_t* ids = (const volatile uint32_t*)h->tl_h;
-        const uint64_t nh = std::min<uint64_t>(tot[0], cap_h), nb = std::min<uint64_t>(tot[1], cap_b);
+        const uint64_t nh = std::min<uint64_t>(t0, cap_h), nb = std::min<uint64_t>(t1, cap_b);
         for (uint64_t i = 0; i < nh; ++i) d = (d ^ ids[i]) * 0xBF58476D1CE4E5B9ull;
         for (uint64_t i = 0; i < nb; ++i) d = (d ^ ids[beat_at + i]) * 0xBF58476D1CE4E5B9ull;
         if (bitmap) {

@@ -59,11 +59,13 @@ SUPP
       for l in wire step cycle tick frames; do
         CPU=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$l -o $l -- python tools/profile_$l.py > /dev/null 2>&1
         cp $(find /tmp/ks_$l -name "*kernel_stats.csv" | head -1) $P/${l}_kernel_stats.csv 2>/dev/null; done ;;
-    tests)     timeout 1500 python -m pytest tests -m gpu -x -q > $P/gpu_tests.log 2>&1; echo "rc=$? $(tail -1 $P/gpu_tests.log)" ;;
+    tests)     timeout 1500 python -m pytest tests -m gpu -x -q --timeout 300 > $P/gpu_tests.log 2>&1; echo "rc=$? $(tail -1 $P/gpu_tests.log)" ;;
     wiretests) timeout 900 python -m pytest tests/test_wire_gpu.py -m gpu -x -q --timeout 240 > $P/gpu_tests_wire.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_wire.log)" ;;
     ticktests) timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_set_gpu.py tests/test_abi_gpu.py -m gpu -x -q -k "tick or election or abi or drive" > $P/gpu_tests_tick.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_tick.log)" ;;
     tileab)    # the streaming decoder's launch shapes, one process: tile 128 / 256, readers, chunk, no readers at all, the SDMA-reader form
       timeout 600 python tools/probe/wire_tile_ab.py > $P/wire_tile_ab.jsonl 2> $P/wire_tile_ab.err; echo "rc=$?"; cut -c1-220 $P/wire_tile_ab.jsonl ;;
+    flagab)    # the completion word three ways (one-thread kernel | write-value packet | last workgroup to arrive), checked and timed
+      timeout 1500 bash tools/probe/flag_ab.sh > $P/flag_ab.txt 2>&1; echo "rc=$?"; cat $P/flag_ab.txt ;;
     steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;
     nodetests) timeout 900 python -m pytest tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_pipe_gpu.py -m gpu -x -q > $P/gpu_tests_node.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_node.log)" ;;
     bench)     # the driver's command: stdout = the ONE contract line (<= 4 KB), the full record (every side leg) beside it

@@ -178,7 +178,7 @@ int raftq_step_frames(raftq_t* h, const void* stream, uint64_t nbytes, const uin
  * props[i]: a group THIS handle's node leads (role == leader; anything else fails the call), at most once per call, with
  * every follower's Progress.Next at the log's tail -- the state bcastAppend leaves behind, i.e. every group outside a
  * catch-up; the caller, who owns Progress.Next (raftq_step.h), sends the others itself -- and 1 <= n_ents entries
- * prop_ents[ent_first .. ent_first + n_ents) in log order.  The new entries get Term = the group's Term, Index = old lastIndex
+ * prop_ents[ent_first .. ent_first + n_ents) in log order (every record of prop_ents[] must name a payload inside the pool).  The new entries get Term = the group's Term, Index = old lastIndex
  * + 1 + k.  The handle needs more than one peer (with one the append commits: raftq_apply_log_deltas reports that).
  *
  * The stream: the frames of msgs[0 .. n_msgs), then for every peer slot p != self, ascending, the n_props MsgApps addressed to

@@ -178,6 +178,10 @@ hipError_t launch_sweep(uint32_t N, const SweepLaunch& L, unsigned flags, int nt
 }
 
 }  // namespace
+// something other than Step is about to change match / committed / first_idx / role on the device: the per-group records' copies
+// of them go stale (raftq_step_kernels.hpp NodeRec)
+static inline void dense_changed(raftq_t* h) { h->node_mirror_fresh = false; }
+
 int raftq_detail::ensure_staging(raftq_t* h, size_t bytes) {
   if (bytes <= h->stage_bytes) return RAFTQ_OK;
   size_t want = std::max(bytes, h->stage_bytes * 2);
@@ -535,6 +539,7 @@ int raftq_load_match(raftq_t* h, const uint64_t* match, const uint64_t* committe
   if (match)
     for (uint32_t p = 0; p < h->N; ++p)
       HIPCHK(h, hipMemcpyAsync(h->match + (size_t)p * h->ld, match + (size_t)p * h->G, h->G * 8, hipMemcpyHostToDevice, h->stream));
+  dense_changed(h);
   if (committed)
     HIPCHK(h, hipMemcpyAsync(h->committed[h->cur], committed, h->G * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -556,6 +561,7 @@ int raftq_load_terms(raftq_t* h, const uint64_t* cur_term, const uint64_t* first
   for (uint64_t g = 0; g < h->G; ++g)
     if (cur_term[g] == 0) f[g] = 0;
   HIPCHK(h, hipMemcpyAsync(h->first_idx, f.data(), h->G * 8, hipMemcpyHostToDevice, h->stream));
+  dense_changed(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_terms = true;
   return RAFTQ_OK;
@@ -659,6 +665,7 @@ static int enqueue_ingest(raftq_t* h, const AbiRec* d, uint64_t n, const raftq_v
   VoteDeltaRec* dev_v = (VoteDeltaRec*)((uint8_t*)h->delta_dev + off_votes);
   const unsigned long long* bad = h->delta_bad;
   const dim3 gm((unsigned)((n + kBlock - 1) / kBlock)), gv((unsigned)((nv + kBlock - 1) / kBlock));
+  if (n) dense_changed(h);  // (match words move under Step's records)
   if (n && trusted)
     hipLaunchKernelGGL((deltas_in_apply_kernel<Rec>), gm, dim3(kBlock), 0, h->stream, (const Rec*)h->ingest_d, n, h->match, h->ld,
                        h->G, h->N, h->delta_bad, h->d_total + 1, em);
@@ -719,6 +726,7 @@ int raftq_apply_term_deltas(raftq_t* h, const raftq_term_delta_t* d, uint64_t n)
     for (auto it = keep.rbegin(); it != keep.rend(); ++it) dst[m++] = d[*it];
   }
   const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
+  dense_changed(h);
   hipLaunchKernelGGL(apply_term_deltas_kernel, grid, dim3(kBlock), 0, h->stream, h->first_idx,
                      (const TermDeltaRec*)h->stage_d, m);
   HIPCHK(h, hipGetLastError());
@@ -790,7 +798,10 @@ static void sweep_done(raftq_t* h, unsigned flags, int gpl) {
   if (commit) {
     h->last_old = h->committed[h->cur];
     h->last_new = h->committed[h->cur ^ 1];
-    if (!(flags & RAFTQ_SWEEP_NO_ADOPT)) h->cur ^= 1;
+    if (!(flags & RAFTQ_SWEEP_NO_ADOPT)) {
+      h->cur ^= 1;
+      dense_changed(h);  // the live commit indices are the sweep's now
+    }
   }
 }
 
@@ -995,6 +1006,7 @@ int raftq_load_roles(raftq_t* h, const uint8_t* role, const uint32_t* elapsed) {
     if (role[g] > RAFTQ_ROLE_LEADER) return fail(h, RAFTQ_EINVAL, "raftq_load_roles: role must be 0, 1 or 2");
   if (int rc = ensure_tick_state(h)) return rc;
   HIPCHK(h, hipMemcpyAsync(h->role, role, h->G, hipMemcpyHostToDevice, h->stream));
+  dense_changed(h);
   if (elapsed) HIPCHK(h, hipMemcpyAsync(h->elapsed, elapsed, h->G * 4, hipMemcpyHostToDevice, h->stream));
   else HIPCHK(h, hipMemsetAsync(h->elapsed, 0, h->ld * 4, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1278,6 +1290,7 @@ int raftq_campaign(raftq_t* h, const uint64_t* groups, uint64_t n, uint32_t self
   std::memcpy(h->stage_h, groups, n * 8);
   hipLaunchKernelGGL(campaign_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
                      h->role, h->elapsed, h->votes, h->N, self_peer, (const uint64_t*)h->stage_d, n);
+  dense_changed(h);  // (role)
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RAFTQ_OK;
@@ -1609,6 +1622,7 @@ static int cycle_impl(raftq_t* h, const char* who, const AbiRec* deltas, uint64_
     // the device found a record out of range: no record of either kind was scattered, and the sweep that ran on
     // the unchanged state is not adopted either -- the handle is exactly where it was before the call
     h->cur = cur_before;
+    dense_changed(h);
     if (n_advanced) *n_advanced = 0;
     if (counts) *counts = raftq_counts_t{0, 0, 0};
     h->adv_listed = 0;
@@ -2041,6 +2055,7 @@ int raftq_clone_state(raftq_t* dst, raftq_t* src) {
                              dst->stream));
   HIPCHK(dst, hipStreamSynchronize(dst->stream));
   dst->have_terms = src->have_terms;
+  dense_changed(dst);
   return RAFTQ_OK;
 }
 

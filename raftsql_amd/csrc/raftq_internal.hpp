@@ -115,6 +115,10 @@ struct raftq {
   const uint64_t* last_new = nullptr;
   // batched Step node state (raftq_step.hip), lazily allocated
   uint32_t self_peer = 0;
+  // the records' copies of the dense arrays (role, committed, first_idx, match) are what those arrays hold: false after anything but
+  // Step / tail reports / proposals wrote them; the next Step-family call re-reads them first (raftq_step.hip ensure_mirror)
+  bool node_mirror_fresh = false;
+  uint64_t node_mirror_refreshes = 0;
   void* node_rec = nullptr;        // raftqk::NodeRec [ld]: term, vote, lead, last_index, last_term + the list words of the batch in flight
   unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
   bool step_compact = false;       // result records in the 40-byte format (raftq_step_set_compact)

@@ -30,27 +30,33 @@ constexpr uint32_t kPropMaxEnts = 1024;  // raft.Config.MaxSizePerMsg's share of
 
 // Nothing is applied unless every record is sound: a group of this handle, led by this node, named once (the group's list
 // count word doubles as the "seen" mark: the apply kernel hands it back zero), 1 .. kPropMaxEnts entries inside prop_ents[],
-// payloads inside the pool.
+// every entry's payload inside the pool.
+// The records lie in page-locked HOST memory: this kernel reads them there ONCE, coalesced (16 bytes a lane: 1 KB a wave
+// instruction over the link), and leaves a copy in device scratch for the kernel behind it -- round 6's first form had both
+// kernels read the host arrays: 33 + 36 us for 32K groups, all of it link latency (profiles/r06/node_kernel_stats_first.csv).
 static __global__ __launch_bounds__(kBlock) void propose_check_kernel(NodeArrays a, const PropRec* __restrict__ props, uint64_t n,
                                                                       const PropEnt* __restrict__ pe, uint64_t n_pe, uint64_t pool_bytes,
-                                                                      unsigned int* bad, unsigned int stamp) {
+                                                                      unsigned int* bad, unsigned int stamp, PropRec* __restrict__ props_d,
+                                                                      PropEnt* __restrict__ pe_d) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  // the entry records, one per lane of the first ceil(n_pe / kBlock) workgroups ... (the grid covers max(n, n_pe) lanes)
   bool is_bad = false;
+  if (i < n_pe) {
+    const PropEnt e = pe[i];
+    pe_d[i] = e;
+    is_bad = e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off);  // (an entry no record names is checked too: harmless)
+  }
   if (i < n) {
     const PropRec p = props[i];
-    is_bad = p.group >= a.n_groups || p.n_ents == 0 || p.n_ents > kPropMaxEnts || (uint64_t)p.ent_first + p.n_ents > n_pe;
-    if (!is_bad) {
-      is_bad = a.role[p.group] != kLeader || atomicAdd(&a.rec[p.group].lst_cnt, 1u) != 0;
-      for (uint32_t k = 0; k < p.n_ents && !is_bad; ++k) {
-        const PropEnt e = pe[p.ent_first + k];
-        is_bad = e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off);
-      }
-    }
+    props_d[i] = p;
+    bool rec_bad = p.group >= a.n_groups || p.n_ents == 0 || p.n_ents > kPropMaxEnts || (uint64_t)p.ent_first + p.n_ents > n_pe;
+    if (!rec_bad) rec_bad = a.role[p.group] != kLeader || atomicAdd(&a.rec[p.group].lst_cnt, 1u) != 0;
+    is_bad |= rec_bad;
   }
   if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicExch(bad, stamp);  // (the word holds this call's stamp: refused)
 }
 
-// msgs_out: the device part of the encoder's message array -- (N - 1) runs of n records, run r = the MsgApps for the r-th peer
+// props / pe: the check kernel's copies in device memory.  msgs_out: the device part of the encoder's message array -- (N - 1) runs of n records, run r = the MsgApps for the r-th peer
 // slot other than this node's; ents_out: the device part of its entry-header array, whose first element is entry `ent_base` of
 // the whole array (a message's ent_first counts from the array's start).
 static __global__ __launch_bounds__(kBlock) void propose_apply_kernel(NodeArrays a, const PropRec* __restrict__ props, uint64_t n,
@@ -70,7 +76,7 @@ static __global__ __launch_bounds__(kBlock) void propose_apply_kernel(NodeArrays
   // largest is somebody else's and did not change -- the host wrapper refuses a single-peer handle.)
   node.last_index = old_last + p.n_ents;
   node.last_term = node.term;
-  if (node.match(a.self) < node.last_index) node.match(a.self) = node.last_index;
+  if (node.match(a.self) < node.last_index) node.set_match(a.self, node.last_index);
   node.lst_cnt = 0;
   node.store();  // (list words back to empty: the check's mark with them)
   for (uint32_t k = 0; k < p.n_ents; ++k) {

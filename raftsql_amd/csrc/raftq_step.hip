@@ -72,9 +72,21 @@ NodeArrays node_arrays(raftq_t* h, uint8_t recs = raftqk::kRecsCaller) {
   return a;
 }
 
+// The records' copies of role / committed / first_idx / match (raftq_step_kernels.hpp NodeRec) are re-read from the dense arrays
+// when something other than Step has changed those since (raftq_capi.hip marks it): enqueued in front of whatever reads a record.
+int ensure_mirror(raftq_t* h) {
+  if (h->node_mirror_fresh) return RAFTQ_OK;
+  hipLaunchKernelGGL(node_mirror_kernel, dim3((unsigned)((h->G + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, node_arrays(h), h->G);
+  HIPCHK(h, hipGetLastError());
+  h->node_mirror_fresh = true;
+  h->node_mirror_refreshes++;
+  return RAFTQ_OK;
+}
+
 }  // namespace
 int raftq_detail::node_arrays_of(raftq_t* h, raftqk::NodeArrays* out) {
   if (int rc = ensure_node_state(h)) return rc;
+  if (int rc = ensure_mirror(h)) return rc;
   *out = node_arrays(h);
   h->last_flags &= ~RAFTQ_SWEEP_NO_ADOPT;  // as in raftq_step_submit: the live state moves
   return RAFTQ_OK;
@@ -400,6 +412,7 @@ struct WireSrc {
 
 // key -> stable radix sort -> walk, on the handle's stream (the path that takes runs of any length)
 static int enqueue_sorted_walk(raftq_t* h, const Scratch& s, uint64_t n, int end_bit, uint8_t recs, void* outs) {
+  if (int rc = ensure_mirror(h)) return rc;
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(step_keys_kernel, grid, dim3(kBlock), 0, h->stream, (const MsgRec*)s.msgs, s.keys_in, s.order_in, n,
@@ -419,6 +432,7 @@ static unsigned d2h_blocks(uint64_t quads) { return (unsigned)std::min<uint64_t>
 
 // `carry`: a slot whose result copy is still pending rides in this batch's walk kernel (nullptr: nothing to carry)
 static int enqueue_list_walk(raftq_t* h, const Scratch& s, uint64_t n, uint8_t recs, raftq::StepSlot* carry) {
+  if (int rc = ensure_mirror(h)) return rc;
   unsigned int* bad = (unsigned int*)(s.n_heads + 1);
   unsigned int* skipped = bad + 1;  // the last word of the 16-byte tail behind the result records
   const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
@@ -906,6 +920,7 @@ static int log_deltas_impl(raftq_t* h, const raftq_log_delta_t* d, uint64_t n, u
   for (uint64_t i = 0; i < n; ++i)
     if (d[i].group >= h->G) return fail(h, RAFTQ_EINVAL, "a log delta is out of range; nothing applied");
   if (int rc = ensure_node_state(h)) return rc;
+  if (int rc = ensure_mirror(h)) return rc;
   const size_t off_out = align256((size_t)n * sizeof(raftq_log_delta_t));
   if (n > 0xfffffffeull) return fail(h, RAFTQ_EINVAL, "raftq_apply_log_deltas: batch too large (n must fit 32 bits)");
   void *stage_h = nullptr, *stage_d = nullptr;

@@ -44,22 +44,30 @@ struct StepOutC {  // == raftq_step_out_c_t: the result record without what the 
 static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32 && sizeof(StepOutC) == 40,
               "record layout");
 
-// What only Step touches of a group, in ONE 64-byte line: the raft scalars and the words of the group's message list of
-// the batch in flight (step_link_kernel / step_lists_kernel).  Round 3 kept each of these in an array of its own: a touched
-// group cost 18 scattered cache lines in and 18 out for ~100 useful bytes -- 54 MB read and 31 MB written per 64K-message
-// batch (profiles/r04/pmc_traffic_legs.json: traffic x4 of the bytes the walk needs).  What the dense kernels stream stays
-// peer-major / group-major SoA: match, committed (the sweep), first_idx (the gated sweep), the vote words (the tally),
-// role / elapsed (Tick) -- the walk reads role and committed with the record and everything else only on the paths that
-// need it (the vote word in poll, first_idx and the match rows in maybeCommit, elapsed never: Step only ever resets it).
-struct __attribute__((aligned(64))) NodeRec {
+// Everything Step's common paths need of a group, in ONE 128-byte line (round 6): the raft scalars, the words of the group's
+// message list of the batch in flight (step_link_kernel / step_lists_kernel), and a copy of what the dense kernels own -- role,
+// committed, the current-term gate and the N match words.  Round 3 kept each scalar in an array of its own (18 scattered lines
+// per touched group); round 4 made the scalars one 64-byte record but still read role, committed, match[from] and -- for every
+// acknowledgement -- all N match rows and the gate from their dense arrays: 33 MB read per 64K-message batch by the DRAM request
+// counters, x2.3 of what the walk needs (profiles/r05/pmc_legs_summary.txt step_lists_kernel: 1.05 M 32-byte requests).  Now a
+// touched group is one line in and one line out.
+//
+// What the dense kernels stream stays peer-major / group-major SoA and stays AUTHORITATIVE: match, committed (the sweep),
+// first_idx (the gated sweep), role / elapsed (Tick), the vote words (the tally).  Step writes a word it changes to BOTH places.
+// A call that changes the dense arrays without Step (raftq_load_*, a batching turn's ingest, an adopted sweep, a campaign list)
+// marks the copies stale (raftq_t::node_mirror_fresh); the next Step-family call re-reads them (node_mirror_kernel) first.
+// raftq_node -- Step, tail reports, proposals, Tick (which writes neither) -- never does.
+struct __attribute__((aligned(128))) NodeRec {
   uint64_t term, last_index, last_term;
   uint32_t lst_head;  // batch position of the last-linked message of the group, kNil = none
   uint32_t lst_cnt;   // messages of the group in this batch
   uint32_t lst_min;   // smallest batch position of the group
   uint8_t vote, lead; // 0 = None, else slot + 1
-  uint8_t pad[2 + 24];
+  uint8_t role, pad;  // copy of role[g]
+  uint64_t committed, first_idx;  // copies of committed[g], first_idx[g]
+  uint64_t match[kMaxPeers];      // copies of match[p][g]
 };
-static_assert(sizeof(NodeRec) == 64, "one cache line");
+static_assert(sizeof(NodeRec) == 128, "one cache line");
 
 struct NodeArrays {
   NodeRec* rec;     // [ld]
@@ -199,55 +207,59 @@ constexpr uint32_t kNil = 0xffffffffu;
 struct Node {
   const NodeArrays& a;
   uint64_t g;
-  uint64_t term, last_index, last_term, committed, first_idx = 0;
+  uint64_t term, last_index, last_term, committed, first_idx;
+  uint64_t mt[kMaxPeers];  // Progress.Match of every peer, from the record
+  uint32_t mt_dirty = 0;   // bit p: mt[p] differs from the dense match[p][g]
   uint32_t vote, lead;
   uint32_t vw = 0;  // the group's vote word (raft.votes as 2 bits per peer)
   uint32_t lst_head, lst_cnt, lst_min;  // the record's list words as loaded (the walk empties them when it stores)
   uint8_t role;
   bool held = false;  // this batch only: a MsgApp with RAFTQ_MSGF_BARRIER was left to the caller -- the group's later messages wait
-  // what has been read / has to be written besides the record (which always is, list words emptied)
-  uint64_t committed0;
+  // what has to be written to the dense arrays besides the record (which always is, list words emptied)
+  uint64_t committed0, first_idx0;
   uint8_t role0;
-  bool fi_known = false, fi_dirty = false, vw_known = false, vw_dirty = false, elapsed_reset = false;
+  bool vw_known = false, vw_dirty = false, elapsed_reset = false;
 
   __device__ Node(const NodeArrays& arr, uint64_t group) : a(arr), g(group) {
-    const NodeRec r = a.rec[g];  // one line: four 16-byte loads
+    const NodeRec r = a.rec[g];  // one line: eight 16-byte loads
     term = r.term; last_index = r.last_index; last_term = r.last_term;
     vote = r.vote; lead = r.lead;
     lst_head = r.lst_head; lst_cnt = r.lst_cnt; lst_min = r.lst_min;
-    committed = committed0 = a.committed[g];
-    role = role0 = a.role[g];
+    committed = committed0 = r.committed;
+    first_idx = first_idx0 = r.first_idx;
+    role = role0 = r.role;
+#pragma unroll
+    for (int p = 0; p < kMaxPeers; ++p) mt[p] = r.match[p];
   }
   // list_reset: the walk hands the group's list back empty (log_deltas_kernel leaves the words as they are)
   __device__ void store(bool list_reset = true) const {
     NodeRec r;
     r.term = term; r.last_index = last_index; r.last_term = last_term;
     r.vote = (uint8_t)vote; r.lead = (uint8_t)lead;
+    r.role = role; r.pad = 0;
     r.lst_head = list_reset ? kNil : lst_head;
     r.lst_cnt = list_reset ? 0u : lst_cnt;
     r.lst_min = list_reset ? kNil : lst_min;
-    __builtin_memset(r.pad, 0, sizeof r.pad);
+    r.committed = committed;
+    r.first_idx = first_idx;
+#pragma unroll
+    for (int p = 0; p < kMaxPeers; ++p) r.match[p] = mt[p];
     a.rec[g] = r;
+    // ... and what changed, where the dense kernels read it
     if (committed != committed0) a.committed[g] = committed;
     if (role != role0) a.role[g] = role;
-    if (fi_dirty) a.first_idx[g] = first_idx;
+    if (first_idx != first_idx0) a.first_idx[g] = first_idx;
+#pragma unroll
+    for (int p = 0; p < kMaxPeers; ++p)
+      if ((mt_dirty >> p) & 1u) a.match[(uint64_t)p * a.ld + g] = mt[p];
     if (elapsed_reset) a.elapsed[g] = 0;
     if (vw_dirty) {
       if (a.n_peers <= 8) reinterpret_cast<uint16_t*>(a.votes)[g] = (uint16_t)vw;
       else reinterpret_cast<uint32_t*>(a.votes)[g] = vw;
     }
   }
-  __device__ void set_first_idx(uint64_t v) {
-    first_idx = v;
-    fi_known = fi_dirty = true;
-  }
-  __device__ uint64_t get_first_idx() {
-    if (!fi_known) {
-      first_idx = a.first_idx[g];
-      fi_known = true;
-    }
-    return first_idx;
-  }
+  __device__ void set_first_idx(uint64_t v) { first_idx = v; }
+  __device__ uint64_t get_first_idx() const { return first_idx; }
   __device__ void set_votes(uint32_t w) {
     vw = w;
     vw_known = vw_dirty = true;
@@ -259,7 +271,18 @@ struct Node {
     }
     return vw;
   }
-  __device__ uint64_t& match(uint32_t p) const { return a.match[(uint64_t)p * a.ld + g]; }
+  // Progress.Match of peer p (a run-time index into registers: selects, not scratch)
+  __device__ uint64_t match(uint32_t p) const {
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kMaxPeers; ++k) v = k == p ? mt[k] : v;
+    return v;
+  }
+  __device__ void set_match(uint32_t p, uint64_t v) {
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kMaxPeers; ++k) mt[k] = k == p ? v : mt[k];
+    mt_dirty |= 1u << p;
+  }
   __device__ uint32_t quorum() const { return a.n_peers / 2 + 1; }
 
   // raft.reset(term)
@@ -268,7 +291,13 @@ struct Node {
     lead = 0;
     elapsed_reset = true;
     set_votes(0);
-    for (uint32_t p = 0; p < a.n_peers; ++p) match(p) = p == a.self ? last_index : 0;
+#pragma unroll
+    for (uint32_t p = 0; p < (uint32_t)kMaxPeers; ++p)
+      if (p < a.n_peers) {
+        const uint64_t v = p == a.self ? last_index : 0;
+        if (mt[p] != v) mt_dirty |= 1u << p;
+        mt[p] = v;
+      }
   }
   __device__ void become_follower(uint64_t t, uint32_t new_lead) {
     reset(t);
@@ -288,7 +317,7 @@ struct Node {
     uint64_t m[kMaxPeers];
     const uint32_t n = a.n_peers, q = quorum();
 #pragma unroll
-    for (uint32_t p = 0; p < kMaxPeers; ++p) m[p] = p < n ? match(p) : 0;
+    for (uint32_t p = 0; p < kMaxPeers; ++p) m[p] = p < n ? mt[p] : 0;
     uint64_t mci = 0;
 #pragma unroll
     for (uint32_t c = 0; c < kMaxPeers; ++c) {
@@ -314,7 +343,7 @@ struct Node {
     last_index += 1;
     last_term = term;
     set_first_idx(last_index);
-    match(a.self) = last_index;
+    set_match(a.self, last_index);
     (void)maybe_commit();
   }
   // raft.poll: the first response of a peer wins; returns {granted, recorded}
@@ -394,7 +423,7 @@ struct Node {
           if (!m.reject) {
             const uint64_t idx = m.index > last_index ? last_index : m.index;
             if (match(m.from) < idx) {
-              match(m.from) = idx;
+              set_match(m.from, idx);
               o.flags |= kFlagUpdated;
               (void)maybe_commit();
             }
@@ -607,6 +636,17 @@ static __global__ __launch_bounds__(kBlock) void node_init_kernel(NodeRec* rec, 
   r.lst_head = r.lst_min = kNil;
   rec[i] = r;
 }
+// the record's copies of what the dense kernels own, re-read (see NodeRec): one lane per group
+static __global__ __launch_bounds__(kBlock) void node_mirror_kernel(NodeArrays a, uint64_t n) {
+  const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n) return;
+  NodeRec* r = a.rec + g;
+  r->role = a.role[g];
+  r->committed = a.committed[g];
+  r->first_idx = a.first_idx[g];
+#pragma unroll
+  for (uint32_t p = 0; p < (uint32_t)kMaxPeers; ++p) r->match[p] = p < a.n_peers ? a.match[(uint64_t)p * a.ld + g] : 0;
+}
 // field: 0 term, 1 vote, 2 lead, 3 last_index, 4 last_term.  `flat` is the ABI's array for groups [g0, g0 + n): u64 or u32.
 template <bool PUT>
 static __global__ __launch_bounds__(kBlock) void node_field_kernel(NodeRec* rec, uint64_t g0, uint64_t n, int field, void* flat) {
@@ -656,7 +696,7 @@ static __global__ __launch_bounds__(kBlock) void log_deltas_kernel(NodeArrays a,
   node.last_index = r.last_index;
   node.last_term = r.last_term;
   if (node.role == kLeader) {
-    if (node.match(a.self) < node.last_index) node.match(a.self) = node.last_index;
+    if (node.match(a.self) < node.last_index) node.set_match(a.self, node.last_index);
     (void)node.maybe_commit();
   } else if (r.commit_to != 0) {
     node.commit_to(r.commit_to);

@@ -435,6 +435,7 @@ int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props
   TileCtl ctl;
   if (int rc = tile_ctl(h, std::max<uint64_t>(n_tiles, (sizes[0] + sizes[1] + sizes[2]) / feed_chunk() + 1), &ctl)) return rc;
   FeedPlan plan = plan_feed(fc, src, sizes, h->wire_lb_tiles, 48u, extra);
+  const size_t o_props = fc.take(n_props * sizeof(PropRec)), o_pe = fc.take(n_prop_ents * sizeof(PropEnt));  // the check kernel's copies of the records
   if (int rc = grow(h, &h->wire_dev, &h->wire_dev_bytes, fc.off)) return rc;
   if (int rc = grow(h, &h->wire_out, &h->wire_out_bytes, cap + 16)) return rc;
   if (int rc = bind_feed(h, plan, (uint8_t*)h->wire_dev, ctl.status[kLbFlags])) return rc;
@@ -446,10 +447,12 @@ int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props
   const unsigned int stamp = h->prop_stamp;
   WireMsg* msgs_dev = (WireMsg*)(plan.in.seg[0].dst + sizes[0]);
   WireEnt* ents_dev = (WireEnt*)(plan.in.seg[1].dst + sizes[1]);
-  const dim3 pg((unsigned)((n_props + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(propose_check_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe, n_prop_ents, pool_bytes, bad,
-                     stamp);
-  hipLaunchKernelGGL(propose_apply_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe,
+  const dim3 pg((unsigned)((n_props + kBlock - 1) / kBlock)), cg((unsigned)((std::max(n_props, n_prop_ents) + kBlock - 1) / kBlock));
+  PropRec* props_d = (PropRec*)((uint8_t*)h->wire_dev + o_props);
+  PropEnt* pe_d = (PropEnt*)((uint8_t*)h->wire_dev + o_pe);
+  hipLaunchKernelGGL(propose_check_kernel, cg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe, n_prop_ents, pool_bytes, bad,
+                     stamp, props_d, pe_d);
+  hipLaunchKernelGGL(propose_apply_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)props_d, n_props, (const PropEnt*)pe_d,
                      (const unsigned int*)bad, stamp, msgs_dev, ents_dev, (uint32_t)n_ents);
   // ... and the marshal of everything right behind it: one wait
   hipLaunchKernelGGL(wire_enc_fused_kernel, dim3(plan.in.readers + workers), dim3(kBlock), 0, h->stream, plan.in, n, n_e, pool_bytes, (uint8_t*)h->wire_out,

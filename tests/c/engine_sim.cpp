@@ -515,11 +515,12 @@ int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props
     const raftq_prop_t& p = props[i];
     bool bad = p.group >= h->G || p.n_ents == 0 || p.n_ents > 1024 || (uint64_t)p.ent_first + p.n_ents > n_prop_ents;
     if (!bad) bad = h->role[p.group] != RAFTQ_ROLE_LEADER || seen[p.group]++;
-    for (uint32_t k = 0; !bad && k < p.n_ents; ++k) {
-      const raftq_prop_ent_t& e = prop_ents[p.ent_first + k];
-      bad = e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off);
-    }
-    if (bad) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a proposal names a group this node does not lead (or twice, or no entries, or a payload outside the pool) -- nothing was appended");
+    if (bad) return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a proposal names a group this node does not lead (or twice, or no entries) -- nothing was appended");
+  }
+  for (uint64_t k = 0; k < n_prop_ents; ++k) {  // every entry record, named or not
+    const raftq_prop_ent_t& e = prop_ents[k];
+    if (e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off))
+      return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a payload outside the pool -- nothing was appended");
   }
   const uint64_t n_dev = n_props * (h->N - 1);
   std::vector<raftq_wire_msg_t> all(n_msgs + n_dev);

@@ -731,3 +731,63 @@ def test_log_deltas_nowait_leaves_the_state_the_waiting_call_does(NodeEngine, or
                 m = _stepgen.random_batch(rng, s, 2000)
                 assert np.array_equal(e.step_batch(m)[0].view(np.uint8), s.step_batch(m).view(np.uint8)), it
         _stepgen.assert_same_state(e, s)
+
+
+def test_records_follow_whatever_else_writes_the_dense_arrays(NodeEngine, oracle):
+    """Round 6: a group's record holds COPIES of what the dense kernels own (role, committed, the current-term gate, the N match
+    words: one line per touched group instead of a dozen scattered sectors).  Whatever changes the dense arrays WITHOUT Step --
+    acknowledgements through the batching turn's ingest, an adopted sweep, reloaded roles, a campaign list, term deltas, a clone --
+    marks the copies stale and the next Step-family call re-reads them: random interleavings of all of those with Step batches and
+    tail reports, every result record and every state word against the oracle after every move."""
+    rng = np.random.default_rng(6006)
+    G, N, me = 3000, 5, 2
+    s = _stepgen.random_state(rng, G, N, me)
+    with NodeEngine(G, N, me) as e, NodeEngine(G, N, me) as twin:
+        _stepgen.load_engine(e, s)
+        for move in range(40):
+            kind = int(rng.integers(0, 7))
+            if kind == 0:  # acks that did NOT come through Step (raftq_apply_deltas: order-independent max)
+                k = 500
+                g, p = rng.integers(0, G, k).astype(np.uint64), rng.integers(0, N, k).astype(np.uint32)
+                v = (s.last_index[g.astype(np.int64)] * rng.random(k)).astype(np.uint64)
+                e.apply_deltas(g, p, v)
+                np.maximum.at(s.match, (p.astype(np.int64), g.astype(np.int64)), v)
+            elif kind == 1:  # an adopted gated sweep: the live commit indices are the sweep's
+                e.sweep(_lib.SWEEP_COMMIT | _lib.SWEEP_GATED)
+                s.committed[:] = oracle.commit_advance(s.match, s.committed, True, s.first_idx)[0]
+            elif kind == 2:  # roles reloaded
+                flip = rng.integers(0, G, 50)
+                s.role[flip] = rng.integers(0, 3, 50)
+                e.load_roles(s.role, s.elapsed)
+            elif kind == 3:  # a campaign list (raftq_campaign: role, elapsed, the vote word)
+                gs = np.unique(rng.integers(0, G, 40)).astype(np.uint64)
+                gs = gs[s.role[gs.astype(np.int64)] != 2]
+                e.campaign(gs, me)
+                s.role[:], s.elapsed[:], s.votes[:] = oracle.campaign(s.role, s.elapsed, s.votes, gs, me)
+            elif kind == 4:  # the gate moved by the caller (raftq_apply_term_deltas)
+                gs = np.unique(rng.integers(0, G, 60)).astype(np.uint64)
+                fi = rng.integers(0, 50, len(gs)).astype(np.uint64)
+                e.apply_term_deltas(gs, np.ones(len(gs), np.uint64), fi)
+                s.first_idx[gs.astype(np.int64)] = fi
+            elif kind == 5:  # tail reports
+                gs = np.unique(rng.integers(0, G, 200)).astype(np.uint64)
+                gi = gs.astype(np.int64)
+                li = s.last_index[gi] + rng.integers(0, 3, len(gs)).astype(np.uint64)
+                got = e.apply_log_deltas(gs, li, s.term[gi], li)
+                want = s.apply_log_deltas(gs, li, s.term[gi], li)
+                assert np.array_equal(got, want)
+            else:  # a clone of the whole state into a fresh handle, stepped there as well
+                twin.clone_state_from(e)
+                twin.load_roles(s.role, s.elapsed)
+                twin.load_node(s.term, s.vote, s.lead, s.last_index, s.last_term)
+                m2 = _stepgen.random_batch(rng, s, 500)
+                import copy
+
+                s2 = copy.deepcopy(s)
+                assert np.array_equal(twin.step_batch(m2)[0], s2.step_batch(m2))
+                _stepgen.assert_same_state(twin, s2)
+            m = _stepgen.random_batch(rng, s, 3000)
+            want = s.step_batch(m)
+            got, _ = e.step_batch(m)
+            assert np.array_equal(got, want), move
+            _stepgen.assert_same_state(e, s)

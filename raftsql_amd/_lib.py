@@ -143,6 +143,7 @@ _STEP_SIGS = [
     ("raftq_step_set_compact", C.c_int, [_H, C.c_int]),
     ("raftq_step_set_msg_flags", C.c_int, [_H, C.c_int]),
     ("raftq_step_results_c", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("raftq_step_results_s", C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
 ]
 STEP_EXPORTS = [s[0] for s in _STEP_SIGS]
 

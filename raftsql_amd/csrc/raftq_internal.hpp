@@ -121,7 +121,7 @@ struct raftq {
   uint64_t node_mirror_refreshes = 0;
   void* node_rec = nullptr;        // raftqk::NodeRec [ld]: term, vote, lead, last_index, last_term + the list words of the batch in flight
   unsigned int* step_stall = nullptr;  // device word: a batch needs the sorted path; later batches wait for the replay
-  bool step_compact = false;       // result records in the 40-byte format (raftq_step_set_compact)
+  uint8_t step_compact = 0;        // result records: 0 = 64 bytes, 1 = 40, 2 = 32 (raftq_step_set_compact)
   bool step_msg_flags = false;     // raftq_msg_t._pad[1] / _resv carry RAFTQ_MSGF_* (raftq_step_set_msg_flags); padding otherwise
   int step_walk_mode = 1;          // 1 = lists (default), 0 = always the sorted walk (RAFTQ_STEP_WALK=sort)
   uint32_t step_stalls_in_a_row = 0, step_sorted_left = 0;  // back-off from the list walk under hot-group traffic

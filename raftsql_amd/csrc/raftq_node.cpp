@@ -794,18 +794,19 @@ int flush_deltas(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
 }
 
 // what one Step result means for the node (the "Ready" consequences of one message)
-// The node reads Step's 40-byte result records (raftq_step_set_compact: what a result says beyond the message it answers --
-// 24 bytes per message less on the link, which is what bounds the inbound half of a turn): group and addressee are the
-// message's own, log_term / last_index share a slot (include/raftq_step.h).
-inline raftq_step_out_t widen(const raftq_step_out_c_t& c, const raftq_wire_msg_t& im) {
+// The node reads Step's 32-byte result records (raftq_step_set_compact(h, 2), round 6: what a result says beyond the message it
+// answers and beyond what the log's owner knows anyway -- 32 bytes per message less on the link than the full record, which is
+// what bounds the inbound half of a turn): group and addressee are the message's own, raftLog.lastIndex() after the message is
+// this node's own log's business, a new leader's log_term is its term and a campaign's rides in `commit` (include/raftq_step.h).
+inline raftq_step_out_t widen(const raftq_step_out_s_t& c, const raftq_wire_msg_t& im) {
   raftq_step_out_t o;
   o.group = im.group;
   o.term = c.term;
   o.index = c.index;
-  o.commit = c.commit;
-  const bool tip = c.type == RAFTQ_OUT_CAMPAIGN || c.type == RAFTQ_OUT_BECAME_LEADER;  // index IS the last index there
-  o.log_term = tip ? c.aux : 0;
-  o.last_index = tip ? c.index : c.aux;
+  const bool campaign = c.type == RAFTQ_OUT_CAMPAIGN;
+  o.commit = campaign ? 0 : c.commit;  // (a campaign moves no commit index: note_commit(0) is a no-op)
+  o.log_term = campaign ? c.commit : c.type == RAFTQ_OUT_BECAME_LEADER ? c.term : 0;
+  o.last_index = 0;  // (nothing below reads it)
   o.to = im.from;
   o.vote = c.vote;
   o.lead = c.lead;
@@ -1141,7 +1142,7 @@ int raftq_node_create(int device, uint64_t n_groups, uint32_t n_peers, uint32_t 
   int rc = raftq_create(device, n_groups, n_peers, &n->h);
   if (rc == RAFTQ_OK) rc = raftq_set_self(n->h, self_peer);
   if (rc == RAFTQ_OK) rc = raftq_step_set_msg_flags(n->h, 1);  // this node fills every byte of every record it stages (RAFTQ_MSGF_*)
-  if (rc == RAFTQ_OK) rc = raftq_step_set_compact(n->h, 1);    // ... and reads 40-byte result records (widen())
+  if (rc == RAFTQ_OK) rc = raftq_step_set_compact(n->h, 2);    // ... and reads 32-byte result records (widen())
   if (rc != RAFTQ_OK) {
     if (n->h) raftq_destroy(n->h);
     delete n;
@@ -1493,7 +1494,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
   // the local messages.
   uint64_t nf = in_off.size() > 1 ? in_off.size() - 1 : 0;
   const raftq_wire_msg_t* wm = nullptr;
-  const raftq_step_out_c_t* fused_outs = nullptr;  // != nullptr: round 1 has been stepped, out[i] answers frame i
+  const raftq_step_out_s_t* fused_outs = nullptr;  // != nullptr: round 1 has been stepped, out[i] answers frame i
   if (nf) {
     lk.unlock();
     ph.next(raftq_node::kPhDecode);
@@ -1518,7 +1519,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     if (rc != RAFTQ_OK) return poison(n, rc, fuse ? "step_frames" : "wire_decode");
     if (fuse) {
       uint64_t n_out = 0;
-      rc = raftq_step_results_c(n->h, &fused_outs, &n_out);
+      rc = raftq_step_results_s(n->h, &fused_outs, &n_out);
       if (rc != RAFTQ_OK || n_out != nf || !fused_outs) return poison(n, rc != RAFTQ_OK ? rc : RAFTQ_ESTATE, "step_frames (results)");
     }
     wm = out;
@@ -1593,7 +1594,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
     raftq_msg_t* staged = nullptr;
     static_assert(sizeof(raftq_msg_t) == sizeof(raftq_wire_msg_t), "the decoder's record is Step's record");
     size_t n_step = 0;
-    const raftq_step_out_c_t* outs = nullptr;
+    const raftq_step_out_s_t* outs = nullptr;
     const bool fused = first_round && fused_outs != nullptr;
     if (fused) {
       // round 1 has been stepped already, every frame of it, by the submission that decoded them (raftq_step_frames): what is
@@ -1644,7 +1645,7 @@ static int node_advance_impl(raftq_node_t* n, uint64_t* n_published) {
       ph.next(raftq_node::kPhStep);
       int rc = raftq_step_batch(n->h, staged, n_step, nullptr, nullptr);
       uint64_t n_out = 0;
-      if (rc == RAFTQ_OK) rc = raftq_step_results_c(n->h, &outs, &n_out);
+      if (rc == RAFTQ_OK) rc = raftq_step_results_s(n->h, &outs, &n_out);
       if (rc != RAFTQ_OK) return poison(n, rc, "step_batch");
     }
     lk.lock();

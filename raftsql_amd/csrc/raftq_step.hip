@@ -24,10 +24,16 @@ using raftq_detail::fail;
 using raftq_detail::use_device;
 
 static_assert(sizeof(raftq_msg_t) == sizeof(MsgRec) && sizeof(raftq_step_out_t) == sizeof(StepOutRec) &&
-                  sizeof(raftq_log_delta_t) == sizeof(LogDeltaRec) && sizeof(raftq_step_out_c_t) == sizeof(StepOutC),
+                  sizeof(raftq_log_delta_t) == sizeof(LogDeltaRec) && sizeof(raftq_step_out_c_t) == sizeof(StepOutC) &&
+                  sizeof(raftq_step_out_s_t) == sizeof(raftqk::StepOutS),
               "ABI struct mismatch");
 
 namespace {
+
+// bytes of one result record in the handle's format
+uint32_t result_rec_bytes(const raftq_t* h) {
+  return h->step_compact == raftqk::kFmtS32 ? (uint32_t)sizeof(raftqk::StepOutS) : h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
+}
 
 int ensure_node_state(raftq_t* h) {
   if (h->node_rec) return RAFTQ_OK;
@@ -149,7 +155,7 @@ int ensure_slot(raftq_t* h, raftq::StepSlot& sl, uint64_t n, int end_bit, Scratc
   const size_t o_msgs = carve(n * sizeof(MsgRec)), o_outs = carve(n * sizeof(StepOutRec) + 16), o_ki = carve(n * 8),
                o_ko = carve(n * 8), o_oi = carve(n * 4), o_oo = carve(n * 4), o_sort = carve(sort_bytes), o_next = carve(n * 4),
                o_m40 = carve(n * sizeof(raftqk::Msg40Rec));
-  const size_t o_nh = o_outs + tail_off(n, h->step_compact ? sizeof(StepOutC) : sizeof(StepOutRec));
+  const size_t o_nh = o_outs + tail_off(n, result_rec_bytes(h));
   // decoded entry headers: an entry costs its message two bytes at least, so nbytes / 2 + 1 always suffice
   const uint64_t w_ents_cap = wire ? wire_nbytes / 2 + 1 : 0;
   size_t w_scan_bytes = 0, o_wfr = 0, o_wcnt = 0, o_wbase = 0, o_wbad = 0, o_wents = 0, o_wscan = 0;
@@ -381,6 +387,16 @@ int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n
   return RAFTQ_OK;
 }
 
+int raftq_step_results_s(raftq_t* h, const raftq_step_out_s_t** out, uint64_t* n) {
+  if (!h) return fail(nullptr, RAFTQ_EINVAL, "null handle");
+  if (!out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results_s: null argument");
+  if (h->step_last_out && h->step_last_rec != sizeof(raftqk::StepOutS))
+    return fail(h, RAFTQ_ESTATE, "raftq_step_results_s: the last batch has records of another format (raftq_step_set_compact)");
+  *out = (const raftq_step_out_s_t*)h->step_last_out;
+  *n = h->step_last_n;
+  return RAFTQ_OK;
+}
+
 int raftq_step_set_msg_flags(raftq_t* h, int on) {
   if (int rc = raftq_detail::use_device_idle(h, "raftq_step_set_msg_flags")) return rc;
   h->step_msg_flags = on != 0;
@@ -389,7 +405,8 @@ int raftq_step_set_msg_flags(raftq_t* h, int on) {
 
 int raftq_step_set_compact(raftq_t* h, int on) {
   if (int rc = raftq_detail::use_device_idle(h, "raftq_step_set_compact")) return rc;
-  h->step_compact = on != 0;
+  if (on < 0 || on > 2) return fail(h, RAFTQ_EINVAL, "raftq_step_set_compact: 0 (64-byte records), 1 (40-byte) or 2 (32-byte)");
+  h->step_compact = (uint8_t)on;
   h->step_last_out = nullptr;
   h->step_last_n = 0;
   return RAFTQ_OK;
@@ -599,7 +616,7 @@ static int submit_impl(raftq_t* h, const void* msgs, uint64_t n, const WireSrc* 
     }
   }
   // touched count + bad + skipped: the default result copy leaves them zeroed behind it (step_d2h_kernel zero_tail)
-  const uint32_t rec = h->step_compact ? (uint32_t)sizeof(StepOutC) : (uint32_t)sizeof(StepOutRec);
+  const uint32_t rec = result_rec_bytes(h);
   // (a frames batch: the decoder that heads the chain zeroes them)
   if (!frames && (!sl.tail_zeroed || sl.tail_n != n || sl.tail_rec != rec || sl.dev != sl.tail_dev)) hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, h->stream, s.n_heads);
   sl.tail_zeroed = false;

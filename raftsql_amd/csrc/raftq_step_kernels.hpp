@@ -41,8 +41,13 @@ struct StepOutC {  // == raftq_step_out_c_t: the result record without what the 
   uint64_t term, index, commit, aux;
   uint8_t vote, lead, type, reject, flags, role, pad[2];
 };
-static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32 && sizeof(StepOutC) == 40,
+struct StepOutS {  // == raftq_step_out_s_t: ... and without aux (include/raftq_step.h says what carried it)
+  uint64_t term, index, commit;
+  uint8_t vote, lead, type, reject, flags, role, pad[2];
+};
+static_assert(sizeof(MsgRec) == 64 && sizeof(StepOutRec) == 64 && sizeof(LogDeltaRec) == 32 && sizeof(StepOutC) == 40 && sizeof(StepOutS) == 32,
               "record layout");
+constexpr uint8_t kFmtFull = 0, kFmtC40 = 1, kFmtS32 = 2;  // raftq_step_set_compact
 
 // Everything Step's common paths need of a group, in ONE 128-byte line (round 6): the raft scalars, the words of the group's
 // message list of the batch in flight (step_link_kernel / step_lists_kernel), and a copy of what the dense kernels own -- role,
@@ -97,9 +102,24 @@ constexpr uint8_t kFollower = 0, kCandidate = 1, kLeader = 2;
 
 // result record i, in the handle's format.  Compact drops group and addressee (= msgs[i].group / .from) and folds
 // log_term / last_index into one slot: log_term is only set by the two result types whose index IS last_index.
-__device__ __forceinline__ void put_result(void* out, uint64_t i, const StepOutRec& o, bool compact) {
-  if (!compact) {
+__device__ __forceinline__ void put_result(void* out, uint64_t i, const StepOutRec& o, uint8_t fmt) {
+  if (fmt == kFmtFull) {
     static_cast<StepOutRec*>(out)[i] = o;
+    return;
+  }
+  if (fmt == kFmtS32) {
+    StepOutS c;
+    c.term = o.term;
+    c.index = o.index;
+    c.commit = o.type == kOutCampaign ? o.log_term : o.commit;
+    c.vote = (uint8_t)o.vote;
+    c.lead = (uint8_t)o.lead;
+    c.type = o.type;
+    c.reject = o.reject;
+    c.flags = o.flags;
+    c.role = o.role;
+    c.pad[0] = c.pad[1] = 0;
+    static_cast<StepOutS*>(out)[i] = c;
     return;
   }
   StepOutC c;
@@ -171,7 +191,7 @@ __device__ __forceinline__ RecClass classify(const MsgRec& m, uint64_t n_groups,
   if (recs == kRecsWire && ((m.pad[1] & 1u) != 0 || m.pad[0] >= n_peers)) return kBad;
   return kTake;
 }
-__device__ __forceinline__ void put_skipped(void* out, uint64_t i, bool compact) {
+__device__ __forceinline__ void put_skipped(void* out, uint64_t i, uint8_t compact) {
   StepOutRec o;
   __builtin_memset(&o, 0, sizeof o);
   o.type = kOutSkipped;
@@ -186,7 +206,7 @@ static __global__ __launch_bounds__(kBlock) void step_keys_kernel(const MsgRec* 
                                                                   uint32_t* __restrict__ order, uint64_t n,
                                                                   uint64_t n_groups, uint32_t n_peers,
                                                                   unsigned int* bad, bool msg_flags, uint8_t recs,
-                                                                  void* __restrict__ out, bool compact) {
+                                                                  void* __restrict__ out, uint8_t compact) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   bool is_bad = false;
   if (i < n) {
@@ -481,7 +501,7 @@ struct Node {
 static __global__ __launch_bounds__(kBlock) void step_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
                                                       const uint64_t* __restrict__ keys_sorted,
                                                       const uint32_t* __restrict__ order, void* __restrict__ out,
-                                                      bool compact, uint64_t n, unsigned long long* n_heads,
+                                                      uint8_t compact, uint64_t n, unsigned long long* n_heads,
                                                       const unsigned int* bad) {
   if (*bad) return;  // a malformed record somewhere in the batch: nothing is applied
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -540,7 +560,7 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
                                                                   uint64_t n_groups, uint32_t n_peers, bool msg_flags, uint8_t recs,
                                                                   NodeRec* rec, uint32_t* __restrict__ next,
                                                                   unsigned int* bad, unsigned int* stall,
-                                                                  void* __restrict__ out, bool compact, CopyRide ride) {
+                                                                  void* __restrict__ out, uint8_t compact, CopyRide ride) {
   if (blockIdx.x < ride.blocks) {
     copy_ride(ride);
     return;
@@ -566,7 +586,7 @@ static __global__ __launch_bounds__(kBlock) void step_link_kernel(const MsgRec* 
 }
 
 static __global__ __launch_bounds__(kBlock) void step_lists_kernel(NodeArrays a, const MsgRec* __restrict__ msgs,
-                                                                   void* __restrict__ out, bool compact, uint64_t n,
+                                                                   void* __restrict__ out, uint8_t compact, uint64_t n,
                                                                    uint64_t n_groups,
                                                                    const uint32_t* __restrict__ next,
                                                                    unsigned long long* n_heads, unsigned int* tail_skipped,

@@ -40,11 +40,14 @@ OUT_DT = np.dtype([("group", "<u8"), ("term", "<u8"), ("index", "<u8"), ("log_te
 # raftq_step_out_c_t: the 40-byte result record (raftq_step_set_compact)
 OUT_C_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("aux", "<u8"), ("vote", "u1"), ("lead", "u1"),
                      ("type", "u1"), ("reject", "u1"), ("flags", "u1"), ("role", "u1"), ("_pad", "u1", (2,))])
+# raftq_step_out_s_t: the 32-byte result record (raftq_step_set_compact(h, 2))
+OUT_S_DT = np.dtype([("term", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("vote", "u1"), ("lead", "u1"), ("type", "u1"), ("reject", "u1"),
+                     ("flags", "u1"), ("role", "u1"), ("_pad", "u1", (2,))])
 LOG_DELTA_DT = np.dtype([("group", "<u8"), ("last_index", "<u8"), ("last_term", "<u8"), ("commit_to", "<u8")])
 # raftq_msg40_t: the 40-byte inbound record (raftq_step_submit_packed); aux = reject_hint on MsgAppResp, log_term otherwise
 MSG40_DT = np.dtype([("group", "<u4"), ("from", "u1"), ("type", "u1"), ("reject", "u1"), ("_pad", "u1"), ("term", "<u8"),
                      ("index", "<u8"), ("aux", "<u8"), ("commit", "<u8")])
-assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32 and OUT_C_DT.itemsize == 40
+assert MSG_DT.itemsize == 64 and OUT_DT.itemsize == 64 and LOG_DELTA_DT.itemsize == 32 and OUT_C_DT.itemsize == 40 and OUT_S_DT.itemsize == 32
 assert MSG40_DT.itemsize == 40
 
 
@@ -82,6 +85,32 @@ def expand_compact(msgs: np.ndarray, recs: np.ndarray) -> np.ndarray:
     return o
 
 
+def expand_short(msgs: np.ndarray, recs: np.ndarray, last_index: np.ndarray, committed: np.ndarray) -> np.ndarray:
+    """raftq_step_out_s_t[] (32 bytes) + the batch it answers + every group's lastIndex / committed BEFORE the batch ->
+    raftq_step_out_t[], exactly (include/raftq_step.h): what the 32-byte record leaves out is tracked per group across the
+    batch -- lastIndex only moves with a result whose `index` IS the last index, a campaign moves no commit index and carries
+    its log_term in that slot, a new leader's log_term is its term.  (A loop over the records: tests and tools, not a hot path.)"""
+    o = np.zeros(len(recs), dtype=OUT_DT)
+    li, co = {}, {}
+    tips = (OUT_CAMPAIGN, OUT_BECAME_LEADER, OUT_APPENDED)
+    for i in range(len(recs)):
+        r = recs[i]
+        t = int(r["type"])
+        if t == OUT_SKIPPED:  # nobody's: an all-zero record in every format
+            o[i]["type"] = t
+            continue
+        g = int(msgs["group"][i])
+        if g not in li:
+            li[g], co[g] = int(last_index[g]), int(committed[g])
+        if t in tips:
+            li[g] = int(r["index"])
+        if t != OUT_CAMPAIGN:
+            co[g] = int(r["commit"])
+        o[i] = (g, r["term"], r["index"], r["commit"] if t == OUT_CAMPAIGN else (r["term"] if t == OUT_BECAME_LEADER else 0), co[g], li[g],
+                msgs["from"][i], r["vote"], r["lead"], t, r["reject"], r["flags"], r["role"])
+    return o
+
+
 class NodeEngine(QuorumEngine):
     """G raft groups' node state on one GPU + batched Step."""
 
@@ -96,10 +125,17 @@ class NodeEngine(QuorumEngine):
         if msg_flags:
             self._chk(self._lib.raftq_step_set_msg_flags(self._h, 1))
 
-    def set_compact(self, on: bool = True) -> None:
-        """result records in the 40-byte format from now on (no batch may be in flight)"""
+    def _results_form(self):
+        """(dtype, accessor) of the handle's result format"""
+        if self.compact == 2:
+            return OUT_S_DT, self._lib.raftq_step_results_s
+        return (OUT_C_DT, self._lib.raftq_step_results_c) if self.compact else (OUT_DT, self._lib.raftq_step_results)
+
+    def set_compact(self, on=True) -> None:
+        """result records in the 40-byte (True / 1) or the 32-byte (2) format from now on, 64-byte ones with False / 0 (no batch
+        may be in flight)"""
         self._chk(self._lib.raftq_step_set_compact(self._h, int(on)))
-        self.compact = bool(on)
+        self.compact = int(on)
 
     def load_node(self, term=None, vote=None, lead=None, last_index=None, last_term=None) -> None:
         def arr(x, dt):
@@ -186,8 +222,7 @@ class NodeEngine(QuorumEngine):
         c = _lib.StepCounts()
         self._chk(self._lib.raftq_step_collect(self._h, None, C.byref(c)))
         p, k = C.c_void_p(None), C.c_uint64(0)
-        dt = OUT_C_DT if self.compact else OUT_DT
-        fn = self._lib.raftq_step_results_c if self.compact else self._lib.raftq_step_results
+        dt, fn = self._results_form()
         self._chk(fn(self._h, C.byref(p), C.byref(k)))
         buf = (C.c_char * (k.value * dt.itemsize)).from_address(p.value)
         a = np.frombuffer(buf, dtype=dt, count=k.value)

@@ -132,8 +132,7 @@ class WireEngine(NodeEngine):
                                               1 if tail_appends else 0, msgs.ctypes.data, ents.ctypes.data if ents is not None else None,
                                               len(ents) if ents is not None else 0, C.byref(c)))
         p, k = C.c_void_p(None), C.c_uint64(0)
-        dt = OUT_C_DT if self.compact else OUT_DT
-        fn = self._lib.raftq_step_results_c if self.compact else self._lib.raftq_step_results
+        dt, fn = self._results_form()
         self._chk(fn(self._h, C.byref(p), C.byref(k)))
         outs = np.frombuffer((C.c_char * (k.value * dt.itemsize)).from_address(p.value), dtype=dt, count=k.value) if k.value else np.zeros(0, dt)
         if copy:

@@ -44,6 +44,7 @@ struct raftq {
   std::vector<raftq_msg_t> stage;
   std::vector<raftq_step_out_t> outs;
   std::vector<raftq_step_out_c_t> outs_c;
+  std::vector<raftq_step_out_s_t> outs_s;
   bool compact = false;
   uint64_t n_out = 0;
   std::vector<raftq_advance_t> adv;  // the advance list of the last CHANGED sweep, ascending group
@@ -454,6 +455,33 @@ int raftq_step_results_c(raftq_t* h, const raftq_step_out_c_t** out, uint64_t* n
     h->outs_c[i] = c;
   }
   *out = h->outs_c.data();
+  *n = h->n_out;
+  return RAFTQ_OK;
+}
+// ... and the 32-byte form (raftq_step_set_compact(h, 2)): no aux; a campaign's log_term rides in `commit`
+int raftq_step_results_s(raftq_t* h, const raftq_step_out_s_t** out, uint64_t* n) {
+  if (!h || !out || !n) return fail(h, RAFTQ_EINVAL, "raftq_step_results_s: null argument");
+  try {
+    h->outs_s.resize((size_t)h->n_out);
+  } catch (...) {
+    return fail(h, RAFTQ_ENOMEM, "raftq_step_results_s: host allocation failed");
+  }
+  for (uint64_t i = 0; i < h->n_out; ++i) {
+    const raftq_step_out_t& o = h->outs[i];
+    raftq_step_out_s_t c;
+    memset(&c, 0, sizeof(c));
+    c.term = o.term;
+    c.index = o.index;
+    c.commit = o.type == RAFTQ_OUT_CAMPAIGN ? o.log_term : o.commit;
+    c.vote = (uint8_t)o.vote;
+    c.lead = (uint8_t)o.lead;
+    c.type = o.type;
+    c.reject = o.reject;
+    c.flags = o.flags;
+    c.role = o.role;
+    h->outs_s[i] = c;
+  }
+  *out = h->outs_s.data();
   *n = h->n_out;
   return RAFTQ_OK;
 }

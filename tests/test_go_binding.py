@@ -29,7 +29,7 @@ LAYOUTS = {
     "Msg": "raftq_msg", "StepOut": "raftq_step_out", "StepOutC": "raftq_step_out_c", "LogDelta": "raftq_log_delta", "Msg40": "raftq_msg40",
     "WireMsg": "raftq_wire_msg", "WireEnt": "raftq_wire_ent", "WalRec": "raftq_wal_rec",
     "TermDelta": "raftq_term_delta", "TickCounts": "raftq_tick_counts", "Delta16": "raftq_delta16", "Advance16": "raftq_advance16",
-    "Prop": "raftq_prop", "PropEnt": "raftq_prop_ent",
+    "Prop": "raftq_prop", "PropEnt": "raftq_prop_ent", "StepOutS": "raftq_step_out_s",
 }
 # Go field name -> C field name where the binding renames on purpose
 ALIASES = {("Msg", "wireto"): "_pad", ("Msg", "flags"): "_pad", ("Msg", "resv"): "_resv"}

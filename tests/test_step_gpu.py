@@ -406,6 +406,56 @@ def test_compact_result_records_expand_to_the_full_ones(NodeEngine, oracle):
         _stepgen.assert_same_state(e, s)
 
 
+def test_short_result_records_expand_to_the_full_ones(NodeEngine, oracle):
+    """raftq_step_set_compact(h, 2): 32-byte result records (round 6) -- the 40-byte ones without `aux`.  Expanded with the batch
+    they answer and every group's lastIndex / committed before it, they are the oracle's 64-byte records, byte for byte: list
+    walk, stall replays and the sorted walk alike, two batches in flight, flagged records (held, deferred, skipped) included;
+    the three formats can be switched between with nothing in flight."""
+    from raftsql_amd import step as S
+    from raftsql_amd.engine import RaftqError
+
+    rng = np.random.default_rng(58)
+    G, N = 3000, 5
+    s = _stepgen.random_state(rng, G, N, 1)
+    with NodeEngine(G, N, 1) as e:
+        _stepgen.load_engine(e, s)
+        e.set_compact(2)
+        prev = None
+        kinds = set()
+        for it in range(14):
+            hot = rng.choice(G, 30) if it % 3 == 0 else None  # runs of ~100 -> the replay path
+            m = _stepgen.random_batch(rng, s, int(rng.integers(1, 5000)), hot_groups=hot)
+            if it % 2:
+                m = _stepgen.with_hold_skip(rng, m)
+            before = (s.last_index.copy(), s.committed.copy())
+            want = s.step_batch(m)
+            e.step_submit(m)
+            if prev is not None:
+                got, touched = e.step_collect()
+                assert got.dtype == S.OUT_S_DT and got.dtype.itemsize == 32
+                assert np.array_equal(S.expand_short(prev[0], got, *prev[3]), prev[1])
+                kinds |= set(np.unique(got["type"]).tolist())
+            prev = (m, want, None, before)
+        got, _ = e.step_collect()
+        assert np.array_equal(S.expand_short(prev[0], got, *prev[3]), prev[1])
+        assert {S.OUT_CAMPAIGN, S.OUT_BECAME_LEADER, S.OUT_PROGRESS, S.OUT_VOTE_RESP, S.OUT_HELD, S.OUT_DEFERRED, S.OUT_SKIPPED} <= kinds
+        _stepgen.assert_same_state(e, s)
+        with pytest.raises(RaftqError):
+            e.set_compact(3)  # no such format
+        for fmt in (1, 0, 2):
+            e.set_compact(fmt)
+            m = _stepgen.random_batch(rng, s, 2000)
+            before = (s.last_index.copy(), s.committed.copy())
+            want = s.step_batch(m)
+            if fmt == 0:
+                assert np.array_equal(e.step_batch(m)[0], want)
+            else:
+                e.step_submit(m)
+                got, _ = e.step_collect()
+                assert np.array_equal(S.expand_compact(m, got) if fmt == 1 else S.expand_short(m, got, *before), want)
+        _stepgen.assert_same_state(e, s)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 7])
 @pytest.mark.parametrize("walk", ["lists", "sort"])
 def test_step_golden_fixture_on_the_gpu(NodeEngine, n, walk, monkeypatch):

@@ -3,9 +3,9 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from oracle import pywire as W
 from raftsql_amd import _lib, step as S_
 from raftsql_amd.engine import pinned_copy, pinned_empty
+from raftsql_amd import wire as W
 from raftsql_amd.wire import WireEngine, PROP_DT, PROP_ENT_DT
 
 G, N, n = 1 << 20, 5, 65536

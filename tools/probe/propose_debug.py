@@ -25,9 +25,10 @@ def try_props(groups, label):
     pool = pinned_copy(np.zeros(k * 50, np.uint8))
     out, off = pinned_empty(k * (N - 1) * 260 + 64, np.uint8), pinned_empty(k * (N - 1) + 1, np.uint64)
     c = _lib.WireCounts()
-    rc = e._lib.raftq_propose_frames(e._h, pinned_copy(props).ctypes.data, k, pinned_copy(pe).ctypes.data, k, None, 0, None, 0, pool.ctypes.data, len(pool),
+    pp, ppe = pinned_copy(props), pinned_copy(pe)
+    rc = e._lib.raftq_propose_frames(e._h, pp.ctypes.data, k, ppe.ctypes.data, k, None, 0, None, 0, pool.ctypes.data, len(pool),
                                      out.ctypes.data, len(out), off.ctypes.data, C.byref(c))
-    print(label, "k", k, "rc", rc, flush=True)
+    print(label, "k", k, "rc", rc, e._lib.raftq_last_error(e._h)[:60] if rc else "", flush=True)
     return rc
 
 g0 = np.sort(rng.choice(G, 16384, replace=False)).astype(np.uint64)

@@ -26,6 +26,7 @@ struct PropEnt {  // == raftq_prop_ent_t
 };
 static_assert(sizeof(PropRec) == 16 && sizeof(PropEnt) == 16, "record layout");
 
+constexpr uint32_t kPropPayload = 1, kPropGroup = 2, kPropCount = 3, kPropRange = 4, kPropNotLeader = 5, kPropTwice = 6;
 constexpr uint32_t kPropMaxEnts = 1024;  // raft.Config.MaxSizePerMsg's share of entries (raft.go:157): more go out as the caller's own sends
 
 // Nothing is applied unless every record is sound: a group of this handle, led by this node, named once (the group's list
@@ -37,23 +38,26 @@ constexpr uint32_t kPropMaxEnts = 1024;  // raft.Config.MaxSizePerMsg's share of
 static __global__ __launch_bounds__(kBlock) void propose_check_kernel(NodeArrays a, const PropRec* __restrict__ props, uint64_t n,
                                                                       const PropEnt* __restrict__ pe, uint64_t n_pe, uint64_t pool_bytes,
                                                                       unsigned int* bad, unsigned int stamp, PropRec* __restrict__ props_d,
-                                                                      PropEnt* __restrict__ pe_d) {
+                                                                      PropEnt* __restrict__ pe_d, unsigned long long* why) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   // the entry records, one per lane of the first ceil(n_pe / kBlock) workgroups ... (the grid covers max(n, n_pe) lanes)
-  bool is_bad = false;
+  uint32_t reason = 0;  // kProp*: what is wrong with record i (the largest (reason, record) of the call goes into *why for the error text)
   if (i < n_pe) {
     const PropEnt e = pe[i];
     pe_d[i] = e;
-    is_bad = e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off);  // (an entry no record names is checked too: harmless)
+    if (e.data_len != 0 && (e.data_off > pool_bytes || e.data_len > pool_bytes - e.data_off)) reason = kPropPayload;  // (an entry no record names is checked too: harmless)
   }
   if (i < n) {
     const PropRec p = props[i];
     props_d[i] = p;
-    bool rec_bad = p.group >= a.n_groups || p.n_ents == 0 || p.n_ents > kPropMaxEnts || (uint64_t)p.ent_first + p.n_ents > n_pe;
-    if (!rec_bad) rec_bad = a.role[p.group] != kLeader || atomicAdd(&a.rec[p.group].lst_cnt, 1u) != 0;
-    is_bad |= rec_bad;
+    if (p.group >= a.n_groups) reason = kPropGroup;
+    else if (p.n_ents == 0 || p.n_ents > kPropMaxEnts) reason = kPropCount;
+    else if ((uint64_t)p.ent_first + p.n_ents > n_pe) reason = kPropRange;
+    else if (a.role[p.group] != kLeader) reason = kPropNotLeader;
+    else if (atomicAdd(&a.rec[p.group].lst_cnt, 1u) != 0) reason = kPropTwice;
   }
-  if (__ballot(is_bad) != 0 && (threadIdx.x & 63) == 0) atomicExch(bad, stamp);  // (the word holds this call's stamp: refused)
+  if (reason) atomicMax(why, ((unsigned long long)(stamp & 0xffffffu) << 40) | ((unsigned long long)reason << 32) | (uint32_t)i);
+  if (__ballot(reason != 0) != 0 && (threadIdx.x & 63) == 0) atomicExch(bad, stamp);  // (the word holds this call's stamp: refused)
 }
 
 // props / pe: the check kernel's copies in device memory.  msgs_out: the device part of the encoder's message array -- (N - 1) runs of n records, run r = the MsgApps for the r-th peer

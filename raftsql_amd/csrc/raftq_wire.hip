@@ -451,7 +451,7 @@ int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props
   PropRec* props_d = (PropRec*)((uint8_t*)h->wire_dev + o_props);
   PropEnt* pe_d = (PropEnt*)((uint8_t*)h->wire_dev + o_pe);
   hipLaunchKernelGGL(propose_check_kernel, cg, dim3(kBlock), 0, h->stream, na, (const PropRec*)v_props, n_props, (const PropEnt*)v_pe, n_prop_ents, pool_bytes, bad,
-                     stamp, props_d, pe_d);
+                     stamp, props_d, pe_d, h->wire_flags + 3);
   hipLaunchKernelGGL(propose_apply_kernel, pg, dim3(kBlock), 0, h->stream, na, (const PropRec*)props_d, n_props, (const PropEnt*)pe_d,
                      (const unsigned int*)bad, stamp, msgs_dev, ents_dev, (uint32_t)n_ents);
   // ... and the marshal of everything right behind it: one wait
@@ -462,10 +462,18 @@ int raftq_propose_frames(raftq_t* h, const raftq_prop_t* props, uint64_t n_props
   HIPCHK(h, raftq_detail::wait_call(h));
   if (int rc = tile_ctl_check(h, "raftq_propose_frames")) return rc;
   const uint64_t total = h->wire_pin[0];
-  if (h->wire_pin[1])
-    return fail(h, RAFTQ_EINVAL,
-                "raftq_propose_frames: a proposal names a group this node does not lead (or names one twice, or carries no entries, or a payload "
-                "outside the pool) -- nothing was appended; or a queued message has to / from >= 255 or a range out of bounds; the output is not valid");
+  if (h->wire_pin[1]) {
+    // which record, and why (the check kernel left the largest (stamp, reason, record) it met; an older call's stamp: the marshal refused)
+    unsigned long long why = 0;
+    (void)hipMemcpy(&why, h->wire_flags + 3, 8, hipMemcpyDeviceToHost);
+    static const char* const kWhy[] = {"?", "an entry's payload lies outside the pool", "its group is out of range", "it carries no entries (or more than 1024)",
+                                       "its entries lie outside prop_ents[]", "this node does not lead its group", "its group is named twice"};
+    const uint32_t reason = (uint32_t)(why >> 32) & 0xffu;
+    if ((why >> 40) == (stamp & 0xffffffu) && reason >= 1 && reason <= 6)
+      return fail(h, RAFTQ_EINVAL, std::string("raftq_propose_frames: record ") + std::to_string((uint32_t)why) + ": " + kWhy[reason] + " -- nothing was appended");
+    return fail(h, RAFTQ_EINVAL, "raftq_propose_frames: a queued message has to / from >= 255, an entry range outside ents[] or a payload outside the pool; the "
+                                 "proposals WERE appended, the output is not valid");
+  }
   if (counts) {
     counts->n_msgs = n;
     counts->n_ents = n_e;

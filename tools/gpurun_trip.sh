@@ -64,6 +64,11 @@ SUPP
     ticktests) timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_set_gpu.py tests/test_abi_gpu.py -m gpu -x -q -k "tick or election or abi or drive" > $P/gpu_tests_tick.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_tick.log)" ;;
     tileab)    # the streaming decoder's launch shapes, one process: tile 128 / 256, readers, chunk, no readers at all, the SDMA-reader form
       timeout 600 python tools/probe/wire_tile_ab.py > $P/wire_tile_ab.jsonl 2> $P/wire_tile_ab.err; echo "rc=$?"; cut -c1-220 $P/wire_tile_ab.jsonl ;;
+    soak400)   # the bench's node legs 400 times, a fresh process each, 0 give-ups wanted
+      timeout 3000 python tools/probe/node_legs_soak.py ${SOAK_RUNS:-400} > $P/node_legs_soak.txt 2>&1; echo "rc=$?"; tail -3 $P/node_legs_soak.txt ;;
+    soakstatic) # ... and with round 4's chunk ownership by position (libraftq_static_chunks.so, built by raftsql_amd/build.py build_lib(variant=)):
+               # the soak must still be able to see the bug it guards against
+      RAFTQ_LIB=$PWD/raftsql_amd/libraftq_static_chunks.so timeout 1500 python tools/probe/node_legs_soak.py ${SOAK_STATIC_RUNS:-120} > $P/node_legs_soak_static_chunks.txt 2>&1; echo "rc=$?"; grep -c FAILED $P/node_legs_soak_static_chunks.txt; tail -2 $P/node_legs_soak_static_chunks.txt ;;
     flagab)    # the completion word three ways (one-thread kernel | write-value packet | last workgroup to arrive), checked and timed
       timeout 1500 bash tools/probe/flag_ab.sh > $P/flag_ab.txt 2>&1; echo "rc=$?"; cat $P/flag_ab.txt ;;
     steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q --timeout 300 > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;

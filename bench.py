@@ -850,17 +850,21 @@ def step_measure(cfg, device, msgs_per_batch=65536, batches=40, with_cpu=True):
                                    "synchronous call: 64-byte records in (the producer's stores, before the call), 64-byte results out")
     out["pipelined"]["roofline"] = leg_roofline("pcie", "message", M * reps, dt_pipe_staged, 0.0, 64.0 * M * reps,
                                                 "staged batches resubmitted (nothing crosses inbound), 64-byte results out")
-    # HBM bytes the walk needs per batch: 64 B of every message in, a result record out, and per touched group its 64-byte
-    # record in and out, role (1), commit index (8), the acked peer's match word in and out (16) -- and, where the ack moves
-    # the quorum, the N match words and the term gate (8 N + 8) and the commit index out (8)
+    # HBM bytes the walk needs per batch (round 6: one 128-byte record per touched group holds everything Step's common paths
+    # read): 64 B of every message in, 4 B of list link in and out, a result record out; per touched group its record in and out
+    # (256 B) and -- an acknowledgement: 75 % of this mix -- the acked peer's match word written where the dense kernels read it
+    # (8 B), the commit index too where it moved (8 B, charged to every ack: the conservative direction)
     tg = touched / nb
-    step_alg = lambda rec: M * (64.0 + rec) + tg * (64 + 64 + 1 + 8 + 16) + 0.75 * tg * (8.0 * N + 16)  # noqa: E731
+    step_alg = lambda rec: M * (64.0 + 8.0 + rec) + tg * 256.0 + 0.75 * tg * 16.0  # noqa: E731
     out["pipelined"]["compact_results"]["roofline"] = leg_roofline(
         "pcie", "message", M * reps, dt_pipe_compact, 0.0, 40.0 * M * reps,
         "staged batches resubmitted, 40-byte results out; the previous batch's results ride out inside this batch's two kernels, "
         "which therefore last as long as the link takes (2.6 MB: 48 us at 55 GB/s + two launch boundaries): PCIe-out-bound. "
         "traffic = HBM bytes of the link + walk kernels per batch (measured with nothing riding: RAFTQ_STEP_DEFER_COPY=0)",
         traffic=leg_traffic(["step_link_kernel", "step_lists_kernel"], leg="step"), algorithmic=step_alg(40.0))
+    out["pipelined"]["short_results"]["roofline"] = leg_roofline(
+        "pcie", "message", M * reps, dt_pipe_short, 0.0, 32.0 * M * reps,
+        "staged batches resubmitted, 32-byte results out (2.1 MB a batch: 38 us at 55 GB/s + two launch boundaries): PCIe-out-bound")
     out["pipelined"]["producer_included"]["roofline_64B"] = leg_roofline(
         "pcie", "message", M, produced[False], 64.0 * M, 40.0 * M, "every batch written into device staging by one host thread, 40-byte results out")
     out["pipelined"]["producer_included"]["roofline_40B"] = leg_roofline(

@@ -54,7 +54,8 @@ LEG_KERNELS = [
     ("scan_partials_kernel", "tick", "stream"), ("compact_hups_kernel", "tick", "stream"),
     ("wire_dec_kernel", "wire", "stream"), ("wire_dec_ents_kernel", "wire", "stream"), ("wire_dec_fused_kernel", "wire", "stream"),
     ("wire_enc_fused_kernel", "wire", "stream"), ("wal_dec_kernel", "wire", "stream"), ("wal_dec_fused_kernel", "wire", "stream"),
-    ("wal_enc_fused_kernel", "wire", "stream"),
+    ("wal_enc_fused_kernel", "wire", "stream"), ("propose_check_kernel", "wire", "line"), ("propose_apply_kernel", "wire", "line"),
+    ("log_deltas_kernel", "wire", "line"),
     ("wire_dec_fused_kernel", "frames", "stream"), ("step_link_kernel", "frames", "line"), ("step_lists_kernel", "frames", "line"),
     ("step_d2h_kernel", "frames", "stream"),
 ]

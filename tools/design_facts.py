@@ -3,7 +3,7 @@
 the file it was read off (DESIGN said 118 / 161 VGPRs where profiles/r02/isa_sweep.txt said
 110 / 144).
 
-  <!-- isa:begin --> ... <!-- isa:end -->     from profiles/r05/isa_sweep.txt (tools/isa_report.py)
+  <!-- isa:begin --> ... <!-- isa:end -->     from profiles/r06/isa_sweep.txt (tools/isa_report.py)
 
 usage: tools/design_facts.py [--check]      (--check: exit 1 if DESIGN.md is not what would be generated;
                                              tests/test_docs.py runs it)"""
@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ISA = os.path.join(ROOT, "profiles", "r05", "isa_sweep.txt")
+ISA = os.path.join(ROOT, "profiles", "r06", "isa_sweep.txt")
 DESIGN = os.path.join(ROOT, "DESIGN.md")
 
 HEADLINE = [
@@ -37,7 +37,7 @@ def isa_block() -> str:
         v = rows[name]
         out.append("| %s | %s | %s | %s | %s | %s |" % (label, v[0], v[2], v[3], v[4], v[5]))
     out.append("")
-    out.append("(`profiles/r05/isa_sweep.txt`, written by `tools/isa_report.py` from `-Rpass-analysis=kernel-resource-usage`; %s; "
+    out.append("(`profiles/r06/isa_sweep.txt`, written by `tools/isa_report.py` from `-Rpass-analysis=kernel-resource-usage`; %s; "
                "this table is regenerated from that file by `tools/design_facts.py` and `tests/test_docs.py` fails when the two disagree.)" % tail)
     return "\n".join(out)
 
@@ -48,7 +48,7 @@ def main():
     new = s[:a] + "<!-- isa:begin -->\n" + isa_block() + "\n" + s[b:]
     if "--check" in sys.argv:
         if new != s:
-            sys.exit("DESIGN.md's ISA table is not what profiles/r05/isa_sweep.txt says: run tools/design_facts.py")
+            sys.exit("DESIGN.md's ISA table is not what profiles/r06/isa_sweep.txt says: run tools/design_facts.py")
         return
     open(DESIGN, "w").write(new)
 

@@ -1023,6 +1023,16 @@ static __global__ __launch_bounds__(TB) void wire_dec_fused_kernel(InFeed in, ui
   __shared__ uint64_t prefix[2];
   __shared__ uint32_t wave_bad[W];
   __shared__ uint32_t tile_slot, feed_slot;
+#if defined(RAFTQ_WIRE_LDS_PAD)
+  // measurement builds only (tools/gpurun_trip.sh soakpad*): round 5's LDS footprint back -- 102 KB, ONE workgroup per CU -- so that
+  // several handles' launches oversubscribe the chip again and the soak meets the residency that starved round 4's readers
+  __shared__ uint32_t lds_pad[RAFTQ_WIRE_LDS_PAD / 4];
+  if (n == ~0ull) {  // (never true: a store and a load the compiler cannot fold keep the array)
+    lds_pad[(threadIdx.x * 977u + ctl.epoch) % (RAFTQ_WIRE_LDS_PAD / 4)] = threadIdx.x;
+    __syncthreads();
+    pin[4 + (threadIdx.x & 1)] = lds_pad[(threadIdx.x * 331u + ctl.ticket_base) % (RAFTQ_WIRE_LDS_PAD / 4)];
+  }
+#endif
   const uint64_t* off = reinterpret_cast<const uint64_t*>(in.seg[0].dst);
   const uint8_t* stream = in.seg[1].dst;
   const uint64_t readable = (nbytes + 15) & ~15ull;

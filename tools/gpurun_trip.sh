@@ -69,6 +69,11 @@ SUPP
     soakstatic) # ... and with round 4's chunk ownership by position (libraftq_static_chunks.so, built by raftsql_amd/build.py build_lib(variant=)):
                # the soak must still be able to see the bug it guards against
       RAFTQ_LIB=$PWD/raftsql_amd/libraftq_static_chunks.so timeout 1500 python tools/probe/node_legs_soak.py ${SOAK_STATIC_RUNS:-120} > $P/node_legs_soak_static_chunks.txt 2>&1; echo "rc=$?"; grep -c FAILED $P/node_legs_soak_static_chunks.txt; tail -2 $P/node_legs_soak_static_chunks.txt ;;
+    soakpad)   # the same soak under ROUND 5's residency (decoder workgroups padded back to 102 KB of LDS: one per CU), where round 4's chunk
+               # ownership starved: libraftq_pad_static.so (pad + RAFTQ_WIRE_STATIC_CHUNKS: must FAIL some runs -- the soak sees the bug)
+               # and libraftq_pad.so (pad only: tickets + workers that serve themselves -- must not)
+      RAFTQ_LIB=$PWD/raftsql_amd/libraftq_pad_static.so timeout 1500 python tools/probe/node_legs_soak.py ${SOAK_PAD_RUNS:-100} > $P/node_legs_soak_pad_static_chunks.txt 2>&1; echo "static rc=$? failed: $(grep -c FAILED $P/node_legs_soak_pad_static_chunks.txt)"; tail -1 $P/node_legs_soak_pad_static_chunks.txt
+      RAFTQ_LIB=$PWD/raftsql_amd/libraftq_pad.so timeout 1500 python tools/probe/node_legs_soak.py ${SOAK_PAD_RUNS:-100} > $P/node_legs_soak_pad.txt 2>&1; echo "tickets + self-serve rc=$? failed: $(grep -c FAILED $P/node_legs_soak_pad.txt)"; tail -1 $P/node_legs_soak_pad.txt ;;
     flagab)    # the completion word three ways (one-thread kernel | write-value packet | last workgroup to arrive), checked and timed
       timeout 1500 bash tools/probe/flag_ab.sh > $P/flag_ab.txt 2>&1; echo "rc=$?"; cat $P/flag_ab.txt ;;
     steptests) timeout 900 python -m pytest tests/test_step_gpu.py tests/test_envelope_gpu.py tests/test_parity_gpu.py -m gpu -x -q --timeout 300 > $P/gpu_tests_step.log 2>&1; echo "rc=$? $(tail -3 $P/gpu_tests_step.log)" ;;

@@ -1070,21 +1070,39 @@ int flush_wal_begin(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   recs.clear();
   pool.clear();
   bool oom = false;
+  // records are built in place in the page-locked array (room is made a group at a time: no staging copy, no per-record
+  // capacity check -- 65K records a turn of the one-node leg)
+  size_t n_put = 0;
+  raftq_wal_rec_t* rbase = recs.as<raftq_wal_rec_t>();
+  auto room = [&](size_t k) {  // room for k more records
+    if ((n_put + k) * sizeof(raftq_wal_rec_t) > recs.cap) {
+      recs.size = n_put * sizeof(raftq_wal_rec_t);
+      if (!recs.reserve(std::max<size_t>((n_put + k) * 2, 4096) * sizeof(raftq_wal_rec_t))) oom = true;
+      rbase = recs.as<raftq_wal_rec_t>();
+    }
+    return !oom;
+  };
   auto put = [&](uint8_t kind, uint64_t group, uint64_t term, uint64_t index, uint32_t vote, const Entry* data) {
-    raftq_wal_rec_t r;
-    std::memset(&r, 0, sizeof(r));
-    r.kind = kind;
+    if (oom) return;
+    raftq_wal_rec_t& r = rbase[n_put++];
     r.group = group;
     r.term = term;
     r.index = index;
+    r.data_off = 0;
+    r.data_len = 0;
     r.vote = vote;
+    r.crc = 0;
+    r.kind = kind;
+    r.entry_type = 0;
+    r.flags = 0;
+    r._pad = 0;
     if (data && data->len) {
       r.data_len = data->len;
       r.data_off = pool.size;
       oom |= !pool.append(data->data, data->len);
     }
-    oom |= !recs.append(&r, sizeof(r));
   };
+  (void)room(3 + n->wal_n_dirty * 2);
   if (!n->wal_head_written) {
     put(RAFTQ_WAL_CRC, 0, 0, 0, 0, nullptr);
     put(RAFTQ_WAL_METADATA, 0, 0, 0, 0, nullptr);
@@ -1095,6 +1113,7 @@ int flush_wal_begin(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
     const uint64_t gi = w * 64 + (uint64_t)__builtin_ctzll(bits);
     Group& g = n->groups[gi];
     g.wal_dirty = false;
+    if (!room(g.log.size() - std::min<uint64_t>(g.wal_upto, g.log.size()) + 1)) break;
     for (uint64_t idx = g.wal_upto + 1; idx <= g.log.size(); ++idx) {
       const Entry& e = g.log[idx - 1];
       put(RAFTQ_WAL_ENTRY, gi, e.term, idx, 0, &e);
@@ -1110,7 +1129,8 @@ int flush_wal_begin(raftq_node_t* n, std::unique_lock<std::mutex>& lk) {
   n->wal_lo = ~0ull;
   n->wal_hi = 0;
   n->wal_n_dirty = 0;
-  const size_t n_recs = recs.count<raftq_wal_rec_t>();
+  recs.size = n_put * sizeof(raftq_wal_rec_t);
+  const size_t n_recs = n_put;
   if (n_recs == 0) return RAFTQ_OK;
   const uint64_t cap = (uint64_t)n_recs * 80 + pool.size;
   if (oom || !n->wal_enc.reserve(cap)) {

@@ -1020,8 +1020,8 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
 
     t_one = timeit(half_turn(lib.raftq_step_results))
     assert res_n.value == n
-    e.set_compact(True)  # 40-byte results: what raftq_node reads
-    t_one_c = timeit(half_turn(lib.raftq_step_results_c))
+    e.set_compact(2)  # 32-byte results: what raftq_node reads (round 5: 40-byte)
+    t_one_c = timeit(half_turn(lib.raftq_step_results_s))
     e.set_compact(False)
     half_in, half_out = float(len(stream) + poff.nbytes), float(pmsgs.nbytes + len(ents) * 32 + 64 * n)
     out["inbound_half_turn"] = {

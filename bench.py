@@ -985,7 +985,10 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
            "moves both ways at once on this link (2 x 41.5 GB/s, profiles/r04/pcie_duplex_probe.jsonl), `frac` against one direction's "
            "63 GB/s as before; traffic = the kernel's HBM bytes (the scratch hop: written once by the readers, read once by the workers)")
     mf["roofline_encode"] = leg_roofline("pcie", "message", n, t_enc_p, enc_in, enc_out, "records + payload pool in, frames + offsets out; " + why,
-                                         traffic=leg_traffic(["wire_enc_fused_kernel"], leg="wire"), algorithmic=2.0 * enc_in + 2.0 * enc_out)
+                                         traffic=leg_traffic(["wire_enc_fused_kernel"], leg="wire"),
+                                         # (the scratch hop of the inputs and the device copy of the stream, each written once and read once; the
+                                         # frame offsets go straight to the caller's array: round 5 charged them to HBM twice -- x0.97)
+                                         algorithmic=2.0 * enc_in + 2.0 * len(stream))
     mf["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_enc_p, enc_in, enc_out)
     mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out; " + why,
                                          traffic=leg_traffic(["wire_dec_fused_kernel"], leg="wire"), algorithmic=2.0 * dec_in)
@@ -1040,56 +1043,62 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     # figure) and pulled over the link by raftq_wire_encode
     from raftsql_amd.wire import PROP_DT, PROP_ENT_DT
 
-    n_prop = n // (N - 1)
-    still_led = np.nonzero(e.read_node()["role"] == 2)[0]  # (the votes of the inbound leg's traffic deposed a few leaders)
-    pg = np.sort(rng.choice(still_led, n_prop, replace=False)).astype(np.uint64)
-    props = np.zeros(n_prop, PROP_DT)
-    props["group"], props["n_ents"], props["ent_first"] = pg, 1, np.arange(n_prop)
-    pents = np.zeros(n_prop, PROP_ENT_DT)
-    pents["data_len"] = rng.integers(40, 120, n_prop)
-    pents["data_off"] = np.cumsum(pents["data_len"]) - pents["data_len"]
-    ppool = pinned_copy(rng.integers(0, 256, int(pents["data_len"].sum()), dtype=np.uint8))
-    p_props, p_pents = pinned_copy(props), pinned_copy(pents)
-    n_out_msgs = n_prop * (N - 1)
-    pf_out, pf_off = pinned_empty(n_out_msgs * 260 + 64, np.uint8), pinned_empty(n_out_msgs + 1, np.uint64)
-    a_prop = (hnd, p_props.ctypes.data, n_prop, p_pents.ctypes.data, n_prop, None, 0, None, 0, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out),
-              pf_off.ctypes.data, r_wcnt)
-    t_prop = timeit(lean(lib.raftq_propose_frames, a_prop))
-    prop_bytes = int(wcnt.bytes)
-    # the same messages as the host would have built them (the state has moved on: the header VALUES differ, their sizes hardly)
-    node_now = e.read_node()
-    hm = np.zeros(n_out_msgs, W.WIRE_MSG_DT)
-    gi = pg.astype(np.int64)
-    for run, to in enumerate([q for q in range(N) if q != 0]):
-        sl = slice(run * n_prop, (run + 1) * n_prop)
-        hm["group"][sl], hm["term"][sl], hm["type"][sl], hm["to"][sl] = pg, node_now["term"][gi], 3, to
-        hm["index"][sl], hm["log_term"][sl], hm["commit"][sl] = node_now["last_index"][gi] - 1, node_now["last_term"][gi], node_now["committed"][gi]
-        hm["ent_first"][sl], hm["n_ents"][sl] = np.arange(n_prop), 1
-    he = np.zeros(n_prop, W.WIRE_ENT_DT)
-    he["term"], he["index"], he["data_off"], he["data_len"] = node_now["term"][gi], node_now["last_index"][gi], pents["data_off"], pents["data_len"]
-    p_hm, p_he = pinned_copy(hm), pinned_copy(he)
-    a_host = (hnd, p_hm.ctypes.data, n_out_msgs, p_he.ctypes.data, n_prop, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out), pf_off.ctypes.data, r_wcnt)
-    deltas = np.zeros(n_prop, S_.LOG_DELTA_DT)
-    deltas["group"] = pg
+    def outbound_leg():
+        n_prop = n // (N - 1)
+        still_led = np.nonzero(e.read_node()["role"] == 2)[0]  # (the votes of the inbound leg's traffic deposed a few leaders)
+        pg = np.sort(rng.choice(still_led, n_prop, replace=False)).astype(np.uint64)
+        props = np.zeros(n_prop, PROP_DT)
+        props["group"], props["n_ents"], props["ent_first"] = pg, 1, np.arange(n_prop)
+        pents = np.zeros(n_prop, PROP_ENT_DT)
+        pents["data_len"] = rng.integers(40, 120, n_prop)
+        pents["data_off"] = np.cumsum(pents["data_len"]) - pents["data_len"]
+        ppool = pinned_copy(rng.integers(0, 256, int(pents["data_len"].sum()), dtype=np.uint8))
+        p_props, p_pents = pinned_copy(props), pinned_copy(pents)
+        n_out_msgs = n_prop * (N - 1)
+        pf_out, pf_off = pinned_empty(n_out_msgs * 260 + 64, np.uint8), pinned_empty(n_out_msgs + 1, np.uint64)
+        a_prop = (hnd, p_props.ctypes.data, n_prop, p_pents.ctypes.data, n_prop, None, 0, None, 0, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out),
+                  pf_off.ctypes.data, r_wcnt)
+        t_prop = timeit(lean(lib.raftq_propose_frames, a_prop))
+        prop_bytes = int(wcnt.bytes)
+        # the same messages as the host would have built them (the state has moved on: the header VALUES differ, their sizes hardly)
+        node_now = e.read_node()
+        hm = np.zeros(n_out_msgs, W.WIRE_MSG_DT)
+        gi = pg.astype(np.int64)
+        for run, to in enumerate([q for q in range(N) if q != 0]):
+            sl = slice(run * n_prop, (run + 1) * n_prop)
+            hm["group"][sl], hm["term"][sl], hm["type"][sl], hm["to"][sl] = pg, node_now["term"][gi], 3, to
+            hm["index"][sl], hm["log_term"][sl], hm["commit"][sl] = node_now["last_index"][gi] - 1, node_now["last_term"][gi], node_now["committed"][gi]
+            hm["ent_first"][sl], hm["n_ents"][sl] = np.arange(n_prop), 1
+        he = np.zeros(n_prop, W.WIRE_ENT_DT)
+        he["term"], he["index"], he["data_off"], he["data_len"] = node_now["term"][gi], node_now["last_index"][gi], pents["data_off"], pents["data_len"]
+        p_hm, p_he = pinned_copy(hm), pinned_copy(he)
+        a_host = (hnd, p_hm.ctypes.data, n_out_msgs, p_he.ctypes.data, n_prop, ppool.ctypes.data, len(ppool), pf_out.ctypes.data, len(pf_out), pf_off.ctypes.data, r_wcnt)
+        deltas = np.zeros(n_prop, S_.LOG_DELTA_DT)
+        deltas["group"] = pg
 
-    def host_way():
-        deltas["last_index"], deltas["last_term"] = node_now["last_index"][gi], node_now["term"][gi]
-        rc = lib.raftq_apply_log_deltas_nowait(hnd, deltas.ctypes.data, n_prop)
-        rc2 = lib.raftq_wire_encode(*a_host)
-        assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
+        def host_way():
+            deltas["last_index"], deltas["last_term"] = node_now["last_index"][gi], node_now["term"][gi]
+            rc = lib.raftq_apply_log_deltas_nowait(hnd, deltas.ctypes.data, n_prop)
+            rc2 = lib.raftq_wire_encode(*a_host)
+            assert rc == 0 and rc2 == 0, e._chk(rc or rc2)
 
-    t_host = timeit(host_way)
-    prop_in = float(p_props.nbytes + p_pents.nbytes + len(ppool))
-    out["outbound_half_turn"] = {
-        "what": "what a leader of %d groups (%d peers) sends for one proposal each: appendEntry + bcastAppend on the device, the %d MsgApp "
-                "headers written into the encoder's input in HBM, and the marshal -- one submission (raftq_propose_frames); against the "
-                "tails reported (raftq_apply_log_deltas_nowait) and the same headers, built on the host beforehand, pulled over the link by "
-                "raftq_wire_encode" % (n_prop, N, n_out_msgs),
-        "groups": n_prop, "msgapps": n_out_msgs, "stream_bytes": prop_bytes,
-        "one_submission_us": t_prop * 1e6, "msgapps_per_s": n_out_msgs / t_prop, "host_built_us": t_host * 1e6,
-        "bytes_in_over_the_link": {"one_submission": prop_in, "host_built": float(p_hm.nbytes + p_he.nbytes + len(ppool) + deltas.nbytes)},
-        "roofline": leg_roofline("pcie", "message", n_out_msgs, t_prop, prop_in, float(prop_bytes + pf_off.nbytes),
-                                 "32 bytes per proposing group + the payloads in, frames + offsets out: bound by the link's OUTBOUND direction")}
+        t_host = timeit(host_way)
+        prop_in = float(p_props.nbytes + p_pents.nbytes + len(ppool))
+        out["outbound_half_turn"] = {
+            "what": "what a leader of %d groups (%d peers) sends for one proposal each: appendEntry + bcastAppend on the device, the %d MsgApp "
+                    "headers written into the encoder's input in HBM, and the marshal -- one submission (raftq_propose_frames); against the "
+                    "tails reported (raftq_apply_log_deltas_nowait) and the same headers, built on the host beforehand, pulled over the link by "
+                    "raftq_wire_encode" % (n_prop, N, n_out_msgs),
+            "groups": n_prop, "msgapps": n_out_msgs, "stream_bytes": prop_bytes,
+            "one_submission_us": t_prop * 1e6, "msgapps_per_s": n_out_msgs / t_prop, "host_built_us": t_host * 1e6,
+            "bytes_in_over_the_link": {"one_submission": prop_in, "host_built": float(p_hm.nbytes + p_he.nbytes + len(ppool) + deltas.nbytes)},
+            "roofline": leg_roofline("pcie", "message", n_out_msgs, t_prop, prop_in, float(prop_bytes + pf_off.nbytes),
+                                     "32 bytes per proposing group + the payloads in, frames + offsets out: bound by the link's OUTBOUND direction")}
+
+    # (RAFTQ_BENCH_WIRE_OUTBOUND=0: tools/pmc_legs.py keeps this leg's encodes out of the counter passes of the codec legs -- the
+    # records are per kernel, and this leg runs wire_enc_fused_kernel on other bytes)
+    if os.environ.get("RAFTQ_BENCH_WIRE_OUTBOUND", "1") != "0":
+        outbound_leg()
     # Step from frames (no entries in this traffic: what a leader of many groups receives)
     m2, _, _ = traffic(0.0)
     s2, off2 = e.wire_encode(m2)
@@ -1184,7 +1193,7 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
     wp = out["wal_frames"]["pinned"]
     w_in, w_out = float(pr.nbytes + pwp.nbytes), float(len(wal) + poff.nbytes)
     wp["roofline_encode"] = leg_roofline("pcie", "record", n, t_wenc_p, w_in, w_out, "records + payload pool in, WAL bytes + offsets out; " + why,
-                                         traffic=leg_traffic(["wal_enc_fused_kernel"], leg="wire"), algorithmic=2.0 * w_in + 2.0 * w_out)
+                                         traffic=leg_traffic(["wal_enc_fused_kernel"], leg="wire"), algorithmic=2.0 * w_in + 2.0 * len(wal))
     wp["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "record", n, t_wenc_p, w_in, w_out)
     wp["roofline_decode"] = leg_roofline("pcie", "record", n, t_wdec_p, w_out, float(precs.nbytes), "WAL bytes + offsets in, 48-byte records out; " + why,
                                          traffic=leg_traffic(["wal_dec_fused_kernel"], leg="wire"), algorithmic=2.0 * w_out)

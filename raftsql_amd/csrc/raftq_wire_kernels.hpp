@@ -325,6 +325,17 @@ __device__ inline void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
   for (uint64_t b = (chunks << 4) + lane; b < n; b += 64) dst[b] = src[b];
 }
 
+// dst[0, n) = src[0, n) by the eight lanes of a sub-group (sub = lane & 7), 16 B per lane per step
+__device__ inline void sub8_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t sub) {
+  const uint64_t chunks = n >> 4;
+  for (uint64_t c = sub; c < chunks; c += 8) {
+    uint4 v;
+    __builtin_memcpy(&v, src + (c << 4), 16);
+    __builtin_memcpy(dst + (c << 4), &v, 16);
+  }
+  for (uint64_t b = (chunks << 4) + sub; b < n; b += 8) dst[b] = src[b];
+}
+
 // ---- protobuf primitives ----------------------------------------------------------------------------
 
 // sovRaft: encoded size of a varint
@@ -1779,19 +1790,40 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
     const bool fits = base + tile_bytes <= cap;  // (workgroup-uniform: a tile that does not fit is not built at all)
     if (fits) {
       if (live && sz != 0) enc_write_frame(m, ents, d_out + at, sz);
-      // payloads: the wave takes its messages that carry entries one after the other, 16 bytes per lane per step
+      // payloads: EIGHT messages of the wave at a time, eight lanes each (16 bytes per lane per step: 128 bytes of payload a step
+      // and message).  Round 5 took a wave's entry-carrying messages one after the other with all 64 lanes -- fine at 15 % MsgApps,
+      // but a turn's proposals are ALL MsgApps with a ~80-byte entry: 64 dependent load-store round trips per wave, ~100 us a
+      // tile, most of what raftq_propose_frames' marshal took (round 6).
       const uint64_t pos0 = at + 8 + msg_head_size(m);
-      for (uint64_t todo = __ballot(walks && !is_bad); todo != 0; todo &= todo - 1) {
-        const int l = __ffsll((long long)todo) - 1;
-        uint64_t pos = wave_bcast_u64(pos0, l);
-        const uint32_t first = __builtin_amdgcn_readlane(m.ent_first, l), cnt = __builtin_amdgcn_readlane(m.n_ents, l);
+      const uint64_t walk_bits = __ballot(walks && !is_bad);
+      const uint32_t n_walk = (uint32_t)__popcll(walk_bits), sub = lane & 7u, grp = lane >> 3;
+      for (uint32_t it = 0; it * 8 < n_walk; ++it) {
+        const uint32_t r = it * 8 + grp;  // this sub-group's message: the lane of the r-th set bit of walk_bits
+        uint32_t at_bit = 0, rr = r;
+        uint64_t w = walk_bits;
+#pragma unroll
+        for (int sft = 32; sft != 0; sft >>= 1) {
+          const uint64_t low = w & ((1ull << sft) - 1);
+          const uint32_t c = (uint32_t)__popcll(low);
+          if (rr >= c) {
+            rr -= c;
+            w >>= sft;
+            at_bit += (uint32_t)sft;
+          } else {
+            w = low;
+          }
+        }
+        const bool mine = r < n_walk;
+        const int src_lane = mine ? (int)at_bit : (int)lane;
+        uint64_t pos = __shfl(pos0, src_lane, 64);
+        const uint32_t first = __shfl(m.ent_first, src_lane, 64), cnt = mine ? __shfl(m.n_ents, src_lane, 64) : (__shfl(m.n_ents, src_lane, 64), 0u);
         for (uint32_t k = 0; k < cnt; ++k) {
           const WireEnt e = ents[first + k];
           const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);
           pos += 1 + sov(es) + 3 + sov(e.type) + sov(e.term) + sov(e.index);
           if (e.data_len) {
             pos += 1 + sov(e.data_len);
-            wave_copy(d_out + pos, pool + e.data_off, e.data_len);
+            sub8_copy(d_out + pos, pool + e.data_off, e.data_len, sub);
             pos += e.data_len;
           }
         }
@@ -1946,9 +1978,31 @@ static __global__ __launch_bounds__(kBlock) void wal_enc_fused_kernel(InFeed in,
       if (live && !is_bad) wal_write_frame(r, crc, dsz, d_out + at);
       uint64_t pos0 = at + 8 + 2 + sov(r.kind) + sov(crc) + 1 + sov(dsz);
       if (r.kind == kWalEntry) pos0 += 3 + sov(r.entry_type) + sov(r.term) + sov(r.index) + 1 + sov(r.data_len);
-      for (uint64_t todo = __ballot(copies); todo != 0; todo &= todo - 1) {  // payloads: pool -> frame by the wave
-        const int l = __ffsll((long long)todo) - 1;
-        wave_copy(d_out + wave_bcast_u64(pos0, l), pool + wave_bcast_u64(r.data_off, l), __builtin_amdgcn_readlane(r.data_len, l));
+      // payloads, pool -> frame: eight records of the wave at a time, eight lanes each (see wire_enc_fused_kernel: a turn's WAL is
+      // nearly all entry records)
+      const uint64_t copy_bits = __ballot(copies);
+      const uint32_t n_copy = (uint32_t)__popcll(copy_bits), sub = lane & 7u, grp = lane >> 3;
+      for (uint32_t it = 0; it * 8 < n_copy; ++it) {
+        const uint32_t rk = it * 8 + grp;
+        uint32_t at_bit = 0, rr = rk;
+        uint64_t w = copy_bits;
+#pragma unroll
+        for (int sft = 32; sft != 0; sft >>= 1) {
+          const uint64_t low = w & ((1ull << sft) - 1);
+          const uint32_t c = (uint32_t)__popcll(low);
+          if (rr >= c) {
+            rr -= c;
+            w >>= sft;
+            at_bit += (uint32_t)sft;
+          } else {
+            w = low;
+          }
+        }
+        const bool mine = rk < n_copy;
+        const int src_lane = mine ? (int)at_bit : (int)lane;
+        const uint64_t dpos = __shfl(pos0, src_lane, 64), spos = __shfl(r.data_off, src_lane, 64);
+        const uint32_t len = __shfl(r.data_len, src_lane, 64);
+        if (mine) sub8_copy(d_out + dpos, pool + spos, len, sub);
       }
       __syncthreads();
       tile_bytes_out(d_out + base, out_h + base, tile_bytes);

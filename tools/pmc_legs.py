@@ -36,7 +36,8 @@ LEGS = {
     "step": ["python", "tools/profile_step.py"],
     "cycle": ["python", "tools/profile_cycle.py"],
     "tick": ["python", "tools/profile_tick.py"],
-    "wire": ["python", "tools/profile_wire.py"],
+    "wire": ["env", "RAFTQ_BENCH_WIRE_OUTBOUND=0", "python", "tools/profile_wire.py"],
+    "propose": ["python", "tools/profile_wire.py"],  # the same script with the outbound half-turn leg on: only raftq_propose_frames' own kernels are read off it
     "frames": ["python", "tools/profile_frames.py"],
     "calib": ["tools/tune/pmc_calib", "12"],
 }
@@ -54,8 +55,8 @@ LEG_KERNELS = [
     ("scan_partials_kernel", "tick", "stream"), ("compact_hups_kernel", "tick", "stream"),
     ("wire_dec_kernel", "wire", "stream"), ("wire_dec_ents_kernel", "wire", "stream"), ("wire_dec_fused_kernel", "wire", "stream"),
     ("wire_enc_fused_kernel", "wire", "stream"), ("wal_dec_kernel", "wire", "stream"), ("wal_dec_fused_kernel", "wire", "stream"),
-    ("wal_enc_fused_kernel", "wire", "stream"), ("propose_check_kernel", "wire", "line"), ("propose_apply_kernel", "wire", "line"),
-    ("log_deltas_kernel", "wire", "line"),
+    ("wal_enc_fused_kernel", "wire", "stream"), ("propose_check_kernel", "propose", "line"), ("propose_apply_kernel", "propose", "line"),
+    ("log_deltas_kernel", "propose", "line"),
     ("wire_dec_fused_kernel", "frames", "stream"), ("step_link_kernel", "frames", "line"), ("step_lists_kernel", "frames", "line"),
     ("step_d2h_kernel", "frames", "stream"),
 ]

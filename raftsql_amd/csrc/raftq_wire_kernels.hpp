@@ -1816,7 +1816,9 @@ static __global__ __launch_bounds__(kBlock) void wire_enc_fused_kernel(InFeed in
         const bool mine = r < n_walk;
         const int src_lane = mine ? (int)at_bit : (int)lane;
         uint64_t pos = __shfl(pos0, src_lane, 64);
-        const uint32_t first = __shfl(m.ent_first, src_lane, 64), cnt = mine ? __shfl(m.n_ents, src_lane, 64) : (__shfl(m.n_ents, src_lane, 64), 0u);
+        // (every lane takes part in every shuffle: a shuffle under a branch only sees the lanes that took it)
+        const uint32_t first = __shfl(m.ent_first, src_lane, 64), cnt_src = __shfl(m.n_ents, src_lane, 64);
+        const uint32_t cnt = mine ? cnt_src : 0u;
         for (uint32_t k = 0; k < cnt; ++k) {
           const WireEnt e = ents[first + k];
           const uint64_t es = entry_size(e.type, e.term, e.index, e.data_len);

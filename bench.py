@@ -991,7 +991,7 @@ def wire_measure(cfg, device, n=65536, reps=12, with_cpu=True):
                                          algorithmic=2.0 * enc_in + 2.0 * len(stream))
     mf["roofline_encode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_enc_p, enc_in, enc_out)
     mf["roofline_decode"] = leg_roofline("pcie", "message", n, t_dec_p, dec_in, dec_out, "frames + offsets in, 64-byte records + entry headers out; " + why,
-                                         traffic=leg_traffic(["wire_dec_fused_kernel"], leg="wire"), algorithmic=2.0 * dec_in)
+                                         traffic=leg_traffic(["wire_dec_fused_kernel"], leg="decode"), algorithmic=2.0 * dec_in)
     mf["roofline_decode"]["duplex"] = leg_roofline("pcie-duplex", "message", n, t_dec_p, dec_in, dec_out)
     # a node's inbound half-turn on the same frames: ONE submission (raftq_step_frames: decode + the node's checks + Step over
     # every frame, one wait) against round 3's way (raftq_wire_decode, wait, the records copied into the staging area,

@@ -37,6 +37,9 @@ LEGS = {
     "cycle": ["python", "tools/profile_cycle.py"],
     "tick": ["python", "tools/profile_tick.py"],
     "wire": ["env", "RAFTQ_BENCH_WIRE_OUTBOUND=0", "python", "tools/profile_wire.py"],
+    # raftq_wire_decode alone, the bench's traffic, page-locked buffers: in the `wire` leg the same kernel also runs as raftq_step_frames'
+    # decoder (which leaves a second copy of the records in HBM for Step), and a median over both kinds of dispatch is neither
+    "decode": ["env", "ONLY=1", "REPS=24", "python", "tools/probe/wire_tile_ab.py"],
     "propose": ["python", "tools/profile_wire.py"],  # the same script with the outbound half-turn leg on: only raftq_propose_frames' own kernels are read off it
     "frames": ["python", "tools/profile_frames.py"],
     "calib": ["tools/tune/pmc_calib", "12"],
@@ -57,7 +60,7 @@ LEG_KERNELS = [
     ("wire_enc_fused_kernel", "wire", "stream"), ("wal_dec_kernel", "wire", "stream"), ("wal_dec_fused_kernel", "wire", "stream"),
     ("wal_enc_fused_kernel", "wire", "stream"), ("propose_check_kernel", "propose", "line"), ("propose_apply_kernel", "propose", "line"),
     ("log_deltas_kernel", "propose", "line"),
-    ("wire_dec_fused_kernel", "frames", "stream"), ("step_link_kernel", "frames", "line"), ("step_lists_kernel", "frames", "line"),
+    ("wire_dec_fused_kernel", "frames", "stream"), ("wire_dec_fused_kernel", "decode", "stream"), ("step_link_kernel", "frames", "line"), ("step_lists_kernel", "frames", "line"),
     ("step_d2h_kernel", "frames", "stream"),
 ]
 

@@ -62,6 +62,8 @@ VARIANTS = [
     ("tile256 sdma 4M (one copy per array)", {"RAFTQ_WIRE_SDMA": "4096"}),
 ]
 KEYS = sorted({k for _, env in VARIANTS for k in env})
+if os.environ.get("ONLY"):  # tools/pmc_legs.py's `decode` leg: the shipped form alone, nothing else of that kernel's name in the process
+    VARIANTS = VARIANTS[:int(os.environ["ONLY"])]
 
 with WireEngine(G, N, self_peer=0, device=0) as e:
     stream, off = e.wire_encode(m, ents, pool)

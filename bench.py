@@ -1400,7 +1400,6 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
 
     peers = N - 1
     per_turn = (1, 4)  # proposals per group per turn: one statement, and a client that batches four
-    turns_of = {k: (waves if k == 1 else max(4, waves // 2)) for k in per_turn}
     warm = 3
     near = gpu_numa_cpus(device) or os.sched_getaffinity(0)
     out = {}
@@ -1408,6 +1407,9 @@ def one_node_measure(device, G=32768, N=3, waves=24, shard_counts=(1, 4)):
     names = {1: "one_statement_per_group_per_turn", 4: "four_statements_per_group_per_turn"}
     for K in shard_counts:
         Gs = G // K
+        # (a shard handle's turn is a quarter of the node's: four times the turns, so that every run is timed over about the same
+        # wall time -- 24 turns of 1.1 ms on four Python threads measured anything between 2.3 and 3.9e7)
+        turns_of = {k: (waves if k == 1 else max(4, waves // 2)) * (4 if K > 1 else 1) for k in per_turn}
         modes = ("one_thread",) if K == 1 else ("caller_threads", "library_threads")
         runs = [(mode, k) for mode in modes for k in per_turn]  # played one after the other on the same nodes: the log goes on
         # -- the peers' script for ONE shard (group ids are the shard's own 0 .. Gs-1: every shard reads the same bytes); built

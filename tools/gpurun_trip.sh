@@ -94,6 +94,10 @@ PY
     onenode)   # one node on one GPU, scripted peers (bench.one_node_measure), as one handle and as four shard handles; with the phase clock
       SHARDS=1,4 timeout 300 python tools/profile_one_node.py > $P/one_node.json 2> $P/one_node.err; echo "rc=$?"
       RAFTQ_PROFILE=1 SHARDS=1 timeout 300 python tools/profile_one_node.py 2>&1 | grep "advance phases" | cut -c1-400 > $P/one_node_phases.txt; cat $P/one_node_phases.txt ;;
+    nodeab)    # the three-node leg with the proposals' MsgApps built on the device (shipped) and on the host (round 5's way), alternated
+      for v in 1 0 1 0 1 0; do
+        echo "RAFTQ_NODE_PROPOSE_DEVICE=$v $(RAFTQ_NODE_PROPOSE_DEVICE=$v timeout 300 python tools/profile_node.py 2>&1 | grep -o "'proposals_committed_everywhere_per_s': [0-9.e+]*" | head -1)"
+      done > $P/three_nodes_ab.txt; cat $P/three_nodes_ab.txt ;;
     onenodestats)  # ... under rocprofv3: the device calls of a turn (one handle)
       SHARDS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/on -o node -- python tools/profile_one_node.py > $P/one_node_under_rocprof.txt 2>&1
       cp $(find /tmp/on -name "*kernel_stats.csv" | head -1) $P/node_kernel_stats.csv; head -12 $P/node_kernel_stats.csv | cut -c1-160 ;;

@@ -94,6 +94,8 @@ PY
     onenode)   # one node on one GPU, scripted peers (bench.one_node_measure), as one handle and as four shard handles; with the phase clock
       SHARDS=1,4 timeout 300 python tools/profile_one_node.py > $P/one_node.json 2> $P/one_node.err; echo "rc=$?"
       RAFTQ_PROFILE=1 SHARDS=1 timeout 300 python tools/profile_one_node.py 2>&1 | grep "advance phases" | cut -c1-400 > $P/one_node_phases.txt; cat $P/one_node_phases.txt ;;
+    ablate)    # the streaming decoder with its outputs taken away (measurement build libraftq_wiretrace.so: build_lib(variant="wiretrace", defines={"RAFTQ_WIRE_TRACE": 1}))
+      RAFTQ_LIB=$PWD/raftsql_amd/libraftq_wiretrace.so timeout 300 python tools/probe/wire_ablate.py > $P/wire_ablate.jsonl 2> $P/wire_ablate.err; echo "rc=$?"; cut -c1-230 $P/wire_ablate.jsonl; tail -3 $P/wire_ablate.err ;;
     nodeab)    # the three-node leg with the proposals' MsgApps built on the device (shipped) and on the host (round 5's way), alternated
       for v in 1 0 1 0 1 0; do
         echo "RAFTQ_NODE_PROPOSE_DEVICE=$v $(RAFTQ_NODE_PROPOSE_DEVICE=$v timeout 300 python tools/profile_node.py 2>&1 | grep -o "'proposals_committed_everywhere_per_s': [0-9.e+]*" | head -1)"
